@@ -1,0 +1,142 @@
+/*
+ * lsrecon.h -- C ABI of the MI355X (gfx950) light-sheet reconstruction hot path.
+ *
+ * This is the drop-in boundary: a flat, extern "C" interface with plain pointers and sizes.
+ * No torch types, no allocation inside, no global scratch: every buffer is a DEVICE pointer
+ * owned by the caller (in the Python host: a torch-ROCm tensor's data_ptr()), every entry
+ * point takes the HIP stream to launch on and is re-entrant across streams.
+ *
+ * What each entry point replaces in the reference (czbiohub-sf/shrimPy, paths relative to the
+ * reference root; biahub = un-vendored dependency pinned at pyproject.toml:91):
+ *
+ *   lsr_deskew_f32          biahub.deskew.fast_deskew_zyx, called at
+ *                           shrimpy/preprocessing.py:408-413 (and the older
+ *                           biahub deskew_data, scripts/measure_psf.py:238-246)
+ *   lsr_affine_f32          registration apply (north-star; docs/data_structure.md:58-62) ==
+ *                           scipy.ndimage.affine_transform(order=1); also the general-matrix
+ *                           deskew path together with lsr_average_slices_f32
+ *   lsr_average_slices_f32  biahub _average_n_slices (average_n_slices setting,
+ *                           config/mda/mantis/dynatrack_demo.yaml:164)
+ *   lsr_correlate_*, lsr_rl_*  Richardson-Lucy deconvolution (north-star; no reference symbol)
+ *
+ * Layout: all volumes are C-order (Z, Y, X) float32, X fastest, densely packed.
+ * Matrices: `M` is a row-major 3x4 double, OUTPUT index -> INPUT coordinate (the
+ * scipy.ndimage convention): in_c = M[c][0]*zo + M[c][1]*yo + M[c][2]*xo + M[c][3].
+ *
+ * Return value: 0 = ok; < 0 = argument error (LSR_E_*), nothing was launched;
+ * > 0 = a hipError_t from the launch. lsr_last_error() returns a thread-local message.
+ * Nothing here synchronises the stream or the device.
+ */
+#ifndef LSRECON_H
+#define LSRECON_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSR_VERSION 100 /* 0.1.0 */
+
+#define LSR_OK 0
+#define LSR_E_NULL (-1)        /* a required pointer is NULL */
+#define LSR_E_SHAPE (-2)       /* a dimension is <= 0 or inconsistent */
+#define LSR_E_UNSUPPORTED (-3) /* valid request this kernel does not cover (see each function) */
+#define LSR_E_ARG (-4)         /* another argument is out of range */
+
+/* Border rule of the order-1 sampler. */
+#define LSR_MODE_CONSTANT 0      /* scipy mode="constant": any coordinate outside [0,n-1] -> cval */
+#define LSR_MODE_GRID_CONSTANT 1 /* scipy mode="grid-constant": blend towards cval over one voxel */
+
+/* Which half of a Richardson-Lucy iteration a correlation launch finishes (fused epilogue). */
+#define LSR_EPI_NONE 0   /* out = corr(in)                                  (plain correlation) */
+#define LSR_EPI_RATIO 1  /* out = aux / (corr(in) + eps)       aux = y      (ratio = y/(Hx+eps)) */
+#define LSR_EPI_UPDATE 2 /* out = aux * corr(in) / norm        aux = x      (x <- x*H^T(ratio)/H^T1) */
+
+typedef void* lsr_stream_t; /* a hipStream_t; NULL = the default stream */
+
+int lsr_version(void);
+const char* lsr_last_error(void);
+
+/*
+ * Oblique-plane deskew with the slice averaging fused in.
+ *
+ *   in   raw stack (Z, Y, X) = (scan, tilt, coverslip)
+ *   out  (Zo, Yo, Xo); Zo == ceil(Zd / avg_n), where Zd is the deskewed depth BEFORE averaging
+ *   M    output->input map over the PRE-average grid (Zd, Yo, Xo). It must have the deskew
+ *        structure: row 0 = (a, 0, b, c) (only z_in is interpolated), row 1 = (+-1, 0, 0, int),
+ *        row 2 = (0, +-1, 0, int). Anything else returns LSR_E_UNSUPPORTED: use
+ *        lsr_affine_f32 + lsr_average_slices_f32 for a general matrix.
+ *   avg_n  >= 1; pre-average slices zd = zo*avg_n + k, k < avg_n, clamped to Zd-1 (edge pad).
+ *
+ * Arithmetic: coordinates and the 2-tap interpolation in fp64 exactly as
+ * scipy.ndimage.affine_transform(order=1, mode="constant", cval=0) evaluates them (result
+ * rounded to f32 once), then ((d0+d1)+...)/avg_n in f32: bit-identical to the CPU oracle.
+ */
+int lsr_deskew_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo,
+                   int64_t Yo, int64_t Xo, int64_t Zd, const double M[12], int avg_n,
+                   lsr_stream_t stream);
+
+/*
+ * General order-1 (trilinear) affine resample; any 3x4 matrix.
+ * mode/cval as scipy.ndimage.affine_transform. fp64 coordinates and weights, same operation
+ * order as scipy: bit-identical to the CPU oracle for finite inputs.
+ */
+int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
+                   int64_t Yo, int64_t Xo, const double M[12], float cval, int mode,
+                   lsr_stream_t stream);
+
+/* out[zo] = mean_k in[min(zo*avg_n + k, Zd-1)], k < avg_n, f32, ((d0+d1)+...)/avg_n. */
+int lsr_average_slices_f32(const float* in, int64_t Zd, int64_t Y, int64_t X, float* out,
+                           int64_t Zo, int avg_n, lsr_stream_t stream);
+
+/*
+ * 3-D correlation with zero-padded borders and a fused Richardson-Lucy epilogue:
+ *
+ *   c[z,y,x] = sum_{a,b,c} w[a,b,c] * in[z+a-pz/2, y+b-py/2, x+c-px/2]      (0 outside)
+ *   out      = epilogue(c, aux)                                  (LSR_EPI_*)
+ *
+ * scipy.ndimage.correlate(in, w, mode="constant") semantics; pass the flipped PSF for
+ * H x = ndimage.convolve(x, psf) and the PSF itself for H^T r. pz, py, px odd, <= 15.
+ *
+ * Dense form: `w` = pz*py*px device floats, C-order.
+ * Separable form: `wz`, `wy`, `wx` device float arrays of pz, py, px taps (w = wz x wy x wx).
+ *
+ * `aux` (epilogues RATIO / UPDATE) and `out` are (Z, Y, X); `out` may alias `aux`, it must
+ * not alias `in`. For LSR_EPI_UPDATE the divisor norm = H^T 1 (the sum of the taps that land
+ * inside the volume) comes from `nz`, `ny`, `nx`:
+ *   separable: device arrays of Z, Y, X floats, norm = nz[z]*ny[y]*nx[x];
+ *   dense:     `norm_table` = device doubles, the (pz+1)*(py+1)*(px+1) inclusive 3-D prefix
+ *              sum of w with a leading zero plane/row/column:
+ *              P[a][b][c] = sum_{a'<a, b'<b, c'<c} w[a'][b'][c'].
+ */
+int lsr_correlate_sep_f32(const float* in, float* out, const float* aux, int64_t Z, int64_t Y,
+                          int64_t X, const float* wz, int pz, const float* wy, int py,
+                          const float* wx, int px, int epilogue, float eps, const float* nz,
+                          const float* ny, const float* nx, lsr_stream_t stream);
+
+int lsr_correlate_dense_f32(const float* in, float* out, const float* aux, int64_t Z, int64_t Y,
+                            int64_t X, const float* w, int pz, int py, int px, int epilogue,
+                            float eps, const double* norm_table, lsr_stream_t stream);
+
+/*
+ * Whole Richardson-Lucy loop: `iters` x { ratio = y/(H x + eps); x <- x * H^T ratio / H^T 1 }.
+ * x is updated in place (caller initialises it, normally x = y); `ratio` is caller scratch of
+ * the same size. Separable: k* = PSF factors along z, y, x (the kernel flips them for H).
+ * Dense: psf = pz*py*px floats, psf_flipped = the same reversed on all three axes.
+ * Launches 2*iters kernels on `stream`; capturable in a hipGraph (no sync, no allocation).
+ */
+int lsr_rl_sep_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X,
+                   const float* kz, const float* kz_flipped, int pz, const float* ky,
+                   const float* ky_flipped, int py, const float* kx, const float* kx_flipped,
+                   int px, const float* nz, const float* ny, const float* nx, int iters, float eps,
+                   lsr_stream_t stream);
+
+int lsr_rl_dense_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X,
+                     const float* psf, const float* psf_flipped, int pz, int py, int px,
+                     const double* norm_table, int iters, float eps, lsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSRECON_H */

@@ -1,0 +1,256 @@
+"""CPU oracle for the light-sheet reconstruction hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the *checker*, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+``shrimpy_amd`` never imports anything under ``oracle/``.
+
+PARITY UNPINNED.  The arithmetic of this path is not in /root/reference: deskew lives in
+the un-vendored dependency ``biahub`` (0.0.1rc2.post17 @ b011bca57d5bf15c777839e4250e594f7471af3e,
+reference ``pyproject.toml:91``, ``uv.lock:323-325``); affine registration and
+Richardson-Lucy have no code or call site in the reference at all
+(``docs/data_structure.md:58-62``), and every reference test that touches deskew stubs it out
+(``shrimpy/tests/test_preprocessing.py:12-13``).  There are therefore no golden vectors to pin
+against.  What this oracle follows instead:
+
+* the ``scipy.ndimage`` path that ``BASELINE.json:north_star`` names as the CPU reference
+  (``affine_transform(order=1, mode="constant", cval=0)``; explicit RL loop over
+  ``ndimage.convolve``),
+* the published biahub geometry (``biahub/deskew.py`` at the pinned revision: output->input
+  matrix, ``Z_shift`` flooring, ``ceil`` of the scan extent, edge-padded slice averaging),
+* the reference's own call sites, which fix names, argument meaning and axis conventions:
+  ``shrimpy/preprocessing.py:226-231, 408-413`` (keyword call, kwargs filtered by signature),
+  ``scripts/measure_psf.py:223-249`` (ratio rounding to 3 decimals; chunks split on raw X are
+  concatenated *reversed* on output axis -2; voxel size used as a 3-tuple scale),
+  ``shrimpy/viewer/ring_buffer.py:98-105`` (one deskewed plane = one tilt row across the scan
+  stack), ``config/mda/mantis/dynatrack_demo.yaml:161-164`` (defaults 30 deg,
+  keep_overhang false, average 3).
+
+Array layout everywhere: numpy C-order ``(Z, Y, X)``; raw stacks are
+``(Z=scan, Y=tilt, X=coverslip)`` (``scripts/measure_psf.py:91,101``).
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+from scipy import ndimage, signal
+
+# --------------------------------------------------------------------------------------
+# Deskew geometry  (biahub.deskew.get_deskewed_data_shape / deskew_data; call sites
+# shrimpy/preprocessing.py:226-231, scripts/measure_psf.py:230-246)
+# --------------------------------------------------------------------------------------
+
+
+def deskew_geometry(raw_shape, ls_angle_deg, px_to_scan_ratio, keep_overhang):
+    """Return ``(matrix3x3, offset3, pre_average_shape)`` of the output->input affine map.
+
+    Rows (scipy convention, output index -> input coordinate)::
+
+        z_in = -r*cos(t) * Z' + r * X' + Z_shift
+        y_in = -Z' + (Y - 1)
+        x_in = -Y' + (X - 1)
+
+    so Z' walks the tilt rows reversed, Y' walks raw X reversed (1:1, no interpolation) and
+    X' is the scan direction -- the only interpolated axis.
+    """
+    Z, Y, X = (int(v) for v in raw_shape)
+    ct = math.cos(ls_angle_deg * math.pi / 180.0)
+    r = float(px_to_scan_ratio)
+    if keep_overhang:
+        z_shift = 0
+        xp = int(math.ceil(Z / r + Y * ct))
+    else:
+        z_shift = int(math.floor(Y * ct * r))
+        xp = int(math.ceil(Z / r - Y * ct))
+    matrix = np.array([[-r * ct, 0.0, r], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]], dtype=np.float64)
+    offset = np.array([float(z_shift), float(Y - 1), float(X - 1)], dtype=np.float64)
+    return matrix, offset, (Y, X, xp)
+
+
+def deskewed_shape(
+    raw_shape, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices=1, pixel_size_um=1.0
+):
+    """Output shape and voxel size (restates biahub ``get_deskewed_data_shape``)."""
+    _, _, (zd, yd, xd) = deskew_geometry(raw_shape, ls_angle_deg, px_to_scan_ratio, keep_overhang)
+    st = math.sin(ls_angle_deg * math.pi / 180.0)
+    shape = (int(math.ceil(zd / average_n_slices)), yd, xd)
+    voxel = (average_n_slices * st * pixel_size_um, pixel_size_um, pixel_size_um)
+    return shape, voxel
+
+
+def average_slices(data, n):
+    """Mean over groups of ``n`` slices along axis 0; the remainder is edge-padded.
+
+    Restates biahub ``_average_n_slices`` (pad ``mode="edge"``, reshape, mean) in float32.
+    """
+    n = int(n)
+    if n <= 1:
+        return data
+    rem = data.shape[0] % n
+    if rem:
+        data = np.pad(data, [(0, n - rem), (0, 0), (0, 0)], mode="edge")
+    grouped = data.reshape((data.shape[0] // n, n) + data.shape[1:])
+    return grouped.mean(axis=1, dtype=np.float32)
+
+
+def affine_apply(volume, matrix, offset, output_shape, cval=0.0, mode="constant"):
+    """``scipy.ndimage.affine_transform`` order-1, the north-star's CPU path.
+
+    ``mode="constant"``: a sample with any coordinate outside ``[0, n-1]`` is ``cval`` (no
+    blending).  ``mode="grid-constant"``: blends towards ``cval`` across the border.
+    """
+    volume = np.ascontiguousarray(volume, dtype=np.float32)
+    return ndimage.affine_transform(
+        volume,
+        np.asarray(matrix, dtype=np.float64),
+        offset=np.asarray(offset, dtype=np.float64),
+        output_shape=tuple(int(s) for s in output_shape),
+        order=1,
+        mode=mode,
+        cval=float(cval),
+        prefilter=False,
+    )
+
+
+def affine_apply_4x4(volume, matrix_4x4, output_shape, cval=0.0, mode="constant"):
+    """Registration apply: 4x4 ZYX homogeneous matrix mapping target -> source voxel coords."""
+    m = np.asarray(matrix_4x4, dtype=np.float64)
+    return affine_apply(volume, m[:3, :3], m[:3, 3], output_shape, cval=cval, mode=mode)
+
+
+def deskew(raw, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices=1):
+    """Deskew a raw ``(Z_scan, Y_tilt, X)`` stack -> ``(ceil(Y/avg), X, Xp)`` float32."""
+    matrix, offset, pre_shape = deskew_geometry(
+        raw.shape, ls_angle_deg, px_to_scan_ratio, keep_overhang
+    )
+    if pre_shape[2] <= 0:
+        raise ValueError(f"deskewed scan extent is not positive: {pre_shape}")
+    out = affine_apply(raw, matrix, offset, pre_shape)
+    return average_slices(out, average_n_slices)
+
+
+# --------------------------------------------------------------------------------------
+# Richardson-Lucy  (north-star: 3-D PSF stencil, zero-padded borders, 20 iterations)
+# --------------------------------------------------------------------------------------
+
+
+def _as_odd_psf(psf):
+    """Zero-pad even-sized axes by one trailing plane so that every axis is odd.
+
+    With ``center = size // 2`` the padded kernel gives the same ``ndimage.correlate`` result.
+    """
+    psf = np.asarray(psf, dtype=np.float32)
+    pad = [(0, 1 - (s % 2)) for s in psf.shape]
+    if any(p[1] for p in pad):
+        psf = np.pad(psf, pad)
+    return psf
+
+
+def rl_norm(shape, psf):
+    """``H^T 1``: the fraction of PSF mass that lands inside the volume, per voxel."""
+    psf = _as_odd_psf(psf)
+    ones = np.ones(shape, dtype=np.float32)
+    return ndimage.correlate(ones, psf, mode="constant", cval=0.0)
+
+
+def richardson_lucy(y, psf, iterations=20, eps=1e-6, x0=None, use_fft=False):
+    """Richardson-Lucy with zero-padded borders::
+
+        x <- x * H^T( y / (H x + eps) ) / (H^T 1)
+
+    ``H x = ndimage.convolve(x, psf, mode="constant")`` (direct stencil, float32 in/out,
+    double accumulate inside scipy); ``H^T r = ndimage.correlate(r, psf)``.  ``x0 = y`` unless
+    given.  The PSF is used as passed (callers normalise it to sum 1).
+    """
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    psf = _as_odd_psf(psf)
+    eps32 = np.float32(eps)
+    norm = rl_norm(y.shape, psf)
+    x = y.copy() if x0 is None else np.ascontiguousarray(x0, dtype=np.float32).copy()
+    psf_flip = psf[::-1, ::-1, ::-1]
+    for _ in range(int(iterations)):
+        if use_fft:
+            blur = signal.fftconvolve(x, psf, mode="same").astype(np.float32)
+        else:
+            blur = ndimage.convolve(x, psf, mode="constant", cval=0.0)
+        ratio = y / (blur + eps32)
+        if use_fft:
+            corr = signal.fftconvolve(ratio, psf_flip, mode="same").astype(np.float32)
+        else:
+            corr = ndimage.correlate(ratio, psf, mode="constant", cval=0.0)
+        x = x * corr / norm
+    return x
+
+
+def rl_iteration_parts(x, y, psf, eps=1e-6):
+    """One RL iteration split the way the device path splits it (ratio, then update)."""
+    psf = _as_odd_psf(psf)
+    blur = ndimage.convolve(np.asarray(x, np.float32), psf, mode="constant", cval=0.0)
+    ratio = np.asarray(y, np.float32) / (blur + np.float32(eps))
+    corr = ndimage.correlate(ratio, psf, mode="constant", cval=0.0)
+    norm = rl_norm(x.shape, psf)
+    return ratio, np.asarray(x, np.float32) * corr / norm
+
+
+# --------------------------------------------------------------------------------------
+# Neighbour step: flat-field (shrimpy/preprocessing.py:385-404)
+# --------------------------------------------------------------------------------------
+
+
+def flat_field_bf(volume):
+    """Divide out the per-pixel median over Z, preserving its mean (float32).
+
+    Follows ``_LabelfreePreprocessor._flat_field_BF`` (``shrimpy/preprocessing.py:403-404``):
+    ``quantile(0.5)`` == ``numpy.median`` (mean of the two middle values for even Z).
+    """
+    v = np.asarray(volume, dtype=np.float32)
+    pattern = np.median(v, axis=0).astype(np.float32)
+    return v / pattern * pattern.mean(dtype=np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic scene + PSF; shared by tests and bench.py's CPU leg
+# --------------------------------------------------------------------------------------
+
+
+def gaussian_psf(shape=(9, 7, 7), sigma=(2.0, 1.2, 1.2)):
+    """Separable anisotropic Gaussian PSF truncated to ``shape``, normalised to sum 1.
+
+    Returns ``(psf3d, (kz, ky, kx))`` with ``psf3d == kz[:,None,None]*ky[None,:,None]*kx``.
+    """
+    ks = []
+    for n, s in zip(shape, sigma):
+        c = n // 2
+        g = np.exp(-0.5 * ((np.arange(n) - c) / s) ** 2)
+        ks.append(g / g.sum())
+    kz, ky, kx = ks
+    psf = (kz[:, None, None] * ky[None, :, None] * kx[None, None, :]).astype(np.float32)
+    return psf, tuple(k.astype(np.float32) for k in ks)
+
+
+def rotated_psf(shape=(9, 7, 7), sigma=(2.0, 1.2, 1.2), angle_deg=30.0):
+    """Non-separable PSF: the Gaussian above rotated about Y (mimics the oblique sheet)."""
+    cz, cy, cx = (n // 2 for n in shape)
+    z, y, x = np.meshgrid(
+        np.arange(shape[0]) - cz, np.arange(shape[1]) - cy, np.arange(shape[2]) - cx, indexing="ij"
+    )
+    a = math.radians(angle_deg)
+    zr = math.cos(a) * z + math.sin(a) * x
+    xr = -math.sin(a) * z + math.cos(a) * x
+    g = np.exp(-0.5 * ((zr / sigma[0]) ** 2 + (y / sigma[1]) ** 2 + (xr / sigma[2]) ** 2))
+    return (g / g.sum()).astype(np.float32)
+
+
+def bead_scene(shape, seed, psf=None, density=2e-5, background=100.0):
+    """Sparse beads U(200,4000) on a flat background, PSF-blurred, Poisson noise, float32."""
+    rng = np.random.default_rng(seed)
+    n = int(np.prod(shape))
+    vol = np.zeros(shape, dtype=np.float32)
+    k = max(1, int(round(density * n)))
+    idx = rng.integers(0, n, size=k)
+    vol.reshape(-1)[idx] = rng.uniform(200.0, 4000.0, size=k).astype(np.float32) * 30.0
+    if psf is not None:
+        vol = ndimage.convolve(vol, np.asarray(psf, np.float32), mode="constant")
+    vol = vol + np.float32(background)
+    return rng.poisson(vol).astype(np.float32)

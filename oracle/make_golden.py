@@ -1,0 +1,126 @@
+"""Generate the small golden fixtures under tests/golden/ from the CPU oracle.
+
+Run in the build container:  python oracle/make_golden.py
+TEST INFRASTRUCTURE ONLY (see oracle/cpu_ref.py header).  The fixtures are DATA: seeded inputs
+and the oracle's outputs (scipy 1.15.3 / numpy 2.2.6), so that the GPU box -- which has neither
+/root/reference nor any need to re-run scipy for them -- can check the HIP path against frozen
+numbers, and so that a change of scipy version shows up as an oracle-vs-golden failure.
+
+A second group of fixtures (``ref_*.npz``) is captured by importing the reference's own
+``shrimpy.preprocessing`` from /root/reference (when present): they pin the neighbour step
+(flat-field) and the boundary contract, see ``capture_reference_fixtures``.
+"""
+
+from __future__ import annotations
+
+import sys
+
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from oracle import cpu_ref as o  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+
+
+def deskew_cases():
+    rng = np.random.default_rng(1001)
+    raw = (rng.random((24, 16, 40)) * 1000).astype(np.float32)
+    cases = {}
+    for name, (ko, avg, r) in {
+        "deskew_nooverhang_avg3": (False, 3, 0.755),
+        "deskew_overhang_avg1": (True, 1, 0.755),
+        "deskew_nooverhang_avg5_r0p4": (False, 5, 0.4),
+    }.items():
+        out = o.deskew(raw, 30.0, r, ko, avg)
+        shape, voxel = o.deskewed_shape(raw.shape, 30.0, r, ko, avg, 0.1133)
+        assert tuple(out.shape) == shape
+        cases[name] = dict(raw=raw, out=out, ls_angle_deg=30.0, px_to_scan_ratio=r,
+                           keep_overhang=ko, average_n_slices=avg, voxel=np.array(voxel))
+    return cases
+
+
+def affine_case():
+    rng = np.random.default_rng(1003)
+    vol = (rng.random((12, 40, 48)) * 500).astype(np.float32)
+    th = np.deg2rad(2.0)
+    rot = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]])
+    m = np.eye(4)
+    m[:3, :3] = rot @ np.diag([1.0, 0.98, 1.02])
+    m[:3, 3] = [0.5, -2.25, 3.75]
+    out_c = o.affine_apply_4x4(vol, m, vol.shape)
+    out_g = o.affine_apply_4x4(vol, m, (10, 44, 50), cval=7.0, mode="grid-constant")
+    return dict(vol=vol, matrix=m, out_constant=out_c, out_grid=out_g, grid_shape=np.array([10, 44, 50]),
+                grid_cval=7.0)
+
+
+def rl_cases():
+    rng = np.random.default_rng(1005)
+    psf_sep, factors = o.gaussian_psf((5, 5, 5), (1.2, 1.0, 1.0))
+    y = o.bead_scene((16, 32, 32), seed=1005, psf=psf_sep, density=2e-3)
+    x_sep = o.richardson_lucy(y, psf_sep, iterations=5)
+    psf_rot = o.rotated_psf((5, 5, 5), (1.2, 0.8, 1.0), 30.0)
+    x_rot = o.richardson_lucy(y, psf_rot, iterations=5)
+    ratio1, x1 = o.rl_iteration_parts(y, y, psf_rot)
+    return dict(y=y, psf_sep=psf_sep, kz=factors[0], ky=factors[1], kx=factors[2], x_sep_5=x_sep,
+                psf_rot=psf_rot, x_rot_5=x_rot, ratio_rot_1=ratio1, x_rot_1=x1,
+                norm_rot=o.rl_norm(y.shape, psf_rot), _unused=rng.random(1))
+
+
+def capture_reference_fixtures():
+    """Import the reference's preprocessing module and record what it pins."""
+    ref = Path("/root/reference")
+    if not ref.exists():
+        print("reference absent: ref_*.npz not regenerated")
+        return
+    sys.path.insert(0, str(ref))
+    sys.dont_write_bytecode = True
+    import torch
+
+    from shrimpy.preprocessing import RECON_STEPS, _LabelfreePreprocessor, _settings_kwargs
+
+    # (1) flat-field on the reference's own test input (shrimpy/tests/test_preprocessing.py:155-160)
+    vol = np.random.default_rng(3).integers(80, 600, (8, 6, 10)).astype(np.float32)
+    pre = _LabelfreePreprocessor(zyx_shape=vol.shape, deskew_settings=None, phase_settings=None,
+                                 vs_config=None, output_channel="BF", apply_flatfield=True)
+    ff = pre._flat_field_BF(torch.as_tensor(vol)).numpy()
+    # odd Z too (median picks the middle value)
+    vol7 = vol[:7]
+    ff7 = pre._flat_field_BF(torch.as_tensor(vol7)).numpy()
+
+    # (2) the channel-dict contract of __call__ with deskew stubbed by an identity
+    class _Deskew:
+        def model_dump(self):
+            return {"ls_angle_deg": 30.0, "px_to_scan_ratio": 0.755, "keep_overhang": False,
+                    "average_n_slices": 3, "pixel_size_um": 0.1133, "scan_step_um": 0.15}
+
+    def callee(raw_data, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices=1):
+        return raw_data
+
+    kept = _settings_kwargs(callee, _Deskew())
+    np.savez_compressed(
+        GOLD / "ref_preprocessing.npz",
+        flatfield_in=vol, flatfield_out=ff, flatfield_in_odd=vol7, flatfield_out_odd=ff7,
+        recon_steps=np.array(RECON_STEPS),
+        settings_kwargs_kept=np.array(sorted(kept)),
+    )
+    print("captured ref_preprocessing.npz from", ref)
+
+
+def main():
+    GOLD.mkdir(parents=True, exist_ok=True)
+    for name, case in deskew_cases().items():
+        np.savez_compressed(GOLD / f"{name}.npz", **case)
+    np.savez_compressed(GOLD / "affine_rot2deg.npz", **affine_case())
+    np.savez_compressed(GOLD / "rl_5iter.npz", **rl_cases())
+    capture_reference_fixtures()
+    for f in sorted(GOLD.glob("*.npz")):
+        print(f.name, f.stat().st_size)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+"""ctypes binding of ``liblsrecon.so`` (C ABI: ``include/lsrecon.h``).
+
+The HIP extension is the product: there is no CPU fallback and nothing here routes through a
+reference implementation.  If the shared library is missing, cannot be loaded, or a tensor is
+not on a HIP device, the call fails loudly with :class:`LsrError`.
+
+PyTorch is plumbing only: tensors own the device memory (so callers can ``clone()`` them and
+``torch.cuda.empty_cache()`` as the reference does, ``shrimpy/dynatrack/tracking.py:1097-1102``)
+and ``torch.cuda.current_stream()`` provides the ``hipStream_t`` every entry point takes.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+from pathlib import Path
+
+CSRC_DIR = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = CSRC_DIR / "liblsrecon.so"
+HEADER_PATH = Path(__file__).resolve().parent.parent / "include" / "lsrecon.h"
+
+# include/lsrecon.h constants
+MODE_CONSTANT = 0
+MODE_GRID_CONSTANT = 1
+EPI_NONE = 0
+EPI_RATIO = 1
+EPI_UPDATE = 2
+E_UNSUPPORTED = -3
+
+_c_f32p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+_stream = ctypes.c_void_p
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+# symbol -> argtypes; every function returns int except lsr_last_error.
+SIGNATURES: dict[str, list] = {
+    "lsr_version": [],
+    "lsr_deskew_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _f64p, _int, _stream],
+    "lsr_affine_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _f64p, _f32, _int, _stream],
+    "lsr_average_slices_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _int, _stream],
+    "lsr_correlate_sep_f32": [
+        _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _int, _c_f32p, _int, _c_f32p, _int,
+        _int, _f32, _c_f32p, _c_f32p, _c_f32p, _stream,
+    ],
+    "lsr_correlate_dense_f32": [
+        _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _int, _int, _int, _int, _f32,
+        ctypes.c_void_p, _stream,
+    ],
+    "lsr_rl_sep_f32": [
+        _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _c_f32p, _c_f32p, _int,
+        _c_f32p, _c_f32p, _int, _c_f32p, _c_f32p, _c_f32p, _int, _f32, _stream,
+    ],
+    "lsr_rl_dense_f32": [
+        _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _int, _int,
+        ctypes.c_void_p, _int, _f32, _stream,
+    ],
+}
+
+
+class LsrError(RuntimeError):
+    """A liblsrecon call failed (argument error or HIP launch error)."""
+
+    def __init__(self, func: str, code: int, message: str):
+        self.func = func
+        self.code = code
+        super().__init__(f"{func} failed ({code}): {message}")
+
+
+class LsrUnsupported(LsrError):
+    """The request is valid but outside what this entry point covers (``LSR_E_UNSUPPORTED``)."""
+
+
+_lock = threading.Lock()
+_lib: ctypes.CDLL | None = None
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile ``liblsrecon.so`` in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", str(CSRC_DIR), "-j", str(min(8, os.cpu_count() or 1))]
+    if force:
+        subprocess.run(["make", "-C", str(CSRC_DIR), "clean"], check=True, capture_output=not verbose)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"building liblsrecon.so failed:\n{proc.stdout}\n{proc.stderr}")
+    if verbose:
+        print(proc.stdout)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load the extension (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not LIB_PATH.exists():
+            raise LsrError(
+                "load", -1,
+                f"{LIB_PATH} is missing; build it with `make -C {CSRC_DIR}` or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.",
+            )
+        # torch ships its own libamdhip64.so.7; import it first so this library binds to the
+        # SAME HIP runtime (same SONAME) and streams / pointers are interchangeable.
+        import torch  # noqa: F401
+
+        lib = ctypes.CDLL(str(LIB_PATH), mode=ctypes.RTLD_GLOBAL)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        lib.lsr_last_error.argtypes = []
+        lib.lsr_last_error.restype = ctypes.c_char_p
+        _lib = lib
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an entry point and raise on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.lsr_last_error().decode("utf-8", "replace")
+        cls = LsrUnsupported if rc == E_UNSUPPORTED else LsrError
+        raise cls(name, rc, msg)
+
+
+def matrix12(matrix_3x4):
+    """Row-major 3x4 -> ``double[12]``."""
+    import numpy as np
+
+    m = np.ascontiguousarray(np.asarray(matrix_3x4, dtype=np.float64).reshape(12))
+    return (ctypes.c_double * 12)(*m.tolist())
+
+
+def require_device_f32(t, name: str):
+    """Validate a tensor handed to the C ABI: HIP device, float32, contiguous."""
+    import torch
+
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
+    if t.device.type != "cuda":
+        raise LsrError(
+            "require_device", -1,
+            f"{name} is on {t.device}; this path runs only on a HIP device (MI355X). "
+            "There is no CPU fallback.",
+        )
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def stream_ptr(device=None) -> int:
+    """The current torch HIP stream of ``device`` as an integer ``hipStream_t``."""
+    import torch
+
+    return int(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,367 @@
+// 3-D PSF correlation with fused Richardson-Lucy epilogues for gfx950.
+//
+// North-star: "each RL iteration is a 3D PSF stencil with LDS tiling"; the reference has no RL
+// symbol (docs/data_structure.md:58-62), the CPU path is an explicit loop over
+// scipy.ndimage.convolve / correlate (oracle/cpu_ref.py:richardson_lucy).
+//
+// Structure: 2.5-D streaming.  A workgroup owns a (32 x 64) column of (y, x) and marches along
+// z.  Every input plane is staged ONCE in LDS with its in-plane halo, filtered in-plane, and
+// its contribution is scattered into PZ per-thread register accumulators -- one per pending
+// output plane -- so there is no z-halo re-read and no z traffic through LDS.  When an output
+// plane has received all PZ contributions it is finished by the fused epilogue:
+//     RATIO : out = y / (c + eps)           (first half of an RL iteration)
+//     UPDATE: out = x * c / (H^T 1)         (second half; H^T 1 evaluated analytically)
+// Algorithmic HBM bytes per voxel per launch: 4 (in) + 4 (aux) + 4 (out) = 12.
+//
+// Separable PSFs (rank-1: wz x wy x wx) take pz+py+px FMAs per voxel: HBM-bound.
+// Dense PSFs take pz*py*px FMAs per voxel: fp32-VALU-bound beyond ~120 taps.  No MFMA.
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTileY = 32;
+constexpr int kTileX = 64;
+constexpr int kRun = kTileY / (kThreads / 64);  // 8 consecutive y per thread, one x column
+constexpr int kMaxTaps = 15;                    // per axis
+constexpr int kARows = kTileY + kMaxTaps - 1;   // staged plane rows incl. halo
+constexpr int kAPitch = kTileX + kMaxTaps - 1 + 2;
+constexpr int kBPitch = kTileX;
+
+struct CorrArgs {
+  const float* in;
+  float* out;
+  const float* aux;
+  int64_t Z, Y, X;
+  const float* wz;  // separable factors (device)
+  const float* wy;
+  const float* wx;
+  const float* w;   // dense taps (device), C-order (pz, py, px)
+  int pz, py, px;
+  int epilogue;
+  float eps;
+  const float* nz;  // separable norm factors
+  const float* ny;
+  const float* nx;
+  const double* norm_table;  // dense: (pz+1)(py+1)(px+1) prefix sums
+  int64_t tiles_x, tiles_y;
+  int64_t z_chunk;  // output planes per workgroup along z
+};
+
+// H^T 1 for the dense form: sum of the taps whose sample lies inside the volume, from the
+// inclusive prefix-sum table P[a][b][c] = sum_{a'<a,b'<b,c'<c} w.
+__device__ double dense_norm(const CorrArgs& p, int64_t z, int64_t y, int64_t x) {
+  const int cz = p.pz / 2, cy = p.py / 2, cx = p.px / 2;
+  const int a0 = static_cast<int>(max(int64_t(0), cz - z));
+  const int a1 = static_cast<int>(min(int64_t(p.pz), p.Z - z + cz));
+  const int b0 = static_cast<int>(max(int64_t(0), cy - y));
+  const int b1 = static_cast<int>(min(int64_t(p.py), p.Y - y + cy));
+  const int c0 = static_cast<int>(max(int64_t(0), cx - x));
+  const int c1 = static_cast<int>(min(int64_t(p.px), p.X - x + cx));
+  const int sb = p.px + 1, sa = (p.py + 1) * sb;
+  const double* P = p.norm_table;
+  if (a0 == 0 && a1 == p.pz && b0 == 0 && b1 == p.py && c0 == 0 && c1 == p.px)
+    return P[p.pz * sa + p.py * sb + p.px];  // interior: every tap lands inside
+  return ((P[a1 * sa + b1 * sb + c1] - P[a0 * sa + b1 * sb + c1]) -
+          (P[a1 * sa + b0 * sb + c1] - P[a0 * sa + b0 * sb + c1])) -
+         ((P[a1 * sa + b1 * sb + c0] - P[a0 * sa + b1 * sb + c0]) -
+          (P[a1 * sa + b0 * sb + c0] - P[a0 * sa + b0 * sb + c0]));
+}
+
+template <int PZ, bool SEP>
+__global__ __launch_bounds__(kThreads) void correlate_march_kernel(CorrArgs p) {
+  __shared__ float bufA[kARows * kAPitch];
+  __shared__ float bufB[SEP ? kARows * kBPitch : 1];
+
+  const int tid = threadIdx.x;
+  const int lx = tid & 63;
+  const int yq = tid >> 6;
+
+  int64_t bid = blockIdx.x;
+  const int64_t tx = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int64_t ty = bid % p.tiles_y;
+  const int64_t zc = bid / p.tiles_y;
+
+  const int64_t x0 = tx * kTileX;
+  const int64_t y0 = ty * kTileY;
+  const int64_t zb = zc * p.z_chunk;
+  const int64_t ze = min(zb + p.z_chunk, p.Z);
+
+  const int py = p.py, px = p.px;
+  const int cz = PZ / 2, cy = py / 2, cx = px / 2;
+  const int a_rows = kTileY + py - 1;
+  const int a_cols = kTileX + px - 1;
+  const int64_t plane = p.Y * p.X;
+
+  // pending output planes: acc[m][j] <-> z_out = zi - cz + j after input plane zi is absorbed
+  float acc[kRun][PZ];
+#pragma unroll
+  for (int m = 0; m < kRun; ++m)
+#pragma unroll
+    for (int j = 0; j < PZ; ++j) acc[m][j] = 0.0f;
+
+  float wzr[PZ];
+  if constexpr (SEP) {
+#pragma unroll
+    for (int a = 0; a < PZ; ++a) wzr[a] = p.wz[a];
+  }
+
+  const int64_t zi_begin = max(zb - cz, int64_t(0));
+  const int64_t zi_end = ze + cz;  // exclusive
+  for (int64_t zi = zi_begin; zi < zi_end; ++zi) {
+    const bool have_plane = zi < p.Z;
+    float pl[kRun];
+#pragma unroll
+    for (int m = 0; m < kRun; ++m) pl[m] = 0.0f;
+
+    if (have_plane) {
+      __syncthreads();  // previous plane's readers of bufA (and bufB) are done
+      // ---- stage plane zi with its (y, x) halo; zero outside the volume ----
+      const float* src = p.in + zi * plane;
+      for (int e = tid; e < a_rows * a_cols; e += kThreads) {
+        const int r = e / a_cols;
+        const int c = e - r * a_cols;
+        const int64_t gy = y0 + r - cy;
+        const int64_t gx = x0 + c - cx;
+        float v = 0.0f;
+        if (gy >= 0 && gy < p.Y && gx >= 0 && gx < p.X) v = src[gy * p.X + gx];
+        bufA[r * kAPitch + c] = v;
+      }
+      __syncthreads();
+
+      if constexpr (SEP) {
+        // ---- x pass: bufB[r][x] = sum_c wx[c] * bufA[r][x + c] ----
+        for (int r = yq; r < a_rows; r += kThreads / 64) {
+          const float* row = bufA + r * kAPitch + lx;
+          float s = 0.0f;
+          for (int c = 0; c < px; ++c) s = fmaf(p.wx[c], row[c], s);
+          bufB[r * kBPitch + lx] = s;
+        }
+        __syncthreads();
+        // ---- y pass: pl[m] = sum_b wy[b] * bufB[yq*8 + m + b][x] ----
+        const float* col = bufB + (yq * kRun) * kBPitch + lx;
+        for (int b = 0; b < py; ++b) {
+          const float wb = p.wy[b];
+#pragma unroll
+          for (int m = 0; m < kRun; ++m) pl[m] = fmaf(wb, col[(m + b) * kBPitch], pl[m]);
+        }
+      }
+    }
+
+    if constexpr (SEP) {
+      // ---- z: shift the pending planes and add this plane's contribution in one FMA ----
+#pragma unroll
+      for (int m = 0; m < kRun; ++m) {
+#pragma unroll
+        for (int j = 0; j < PZ - 1; ++j) acc[m][j] = fmaf(wzr[PZ - 1 - j], pl[m], acc[m][j + 1]);
+        acc[m][PZ - 1] = wzr[0] * pl[m];
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < kRun; ++m) {
+#pragma unroll
+        for (int j = 0; j < PZ - 1; ++j) acc[m][j] = acc[m][j + 1];
+        acc[m][PZ - 1] = 0.0f;
+      }
+      if (have_plane) {
+        const float* base = bufA + (yq * kRun) * kAPitch + lx;
+        const int tap_plane = py * px;
+        for (int b = 0; b < py; ++b) {
+          for (int c = 0; c < px; ++c) {
+            float wv[PZ];
+#pragma unroll
+            for (int a = 0; a < PZ; ++a) wv[a] = p.w[a * tap_plane + b * px + c];
+#pragma unroll
+            for (int m = 0; m < kRun; ++m) {
+              const float v = base[(m + b) * kAPitch + c];
+#pragma unroll
+              for (int j = 0; j < PZ; ++j) acc[m][j] = fmaf(wv[PZ - 1 - j], v, acc[m][j]);
+            }
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: output plane z_out has now seen all PZ input planes ----
+    const int64_t z_out = zi - cz;
+    if (z_out >= zb) {
+      const int64_t gx = x0 + lx;
+      if (gx < p.X) {
+#pragma unroll
+        for (int m = 0; m < kRun; ++m) {
+          const int64_t gy = y0 + yq * kRun + m;
+          if (gy < p.Y) {
+            const int64_t o = z_out * plane + gy * p.X + gx;
+            const float c = acc[m][0];
+            float r;
+            if (p.epilogue == LSR_EPI_RATIO) {
+              r = p.aux[o] / (c + p.eps);
+            } else if (p.epilogue == LSR_EPI_UPDATE) {
+              float nrm;
+              if constexpr (SEP) {
+                nrm = p.nz[z_out] * p.ny[gy] * p.nx[gx];
+              } else {
+                nrm = static_cast<float>(dense_norm(p, z_out, gy, gx));
+              }
+              r = p.aux[o] * c / nrm;
+            } else {
+              r = c;
+            }
+            p.out[o] = r;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool SEP>
+int launch_correlate(const CorrArgs& p, hipStream_t s) {
+  const int64_t blocks = p.tiles_x * p.tiles_y * lsr::ceil_div(p.Z, p.z_chunk);
+  if (blocks >= (int64_t(1) << 31))
+    return lsr::fail(LSR_E_SHAPE, "grid of %lld workgroups is too large", (long long)blocks);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(kThreads);
+  switch (p.pz) {
+#define LSR_CASE(N)                                                                    \
+  case N:                                                                              \
+    hipLaunchKernelGGL((correlate_march_kernel<N, SEP>), grid, block, 0, s, p);        \
+    break;
+    LSR_CASE(1)
+    LSR_CASE(3)
+    LSR_CASE(5)
+    LSR_CASE(7)
+    LSR_CASE(9)
+    LSR_CASE(11)
+    LSR_CASE(13)
+    LSR_CASE(15)
+#undef LSR_CASE
+    default:
+      return lsr::fail(LSR_E_UNSUPPORTED, "pz = %d: taps per axis must be odd and <= %d", p.pz,
+                       kMaxTaps);
+  }
+  return lsr::launch_status(SEP ? "lsr_correlate_sep_f32" : "lsr_correlate_dense_f32");
+}
+
+int check_common(const float* in, float* out, const float* aux, int64_t Z, int64_t Y, int64_t X,
+                 int pz, int py, int px, int epilogue) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(out);
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
+              (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE(pz >= 1 && py >= 1 && px >= 1 && (pz & 1) && (py & 1) && (px & 1) &&
+                  pz <= kMaxTaps && py <= kMaxTaps && px <= kMaxTaps,
+              LSR_E_UNSUPPORTED, "PSF taps (%d,%d,%d) must be odd and <= %d per axis", pz, py, px,
+              kMaxTaps);
+  LSR_REQUIRE(epilogue == LSR_EPI_NONE || epilogue == LSR_EPI_RATIO || epilogue == LSR_EPI_UPDATE,
+              LSR_E_ARG, "unknown epilogue %d", epilogue);
+  if (epilogue != LSR_EPI_NONE) LSR_REQUIRE_PTR(aux);
+  LSR_REQUIRE(in != out, LSR_E_ARG, "out must not alias in");
+  return LSR_OK;
+}
+
+// Split z only as far as needed to fill the chip: every chunk re-reads pz-1 halo planes.
+int64_t pick_z_chunk(int64_t Z, int64_t tiles_xy, int pz) {
+  const int64_t want = 256 * 8;  // workgroups for ~8 per CU
+  int64_t chunks = lsr::ceil_div(want, tiles_xy);
+  if (chunks < 1) chunks = 1;
+  int64_t chunk = lsr::ceil_div(Z, chunks);
+  const int64_t min_chunk = 8 * static_cast<int64_t>(pz);  // keep halo overhead <= ~12 %
+  if (chunk < min_chunk) chunk = min_chunk;
+  if (chunk > Z) chunk = Z;
+  return chunk;
+}
+
+}  // namespace
+
+extern "C" int lsr_correlate_sep_f32(const float* in, float* out, const float* aux, int64_t Z,
+                                     int64_t Y, int64_t X, const float* wz, int pz,
+                                     const float* wy, int py, const float* wx, int px,
+                                     int epilogue, float eps, const float* nz, const float* ny,
+                                     const float* nx, lsr_stream_t stream) {
+  if (int rc = check_common(in, out, aux, Z, Y, X, pz, py, px, epilogue)) return rc;
+  LSR_REQUIRE_PTR(wz);
+  LSR_REQUIRE_PTR(wy);
+  LSR_REQUIRE_PTR(wx);
+  if (epilogue == LSR_EPI_UPDATE) {
+    LSR_REQUIRE_PTR(nz);
+    LSR_REQUIRE_PTR(ny);
+    LSR_REQUIRE_PTR(nx);
+  }
+  CorrArgs p{};
+  p.in = in; p.out = out; p.aux = aux;
+  p.Z = Z; p.Y = Y; p.X = X;
+  p.wz = wz; p.wy = wy; p.wx = wx;
+  p.pz = pz; p.py = py; p.px = px;
+  p.epilogue = epilogue; p.eps = eps;
+  p.nz = nz; p.ny = ny; p.nx = nx;
+  p.tiles_x = lsr::ceil_div(X, kTileX);
+  p.tiles_y = lsr::ceil_div(Y, kTileY);
+  p.z_chunk = pick_z_chunk(Z, p.tiles_x * p.tiles_y, pz);
+  return launch_correlate<true>(p, lsr::as_stream(stream));
+}
+
+extern "C" int lsr_correlate_dense_f32(const float* in, float* out, const float* aux, int64_t Z,
+                                       int64_t Y, int64_t X, const float* w, int pz, int py,
+                                       int px, int epilogue, float eps, const double* norm_table,
+                                       lsr_stream_t stream) {
+  if (int rc = check_common(in, out, aux, Z, Y, X, pz, py, px, epilogue)) return rc;
+  LSR_REQUIRE_PTR(w);
+  if (epilogue == LSR_EPI_UPDATE) LSR_REQUIRE_PTR(norm_table);
+  CorrArgs p{};
+  p.in = in; p.out = out; p.aux = aux;
+  p.Z = Z; p.Y = Y; p.X = X;
+  p.w = w;
+  p.pz = pz; p.py = py; p.px = px;
+  p.epilogue = epilogue; p.eps = eps;
+  p.norm_table = norm_table;
+  p.tiles_x = lsr::ceil_div(X, kTileX);
+  p.tiles_y = lsr::ceil_div(Y, kTileY);
+  p.z_chunk = pick_z_chunk(Z, p.tiles_x * p.tiles_y, pz);
+  return launch_correlate<false>(p, lsr::as_stream(stream));
+}
+
+extern "C" int lsr_rl_sep_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y,
+                              int64_t X, const float* kz, const float* kz_flipped, int pz,
+                              const float* ky, const float* ky_flipped, int py, const float* kx,
+                              const float* kx_flipped, int px, const float* nz, const float* ny,
+                              const float* nx, int iters, float eps, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(y);
+  LSR_REQUIRE_PTR(x);
+  LSR_REQUIRE_PTR(ratio);
+  LSR_REQUIRE(iters >= 0, LSR_E_ARG, "iters %d must be >= 0", iters);
+  LSR_REQUIRE(ratio != x && ratio != y && x != y, LSR_E_ARG, "y, x and ratio must be distinct");
+  for (int it = 0; it < iters; ++it) {
+    // H x = convolve(x, psf) = correlate(x, flipped psf)
+    int rc = lsr_correlate_sep_f32(x, ratio, y, Z, Y, X, kz_flipped, pz, ky_flipped, py,
+                                   kx_flipped, px, LSR_EPI_RATIO, eps, nullptr, nullptr, nullptr,
+                                   stream);
+    if (rc) return rc;
+    // H^T r = correlate(r, psf)
+    rc = lsr_correlate_sep_f32(ratio, x, x, Z, Y, X, kz, pz, ky, py, kx, px, LSR_EPI_UPDATE, eps,
+                               nz, ny, nx, stream);
+    if (rc) return rc;
+  }
+  return LSR_OK;
+}
+
+extern "C" int lsr_rl_dense_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y,
+                                int64_t X, const float* psf, const float* psf_flipped, int pz,
+                                int py, int px, const double* norm_table, int iters, float eps,
+                                lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(y);
+  LSR_REQUIRE_PTR(x);
+  LSR_REQUIRE_PTR(ratio);
+  LSR_REQUIRE(iters >= 0, LSR_E_ARG, "iters %d must be >= 0", iters);
+  LSR_REQUIRE(ratio != x && ratio != y && x != y, LSR_E_ARG, "y, x and ratio must be distinct");
+  for (int it = 0; it < iters; ++it) {
+    int rc = lsr_correlate_dense_f32(x, ratio, y, Z, Y, X, psf_flipped, pz, py, px, LSR_EPI_RATIO,
+                                     eps, nullptr, stream);
+    if (rc) return rc;
+    rc = lsr_correlate_dense_f32(ratio, x, x, Z, Y, X, psf, pz, py, px, LSR_EPI_UPDATE, eps,
+                                 norm_table, stream);
+    if (rc) return rc;
+  }
+  return LSR_OK;
+}

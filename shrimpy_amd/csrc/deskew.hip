@@ -1,0 +1,234 @@
+// Oblique-plane deskew for gfx950, slice averaging fused in.
+//
+// Replaces biahub.deskew.fast_deskew_zyx as called at shrimpy/preprocessing.py:408-413
+// (reference root /root/reference). Geometry (matrix rows, output shape) is computed on the
+// host (shrimpy_amd/geometry.py); this file only evaluates it.
+//
+// The deskew map interpolates along ONE input axis only:
+//     z_in = a*zd + b*xo + c      (fractional; zd = pre-average output plane, xo = scan axis)
+//     y_in = sy*zd + oy           (integer: one tilt row per output plane)
+//     x_in = sx*yo + ox           (integer: raw X <-> output Y', 1:1)
+// so an output plane (Y', X') is a transposed, 1-D-resampled copy of the input slice
+// in[:, y_in, :].  The output-fastest axis X' walks the input's SLOWEST axis, hence a
+// workgroup stages an input slab (z-range x 64 contiguous x) in LDS with coalesced 256-B row
+// reads, and emits 256-B coalesced stores along X' -- a resampling transpose through LDS.
+//
+// HBM traffic per launch: 4*N_in (each raw voxel read ~once; neighbouring X' tiles share
+// 1-2 slab rows) + 4*N_out.  fp64 work is ~10 DP ops per pre-average voxel, far below the
+// HBM time, so the arithmetic follows scipy.ndimage exactly (see common.hpp).
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kTileY = 64;    // output Y' per workgroup == contiguous raw-x run (256 B rows)
+constexpr int kTileX = 64;    // output X' per workgroup (one wave-width of coalesced stores)
+constexpr int kSlabRows = 68; // LDS rows (input z) a workgroup can stage
+constexpr int kPitch = kTileY + 1;  // +1 float: lanes walk z at ~b rows/lane -> distinct banks
+constexpr int kThreads = 256;
+constexpr int kRowsPerThread = kTileY * kTileX / kThreads;  // 16 output points per thread
+constexpr int kMaxAvg = 4096;  // sanity bound only
+
+struct DeskewArgs {
+  const float* in;
+  float* out;
+  int64_t Z, Y, X;          // raw
+  int64_t Zo, Yo, Xo, Zd;   // output, and pre-average depth
+  double a, b, c;           // z_in = a*zd + b*xo + c
+  int64_t oy, ox;
+  int sy, sx;
+  int avg_n;
+  int tile_x;               // X' handled per workgroup (<= kTileX, chosen so the slab fits)
+  int64_t tiles_x, tiles_y; // workgroup grid, flattened: x fastest, then y, then zo
+};
+
+__global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
+  __shared__ float slab[kSlabRows * kPitch];
+
+  const int tid = threadIdx.x;
+  int64_t bid = blockIdx.x;
+  const int64_t tx = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int64_t ty = bid % p.tiles_y;
+  const int64_t zo = bid / p.tiles_y;
+
+  const int64_t xo0 = tx * p.tile_x;
+  const int64_t yo0 = ty * kTileY;
+  const int n_xo = static_cast<int>(min(static_cast<int64_t>(p.tile_x), p.Xo - xo0));
+  const int n_yo = static_cast<int>(min(static_cast<int64_t>(kTileY), p.Yo - yo0));
+
+  // compute-phase mapping: lane -> X' (coalesced stores), 4 waves stride over Y'
+  const int li = tid & 63;
+  const int lj0 = tid >> 6;
+  const double xo_d = static_cast<double>(xo0 + li);
+
+  float acc[kRowsPerThread];
+#pragma unroll
+  for (int m = 0; m < kRowsPerThread; ++m) acc[m] = 0.0f;
+
+  for (int k = 0; k < p.avg_n; ++k) {
+    const int64_t zd = min(zo * p.avg_n + k, p.Zd - 1);  // edge padding of the remainder
+    const int64_t y_in = p.sy * zd + p.oy;
+    const bool row_ok = (y_in >= 0) && (y_in < p.Y);
+
+    // z_in at both ends of the tile (monotonic in xo): the slab's z-range.
+    const double zd_d = static_cast<double>(zd);
+    const double z_first =
+        lsr::affine_coord(zd_d, 0.0, static_cast<double>(xo0), p.a, 0.0, p.b, p.c);
+    const double z_last =
+        lsr::affine_coord(zd_d, 0.0, static_cast<double>(xo0 + n_xo - 1), p.a, 0.0, p.b, p.c);
+    const double z_lo_d = floor(fmin(z_first, z_last));
+    const double z_hi_d = floor(fmax(z_first, z_last)) + 1.0;
+    // clamp to the volume (as doubles first: they may be far outside int range)
+    const double zmax_d = static_cast<double>(p.Z - 1);
+    const bool any_z = (z_hi_d >= 0.0) && (z_lo_d <= zmax_d);
+    const int64_t z_lo = static_cast<int64_t>(fmin(fmax(z_lo_d, 0.0), zmax_d));
+    const int64_t z_hi = static_cast<int64_t>(fmin(fmax(z_hi_d, 0.0), zmax_d));
+    const int n_rows = any_z ? static_cast<int>(z_hi - z_lo + 1) : 0;  // <= kSlabRows by host
+
+    if (k > 0) __syncthreads();  // previous slab fully consumed
+    if (row_ok && n_rows > 0) {
+      // stage: slab[zl][j] = in[z_lo+zl][y_in][sx*(yo0+j)+ox]; lanes along raw x (coalesced)
+      const int col = tid & 63;          // position inside the contiguous 64-float x run
+      const int j = (p.sx > 0) ? col : (kTileY - 1 - col);
+      const int64_t x_in = p.sx * (yo0 + j) + p.ox;
+      const bool col_ok = (j < n_yo) && (x_in >= 0) && (x_in < p.X);
+      const float* src = p.in + (z_lo * p.Y + y_in) * p.X + x_in;
+      const int64_t z_stride = p.Y * p.X;
+      for (int zl = tid >> 6; zl < n_rows; zl += kThreads / 64) {
+        float v = 0.0f;
+        if (col_ok) v = src[zl * z_stride];
+        slab[zl * kPitch + j] = v;
+      }
+    }
+    __syncthreads();
+
+    // sample: scipy order-1 along z only (the y/x weights are exactly 1 and 0)
+    const double z_in = lsr::affine_coord(zd_d, 0.0, xo_d, p.a, 0.0, p.b, p.c);
+    const bool ok = row_ok && (li < n_xo) && !(z_in < 0.0) && !(z_in > zmax_d);
+    if (ok) {
+      const double zf = floor(z_in);
+      const double f = z_in - zf;
+      const double w0 = 1.0 - f;
+      const double w1 = 1.0 - w0;
+      const int64_t z0 = static_cast<int64_t>(zf);
+      const int r0 = static_cast<int>(z0 - z_lo);
+      const int r1 = static_cast<int>(min(z0 + 1, p.Z - 1) - z_lo);
+      const float* s0 = slab + r0 * kPitch;
+      const float* s1 = slab + r1 * kPitch;
+#pragma unroll
+      for (int m = 0; m < kRowsPerThread; ++m) {
+        const int j = lj0 + 4 * m;
+        double t = lsr::dadd(0.0, lsr::dmul(static_cast<double>(s0[j]), w0));
+        t = lsr::dadd(t, lsr::dmul(static_cast<double>(s1[j]), w1));
+        const float d = static_cast<float>(t);
+        acc[m] = (k == 0) ? d : (acc[m] + d);
+      }
+    }
+  }
+
+  if (li < n_xo) {
+    const float denom = static_cast<float>(p.avg_n);
+    float* dst = p.out + (zo * p.Yo + yo0) * p.Xo + xo0 + li;
+#pragma unroll
+    for (int m = 0; m < kRowsPerThread; ++m) {
+      const int j = lj0 + 4 * m;
+      if (j < n_yo) dst[static_cast<int64_t>(j) * p.Xo] = (p.avg_n > 1) ? acc[m] / denom : acc[m];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void average_slices_kernel(const float* __restrict__ in,
+                                                             float* __restrict__ out, int64_t Zd,
+                                                             int64_t plane, int64_t Zo,
+                                                             int avg_n) {
+  const int64_t total = Zo * plane;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += stride) {
+    const int64_t zo = i / plane;
+    const int64_t r = i - zo * plane;
+    float acc = 0.0f;
+    for (int k = 0; k < avg_n; ++k) {
+      const int64_t zd = min(zo * avg_n + k, Zd - 1);
+      const float d = in[zd * plane + r];
+      acc = (k == 0) ? d : (acc + d);
+    }
+    out[i] = (avg_n > 1) ? acc / static_cast<float>(avg_n) : acc;
+  }
+}
+
+bool is_integer(double v) { return v == static_cast<double>(static_cast<int64_t>(v)); }
+
+}  // namespace
+
+extern "C" int lsr_deskew_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* out,
+                              int64_t Zo, int64_t Yo, int64_t Xo, int64_t Zd, const double M[12],
+                              int avg_n, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(out);
+  LSR_REQUIRE_PTR(M);
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "raw shape (%lld,%lld,%lld) must be positive",
+              (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE(Zo > 0 && Yo > 0 && Xo > 0 && Zd > 0, LSR_E_SHAPE,
+              "output shape (%lld,%lld,%lld) / Zd %lld must be positive", (long long)Zo,
+              (long long)Yo, (long long)Xo, (long long)Zd);
+  LSR_REQUIRE(avg_n >= 1 && avg_n <= kMaxAvg, LSR_E_ARG, "avg_n %d outside [1,%d]", avg_n,
+              kMaxAvg);
+  LSR_REQUIRE(Zo == lsr::ceil_div(Zd, avg_n), LSR_E_SHAPE,
+              "Zo %lld != ceil(Zd %lld / avg_n %d)", (long long)Zo, (long long)Zd, avg_n);
+  for (int i = 0; i < 12; ++i)
+    LSR_REQUIRE(M[i] == M[i] && M[i] - M[i] == 0.0, LSR_E_ARG, "M[%d] is not finite", i);
+
+  // deskew structure: only z_in is fractional
+  const bool structured = M[1] == 0.0 && (M[4] == 1.0 || M[4] == -1.0) && M[5] == 0.0 &&
+                          M[6] == 0.0 && is_integer(M[7]) && M[8] == 0.0 &&
+                          (M[9] == 1.0 || M[9] == -1.0) && M[10] == 0.0 && is_integer(M[11]);
+  LSR_REQUIRE(structured, LSR_E_UNSUPPORTED,
+              "matrix is not a deskew shear (rows 1,2 must be signed unit axes with integer "
+              "offsets, M[0][1] == 0): use lsr_affine_f32 + lsr_average_slices_f32");
+
+  DeskewArgs p;
+  p.in = in;
+  p.out = out;
+  p.Z = Z; p.Y = Y; p.X = X;
+  p.Zo = Zo; p.Yo = Yo; p.Xo = Xo; p.Zd = Zd;
+  p.a = M[0]; p.b = M[2]; p.c = M[3];
+  p.sy = static_cast<int>(M[4]); p.oy = static_cast<int64_t>(M[7]);
+  p.sx = static_cast<int>(M[9]); p.ox = static_cast<int64_t>(M[11]);
+  p.avg_n = avg_n;
+
+  // slab rows needed by a tile of w X' values: floor span of |b|*(w-1) plus the +1 neighbour
+  const double ab = p.b < 0 ? -p.b : p.b;
+  int tile_x = kTileX;
+  while (tile_x > 1 && ab * (tile_x - 1) + 3.0 > static_cast<double>(kSlabRows)) tile_x >>= 1;
+  LSR_REQUIRE(ab * (tile_x - 1) + 3.0 <= static_cast<double>(kSlabRows), LSR_E_UNSUPPORTED,
+              "scan step per output voxel |b| = %g is too large for the LDS slab", ab);
+  p.tile_x = tile_x;
+  p.tiles_x = lsr::ceil_div(Xo, tile_x);
+  p.tiles_y = lsr::ceil_div(Yo, kTileY);
+  const int64_t blocks = p.tiles_x * p.tiles_y * Zo;
+  LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
+              (long long)blocks);
+
+  hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
+                     lsr::as_stream(stream), p);
+  return lsr::launch_status("lsr_deskew_f32");
+}
+
+extern "C" int lsr_average_slices_f32(const float* in, int64_t Zd, int64_t Y, int64_t X,
+                                      float* out, int64_t Zo, int avg_n, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(out);
+  LSR_REQUIRE(Zd > 0 && Y > 0 && X > 0 && Zo > 0, LSR_E_SHAPE, "shape must be positive");
+  LSR_REQUIRE(avg_n >= 1 && avg_n <= kMaxAvg, LSR_E_ARG, "avg_n %d outside [1,%d]", avg_n,
+              kMaxAvg);
+  LSR_REQUIRE(Zo == lsr::ceil_div(Zd, avg_n), LSR_E_SHAPE, "Zo %lld != ceil(Zd %lld / avg_n %d)",
+              (long long)Zo, (long long)Zd, avg_n);
+  const int64_t plane = Y * X;
+  const int64_t total = Zo * plane;
+  const int64_t blocks = lsr::ceil_div(total, 256) < 8192 ? lsr::ceil_div(total, 256) : 8192;
+  hipLaunchKernelGGL(average_slices_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                     lsr::as_stream(stream), in, out, Zd, plane, Zo, avg_n);
+  return lsr::launch_status("lsr_average_slices_f32");
+}

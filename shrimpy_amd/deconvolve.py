@@ -1,0 +1,292 @@
+"""Richardson-Lucy 3-D deconvolution on MI355X.
+
+No reference symbol exists (``docs/data_structure.md:58-62``: "algorithms for deconvolution ...
+are being developed"); the north-star defines the step: 20 iterations of
+
+    x <- x * H^T( y / (H x + eps) ) / (H^T 1)
+
+with a 3-D PSF stencil and zero-padded borders, CPU path = explicit loop over
+``scipy.ndimage.convolve`` / ``correlate`` (``oracle/cpu_ref.py:richardson_lucy``, test-only).
+
+Each iteration is two launches of the z-marching LDS stencil ``csrc/correlate.hip`` with fused
+epilogues (ratio; multiplicative update with analytic ``H^T 1``): 12 algorithmic bytes per voxel
+per launch.  Rank-1 (separable) PSFs run ``pz+py+px`` FMAs per voxel and are HBM-bound; dense
+PSFs run ``pz*py*px`` FMAs per voxel and are fp32-VALU-bound.  float32 throughout; agreement
+with the float64-accumulating scipy loop is stated in ``tests/test_gpu_parity.py``.
+No CPU fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["richardson_lucy", "RichardsonLucyPlan", "factor_psf", "correlate3d", "prepare_psf"]
+
+MAX_TAPS = 15
+
+
+def prepare_psf(psf) -> np.ndarray:
+    """float32 (pz, py, px) with every axis odd: even axes get one trailing zero plane.
+
+    With ``center = size // 2`` the padded kernel produces the same correlation.
+    """
+    p = np.asarray(psf, dtype=np.float32)
+    if p.ndim != 3:
+        raise ValueError(f"psf must be 3-D (Z, Y, X), got shape {p.shape}")
+    if not np.all(np.isfinite(p)):
+        raise ValueError("psf contains non-finite values")
+    pad = [(0, 1 - (s % 2)) for s in p.shape]
+    if any(hi for _, hi in pad):
+        p = np.pad(p, pad)
+    if max(p.shape) > MAX_TAPS:
+        raise ValueError(f"psf shape {p.shape} exceeds {MAX_TAPS} taps per axis")
+    return np.ascontiguousarray(p)
+
+
+def factor_psf(psf, rtol: float = 1e-6):
+    """Rank-1 factorisation ``psf ~= kz x ky x kx`` or ``None``.
+
+    Accepted when ``max|psf - kz*ky*kx| <= rtol * max|psf|`` (float64 check).  Factors are
+    returned as float32 with the overall scale carried by ``kz``.
+    """
+    p = np.asarray(psf, dtype=np.float64)
+    pz, py, px = p.shape
+    peak = np.abs(p).max()
+    if peak == 0:
+        return None
+    u, s, vt = np.linalg.svd(p.reshape(pz, py * px), full_matrices=False)
+    kz = u[:, 0] * s[0]
+    yx = vt[0].reshape(py, px)
+    u2, s2, vt2 = np.linalg.svd(yx, full_matrices=False)
+    ky = u2[:, 0] * s2[0]
+    kx = vt2[0]
+    # fix signs so the in-plane factors are predominantly positive
+    if ky.sum() < 0:
+        ky, kz = -ky, -kz
+    if kx.sum() < 0:
+        kx, kz = -kx, -kz
+    # balance: in-plane factors sum to 1, scale stays in kz
+    sy, sx = ky.sum(), kx.sum()
+    if sy != 0 and sx != 0:
+        ky, kx, kz = ky / sy, kx / sx, kz * sy * sx
+    approx = kz[:, None, None] * ky[None, :, None] * kx[None, None, :]
+    if np.abs(approx - p).max() > rtol * peak:
+        return None
+    return kz.astype(np.float32), ky.astype(np.float32), kx.astype(np.float32)
+
+
+def _axis_norm(k: np.ndarray, n: int) -> np.ndarray:
+    """sum of the taps of a 1-D correlation kernel that land inside [0, n), per position."""
+    p = len(k)
+    c = p // 2
+    cs = np.concatenate([[0.0], np.cumsum(k.astype(np.float64))])
+    pos = np.arange(n)
+    lo = np.maximum(0, c - pos)
+    hi = np.minimum(p, n - pos + c)
+    return (cs[hi] - cs[lo]).astype(np.float32)
+
+
+def _prefix_table(w: np.ndarray) -> np.ndarray:
+    pz, py, px = w.shape
+    t = np.zeros((pz + 1, py + 1, px + 1), dtype=np.float64)
+    t[1:, 1:, 1:] = w.astype(np.float64).cumsum(0).cumsum(1).cumsum(2)
+    return t
+
+
+@dataclass
+class _DevicePsf:
+    separable: bool
+    shape: tuple[int, int, int]
+    # separable
+    k: tuple | None = None
+    k_flipped: tuple | None = None
+    # dense
+    w: object | None = None
+    w_flipped: object | None = None
+    norm_table: object | None = None
+
+
+class RichardsonLucyPlan:
+    """PSF taps, border normalisation and scratch for one (volume shape, PSF, device).
+
+    ``plan(y)`` runs ``iterations`` RL iterations and returns the estimate (a new tensor).
+    """
+
+    def __init__(self, shape_zyx, psf, device, *, separable: str = "auto",
+                 separable_rtol: float = 1e-6, psf_factors=None):
+        import torch
+
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.LsrError("RichardsonLucyPlan", -1,
+                                f"device {self.device} is not a GPU; there is no CPU fallback")
+        self.shape = tuple(int(v) for v in shape_zyx)
+        if len(self.shape) != 3 or min(self.shape) <= 0:
+            raise ValueError(f"shape_zyx must be three positive ints, got {self.shape}")
+        if separable not in ("auto", "force", "never"):
+            raise ValueError("separable must be 'auto', 'force' or 'never'")
+
+        factors = None
+        if psf_factors is not None:
+            factors = tuple(np.asarray(k, dtype=np.float32).ravel() for k in psf_factors)
+            if len(factors) != 3 or any(len(k) % 2 == 0 or len(k) > MAX_TAPS for k in factors):
+                raise ValueError("psf_factors must be three odd-length 1-D kernels (<= 15 taps)")
+            self.psf = (factors[0][:, None, None] * factors[1][None, :, None]
+                        * factors[2][None, None, :]).astype(np.float32)
+        else:
+            self.psf = prepare_psf(psf)
+            if separable != "never":
+                factors = factor_psf(self.psf, separable_rtol)
+                if factors is None and separable == "force":
+                    raise ValueError("psf is not rank-1 within separable_rtol")
+
+        def dev(a, dtype=torch.float32):
+            return torch.as_tensor(np.ascontiguousarray(a), device=self.device).to(dtype)
+
+        z, y, x = self.shape
+        if factors is not None:
+            kz, ky, kx = factors
+            self._psf = _DevicePsf(
+                separable=True,
+                shape=(len(kz), len(ky), len(kx)),
+                k=(dev(kz), dev(ky), dev(kx)),
+                k_flipped=(dev(kz[::-1]), dev(ky[::-1]), dev(kx[::-1])),
+            )
+            self._norm = (dev(_axis_norm(kz, z)), dev(_axis_norm(ky, y)), dev(_axis_norm(kx, x)))
+        else:
+            w = self.psf
+            self._psf = _DevicePsf(
+                separable=False,
+                shape=tuple(w.shape),
+                w=dev(w.ravel()),
+                w_flipped=dev(w[::-1, ::-1, ::-1].ravel()),
+                norm_table=dev(_prefix_table(w).ravel(), torch.float64),
+            )
+            self._norm = None
+        self._ratio = None
+
+    @property
+    def separable(self) -> bool:
+        return self._psf.separable
+
+    def _scratch(self):
+        import torch
+
+        if self._ratio is None:
+            self._ratio = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        return self._ratio
+
+    def release(self) -> None:
+        """Drop the ratio scratch volume."""
+        self._ratio = None
+
+    def __call__(self, y, iterations: int = 20, eps: float = 1e-6, x0=None, out=None):
+        import torch
+
+        y = _lib.require_device_f32(y, "y")
+        if tuple(y.shape) != self.shape or y.device != self.device:
+            raise ValueError(f"y must be {self.shape} on {self.device}, got {tuple(y.shape)} on {y.device}")
+        iterations = int(iterations)
+        if iterations < 0:
+            raise ValueError("iterations must be >= 0")
+        if not eps > 0:
+            raise ValueError("eps must be > 0")
+        init = y if x0 is None else _lib.require_device_f32(x0, "x0")
+        if out is None:
+            x = init.clone()
+        else:
+            x = _lib.require_device_f32(out, "out")
+            if tuple(x.shape) != self.shape or x.data_ptr() == y.data_ptr():
+                raise ValueError("out must have the volume shape and must not alias y")
+            x.copy_(init)
+        if iterations == 0:
+            return x
+        ratio = self._scratch()
+        z, yy, xx = self.shape
+        ps = self._psf
+        with torch.cuda.device(self.device):
+            stream = _lib.stream_ptr(self.device)
+            if ps.separable:
+                (kz, ky, kx), (fz, fy, fx) = ps.k, ps.k_flipped
+                nz, ny, nx = self._norm
+                _lib.call(
+                    "lsr_rl_sep_f32", y.data_ptr(), x.data_ptr(), ratio.data_ptr(), z, yy, xx,
+                    kz.data_ptr(), fz.data_ptr(), ps.shape[0], ky.data_ptr(), fy.data_ptr(),
+                    ps.shape[1], kx.data_ptr(), fx.data_ptr(), ps.shape[2], nz.data_ptr(),
+                    ny.data_ptr(), nx.data_ptr(), iterations, ctypes.c_float(eps), stream,
+                )
+            else:
+                _lib.call(
+                    "lsr_rl_dense_f32", y.data_ptr(), x.data_ptr(), ratio.data_ptr(), z, yy, xx,
+                    ps.w.data_ptr(), ps.w_flipped.data_ptr(), ps.shape[0], ps.shape[1], ps.shape[2],
+                    ps.norm_table.data_ptr(), iterations, ctypes.c_float(eps), stream,
+                )
+        return x
+
+
+def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=None, *,
+                    separable: str = "auto", separable_rtol: float = 1e-6, psf_factors=None):
+    """Richardson-Lucy deconvolution of a (Z, Y, X) float32 device tensor; returns a new tensor.
+
+    ``psf`` is used as given (normalise it to sum 1 for flux conservation).  ``x0`` defaults to
+    ``y``.  ``separable="auto"`` takes the rank-1 fast path when the PSF factorises within
+    ``separable_rtol``; pass ``psf_factors=(kz, ky, kx)`` to skip the test.
+    """
+    import torch
+
+    if not isinstance(y, torch.Tensor):
+        raise TypeError(f"y must be a torch.Tensor, got {type(y).__name__}")
+    if y.dim() != 3:
+        raise ValueError(f"y must be (Z, Y, X), got shape {tuple(y.shape)}")
+    if y.dtype != torch.float32:
+        y = y.to(torch.float32)
+    y = y.contiguous()
+    plan = RichardsonLucyPlan(tuple(y.shape), psf, y.device, separable=separable,
+                              separable_rtol=separable_rtol, psf_factors=psf_factors)
+    return plan(y, iterations=iterations, eps=eps, x0=x0)
+
+
+def correlate3d(volume, weights=None, *, weight_factors=None):
+    """``scipy.ndimage.correlate(volume, weights, mode="constant", cval=0)`` on the device.
+
+    Pass ``weight_factors=(wz, wy, wx)`` for the separable kernel.  (The un-fused building block of
+    the RL launches; also used for PSF-blurring synthetic scenes.)
+    """
+    import torch
+
+    vol = _lib.require_device_f32(volume, "volume")
+    if vol.dim() != 3:
+        raise ValueError("volume must be (Z, Y, X)")
+    out = torch.empty_like(vol)
+    z, y, x = (int(v) for v in vol.shape)
+
+    def dev(a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=vol.device)
+
+    with torch.cuda.device(vol.device):
+        stream = _lib.stream_ptr(vol.device)
+        if weight_factors is not None:
+            wz, wy, wx = (np.asarray(k, dtype=np.float32).ravel() for k in weight_factors)
+            dz, dy, dx = dev(wz), dev(wy), dev(wx)
+            _lib.call(
+                "lsr_correlate_sep_f32", vol.data_ptr(), out.data_ptr(), None, z, y, x,
+                dz.data_ptr(), len(wz), dy.data_ptr(), len(wy), dx.data_ptr(), len(wx),
+                _lib.EPI_NONE, ctypes.c_float(0.0), None, None, None, stream,
+            )
+        else:
+            w = prepare_psf(weights)
+            dw = dev(w.ravel())
+            _lib.call(
+                "lsr_correlate_dense_f32", vol.data_ptr(), out.data_ptr(), None, z, y, x,
+                dw.data_ptr(), w.shape[0], w.shape[1], w.shape[2], _lib.EPI_NONE,
+                ctypes.c_float(0.0), None, stream,
+            )
+        # the tap tensors must outlive the launch: the caching allocator keeps their blocks on
+        # this stream, so reuse after free is stream-ordered
+    return out

@@ -1,0 +1,166 @@
+"""Drop-in for ``biahub.deskew`` on MI355X: same names, argument meaning and error behaviour.
+
+``import shrimpy_amd.deskew as biahub_deskew`` serves every call the reference makes:
+
+* ``fast_deskew_zyx(raw_data=volume, **kwargs)``            ``shrimpy/preprocessing.py:408-413``
+* ``get_deskewed_data_shape(raw_data_shape=..., **kwargs)`` ``shrimpy/preprocessing.py:226-231``,
+  ``scripts/measure_psf.py:230-234`` (with ``pixel_size_um=``)
+* ``deskew_data(chunk, device=..., **settings)`` (older API)  ``scripts/measure_psf.py:238-246``
+
+The reference filters kwargs by ``inspect.signature`` (``shrimpy/preprocessing.py:53-56``), so the
+parameter NAMES below are the API.  The arithmetic runs in the HIP kernel ``lsr_deskew_f32``
+(``csrc/deskew.hip``): fused slice averaging, results bit-identical to
+``scipy.ndimage.affine_transform(order=1, mode="constant", cval=0)`` + edge-padded float32 mean.
+There is no CPU fallback: a CPU tensor raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .geometry import as_matrix_3x4, deskew_geometry
+
+__all__ = [
+    "fast_deskew_zyx",
+    "get_deskewed_data_shape",
+    "deskew_data",
+    "deskew_with_matrix",
+    "average_n_slices",
+]
+
+
+def get_deskewed_data_shape(
+    raw_data_shape,
+    ls_angle_deg: float,
+    px_to_scan_ratio: float,
+    keep_overhang: bool,
+    average_n_slices: int = 1,
+    pixel_size_um: float = 1,
+):
+    """Shape of the deskewed volume and its voxel size.
+
+    Returns ``((ceil(Y/avg), X, Xp), (avg*sin(theta)*px, px, px))`` for a raw ``(Z, Y, X)`` stack.
+    """
+    geo = deskew_geometry(
+        raw_data_shape, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices, pixel_size_um
+    )
+    return geo.output_shape, geo.voxel_size
+
+
+def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices: int = 1, out=None):
+    """Deskew with an explicit output->input matrix over the pre-average grid.
+
+    Shear-structured matrices (only ``z_in`` fractional) run the fused transpose kernel; any other
+    3x4 map runs the general trilinear kernel followed by the slice-averaging kernel.
+    """
+    import torch
+
+    raw = _lib.require_device_f32(raw_data, "raw_data")
+    if raw.dim() != 3:
+        raise ValueError(f"raw_data must be (Z, Y, X), got shape {tuple(raw.shape)}")
+    m = as_matrix_3x4(matrix_3x4)
+    zd, yo, xo = (int(v) for v in pre_average_shape)
+    avg = int(average_n_slices)
+    if avg < 1:
+        raise ValueError(f"average_n_slices must be >= 1, got {avg}")
+    if min(zd, yo, xo) <= 0:
+        raise ValueError(
+            f"deskewed shape {(zd, yo, xo)} is empty: the scan is too short for this tilt "
+            "(use keep_overhang=True or a longer scan)"
+        )
+    zo = -(-zd // avg)
+    if out is None:
+        out = torch.empty((zo, yo, xo), dtype=torch.float32, device=raw.device)
+    else:
+        _lib.require_device_f32(out, "out")
+        if tuple(out.shape) != (zo, yo, xo) or out.device != raw.device:
+            raise ValueError(f"out must be {(zo, yo, xo)} on {raw.device}")
+    z, y, x = (int(v) for v in raw.shape)
+    with torch.cuda.device(raw.device):
+        stream = _lib.stream_ptr(raw.device)
+        try:
+            _lib.call(
+                "lsr_deskew_f32", raw.data_ptr(), z, y, x, out.data_ptr(), zo, yo, xo, zd,
+                _lib.matrix12(m), avg, stream,
+            )
+        except _lib.LsrUnsupported:
+            # general matrix: trilinear gather, then average
+            pre = out if avg == 1 else torch.empty((zd, yo, xo), dtype=torch.float32, device=raw.device)
+            _lib.call(
+                "lsr_affine_f32", raw.data_ptr(), z, y, x, pre.data_ptr(), zd, yo, xo,
+                _lib.matrix12(m), ctypes.c_float(0.0), _lib.MODE_CONSTANT, stream,
+            )
+            if avg > 1:
+                _average_into(pre, out, avg, stream)
+    return out
+
+
+def _average_into(pre, out, avg: int, stream: int) -> None:
+    zd, y, x = (int(v) for v in pre.shape)
+    _lib.call("lsr_average_slices_f32", pre.data_ptr(), zd, y, x, out.data_ptr(), int(out.shape[0]), avg, stream)
+
+
+def average_n_slices(data, average_window_width: int = 1):
+    """Mean over groups of slices along axis 0, remainder edge-padded (device tensor in/out)."""
+    import torch
+
+    avg = int(average_window_width)
+    if avg < 1:
+        raise ValueError(f"average_window_width must be >= 1, got {avg}")
+    data = _lib.require_device_f32(data, "data")
+    if avg == 1:
+        return data
+    zd = int(data.shape[0])
+    out = torch.empty((-(-zd // avg),) + tuple(data.shape[1:]), dtype=torch.float32, device=data.device)
+    with torch.cuda.device(data.device):
+        _average_into(data, out, avg, _lib.stream_ptr(data.device))
+    return out
+
+
+def fast_deskew_zyx(
+    raw_data,
+    ls_angle_deg: float,
+    px_to_scan_ratio: float,
+    keep_overhang: bool,
+    average_n_slices: int = 1,
+):
+    """Deskew a raw ``(Z_scan, Y_tilt, X)`` float32 device tensor; returns a tensor on the same device.
+
+    Output axes ``(Z', Y', X')``: ``Z'`` = reversed tilt rows averaged in groups of
+    ``average_n_slices``, ``Y'`` = reversed raw X, ``X'`` = scan direction (the interpolated axis).
+    """
+    import torch
+
+    if not isinstance(raw_data, torch.Tensor):
+        raise TypeError(f"raw_data must be a torch.Tensor, got {type(raw_data).__name__}")
+    if raw_data.dim() != 3:
+        raise ValueError(f"raw_data must be (Z, Y, X), got shape {tuple(raw_data.shape)}")
+    if raw_data.dtype != torch.float32:
+        raw_data = raw_data.to(torch.float32)
+    raw_data = raw_data.contiguous()
+    geo = deskew_geometry(
+        tuple(raw_data.shape), ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices
+    )
+    return deskew_with_matrix(raw_data, geo.matrix_3x4, geo.pre_average_shape, average_n_slices)
+
+
+def deskew_data(
+    raw_data,
+    ls_angle_deg: float,
+    px_to_scan_ratio: float,
+    keep_overhang: bool,
+    average_n_slices: int = 1,
+    device="cuda",
+):
+    """Older biahub entry point: numpy in, numpy out, compute on ``device`` (must be a GPU)."""
+    import torch
+
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.LsrError("deskew_data", -1, f"device {dev} is not a GPU; there is no CPU fallback")
+    vol = torch.as_tensor(np.ascontiguousarray(raw_data, dtype=np.float32), device=dev)
+    out = fast_deskew_zyx(vol, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices)
+    return out.cpu().numpy()

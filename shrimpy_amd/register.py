@@ -1,0 +1,82 @@
+"""Affine registration apply (label-free <-> fluorescence) on MI355X.
+
+The reference has no symbol for this step ("algorithms for deconvolution and registration ...
+are being developed", ``docs/data_structure.md:58-62``); the north-star defines it as the
+``scipy.ndimage.affine_transform(moving, M, output_shape=target.shape, order=1,
+mode="constant", cval=0)`` path.  ``affine_transform_zyx`` is a 4x4 homogeneous matrix in ZYX voxel
+units mapping TARGET (output) index -> SOURCE (moving) coordinate.
+
+Runs the HIP kernel ``lsr_affine_f32`` (``csrc/affine.hip``); results are bit-identical to scipy
+for finite inputs.  No CPU fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+from . import _lib
+from .geometry import as_matrix_3x4
+
+__all__ = ["apply_affine_transform_zyx", "affine_transform"]
+
+_MODES = {"constant": _lib.MODE_CONSTANT, "grid-constant": _lib.MODE_GRID_CONSTANT}
+
+
+def apply_affine_transform_zyx(moving, affine_transform_zyx, output_shape_zyx=None, *,
+                               mode: str = "constant", cval: float = 0.0, out=None):
+    """Resample ``moving`` (Z, Y, X float32 device tensor) onto the target grid.
+
+    Parameters
+    ----------
+    affine_transform_zyx : 4x4 or 3x4 array-like, target index -> moving coordinate.
+    output_shape_zyx : target grid shape; defaults to ``moving.shape``.
+    mode : ``"constant"`` (scipy default: any coordinate outside ``[0, n-1]`` gives ``cval``) or
+        ``"grid-constant"`` (blend towards ``cval`` across the border).
+    """
+    import torch
+
+    if mode not in _MODES:
+        raise ValueError(f"mode must be one of {sorted(_MODES)}, got {mode!r}")
+    if not isinstance(moving, torch.Tensor):
+        raise TypeError(f"moving must be a torch.Tensor, got {type(moving).__name__}")
+    if moving.dim() != 3:
+        raise ValueError(f"moving must be (Z, Y, X), got shape {tuple(moving.shape)}")
+    if moving.dtype != torch.float32:
+        moving = moving.to(torch.float32)
+    moving = _lib.require_device_f32(moving.contiguous(), "moving")
+    m = as_matrix_3x4(affine_transform_zyx)
+    shape = tuple(int(v) for v in (output_shape_zyx if output_shape_zyx is not None else moving.shape))
+    if len(shape) != 3 or min(shape) <= 0:
+        raise ValueError(f"output_shape_zyx must be three positive ints, got {shape}")
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=moving.device)
+    else:
+        _lib.require_device_f32(out, "out")
+        if tuple(out.shape) != shape or out.device != moving.device:
+            raise ValueError(f"out must be {shape} on {moving.device}")
+        if out.data_ptr() == moving.data_ptr():
+            raise ValueError("out must not alias moving")
+    zi, yi, xi = (int(v) for v in moving.shape)
+    with torch.cuda.device(moving.device):
+        _lib.call(
+            "lsr_affine_f32", moving.data_ptr(), zi, yi, xi, out.data_ptr(), shape[0], shape[1],
+            shape[2], _lib.matrix12(m), ctypes.c_float(float(cval)), _MODES[mode],
+            _lib.stream_ptr(moving.device),
+        )
+    return out
+
+
+def affine_transform(input, matrix, offset=0.0, output_shape=None, order=1, mode="constant",
+                     cval=0.0):
+    """``scipy.ndimage.affine_transform``-shaped convenience (order 1 only, 3-D, device tensors)."""
+    import numpy as np
+
+    if order != 1:
+        raise ValueError("only order=1 (trilinear) is implemented")
+    mat = np.asarray(matrix, dtype=np.float64)
+    if mat.shape == (3,):
+        mat = np.diag(mat)
+    if mat.shape == (3, 3):
+        off = np.broadcast_to(np.asarray(offset, dtype=np.float64), (3,))
+        mat = np.concatenate([mat, off[:, None]], axis=1)
+    return apply_affine_transform_zyx(input, mat, output_shape, mode=mode, cval=cval)

@@ -1,0 +1,150 @@
+"""Settings models of the reconstruction path (pydantic, ``extra="forbid"``, YAML-loadable).
+
+``DeskewSettings`` mirrors ``biahub.settings.DeskewSettings`` as the reference uses it:
+constructed from a plain dict (``shrimpy/preprocessing.py:137-140``), dumped with
+``.model_dump()`` and filtered to the callee's signature (``:44-56``), attributes
+``px_to_scan_ratio`` / ``pixel_size_um`` / ``scan_step_um`` read by ``getattr`` (``:240-242``).
+Field names are evidenced at ``shrimpy/dynatrack/tracking.py:200-204``,
+``shrimpy/dynatrack/manager.py:297-299`` (scale injection) and
+``config/mda/mantis/dynatrack_demo.yaml:161-164``; the ratio rounding rule at
+``scripts/measure_psf.py:225``.  The strict-validation idiom is the reference's own
+(``shrimpy/config.py:82-127``).
+
+``RegisterSettings`` and ``DeconvolveSettings`` have no reference counterpart (registration and
+deconvolution are "being developed", ``docs/data_structure.md:58-62``); they follow the same idiom.
+"""
+
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Literal, Optional
+
+import numpy as np
+import yaml
+
+from pydantic import (
+    BaseModel,
+    ConfigDict,
+    NonNegativeInt,
+    PositiveFloat,
+    PositiveInt,
+    field_validator,
+    model_validator,
+)
+
+
+class _StrictModel(BaseModel):
+    model_config = ConfigDict(extra="forbid")
+
+    @classmethod
+    def from_yaml(cls, path: str | Path):
+        """Load and validate a YAML settings file."""
+        with open(path) as f:
+            raw = yaml.safe_load(f)
+        if not isinstance(raw, dict):
+            raise ValueError(f"{path}: expected a mapping at the top level")
+        return cls(**raw)
+
+    def to_yaml(self, path: str | Path) -> None:
+        with open(path, "w") as f:
+            yaml.safe_dump(self.model_dump(mode="json"), f, sort_keys=False)
+
+
+class DeskewSettings(_StrictModel):
+    """Oblique light-sheet deskew parameters.
+
+    Either ``px_to_scan_ratio`` or ``scan_step_um`` must be given; the ratio is derived as
+    ``round(pixel_size_um / scan_step_um, 3)`` when absent.
+    """
+
+    pixel_size_um: PositiveFloat
+    ls_angle_deg: PositiveFloat
+    px_to_scan_ratio: Optional[PositiveFloat] = None
+    scan_step_um: Optional[PositiveFloat] = None
+    keep_overhang: bool = False
+    average_n_slices: PositiveInt = 3
+
+    @field_validator("ls_angle_deg")
+    @classmethod
+    def _angle_range(cls, v: float) -> float:
+        if v > 45:
+            raise ValueError("light-sheet angle must be in (0, 45] degrees")
+        return round(float(v), 2)
+
+    @field_validator("px_to_scan_ratio")
+    @classmethod
+    def _round_ratio(cls, v):
+        return None if v is None else round(float(v), 3)
+
+    @model_validator(mode="after")
+    def _derive_ratio(self):
+        if self.px_to_scan_ratio is None:
+            if self.scan_step_um is None:
+                raise ValueError(
+                    "if px_to_scan_ratio is not provided, both pixel_size_um and scan_step_um "
+                    "must be provided"
+                )
+            ratio = round(self.pixel_size_um / self.scan_step_um, 3)
+            if not ratio > 0:
+                raise ValueError("derived px_to_scan_ratio rounds to zero")
+            object.__setattr__(self, "px_to_scan_ratio", ratio)
+        return self
+
+
+class RegisterSettings(_StrictModel):
+    """Affine registration apply (label-free <-> fluorescence).
+
+    ``affine_transform_zyx`` is a homogeneous 4x4 in ZYX voxel units mapping TARGET (output)
+    coordinates to SOURCE (moving) coordinates -- the ``scipy.ndimage.affine_transform`` convention.
+    """
+
+    source_channel_names: list[str] = []
+    target_channel_name: Optional[str] = None
+    affine_transform_zyx: list[list[float]]
+    output_shape_zyx: Optional[tuple[PositiveInt, PositiveInt, PositiveInt]] = None
+    mode: Literal["constant", "grid-constant"] = "constant"
+    cval: float = 0.0
+    keep_overhang: bool = False
+
+    @field_validator("affine_transform_zyx")
+    @classmethod
+    def _check_affine(cls, v):
+        m = np.asarray(v, dtype=np.float64)
+        if m.shape != (4, 4):
+            raise ValueError(f"affine_transform_zyx must be 4x4, got {m.shape}")
+        if not np.all(np.isfinite(m)):
+            raise ValueError("affine_transform_zyx contains non-finite entries")
+        if not np.allclose(m[3], [0, 0, 0, 1]):
+            raise ValueError("last row of affine_transform_zyx must be [0, 0, 0, 1]")
+        return m.tolist()
+
+
+class DeconvolveSettings(_StrictModel):
+    """Richardson-Lucy deconvolution.
+
+    The PSF comes from ``psf_path`` (``.npy`` ZYX array) or, when absent, is the separable
+    anisotropic Gaussian ``gaussian_sigma_zyx`` truncated to ``gaussian_shape_zyx``.
+    """
+
+    iterations: NonNegativeInt = 20
+    eps: PositiveFloat = 1e-6
+    psf_path: Optional[str] = None
+    gaussian_sigma_zyx: tuple[PositiveFloat, PositiveFloat, PositiveFloat] = (2.0, 1.2, 1.2)
+    gaussian_shape_zyx: tuple[PositiveInt, PositiveInt, PositiveInt] = (9, 7, 7)
+    separable: Literal["auto", "force", "never"] = "auto"
+    separable_rtol: PositiveFloat = 1e-6
+
+    @field_validator("gaussian_shape_zyx")
+    @classmethod
+    def _odd_taps(cls, v):
+        if any(n % 2 == 0 or n > 15 for n in v):
+            raise ValueError("gaussian_shape_zyx entries must be odd and <= 15")
+        return v
+
+
+class ReconstructSettings(_StrictModel):
+    """Whole per-volume pipeline: deskew -> (register) -> (deconvolve)."""
+
+    deskew: Optional[DeskewSettings] = None
+    registration: Optional[RegisterSettings] = None
+    deconvolution: Optional[DeconvolveSettings] = None

@@ -1,0 +1,252 @@
+"""CPU tests of the host side: geometry, settings, C-ABI surface, loud failure without a GPU.
+
+No compute call is made here (there is no GPU in the build container).
+"""
+
+import ctypes
+import inspect
+import re
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as o
+from shrimpy_amd import _lib, geometry
+from shrimpy_amd.settings import (
+    DeconvolveSettings,
+    DeskewSettings,
+    ReconstructSettings,
+    RegisterSettings,
+)
+
+# ---------------------------------------------------------------- geometry vs the oracle's own
+
+
+@pytest.mark.parametrize("raw_shape", [(24, 16, 40), (2048, 512, 2048), (256, 64, 256), (1201, 256, 1600)])
+@pytest.mark.parametrize("keep_overhang", [False, True])
+@pytest.mark.parametrize("avg", [1, 3, 5])
+def test_geometry_agrees_with_oracle(raw_shape, keep_overhang, avg):
+    geo = geometry.deskew_geometry(raw_shape, 30.0, 0.755, keep_overhang, avg, 0.1133)
+    m, off, pre = o.deskew_geometry(raw_shape, 30.0, 0.755, keep_overhang)
+    np.testing.assert_array_equal(geo.matrix_3x4[:, :3], m)
+    np.testing.assert_array_equal(geo.matrix_3x4[:, 3], off)
+    assert geo.pre_average_shape == pre
+    shape, voxel = o.deskewed_shape(raw_shape, 30.0, 0.755, keep_overhang, avg, 0.1133)
+    assert geo.output_shape == shape
+    assert geo.voxel_size == pytest.approx(voxel)
+
+
+def test_get_deskewed_data_shape_signature_is_the_reference_call():
+    """``shrimpy/preprocessing.py:226-231`` calls it with ``raw_data_shape=`` + filtered settings;
+    ``scripts/measure_psf.py:230-234`` adds ``pixel_size_um=``."""
+    from shrimpy_amd.deskew import fast_deskew_zyx, get_deskewed_data_shape
+
+    params = list(inspect.signature(get_deskewed_data_shape).parameters)
+    assert params == ["raw_data_shape", "ls_angle_deg", "px_to_scan_ratio", "keep_overhang",
+                      "average_n_slices", "pixel_size_um"]
+    params = list(inspect.signature(fast_deskew_zyx).parameters)
+    assert params == ["raw_data", "ls_angle_deg", "px_to_scan_ratio", "keep_overhang", "average_n_slices"]
+    shape, voxel = get_deskewed_data_shape(
+        raw_data_shape=(2048, 512, 2048), ls_angle_deg=30, px_to_scan_ratio=0.755,
+        keep_overhang=False, average_n_slices=3, pixel_size_um=0.1133)
+    assert shape == (171, 2048, 2270)
+    assert len(voxel) == 3
+
+
+def test_empty_deskew_is_reported_by_the_shape_rule():
+    # tilt longer than the scan: the no-overhang window is empty (SURVEY section 8 preamble)
+    shape, _ = geometry.deskew_geometry((512, 2048, 64), 30.0, 0.755, False)[2:], None
+    assert shape[0][2] < 0
+
+
+def test_geometry_rejects_bad_input():
+    with pytest.raises(ValueError):
+        geometry.deskew_geometry((4, 4), 30, 0.755, False)
+    with pytest.raises(ValueError):
+        geometry.deskew_geometry((4, 0, 4), 30, 0.755, False)
+    with pytest.raises(ValueError):
+        geometry.deskew_geometry((4, 4, 4), 30, 0.0, False)
+    with pytest.raises(ValueError):
+        geometry.deskew_geometry((4, 4, 4), 30, 0.755, False, average_n_slices=0)
+    with pytest.raises(ValueError):
+        geometry.as_matrix_3x4(np.eye(3))
+    with pytest.raises(ValueError):
+        geometry.as_matrix_3x4(np.full((3, 4), np.nan))
+
+
+# ---------------------------------------------------------------- settings
+
+
+def test_deskew_settings_derive_ratio_like_the_reference_scripts():
+    """``scripts/measure_psf.py:225``: ratio = round(pixel / scan_step, 3); scale injection
+    supplies pixel_size_um + scan_step_um (``shrimpy/dynatrack/manager.py:297-299``)."""
+    s = DeskewSettings(ls_angle_deg=30.0, keep_overhang=False, average_n_slices=3,
+                       pixel_size_um=0.1133, scan_step_um=0.15)
+    assert s.px_to_scan_ratio == 0.755
+    d = s.model_dump()
+    assert set(d) == {"pixel_size_um", "ls_angle_deg", "px_to_scan_ratio", "scan_step_um",
+                      "keep_overhang", "average_n_slices"}
+    # attributes the reference reads by getattr (shrimpy/preprocessing.py:240-242)
+    assert (s.px_to_scan_ratio, s.pixel_size_um, s.scan_step_um) == (0.755, 0.1133, 0.15)
+
+
+def test_deskew_settings_defaults_and_validation():
+    s = DeskewSettings(pixel_size_um=0.1, ls_angle_deg=30, px_to_scan_ratio=0.75549)
+    assert s.keep_overhang is False and s.average_n_slices == 3 and s.px_to_scan_ratio == 0.755
+    with pytest.raises(ValueError):
+        DeskewSettings(pixel_size_um=0.1, ls_angle_deg=30)  # neither ratio nor scan step
+    with pytest.raises(ValueError):
+        DeskewSettings(pixel_size_um=0.1, ls_angle_deg=50, px_to_scan_ratio=0.7)
+    with pytest.raises(ValueError):
+        DeskewSettings(pixel_size_um=0.1, ls_angle_deg=30, px_to_scan_ratio=0.7, bogus=1)  # extra=forbid
+    with pytest.raises(ValueError):
+        DeskewSettings(pixel_size_um=0.1, ls_angle_deg=30, px_to_scan_ratio=0.7, average_n_slices=0)
+
+
+def test_settings_kwargs_filtering_keeps_exactly_the_callee_params(golden_dir):
+    """The reference filters ``model_dump()`` by the callee signature
+    (``shrimpy/preprocessing.py:44-56``); the kept set was captured from the reference itself."""
+    from shrimpy_amd.deskew import fast_deskew_zyx
+
+    s = DeskewSettings(ls_angle_deg=30.0, pixel_size_um=0.1133, scan_step_um=0.15)
+    accepted = set(inspect.signature(fast_deskew_zyx).parameters)
+    kept = sorted(k for k in s.model_dump() if k in accepted)
+    ref = np.load(golden_dir / "ref_preprocessing.npz")
+    assert kept == list(ref["settings_kwargs_kept"])
+
+
+def test_register_and_deconvolve_settings(tmp_path):
+    m = np.eye(4).tolist()
+    r = RegisterSettings(affine_transform_zyx=m)
+    assert r.mode == "constant" and r.cval == 0.0
+    with pytest.raises(ValueError):
+        RegisterSettings(affine_transform_zyx=np.eye(3).tolist())
+    with pytest.raises(ValueError):
+        bad = np.eye(4)
+        bad[3, 0] = 1
+        RegisterSettings(affine_transform_zyx=bad.tolist())
+    d = DeconvolveSettings()
+    assert d.iterations == 20 and d.gaussian_shape_zyx == (9, 7, 7)
+    with pytest.raises(ValueError):
+        DeconvolveSettings(gaussian_shape_zyx=(8, 7, 7))
+    full = ReconstructSettings(
+        deskew=DeskewSettings(pixel_size_um=0.1133, ls_angle_deg=30, scan_step_um=0.15),
+        registration=r, deconvolution=d)
+    p = tmp_path / "recon.yml"
+    full.to_yaml(p)
+    again = ReconstructSettings.from_yaml(p)
+    assert again == full
+
+
+# ---------------------------------------------------------------- C ABI surface
+
+
+def _declared_symbols():
+    text = _lib.HEADER_PATH.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lsr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    assert _lib.LIB_PATH.exists(), "build liblsrecon.so first (__graft_entry__.build())"
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    declared = _declared_symbols()
+    assert "lsr_deskew_f32" in declared and "lsr_rl_sep_f32" in declared
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/lsrecon.h but not exported"
+    # and the ctypes table binds exactly the declared compute entry points
+    assert sorted(set(_lib.SIGNATURES) | {"lsr_last_error"}) == declared
+
+
+def test_library_loads_and_reports_version_and_arg_errors():
+    lib = _lib.load()
+    assert lib.lsr_version() == 100
+    # argument validation happens before any launch: safe without a GPU
+    rc = lib.lsr_deskew_f32(None, 1, 1, 1, None, 1, 1, 1, 1, None, 1, None)
+    assert rc == -1 and b"NULL" in lib.lsr_last_error()
+    m = _lib.matrix12(np.eye(3, 4))
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.lsr_deskew_f32(p, 4, 4, 4, p, 2, 4, 4, 4, m, 3, None)
+    assert rc == -3, "identity is not a deskew shear -> LSR_E_UNSUPPORTED"
+    rc = lib.lsr_deskew_f32(p, 4, 0, 4, p, 2, 4, 4, 4, m, 3, None)
+    assert rc == -2
+    rc = lib.lsr_correlate_sep_f32(p, p, None, 4, 4, 4, p, 4, p, 3, p, 3, 0, 0.0, None, None, None, None)
+    assert rc == -3, "even tap count is unsupported"
+    rc = lib.lsr_affine_f32(p, 2, 2, 2, p, 2, 2, 2, m, 0.0, 7, None)
+    assert rc == -4
+    with pytest.raises(_lib.LsrUnsupported):
+        _lib.call("lsr_deskew_f32", p, 4, 4, 4, p, 2, 4, 4, 4, m, 3, None)
+
+
+def test_product_path_fails_loudly_on_cpu_tensors():
+    """No CPU fallback: the reference's ``cpu`` device branch (``shrimpy/preprocessing.py:80``) gets
+    an exception, which ``_step`` logs and re-raises (``:377-381``)."""
+    import torch
+
+    from shrimpy_amd.deconvolve import richardson_lucy
+    from shrimpy_amd.deskew import deskew_data, fast_deskew_zyx
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    v = torch.zeros((8, 4, 4))
+    with pytest.raises(_lib.LsrError, match="no CPU fallback"):
+        fast_deskew_zyx(raw_data=v, ls_angle_deg=30, px_to_scan_ratio=0.755, keep_overhang=True)
+    with pytest.raises(_lib.LsrError, match="no CPU fallback"):
+        apply_affine_transform_zyx(v, np.eye(4))
+    with pytest.raises(_lib.LsrError, match="no CPU fallback"):
+        richardson_lucy(v, np.ones((3, 3, 3), np.float32) / 27)
+    with pytest.raises(_lib.LsrError, match="no CPU fallback"):
+        deskew_data(np.zeros((8, 4, 4), np.float32), 30, 0.755, True, device="cpu")
+
+
+def test_product_never_imports_the_oracle():
+    import pathlib
+
+    pkg = pathlib.Path(_lib.__file__).parent
+    for f in pkg.rglob("*.py"):
+        src = f.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+        assert not re.search(r"^\s*(from|import)\s+scipy\b", src, flags=re.M), (
+            f"{f} must not import scipy (the CPU reference path)")
+
+
+# ---------------------------------------------------------------- PSF preparation (host math)
+
+
+def test_factor_psf_recovers_separable_factors_and_rejects_rotated():
+    from shrimpy_amd.deconvolve import factor_psf, prepare_psf
+
+    psf, (kz, ky, kx) = o.gaussian_psf()
+    f = factor_psf(prepare_psf(psf))
+    assert f is not None
+    rec = f[0][:, None, None] * f[1][None, :, None] * f[2][None, None, :]
+    np.testing.assert_allclose(rec, psf, atol=1e-6 * psf.max())
+    assert factor_psf(prepare_psf(o.rotated_psf())) is None
+
+
+def test_axis_norm_and_prefix_table_match_oracle_norm():
+    from shrimpy_amd.deconvolve import _axis_norm, _prefix_table
+
+    psf, (kz, ky, kx) = o.gaussian_psf((5, 3, 7), (1.0, 0.8, 1.5))
+    shape = (6, 9, 11)
+    ref = o.rl_norm(shape, psf)
+    sep = (_axis_norm(kz, shape[0])[:, None, None] * _axis_norm(ky, shape[1])[None, :, None]
+           * _axis_norm(kx, shape[2])[None, None, :])
+    np.testing.assert_allclose(sep, ref, rtol=1e-6)
+    t = _prefix_table(psf)
+    assert t.shape == (6, 4, 8) and t[0].max() == 0 and abs(t[-1, -1, -1] - psf.sum(dtype=np.float64)) < 1e-12
+    # volume narrower than the PSF along z: both borders clip at once
+    thin = o.rl_norm((3, 9, 11), psf)
+    sep = (_axis_norm(kz, 3)[:, None, None] * _axis_norm(ky, 9)[None, :, None]
+           * _axis_norm(kx, 11)[None, None, :])
+    np.testing.assert_allclose(sep, thin, rtol=1e-6)
+
+
+def test_prepare_psf_pads_even_axes_and_bounds_size():
+    from shrimpy_amd.deconvolve import prepare_psf
+
+    assert prepare_psf(np.ones((2, 4, 3), np.float32)).shape == (3, 5, 3)
+    with pytest.raises(ValueError):
+        prepare_psf(np.ones((17, 3, 3), np.float32))
+    with pytest.raises(ValueError):
+        prepare_psf(np.ones((3, 3), np.float32))

@@ -1,0 +1,158 @@
+"""CPU tests of the oracle itself: frozen golden vectors, known answers, reference-captured fixtures.
+
+Nothing here touches the GPU or the HIP library.  The oracle (``oracle/cpu_ref.py``) is test
+infrastructure; these tests are what it is pinned by (parity with the reference's own arithmetic
+is UNPINNED: the reference holds no golden vector for this path, see the oracle header).
+"""
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as o
+
+DESKEW_CASES = ["deskew_nooverhang_avg3", "deskew_overhang_avg1", "deskew_nooverhang_avg5_r0p4"]
+
+
+@pytest.mark.parametrize("name", DESKEW_CASES)
+def test_deskew_matches_frozen_golden(golden_dir, name):
+    g = np.load(golden_dir / f"{name}.npz")
+    out = o.deskew(g["raw"], float(g["ls_angle_deg"]), float(g["px_to_scan_ratio"]),
+                   bool(g["keep_overhang"]), int(g["average_n_slices"]))
+    assert out.dtype == np.float32
+    np.testing.assert_array_equal(out, g["out"])
+
+
+def test_affine_matches_frozen_golden(golden_dir):
+    g = np.load(golden_dir / "affine_rot2deg.npz")
+    np.testing.assert_array_equal(o.affine_apply_4x4(g["vol"], g["matrix"], g["vol"].shape), g["out_constant"])
+    out_g = o.affine_apply_4x4(g["vol"], g["matrix"], tuple(g["grid_shape"]), cval=float(g["grid_cval"]),
+                               mode="grid-constant")
+    np.testing.assert_array_equal(out_g, g["out_grid"])
+
+
+def test_rl_matches_frozen_golden(golden_dir):
+    g = np.load(golden_dir / "rl_5iter.npz")
+    np.testing.assert_array_equal(o.richardson_lucy(g["y"], g["psf_sep"], 5), g["x_sep_5"])
+    np.testing.assert_array_equal(o.richardson_lucy(g["y"], g["psf_rot"], 5), g["x_rot_5"])
+
+
+def test_flatfield_matches_reference_capture(golden_dir):
+    """The neighbour step: oracle == what the reference's own ``_flat_field_BF`` produced
+    (captured by ``oracle/make_golden.py`` importing ``/root/reference/shrimpy/preprocessing.py``)."""
+    g = np.load(golden_dir / "ref_preprocessing.npz")
+    np.testing.assert_allclose(o.flat_field_bf(g["flatfield_in"]), g["flatfield_out"], rtol=2e-6)
+    np.testing.assert_allclose(o.flat_field_bf(g["flatfield_in_odd"]), g["flatfield_out_odd"], rtol=2e-6)
+
+
+# ---------------------------------------------------------------- known answers
+
+
+def test_deskew_shape_rule_known_values():
+    # config-2 mapping (2048, 512, 2048), 30 deg, r=0.755, avg 3
+    shape, voxel = o.deskewed_shape((2048, 512, 2048), 30.0, 0.755, False, 3, 0.1133)
+    assert shape == (171, 2048, 2270)
+    assert voxel == pytest.approx((3 * 0.5 * 0.1133, 0.1133, 0.1133))
+    shape_k, _ = o.deskewed_shape((2048, 512, 2048), 30.0, 0.755, True, 1)
+    assert shape_k == (512, 2048, int(np.ceil(2048 / 0.755 + 512 * np.cos(np.pi / 6))))
+
+
+def test_deskew_reproduces_a_linear_field_exactly_inside():
+    """Order-1 interpolation is exact on a field linear in z: the deskew of raw[z,y,x] = z is the
+    z-coordinate map itself wherever the sample is in range."""
+    Z, Y, X = 40, 10, 6
+    raw = np.broadcast_to(np.arange(Z, dtype=np.float32)[:, None, None], (Z, Y, X)).copy()
+    m, off, shape = o.deskew_geometry(raw.shape, 30.0, 0.755, True)
+    out = o.affine_apply(raw, m, off, shape)
+    zp, _, xp = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+    z_in = m[0, 0] * zp + m[0, 2] * xp + off[0]
+    inside = (z_in >= 0) & (z_in <= Z - 1)
+    np.testing.assert_allclose(out[inside], z_in[inside], rtol=0, atol=1e-4)
+    assert np.all(out[~inside] == 0)
+
+
+def test_deskew_chunks_along_raw_x_concatenate_reversed():
+    """``scripts/measure_psf.py:221,249``: deskew is independent along raw X and chunks are
+    concatenated in REVERSE order on output axis -2."""
+    rng = np.random.default_rng(5)
+    raw = rng.random((40, 12, 16)).astype(np.float32)
+    whole = o.deskew(raw, 30.0, 0.755, True, 3)
+    chunks = [o.deskew(c, 30.0, 0.755, True, 3) for c in np.split(raw, 4, axis=-1)]
+    np.testing.assert_array_equal(np.concatenate(chunks[::-1], axis=-2), whole)
+
+
+def test_average_slices_edge_padding():
+    d = np.arange(5 * 2 * 2, dtype=np.float32).reshape(5, 2, 2)
+    a = o.average_slices(d, 3)
+    assert a.shape == (2, 2, 2)
+    np.testing.assert_array_equal(a[0], (d[0] + d[1] + d[2]) / np.float32(3))
+    np.testing.assert_array_equal(a[1], (d[3] + d[4] + d[4]) / np.float32(3))  # edge pad
+
+
+def test_affine_identity_and_integer_shift():
+    rng = np.random.default_rng(7)
+    v = rng.random((6, 7, 8)).astype(np.float32)
+    np.testing.assert_array_equal(o.affine_apply(v, np.eye(3), np.zeros(3), v.shape), v)
+    sh = o.affine_apply(v, np.eye(3), np.array([1.0, 0.0, -2.0]), v.shape)
+    np.testing.assert_array_equal(sh[:-1, :, 2:], v[1:, :, :-2])
+    assert np.all(sh[-1] == 0) and np.all(sh[:, :, :2] == 0)
+
+
+def test_constant_mode_has_no_border_blending():
+    """with mode="constant" a coordinate at -1e-9 is OUT, n-1 exactly is IN."""
+    v = np.ones((4, 4, 4), dtype=np.float32)
+    out = o.affine_apply(v, np.eye(3), np.array([-1e-9, 0.0, 0.0]), v.shape)
+    assert np.all(out[0] == 0) and np.all(out[1:] == 1)
+    out = o.affine_apply(v, np.eye(3), np.array([0.0, 0.0, 0.0]), (4, 4, 4))
+    assert np.all(out == 1)  # index n-1 exactly is inside
+
+
+def test_rl_delta_psf_is_identity():
+    rng = np.random.default_rng(9)
+    y = (rng.random((6, 8, 10)) * 100 + 1).astype(np.float32)
+    psf = np.zeros((3, 3, 3), np.float32)
+    psf[1, 1, 1] = 1
+    x = o.richardson_lucy(y, psf, 3)
+    np.testing.assert_allclose(x, y, rtol=1e-5)
+
+
+def test_rl_direct_and_fft_agree():
+    psf, _ = o.gaussian_psf((5, 5, 5), (1.2, 1.0, 1.0))
+    y = o.bead_scene((12, 24, 24), seed=11, psf=psf, density=2e-3)
+    a = o.richardson_lucy(y, psf, 5)
+    b = o.richardson_lucy(y, psf, 5, use_fft=True)
+    np.testing.assert_allclose(a, b, rtol=2e-3, atol=1e-2)
+
+
+def test_rl_tolerates_all_zero_volume():
+    """Autofocus-failed stacks are written as all-zero volumes
+    (``shrimpy/tests/test_mantis_integration.py:285-341``)."""
+    psf, _ = o.gaussian_psf((3, 3, 3), (1, 1, 1))
+    x = o.richardson_lucy(np.zeros((4, 6, 6), np.float32), psf, 4)
+    assert np.all(x == 0) and np.all(np.isfinite(x))
+
+
+def test_rl_increases_bead_contrast_and_stays_nonnegative():
+    psf, _ = o.gaussian_psf((9, 7, 7), (2.0, 1.2, 1.2))
+    y = o.bead_scene((20, 32, 32), seed=13, psf=psf, density=1e-3)
+    x = o.richardson_lucy(y, psf, 20)
+    assert x.min() >= 0
+    assert x.max() > 1.5 * y.max()
+    assert np.all(np.isfinite(x))
+
+
+def test_even_psf_axis_padding_is_equivalent():
+    from scipy import ndimage
+
+    rng = np.random.default_rng(15)
+    v = rng.random((6, 9, 9)).astype(np.float32)
+    w = rng.random((2, 4, 3)).astype(np.float32)
+    np.testing.assert_allclose(
+        ndimage.correlate(v, o._as_odd_psf(w), mode="constant"),
+        ndimage.correlate(v, w, mode="constant"), rtol=1e-6)
+
+
+def test_gaussian_psf_is_separable_and_normalised():
+    psf, (kz, ky, kx) = o.gaussian_psf()
+    assert psf.shape == (9, 7, 7)
+    assert abs(psf.sum(dtype=np.float64) - 1) < 1e-6
+    np.testing.assert_allclose(psf, kz[:, None, None] * ky[None, :, None] * kx[None, None, :], rtol=1e-6)
