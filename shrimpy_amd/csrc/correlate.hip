@@ -17,6 +17,7 @@
 // Dense PSFs take pz*py*px FMAs per voxel: fp32-VALU-bound beyond ~120 taps.  No MFMA.
 
 #include "common.hpp"
+#include "correlate_common.hpp"
 
 namespace {
 
@@ -29,25 +30,7 @@ constexpr int kARows = kTileY + kMaxTaps - 1;   // staged plane rows incl. halo
 constexpr int kAPitch = kTileX + kMaxTaps - 1 + 2;
 constexpr int kBPitch = kTileX;
 
-struct CorrArgs {
-  const float* in;
-  float* out;
-  const float* aux;
-  int64_t Z, Y, X;
-  const float* wz;  // separable factors (device)
-  const float* wy;
-  const float* wx;
-  const float* w;   // dense taps (device), C-order (pz, py, px)
-  int pz, py, px;
-  int epilogue;
-  float eps;
-  const float* nz;  // separable norm factors
-  const float* ny;
-  const float* nx;
-  const double* norm_table;  // dense: (pz+1)(py+1)(px+1) prefix sums
-  int64_t tiles_x, tiles_y;
-  int64_t z_chunk;  // output planes per workgroup along z
-};
+using lsr::CorrArgs;
 
 // H^T 1 for the dense form: sum of the taps whose sample lies inside the volume, from the
 // inclusive prefix-sum table P[a][b][c] = sum_{a'<a,b'<b,c'<c} w.
@@ -298,8 +281,11 @@ extern "C" int lsr_correlate_sep_f32(const float* in, float* out, const float* a
   p.nz = nz; p.ny = ny; p.nx = nx;
   p.tiles_x = lsr::ceil_div(X, kTileX);
   p.tiles_y = lsr::ceil_div(Y, kTileY);
-  p.z_chunk = pick_z_chunk(Z, p.tiles_x * p.tiles_y, pz);
-  return launch_correlate<true>(p, lsr::as_stream(stream));
+  int PZ = 0, PYX = 0;
+  LSR_REQUIRE(lsr::sep_fast_supported(pz, py, px, &PZ, &PYX), LSR_E_UNSUPPORTED,
+              "no separable specialisation for taps (%d,%d,%d)", pz, py, px);
+  p.z_chunk = pick_z_chunk(Z, p.tiles_x * p.tiles_y, PZ);
+  return lsr::launch_sep_fast(p, PZ, PYX, lsr::as_stream(stream));
 }
 
 extern "C" int lsr_correlate_dense_f32(const float* in, float* out, const float* aux, int64_t Z,
