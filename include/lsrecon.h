@@ -120,17 +120,50 @@ int lsr_correlate_dense_f32(const float* in, float* out, const float* aux, int64
                             float eps, const double* norm_table, lsr_stream_t stream);
 
 /*
- * Whole Richardson-Lucy loop: `iters` x { ratio = y/(H x + eps); x <- x * H^T ratio / H^T 1 }.
- * x is updated in place (caller initialises it, normally x = y); `ratio` is caller scratch of
- * the same size. Separable: k* = PSF factors along z, y, x (the kernel flips them for H).
- * Dense: psf = pz*py*px floats, psf_flipped = the same reversed on all three axes.
- * Launches 2*iters kernels on `stream`; capturable in a hipGraph (no sync, no allocation).
+ * The tuned (HBM-bound) separable kernel reads its input through a ZERO HALO instead of bounds
+ * checks: zero padding is real memory, every load is unconditional and 16-byte aligned.
+ *
+ * lsr_sep_padded_shape: for a (Y, X) plane and a pz x py x px PSF returns
+ *   shape[0] = rows and shape[1] = pitch (floats, multiple of 4) of the padded plane,
+ *   shape[2], shape[3] = row / column of the logical element (y=0, x=0) inside it.
+ * A padded volume is Z such planes, contiguous, base 128-byte aligned; everything outside the
+ * logical (Y, X) window must be zero (the kernels only ever write inside it, so zero it once).
+ * The logical origin sits at column 32 so that output runs start on 128-byte lines.
+ *
+ * lsr_correlate_sep_strided_f32: as lsr_correlate_sep_f32, with explicit strides (floats).
+ * `in`, `aux`, `out` point at the LOGICAL element (0,0,0) of their volume; `in` must live in a
+ * padded volume as above; `aux` / `out` may be dense (pitch X, plane Y*X) or padded.
  */
-int lsr_rl_sep_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X,
-                   const float* kz, const float* kz_flipped, int pz, const float* ky,
-                   const float* ky_flipped, int py, const float* kx, const float* kx_flipped,
-                   int px, const float* nz, const float* ny, const float* nx, int iters, float eps,
-                   lsr_stream_t stream);
+int lsr_sep_padded_shape(int64_t Y, int64_t X, int pz, int py, int px, int64_t shape[4]);
+
+int lsr_correlate_sep_strided_f32(const float* in, int64_t in_pitch, int64_t in_plane,
+                                  const float* aux, int64_t aux_pitch, int64_t aux_plane,
+                                  float* out, int64_t out_pitch, int64_t out_plane, int64_t Z,
+                                  int64_t Y, int64_t X, const float* wz, int pz, const float* wy,
+                                  int py, const float* wx, int px, int epilogue, float eps,
+                                  const float* nz, const float* ny, const float* nx,
+                                  lsr_stream_t stream);
+
+/*
+ * Whole Richardson-Lucy loop: `iters` x { ratio = y/(H x + eps); x <- x * H^T ratio / H^T 1 }.
+ * Launches 2*iters kernels on `stream`; capturable in a hipGraph (no sync, no allocation).
+ *
+ * Separable: k* = PSF factors along z, y, x, k*_flipped the same reversed (H = correlation with
+ * the flipped taps). `x_pad` and `ratio_pad` are padded volumes (lsr_sep_padded_shape) with zero
+ * halos: the caller writes the initial estimate (normally y) into the logical window of `x_pad`;
+ * `ratio_pad` is scratch. The final estimate is written to the dense (Z, Y, X) `x_out`, or left
+ * in `x_pad` if `x_out` is NULL. `y` points at its logical (0,0,0) with strides y_pitch / y_plane
+ * (dense: X and Y*X; a padded y keeps the ratio launch's reads on cache-line boundaries).
+ *
+ * Dense: psf = pz*py*px floats, psf_flipped = the same reversed on all three axes; x (dense) is
+ * updated in place (caller initialises it), `ratio` is dense scratch.
+ */
+int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, float* x_pad,
+                   float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X,
+                   const float* kz, const float* kz_flipped, int pz,
+                   const float* ky, const float* ky_flipped, int py, const float* kx,
+                   const float* kx_flipped, int px, const float* nz, const float* ny,
+                   const float* nx, int iters, float eps, lsr_stream_t stream);
 
 int lsr_rl_dense_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X,
                      const float* psf, const float* psf_flipped, int pz, int py, int px,

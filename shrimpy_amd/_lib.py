@@ -51,9 +51,14 @@ SIGNATURES: dict[str, list] = {
         _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _int, _int, _int, _int, _f32,
         ctypes.c_void_p, _stream,
     ],
+    "lsr_sep_padded_shape": [_i64, _i64, _int, _int, _int, ctypes.POINTER(ctypes.c_int64)],
+    "lsr_correlate_sep_strided_f32": [
+        _c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64,
+        _c_f32p, _int, _c_f32p, _int, _c_f32p, _int, _int, _f32, _c_f32p, _c_f32p, _c_f32p, _stream,
+    ],
     "lsr_rl_sep_f32": [
-        _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _c_f32p, _c_f32p, _int,
-        _c_f32p, _c_f32p, _int, _c_f32p, _c_f32p, _c_f32p, _int, _f32, _stream,
+        _c_f32p, _i64, _i64, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _c_f32p,
+        _c_f32p, _int, _c_f32p, _c_f32p, _int, _c_f32p, _c_f32p, _c_f32p, _int, _f32, _stream,
     ],
     "lsr_rl_dense_f32": [
         _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _int, _int,

@@ -263,6 +263,7 @@ extern "C" int lsr_correlate_sep_f32(const float* in, float* out, const float* a
                                      const float* wy, int py, const float* wx, int px,
                                      int epilogue, float eps, const float* nz, const float* ny,
                                      const float* nx, lsr_stream_t stream) {
+  // Dense volumes without a halo: the generic bounds-checked kernel (correct, not tuned).
   if (int rc = check_common(in, out, aux, Z, Y, X, pz, py, px, epilogue)) return rc;
   LSR_REQUIRE_PTR(wz);
   LSR_REQUIRE_PTR(wy);
@@ -281,11 +282,118 @@ extern "C" int lsr_correlate_sep_f32(const float* in, float* out, const float* a
   p.nz = nz; p.ny = ny; p.nx = nx;
   p.tiles_x = lsr::ceil_div(X, kTileX);
   p.tiles_y = lsr::ceil_div(Y, kTileY);
-  int PZ = 0, PYX = 0;
-  LSR_REQUIRE(lsr::sep_fast_supported(pz, py, px, &PZ, &PYX), LSR_E_UNSUPPORTED,
-              "no separable specialisation for taps (%d,%d,%d)", pz, py, px);
-  p.z_chunk = pick_z_chunk(Z, p.tiles_x * p.tiles_y, PZ);
-  return lsr::launch_sep_fast(p, PZ, PYX, lsr::as_stream(stream));
+  p.z_chunk = pick_z_chunk(Z, p.tiles_x * p.tiles_y, pz);
+  return launch_correlate<true>(p, lsr::as_stream(stream));
+}
+
+namespace {
+
+// compiled tap counts of the tuned kernel: 3,5,...,15 along z, square 3..15 in plane; smaller
+// PSFs are centred in the next size up (zero taps elsewhere)
+void sep_compiled_taps(int pz, int py, int px, int* PZ, int* PYX) {
+  *PZ = lsr::sep_round_taps(pz);
+  *PYX = lsr::sep_round_taps(py > px ? py : px);
+}
+
+int check_taps(int pz, int py, int px) {
+  LSR_REQUIRE(pz >= 1 && py >= 1 && px >= 1 && (pz & 1) && (py & 1) && (px & 1) &&
+                  pz <= kMaxTaps && py <= kMaxTaps && px <= kMaxTaps,
+              LSR_E_UNSUPPORTED, "PSF taps (%d,%d,%d) must be odd and <= %d per axis", pz, py, px,
+              kMaxTaps);
+  return LSR_OK;
+}
+
+}  // namespace
+
+extern "C" int lsr_sep_padded_shape(int64_t Y, int64_t X, int pz, int py, int px,
+                                    int64_t shape[4]) {
+  LSR_REQUIRE_PTR(shape);
+  LSR_REQUIRE(Y > 0 && X > 0, LSR_E_SHAPE, "plane (%lld,%lld) must be positive", (long long)Y,
+              (long long)X);
+  if (int rc = check_taps(pz, py, px)) return rc;
+  int PZ, PYX;
+  sep_compiled_taps(pz, py, px, &PZ, &PYX);
+  const int64_t tiles_y = lsr::ceil_div(Y, lsr::kSepTileY), tiles_x = lsr::ceil_div(X, lsr::kSepTileX);
+  shape[0] = tiles_y * lsr::kSepTileY + PYX - 1;                          // rows
+  // pitch: a multiple of 32 floats (128-B lines) covering the last tile's staged window
+  shape[1] = (lsr::kSepOriginCol - PYX / 2 + (tiles_x - 1) * lsr::kSepTileX +
+              lsr::sep_stage_cols(PYX) + 31) / 32 * 32;
+  shape[2] = PYX / 2;                                                     // row of logical y = 0
+  shape[3] = lsr::kSepOriginCol;                                          // col of logical x = 0
+  return LSR_OK;
+}
+
+extern "C" int lsr_correlate_sep_strided_f32(
+    const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch,
+    int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y,
+    int64_t X, const float* wz, int pz, const float* wy, int py, const float* wx, int px,
+    int epilogue, float eps, const float* nz, const float* ny, const float* nx,
+    lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(out);
+  LSR_REQUIRE_PTR(wz);
+  LSR_REQUIRE_PTR(wy);
+  LSR_REQUIRE_PTR(wx);
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
+              (long long)Z, (long long)Y, (long long)X);
+  if (int rc = check_taps(pz, py, px)) return rc;
+  LSR_REQUIRE(epilogue == LSR_EPI_NONE || epilogue == LSR_EPI_RATIO || epilogue == LSR_EPI_UPDATE,
+              LSR_E_ARG, "unknown epilogue %d", epilogue);
+  if (epilogue != LSR_EPI_NONE) LSR_REQUIRE_PTR(aux);
+  if (epilogue == LSR_EPI_UPDATE) {
+    LSR_REQUIRE_PTR(nz);
+    LSR_REQUIRE_PTR(ny);
+    LSR_REQUIRE_PTR(nx);
+  }
+  LSR_REQUIRE(in != out, LSR_E_ARG, "out must not alias in");
+  int PZ, PYX;
+  sep_compiled_taps(pz, py, px, &PZ, &PYX);
+  int64_t need[4];
+  lsr_sep_padded_shape(Y, X, pz, py, px, need);
+  LSR_REQUIRE(in_pitch >= need[1] && in_plane >= need[0] * in_pitch, LSR_E_SHAPE,
+              "in strides (%lld,%lld) are smaller than the padded shape (%lld rows x %lld) that "
+              "lsr_sep_padded_shape asks for",
+              (long long)in_pitch, (long long)in_plane, (long long)need[0], (long long)need[1]);
+  LSR_REQUIRE(in_pitch % 4 == 0 && in_plane % 4 == 0, LSR_E_ARG,
+              "pitch and plane stride of the padded input must be multiples of 4 floats");
+  const int64_t lim = int64_t(1) << 30;
+  LSR_REQUIRE(in_plane < lim && aux_plane < lim && out_plane < lim && Z < lim, LSR_E_UNSUPPORTED,
+              "plane strides exceed the kernel's 32-bit in-plane offsets");
+  LSR_REQUIRE(out_pitch >= X && (epilogue == LSR_EPI_NONE || aux_pitch >= X), LSR_E_SHAPE,
+              "aux/out pitch smaller than X");
+
+  lsr::SepArgs p{};
+  p.in = in; p.aux = aux; p.out = out;
+  p.in_plane = in_plane; p.aux_plane = aux_plane; p.out_plane = out_plane;
+  p.in_pitch = static_cast<int>(in_pitch);
+  p.aux_pitch = static_cast<int>(aux_pitch);
+  p.out_pitch = static_cast<int>(out_pitch);
+  p.Z = static_cast<int>(Z); p.Y = static_cast<int>(Y); p.X = static_cast<int>(X);
+  p.wz = wz; p.wy = wy; p.wx = wx;
+  p.pz = pz; p.py = py; p.px = px;
+  p.epilogue = epilogue; p.eps = eps;
+  p.nz = nz; p.ny = ny; p.nx = nx;
+  p.tiles_x = static_cast<int>(lsr::ceil_div(X, lsr::kSepTileX));
+  p.tiles_y = static_cast<int>(lsr::ceil_div(Y, lsr::kSepTileY));
+  p.z_chunk = static_cast<int>(pick_z_chunk(Z, int64_t(p.tiles_x) * p.tiles_y, PZ));
+  const int64_t blocks64 = int64_t(p.tiles_x) * p.tiles_y * lsr::ceil_div(Z, p.z_chunk);
+  LSR_REQUIRE(blocks64 < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
+              (long long)blocks64);
+  const unsigned blocks = static_cast<unsigned>(blocks64);
+  hipStream_t s = lsr::as_stream(stream);
+  bool ok = false;
+  switch (PZ) {
+    case 3: ok = lsr::launch_sep_pz3(PYX, p, blocks, s); break;
+    case 5: ok = lsr::launch_sep_pz5(PYX, p, blocks, s); break;
+    case 7: ok = lsr::launch_sep_pz7(PYX, p, blocks, s); break;
+    case 9: ok = lsr::launch_sep_pz9(PYX, p, blocks, s); break;
+    case 11: ok = lsr::launch_sep_pz11(PYX, p, blocks, s); break;
+    case 13: ok = lsr::launch_sep_pz13(PYX, p, blocks, s); break;
+    case 15: ok = lsr::launch_sep_pz15(PYX, p, blocks, s); break;
+    default: break;
+  }
+  LSR_REQUIRE(ok, LSR_E_UNSUPPORTED, "no separable specialisation for taps (%d,%d,%d)", pz, py, px);
+  return lsr::launch_status("lsr_correlate_sep_strided_f32");
 }
 
 extern "C" int lsr_correlate_dense_f32(const float* in, float* out, const float* aux, int64_t Z,
@@ -308,25 +416,36 @@ extern "C" int lsr_correlate_dense_f32(const float* in, float* out, const float*
   return launch_correlate<false>(p, lsr::as_stream(stream));
 }
 
-extern "C" int lsr_rl_sep_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y,
-                              int64_t X, const float* kz, const float* kz_flipped, int pz,
-                              const float* ky, const float* ky_flipped, int py, const float* kx,
+extern "C" int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, float* x_pad,
+                              float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X,
+                              const float* kz,
+                              const float* kz_flipped, int pz, const float* ky,
+                              const float* ky_flipped, int py, const float* kx,
                               const float* kx_flipped, int px, const float* nz, const float* ny,
                               const float* nx, int iters, float eps, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(y);
-  LSR_REQUIRE_PTR(x);
-  LSR_REQUIRE_PTR(ratio);
-  LSR_REQUIRE(iters >= 0, LSR_E_ARG, "iters %d must be >= 0", iters);
-  LSR_REQUIRE(ratio != x && ratio != y && x != y, LSR_E_ARG, "y, x and ratio must be distinct");
+  LSR_REQUIRE_PTR(x_pad);
+  LSR_REQUIRE_PTR(ratio_pad);
+  LSR_REQUIRE(iters >= 1, LSR_E_ARG, "iters %d must be >= 1", iters);
+  LSR_REQUIRE(ratio_pad != x_pad, LSR_E_ARG, "x_pad and ratio_pad must be distinct");
+  int64_t ps[4];
+  if (int rc = lsr_sep_padded_shape(Y, X, pz, py, px, ps)) return rc;
+  const int64_t pitch = ps[1], plane = ps[0] * ps[1];
+  const int64_t origin = ps[2] * pitch + ps[3];
+  float* xl = x_pad + origin;        // logical (0,0,0) inside the padded volumes
+  float* rl = ratio_pad + origin;
   for (int it = 0; it < iters; ++it) {
-    // H x = convolve(x, psf) = correlate(x, flipped psf)
-    int rc = lsr_correlate_sep_f32(x, ratio, y, Z, Y, X, kz_flipped, pz, ky_flipped, py,
-                                   kx_flipped, px, LSR_EPI_RATIO, eps, nullptr, nullptr, nullptr,
-                                   stream);
+    // ratio = y / (H x + eps);  H x = convolve(x, psf) = correlate(x, flipped psf)
+    int rc = lsr_correlate_sep_strided_f32(xl, pitch, plane, y, y_pitch, y_plane, rl, pitch, plane, Z, Y, X,
+                                           kz_flipped, pz, ky_flipped, py, kx_flipped, px,
+                                           LSR_EPI_RATIO, eps, nullptr, nullptr, nullptr, stream);
     if (rc) return rc;
-    // H^T r = correlate(r, psf)
-    rc = lsr_correlate_sep_f32(ratio, x, x, Z, Y, X, kz, pz, ky, py, kx, px, LSR_EPI_UPDATE, eps,
-                               nz, ny, nx, stream);
+    // x <- x * H^T ratio / H^T 1;  H^T r = correlate(r, psf).  The last update may go straight
+    // to the dense result.
+    const bool last = it + 1 == iters && x_out != nullptr;
+    rc = lsr_correlate_sep_strided_f32(rl, pitch, plane, xl, pitch, plane, last ? x_out : xl,
+                                       last ? X : pitch, last ? Y * X : plane, Z, Y, X, kz, pz, ky,
+                                       py, kx, px, LSR_EPI_UPDATE, eps, nz, ny, nx, stream);
     if (rc) return rc;
   }
   return LSR_OK;

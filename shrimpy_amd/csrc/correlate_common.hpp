@@ -1,10 +1,11 @@
-// Argument block shared by the correlation kernels (correlate.hip, correlate_sep.hip).
+// Argument blocks shared by the correlation kernels (correlate.hip, correlate_sep.hip).
 #pragma once
 
 #include "common.hpp"
 
 namespace lsr {
 
+// Generic kernels (dense volumes, zero padding evaluated with bounds checks).
 struct CorrArgs {
   const float* in;
   float* out;
@@ -25,8 +26,53 @@ struct CorrArgs {
   int64_t z_chunk;  // output planes per workgroup along z
 };
 
-// correlate_sep.hip: compile-time-tap specialisations of the separable kernel.
-bool sep_fast_supported(int pz, int py, int px, int* PZ, int* PYX);
-int launch_sep_fast(const CorrArgs& p, int PZ, int PYX, hipStream_t s);
+// Tuned separable kernel: every volume is strided, `in` additionally carries a zero halo so that
+// no load needs a bounds check.  Pointers address the LOGICAL element (0,0,0).
+struct SepArgs {
+  const float* in;
+  const float* aux;
+  float* out;
+  int64_t in_plane, aux_plane, out_plane;  // z strides (floats)
+  int in_pitch, aux_pitch, out_pitch;      // y strides (floats)
+  int Z, Y, X;
+  const float* wz;
+  const float* wy;
+  const float* wx;
+  int pz, py, px;
+  int epilogue;
+  float eps;
+  const float* nz;
+  const float* ny;
+  const float* nx;
+  int tiles_x, tiles_y;
+  int z_chunk;
+};
+
+// Tile geometry of the tuned kernel, needed by the host to size the halo (see lsr_sep_halo).
+constexpr int kSepTileY = 32;
+constexpr int kSepTileX = 64;
+// Column of logical x = 0 inside a padded row: a whole 128-byte line, so that every tile's 64-wide
+// output run (and its `aux` run, when that volume is padded too) starts on a cache line.  Measured:
+// RL launch 2.93 ms -> 2.18 ms against an origin at column PX/2 (line-straddling stores).
+constexpr int kSepOriginCol = 32;
+inline int sep_round_taps(int n) { return n < 3 ? 3 : n; }  // compiled: 3, 5, ..., 15
+// floats staged per row: 64 + PX - 1 rounded up to a multiple of 4, and at least 4*15 + 12
+inline int sep_stage_cols(int PX) {
+  int c = (kSepTileX + PX - 1 + 3) / 4 * 4;
+  return c < 72 ? 72 : c;
+}
+
+// correlate_sep.hip, compiled once per PZ (-DLSR_SEP_PZ=n).  `pyx` is the (square) in-plane tap
+// count; false = no such specialisation.
+#define LSR_DECL_SEP(n) \
+  bool launch_sep_pz##n(int pyx, const SepArgs& p, unsigned blocks, hipStream_t s);
+LSR_DECL_SEP(3)
+LSR_DECL_SEP(5)
+LSR_DECL_SEP(7)
+LSR_DECL_SEP(9)
+LSR_DECL_SEP(11)
+LSR_DECL_SEP(13)
+LSR_DECL_SEP(15)
+#undef LSR_DECL_SEP
 
 }  // namespace lsr

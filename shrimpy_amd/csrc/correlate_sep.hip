@@ -1,74 +1,137 @@
 // Separable (rank-1) 3-D PSF correlation with fused Richardson-Lucy epilogues -- the HBM-bound
-// headline kernel.  See correlate.hip for the streaming idea; this file is the tuned form with
-// compile-time tap counts.
+// headline kernel.  Compile-time tap counts; one translation unit per PZ (-DLSR_SEP_PZ=n).
 //
-// Work decomposition (256 threads = 4 waves, tile 32 (y) x 64 (x), marching along z):
-//   per input plane
-//     stage   : the plane's (32+PY-1) x (64+PX-1) window, HBM -> registers -> LDS `A`.  The
-//               registers are loaded one plane AHEAD (issued right after the barrier, consumed
-//               at the top of the next iteration), so HBM latency hides behind a whole plane of
-//               compute.  Rows are 256-B coalesced; the PX-1 halo columns go in one extra load.
-//     x pass  : A -> B, 4 outputs per thread from a (4+PX-1)-float register window read with
-//               ds_read_b64 (A pitch = 2 mod 4 floats: conflict-free at 16-B lane stride).
-//     y pass  : B -> registers, 8 outputs per thread down one column (conflict-free ds_read_b32,
-//               8+PY-1 reads for 8 outputs).
-//     z       : PZ pending output planes per point live in registers; one FMA per pending plane
-//               both shifts the window and adds this plane's contribution.
-//     epilogue: the completed plane: ratio = y * rcp(c + eps)   or   x * c * rcp(H^T 1).
-//               `aux` is loaded at the top of the iteration, BEFORE the prefetch, so waiting for
-//               it leaves the prefetch in flight (vmcnt counts in order).
-//   two workgroup barriers per plane; LDS 20 KB per workgroup.
+// The input volume carries a ZERO HALO (lsr_sep_padded_shape): zero padding of the correlation is
+// real memory, so every load in this kernel is unconditional, in bounds and 16-byte aligned.
 //
-// Algorithmic HBM bytes: 12 per voxel per launch.  Real traffic adds the in-plane halo
-// ((38*70)/(32*64) = 1.30x on the `in` stream only, mostly L2/MALL hits thanks to the XCD-aware
-// tile order) and PZ-1 planes per z-chunk.
+// A 512-thread workgroup (8 waves) owns a 32 (y) x 64 (x) column and marches along z, one
+// workgroup barrier per plane.  Iteration zi:
+//   commit   : plane zi+2, fetched two iterations ago into registers, -> LDS A[zi&1] (a linear
+//              16-B-per-thread copy of the (32+PY-1) x 72 window).
+//   prefetch : plane zi+4 -> the registers just freed (global_load_dwordx4, 288-B row runs), and
+//              the `aux` values of the NEXT iteration's output plane.  Two planes per workgroup
+//              are always in flight; nothing waits on them inside this iteration.
+//   x pass   : plane zi+1, A[(zi+1)&1] -> B[(zi+1)&1].  A thread owns (row, 4 consecutive x); its
+//              4+PX-1 inputs come from 3..5 ds_read_b128.  Lanes are assigned to items by the
+//              HARDWARE's b128 lane groups, so each group reads one contiguous 256-B row run:
+//              conflict-free for any pitch.  B's pitch (80) keeps the b128 writes conflict-free.
+//   y pass   : plane zi from B[zi&1]; thread = one column x 4 rows (4+PY-1 ds_read_b32).
+//   z        : PZ pending output planes per point in registers; one FMA per pending plane both
+//              shifts the window and absorbs this plane.
+//   epilogue : completed plane zi-PZ/2: ratio = y*rcp(c+eps) or x*c*rcp(H^T 1), strided store.
+//
+// THE MEMORY PIPELINE IS MANAGED BY HAND.  With loads and stores pending on the same counter,
+// hipcc (ROCm 7.2) treats vmcnt as out of order and turns every wait for a load into vmcnt(0) --
+// a full drain, store acknowledgements included, once per plane (measured in round 1: it capped
+// the kernel at 47 % of the HBM peak).  So the loads are inline asm (invisible to the compiler's
+// wait insertion), each consumer is preceded by a hand-counted `s_waitcnt vmcnt(N)` tied to the
+// destination registers, and the barrier is a raw s_barrier.  vmcnt retires in issue order on
+// gfx950 (loads and stores alike), so N = the number of LOADS issued after the wanted one is a
+// safe bound: younger stores only make the wait return a little later, never too early.
+//
+// Algorithmic HBM bytes: 12 per voxel per launch (in + aux + out).  Real traffic adds the in-plane
+// halo of `in` ((32+PY-1)*72/(32*64) = 1.34x for 7x7), largely L2 hits thanks to the XCD-aware
+// tile order, and PZ-1 planes per z-chunk.
 
 #include "common.hpp"
 #include "correlate_common.hpp"
 
+#ifndef LSR_SEP_PZ
+#error "compile with -DLSR_SEP_PZ=<odd tap count along z>"
+#endif
+
 namespace {
 
-using lsr::CorrArgs;
+using lsr::SepArgs;
 
-constexpr int kThreads = 256;
-constexpr int kTY = 32;
-constexpr int kTX = 64;
-constexpr int kRun = 8;  // consecutive y per thread in the y/z passes
+constexpr int kTY = lsr::kSepTileY;      // 32
+constexpr int kTX = lsr::kSepTileX;      // 64
+constexpr int kRun = 4;                  // consecutive y per thread in the y / z passes
+constexpr int kWaves = kTY / kRun;       // 8
+constexpr int kThreads = 64 * kWaves;    // 512
 
 template <int PY, int PX>
 struct Tile {
-  static constexpr int AR = kTY + PY - 1;                      // staged rows
-  static constexpr int AC = kTX + PX - 1;                      // staged cols (even: PX odd)
-  static constexpr int PA = (AC % 4 == 2) ? AC : AC + 2;       // pitch = 2 (mod 4) floats
-  static constexpr int PB = kTX;
-  static constexpr int TAIL = PX - 1;                          // halo columns beyond 64 (>= 2)
-  static constexpr int TAIL_LOADS = (AR * TAIL + kThreads - 1) / kThreads;
-  static constexpr int MAIN_LOADS = (AR + 3) / 4;              // rows per wave
-  static constexpr int XITEMS = AR * (kTX / 4);                // (row, 4-wide x group) items
-  static constexpr int XITERS = (XITEMS + kThreads - 1) / kThreads;
-  static constexpr int WIN = 4 + PX - 1;                       // x-pass register window (even)
+  static constexpr int AR = kTY + PY - 1;                        // input rows of a tile
+  static constexpr int AC = kTX + PX - 1;                        // input cols of a tile
+  static constexpr int PA0 = (AC + 3) / 4 * 4;
+  static constexpr int PA = PA0 < 72 ? 72 : PA0;                 // staged cols == LDS pitch of A
+  static constexpr int CH = PA / 4;                              // 16-B chunks per staged row
+  static constexpr int NCH = AR * CH;                            // chunks per plane
+  static constexpr int SL = (NCH + kThreads - 1) / kThreads;     // chunks per thread
+  static constexpr int WIN = 4 + PX - 1;                         // inputs of an x-pass item
+  static constexpr int NPIECE = (WIN + 3) / 4;                   // ds_read_b128 per item
+  static constexpr int PB = 80;                                  // LDS pitch of B (16 mod 32)
+  static constexpr int ASZ = AR * PA;
+  static constexpr int BSZ = AR * PB;
+  static_assert(4 * 15 + 4 * NPIECE <= PA, "x-pass reads stay inside a staged row");
+  static_assert(AR <= 2 * kTY, "at most two x-pass items per thread");
+  static_assert(SL == 2, "the hand-counted waits assume two staging loads per thread");
 };
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native 16-byte vector (one VGPR quad)
+
 __device__ __forceinline__ float fast_rcp(float d) {
-  // v_rcp_f32 (1 ulp) + one Newton step
-  float r = __builtin_amdgcn_rcpf(d);
-  return fmaf(fmaf(-d, r, 1.0f), r, r);
+  float r = __builtin_amdgcn_rcpf(d);    // v_rcp_f32, 1 ulp
+  return fmaf(fmaf(-d, r, 1.0f), r, r);  // + one Newton step
 }
 
-template <int PZ, int PY, int PX>
-__global__ __launch_bounds__(kThreads) void correlate_sep_kernel(CorrArgs p) {
+// ---- hand-managed global loads: scalar base + unsigned 32-bit byte offset per lane -------------
+__device__ __forceinline__ void gload_x4(f32x4& dst, const float* sbase, int voff_bytes) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void gload_x1(float& dst, const float* sbase, int voff_bytes) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+}
+// Wait until at most N vector-memory operations are outstanding; the registers are passed
+// through so that every later use depends on this statement.
+template <int N>
+__device__ __forceinline__ void wait_loads(f32x4& a, f32x4& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_loads(float (&a)[kRun], float& b) {
+  asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes have landed
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// ds_read_b128 is serviced in four fixed 16-lane groups: {0-3,12-15,20-27}, {4-11,16-19,28-31} and
+// the same +32 (MI355X_MICROARCH.md, LDS).  Returns the group (0..3) and the rank inside it (0..15).
+__device__ __forceinline__ void b128_lane_group(int lane, int& group, int& rank) {
+  const int m = lane & 31;
+  int gs, r;
+  if (m < 4) { gs = 0; r = m; }
+  else if (m < 12) { gs = 1; r = m - 4; }
+  else if (m < 16) { gs = 0; r = m - 8; }
+  else if (m < 20) { gs = 1; r = m - 8; }
+  else if (m < 28) { gs = 0; r = m - 12; }
+  else { gs = 1; r = m - 16; }
+  group = 2 * (lane >> 5) + gs;
+  rank = r;
+}
+
+template <int PZ, int PY, int PX, int EPI>
+__global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
   using T = Tile<PY, PX>;
-  __shared__ __attribute__((aligned(16))) float bufA[T::AR * T::PA];
-  __shared__ __attribute__((aligned(16))) float bufB[T::AR * T::PB];
+  // LDS is addressed in 16-byte units wherever b128 accesses are wanted, so their alignment is
+  // part of the type (hipcc otherwise splits them into ds_read2_b32 / ds_read2_b64)
+  __shared__ f32x4 bufA4[2 * T::ASZ / 4];
+  __shared__ f32x4 bufB4[2 * T::BSZ / 4];
+  float* const bufB = reinterpret_cast<float*>(bufB4);
+
+  // loads per iteration besides the two staging loads: aux rows (+ nz for the update)
+  constexpr int NA = EPI == LSR_EPI_NONE ? 0 : (EPI == LSR_EPI_UPDATE ? kRun + 1 : kRun);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  // wave index as a SCALAR: everything derived from it (row predicates, row base pointers)
-  // then lives in SGPRs / SALU instead of per-lane VGPRs
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar
 
-  // ---- XCD-aware tile order: workgroups b, b+8, ... share an XCD (round-robin dispatch), so
-  // give each XCD a contiguous run of tiles: x-neighbours then share halo columns in one L2.
+  // XCD-aware tile order: workgroups b, b+8, ... share an XCD (round-robin dispatch), so give
+  // each XCD a contiguous run of tiles: x-neighbours then share their halo columns in one L2.
   int bid = blockIdx.x;
   {
     const int nblk = gridDim.x;
@@ -76,98 +139,73 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(CorrArgs p) {
     const int xcd = bid % 8, idx = bid / 8;
     bid = xcd * per + (xcd < rem ? xcd : rem) + idx;  // XCD k owns per + (k < rem) tiles
   }
-  const int tiles_x = static_cast<int>(p.tiles_x), tiles_y = static_cast<int>(p.tiles_y);
-  const int tx = bid % tiles_x;
-  const int ty = (bid / tiles_x) % tiles_y;
-  const int zc = bid / (tiles_x * tiles_y);
+  const int tx = bid % p.tiles_x;
+  const int ty = (bid / p.tiles_x) % p.tiles_y;
+  const int zc = bid / (p.tiles_x * p.tiles_y);
 
-  const int Z = static_cast<int>(p.Z), Y = static_cast<int>(p.Y), X = static_cast<int>(p.X);
-  const int x0 = tx * kTX;
-  const int y0 = ty * kTY;
-  const int zb = zc * static_cast<int>(p.z_chunk);
-  const int ze = min(zb + static_cast<int>(p.z_chunk), Z);
+  const int Z = p.Z, Y = p.Y, X = p.X;
+  const int x0 = tx * kTX, y0 = ty * kTY;
+  const int zb = zc * p.z_chunk;
+  const int ze = min(zb + p.z_chunk, Z);
   constexpr int cz = PZ / 2, cy = PY / 2, cx = PX / 2;
-  const int64_t plane = static_cast<int64_t>(Y) * X;
 
-  // ---- taps: wave-uniform, kept in scalar registers
-  // (the caller's pz/py/px taps are centred inside the compiled PZ/PY/PX, zero elsewhere)
+  // taps: wave-uniform -> SGPRs.  The caller's pz/py/px taps sit centred in PZ/PY/PX.
   float wz[PZ], wy[PY], wx[PX];
-  const int oz = (PZ - p.pz) / 2, oy = (PY - p.py) / 2, ox = (PX - p.px) / 2;
+  {
+    const int oz = (PZ - p.pz) / 2, oy = (PY - p.py) / 2, ox = (PX - p.px) / 2;
 #pragma unroll
-  for (int i = 0; i < PZ; ++i) wz[i] = (i >= oz && i < oz + p.pz) ? p.wz[i - oz] : 0.0f;
+    for (int i = 0; i < PZ; ++i) wz[i] = (i >= oz && i < oz + p.pz) ? p.wz[i - oz] : 0.0f;
 #pragma unroll
-  for (int i = 0; i < PY; ++i) wy[i] = (i >= oy && i < oy + p.py) ? p.wy[i - oy] : 0.0f;
+    for (int i = 0; i < PY; ++i) wy[i] = (i >= oy && i < oy + p.py) ? p.wy[i - oy] : 0.0f;
 #pragma unroll
-  for (int i = 0; i < PX; ++i) wx[i] = (i >= ox && i < ox + p.px) ? p.wx[i - ox] : 0.0f;
-
-  // ---- staging geometry (constant over z).  Main part: wave w stages rows w, w+4, ...; lane =
-  // column.  Tail: the PX-1 columns beyond 64, one element per thread.
-  const int row0 = y0 - cy;  // global y of staged row 0
-  const int gx_main = x0 - cx + lane;
-  const bool xok_main = gx_main >= 0 && gx_main < X;
-  const int voff_main = xok_main ? gx_main : 0;  // per-lane part of the address (floats)
-  // tail element e = tid + 256*t -> (row e / TAIL, column 64 + e % TAIL)
-  int voff_tail[T::TAIL_LOADS];
-  int lds_tail[T::TAIL_LOADS];  // < 0: not this thread's element
-#pragma unroll
-  for (int t = 0; t < T::TAIL_LOADS; ++t) {
-    const int e = tid + t * kThreads;
-    const int r = e / T::TAIL, c = kTX + e % T::TAIL;
-    const int gy = row0 + r, gx = x0 - cx + c;
-    const bool mine = r < T::AR;
-    const bool ok = mine && gy >= 0 && gy < Y && gx >= 0 && gx < X;
-    lds_tail[t] = mine ? r * T::PA + c : -1;
-    voff_tail[t] = ok ? gy * X + gx : -1;
+    for (int i = 0; i < PX; ++i) wx[i] = (i >= ox && i < ox + p.px) ? p.wx[i - ox] : 0.0f;
   }
 
-  float stage[T::MAIN_LOADS];
-  float stage_tail[T::TAIL_LOADS];
+  // ---- staging: chunk e = tid + 512*k of the (AR x PA) window; the LDS image is linear in e.
+  // Threads past the last chunk re-fetch and re-write the last one (benign): nothing conditional.
+  // Global side: scalar base = the window's first element, per-lane byte offset >= 0.
+  const float* const in_tile = p.in + (static_cast<int64_t>(y0 - cy) * p.in_pitch + (x0 - cx));
+  int s_voff[T::SL];  // byte offset from in_tile (+ z * plane)
+  int s_loff[T::SL];  // 16-byte chunk index inside an A buffer
+#pragma unroll
+  for (int k = 0; k < T::SL; ++k) {
+    const int e = min(tid + k * kThreads, T::NCH - 1);
+    const int r = e / T::CH, c = e - r * T::CH;
+    s_voff[k] = (r * p.in_pitch + 4 * c) * 4;
+    s_loff[k] = e;
+  }
+  f32x4 st0[T::SL], st1[T::SL];  // plane q is staged in set q & 1
 
-  auto prefetch = [&](int zi) {
-    const float* src = p.in + zi * plane;
-#pragma unroll
-    for (int i = 0; i < T::MAIN_LOADS; ++i) {
-      const int r = wave + 4 * i;     // scalar
-      const int gy = row0 + r;        // scalar
-      float v = 0.0f;
-      if (r < T::AR && gy >= 0 && gy < Y) {            // wave-uniform branch
-        const float* rowp = src + static_cast<int64_t>(gy) * X;  // scalar base
-        if (xok_main) v = rowp[voff_main];
-      }
-      stage[i] = v;
-    }
-#pragma unroll
-    for (int t = 0; t < T::TAIL_LOADS; ++t)
-      stage_tail[t] = voff_tail[t] >= 0 ? src[voff_tail[t]] : 0.0f;
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int i = 0; i < T::MAIN_LOADS; ++i) {
-      const int r = wave + 4 * i;
-      if (r < T::AR) bufA[r * T::PA + lane] = stage[i];
-    }
-#pragma unroll
-    for (int t = 0; t < T::TAIL_LOADS; ++t)
-      if (lds_tail[t] >= 0) bufA[lds_tail[t]] = stage_tail[t];
-  };
+  // ---- x pass: lane -> (row group, x group) by hardware b128 lane group
+  int xg, xq;
+  b128_lane_group(lane, xg, xq);
+  const int xrow0 = 4 * wave + xg;                 // item 0: rows 0..31
+  const bool has1 = kTY + xrow0 < T::AR;           // item 1: rows 32.. (only some lanes)
+  const int xa = xrow0 * (T::PA / 4) + xq;         // 16-B units; + kTY*PA/4 for item 1
+  const int xb = xrow0 * (T::PB / 4) + xq;         // 16-B units; + kTY*PB/4 for item 1
 
-  // ---- output geometry: thread owns column `lane`, rows wave*8 .. wave*8+7 (row part scalar)
+  // ---- y / z pass and epilogue: thread owns column `lane`, rows 4*wave .. 4*wave+3
+  const int ycol = (wave * kRun) * T::PB + lane;
   const int gx_out = x0 + lane;
-  const bool xok_out = gx_out < X;
-  const int voff_out = xok_out ? gx_out : 0;
-  const int gy_out0 = y0 + wave * kRun;                     // scalar
-  const int nrows_out = min(max(Y - gy_out0, 0), kRun);     // scalar: valid rows of this wave
-  const int epi = p.epilogue;
-
-  // reciprocal of the in-plane part of H^T 1 for the UPDATE epilogue
-  float rnyx[kRun];
+  const bool xok = gx_out < X;
+  const int gxc = min(gx_out, X - 1);              // clamped: aux loads are always in bounds
+  const int gy_out0 = y0 + wave * kRun;            // scalar
+  int a_voff[kRun], o_off[kRun];
+  bool ok[kRun];
+#pragma unroll
+  for (int m = 0; m < kRun; ++m) {
+    const int gy = gy_out0 + m;
+    ok[m] = xok && gy < Y;
+    a_voff[m] = (min(gy, Y - 1) * p.aux_pitch + gxc) * 4;
+    o_off[m] = min(gy, Y - 1) * p.out_pitch + gxc;
+  }
+  float rnyx[kRun];  // reciprocal of the in-plane part of H^T 1 (UPDATE epilogue)
 #pragma unroll
   for (int m = 0; m < kRun; ++m) rnyx[m] = 0.0f;
-  if (epi == LSR_EPI_UPDATE && xok_out) {
-    const float nxv = p.nx[gx_out];
+  if constexpr (EPI == LSR_EPI_UPDATE) {
+    const float nxv = p.nx[gxc];
 #pragma unroll
-    for (int m = 0; m < kRun; ++m)
-      if (m < nrows_out) rnyx[m] = fast_rcp(p.ny[gy_out0 + m] * nxv);
+    for (int m = 0; m < kRun; ++m) rnyx[m] = fast_rcp(p.ny[min(gy_out0 + m, Y - 1)] * nxv);
   }
 
   // pending output planes: acc[j][m] <-> z_out = zi - cz + j once plane zi is absorbed
@@ -176,141 +214,156 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(CorrArgs p) {
   for (int j = 0; j < PZ; ++j)
 #pragma unroll
     for (int m = 0; m < kRun; ++m) acc[j][m] = 0.0f;
-
-  // LDS offsets of this thread's first x-pass item and of its y-pass column
-  const int xitem_a = (tid >> 4) * T::PA + 4 * (tid & 15);
-  const int xitem_b = (tid >> 4) * T::PB + 4 * (tid & 15);
-  const int ycol = (wave * kRun) * T::PB + lane;
+  // aux (and nz) of output plane zi - cz live in set zi & 1, requested one iteration ahead
+  float aux0[kRun], aux1[kRun];
+#pragma unroll
+  for (int m = 0; m < kRun; ++m) aux0[m] = aux1[m] = 0.0f;
+  float nzv0 = 1.0f, nzv1 = 1.0f;
 
   const int zi_begin = max(zb - cz, 0);
   const int zi_end = ze + cz;  // exclusive; planes >= Z contribute zeros
-  if (zi_begin < Z) prefetch(zi_begin);
 
-  for (int zi = zi_begin; zi < zi_end; ++zi) {
-    const bool have_plane = zi < Z;
-    const int z_out = zi - cz;
-    const bool emit = z_out >= zb;
-
-    float pl[kRun];
+  auto fetch = [&](int zplane, f32x4 (&st)[T::SL]) {  // 2 loads
+    const float* src = in_tile + static_cast<int64_t>(min(max(zplane, 0), Z - 1)) * p.in_plane;
+    gload_x4(st[0], src, s_voff[0]);
+    gload_x4(st[1], src, s_voff[1]);
+  };
+  auto fetch_aux = [&](int zout, float (&aux)[kRun], float& nzv) {  // NA loads
+    if constexpr (EPI != LSR_EPI_NONE) {
+      const int zc_ = min(max(zout, 0), Z - 1);
+      const float* a = p.aux + static_cast<int64_t>(zc_) * p.aux_plane;
 #pragma unroll
-    for (int m = 0; m < kRun; ++m) pl[m] = 0.0f;
-    float aux[kRun];
-#pragma unroll
-    for (int m = 0; m < kRun; ++m) aux[m] = 0.0f;
-
-    if (have_plane) {
-      commit();          // plane zi: registers -> A (all waves left the x pass of zi-1: barrier 2)
-      __syncthreads();   // barrier 1: A complete; every wave is done with B of plane zi-1
+      for (int m = 0; m < kRun; ++m) gload_x1(aux[m], a, a_voff[m]);
+      if constexpr (EPI == LSR_EPI_UPDATE) gload_x1(nzv, p.nz + zc_, 0);
     }
-    // aux first, then the prefetch: waiting for aux later leaves the prefetch in flight
-    if (emit && epi != LSR_EPI_NONE && xok_out) {
-      const float* a = p.aux + z_out * plane + static_cast<int64_t>(gy_out0) * X;  // scalar
-#pragma unroll
-      for (int m = 0; m < kRun; ++m)
-        if (m < nrows_out) aux[m] = (a + m * X)[voff_out];
-    }
-    if (zi + 1 < Z && zi + 1 < zi_end) prefetch(zi + 1);
+  };
 
-    if (have_plane) {
-      // ---- x pass: item = (row, group of 4 x); 16 items per row, 4 rows per wave-instruction
-#pragma unroll 1
-      for (int it = 0; it < T::XITERS; ++it) {
-        if (tid + it * kThreads < T::XITEMS) {
-          const float2* src =
-              reinterpret_cast<const float2*>(bufA + xitem_a + it * (kThreads / 16) * T::PA);
-          float win[T::WIN];
+  // One iteration; `par` = zi & 1 is a literal at both call sites.
+  auto iteration = [&](const int zi, const int par, f32x4 (&st)[T::SL], float (&aux_use)[kRun],
+                       float& nz_use, float (&aux_load)[kRun], float& nz_load) {
+    f32x4* A_commit = bufA4 + par * (T::ASZ / 4);            // plane zi+2
+    const f32x4* A_x = bufA4 + (par ^ 1) * (T::ASZ / 4);     // plane zi+1
+    f32x4* B_x = bufB4 + (par ^ 1) * (T::BSZ / 4);           // plane zi+1
+    const float* B_y = bufB + par * T::BSZ;                  // plane zi
+
+    // commit plane zi+2.  Its loads were issued two iterations ago; issued since: aux (NA),
+    // the other staging set (2), aux (NA).
+    wait_loads<2 + 2 * NA>(st[0], st[1]);
+    A_commit[s_loff[0]] = st[0];
+    A_commit[s_loff[1]] = st[1];
+    __builtin_amdgcn_sched_barrier(0);  // the refill reuses these registers: keep it behind
+    fetch(zi + 4, st);
+    fetch_aux(zi + 1 - cz, aux_load, nz_load);
+
+    // x pass of plane zi+1
 #pragma unroll
-          for (int i = 0; i < T::WIN / 2; ++i) {
-            const float2 v = src[i];
-            win[2 * i] = v.x;
-            win[2 * i + 1] = v.y;
-          }
-          float4 o;
-          o.x = wx[0] * win[0];
-          o.y = wx[0] * win[1];
-          o.z = wx[0] * win[2];
-          o.w = wx[0] * win[3];
+    for (int it = 0; it < 2; ++it) {
+      if (it == 0 || has1) {
+        const f32x4* src = A_x + xa + it * (kTY * T::PA / 4);
+        float w[4 * T::NPIECE];
 #pragma unroll
-          for (int c = 1; c < PX; ++c) {
-            o.x = fmaf(wx[c], win[c], o.x);
-            o.y = fmaf(wx[c], win[c + 1], o.y);
-            o.z = fmaf(wx[c], win[c + 2], o.z);
-            o.w = fmaf(wx[c], win[c + 3], o.w);
-          }
-          *reinterpret_cast<float4*>(bufB + xitem_b + it * (kThreads / 16) * T::PB) = o;
+        for (int i = 0; i < T::NPIECE; ++i) {
+          const f32x4 v = src[i];
+          w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+        f32x4 o;
+        o.x = wx[0] * w[0];
+        o.y = wx[0] * w[1];
+        o.z = wx[0] * w[2];
+        o.w = wx[0] * w[3];
+#pragma unroll
+        for (int c = 1; c < PX; ++c) {
+          o.x = fmaf(wx[c], w[c], o.x);
+          o.y = fmaf(wx[c], w[c + 1], o.y);
+          o.z = fmaf(wx[c], w[c + 2], o.z);
+          o.w = fmaf(wx[c], w[c + 3], o.w);
+        }
+        B_x[xb + it * (kTY * T::PB / 4)] = o;
+      }
+    }
+
+    if (zi >= zi_begin && zi < zi_end) {  // wave-uniform
+      float pl[kRun];
+#pragma unroll
+      for (int m = 0; m < kRun; ++m) pl[m] = 0.0f;
+      if (zi < Z) {
+        const float* col = B_y + ycol;
+        float cv[kRun + PY - 1];
+#pragma unroll
+        for (int j = 0; j < kRun + PY - 1; ++j) cv[j] = col[j * T::PB];
+#pragma unroll
+        for (int m = 0; m < kRun; ++m) {
+          float s = wy[0] * cv[m];
+#pragma unroll
+          for (int b = 1; b < PY; ++b) s = fmaf(wy[b], cv[m + b], s);
+          pl[m] = s;
         }
       }
-      __syncthreads();  // barrier 2: B complete; A free for the next commit
+      // z: shift the pending planes and absorb this plane in the same FMA
+#pragma unroll
+      for (int j = 0; j < PZ - 1; ++j)
+#pragma unroll
+        for (int m = 0; m < kRun; ++m) acc[j][m] = fmaf(wz[PZ - 1 - j], pl[m], acc[j + 1][m]);
+#pragma unroll
+      for (int m = 0; m < kRun; ++m) acc[PZ - 1][m] = wz[0] * pl[m];
 
-      // ---- y pass: 8 outputs down one column from 8+PY-1 reads
-      const float* col = bufB + ycol;
-      float cv[kRun + PY - 1];
+      const int z_out = zi - cz;
+      if (z_out >= zb) {  // wave-uniform
+        float* o = p.out + static_cast<int64_t>(z_out) * p.out_plane;  // scalar
+        if constexpr (EPI != LSR_EPI_NONE) {
+          // aux of this plane was requested in the previous iteration; issued since: this
+          // iteration's staging loads (2) and aux (NA)
+          wait_loads<2 + NA>(aux_use, nz_use);
+        }
+        if constexpr (EPI == LSR_EPI_RATIO) {
 #pragma unroll
-      for (int j = 0; j < kRun + PY - 1; ++j) cv[j] = col[j * T::PB];
+          for (int m = 0; m < kRun; ++m)
+            if (ok[m]) o[o_off[m]] = aux_use[m] * fast_rcp(acc[0][m] + p.eps);
+        } else if constexpr (EPI == LSR_EPI_UPDATE) {
+          const float rz = fast_rcp(nz_use);
 #pragma unroll
-      for (int m = 0; m < kRun; ++m) {
-        float s = wy[0] * cv[m];
+          for (int m = 0; m < kRun; ++m)
+            if (ok[m]) o[o_off[m]] = aux_use[m] * acc[0][m] * (rz * rnyx[m]);
+        } else {
 #pragma unroll
-        for (int b = 1; b < PY; ++b) s = fmaf(wy[b], cv[m + b], s);
-        pl[m] = s;
+          for (int m = 0; m < kRun; ++m)
+            if (ok[m]) o[o_off[m]] = acc[0][m];
+        }
       }
     }
+    lds_barrier();  // A[par], B[par^1] complete; A[par^1], B[par] free
+  };
 
-    // ---- z: shift the pending planes and absorb this plane in the same FMA
-#pragma unroll
-    for (int j = 0; j < PZ - 1; ++j)
-#pragma unroll
-      for (int m = 0; m < kRun; ++m) acc[j][m] = fmaf(wz[PZ - 1 - j], pl[m], acc[j + 1][m]);
-#pragma unroll
-    for (int m = 0; m < kRun; ++m) acc[PZ - 1][m] = wz[0] * pl[m];
-
-    // ---- epilogue for the completed plane z_out
-    if (emit && xok_out) {
-      float* o = p.out + z_out * plane + static_cast<int64_t>(gy_out0) * X;  // scalar
-      if (epi == LSR_EPI_RATIO) {
-#pragma unroll
-        for (int m = 0; m < kRun; ++m)
-          if (m < nrows_out) (o + m * X)[voff_out] = aux[m] * fast_rcp(acc[0][m] + p.eps);
-      } else if (epi == LSR_EPI_UPDATE) {
-        const float rz = fast_rcp(p.nz[z_out]);
-#pragma unroll
-        for (int m = 0; m < kRun; ++m)
-          if (m < nrows_out) (o + m * X)[voff_out] = aux[m] * acc[0][m] * (rz * rnyx[m]);
-      } else {
-#pragma unroll
-        for (int m = 0; m < kRun; ++m)
-          if (m < nrows_out) (o + m * X)[voff_out] = acc[0][m];
-      }
-    }
+  // Start two planes early at an even index: the extra leading iterations only move (valid,
+  // clamped) data through the pipeline, nothing they produce is consumed.  The prologue issues
+  // the same load sequence an iteration pair would, so the hand-counted waits hold from the start.
+  const int zs = (zi_begin - 2) & ~1;
+  fetch(zs + 2, st0);
+  fetch_aux(zs - 1 - cz, aux1, nzv1);
+  fetch(zs + 3, st1);
+  fetch_aux(zs - cz, aux0, nzv0);
+  for (int zi = zs; zi < zi_end; zi += 2) {
+    iteration(zi, 0, st0, aux0, nzv0, aux1, nzv1);
+    iteration(zi + 1, 1, st1, aux1, nzv1, aux0, nzv0);
   }
-}
-
-// Tap counts with a compiled specialisation; other (odd) sizes are zero-padded up to the next
-// one by the dispatcher, which keeps the centre tap in place.
-constexpr int kSizes[] = {3, 5, 7, 9, 11, 13, 15};
-
-int round_up_taps(int n) {
-  for (int s : kSizes)
-    if (n <= s) return s;
-  return -1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land after the wave has ended
 }
 
 template <int PZ, int PYX>
-void launch_one(const CorrArgs& p, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((correlate_sep_kernel<PZ, PYX, PYX>), grid, dim3(kThreads), 0, s, p);
-}
-
-template <int PZ>
-bool launch_pz(int pyx, const CorrArgs& p, dim3 grid, hipStream_t s) {
-  switch (pyx) {
-    case 3: launch_one<PZ, 3>(p, grid, s); return true;
-    case 5: launch_one<PZ, 5>(p, grid, s); return true;
-    case 7: launch_one<PZ, 7>(p, grid, s); return true;
-    case 9: launch_one<PZ, 9>(p, grid, s); return true;
-    case 11: launch_one<PZ, 11>(p, grid, s); return true;
-    case 13: launch_one<PZ, 13>(p, grid, s); return true;
-    case 15: launch_one<PZ, 15>(p, grid, s); return true;
-    default: return false;
+bool launch_one(const SepArgs& p, dim3 grid, hipStream_t s) {
+  const dim3 block(kThreads);
+  switch (p.epilogue) {
+    case LSR_EPI_NONE:
+      hipLaunchKernelGGL((correlate_sep_kernel<PZ, PYX, PYX, LSR_EPI_NONE>), grid, block, 0, s, p);
+      return true;
+    case LSR_EPI_RATIO:
+      hipLaunchKernelGGL((correlate_sep_kernel<PZ, PYX, PYX, LSR_EPI_RATIO>), grid, block, 0, s, p);
+      return true;
+    case LSR_EPI_UPDATE:
+      hipLaunchKernelGGL((correlate_sep_kernel<PZ, PYX, PYX, LSR_EPI_UPDATE>), grid, block, 0, s, p);
+      return true;
+    default:
+      return false;
   }
 }
 
@@ -318,36 +371,22 @@ bool launch_pz(int pyx, const CorrArgs& p, dim3 grid, hipStream_t s) {
 
 namespace lsr {
 
-bool sep_fast_supported(int pz, int py, int px, int* PZ, int* PYX) {
-  const int a = round_up_taps(pz);
-  const int b = round_up_taps(py > px ? py : px);
-  if (a < 0 || b < 0) return false;
-  *PZ = a;
-  *PYX = b;
-  return true;
-}
-
-int launch_sep_fast(const CorrArgs& p, int PZ, int PYX, hipStream_t s) {
-  const int64_t blocks = p.tiles_x * p.tiles_y * ceil_div(p.Z, p.z_chunk);
-  if (blocks >= (int64_t(1) << 31))
-    return fail(LSR_E_SHAPE, "grid of %lld workgroups is too large", (long long)blocks);
-  if (p.Y * p.X >= (int64_t(1) << 30))
-    return fail(LSR_E_UNSUPPORTED, "plane of %lld voxels exceeds the 32-bit in-plane offsets",
-                (long long)(p.Y * p.X));
-  const dim3 grid(static_cast<unsigned>(blocks));
-  bool ok = false;
-  switch (PZ) {
-    case 3: ok = launch_pz<3>(PYX, p, grid, s); break;
-    case 5: ok = launch_pz<5>(PYX, p, grid, s); break;
-    case 7: ok = launch_pz<7>(PYX, p, grid, s); break;
-    case 9: ok = launch_pz<9>(PYX, p, grid, s); break;
-    case 11: ok = launch_pz<11>(PYX, p, grid, s); break;
-    case 13: ok = launch_pz<13>(PYX, p, grid, s); break;
-    case 15: ok = launch_pz<15>(PYX, p, grid, s); break;
-    default: break;
+// One definition per translation unit: -DLSR_SEP_PZ=3 ... 15.
+#define LSR_CAT2(a, b) a##b
+#define LSR_CAT(a, b) LSR_CAT2(a, b)
+bool LSR_CAT(launch_sep_pz, LSR_SEP_PZ)(int pyx, const SepArgs& p, unsigned blocks, hipStream_t s) {
+  constexpr int PZ = LSR_SEP_PZ;
+  const dim3 grid(blocks);
+  switch (pyx) {
+    case 3: return launch_one<PZ, 3>(p, grid, s);
+    case 5: return launch_one<PZ, 5>(p, grid, s);
+    case 7: return launch_one<PZ, 7>(p, grid, s);
+    case 9: return launch_one<PZ, 9>(p, grid, s);
+    case 11: return launch_one<PZ, 11>(p, grid, s);
+    case 13: return launch_one<PZ, 13>(p, grid, s);
+    case 15: return launch_one<PZ, 15>(p, grid, s);
+    default: return false;
   }
-  if (!ok) return fail(LSR_E_UNSUPPORTED, "no specialisation for taps (%d, %d)", PZ, PYX);
-  return launch_status("lsr_correlate_sep_f32");
 }
 
 }  // namespace lsr

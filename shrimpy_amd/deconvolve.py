@@ -26,7 +26,8 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["richardson_lucy", "RichardsonLucyPlan", "factor_psf", "correlate3d", "prepare_psf"]
+__all__ = ["richardson_lucy", "RichardsonLucyPlan", "factor_psf", "correlate3d", "prepare_psf",
+           "padded_shape", "PaddedVolume"]
 
 MAX_TAPS = 15
 
@@ -99,6 +100,34 @@ def _prefix_table(w: np.ndarray) -> np.ndarray:
     return t
 
 
+def padded_shape(shape_zyx, psf_shape):
+    """Padded plane geometry the tuned separable kernel reads through (``lsr_sep_padded_shape``).
+
+    Returns ``(rows, pitch, origin_row, origin_col)``: a padded volume is ``(Z, rows, pitch)``
+    float32 with the logical ``(Y, X)`` window at ``[origin_row:, origin_col:]`` and zeros elsewhere.
+    """
+    out = (ctypes.c_int64 * 4)()
+    _lib.call("lsr_sep_padded_shape", int(shape_zyx[1]), int(shape_zyx[2]), int(psf_shape[0]),
+              int(psf_shape[1]), int(psf_shape[2]), out)
+    return tuple(int(v) for v in out)
+
+
+class PaddedVolume:
+    """A zero-haloed working volume: ``.full`` is the allocation, ``.view`` the logical window."""
+
+    def __init__(self, shape_zyx, psf_shape, device):
+        import torch
+
+        z, y, x = (int(v) for v in shape_zyx)
+        rows, pitch, oy, ox = padded_shape(shape_zyx, psf_shape)
+        self.full = torch.zeros((z, rows, pitch), dtype=torch.float32, device=device)
+        self.view = self.full[:, oy:oy + y, ox:ox + x]
+        self.pitch, self.plane = pitch, rows * pitch
+
+    def logical_ptr(self) -> int:
+        return self.view.data_ptr()
+
+
 @dataclass
 class _DevicePsf:
     separable: bool
@@ -169,7 +198,9 @@ class RichardsonLucyPlan:
                 norm_table=dev(_prefix_table(w).ravel(), torch.float64),
             )
             self._norm = None
-        self._ratio = None
+        self._ratio = None   # dense path: ratio scratch
+        self._x_pad = None   # separable path: zero-haloed working volumes
+        self._ratio_pad = None
 
     @property
     def separable(self) -> bool:
@@ -178,13 +209,18 @@ class RichardsonLucyPlan:
     def _scratch(self):
         import torch
 
+        if self._psf.separable:
+            if self._x_pad is None:
+                self._x_pad = PaddedVolume(self.shape, self._psf.shape, self.device)
+                self._ratio_pad = PaddedVolume(self.shape, self._psf.shape, self.device)
+            return self._x_pad, self._ratio_pad
         if self._ratio is None:
             self._ratio = torch.empty(self.shape, dtype=torch.float32, device=self.device)
         return self._ratio
 
     def release(self) -> None:
-        """Drop the ratio scratch volume."""
-        self._ratio = None
+        """Drop the scratch volumes."""
+        self._ratio = self._x_pad = self._ratio_pad = None
 
     def __call__(self, y, iterations: int = 20, eps: float = 1e-6, x0=None, out=None):
         import torch
@@ -198,30 +234,39 @@ class RichardsonLucyPlan:
         if not eps > 0:
             raise ValueError("eps must be > 0")
         init = y if x0 is None else _lib.require_device_f32(x0, "x0")
+        if tuple(init.shape) != self.shape:
+            raise ValueError(f"x0 must be {self.shape}")
         if out is None:
-            x = init.clone()
+            x = torch.empty(self.shape, dtype=torch.float32, device=self.device)
         else:
             x = _lib.require_device_f32(out, "out")
             if tuple(x.shape) != self.shape or x.data_ptr() == y.data_ptr():
                 raise ValueError("out must have the volume shape and must not alias y")
-            x.copy_(init)
         if iterations == 0:
+            x.copy_(init)
             return x
-        ratio = self._scratch()
         z, yy, xx = self.shape
         ps = self._psf
         with torch.cuda.device(self.device):
             stream = _lib.stream_ptr(self.device)
             if ps.separable:
+                # working volumes carry a zero halo: the kernels never bounds-check a load
+                x_pad, ratio_pad = self._scratch()
+                x_pad.view.copy_(init)
                 (kz, ky, kx), (fz, fy, fx) = ps.k, ps.k_flipped
                 nz, ny, nx = self._norm
                 _lib.call(
-                    "lsr_rl_sep_f32", y.data_ptr(), x.data_ptr(), ratio.data_ptr(), z, yy, xx,
-                    kz.data_ptr(), fz.data_ptr(), ps.shape[0], ky.data_ptr(), fy.data_ptr(),
-                    ps.shape[1], kx.data_ptr(), fx.data_ptr(), ps.shape[2], nz.data_ptr(),
-                    ny.data_ptr(), nx.data_ptr(), iterations, ctypes.c_float(eps), stream,
+                    # y stays dense: padding it too (line-aligned aux reads) measured no gain
+                    "lsr_rl_sep_f32", y.data_ptr(), xx, yy * xx,
+                    x_pad.full.data_ptr(), ratio_pad.full.data_ptr(),
+                    x.data_ptr(), z, yy, xx, kz.data_ptr(), fz.data_ptr(), ps.shape[0],
+                    ky.data_ptr(), fy.data_ptr(), ps.shape[1], kx.data_ptr(), fx.data_ptr(),
+                    ps.shape[2], nz.data_ptr(), ny.data_ptr(), nx.data_ptr(), iterations,
+                    ctypes.c_float(eps), stream,
                 )
             else:
+                x.copy_(init)
+                ratio = self._scratch()
                 _lib.call(
                     "lsr_rl_dense_f32", y.data_ptr(), x.data_ptr(), ratio.data_ptr(), z, yy, xx,
                     ps.w.data_ptr(), ps.w_flipped.data_ptr(), ps.shape[0], ps.shape[1], ps.shape[2],
@@ -274,10 +319,12 @@ def correlate3d(volume, weights=None, *, weight_factors=None):
         if weight_factors is not None:
             wz, wy, wx = (np.asarray(k, dtype=np.float32).ravel() for k in weight_factors)
             dz, dy, dx = dev(wz), dev(wy), dev(wx)
+            pad = PaddedVolume(vol.shape, (len(wz), len(wy), len(wx)), vol.device)
+            pad.view.copy_(vol)
             _lib.call(
-                "lsr_correlate_sep_f32", vol.data_ptr(), out.data_ptr(), None, z, y, x,
-                dz.data_ptr(), len(wz), dy.data_ptr(), len(wy), dx.data_ptr(), len(wx),
-                _lib.EPI_NONE, ctypes.c_float(0.0), None, None, None, stream,
+                "lsr_correlate_sep_strided_f32", pad.logical_ptr(), pad.pitch, pad.plane, None, 0, 0,
+                out.data_ptr(), x, y * x, z, y, x, dz.data_ptr(), len(wz), dy.data_ptr(), len(wy),
+                dx.data_ptr(), len(wx), _lib.EPI_NONE, ctypes.c_float(0.0), None, None, None, stream,
             )
         else:
             w = prepare_psf(weights)
