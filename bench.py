@@ -115,7 +115,7 @@ def _cpu_worker(args):
     return dt, float(x.mean())
 
 
-def cpu_baseline(sample_shape=(384, 96, 384), max_procs=16):
+def cpu_baseline(sample_shape=(640, 128, 640), max_procs=16):
     """Oracle (kind "port": scipy.ndimage deskew + separable correlate1d RL) on the host cores."""
     import multiprocessing as mp
 
@@ -206,7 +206,7 @@ def main():
                            out=deskewed)
         if ev:
             ev[1].record()
-        plan(deskewed, iterations=RL_ITERS, out=estimate)
+        plan(deskewed, iterations=RL_ITERS, out=estimate, events=(ev[3], ev[4]) if ev else None)
         if ev:
             ev[2].record()
 
@@ -222,7 +222,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -237,12 +237,13 @@ def main():
     elapsed = float(t.item())
 
     deskew_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
-    rl_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
+    rl_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps          # incl. x0 = y copy
+    rl_kernels_ms = sum(e[3].elapsed_time(e[4]) for e in events) / args.steps  # the 2*iters launches
     assert torch.isfinite(estimate).all(), "non-finite RL output"
 
     if rank == 0:
         launches = 2 * RL_ITERS
-        launch_s = rl_ms * 1e-3 / launches        # HIP-event time of the RL section / launches
+        launch_s = rl_kernels_ms * 1e-3 / launches  # HIP events right around the launches, / count
         bytes_per_launch = 12.0 * n_o             # in + aux + out, 4 B each
         achieved = bytes_per_launch / launch_s / 1e9
         total_bytes = 4.0 * n_in + 4.0 * n_o + 24.0 * RL_ITERS * n_o + 8.0 * n_o
@@ -279,12 +280,14 @@ def main():
                 "rl_iterations": RL_ITERS,
                 "deskew_ms": deskew_ms,
                 "rl_ms": rl_ms,
+                "rl_kernels_ms": rl_kernels_ms,
                 "algorithmic_bytes_per_step": total_bytes,
                 "whole_step_hbm_frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "parallelism": f"positions x{world} (independent units, no data-path collective)",
             },
             "roofline": {
-                "kernel": "correlate_march_kernel (RL ratio/update launch)",
+                "kernel": ("correlate_sep_kernel<9,7,7> (RL ratio / update launch)" if args.psf == "separable"
+                           else "correlate_march_kernel<9,false> (dense RL launch)"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -49,6 +49,7 @@ constexpr int kTX = lsr::kSepTileX;      // 64
 constexpr int kRun = 4;                  // consecutive y per thread in the y / z passes
 constexpr int kWaves = kTY / kRun;       // 8
 constexpr int kThreads = 64 * kWaves;    // 512
+constexpr int kBand = 8;                 // tile rows per band of the tile walk (see the kernel)
 
 template <int PY, int PX>
 struct Tile {
@@ -139,9 +140,17 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
     const int xcd = bid % 8, idx = bid / 8;
     bid = xcd * per + (xcd < rem ? xcd : rem) + idx;  // XCD k owns per + (k < rem) tiles
   }
-  const int tx = bid % p.tiles_x;
-  const int ty = (bid / p.tiles_x) % p.tiles_y;
-  const int zc = bid / (p.tiles_x * p.tiles_y);
+  // ... and walk the (y, x) tile grid in bands of 8 tile rows, column-major inside a band: any
+  // 64 consecutive tiles (= the workgroups an XCD keeps resident) then form an 8 x 8 patch, so
+  // halo rows AND halo columns are shared inside one L2.
+  const int tiles_xy = p.tiles_x * p.tiles_y;
+  const int zc = bid / tiles_xy;
+  const int lin = bid - zc * tiles_xy;
+  const int band = lin / (p.tiles_x * kBand);
+  const int lb = lin - band * (p.tiles_x * kBand);
+  const int band_h = min(kBand, p.tiles_y - band * kBand);
+  const int tx = lb / band_h;
+  const int ty = band * kBand + (lb - tx * band_h);
 
   const int Z = p.Z, Y = p.Y, X = p.X;
   const int x0 = tx * kTX, y0 = ty * kTY;

@@ -222,7 +222,9 @@ class RichardsonLucyPlan:
         """Drop the scratch volumes."""
         self._ratio = self._x_pad = self._ratio_pad = None
 
-    def __call__(self, y, iterations: int = 20, eps: float = 1e-6, x0=None, out=None):
+    def __call__(self, y, iterations: int = 20, eps: float = 1e-6, x0=None, out=None, events=None):
+        """Run RL.  ``events`` = optional ``(start, end)`` torch events recorded on the launch
+        stream right around the ``2 * iterations`` kernel launches (what ``bench.py`` times)."""
         import torch
 
         y = _lib.require_device_f32(y, "y")
@@ -255,6 +257,8 @@ class RichardsonLucyPlan:
                 x_pad.view.copy_(init)
                 (kz, ky, kx), (fz, fy, fx) = ps.k, ps.k_flipped
                 nz, ny, nx = self._norm
+                if events:
+                    events[0].record()
                 _lib.call(
                     # y stays dense: padding it too (line-aligned aux reads) measured no gain
                     "lsr_rl_sep_f32", y.data_ptr(), xx, yy * xx,
@@ -267,11 +271,15 @@ class RichardsonLucyPlan:
             else:
                 x.copy_(init)
                 ratio = self._scratch()
+                if events:
+                    events[0].record()
                 _lib.call(
                     "lsr_rl_dense_f32", y.data_ptr(), x.data_ptr(), ratio.data_ptr(), z, yy, xx,
                     ps.w.data_ptr(), ps.w_flipped.data_ptr(), ps.shape[0], ps.shape[1], ps.shape[2],
                     ps.norm_table.data_ptr(), iterations, ctypes.c_float(eps), stream,
                 )
+            if events:
+                events[1].record()
         return x
 
 

@@ -1,0 +1,222 @@
+"""Per-volume reconstruction (deskew -> register -> deconvolve) and its sharding over GPUs.
+
+The unit of work is one ``(position, timepoint, channel)`` volume; units are independent (the
+reference treats every (t, p) stack on its own: ``shrimpy/dynatrack/manager.py:357-384``, one job
+per stack ``shrimpy/dynatrack/worker.py:223-252``; production runs them as SLURM array jobs,
+``docs/data_structure.md:64``).  So the multi-GPU layout is one process per GPU, a static
+round-robin of units over ranks, **no collective on the data path**: every rank reads and writes
+its own positions.  ``torch.distributed`` (RCCL over xGMI when the tensors live on GPUs, gloo in the
+CPU tests) carries only the timing barrier and the optional final gather of results to rank 0.
+"""
+
+from __future__ import annotations
+
+import logging
+import time
+
+from dataclasses import dataclass, field
+from typing import Callable, Iterable, Sequence
+
+import numpy as np
+
+from .settings import DeconvolveSettings, DeskewSettings, ReconstructSettings, RegisterSettings
+
+logger = logging.getLogger(__name__)
+
+__all__ = [
+    "Unit", "enumerate_units", "shard_units", "VolumeReconstructor", "run_sharded",
+    "gather_to_rank0", "gaussian_psf_factors",
+]
+
+
+@dataclass(frozen=True)
+class Unit:
+    """One independent volume of a plate: position key (``"row/col/fov"``), timepoint, channel."""
+
+    position: str
+    t: int = 0
+    c: int = 0
+
+
+def enumerate_units(positions: Sequence[str], n_t: int = 1, channels: Sequence[int] = (0,)) -> list[Unit]:
+    """All units of a plate in a fixed order: position-major, then time, then channel."""
+    return [Unit(p, t, c) for p in positions for t in range(int(n_t)) for c in channels]
+
+
+def shard_units(units: Sequence, rank: int, world_size: int) -> list:
+    """Static round-robin: rank ``r`` owns units ``r, r + W, r + 2W, ...``.
+
+    Deterministic, needs no communication, and balances to within one unit (96 positions over 8
+    GPUs -> 12 each).
+    """
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError(f"bad rank/world_size {rank}/{world_size}")
+    return list(units[rank::world_size])
+
+
+def gaussian_psf_factors(shape_zyx=(9, 7, 7), sigma_zyx=(2.0, 1.2, 1.2)):
+    """1-D factors of the separable anisotropic Gaussian PSF, each normalised to sum 1 (float32)."""
+    ks = []
+    for n, s in zip(shape_zyx, sigma_zyx):
+        g = np.exp(-0.5 * ((np.arange(n) - n // 2) / s) ** 2)
+        ks.append((g / g.sum()).astype(np.float32))
+    return tuple(ks)
+
+
+class VolumeReconstructor:
+    """Deskew -> (affine register) -> (Richardson-Lucy) for volumes of one raw shape on one device.
+
+    Plans (PSF taps, border normalisation, padded working volumes) are built once and reused for
+    every unit the rank owns.
+    """
+
+    def __init__(self, raw_shape_zyx, settings: ReconstructSettings, device):
+        import torch
+
+        self.device = torch.device(device)
+        self.raw_shape = tuple(int(v) for v in raw_shape_zyx)
+        self.settings = settings
+        shape = self.raw_shape
+        self._geo = None
+        if settings.deskew is not None:
+            from .geometry import deskew_geometry
+
+            d: DeskewSettings = settings.deskew
+            self._geo = deskew_geometry(shape, d.ls_angle_deg, d.px_to_scan_ratio, d.keep_overhang,
+                                        d.average_n_slices, d.pixel_size_um)
+            shape = self._geo.output_shape
+        self._register: RegisterSettings | None = settings.registration
+        if self._register is not None and self._register.output_shape_zyx is not None:
+            shape = tuple(self._register.output_shape_zyx)
+        self.output_shape = tuple(shape)
+        self._plan = None
+        dec: DeconvolveSettings | None = settings.deconvolution
+        if dec is not None and dec.iterations > 0:
+            from .deconvolve import RichardsonLucyPlan
+
+            if dec.psf_path:
+                psf = np.load(dec.psf_path).astype(np.float32)
+                self._plan = RichardsonLucyPlan(
+                    self.output_shape, psf, self.device,
+                    separable={"auto": "auto", "force": "force", "never": "never"}[dec.separable],
+                    separable_rtol=dec.separable_rtol)
+            else:
+                factors = gaussian_psf_factors(dec.gaussian_shape_zyx, dec.gaussian_sigma_zyx)
+                if dec.separable == "never":
+                    psf = factors[0][:, None, None] * factors[1][None, :, None] * factors[2][None, None, :]
+                    self._plan = RichardsonLucyPlan(self.output_shape, psf, self.device, separable="never")
+                else:
+                    self._plan = RichardsonLucyPlan(self.output_shape, None, self.device, psf_factors=factors)
+
+    def __call__(self, raw):
+        """``raw``: (Z, Y, X) numpy array or tensor -> reconstructed float32 tensor on ``device``."""
+        import torch
+
+        from .deskew import deskew_with_matrix
+        from .register import apply_affine_transform_zyx
+
+        vol = torch.as_tensor(raw, device=self.device, dtype=torch.float32).contiguous()
+        if tuple(vol.shape) != self.raw_shape:
+            raise ValueError(f"expected raw shape {self.raw_shape}, got {tuple(vol.shape)}")
+        if self._geo is not None:
+            vol = deskew_with_matrix(vol, self._geo.matrix_3x4, self._geo.pre_average_shape,
+                                     self.settings.deskew.average_n_slices)
+        if self._register is not None:
+            r = self._register
+            vol = apply_affine_transform_zyx(vol, np.asarray(r.affine_transform_zyx), self.output_shape,
+                                             mode=r.mode, cval=r.cval)
+        if self._plan is not None:
+            dec = self.settings.deconvolution
+            vol = self._plan(vol, iterations=dec.iterations, eps=dec.eps)
+        return vol
+
+
+@dataclass
+class ShardReport:
+    rank: int
+    world_size: int
+    units: list = field(default_factory=list)
+    seconds: float = 0.0         # this rank's wall time
+    max_seconds: float = 0.0     # max over ranks (what the job took)
+    n_units_total: int = 0
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def run_sharded(
+    units: Sequence,
+    load: Callable[[object], object],
+    process: Callable[[object], object],
+    store: Callable[[object, object], None],
+    *,
+    synchronize: Callable[[], None] | None = None,
+) -> ShardReport:
+    """Run ``store(unit, process(load(unit)))`` for this rank's share of ``units``.
+
+    Rank and world size come from the initialised ``torch.distributed`` group (single process
+    otherwise).  There is no data-path collective; a barrier brackets the timed region and the
+    reported job time is the max over ranks.
+    """
+    import torch
+
+    dist = _dist()
+    rank = dist.get_rank() if dist else 0
+    world = dist.get_world_size() if dist else 1
+    mine = shard_units(list(units), rank, world)
+    sync = synchronize or (lambda: None)
+
+    if dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for unit in mine:
+        store(unit, process(load(unit)))
+    sync()
+    seconds = time.perf_counter() - t0
+    max_seconds = seconds
+    if dist:
+        backend = dist.get_backend()
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        max_seconds = float(t.item())
+        dist.barrier()
+    logger.info("rank %d/%d: %d of %d units in %.3fs (job %.3fs)", rank, world, len(mine), len(units),
+                seconds, max_seconds)
+    return ShardReport(rank, world, mine, seconds, max_seconds, len(units))
+
+
+def gather_to_rank0(local: Iterable, n_total: int):
+    """Optional final gather (the north-star's "stitched-volume gather"): rank 0 receives every
+    rank's result tensors in unit order; other ranks return ``None``.
+
+    ``local`` = this rank's results in the order of ``shard_units``.  Point-to-point sends to rank 0
+    (each peer over its own xGMI link when the backend is RCCL) rather than a ring all-gather,
+    which would be bound by one link for this many-to-one pattern.
+    """
+    import torch
+
+    dist = _dist()
+    local = list(local)
+    if dist is None:
+        return local
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if rank != 0:
+        for t in local:
+            dist.send(t.contiguous(), dst=0)
+        return None
+    out: list = [None] * n_total
+    for i, t in enumerate(local):
+        out[i * world] = t
+    for src in range(1, world):
+        for k, idx in enumerate(range(src, n_total, world)):
+            buf = torch.empty_like(local[0]) if local else None
+            if buf is None:
+                raise RuntimeError("rank 0 owns no unit: cannot infer the result shape")
+            dist.recv(buf, src=src)
+            out[idx] = buf
+    return out

@@ -1,0 +1,132 @@
+"""Sharding of independent (position, timepoint, channel) units over ranks.
+
+The N > 1 path is exercised with real ``torch.distributed`` processes (gloo, world_size 2, CPU):
+the partition, the barrier + max-over-ranks timing and the optional gather to rank 0.  The
+compute callable is a stand-in here (no GPU in the build container); the GPU test at the bottom
+runs the real ``VolumeReconstructor`` on one device.
+"""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from shrimpy_amd.pipeline import Unit, enumerate_units, shard_units
+
+
+def test_enumerate_units_order():
+    units = enumerate_units(["A/1/0", "A/2/0"], n_t=2, channels=(0, 1))
+    assert len(units) == 8
+    assert units[0] == Unit("A/1/0", 0, 0) and units[1] == Unit("A/1/0", 0, 1)
+    assert units[4] == Unit("A/2/0", 0, 0)
+
+
+@pytest.mark.parametrize("n,world", [(96, 8), (96, 1), (5, 8), (0, 4), (19200, 8), (7, 2)])
+def test_shard_units_is_a_balanced_partition(n, world):
+    units = list(range(n))
+    shards = [shard_units(units, r, world) for r in range(world)]
+    assert sorted(u for s in shards for u in s) == units          # every unit exactly once
+    sizes = [len(s) for s in shards]
+    assert max(sizes) - min(sizes) <= 1                           # 96 positions / 8 GPUs -> 12 each
+    assert shards[0][:2] == units[0:2 * world:world]
+
+
+def test_shard_units_rejects_bad_rank():
+    with pytest.raises(ValueError):
+        shard_units([1, 2], 2, 2)
+    with pytest.raises(ValueError):
+        shard_units([1, 2], 0, 0)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+
+    from shrimpy_amd.pipeline import gather_to_rank0, run_sharded
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        units = enumerate_units([f"A/{i}/0" for i in range(7)])
+        results = {}
+
+        def load(u):
+            return torch.full((2, 3, 4), float(int(u.position.split("/")[1])))
+
+        def process(v):
+            return v * 2 + 1
+
+        def store(u, v):
+            results[u] = v
+
+        rep = run_sharded(units, load, process, store)
+        assert rep.world_size == world and rep.rank == rank
+        assert rep.units == shard_units(units, rank, world)
+        assert rep.max_seconds >= rep.seconds > 0
+        gathered = gather_to_rank0([results[u] for u in rep.units], len(units))
+        if rank == 0:
+            vals = [float(t[0, 0, 0]) for t in gathered]
+            np.save(os.path.join(tmp, "gathered.npy"), np.array(vals))
+        else:
+            assert gathered is None
+        with open(os.path.join(tmp, f"ok{rank}"), "w") as f:
+            f.write(",".join(u.position for u in rep.units))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_run_sharded_world_size_2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    owned = [(tmp_path / f"ok{r}").read_text().split(",") for r in range(world)]
+    assert owned[0] == ["A/0/0", "A/2/0", "A/4/0", "A/6/0"]
+    assert owned[1] == ["A/1/0", "A/3/0", "A/5/0"]
+    # rank 0 holds every unit's result, in unit order
+    np.testing.assert_array_equal(np.load(tmp_path / "gathered.npy"), [2 * i + 1 for i in range(7)])
+
+
+def test_run_sharded_single_process():
+    from shrimpy_amd.pipeline import gather_to_rank0, run_sharded
+
+    out = {}
+    rep = run_sharded(list(range(5)), lambda u: u, lambda v: v * v, lambda u, v: out.__setitem__(u, v))
+    assert rep.world_size == 1 and out == {i: i * i for i in range(5)}
+    assert gather_to_rank0([1, 2, 3], 3) == [1, 2, 3]
+
+
+@pytest.mark.gpu
+def test_volume_reconstructor_matches_oracle(device):
+    """The whole per-volume path on one GPU vs the oracle, small size."""
+    import torch
+
+    from oracle import cpu_ref as o
+    from shrimpy_amd.pipeline import VolumeReconstructor
+    from shrimpy_amd.settings import DeconvolveSettings, DeskewSettings, ReconstructSettings, RegisterSettings
+
+    psf, factors = o.gaussian_psf((9, 7, 7), (2.0, 1.2, 1.2))
+    raw = o.bead_scene((96, 24, 80), seed=77, psf=psf, density=1e-3)
+    m = np.eye(4)
+    m[:3, 3] = [0.25, -1.5, 2.0]
+    settings = ReconstructSettings(
+        deskew=DeskewSettings(pixel_size_um=0.1133, ls_angle_deg=30, scan_step_um=0.15),
+        registration=RegisterSettings(affine_transform_zyx=m.tolist()),
+        deconvolution=DeconvolveSettings(iterations=10),
+    )
+    rec = VolumeReconstructor(raw.shape, settings, device)
+    out = rec(raw).cpu().numpy().astype(np.float64)
+    d = o.deskew(raw, 30.0, 0.755, False, 3)
+    assert rec.output_shape == d.shape
+    a = o.affine_apply_4x4(d, m, d.shape)
+    ref = o.richardson_lucy(a, psf, 10).astype(np.float64)
+    tol = 1e-4 * np.abs(ref) + 5e-5 * np.abs(ref).max()
+    assert np.all(np.abs(out - ref) <= tol)
+    assert torch.cuda.is_available()

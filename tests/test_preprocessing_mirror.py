@@ -1,0 +1,176 @@
+"""CPU tests of the preprocessor mirror; they read like the reference's
+``shrimpy/tests/test_preprocessing.py`` (heavy steps monkeypatched, control flow exercised).
+
+The last test runs the REFERENCE's own ``shrimpy.preprocessing`` with this package standing in for
+``biahub`` (skipped where /root/reference is absent, e.g. on the GPU box): the drop-in claim,
+checked against the caller's real code.
+"""
+
+import sys
+import types
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from shrimpy_amd import preprocessing as pp
+from shrimpy_amd.preprocessing import _LabelfreePreprocessor, _settings_kwargs, build_preprocessor
+
+ZYX = (16, 64, 64)
+DESKEW = dict(ls_angle_deg=30.0, pixel_size_um=0.1133, scan_step_um=0.15, keep_overhang=False,
+              average_n_slices=3)
+
+
+def test_no_pipeline_returns_none():
+    assert build_preprocessor(ZYX, None) is None
+    assert build_preprocessor(ZYX, []) is None
+    assert build_preprocessor(ZYX, ["sum_projection", "segmentation"]) is None
+
+
+def test_out_of_scope_steps_fail_loudly():
+    with pytest.raises(NotImplementedError, match="phase"):
+        build_preprocessor(ZYX, ["deskew", "phase"], deskew=DESKEW)
+    with pytest.raises(NotImplementedError):
+        build_preprocessor(ZYX, ["vs"])
+
+
+def test_recon_steps_match_reference(golden_dir):
+    ref = np.load(golden_dir / "ref_preprocessing.npz")
+    assert tuple(ref["recon_steps"]) == pp.RECON_STEPS
+
+
+def test_settings_kwargs_filters_to_signature():
+    class FakeSettings:
+        def model_dump(self):
+            return {"a": 1, "b": 2, "unused": 3}
+
+    def func(a, b):
+        return a, b
+
+    assert _settings_kwargs(func, FakeSettings()) == {"a": 1, "b": 2}
+
+
+def _bare(**kw):
+    d = dict(zyx_shape=ZYX, deskew_settings=None, output_channel="BF")
+    d.update(kw)
+    pre = _LabelfreePreprocessor(**d)
+    pre._device = None  # keep tensors on CPU: no kernel is called in these tests
+    return pre
+
+
+def test_call_keys_output_channel_and_dtype():
+    import torch
+
+    out = _bare()(np.zeros(ZYX, dtype="uint16"))
+    assert set(out) == {"BF"} and isinstance(out["BF"], torch.Tensor)
+    assert out["BF"].dtype == torch.float32 and tuple(out["BF"].shape) == ZYX
+
+
+def test_call_runs_flatfield_then_deskew_and_exposes_intermediate(monkeypatch):
+    import torch
+
+    from shrimpy_amd.settings import DeskewSettings
+
+    order = []
+    pre = _bare(deskew_settings=DeskewSettings(**DESKEW), apply_flatfield=True)
+    monkeypatch.setattr(pre, "_flat_field_BF", lambda v: (order.append("flatfield"), v)[1])
+    monkeypatch.setattr(pre, "_deskew", lambda v: (order.append("deskew"), v[:4])[1])
+    out = pre(np.ones(ZYX, dtype="float32"), label="A/1/0", return_intermediates=True)
+    assert order == ["flatfield", "deskew"]
+    assert set(out) == {"BF", "deskew"} and out["deskew"] is out["BF"]
+    assert tuple(out["BF"].shape) == (4, 64, 64)
+    out = pre(np.ones(ZYX, dtype="float32"))
+    assert set(out) == {"BF"}
+    assert isinstance(out["BF"], torch.Tensor)
+
+
+def test_step_logs_and_reraises(caplog):
+    pre = _bare()
+
+    def boom(_):
+        raise ValueError("bad stack")
+
+    with caplog.at_level("ERROR"), pytest.raises(ValueError, match="bad stack"):
+        pre._step("[p0] ", "deskew", boom, None)
+    assert "[p0] deskew FAILED: bad stack" in caplog.text
+
+
+def test_flatfield_matches_reference_capture(golden_dir):
+    """Same torch expression as the reference: compare with what the reference produced."""
+    import torch
+
+    g = np.load(golden_dir / "ref_preprocessing.npz")
+    out = _bare()._flat_field_BF(torch.as_tensor(g["flatfield_in"]))
+    np.testing.assert_allclose(out.numpy(), g["flatfield_out"], rtol=1e-6)
+
+
+def test_warm_up_without_gpu_raises_instead_of_falling_back(monkeypatch):
+    import torch
+
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        build_preprocessor(ZYX, ["deskew"], deskew=DESKEW)
+    # a flat-field-only pipeline has no kernel: the torch expression may run where the tensor is
+    pre = build_preprocessor(ZYX, ["flatfield"])
+    assert pre is not None
+    with pytest.raises(RuntimeError, match="GPU required"):
+        build_preprocessor(ZYX, ["flatfield"], require_gpu=True)
+
+
+def test_warm_up_resolves_deskewed_shape(monkeypatch):
+    import torch
+
+    pre = build_preprocessor.__globals__["_LabelfreePreprocessor"](
+        zyx_shape=(2048, 512, 2048), deskew_settings=__import__("shrimpy_amd.settings", fromlist=["x"]).DeskewSettings(**DESKEW),
+        output_channel="BF")
+    monkeypatch.setattr(pp, "_resolve_device", lambda: torch.device("cuda"))
+    pre.warm_up()
+    assert pre._zyx_shape == (171, 2048, 2270)
+
+
+REFERENCE = Path("/root/reference")
+
+
+@pytest.mark.skipif(not (REFERENCE / "shrimpy" / "preprocessing.py").exists(),
+                    reason="the reference is only mounted in the build container")
+def test_dropin_through_the_reference_preprocessor(monkeypatch):
+    """The reference's ``build_preprocessor`` / ``_LabelfreePreprocessor`` run unmodified with this
+    package bound as ``biahub``: settings validation, kwargs filtering by signature, warm-up shape
+    call and the deskew call all go through our modules.  (No GPU here: the C-ABI launch itself is
+    replaced by the oracle for this one check of the *interface*.)"""
+    import torch
+
+    import shrimpy_amd.deskew as our_deskew
+    import shrimpy_amd.settings as our_settings
+
+    from oracle import cpu_ref as o
+
+    biahub = types.ModuleType("biahub")
+    biahub.deskew = our_deskew
+    biahub.settings = our_settings
+    monkeypatch.setitem(sys.modules, "biahub", biahub)
+    monkeypatch.setitem(sys.modules, "biahub.deskew", our_deskew)
+    monkeypatch.setitem(sys.modules, "biahub.settings", our_settings)
+    monkeypatch.syspath_prepend(str(REFERENCE))
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    ref_pp = __import__("shrimpy.preprocessing", fromlist=["build_preprocessor"])
+
+    calls = {}
+
+    def fake_launch(raw, matrix, pre_shape, avg=1, out=None):
+        calls["args"] = (tuple(raw.shape), pre_shape, avg)
+        m = np.asarray(matrix)
+        res = o.average_slices(o.affine_apply(raw.numpy(), m[:, :3], m[:, 3], pre_shape), avg)
+        return torch.as_tensor(res)
+
+    monkeypatch.setattr(our_deskew, "deskew_with_matrix", fake_launch)
+    raw_shape = (48, 12, 20)
+    pre = ref_pp.build_preprocessor(raw_shape, ["deskew"], deskew=dict(DESKEW), output_channel="BF")
+    expect_shape, _ = our_deskew.get_deskewed_data_shape(raw_shape, 30.0, 0.755, False, 3)
+    assert tuple(pre._zyx_shape) == expect_shape  # the reference's warm_up called OUR shape rule
+    raw = np.random.default_rng(0).integers(80, 600, raw_shape).astype(np.uint16)
+    out = pre(raw, label="A/1/0", return_intermediates=True)
+    assert set(out) == {"BF", "deskew"}
+    assert calls["args"] == (raw_shape, (12, 20, expect_shape[2]), 3)
+    np.testing.assert_array_equal(out["BF"].numpy(), o.deskew(raw.astype(np.float32), 30.0, 0.755, False, 3))
