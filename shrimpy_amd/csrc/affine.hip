@@ -5,112 +5,123 @@
 // scipy.ndimage.affine_transform(order=1, mode="constant"|"grid-constant").  Also the
 // general-matrix fallback of deskew (any 3x4 map), with lsr_average_slices_f32.
 //
-// Memory-bound 8-tap gather: lanes run along the output-fastest axis (coalesced 256-B stores);
-// for the near-identity maps of registration consecutive lanes read consecutive input
-// addresses, so the 8 taps of a wave touch ~4 rows x 2 planes of 256-B segments that the
-// vector L1 / XCD L2 serve after the first touch.  Algorithmic bytes: 4*N_src + 4*N_out.
+// 8-tap gather: lanes run along the output-fastest axis (coalesced 256-B stores); for the
+// near-identity maps of registration consecutive lanes read consecutive input addresses, so the 8
+// taps of a wave touch ~4 rows x 2 planes of 256-B segments that the vector L1 / XCD L2 serve after
+// the first touch.  Algorithmic bytes: 4*N_src + 4*N_out.
 //
 // Arithmetic: coordinates, weights and the 8-corner sum in fp64, in scipy's operation order
 // (see common.hpp), result rounded to f32 once -> bit-identical to the CPU oracle for finite
-// inputs.  The fp64 cost (~60 DP ops / voxel) is comparable to the HBM time; see DESIGN.md.
+// inputs.  That makes the kernel fp64-VALU-bound (~60 DP ops per voxel ~ the HBM time at the
+// 78 TFLOP/s fp64 vector rate), so everything else is kept cheap: a thread produces 4 voxels of
+// one output row (the (zo, yo) part of each coordinate is computed once per row -- scipy's sum
+// order ((zo*m0 + yo*m1) + xo*m2) + shift makes that prefix exact to hoist), indices are 32-bit.
 
 #include "common.hpp"
 
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kTileX = 64;
-constexpr int kTileY = 4;
+constexpr int kLanesX = 64;
+constexpr int kRows = kThreads / kLanesX;  // 4 output rows per workgroup
+constexpr int kPerThread = 4;              // voxels per thread along x, stride 64
+constexpr int kTileX = kLanesX * kPerThread;
 
 struct AffineArgs {
   const float* in;
   float* out;
-  int64_t Zi, Yi, Xi;
-  int64_t Zo, Yo, Xo;
+  int Zi, Yi, Xi;
+  int Zo, Yo, Xo;
   double m[12];
   float cval;
   int mode;
-  int64_t tiles_x, tiles_y;
+  int tiles_x, tiles_y;
 };
 
 struct AxisTap {
-  int64_t i0, i1;   // clamped neighbour indices
+  int i0, i1;       // clamped neighbour indices
   double w0, w1;    // scipy weights: w0 = 1 - f, w1 = 1 - w0
   bool out0, out1;  // grid-constant: neighbour is outside the volume -> cval
 };
 
 // Returns false if (mode constant) the coordinate is outside [0, n-1] -> whole sample is cval.
-__device__ __forceinline__ bool axis_tap(double c, int64_t n, int mode, AxisTap& t) {
-  if (mode == LSR_MODE_CONSTANT && (c < 0.0 || c > static_cast<double>(n - 1))) return false;
+template <bool GRID>
+__device__ __forceinline__ bool axis_tap(double c, int n, AxisTap& t) {
+  if (!GRID && (c < 0.0 || c > static_cast<double>(n - 1))) return false;
   const double fl = floor(c);
   const double f = c - fl;
   t.w0 = 1.0 - f;
   t.w1 = 1.0 - t.w0;
   // indices only matter while a neighbour can be inside; clamp far-away coordinates first
-  const double lim = static_cast<double>(n) + 1.0;
-  const int64_t start = static_cast<int64_t>(fmin(fmax(fl, -2.0), lim));
-  t.out0 = (start < 0) || (start >= n);
-  t.out1 = (start + 1 < 0) || (start + 1 >= n);
-  t.i0 = min(max(start, int64_t(0)), n - 1);
-  t.i1 = min(max(start + 1, int64_t(0)), n - 1);
+  const int start = static_cast<int>(fmin(fmax(fl, -2.0), static_cast<double>(n) + 1.0));
+  t.out0 = GRID && (start < 0 || start >= n);
+  t.out1 = GRID && (start + 1 < 0 || start + 1 >= n);
+  t.i0 = min(max(start, 0), n - 1);
+  t.i1 = min(max(start + 1, 0), n - 1);
   return true;
 }
 
+template <bool GRID>
 __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
-  int64_t bid = blockIdx.x;
-  const int64_t tx = bid % p.tiles_x;
+  int bid = blockIdx.x;
+  const int tx = bid % p.tiles_x;
   bid /= p.tiles_x;
-  const int64_t ty = bid % p.tiles_y;
-  const int64_t zo = bid / p.tiles_y;
-  const int64_t xo = tx * kTileX + (threadIdx.x & 63);
-  const int64_t yo = ty * kTileY + (threadIdx.x >> 6);
-  if (xo >= p.Xo || yo >= p.Yo) return;
+  const int ty = bid % p.tiles_y;
+  const int zo = bid / p.tiles_y;
+  const int yo = ty * kRows + static_cast<int>(threadIdx.x >> 6);
+  if (yo >= p.Yo) return;
+  const int x_first = tx * kTileX + static_cast<int>(threadIdx.x & 63);
 
-  const double zd = static_cast<double>(zo), yd = static_cast<double>(yo),
-               xd = static_cast<double>(xo);
-  const double cz = lsr::affine_coord(zd, yd, xd, p.m[0], p.m[1], p.m[2], p.m[3]);
-  const double cy = lsr::affine_coord(zd, yd, xd, p.m[4], p.m[5], p.m[6], p.m[7]);
-  const double cx = lsr::affine_coord(zd, yd, xd, p.m[8], p.m[9], p.m[10], p.m[11]);
+  // row part of each coordinate: (zo*m0 + yo*m1), scipy's first two terms
+  const double zd = static_cast<double>(zo), yd = static_cast<double>(yo);
+  const double rz = lsr::dadd(lsr::dmul(zd, p.m[0]), lsr::dmul(yd, p.m[1]));
+  const double ry = lsr::dadd(lsr::dmul(zd, p.m[4]), lsr::dmul(yd, p.m[5]));
+  const double rx = lsr::dadd(lsr::dmul(zd, p.m[8]), lsr::dmul(yd, p.m[9]));
+  const int64_t sz = static_cast<int64_t>(p.Yi) * p.Xi;
+  const double cv = static_cast<double>(p.cval);
+  float* orow = p.out + (static_cast<int64_t>(zo) * p.Yo + yo) * p.Xo;
 
-  AxisTap tz, ty_, tx_;
-  float result = p.cval;
-  if (axis_tap(cz, p.Zi, p.mode, tz) && axis_tap(cy, p.Yi, p.mode, ty_) &&
-      axis_tap(cx, p.Xi, p.mode, tx_)) {
-    const bool grid = p.mode == LSR_MODE_GRID_CONSTANT;
-    const double cv = static_cast<double>(p.cval);
-    const int64_t sz = p.Yi * p.Xi;
-    double t = 0.0;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int64_t iz = a ? tz.i1 : tz.i0;
-      const double wz = a ? tz.w1 : tz.w0;
-      const bool oz = a ? tz.out1 : tz.out0;
+  for (int k = 0; k < kPerThread; ++k) {
+    const int xo = x_first + k * kLanesX;
+    if (xo >= p.Xo) break;
+    const double xd = static_cast<double>(xo);
+    const double cz = lsr::dadd(lsr::dadd(rz, lsr::dmul(xd, p.m[2])), p.m[3]);
+    const double cy = lsr::dadd(lsr::dadd(ry, lsr::dmul(xd, p.m[6])), p.m[7]);
+    const double cx = lsr::dadd(lsr::dadd(rx, lsr::dmul(xd, p.m[10])), p.m[11]);
+
+    AxisTap tz, ty_, tx_;
+    float result = p.cval;
+    if (axis_tap<GRID>(cz, p.Zi, tz) && axis_tap<GRID>(cy, p.Yi, ty_) &&
+        axis_tap<GRID>(cx, p.Xi, tx_)) {
+      double t = 0.0;
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int64_t iy = b ? ty_.i1 : ty_.i0;
-        const double wy = b ? ty_.w1 : ty_.w0;
-        const bool oy = b ? ty_.out1 : ty_.out0;
+      for (int a = 0; a < 2; ++a) {
+        const int64_t oz = (a ? tz.i1 : tz.i0) * sz;
+        const double wz = a ? tz.w1 : tz.w0;
+        const bool bz = a ? tz.out1 : tz.out0;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int64_t ix = c ? tx_.i1 : tx_.i0;
-          const double wx = c ? tx_.w1 : tx_.w0;
-          const bool ox = c ? tx_.out1 : tx_.out0;
-          double coeff;
-          if (grid && (oz || oy || ox)) {
-            coeff = cv;
-          } else {
-            coeff = static_cast<double>(p.in[iz * sz + iy * p.Xi + ix]);
+        for (int b = 0; b < 2; ++b) {
+          const int64_t oy = oz + static_cast<int64_t>(b ? ty_.i1 : ty_.i0) * p.Xi;
+          const double wy = b ? ty_.w1 : ty_.w0;
+          const bool by = b ? ty_.out1 : ty_.out0;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const double wx = c ? tx_.w1 : tx_.w0;
+            const bool bx = c ? tx_.out1 : tx_.out0;
+            double coeff = static_cast<double>(p.in[oy + (c ? tx_.i1 : tx_.i0)]);
+            if (GRID && (bz || by || bx)) coeff = cv;
+            coeff = lsr::dmul(coeff, wz);
+            coeff = lsr::dmul(coeff, wy);
+            coeff = lsr::dmul(coeff, wx);
+            t = lsr::dadd(t, coeff);
           }
-          coeff = lsr::dmul(coeff, wz);
-          coeff = lsr::dmul(coeff, wy);
-          coeff = lsr::dmul(coeff, wx);
-          t = lsr::dadd(t, coeff);
         }
       }
+      result = static_cast<float>(t);
     }
-    result = static_cast<float>(t);
+    orow[xo] = result;
   }
-  p.out[(zo * p.Yo + yo) * p.Xo + xo] = result;
 }
 
 }  // namespace
@@ -127,6 +138,9 @@ extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t X
   LSR_REQUIRE(Zo > 0 && Yo > 0 && Xo > 0, LSR_E_SHAPE,
               "output shape (%lld,%lld,%lld) must be positive", (long long)Zo, (long long)Yo,
               (long long)Xo);
+  const int64_t lim = int64_t(1) << 30;
+  LSR_REQUIRE(Zi < lim && Yi < lim && Xi < lim && Zo < lim && Yo < lim && Xo < lim,
+              LSR_E_UNSUPPORTED, "a dimension exceeds 2^30");
   LSR_REQUIRE(mode == LSR_MODE_CONSTANT || mode == LSR_MODE_GRID_CONSTANT, LSR_E_ARG,
               "unknown border mode %d", mode);
   for (int i = 0; i < 12; ++i)
@@ -135,17 +149,21 @@ extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t X
   AffineArgs p;
   p.in = in;
   p.out = out;
-  p.Zi = Zi; p.Yi = Yi; p.Xi = Xi;
-  p.Zo = Zo; p.Yo = Yo; p.Xo = Xo;
+  p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
+  p.Zo = static_cast<int>(Zo); p.Yo = static_cast<int>(Yo); p.Xo = static_cast<int>(Xo);
   for (int i = 0; i < 12; ++i) p.m[i] = M[i];
   p.cval = cval;
   p.mode = mode;
-  p.tiles_x = lsr::ceil_div(Xo, kTileX);
-  p.tiles_y = lsr::ceil_div(Yo, kTileY);
-  const int64_t blocks = p.tiles_x * p.tiles_y * Zo;
+  p.tiles_x = static_cast<int>(lsr::ceil_div(Xo, kTileX));
+  p.tiles_y = static_cast<int>(lsr::ceil_div(Yo, kRows));
+  const int64_t blocks = int64_t(p.tiles_x) * p.tiles_y * Zo;
   LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
               (long long)blocks);
-  hipLaunchKernelGGL(affine_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
-                     lsr::as_stream(stream), p);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(kThreads);
+  if (mode == LSR_MODE_GRID_CONSTANT) {
+    hipLaunchKernelGGL(affine_kernel<true>, grid, block, 0, lsr::as_stream(stream), p);
+  } else {
+    hipLaunchKernelGGL(affine_kernel<false>, grid, block, 0, lsr::as_stream(stream), p);
+  }
   return lsr::launch_status("lsr_affine_f32");
 }

@@ -1,0 +1,103 @@
+"""Per-kernel timings that bench.py does not cover: affine apply (BASELINE config 3), the dense-PSF
+RL launch, and the deskew kernel alone.  Prints one JSON object per kernel.
+
+    python tools/bench_kernels.py [--reps 5]
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def timed(fn, reps):
+    import torch
+
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--skip-dense", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import bench
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+    from shrimpy_amd.deskew import deskew_with_matrix
+    from shrimpy_amd.geometry import deskew_geometry
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+
+    # ---- affine apply, config 3: 2048 x 2048 x 256 volume, rotation 2 deg o scale o translation
+    shape = (256, 2048, 2048)
+    vol = torch.rand(shape, device=dev, generator=g) * 1000
+    out = torch.empty_like(vol)
+    th = np.deg2rad(2.0)
+    rot = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]])
+    m = np.eye(4)
+    m[:3, :3] = rot @ np.diag([1.0, 0.98, 1.02])
+    m[:3, 3] = [3.5, -12.25, 20.75]
+    for mode in ("constant", "grid-constant"):
+        ms = timed(lambda: apply_affine_transform_zyx(vol, m, mode=mode, out=out), args.reps)
+        nbytes = 8.0 * vol.numel()
+        print(json.dumps({"kernel": f"affine_kernel ({mode})", "shape": shape, "ms": ms,
+                          "algorithmic_GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / 8000,
+                          "voxels_per_s": vol.numel() / (ms * 1e-3)}))
+    del vol, out
+
+    # ---- deskew alone, config 2 and config 4 mappings
+    for name in ("config2", "config4"):
+        raw_shape = bench.WORKLOADS[name]
+        raw = torch.rand(raw_shape, device=dev, generator=g)
+        geo = deskew_geometry(raw_shape, **bench.DESKEW)
+        dst = torch.empty(geo.output_shape, device=dev)
+        ms = timed(lambda: deskew_with_matrix(raw, geo.matrix_3x4, geo.pre_average_shape, 3, out=dst), args.reps)
+        nbytes = 4.0 * raw.numel() + 4.0 * dst.numel()
+        print(json.dumps({"kernel": "deskew_kernel", "workload": name, "raw": raw_shape,
+                          "out": geo.output_shape, "ms": ms, "algorithmic_GBps": nbytes / ms / 1e6,
+                          "frac_of_8TBps": nbytes / ms / 1e6 / 8000}))
+        del raw, dst
+
+    # ---- RL launches on the config-2 grid: separable (tuned) and dense (generic)
+    oshape = (171, 2048, 2270)
+    y = torch.poisson(torch.full(oshape, 100.0, device=dev), generator=g)
+    plans = [("separable 9x7x7", RichardsonLucyPlan(oshape, None, dev, psf_factors=bench.gaussian_factors()), 4)]
+    if not args.skip_dense:
+        plans.append(("dense 9x7x7 (rotated)", RichardsonLucyPlan(oshape, bench.rotated_psf(), dev, separable="never"), 1))
+    for name, plan, iters in plans:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        plan(y, iterations=1)
+        torch.cuda.synchronize()
+        plan(y, iterations=iters, events=ev)
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / (2 * iters)
+        nbytes = 12.0 * y.numel()
+        taps = 23 if plan.separable else 441
+        print(json.dumps({"kernel": f"RL launch, {name}", "grid": oshape, "ms_per_launch": ms,
+                          "algorithmic_GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / 8000,
+                          "fma_TFLOPs": 2.0 * taps * y.numel() / ms / 1e9}))
+
+
+if __name__ == "__main__":
+    main()
