@@ -203,6 +203,25 @@ def test_correlate_sep_and_dense_vs_scipy(device, pshape, vshape):
     _close(sep, ref, 2e-5, 2e-6)
 
 
+def test_correlate_long_z_runs_several_z_chunks(device):
+    """Few tiles and a long z axis: the launch splits z into chunks, each re-reading PZ-1 halo
+    planes; results must not depend on the split."""
+    from scipy import ndimage
+
+    from shrimpy_amd.deconvolve import correlate3d, richardson_lucy
+
+    rng = np.random.default_rng(45)
+    vol = (rng.random((230, 40, 70)) + 0.5).astype(np.float32)
+    ks = [rng.random(n).astype(np.float32) + 0.1 for n in (9, 7, 7)]
+    ks = [k / k.sum() for k in ks]
+    ref = vol
+    for axis, k in enumerate(ks):
+        ref = ndimage.correlate1d(ref, k, axis=axis, mode="constant", cval=0.0)
+    _close(correlate3d(_t(vol, device), weight_factors=ks).cpu().numpy(), ref, 2e-5, 2e-6)
+    x = richardson_lucy(_t(vol, device), psf_factors=ks, iterations=3).cpu().numpy()
+    _close(x, o.richardson_lucy_separable(vol, ks, 3), 5e-5, 2e-5)
+
+
 def test_correlate_is_not_convolve(device):
     """Asymmetric kernel: a flipped implementation fails this."""
     from scipy import ndimage
