@@ -169,6 +169,34 @@ int lsr_rl_dense_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t 
                      const float* psf, const float* psf_flipped, int pz, int py, int px,
                      const double* norm_table, int iters, float eps, lsr_stream_t stream);
 
+/*
+ * Tuned dense (non-separable) path: fp32-VALU-bound stencil on padded volumes, for PSFs with
+ * pz <= 11 and py, px <= 9 (anything else: LSR_E_UNSUPPORTED, use the generic dense entries).
+ *
+ * The taps are prepared ONCE on the host and uploaded by the caller:
+ *   n = lsr_dense_taps_count(pz, py, px)                    number of floats (or < 0)
+ *   lsr_dense_prepare_taps(psf_host, pz, py, px, flip, taps_host)   HOST pointers, no GPU work;
+ *       flip = 0: correlation with the PSF (H^T), flip = 1: with the reversed PSF (H = convolution)
+ * and `taps` below is that array in DEVICE memory. `in` lives in a padded volume
+ * (lsr_sep_padded_shape); `norm_table` as for lsr_correlate_dense_f32, `norm_full` = sum of taps.
+ */
+int lsr_dense_taps_count(int pz, int py, int px);
+int lsr_dense_prepare_taps(const float* psf_host, int pz, int py, int px, int flip,
+                           float* taps_host);
+
+int lsr_correlate_dense_padded_f32(const float* in, int64_t in_pitch, int64_t in_plane,
+                                   const float* aux, int64_t aux_pitch, int64_t aux_plane,
+                                   float* out, int64_t out_pitch, int64_t out_plane, int64_t Z,
+                                   int64_t Y, int64_t X, const float* taps, int pz, int py, int px,
+                                   int epilogue, float eps, const double* norm_table,
+                                   float norm_full, lsr_stream_t stream);
+
+int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane, float* x_pad,
+                            float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X,
+                            const float* taps, const float* taps_flipped, int pz, int py, int px,
+                            const double* norm_table, float norm_full, int iters, float eps,
+                            lsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

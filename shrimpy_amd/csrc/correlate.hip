@@ -470,3 +470,148 @@ extern "C" int lsr_rl_dense_f32(const float* y, float* x, float* ratio, int64_t 
   }
   return LSR_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Tuned dense path (correlate_dense.hip): padded input, taps prepared once by the host.
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+bool dense_compiled_taps(int pz, int py, int px, int* PZ, int* PYX) {
+  const int a = lsr::sep_round_taps(pz);
+  const int b = lsr::sep_round_taps(py > px ? py : px);
+  if (a > 11 || b > 9) return false;
+  *PZ = a;
+  *PYX = b;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int lsr_dense_taps_count(int pz, int py, int px) {
+  if (int rc = check_taps(pz, py, px)) return rc;
+  int PZ, PYX;
+  LSR_REQUIRE(dense_compiled_taps(pz, py, px, &PZ, &PYX), LSR_E_UNSUPPORTED,
+              "the tuned dense kernel covers pz <= 11 and py, px <= 9 (got %d,%d,%d): use "
+              "lsr_correlate_dense_f32",
+              pz, py, px);
+  return PZ * PYX * PYX;
+}
+
+extern "C" int lsr_dense_prepare_taps(const float* psf_host, int pz, int py, int px, int flip,
+                                      float* taps_host) {
+  LSR_REQUIRE_PTR(psf_host);
+  LSR_REQUIRE_PTR(taps_host);
+  const int n = lsr_dense_taps_count(pz, py, px);
+  if (n < 0) return n;
+  int PZ, PYX;
+  dense_compiled_taps(pz, py, px, &PZ, &PYX);
+  for (int i = 0; i < n; ++i) taps_host[i] = 0.0f;
+  const int oz = (PZ - pz) / 2, oy = (PYX - py) / 2, ox = (PYX - px) / 2;
+  for (int a = 0; a < pz; ++a)
+    for (int b = 0; b < py; ++b)
+      for (int c = 0; c < px; ++c) {
+        // correlation tap (a, b, c); flip = the convolution H x = correlate with the reversed PSF
+        const float v = flip ? psf_host[((pz - 1 - a) * py + (py - 1 - b)) * px + (px - 1 - c)]
+                             : psf_host[(a * py + b) * px + c];
+        const int A = a + oz, B = b + oy, C = c + ox;
+        taps_host[(C * PYX + B) * PZ + (PZ - 1 - A)] = v;  // [c][b][j], j = PZ-1-a
+      }
+  return LSR_OK;
+}
+
+extern "C" int lsr_correlate_dense_padded_f32(
+    const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch,
+    int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y,
+    int64_t X, const float* taps, int pz, int py, int px, int epilogue, float eps,
+    const double* norm_table, float norm_full, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(out);
+  LSR_REQUIRE_PTR(taps);
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
+              (long long)Z, (long long)Y, (long long)X);
+  if (int rc = check_taps(pz, py, px)) return rc;
+  int PZ, PYX;
+  LSR_REQUIRE(dense_compiled_taps(pz, py, px, &PZ, &PYX), LSR_E_UNSUPPORTED,
+              "the tuned dense kernel covers pz <= 11 and py, px <= 9 (got %d,%d,%d)", pz, py, px);
+  LSR_REQUIRE(epilogue == LSR_EPI_NONE || epilogue == LSR_EPI_RATIO || epilogue == LSR_EPI_UPDATE,
+              LSR_E_ARG, "unknown epilogue %d", epilogue);
+  if (epilogue != LSR_EPI_NONE) LSR_REQUIRE_PTR(aux);
+  if (epilogue == LSR_EPI_UPDATE) LSR_REQUIRE_PTR(norm_table);
+  LSR_REQUIRE(in != out, LSR_E_ARG, "out must not alias in");
+  int64_t need[4];
+  lsr_sep_padded_shape(Y, X, pz, py, px, need);
+  LSR_REQUIRE(in_pitch >= need[1] && in_plane >= need[0] * in_pitch, LSR_E_SHAPE,
+              "in strides (%lld,%lld) are smaller than the padded shape (%lld rows x %lld)",
+              (long long)in_pitch, (long long)in_plane, (long long)need[0], (long long)need[1]);
+  LSR_REQUIRE(in_pitch % 4 == 0 && in_plane % 4 == 0, LSR_E_ARG,
+              "pitch and plane stride of the padded input must be multiples of 4 floats");
+  const int64_t lim = int64_t(1) << 30;
+  LSR_REQUIRE(in_plane < lim && aux_plane < lim && out_plane < lim && Z < lim, LSR_E_UNSUPPORTED,
+              "plane strides exceed the kernel's 32-bit in-plane offsets");
+  LSR_REQUIRE(out_pitch >= X && (epilogue == LSR_EPI_NONE || aux_pitch >= X), LSR_E_SHAPE,
+              "aux/out pitch smaller than X");
+
+  lsr::DenseArgs p{};
+  p.in = in; p.aux = aux; p.out = out;
+  p.in_plane = in_plane; p.aux_plane = aux_plane; p.out_plane = out_plane;
+  p.in_pitch = static_cast<int>(in_pitch);
+  p.aux_pitch = static_cast<int>(aux_pitch);
+  p.out_pitch = static_cast<int>(out_pitch);
+  p.Z = static_cast<int>(Z); p.Y = static_cast<int>(Y); p.X = static_cast<int>(X);
+  p.pz = pz; p.py = py; p.px = px;
+  p.epilogue = epilogue; p.eps = eps;
+  p.norm_full = norm_full;
+  p.norm_table = norm_table;
+  p.taps = taps;
+  p.tiles_x = static_cast<int>(lsr::ceil_div(X, lsr::kSepTileX));
+  p.tiles_y = static_cast<int>(lsr::ceil_div(Y, lsr::kSepTileY));
+  p.z_chunk = static_cast<int>(pick_z_chunk(Z, int64_t(p.tiles_x) * p.tiles_y, PZ));
+  const int64_t blocks64 = int64_t(p.tiles_x) * p.tiles_y * lsr::ceil_div(Z, p.z_chunk);
+  LSR_REQUIRE(blocks64 < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
+              (long long)blocks64);
+  const unsigned blocks = static_cast<unsigned>(blocks64);
+  hipStream_t s = lsr::as_stream(stream);
+  bool ok = false;
+  switch (PZ) {
+    case 3: ok = lsr::launch_dense_pz3(PYX, p, blocks, s); break;
+    case 5: ok = lsr::launch_dense_pz5(PYX, p, blocks, s); break;
+    case 7: ok = lsr::launch_dense_pz7(PYX, p, blocks, s); break;
+    case 9: ok = lsr::launch_dense_pz9(PYX, p, blocks, s); break;
+    case 11: ok = lsr::launch_dense_pz11(PYX, p, blocks, s); break;
+    default: break;
+  }
+  LSR_REQUIRE(ok, LSR_E_UNSUPPORTED, "no dense specialisation for taps (%d,%d,%d)", pz, py, px);
+  return lsr::launch_status("lsr_correlate_dense_padded_f32");
+}
+
+extern "C" int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane,
+                                       float* x_pad, float* ratio_pad, float* x_out, int64_t Z,
+                                       int64_t Y, int64_t X, const float* taps,
+                                       const float* taps_flipped, int pz, int py, int px,
+                                       const double* norm_table, float norm_full, int iters,
+                                       float eps, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(y);
+  LSR_REQUIRE_PTR(x_pad);
+  LSR_REQUIRE_PTR(ratio_pad);
+  LSR_REQUIRE(iters >= 1, LSR_E_ARG, "iters %d must be >= 1", iters);
+  LSR_REQUIRE(ratio_pad != x_pad, LSR_E_ARG, "x_pad and ratio_pad must be distinct");
+  int64_t ps[4];
+  if (int rc = lsr_sep_padded_shape(Y, X, pz, py, px, ps)) return rc;
+  const int64_t pitch = ps[1], plane = ps[0] * ps[1];
+  const int64_t origin = ps[2] * pitch + ps[3];
+  float* xl = x_pad + origin;
+  float* rl = ratio_pad + origin;
+  for (int it = 0; it < iters; ++it) {
+    int rc = lsr_correlate_dense_padded_f32(xl, pitch, plane, y, y_pitch, y_plane, rl, pitch, plane,
+                                            Z, Y, X, taps_flipped, pz, py, px, LSR_EPI_RATIO, eps,
+                                            nullptr, 0.0f, stream);
+    if (rc) return rc;
+    const bool last = it + 1 == iters && x_out != nullptr;
+    rc = lsr_correlate_dense_padded_f32(rl, pitch, plane, xl, pitch, plane, last ? x_out : xl,
+                                        last ? X : pitch, last ? Y * X : plane, Z, Y, X, taps, pz,
+                                        py, px, LSR_EPI_UPDATE, eps, norm_table, norm_full, stream);
+    if (rc) return rc;
+  }
+  return LSR_OK;
+}

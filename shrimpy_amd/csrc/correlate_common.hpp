@@ -48,6 +48,28 @@ struct SepArgs {
   int z_chunk;
 };
 
+// Tuned dense kernel: like SepArgs.  `taps` is a small DEVICE array prepared by
+// lsr_dense_prepare_taps: layout [c][b][j] over the COMPILED extents (PZ, PYX, PYX), j = PZ-1-a
+// (z reversed: the order in which a staged plane feeds the pending output planes), the caller's
+// taps centred, zeros elsewhere.  The kernel reads it through the constant address space, i.e.
+// the scalar cache: every FMA takes its weight from an SGPR.
+struct DenseArgs {
+  const float* in;
+  const float* aux;
+  float* out;
+  int64_t in_plane, aux_plane, out_plane;
+  int in_pitch, aux_pitch, out_pitch;
+  int Z, Y, X;
+  int pz, py, px;            // the caller's PSF extents (norm table geometry)
+  int epilogue;
+  float eps;
+  float norm_full;           // sum of all taps (interior voxels)
+  const double* norm_table;  // (pz+1)(py+1)(px+1) prefix sums (border voxels)
+  int tiles_x, tiles_y;
+  int z_chunk;
+  const float* taps;
+};
+
 // Tile geometry of the tuned kernel, needed by the host to size the halo (see lsr_sep_halo).
 constexpr int kSepTileY = 32;
 constexpr int kSepTileX = 64;
@@ -74,5 +96,15 @@ LSR_DECL_SEP(11)
 LSR_DECL_SEP(13)
 LSR_DECL_SEP(15)
 #undef LSR_DECL_SEP
+
+// correlate_dense.hip, compiled once per PZ (-DLSR_DENSE_PZ=n); pyx in {3,5,7,9}, PZ*pyx*pyx <= 900.
+#define LSR_DECL_DENSE(n) \
+  bool launch_dense_pz##n(int pyx, const DenseArgs& p, unsigned blocks, hipStream_t s);
+LSR_DECL_DENSE(3)
+LSR_DECL_DENSE(5)
+LSR_DECL_DENSE(7)
+LSR_DECL_DENSE(9)
+LSR_DECL_DENSE(11)
+#undef LSR_DECL_DENSE
 
 }  // namespace lsr

@@ -1,0 +1,324 @@
+// Dense (non-separable) 3-D PSF correlation with fused Richardson-Lucy epilogues -- the
+// fp32-VALU-bound kernel (pz*py*px FMAs per voxel; a 9x7x7 PSF is 441 taps).
+// One translation unit per PZ (-DLSR_DENSE_PZ=n).
+//
+// Same skeleton as correlate_sep.hip: zero-haloed padded input, a 512-thread workgroup owns a
+// 32 x 64 (y, x) column and marches along z, planes are fetched two iterations ahead into
+// registers and committed to a double-buffered LDS window, loads and waits are managed by hand
+// (see the header of correlate_sep.hip for why), one workgroup barrier per plane.
+//
+// The compute differs: every staged plane contributes to PZ pending output planes at once.
+// A thread owns one column and 4 rows; for each in-plane tap (b, c) it holds the 4+PYX-1 column
+// values in registers (conflict-free ds_read_b32) and issues PZ x 4 FMAs whose weight operand is
+// an SGPR: the taps are read through the CONSTANT address space (scalar cache) -- the one way a
+// kernel that also stores to global memory gets scalar loads -- one (b, c) group ahead of its use.
+// An opaque per-plane offset (always 0) keeps hipcc from hoisting all pz*py*px loads out of the
+// plane loop, which would spill ~1800 SGPRs.  The whole tap nest is unrolled (1764 FMAs per
+// thread and plane for 9x7x7).
+//
+// Roofline: 2*pz*py*px flop per voxel per launch against the 157 TFLOP/s fp32 vector peak;
+// algorithmic HBM bytes stay 12 per voxel per launch (far below the VALU time beyond ~120 taps).
+
+#include "common.hpp"
+#include "correlate_common.hpp"
+
+#ifndef LSR_DENSE_PZ
+#error "compile with -DLSR_DENSE_PZ=<odd tap count along z>"
+#endif
+
+namespace {
+
+using lsr::DenseArgs;
+
+constexpr int kTY = lsr::kSepTileY;      // 32
+constexpr int kTX = lsr::kSepTileX;      // 64
+constexpr int kRun = 4;                  // rows per thread
+constexpr int kWaves = kTY / kRun;       // 8
+constexpr int kThreads = 64 * kWaves;    // 512
+constexpr int kBand = 8;
+
+template <int PYX>
+struct Tile {
+  static constexpr int AR = kTY + PYX - 1;
+  static constexpr int AC = kTX + PYX - 1;
+  static constexpr int PA0 = (AC + 3) / 4 * 4;
+  static constexpr int PA = PA0 < 72 ? 72 : PA0;   // must equal lsr::sep_stage_cols(PYX)
+  static constexpr int CH = PA / 4;
+  static constexpr int NCH = AR * CH;
+  static constexpr int SL = (NCH + kThreads - 1) / kThreads;
+  static constexpr int ASZ = AR * PA;
+  static_assert(SL == 2, "the hand-counted waits assume two staging loads per thread");
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float fast_rcp(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ void gload_x4(f32x4& dst, const float* sbase, int voff_bytes) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void gload_x1(float& dst, const float* sbase, int voff_bytes) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_loads(f32x4& a, f32x4& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_loads(float (&a)[kRun]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// H^T 1 at (z, y, x): the sum of the taps whose sample lies inside the volume, from the prefix-sum
+// table P[a][b][c] = sum_{a'<a, b'<b, c'<c} w of the CALLER's pz x py x px PSF.
+__device__ float dense_norm(const DenseArgs& p, int z, int y, int x) {
+  const int cz = p.pz / 2, cy = p.py / 2, cx = p.px / 2;
+  const int a0 = max(0, cz - z), a1 = min(p.pz, p.Z - z + cz);
+  const int b0 = max(0, cy - y), b1 = min(p.py, p.Y - y + cy);
+  const int c0 = max(0, cx - x), c1 = min(p.px, p.X - x + cx);
+  const int sb = p.px + 1, sa = (p.py + 1) * sb;
+  const double* P = p.norm_table;
+  return static_cast<float>(((P[a1 * sa + b1 * sb + c1] - P[a0 * sa + b1 * sb + c1]) -
+                             (P[a1 * sa + b0 * sb + c1] - P[a0 * sa + b0 * sb + c1])) -
+                            ((P[a1 * sa + b1 * sb + c0] - P[a0 * sa + b1 * sb + c0]) -
+                             (P[a1 * sa + b0 * sb + c0] - P[a0 * sa + b0 * sb + c0])));
+}
+
+template <int PZ, int PYX, int EPI>
+__global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) {
+  using T = Tile<PYX>;
+  __shared__ f32x4 bufA4[2 * T::ASZ / 4];
+  constexpr int NA = EPI == LSR_EPI_NONE ? 0 : kRun;  // aux loads per iteration
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // XCD-aware, band-swizzled tile order (see correlate_sep.hip)
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int per = nblk / 8, rem = nblk % 8;
+    const int xcd = bid % 8, idx = bid / 8;
+    bid = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  }
+  const int tiles_xy = p.tiles_x * p.tiles_y;
+  const int zc = bid / tiles_xy;
+  const int lin = bid - zc * tiles_xy;
+  const int band = lin / (p.tiles_x * kBand);
+  const int lb = lin - band * (p.tiles_x * kBand);
+  const int band_h = min(kBand, p.tiles_y - band * kBand);
+  const int tx = lb / band_h;
+  const int ty = band * kBand + (lb - tx * band_h);
+
+  const int Z = p.Z, Y = p.Y, X = p.X;
+  const int x0 = tx * kTX, y0 = ty * kTY;
+  const int zb = zc * p.z_chunk;
+  const int ze = min(zb + p.z_chunk, Z);
+  constexpr int cz = PZ / 2, cyx = PYX / 2;
+
+  // ---- staging (identical to the separable kernel)
+  const float* const in_tile = p.in + (static_cast<int64_t>(y0 - cyx) * p.in_pitch + (x0 - cyx));
+  int s_voff[T::SL], s_loff[T::SL];
+#pragma unroll
+  for (int k = 0; k < T::SL; ++k) {
+    const int e = min(tid + k * kThreads, T::NCH - 1);
+    const int r = e / T::CH, c = e - r * T::CH;
+    s_voff[k] = (r * p.in_pitch + 4 * c) * 4;
+    s_loff[k] = e;
+  }
+  f32x4 st0[T::SL], st1[T::SL];
+
+  // ---- compute / epilogue geometry: column `lane`, rows 4*wave .. 4*wave+3
+  const int acol = (wave * kRun) * T::PA + lane;
+  const int gx_out = x0 + lane;
+  const bool xok = gx_out < X;
+  const int gxc = min(gx_out, X - 1);
+  const int gy_out0 = y0 + wave * kRun;
+  int a_voff[kRun], o_off[kRun];
+  bool ok[kRun];
+#pragma unroll
+  for (int m = 0; m < kRun; ++m) {
+    const int gy = gy_out0 + m;
+    ok[m] = xok && gy < Y;
+    a_voff[m] = (min(gy, Y - 1) * p.aux_pitch + gxc) * 4;
+    o_off[m] = min(gy, Y - 1) * p.out_pitch + gxc;
+  }
+  // in-plane interior test for the norm of the UPDATE epilogue (the caller's PSF extents)
+  bool yx_inside[kRun];
+  {
+    const int ry = p.py / 2, rx = p.px / 2;
+#pragma unroll
+    for (int m = 0; m < kRun; ++m) {
+      const int gy = gy_out0 + m;
+      yx_inside[m] = gy >= ry && gy < Y - ry && gx_out >= rx && gx_out < X - rx;
+    }
+  }
+
+  typedef const float __attribute__((address_space(4))) cfloat;  // constant AS: scalar loads
+  const cfloat* const taps_base = (const cfloat*)p.taps;
+
+  float acc[PZ][kRun];
+#pragma unroll
+  for (int j = 0; j < PZ; ++j)
+#pragma unroll
+    for (int m = 0; m < kRun; ++m) acc[j][m] = 0.0f;
+  float aux0[kRun], aux1[kRun];
+#pragma unroll
+  for (int m = 0; m < kRun; ++m) aux0[m] = aux1[m] = 0.0f;
+
+  const int zi_begin = max(zb - cz, 0);
+  const int zi_end = ze + cz;
+
+  auto fetch = [&](int zplane, f32x4 (&st)[T::SL]) {
+    const float* src = in_tile + static_cast<int64_t>(min(max(zplane, 0), Z - 1)) * p.in_plane;
+    gload_x4(st[0], src, s_voff[0]);
+    gload_x4(st[1], src, s_voff[1]);
+  };
+  auto fetch_aux = [&](int zout, float (&aux)[kRun]) {
+    if constexpr (EPI != LSR_EPI_NONE) {
+      const float* a = p.aux + static_cast<int64_t>(min(max(zout, 0), Z - 1)) * p.aux_plane;
+#pragma unroll
+      for (int m = 0; m < kRun; ++m) gload_x1(aux[m], a, a_voff[m]);
+    }
+  };
+
+  // Iteration zi consumes plane zi+1 (committed one iteration earlier into A[par^1]).
+  auto iteration = [&](const int zi, const int par, f32x4 (&st)[T::SL], float (&aux_use)[kRun],
+                       float (&aux_load)[kRun]) {
+    f32x4* A_commit = bufA4 + par * (T::ASZ / 4);  // plane zi+2
+    const float* A_c = reinterpret_cast<const float*>(bufA4 + (par ^ 1) * (T::ASZ / 4)) + acol;
+
+    wait_loads<2 + 2 * NA>(st[0], st[1]);
+    A_commit[s_loff[0]] = st[0];
+    A_commit[s_loff[1]] = st[1];
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(zi + 4, st);
+    fetch_aux(zi + 2 - cz, aux_load);
+
+    const int zcur = zi + 1;
+    if (zcur >= zi_begin && zcur < zi_end) {  // wave-uniform
+      // pending planes move up by one: acc[j] <-> z_out = zcur - cz + j
+#pragma unroll
+      for (int j = 0; j < PZ - 1; ++j)
+#pragma unroll
+        for (int m = 0; m < kRun; ++m) acc[j][m] = acc[j + 1][m];
+#pragma unroll
+      for (int m = 0; m < kRun; ++m) acc[PZ - 1][m] = 0.0f;
+
+      if (zcur < Z) {
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));  // loop-variant for the optimiser, always 0
+        const cfloat* taps = taps_base + opaque;
+        float wq[2][PZ];
+#pragma unroll
+        for (int j = 0; j < PZ; ++j) wq[0][j] = taps[j];
+#pragma unroll
+        for (int c = 0; c < PYX; ++c) {
+          float cv[kRun + PYX - 1];
+#pragma unroll
+          for (int j = 0; j < kRun + PYX - 1; ++j) cv[j] = A_c[j * T::PA + c];
+#pragma unroll
+          for (int b = 0; b < PYX; ++b) {
+            constexpr int G = PYX * PYX;
+            const int g = c * PYX + b;
+            // taps of the NEXT (b, c) group -> the other SGPR set
+            if (g + 1 < G) {
+#pragma unroll
+              for (int j = 0; j < PZ; ++j) wq[(g + 1) & 1][j] = taps[(g + 1) * PZ + j];
+            }
+#pragma unroll
+            for (int j = 0; j < PZ; ++j)
+#pragma unroll
+              for (int m = 0; m < kRun; ++m) acc[j][m] = fmaf(wq[g & 1][j], cv[m + b], acc[j][m]);
+          }
+        }
+      }
+
+      const int z_out = zcur - cz;
+      if (z_out >= zb) {  // wave-uniform
+        float* o = p.out + static_cast<int64_t>(z_out) * p.out_plane;
+        if constexpr (EPI != LSR_EPI_NONE) wait_loads<2 + NA>(aux_use);
+        if constexpr (EPI == LSR_EPI_RATIO) {
+#pragma unroll
+          for (int m = 0; m < kRun; ++m)
+            if (ok[m]) o[o_off[m]] = aux_use[m] * fast_rcp(acc[0][m] + p.eps);
+        } else if constexpr (EPI == LSR_EPI_UPDATE) {
+          const int rz = p.pz / 2;
+          const bool z_inside = z_out >= rz && z_out < Z - rz;
+#pragma unroll
+          for (int m = 0; m < kRun; ++m) {
+            if (ok[m]) {
+              const float nrm = (z_inside && yx_inside[m]) ? p.norm_full
+                                                           : dense_norm(p, z_out, gy_out0 + m, gx_out);
+              o[o_off[m]] = aux_use[m] * acc[0][m] * fast_rcp(nrm);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < kRun; ++m)
+            if (ok[m]) o[o_off[m]] = acc[0][m];
+        }
+      }
+    }
+    lds_barrier();
+  };
+
+  const int zs = (zi_begin - 2) & ~1;
+  fetch(zs + 2, st0);
+  fetch_aux(zs - cz, aux1);      // placeholder: keeps the load count of an iteration pair
+  fetch(zs + 3, st1);
+  fetch_aux(zs + 1 - cz, aux0);  // output plane of iteration zs
+  for (int zi = zs; zi + 1 < zi_end; zi += 2) {
+    iteration(zi, 0, st0, aux0, aux1);
+    iteration(zi + 1, 1, st1, aux1, aux0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int PZ, int PYX>
+bool launch_one(const DenseArgs& p, dim3 grid, hipStream_t s) {
+  {
+    const dim3 block(kThreads);
+    switch (p.epilogue) {
+      case LSR_EPI_NONE:
+        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_NONE>), grid, block, 0, s, p);
+        return true;
+      case LSR_EPI_RATIO:
+        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_RATIO>), grid, block, 0, s, p);
+        return true;
+      case LSR_EPI_UPDATE:
+        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_UPDATE>), grid, block, 0, s, p);
+        return true;
+      default:
+        return false;
+    }
+  }
+}
+
+}  // namespace
+
+namespace lsr {
+
+#define LSR_CAT2(a, b) a##b
+#define LSR_CAT(a, b) LSR_CAT2(a, b)
+bool LSR_CAT(launch_dense_pz, LSR_DENSE_PZ)(int pyx, const DenseArgs& p, unsigned blocks, hipStream_t s) {
+  constexpr int PZ = LSR_DENSE_PZ;
+  const dim3 grid(blocks);
+  switch (pyx) {
+    case 3: return launch_one<PZ, 3>(p, grid, s);
+    case 5: return launch_one<PZ, 5>(p, grid, s);
+    case 7: return launch_one<PZ, 7>(p, grid, s);
+    case 9: return launch_one<PZ, 9>(p, grid, s);
+    default: return false;
+  }
+}
+
+}  // namespace lsr

@@ -100,6 +100,23 @@ def _prefix_table(w: np.ndarray) -> np.ndarray:
     return t
 
 
+def prepared_dense_taps(psf: np.ndarray):
+    """``(taps, taps_flipped)`` host arrays in the tuned dense kernel's layout, or ``None`` when the
+    PSF is outside its range (pz <= 11, py, px <= 9): see ``lsr_dense_prepare_taps``."""
+    pz, py, px = (int(v) for v in psf.shape)
+    lib = _lib.load()
+    n = lib.lsr_dense_taps_count(pz, py, px)
+    if n < 0:
+        return None
+    src = np.ascontiguousarray(psf, dtype=np.float32)
+    out = []
+    for flip in (0, 1):
+        buf = np.empty(n, dtype=np.float32)
+        _lib.call("lsr_dense_prepare_taps", src.ctypes.data, pz, py, px, flip, buf.ctypes.data)
+        out.append(buf)
+    return tuple(out)
+
+
 def padded_shape(shape_zyx, psf_shape):
     """Padded plane geometry the tuned separable kernel reads through (``lsr_sep_padded_shape``).
 
@@ -139,6 +156,9 @@ class _DevicePsf:
     w: object | None = None
     w_flipped: object | None = None
     norm_table: object | None = None
+    taps: object | None = None          # tuned dense kernel: host-prepared tap arrays (device)
+    taps_flipped: object | None = None
+    norm_full: float = 1.0
 
 
 class RichardsonLucyPlan:
@@ -196,7 +216,11 @@ class RichardsonLucyPlan:
                 w=dev(w.ravel()),
                 w_flipped=dev(w[::-1, ::-1, ::-1].ravel()),
                 norm_table=dev(_prefix_table(w).ravel(), torch.float64),
+                norm_full=float(w.astype(np.float64).sum()),
             )
+            taps = prepared_dense_taps(w)
+            if taps is not None:  # PSF small enough for the tuned dense kernel
+                self._psf.taps, self._psf.taps_flipped = dev(taps[0]), dev(taps[1])
             self._norm = None
         self._ratio = None   # dense path: ratio scratch
         self._x_pad = None   # separable path: zero-haloed working volumes
@@ -209,7 +233,7 @@ class RichardsonLucyPlan:
     def _scratch(self):
         import torch
 
-        if self._psf.separable:
+        if self._psf.separable or self._psf.taps is not None:
             if self._x_pad is None:
                 self._x_pad = PaddedVolume(self.shape, self._psf.shape, self.device)
                 self._ratio_pad = PaddedVolume(self.shape, self._psf.shape, self.device)
@@ -268,6 +292,18 @@ class RichardsonLucyPlan:
                     ps.shape[2], nz.data_ptr(), ny.data_ptr(), nx.data_ptr(), iterations,
                     ctypes.c_float(eps), stream,
                 )
+            elif ps.taps is not None:
+                x_pad, ratio_pad = self._scratch()
+                x_pad.view.copy_(init)
+                if events:
+                    events[0].record()
+                _lib.call(
+                    "lsr_rl_dense_padded_f32", y.data_ptr(), xx, yy * xx, x_pad.full.data_ptr(),
+                    ratio_pad.full.data_ptr(), x.data_ptr(), z, yy, xx, ps.taps.data_ptr(),
+                    ps.taps_flipped.data_ptr(), ps.shape[0], ps.shape[1], ps.shape[2],
+                    ps.norm_table.data_ptr(), ctypes.c_float(ps.norm_full), iterations,
+                    ctypes.c_float(eps), stream,
+                )
             else:
                 x.copy_(init)
                 ratio = self._scratch()
@@ -305,11 +341,12 @@ def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=Non
     return plan(y, iterations=iterations, eps=eps, x0=x0)
 
 
-def correlate3d(volume, weights=None, *, weight_factors=None):
+def correlate3d(volume, weights=None, *, weight_factors=None, tuned: bool = True):
     """``scipy.ndimage.correlate(volume, weights, mode="constant", cval=0)`` on the device.
 
-    Pass ``weight_factors=(wz, wy, wx)`` for the separable kernel.  (The un-fused building block of
-    the RL launches; also used for PSF-blurring synthetic scenes.)
+    Pass ``weight_factors=(wz, wy, wx)`` for the separable kernel.  ``tuned=False`` forces the
+    generic bounds-checked dense kernel (any size up to 15 taps per axis).  (The un-fused building
+    block of the RL launches; also used for PSF-blurring synthetic scenes.)
     """
     import torch
 
@@ -336,12 +373,23 @@ def correlate3d(volume, weights=None, *, weight_factors=None):
             )
         else:
             w = prepare_psf(weights)
-            dw = dev(w.ravel())
-            _lib.call(
-                "lsr_correlate_dense_f32", vol.data_ptr(), out.data_ptr(), None, z, y, x,
-                dw.data_ptr(), w.shape[0], w.shape[1], w.shape[2], _lib.EPI_NONE,
-                ctypes.c_float(0.0), None, stream,
-            )
+            taps = prepared_dense_taps(w) if tuned else None
+            if taps is not None:
+                dt = dev(taps[0])
+                pad = PaddedVolume(vol.shape, w.shape, vol.device)
+                pad.view.copy_(vol)
+                _lib.call(
+                    "lsr_correlate_dense_padded_f32", pad.logical_ptr(), pad.pitch, pad.plane, None, 0, 0,
+                    out.data_ptr(), x, y * x, z, y, x, dt.data_ptr(), w.shape[0], w.shape[1], w.shape[2],
+                    _lib.EPI_NONE, ctypes.c_float(0.0), None, ctypes.c_float(1.0), stream,
+                )
+            else:
+                dw = dev(w.ravel())
+                _lib.call(
+                    "lsr_correlate_dense_f32", vol.data_ptr(), out.data_ptr(), None, z, y, x,
+                    dw.data_ptr(), w.shape[0], w.shape[1], w.shape[2], _lib.EPI_NONE,
+                    ctypes.c_float(0.0), None, stream,
+                )
         # the tap tensors must outlive the launch: the caching allocator keeps their blocks on
         # this stream, so reuse after free is stream-ordered
     return out

@@ -197,8 +197,10 @@ def test_correlate_sep_and_dense_vs_scipy(device, pshape, vshape):
     ks = [rng.random(n).astype(np.float32) + 0.1 for n in pshape]
     w = (ks[0][:, None, None] * ks[1][None, :, None] * ks[2][None, None, :]).astype(np.float32)
     ref = ndimage.correlate(vol, w, mode="constant", cval=0.0)
-    dense = correlate3d(_t(vol, device), w).cpu().numpy()
+    dense = correlate3d(_t(vol, device), w).cpu().numpy()            # tuned where pz<=11, pyx<=9
     _close(dense, ref, 2e-5, 2e-6)
+    generic = correlate3d(_t(vol, device), w, tuned=False).cpu().numpy()
+    _close(generic, ref, 2e-5, 2e-6)
     sep = correlate3d(_t(vol, device), weight_factors=ks).cpu().numpy()
     _close(sep, ref, 2e-5, 2e-6)
 
