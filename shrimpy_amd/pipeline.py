@@ -154,12 +154,18 @@ def run_sharded(
     store: Callable[[object, object], None],
     *,
     synchronize: Callable[[], None] | None = None,
+    overlap_io: bool = True,
 ) -> ShardReport:
     """Run ``store(unit, process(load(unit)))`` for this rank's share of ``units``.
 
     Rank and world size come from the initialised ``torch.distributed`` group (single process
     otherwise).  There is no data-path collective; a barrier brackets the timed region and the
     reported job time is the max over ranks.
+
+    With ``overlap_io`` the host side is a three-stage pipeline: while the GPU processes unit k, one
+    background thread reads unit k+1 (``load``) and another writes unit k-1 (``store``), so disk
+    I/O hides behind compute (at config-2 size a volume is 8.6 GB in and 3.2 GB out against ~90 ms
+    of kernels: the I/O is what needs hiding).  ``process`` always runs on the calling thread.
     """
     import torch
 
@@ -173,8 +179,26 @@ def run_sharded(
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for unit in mine:
-        store(unit, process(load(unit)))
+    if overlap_io and len(mine) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(1, "lsr-load") as loader, ThreadPoolExecutor(1, "lsr-store") as storer:
+            pending_store = None
+            nxt = loader.submit(load, mine[0])
+            for i, unit in enumerate(mine):
+                data = nxt.result()
+                if i + 1 < len(mine):
+                    nxt = loader.submit(load, mine[i + 1])
+                result = process(data)
+                sync()  # the result must be complete before another thread reads it
+                if pending_store is not None:
+                    pending_store.result()  # surface store errors, keep at most one in flight
+                pending_store = storer.submit(store, unit, result)
+            if pending_store is not None:
+                pending_store.result()
+    else:
+        for unit in mine:
+            store(unit, process(load(unit)))
     sync()
     seconds = time.perf_counter() - t0
     max_seconds = seconds

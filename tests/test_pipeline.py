@@ -130,3 +130,45 @@ def test_volume_reconstructor_matches_oracle(device):
     tol = 1e-4 * np.abs(ref) + 5e-5 * np.abs(ref).max()
     assert np.all(np.abs(out - ref) <= tol)
     assert torch.cuda.is_available()
+
+
+def test_run_sharded_overlaps_io_with_compute_and_keeps_order():
+    """Loads run one unit ahead and stores one unit behind, on background threads; results are
+    the same as the serial loop and errors in a store surface."""
+    import threading
+    import time as _t
+
+    from shrimpy_amd.pipeline import run_sharded
+
+    events, out = [], {}
+    main = threading.get_ident()
+
+    def load(u):
+        events.append(("load", u, threading.get_ident() != main))
+        _t.sleep(0.02)
+        return u
+
+    def process(v):
+        events.append(("process", v, threading.get_ident() == main))
+        _t.sleep(0.02)
+        return v * 10
+
+    def store(u, v):
+        events.append(("store", u, threading.get_ident() != main))
+        out[u] = v
+
+    rep = run_sharded(list(range(6)), load, process, store)
+    assert out == {i: i * 10 for i in range(6)} and rep.units == list(range(6))
+    assert all(flag for _, _, flag in events)            # loads/stores off-thread, process on-thread
+    order = [(k, u) for k, u, _ in events]
+    assert order.index(("load", 1)) < order.index(("store", 0))  # unit 1 was being read before 0 was written
+    serial = {}
+    run_sharded(list(range(6)), lambda u: u, lambda v: v * 10, lambda u, v: serial.__setitem__(u, v),
+                overlap_io=False)
+    assert serial == out
+
+    def bad_store(u, v):
+        raise OSError("disk full")
+
+    with pytest.raises(OSError, match="disk full"):
+        run_sharded(list(range(3)), lambda u: u, lambda v: v, bad_store)
