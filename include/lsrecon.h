@@ -47,6 +47,9 @@ extern "C" {
 /* Border rule of the order-1 sampler. */
 #define LSR_MODE_CONSTANT 0      /* scipy mode="constant": any coordinate outside [0,n-1] -> cval */
 #define LSR_MODE_GRID_CONSTANT 1 /* scipy mode="grid-constant": blend towards cval over one voxel */
+/* OR-able flag for lsr_affine_f32: interpolate in f32 (coordinates and border decisions stay
+ * fp64). Not bit-identical to scipy (~1e-6 relative) but HBM-bound instead of fp64-VALU-bound. */
+#define LSR_MODE_F32_INTERP 256
 
 /* Which half of a Richardson-Lucy iteration a correlation launch finishes (fused epilogue). */
 #define LSR_EPI_NONE 0   /* out = corr(in)                                  (plain correlation) */

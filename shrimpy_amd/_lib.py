@@ -25,6 +25,7 @@ HEADER_PATH = Path(__file__).resolve().parent.parent / "include" / "lsrecon.h"
 # include/lsrecon.h constants
 MODE_CONSTANT = 0
 MODE_GRID_CONSTANT = 1
+MODE_F32_INTERP = 256
 EPI_NONE = 0
 EPI_RATIO = 1
 EPI_UPDATE = 2

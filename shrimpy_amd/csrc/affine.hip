@@ -61,7 +61,7 @@ __device__ __forceinline__ bool axis_tap(double c, int n, AxisTap& t) {
   return true;
 }
 
-template <bool GRID>
+template <bool GRID, bool F32>
 __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
   int bid = blockIdx.x;
   const int tx = bid % p.tiles_x;
@@ -94,6 +94,34 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
     float result = p.cval;
     if (axis_tap<GRID>(cz, p.Zi, tz) && axis_tap<GRID>(cy, p.Yi, ty_) &&
         axis_tap<GRID>(cx, p.Xi, tx_)) {
+      if constexpr (F32) {
+        // LSR_MODE_F32_INTERP: fp64 coordinates (border decisions unchanged), f32 weights and
+        // FMAs -- not bit-identical to scipy (~1e-6 relative), HBM-bound instead of fp64-bound
+        const float wz1 = static_cast<float>(tz.w1), wy1 = static_cast<float>(ty_.w1),
+                    wx1 = static_cast<float>(tx_.w1);
+        float v[2][2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int64_t o = (a ? tz.i1 : tz.i0) * sz + static_cast<int64_t>(b ? ty_.i1 : ty_.i0) * p.Xi +
+                                (c ? tx_.i1 : tx_.i0);
+              float val = p.in[o];
+              if (GRID && ((a ? tz.out1 : tz.out0) || (b ? ty_.out1 : ty_.out0) || (c ? tx_.out1 : tx_.out0)))
+                val = p.cval;
+              v[a][b][c] = val;
+            }
+        float r2[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) r2[a][b] = fmaf(wx1, v[a][b][1] - v[a][b][0], v[a][b][0]);
+        const float r10 = fmaf(wy1, r2[0][1] - r2[0][0], r2[0][0]);
+        const float r11 = fmaf(wy1, r2[1][1] - r2[1][0], r2[1][0]);
+        result = fmaf(wz1, r11 - r10, r10);
+      } else {
       double t = 0.0;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
@@ -119,6 +147,7 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
         }
       }
       result = static_cast<float>(t);
+      }
     }
     orow[xo] = result;
   }
@@ -141,6 +170,8 @@ extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t X
   const int64_t lim = int64_t(1) << 30;
   LSR_REQUIRE(Zi < lim && Yi < lim && Xi < lim && Zo < lim && Yo < lim && Xo < lim,
               LSR_E_UNSUPPORTED, "a dimension exceeds 2^30");
+  const bool f32 = (mode & LSR_MODE_F32_INTERP) != 0;
+  mode &= ~LSR_MODE_F32_INTERP;
   LSR_REQUIRE(mode == LSR_MODE_CONSTANT || mode == LSR_MODE_GRID_CONSTANT, LSR_E_ARG,
               "unknown border mode %d", mode);
   for (int i = 0; i < 12; ++i)
@@ -160,10 +191,13 @@ extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t X
   LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
               (long long)blocks);
   const dim3 grid(static_cast<unsigned>(blocks)), block(kThreads);
+  hipStream_t s = lsr::as_stream(stream);
   if (mode == LSR_MODE_GRID_CONSTANT) {
-    hipLaunchKernelGGL(affine_kernel<true>, grid, block, 0, lsr::as_stream(stream), p);
+    if (f32) hipLaunchKernelGGL((affine_kernel<true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((affine_kernel<true, false>), grid, block, 0, s, p);
   } else {
-    hipLaunchKernelGGL(affine_kernel<false>, grid, block, 0, lsr::as_stream(stream), p);
+    if (f32) hipLaunchKernelGGL((affine_kernel<false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((affine_kernel<false, false>), grid, block, 0, s, p);
   }
   return lsr::launch_status("lsr_affine_f32");
 }

@@ -23,7 +23,8 @@ _MODES = {"constant": _lib.MODE_CONSTANT, "grid-constant": _lib.MODE_GRID_CONSTA
 
 
 def apply_affine_transform_zyx(moving, affine_transform_zyx, output_shape_zyx=None, *,
-                               mode: str = "constant", cval: float = 0.0, out=None):
+                               mode: str = "constant", cval: float = 0.0, out=None,
+                               exact: bool = True):
     """Resample ``moving`` (Z, Y, X float32 device tensor) onto the target grid.
 
     Parameters
@@ -32,6 +33,9 @@ def apply_affine_transform_zyx(moving, affine_transform_zyx, output_shape_zyx=No
     output_shape_zyx : target grid shape; defaults to ``moving.shape``.
     mode : ``"constant"`` (scipy default: any coordinate outside ``[0, n-1]`` gives ``cval``) or
         ``"grid-constant"`` (blend towards ``cval`` across the border).
+    exact : ``True`` (default) interpolates in fp64 in scipy's operation order -- bit-identical to
+        ``scipy.ndimage.affine_transform``; ``False`` interpolates in float32 (border decisions
+        unchanged, ~1e-6 relative difference), which is about 2x faster (HBM-bound).
     """
     import torch
 
@@ -60,7 +64,8 @@ def apply_affine_transform_zyx(moving, affine_transform_zyx, output_shape_zyx=No
     with torch.cuda.device(moving.device):
         _lib.call(
             "lsr_affine_f32", moving.data_ptr(), zi, yi, xi, out.data_ptr(), shape[0], shape[1],
-            shape[2], _lib.matrix12(m), ctypes.c_float(float(cval)), _MODES[mode],
+            shape[2], _lib.matrix12(m), ctypes.c_float(float(cval)),
+            _MODES[mode] | (0 if exact else _lib.MODE_F32_INTERP),
             _lib.stream_ptr(moving.device),
         )
     return out

@@ -157,6 +157,22 @@ def test_affine_vs_oracle_bit_exact(device, mode, shape, out_shape):
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("mode", ["constant", "grid-constant"])
+def test_affine_f32_interpolation_mode_is_close_and_keeps_the_border(device, mode):
+    """``exact=False``: f32 interpolation; tolerance 2e-5 of the data range, and the
+    in/out-of-range decisions (exact zeros of mode="constant") are unchanged."""
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    rng = np.random.default_rng(35)
+    vol = (rng.random((20, 96, 130)) * 1000).astype(np.float32)
+    m = _config3_matrix()
+    ref = o.affine_apply_4x4(vol, m, vol.shape, cval=0.0, mode=mode)
+    out = apply_affine_transform_zyx(_t(vol, device), m, mode=mode, exact=False).cpu().numpy()
+    assert np.abs(out - ref).max() <= 2e-5 * 1000
+    if mode == "constant":
+        np.testing.assert_array_equal(out == 0, ref == 0)
+
+
 def test_affine_border_rule_exact_on_grid_points(device):
     """Coordinates that land exactly on 0 and n-1 are inside; -1e-9 is outside."""
     from shrimpy_amd.register import affine_transform

@@ -58,10 +58,10 @@ def main():
     m = np.eye(4)
     m[:3, :3] = rot @ np.diag([1.0, 0.98, 1.02])
     m[:3, 3] = [3.5, -12.25, 20.75]
-    for mode in ("constant", "grid-constant"):
-        ms = timed(lambda: apply_affine_transform_zyx(vol, m, mode=mode, out=out), args.reps)
+    for mode, exact in (("constant", True), ("grid-constant", True), ("constant", False)):
+        ms = timed(lambda: apply_affine_transform_zyx(vol, m, mode=mode, out=out, exact=exact), args.reps)
         nbytes = 8.0 * vol.numel()
-        print(json.dumps({"kernel": f"affine_kernel ({mode})", "shape": shape, "ms": ms,
+        print(json.dumps({"kernel": f"affine_kernel ({mode}, {'exact fp64' if exact else 'f32 interp'})", "shape": shape, "ms": ms,
                           "algorithmic_GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / 8000,
                           "voxels_per_s": vol.numel() / (ms * 1e-3)}))
     del vol, out
