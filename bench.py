@@ -192,7 +192,8 @@ def main():
         plan = RichardsonLucyPlan(out_shape, None, device, psf_factors=gaussian_factors())
     else:
         plan = RichardsonLucyPlan(out_shape, rotated_psf(), device, separable="never")
-    deskewed = torch.empty(out_shape, dtype=torch.float32, device=device)
+    # the deskew kernel writes straight into the RL kernels' padded, line-aligned input volume
+    deskewed = plan.new_padded_input() if (plan.separable or args.psf == "dense") else torch.empty(out_shape, dtype=torch.float32, device=device)
     estimate = torch.empty(out_shape, dtype=torch.float32, device=device)
 
     from shrimpy_amd.deskew import deskew_with_matrix
@@ -213,8 +214,8 @@ def main():
 
     # sanity: the drop-in entry point gives the same tensor as the preallocated-output form
     if rank == 0 and args.workload in ("config1", "small"):
-        assert torch.equal(fast_deskew_zyx(raw_data=raw, **DESKEW),
-                           deskew_with_matrix(raw, geo.matrix_3x4, geo.pre_average_shape, 3))
+        padded = deskew_with_matrix(raw, geo.matrix_3x4, geo.pre_average_shape, 3, out=plan.new_padded_input())
+        assert torch.equal(fast_deskew_zyx(raw_data=raw, **DESKEW), padded.view)
 
     def barrier():
         if world > 1:

@@ -65,7 +65,9 @@ const char* lsr_last_error(void);
  * Oblique-plane deskew with the slice averaging fused in.
  *
  *   in   raw stack (Z, Y, X) = (scan, tilt, coverslip)
- *   out  (Zo, Yo, Xo); Zo == ceil(Zd / avg_n), where Zd is the deskewed depth BEFORE averaging
+ *   out  (Zo, Yo, Xo) with strides out_pitch (y) and out_plane (z) in floats -- dense: Xo and
+ *        Yo*Xo; a padded volume (lsr_sep_padded_shape) lets the deskew write the RL input in
+ *        place, on cache-line-aligned rows; Zo == ceil(Zd / avg_n), Zd = depth BEFORE averaging
  *   M    output->input map over the PRE-average grid (Zd, Yo, Xo). It must have the deskew
  *        structure: row 0 = (a, 0, b, c) (only z_in is interpolated), row 1 = (+-1, 0, 0, int),
  *        row 2 = (0, +-1, 0, int). Anything else returns LSR_E_UNSUPPORTED: use
@@ -77,8 +79,8 @@ const char* lsr_last_error(void);
  * rounded to f32 once), then ((d0+d1)+...)/avg_n in f32: bit-identical to the CPU oracle.
  */
 int lsr_deskew_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo,
-                   int64_t Yo, int64_t Xo, int64_t Zd, const double M[12], int avg_n,
-                   lsr_stream_t stream);
+                   int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd,
+                   const double M[12], int avg_n, lsr_stream_t stream);
 
 /*
  * General order-1 (trilinear) affine resample; any 3x4 matrix.
@@ -153,16 +155,17 @@ int lsr_correlate_sep_strided_f32(const float* in, int64_t in_pitch, int64_t in_
  *
  * Separable: k* = PSF factors along z, y, x, k*_flipped the same reversed (H = correlation with
  * the flipped taps). `x_pad` and `ratio_pad` are padded volumes (lsr_sep_padded_shape) with zero
- * halos: the caller writes the initial estimate (normally y) into the logical window of `x_pad`;
- * `ratio_pad` is scratch. The final estimate is written to the dense (Z, Y, X) `x_out`, or left
+ * halos: the caller writes the initial estimate into the logical window of `x_pad` -- or sets
+ * `init_from_y`, which starts from x = y without that copy (then `y` itself must live in a padded
+ * volume with a zero halo, e.g. written there by lsr_deskew_f32); `ratio_pad` is scratch. The final estimate is written to the dense (Z, Y, X) `x_out`, or left
  * in `x_pad` if `x_out` is NULL. `y` points at its logical (0,0,0) with strides y_pitch / y_plane
  * (dense: X and Y*X; a padded y keeps the ratio launch's reads on cache-line boundaries).
  *
  * Dense: psf = pz*py*px floats, psf_flipped = the same reversed on all three axes; x (dense) is
  * updated in place (caller initialises it), `ratio` is dense scratch.
  */
-int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, float* x_pad,
-                   float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X,
+int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
+                   float* x_pad, float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X,
                    const float* kz, const float* kz_flipped, int pz,
                    const float* ky, const float* ky_flipped, int py, const float* kx,
                    const float* kx_flipped, int px, const float* nz, const float* ny,
@@ -194,8 +197,8 @@ int lsr_correlate_dense_padded_f32(const float* in, int64_t in_pitch, int64_t in
                                    int epilogue, float eps, const double* norm_table,
                                    float norm_full, lsr_stream_t stream);
 
-int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane, float* x_pad,
-                            float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X,
+int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
+                            float* x_pad, float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X,
                             const float* taps, const float* taps_flipped, int pz, int py, int px,
                             const double* norm_table, float norm_full, int iters, float eps,
                             lsr_stream_t stream);

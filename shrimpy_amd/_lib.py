@@ -41,7 +41,7 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 # symbol -> argtypes; every function returns int except lsr_last_error.
 SIGNATURES: dict[str, list] = {
     "lsr_version": [],
-    "lsr_deskew_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _f64p, _int, _stream],
+    "lsr_deskew_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p, _int, _stream],
     "lsr_affine_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _f64p, _f32, _int, _stream],
     "lsr_average_slices_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _int, _stream],
     "lsr_correlate_sep_f32": [
@@ -58,7 +58,7 @@ SIGNATURES: dict[str, list] = {
         _c_f32p, _int, _c_f32p, _int, _c_f32p, _int, _int, _f32, _c_f32p, _c_f32p, _c_f32p, _stream,
     ],
     "lsr_rl_sep_f32": [
-        _c_f32p, _i64, _i64, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _c_f32p,
+        _c_f32p, _i64, _i64, _int, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _c_f32p,
         _c_f32p, _int, _c_f32p, _c_f32p, _int, _c_f32p, _c_f32p, _c_f32p, _int, _f32, _stream,
     ],
     "lsr_dense_taps_count": [_int, _int, _int],
@@ -68,7 +68,7 @@ SIGNATURES: dict[str, list] = {
         _c_f32p, _int, _int, _int, _int, _f32, ctypes.c_void_p, _f32, _stream,
     ],
     "lsr_rl_dense_padded_f32": [
-        _c_f32p, _i64, _i64, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p,
+        _c_f32p, _i64, _i64, _int, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p,
         _int, _int, _int, ctypes.c_void_p, _f32, _int, _f32, _stream,
     ],
     "lsr_rl_dense_f32": [

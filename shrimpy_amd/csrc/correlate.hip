@@ -416,9 +416,9 @@ extern "C" int lsr_correlate_dense_f32(const float* in, float* out, const float*
   return launch_correlate<false>(p, lsr::as_stream(stream));
 }
 
-extern "C" int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, float* x_pad,
-                              float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X,
-                              const float* kz,
+extern "C" int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
+                              float* x_pad, float* ratio_pad, float* x_out, int64_t Z, int64_t Y,
+                              int64_t X, const float* kz,
                               const float* kz_flipped, int pz, const float* ky,
                               const float* ky_flipped, int py, const float* kx,
                               const float* kx_flipped, int px, const float* nz, const float* ny,
@@ -435,15 +435,20 @@ extern "C" int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, 
   float* xl = x_pad + origin;        // logical (0,0,0) inside the padded volumes
   float* rl = ratio_pad + origin;
   for (int it = 0; it < iters; ++it) {
-    // ratio = y / (H x + eps);  H x = convolve(x, psf) = correlate(x, flipped psf)
-    int rc = lsr_correlate_sep_strided_f32(xl, pitch, plane, y, y_pitch, y_plane, rl, pitch, plane, Z, Y, X,
-                                           kz_flipped, pz, ky_flipped, py, kx_flipped, px,
-                                           LSR_EPI_RATIO, eps, nullptr, nullptr, nullptr, stream);
+    // ratio = y / (H x + eps);  H x = convolve(x, psf) = correlate(x, flipped psf).
+    // With init_from_y the first iteration reads x = y straight from the (padded) y volume.
+    const bool from_y = init_from_y && it == 0;
+    const float* xin = from_y ? y : xl;
+    const int64_t xin_pitch = from_y ? y_pitch : pitch, xin_plane = from_y ? y_plane : plane;
+    int rc = lsr_correlate_sep_strided_f32(xin, xin_pitch, xin_plane, y, y_pitch, y_plane, rl, pitch,
+                                           plane, Z, Y, X, kz_flipped, pz, ky_flipped, py,
+                                           kx_flipped, px, LSR_EPI_RATIO, eps, nullptr, nullptr,
+                                           nullptr, stream);
     if (rc) return rc;
     // x <- x * H^T ratio / H^T 1;  H^T r = correlate(r, psf).  The last update may go straight
     // to the dense result.
     const bool last = it + 1 == iters && x_out != nullptr;
-    rc = lsr_correlate_sep_strided_f32(rl, pitch, plane, xl, pitch, plane, last ? x_out : xl,
+    rc = lsr_correlate_sep_strided_f32(rl, pitch, plane, xin, xin_pitch, xin_plane, last ? x_out : xl,
                                        last ? X : pitch, last ? Y * X : plane, Z, Y, X, kz, pz, ky,
                                        py, kx, px, LSR_EPI_UPDATE, eps, nz, ny, nx, stream);
     if (rc) return rc;
@@ -586,7 +591,8 @@ extern "C" int lsr_correlate_dense_padded_f32(
 }
 
 extern "C" int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane,
-                                       float* x_pad, float* ratio_pad, float* x_out, int64_t Z,
+                                       int init_from_y, float* x_pad, float* ratio_pad,
+                                       float* x_out, int64_t Z,
                                        int64_t Y, int64_t X, const float* taps,
                                        const float* taps_flipped, int pz, int py, int px,
                                        const double* norm_table, float norm_full, int iters,
@@ -603,12 +609,15 @@ extern "C" int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t 
   float* xl = x_pad + origin;
   float* rl = ratio_pad + origin;
   for (int it = 0; it < iters; ++it) {
-    int rc = lsr_correlate_dense_padded_f32(xl, pitch, plane, y, y_pitch, y_plane, rl, pitch, plane,
-                                            Z, Y, X, taps_flipped, pz, py, px, LSR_EPI_RATIO, eps,
-                                            nullptr, 0.0f, stream);
+    const bool from_y = init_from_y && it == 0;
+    const float* xin = from_y ? y : xl;
+    const int64_t xin_pitch = from_y ? y_pitch : pitch, xin_plane = from_y ? y_plane : plane;
+    int rc = lsr_correlate_dense_padded_f32(xin, xin_pitch, xin_plane, y, y_pitch, y_plane, rl, pitch,
+                                            plane, Z, Y, X, taps_flipped, pz, py, px, LSR_EPI_RATIO,
+                                            eps, nullptr, 0.0f, stream);
     if (rc) return rc;
     const bool last = it + 1 == iters && x_out != nullptr;
-    rc = lsr_correlate_dense_padded_f32(rl, pitch, plane, xl, pitch, plane, last ? x_out : xl,
+    rc = lsr_correlate_dense_padded_f32(rl, pitch, plane, xin, xin_pitch, xin_plane, last ? x_out : xl,
                                         last ? X : pitch, last ? Y * X : plane, Z, Y, X, taps, pz,
                                         py, px, LSR_EPI_UPDATE, eps, norm_table, norm_full, stream);
     if (rc) return rc;

@@ -34,6 +34,7 @@ struct DeskewArgs {
   float* out;
   int64_t Z, Y, X;          // raw
   int64_t Zo, Yo, Xo, Zd;   // output, and pre-average depth
+  int64_t out_pitch, out_plane;  // output strides in floats (dense: Xo, Yo*Xo)
   double a, b, c;           // z_in = a*zd + b*xo + c
   int64_t oy, ox;
   int sy, sx;
@@ -129,11 +130,11 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
 
   if (li < n_xo) {
     const float denom = static_cast<float>(p.avg_n);
-    float* dst = p.out + (zo * p.Yo + yo0) * p.Xo + xo0 + li;
+    float* dst = p.out + zo * p.out_plane + yo0 * p.out_pitch + xo0 + li;
 #pragma unroll
     for (int m = 0; m < kRowsPerThread; ++m) {
       const int j = lj0 + 4 * m;
-      if (j < n_yo) dst[static_cast<int64_t>(j) * p.Xo] = (p.avg_n > 1) ? acc[m] / denom : acc[m];
+      if (j < n_yo) dst[static_cast<int64_t>(j) * p.out_pitch] = (p.avg_n > 1) ? acc[m] / denom : acc[m];
     }
   }
 }
@@ -163,8 +164,9 @@ bool is_integer(double v) { return v == static_cast<double>(static_cast<int64_t>
 }  // namespace
 
 extern "C" int lsr_deskew_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* out,
-                              int64_t Zo, int64_t Yo, int64_t Xo, int64_t Zd, const double M[12],
-                              int avg_n, lsr_stream_t stream) {
+                              int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch,
+                              int64_t out_plane, int64_t Zd, const double M[12], int avg_n,
+                              lsr_stream_t stream) {
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE_PTR(M);
@@ -177,6 +179,9 @@ extern "C" int lsr_deskew_f32(const float* in, int64_t Z, int64_t Y, int64_t X, 
               kMaxAvg);
   LSR_REQUIRE(Zo == lsr::ceil_div(Zd, avg_n), LSR_E_SHAPE,
               "Zo %lld != ceil(Zd %lld / avg_n %d)", (long long)Zo, (long long)Zd, avg_n);
+  LSR_REQUIRE(out_pitch >= Xo && out_plane >= Yo * out_pitch, LSR_E_SHAPE,
+              "output strides (%lld, %lld) are smaller than the output plane (%lld x %lld)",
+              (long long)out_pitch, (long long)out_plane, (long long)Yo, (long long)Xo);
   for (int i = 0; i < 12; ++i)
     LSR_REQUIRE(M[i] == M[i] && M[i] - M[i] == 0.0, LSR_E_ARG, "M[%d] is not finite", i);
 
@@ -193,6 +198,7 @@ extern "C" int lsr_deskew_f32(const float* in, int64_t Z, int64_t Y, int64_t X, 
   p.out = out;
   p.Z = Z; p.Y = Y; p.X = X;
   p.Zo = Zo; p.Yo = Yo; p.Xo = Xo; p.Zd = Zd;
+  p.out_pitch = out_pitch; p.out_plane = out_plane;
   p.a = M[0]; p.b = M[2]; p.c = M[3];
   p.sy = static_cast<int>(M[4]); p.oy = static_cast<int64_t>(M[7]);
   p.sx = static_cast<int>(M[9]); p.ox = static_cast<int64_t>(M[11]);

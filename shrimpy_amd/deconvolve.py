@@ -242,6 +242,16 @@ class RichardsonLucyPlan:
             self._ratio = torch.empty(self.shape, dtype=torch.float32, device=self.device)
         return self._ratio
 
+    def padded_geometry(self):
+        """(pitch, plane, rows, origin_row, origin_col) of this plan's padded working volumes."""
+        rows, pitch, oy, ox = padded_shape(self.shape, self._psf.shape)
+        return pitch, rows * pitch, rows, oy, ox
+
+    def new_padded_input(self) -> "PaddedVolume":
+        """A zero-haloed volume in this plan's geometry, for a producer (the deskew kernel) to write
+        ``y`` into; pass it to ``plan(...)`` to skip both the pad copy and the ``x0 = y`` copy."""
+        return PaddedVolume(self.shape, self._psf.shape, self.device)
+
     def release(self) -> None:
         """Drop the scratch volumes."""
         self._ratio = self._x_pad = self._ratio_pad = None
@@ -251,14 +261,28 @@ class RichardsonLucyPlan:
         stream right around the ``2 * iterations`` kernel launches (what ``bench.py`` times)."""
         import torch
 
-        y = _lib.require_device_f32(y, "y")
+        y_padded = None
+        if isinstance(y, PaddedVolume):  # e.g. written in place by the deskew kernel
+            if not (self._psf.separable or self._psf.taps is not None):
+                y = y.view.contiguous()
+            else:
+                y_padded, y = y, y.view
+        else:
+            y = _lib.require_device_f32(y, "y")
         if tuple(y.shape) != self.shape or y.device != self.device:
             raise ValueError(f"y must be {self.shape} on {self.device}, got {tuple(y.shape)} on {y.device}")
+        if y_padded is not None and (y_padded.pitch, y_padded.plane) != self.padded_geometry()[:2]:
+            raise ValueError("the padded y does not have this plan's padded geometry")
         iterations = int(iterations)
         if iterations < 0:
             raise ValueError("iterations must be >= 0")
         if not eps > 0:
             raise ValueError("eps must be > 0")
+        # x0 = y with a padded y needs no initial copy: the first iteration reads y directly
+        from_y = y_padded is not None and x0 is None and iterations > 0
+        y_ptr, y_pitch, y_plane = ((y_padded.logical_ptr(), y_padded.pitch, y_padded.plane)
+                                   if y_padded is not None else (y.data_ptr(), self.shape[2],
+                                                                 self.shape[1] * self.shape[2]))
         init = y if x0 is None else _lib.require_device_f32(x0, "x0")
         if tuple(init.shape) != self.shape:
             raise ValueError(f"x0 must be {self.shape}")
@@ -278,14 +302,14 @@ class RichardsonLucyPlan:
             if ps.separable:
                 # working volumes carry a zero halo: the kernels never bounds-check a load
                 x_pad, ratio_pad = self._scratch()
-                x_pad.view.copy_(init)
+                if not from_y:
+                    x_pad.view.copy_(init)
                 (kz, ky, kx), (fz, fy, fx) = ps.k, ps.k_flipped
                 nz, ny, nx = self._norm
                 if events:
                     events[0].record()
                 _lib.call(
-                    # y stays dense: padding it too (line-aligned aux reads) measured no gain
-                    "lsr_rl_sep_f32", y.data_ptr(), xx, yy * xx,
+                    "lsr_rl_sep_f32", y_ptr, y_pitch, y_plane, int(from_y),
                     x_pad.full.data_ptr(), ratio_pad.full.data_ptr(),
                     x.data_ptr(), z, yy, xx, kz.data_ptr(), fz.data_ptr(), ps.shape[0],
                     ky.data_ptr(), fy.data_ptr(), ps.shape[1], kx.data_ptr(), fx.data_ptr(),
@@ -294,11 +318,12 @@ class RichardsonLucyPlan:
                 )
             elif ps.taps is not None:
                 x_pad, ratio_pad = self._scratch()
-                x_pad.view.copy_(init)
+                if not from_y:
+                    x_pad.view.copy_(init)
                 if events:
                     events[0].record()
                 _lib.call(
-                    "lsr_rl_dense_padded_f32", y.data_ptr(), xx, yy * xx, x_pad.full.data_ptr(),
+                    "lsr_rl_dense_padded_f32", y_ptr, y_pitch, y_plane, int(from_y), x_pad.full.data_ptr(),
                     ratio_pad.full.data_ptr(), x.data_ptr(), z, yy, xx, ps.taps.data_ptr(),
                     ps.taps_flipped.data_ptr(), ps.shape[0], ps.shape[1], ps.shape[2],
                     ps.norm_table.data_ptr(), ctypes.c_float(ps.norm_full), iterations,

@@ -55,6 +55,8 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
 
     Shear-structured matrices (only ``z_in`` fractional) run the fused transpose kernel; any other
     3x4 map runs the general trilinear kernel followed by the slice-averaging kernel.
+    ``out`` may be a dense tensor or a :class:`shrimpy_amd.deconvolve.PaddedVolume` (shear
+    matrices only): the deskewed volume then lands, line-aligned, where the RL kernels read it.
     """
     import torch
 
@@ -72,21 +74,30 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
             "(use keep_overhang=True or a longer scan)"
         )
     zo = -(-zd // avg)
+    result = out
     if out is None:
-        out = torch.empty((zo, yo, xo), dtype=torch.float32, device=raw.device)
+        out = result = torch.empty((zo, yo, xo), dtype=torch.float32, device=raw.device)
+        out_ptr, out_pitch, out_plane = out.data_ptr(), xo, yo * xo
+    elif hasattr(out, "logical_ptr"):  # a PaddedVolume: write the RL input in place
+        if tuple(out.view.shape) != (zo, yo, xo) or out.full.device != raw.device:
+            raise ValueError(f"out must hold a {(zo, yo, xo)} window on {raw.device}")
+        out_ptr, out_pitch, out_plane = out.logical_ptr(), out.pitch, out.plane
     else:
         _lib.require_device_f32(out, "out")
         if tuple(out.shape) != (zo, yo, xo) or out.device != raw.device:
             raise ValueError(f"out must be {(zo, yo, xo)} on {raw.device}")
+        out_ptr, out_pitch, out_plane = out.data_ptr(), xo, yo * xo
     z, y, x = (int(v) for v in raw.shape)
     with torch.cuda.device(raw.device):
         stream = _lib.stream_ptr(raw.device)
         try:
             _lib.call(
-                "lsr_deskew_f32", raw.data_ptr(), z, y, x, out.data_ptr(), zo, yo, xo, zd,
-                _lib.matrix12(m), avg, stream,
+                "lsr_deskew_f32", raw.data_ptr(), z, y, x, out_ptr, zo, yo, xo, out_pitch, out_plane,
+                zd, _lib.matrix12(m), avg, stream,
             )
         except _lib.LsrUnsupported:
+            if hasattr(out, "logical_ptr"):
+                raise
             # general matrix: trilinear gather, then average
             pre = out if avg == 1 else torch.empty((zd, yo, xo), dtype=torch.float32, device=raw.device)
             _lib.call(
@@ -95,7 +106,7 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
             )
             if avg > 1:
                 _average_into(pre, out, avg, stream)
-    return out
+    return result
 
 
 def _average_into(pre, out, avg: int, stream: int) -> None:

@@ -90,6 +90,7 @@ class VolumeReconstructor:
             shape = tuple(self._register.output_shape_zyx)
         self.output_shape = tuple(shape)
         self._plan = None
+        self._y_pad = None
         dec: DeconvolveSettings | None = settings.deconvolution
         if dec is not None and dec.iterations > 0:
             from .deconvolve import RichardsonLucyPlan
@@ -119,8 +120,15 @@ class VolumeReconstructor:
         if tuple(vol.shape) != self.raw_shape:
             raise ValueError(f"expected raw shape {self.raw_shape}, got {tuple(vol.shape)}")
         if self._geo is not None:
+            target = None
+            if self._plan is not None and self._register is None and (
+                    self._plan.separable or self._plan._psf.taps is not None):
+                # deskew straight into the RL kernels' padded, line-aligned input volume
+                if self._y_pad is None:
+                    self._y_pad = self._plan.new_padded_input()
+                target = self._y_pad
             vol = deskew_with_matrix(vol, self._geo.matrix_3x4, self._geo.pre_average_shape,
-                                     self.settings.deskew.average_n_slices)
+                                     self.settings.deskew.average_n_slices, out=target)
         if self._register is not None:
             r = self._register
             vol = apply_affine_transform_zyx(vol, np.asarray(r.affine_transform_zyx), self.output_shape,

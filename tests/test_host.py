@@ -162,21 +162,21 @@ def test_library_loads_and_reports_version_and_arg_errors():
     lib = _lib.load()
     assert lib.lsr_version() == 100
     # argument validation happens before any launch: safe without a GPU
-    rc = lib.lsr_deskew_f32(None, 1, 1, 1, None, 1, 1, 1, 1, None, 1, None)
+    rc = lib.lsr_deskew_f32(None, 1, 1, 1, None, 1, 1, 1, 1, 1, 1, None, 1, None)
     assert rc == -1 and b"NULL" in lib.lsr_last_error()
     m = _lib.matrix12(np.eye(3, 4))
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    rc = lib.lsr_deskew_f32(p, 4, 4, 4, p, 2, 4, 4, 4, m, 3, None)
+    rc = lib.lsr_deskew_f32(p, 4, 4, 4, p, 2, 4, 4, 4, 16, 4, m, 3, None)
     assert rc == -3, "identity is not a deskew shear -> LSR_E_UNSUPPORTED"
-    rc = lib.lsr_deskew_f32(p, 4, 0, 4, p, 2, 4, 4, 4, m, 3, None)
+    rc = lib.lsr_deskew_f32(p, 4, 0, 4, p, 2, 4, 4, 4, 16, 4, m, 3, None)
     assert rc == -2
     rc = lib.lsr_correlate_sep_f32(p, p, None, 4, 4, 4, p, 4, p, 3, p, 3, 0, 0.0, None, None, None, None)
     assert rc == -3, "even tap count is unsupported"
     rc = lib.lsr_affine_f32(p, 2, 2, 2, p, 2, 2, 2, m, 0.0, 7, None)
     assert rc == -4
     with pytest.raises(_lib.LsrUnsupported):
-        _lib.call("lsr_deskew_f32", p, 4, 4, 4, p, 2, 4, 4, 4, m, 3, None)
+        _lib.call("lsr_deskew_f32", p, 4, 4, 4, p, 2, 4, 4, 4, 16, 4, m, 3, None)
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():
