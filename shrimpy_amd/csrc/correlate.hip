@@ -313,11 +313,16 @@ extern "C" int lsr_sep_padded_shape(int64_t Y, int64_t X, int pz, int py, int px
   if (int rc = check_taps(pz, py, px)) return rc;
   int PZ, PYX;
   sep_compiled_taps(pz, py, px, &PZ, &PYX);
-  const int64_t tiles_y = lsr::ceil_div(Y, lsr::kSepTileY), tiles_x = lsr::ceil_div(X, lsr::kSepTileX);
-  shape[0] = tiles_y * lsr::kSepTileY + PYX - 1;                          // rows
+  // the volume must satisfy both tuned kernels: dense (32 x 64 tiles) and separable (wide tiles)
+  auto up = [](int64_t v, int64_t m) { return lsr::ceil_div(v, m) * m; };
+  // (32-row tiles cover the separable kernel's 32- and 24-row variants only if both are honoured)
+  const int64_t rows_a = up(Y, 32), rows_b = up(Y, 24);
+  shape[0] = (rows_a > rows_b ? rows_a : rows_b) + PYX - 1;               // rows
+  const int64_t cols_a = (lsr::ceil_div(X, lsr::kSepTileX) - 1) * lsr::kSepTileX + lsr::sep_stage_cols(PYX);
+  const int64_t cols_b =
+      (lsr::ceil_div(X, lsr::kSepWideTileX) - 1) * lsr::kSepWideTileX + lsr::sep_wide_stage_cols(PYX);
   // pitch: a multiple of 32 floats (128-B lines) covering the last tile's staged window
-  shape[1] = (lsr::kSepOriginCol - PYX / 2 + (tiles_x - 1) * lsr::kSepTileX +
-              lsr::sep_stage_cols(PYX) + 31) / 32 * 32;
+  shape[1] = up(lsr::kSepOriginCol - PYX / 2 + (cols_a > cols_b ? cols_a : cols_b), 32);
   shape[2] = PYX / 2;                                                     // row of logical y = 0
   shape[3] = lsr::kSepOriginCol;                                          // col of logical x = 0
   return LSR_OK;
@@ -373,8 +378,8 @@ extern "C" int lsr_correlate_sep_strided_f32(
   p.pz = pz; p.py = py; p.px = px;
   p.epilogue = epilogue; p.eps = eps;
   p.nz = nz; p.ny = ny; p.nx = nx;
-  p.tiles_x = static_cast<int>(lsr::ceil_div(X, lsr::kSepTileX));
-  p.tiles_y = static_cast<int>(lsr::ceil_div(Y, lsr::kSepTileY));
+  p.tiles_x = static_cast<int>(lsr::ceil_div(X, lsr::kSepWideTileX));
+  p.tiles_y = static_cast<int>(lsr::ceil_div(Y, lsr::sep_wide_tile_y(PZ)));
   p.z_chunk = static_cast<int>(pick_z_chunk(Z, int64_t(p.tiles_x) * p.tiles_y, PZ));
   const int64_t blocks64 = int64_t(p.tiles_x) * p.tiles_y * lsr::ceil_div(Z, p.z_chunk);
   LSR_REQUIRE(blocks64 < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",

@@ -70,19 +70,29 @@ struct DenseArgs {
   const float* taps;
 };
 
-// Tile geometry of the tuned kernel, needed by the host to size the halo (see lsr_sep_halo).
+// Tile geometry of the tuned kernels, needed by the host to size the halo (lsr_sep_padded_shape).
+// Dense kernel: 32 x 64 tiles.  Separable kernel: kSepWideTileY x kSepWideTileX.
 constexpr int kSepTileY = 32;
 constexpr int kSepTileX = 64;
-// Column of logical x = 0 inside a padded row: a whole 128-byte line, so that every tile's 64-wide
-// output run (and its `aux` run, when that volume is padded too) starts on a cache line.  Measured:
+constexpr int kSepCols = 2;                       // 64-column groups per separable tile
+constexpr int kSepWideTileX = 64 * kSepCols;      // 128
+// rows per thread of the separable kernel (8 waves -> 8*run tile rows): 4 while the z accumulators
+// (PZ x 2*run registers) fit the 256-VGPR budget of one 512-thread workgroup per CU, else 3
+constexpr int sep_run(int PZ) { return PZ <= 9 ? 4 : 3; }
+constexpr int sep_wide_tile_y(int PZ) { return 8 * sep_run(PZ); }
+// Column of logical x = 0 inside a padded row: a whole 128-byte line, so that every tile's output
+// run (and its `aux` run, when that volume is padded too) starts on a cache line.  Measured:
 // RL launch 2.93 ms -> 2.18 ms against an origin at column PX/2 (line-straddling stores).
 constexpr int kSepOriginCol = 32;
 inline int sep_round_taps(int n) { return n < 3 ? 3 : n; }  // compiled: 3, 5, ..., 15
-// floats staged per row: 64 + PX - 1 rounded up to a multiple of 4, and at least 4*15 + 12
+// floats the dense kernel stages per row: 64 + PX - 1 rounded up to a multiple of 4, at least 72
 inline int sep_stage_cols(int PX) {
   int c = (kSepTileX + PX - 1 + 3) / 4 * 4;
   return c < 72 ? 72 : c;
 }
+// floats the separable kernel stages per row: its last x-pass item reads ceil((4+PX-1)/4) 16-byte
+// pieces starting at column tile_x - 4
+inline int sep_wide_stage_cols(int PX) { return kSepWideTileX - 4 + 4 * ((4 + PX - 1 + 3) / 4); }
 
 // correlate_sep.hip, compiled once per PZ (-DLSR_SEP_PZ=n).  `pyx` is the (square) in-plane tap
 // count; false = no such specialisation.

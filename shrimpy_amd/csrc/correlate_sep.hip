@@ -2,23 +2,31 @@
 // headline kernel.  Compile-time tap counts; one translation unit per PZ (-DLSR_SEP_PZ=n).
 //
 // The input volume carries a ZERO HALO (lsr_sep_padded_shape): zero padding of the correlation is
-// real memory, so every load in this kernel is unconditional, in bounds and 16-byte aligned.
+// real memory, so every load in this kernel is unconditional and in bounds.
 //
-// A 512-thread workgroup (8 waves) owns a 32 (y) x 64 (x) column and marches along z, one
+// A 512-thread workgroup (8 waves) owns a 8*kRun (y) x 64*kCols (x) column and marches along z, one
 // workgroup barrier per plane.  Iteration zi:
 //   commit   : plane zi+2, fetched two iterations ago into registers, -> LDS A[zi&1] (a linear
-//              16-B-per-thread copy of the (32+PY-1) x 72 window).
-//   prefetch : plane zi+4 -> the registers just freed (global_load_dwordx4, 288-B row runs), and
+//              16-B-per-thread copy of the (8*kRun+PY-1) x (64*kCols+8) window).
+//   prefetch : plane zi+4 -> the registers just freed (global_load_dwordx4, whole row runs), and
 //              the `aux` values of the NEXT iteration's output plane.  Two planes per workgroup
 //              are always in flight; nothing waits on them inside this iteration.
 //   x pass   : plane zi+1, A[(zi+1)&1] -> B[(zi+1)&1].  A thread owns (row, 4 consecutive x); its
 //              4+PX-1 inputs come from 3..5 ds_read_b128.  Lanes are assigned to items by the
 //              HARDWARE's b128 lane groups, so each group reads one contiguous 256-B row run:
-//              conflict-free for any pitch.  B's pitch (80) keeps the b128 writes conflict-free.
-//   y pass   : plane zi from B[zi&1]; thread = one column x 4 rows (4+PY-1 ds_read_b32).
+//              conflict-free for any pitch.  B's pitch (16 mod 32) keeps the b128 writes
+//              conflict-free.
+//   y pass   : plane zi from B[zi&1]; thread = kCols columns x kRun rows (kRun+PY-1 ds_read_b32 each).
 //   z        : PZ pending output planes per point in registers; one FMA per pending plane both
 //              shifts the window and absorbs this plane.
 //   epilogue : completed plane zi-PZ/2: ratio = y*rcp(c+eps) or x*c*rcp(H^T 1), strided store.
+//
+// kCols = 2, kRun = 4 (a 32 x 128 tile, 85 KB of LDS for 9x7x7, one workgroup per CU; kRun = 3
+// from PZ = 11 up, where the z accumulators would otherwise spill): the in-plane window of a tile then spans 6
+// cache lines per row for 4 lines of output instead of 8 for 4 with two 64-wide tiles.  Neighbour
+// workgroups ask for their shared halo lines at the same moment and L2 does not merge those
+// misses (measured: 1.41x reads vs algorithmic with 64-wide tiles), so fewer, wider tiles is the
+// way to cut the re-fetch; occupancy (1 vs 2 workgroups per CU) measured no difference.
 //
 // THE MEMORY PIPELINE IS MANAGED BY HAND.  With loads and stores pending on the same counter,
 // hipcc (ROCm 7.2) treats vmcnt as out of order and turns every wait for a load into vmcnt(0) --
@@ -29,9 +37,7 @@
 // gfx950 (loads and stores alike), so N = the number of LOADS issued after the wanted one is a
 // safe bound: younger stores only make the wait return a little later, never too early.
 //
-// Algorithmic HBM bytes: 12 per voxel per launch (in + aux + out).  Real traffic adds the in-plane
-// halo of `in` ((32+PY-1)*72/(32*64) = 1.34x for 7x7), largely L2 hits thanks to the XCD-aware
-// tile order, and PZ-1 planes per z-chunk.
+// Algorithmic HBM bytes: 12 per voxel per launch (in + aux + out).
 
 #include "common.hpp"
 #include "correlate_common.hpp"
@@ -44,30 +50,32 @@ namespace {
 
 using lsr::SepArgs;
 
-constexpr int kTY = lsr::kSepTileY;      // 32
-constexpr int kTX = lsr::kSepTileX;      // 64
-constexpr int kRun = 4;                  // consecutive y per thread in the y / z passes
-constexpr int kWaves = kTY / kRun;       // 8
+constexpr int kCols = lsr::kSepCols;     // 64-wide column groups per workgroup (2)
+constexpr int kRun = lsr::sep_run(LSR_SEP_PZ);  // consecutive y per thread in the y / z passes
+constexpr int kTY = 8 * kRun;           // 8 waves * kRun rows (32 or 24)
+constexpr int kTX = lsr::kSepWideTileX; // 64 * kCols (128)
+constexpr int kPts = kRun * kCols;      // output points per thread
+constexpr int kWaves = 8;
 constexpr int kThreads = 64 * kWaves;    // 512
 constexpr int kBand = 8;                 // tile rows per band of the tile walk (see the kernel)
 
 template <int PY, int PX>
 struct Tile {
   static constexpr int AR = kTY + PY - 1;                        // input rows of a tile
-  static constexpr int AC = kTX + PX - 1;                        // input cols of a tile
-  static constexpr int PA0 = (AC + 3) / 4 * 4;
-  static constexpr int PA = PA0 < 72 ? 72 : PA0;                 // staged cols == LDS pitch of A
+  static constexpr int WIN = 4 + PX - 1;                         // inputs of an x-pass item
+  static constexpr int NPIECE = (WIN + 3) / 4;                   // ds_read_b128 per item
+  static constexpr int PA = kTX - 4 + 4 * NPIECE;                // staged cols == LDS pitch of A
   static constexpr int CH = PA / 4;                              // 16-B chunks per staged row
   static constexpr int NCH = AR * CH;                            // chunks per plane
   static constexpr int SL = (NCH + kThreads - 1) / kThreads;     // chunks per thread
-  static constexpr int WIN = 4 + PX - 1;                         // inputs of an x-pass item
-  static constexpr int NPIECE = (WIN + 3) / 4;                   // ds_read_b128 per item
-  static constexpr int PB = 80;                                  // LDS pitch of B (16 mod 32)
+  static constexpr int PB = kTX + 16;                            // LDS pitch of B (16 mod 32)
   static constexpr int ASZ = AR * PA;
   static constexpr int BSZ = AR * PB;
-  static_assert(4 * 15 + 4 * NPIECE <= PA, "x-pass reads stay inside a staged row");
-  static_assert(AR <= 2 * kTY, "at most two x-pass items per thread");
-  static_assert(SL == 2, "the hand-counted waits assume two staging loads per thread");
+  static constexpr int RS = AR * kCols;                          // (row, 64-col segment) pairs
+  static constexpr int XIT = (RS + 4 * kWaves - 1) / (4 * kWaves);  // x-pass items per thread
+  static_assert(PA >= kTX + PX - 1, "staged window covers the halo");
+  static_assert(SL >= 2 && SL <= 4, "the hand-written waits cover two to four staging loads");
+  static_assert(2 * (ASZ + BSZ) * 4 <= 160 * 1024, "LDS per workgroup");
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native 16-byte vector (one VGPR quad)
@@ -86,13 +94,33 @@ __device__ __forceinline__ void gload_x1(float& dst, const float* sbase, int vof
 }
 // Wait until at most N vector-memory operations are outstanding; the registers are passed
 // through so that every later use depends on this statement.
-template <int N>
-__device__ __forceinline__ void wait_loads(f32x4& a, f32x4& b) {
-  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+template <int N, int SL>
+__device__ __forceinline__ void wait_stage(f32x4 (&st)[SL]) {
+  if constexpr (SL == 2) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(st[0]), "+v"(st[1]) : "n"(N) : "memory");
+  } else if constexpr (SL == 3) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]) : "n"(N) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]) : "n"(N) : "memory");
+  }
 }
 template <int N>
-__device__ __forceinline__ void wait_loads(float (&a)[kRun], float& b) {
-  asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b) : "n"(N) : "memory");
+__device__ __forceinline__ void wait_aux(float (&a)[kPts], float& b) {
+  if constexpr (kPts == 4) {
+    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b) : "n"(N) : "memory");
+  } else if constexpr (kPts == 6) {
+    asm volatile("s_waitcnt vmcnt(%7)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(b)
+                 : "n"(N)
+                 : "memory");
+  } else {
+    static_assert(kPts == 8, "one or two columns per thread");
+    asm volatile("s_waitcnt vmcnt(%9)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]),
+                   "+v"(a[7]), "+v"(b)
+                 : "n"(N)
+                 : "memory");
+  }
 }
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes have landed
@@ -124,15 +152,20 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
   __shared__ f32x4 bufB4[2 * T::BSZ / 4];
   float* const bufB = reinterpret_cast<float*>(bufB4);
 
-  // loads per iteration besides the two staging loads: aux rows (+ nz for the update)
-  constexpr int NA = EPI == LSR_EPI_NONE ? 0 : (EPI == LSR_EPI_UPDATE ? kRun + 1 : kRun);
+  // loads per iteration besides the staging loads: aux values (+ nz for the update)
+#ifdef LSR_PROBE_NOAUX
+  constexpr int NA = 0;
+#else
+  constexpr int NA = EPI == LSR_EPI_NONE ? 0 : (EPI == LSR_EPI_UPDATE ? kPts + 1 : kPts);
+#endif
+  constexpr int SL = T::SL;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar
 
   // XCD-aware tile order: workgroups b, b+8, ... share an XCD (round-robin dispatch), so give
-  // each XCD a contiguous run of tiles: x-neighbours then share their halo columns in one L2.
+  // each XCD a contiguous run of tiles ...
   int bid = blockIdx.x;
   {
     const int nblk = gridDim.x;
@@ -140,9 +173,8 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
     const int xcd = bid % 8, idx = bid / 8;
     bid = xcd * per + (xcd < rem ? xcd : rem) + idx;  // XCD k owns per + (k < rem) tiles
   }
-  // ... and walk the (y, x) tile grid in bands of 8 tile rows, column-major inside a band: any
-  // 64 consecutive tiles (= the workgroups an XCD keeps resident) then form an 8 x 8 patch, so
-  // halo rows AND halo columns are shared inside one L2.
+  // ... and walk the (y, x) tile grid in bands of 8 tile rows, column-major inside a band, so
+  // that the workgroups an XCD keeps resident form a compact patch.
   const int tiles_xy = p.tiles_x * p.tiles_y;
   const int zc = bid / tiles_xy;
   const int lin = bid - zc * tiles_xy;
@@ -174,101 +206,108 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
   // Threads past the last chunk re-fetch and re-write the last one (benign): nothing conditional.
   // Global side: scalar base = the window's first element, per-lane byte offset >= 0.
   const float* const in_tile = p.in + (static_cast<int64_t>(y0 - cy) * p.in_pitch + (x0 - cx));
-  int s_voff[T::SL];  // byte offset from in_tile (+ z * plane)
-  int s_loff[T::SL];  // 16-byte chunk index inside an A buffer
+  int s_voff[SL];  // byte offset from in_tile (+ z * plane)
+  int s_loff[SL];  // 16-byte chunk index inside an A buffer
 #pragma unroll
-  for (int k = 0; k < T::SL; ++k) {
+  for (int k = 0; k < SL; ++k) {
     const int e = min(tid + k * kThreads, T::NCH - 1);
     const int r = e / T::CH, c = e - r * T::CH;
     s_voff[k] = (r * p.in_pitch + 4 * c) * 4;
     s_loff[k] = e;
   }
-  f32x4 st0[T::SL], st1[T::SL];  // plane q is staged in set q & 1
+  f32x4 st0[SL], st1[SL];  // plane q is staged in set q & 1
 
-  // ---- x pass: lane -> (row group, x group) by hardware b128 lane group
+  // ---- x pass: lane -> (row-segment, x group) by hardware b128 lane group; a row-segment is one
+  // 64-column run of one staged row, item `it` of this thread is row-segment xrs0 + 32*it
   int xg, xq;
   b128_lane_group(lane, xg, xq);
-  const int xrow0 = 4 * wave + xg;                 // item 0: rows 0..31
-  const bool has1 = kTY + xrow0 < T::AR;           // item 1: rows 32.. (only some lanes)
-  const int xa = xrow0 * (T::PA / 4) + xq;         // 16-B units; + kTY*PA/4 for item 1
-  const int xb = xrow0 * (T::PB / 4) + xq;         // 16-B units; + kTY*PB/4 for item 1
+  const int xrs0 = 4 * wave + xg;
 
-  // ---- y / z pass and epilogue: thread owns column `lane`, rows 4*wave .. 4*wave+3
+  // ---- y / z pass and epilogue: thread owns columns lane + 64*col, rows 4*wave .. 4*wave+3
   const int ycol = (wave * kRun) * T::PB + lane;
-  const int gx_out = x0 + lane;
-  const bool xok = gx_out < X;
-  const int gxc = min(gx_out, X - 1);              // clamped: aux loads are always in bounds
-  const int gy_out0 = y0 + wave * kRun;            // scalar
-  int a_voff[kRun], o_off[kRun];
-  bool ok[kRun];
+  const int gy_out0 = y0 + wave * kRun;  // scalar
+  int a_voff[kPts], o_off[kPts];
+  bool ok[kPts];
 #pragma unroll
-  for (int m = 0; m < kRun; ++m) {
-    const int gy = gy_out0 + m;
-    ok[m] = xok && gy < Y;
-    a_voff[m] = (min(gy, Y - 1) * p.aux_pitch + gxc) * 4;
-    o_off[m] = min(gy, Y - 1) * p.out_pitch + gxc;
+  for (int col = 0; col < kCols; ++col) {
+    const int gx = x0 + lane + 64 * col;
+    const int gxc = min(gx, X - 1);  // clamped: aux loads are always in bounds
+#pragma unroll
+    for (int m = 0; m < kRun; ++m) {
+      const int gy = gy_out0 + m;
+      ok[col * kRun + m] = gx < X && gy < Y;
+      a_voff[col * kRun + m] = (min(gy, Y - 1) * p.aux_pitch + gxc) * 4;
+      o_off[col * kRun + m] = min(gy, Y - 1) * p.out_pitch + gxc;
+    }
   }
-  float rnyx[kRun];  // reciprocal of the in-plane part of H^T 1 (UPDATE epilogue)
+  float rnyx[kPts];  // reciprocal of the in-plane part of H^T 1 (UPDATE epilogue)
 #pragma unroll
-  for (int m = 0; m < kRun; ++m) rnyx[m] = 0.0f;
+  for (int i = 0; i < kPts; ++i) rnyx[i] = 0.0f;
   if constexpr (EPI == LSR_EPI_UPDATE) {
-    const float nxv = p.nx[gxc];
 #pragma unroll
-    for (int m = 0; m < kRun; ++m) rnyx[m] = fast_rcp(p.ny[min(gy_out0 + m, Y - 1)] * nxv);
+    for (int col = 0; col < kCols; ++col) {
+      const float nxv = p.nx[min(x0 + lane + 64 * col, X - 1)];
+#pragma unroll
+      for (int m = 0; m < kRun; ++m)
+        rnyx[col * kRun + m] = fast_rcp(p.ny[min(gy_out0 + m, Y - 1)] * nxv);
+    }
   }
 
-  // pending output planes: acc[j][m] <-> z_out = zi - cz + j once plane zi is absorbed
-  float acc[PZ][kRun];
+  // pending output planes: acc[j][i] <-> z_out = zi - cz + j once plane zi is absorbed
+  float acc[PZ][kPts];
 #pragma unroll
   for (int j = 0; j < PZ; ++j)
 #pragma unroll
-    for (int m = 0; m < kRun; ++m) acc[j][m] = 0.0f;
+    for (int i = 0; i < kPts; ++i) acc[j][i] = 0.0f;
   // aux (and nz) of output plane zi - cz live in set zi & 1, requested one iteration ahead
-  float aux0[kRun], aux1[kRun];
+  float aux0[kPts], aux1[kPts];
 #pragma unroll
-  for (int m = 0; m < kRun; ++m) aux0[m] = aux1[m] = 0.0f;
+  for (int i = 0; i < kPts; ++i) aux0[i] = aux1[i] = 0.0f;
   float nzv0 = 1.0f, nzv1 = 1.0f;
 
   const int zi_begin = max(zb - cz, 0);
   const int zi_end = ze + cz;  // exclusive; planes >= Z contribute zeros
 
-  auto fetch = [&](int zplane, f32x4 (&st)[T::SL]) {  // 2 loads
+  auto fetch = [&](int zplane, f32x4 (&st)[SL]) {  // SL loads
     const float* src = in_tile + static_cast<int64_t>(min(max(zplane, 0), Z - 1)) * p.in_plane;
-    gload_x4(st[0], src, s_voff[0]);
-    gload_x4(st[1], src, s_voff[1]);
+#pragma unroll
+    for (int k = 0; k < SL; ++k) gload_x4(st[k], src, s_voff[k]);
   };
-  auto fetch_aux = [&](int zout, float (&aux)[kRun], float& nzv) {  // NA loads
-    if constexpr (EPI != LSR_EPI_NONE) {
+  auto fetch_aux = [&](int zout, float (&aux)[kPts], float& nzv) {  // NA loads
+    if constexpr (EPI != LSR_EPI_NONE && NA != 0) {
       const int zc_ = min(max(zout, 0), Z - 1);
       const float* a = p.aux + static_cast<int64_t>(zc_) * p.aux_plane;
 #pragma unroll
-      for (int m = 0; m < kRun; ++m) gload_x1(aux[m], a, a_voff[m]);
+      for (int i = 0; i < kPts; ++i) gload_x1(aux[i], a, a_voff[i]);
       if constexpr (EPI == LSR_EPI_UPDATE) gload_x1(nzv, p.nz + zc_, 0);
     }
   };
 
   // One iteration; `par` = zi & 1 is a literal at both call sites.
-  auto iteration = [&](const int zi, const int par, f32x4 (&st)[T::SL], float (&aux_use)[kRun],
-                       float& nz_use, float (&aux_load)[kRun], float& nz_load) {
+  auto iteration = [&](const int zi, const int par, f32x4 (&st)[SL], float (&aux_use)[kPts],
+                       float& nz_use, float (&aux_load)[kPts], float& nz_load) {
     f32x4* A_commit = bufA4 + par * (T::ASZ / 4);            // plane zi+2
     const f32x4* A_x = bufA4 + (par ^ 1) * (T::ASZ / 4);     // plane zi+1
     f32x4* B_x = bufB4 + (par ^ 1) * (T::BSZ / 4);           // plane zi+1
     const float* B_y = bufB + par * T::BSZ;                  // plane zi
 
     // commit plane zi+2.  Its loads were issued two iterations ago; issued since: aux (NA),
-    // the other staging set (2), aux (NA).
-    wait_loads<2 + 2 * NA>(st[0], st[1]);
-    A_commit[s_loff[0]] = st[0];
-    A_commit[s_loff[1]] = st[1];
+    // the other staging set (SL), aux (NA).
+    wait_stage<SL + 2 * NA>(st);
+#pragma unroll
+    for (int k = 0; k < SL; ++k) A_commit[s_loff[k]] = st[k];
     __builtin_amdgcn_sched_barrier(0);  // the refill reuses these registers: keep it behind
     fetch(zi + 4, st);
     fetch_aux(zi + 1 - cz, aux_load, nz_load);
 
     // x pass of plane zi+1
+#ifndef LSR_SEP_PROBE
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      if (it == 0 || has1) {
-        const f32x4* src = A_x + xa + it * (kTY * T::PA / 4);
+    for (int it = 0; it < T::XIT; ++it) {
+      const int rs = xrs0 + it * (4 * kWaves);
+      if (it + 1 < T::XIT || rs < T::RS) {
+        const int row = rs / kCols, seg = rs - row * kCols;
+        const f32x4* src = A_x + row * (T::PA / 4) + seg * 16 + xq;
         float w[4 * T::NPIECE];
 #pragma unroll
         for (int i = 0; i < T::NPIECE; ++i) {
@@ -287,56 +326,78 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
           o.z = fmaf(wx[c], w[c + 2], o.z);
           o.w = fmaf(wx[c], w[c + 3], o.w);
         }
-        B_x[xb + it * (kTY * T::PB / 4)] = o;
+        B_x[row * (T::PB / 4) + seg * 16 + xq] = o;
       }
     }
+#else
+    (void)A_x; (void)B_x;
+#endif
 
     if (zi >= zi_begin && zi < zi_end) {  // wave-uniform
-      float pl[kRun];
+      float pl[kPts];
 #pragma unroll
-      for (int m = 0; m < kRun; ++m) pl[m] = 0.0f;
+      for (int i = 0; i < kPts; ++i) pl[i] = 0.0f;
+#ifdef LSR_SEP_PROBE
+      (void)B_y;
+#pragma unroll
+      for (int i = 0; i < kPts; ++i) pl[i] = reinterpret_cast<const float*>(A_x)[tid + 512 * i];
+      if (false) {
+#else
       if (zi < Z) {
-        const float* col = B_y + ycol;
-        float cv[kRun + PY - 1];
+#endif
 #pragma unroll
-        for (int j = 0; j < kRun + PY - 1; ++j) cv[j] = col[j * T::PB];
+        for (int col = 0; col < kCols; ++col) {
+          const float* colp = B_y + ycol + 64 * col;
+          float cv[kRun + PY - 1];
 #pragma unroll
-        for (int m = 0; m < kRun; ++m) {
-          float s = wy[0] * cv[m];
+          for (int j = 0; j < kRun + PY - 1; ++j) cv[j] = colp[j * T::PB];
 #pragma unroll
-          for (int b = 1; b < PY; ++b) s = fmaf(wy[b], cv[m + b], s);
-          pl[m] = s;
+          for (int m = 0; m < kRun; ++m) {
+            float s = wy[0] * cv[m];
+#pragma unroll
+            for (int b = 1; b < PY; ++b) s = fmaf(wy[b], cv[m + b], s);
+            pl[col * kRun + m] = s;
+          }
         }
       }
       // z: shift the pending planes and absorb this plane in the same FMA
+#ifdef LSR_SEP_PROBE
+#pragma unroll
+      for (int i = 0; i < kPts; ++i) acc[0][i] = pl[i];
+#else
 #pragma unroll
       for (int j = 0; j < PZ - 1; ++j)
 #pragma unroll
-        for (int m = 0; m < kRun; ++m) acc[j][m] = fmaf(wz[PZ - 1 - j], pl[m], acc[j + 1][m]);
+        for (int i = 0; i < kPts; ++i) acc[j][i] = fmaf(wz[PZ - 1 - j], pl[i], acc[j + 1][i]);
 #pragma unroll
-      for (int m = 0; m < kRun; ++m) acc[PZ - 1][m] = wz[0] * pl[m];
+      for (int i = 0; i < kPts; ++i) acc[PZ - 1][i] = wz[0] * pl[i];
+#endif
 
       const int z_out = zi - cz;
+#ifdef LSR_PROBE_NOSTORE
+      if (z_out >= zb && acc[0][0] == 12345.678f) {
+#else
       if (z_out >= zb) {  // wave-uniform
+#endif
         float* o = p.out + static_cast<int64_t>(z_out) * p.out_plane;  // scalar
-        if constexpr (EPI != LSR_EPI_NONE) {
+        if constexpr (EPI != LSR_EPI_NONE && NA != 0) {
           // aux of this plane was requested in the previous iteration; issued since: this
-          // iteration's staging loads (2) and aux (NA)
-          wait_loads<2 + NA>(aux_use, nz_use);
+          // iteration's staging loads (SL) and aux (NA)
+          wait_aux<SL + NA>(aux_use, nz_use);
         }
         if constexpr (EPI == LSR_EPI_RATIO) {
 #pragma unroll
-          for (int m = 0; m < kRun; ++m)
-            if (ok[m]) o[o_off[m]] = aux_use[m] * fast_rcp(acc[0][m] + p.eps);
+          for (int i = 0; i < kPts; ++i)
+            if (ok[i]) o[o_off[i]] = aux_use[i] * fast_rcp(acc[0][i] + p.eps);
         } else if constexpr (EPI == LSR_EPI_UPDATE) {
           const float rz = fast_rcp(nz_use);
 #pragma unroll
-          for (int m = 0; m < kRun; ++m)
-            if (ok[m]) o[o_off[m]] = aux_use[m] * acc[0][m] * (rz * rnyx[m]);
+          for (int i = 0; i < kPts; ++i)
+            if (ok[i]) o[o_off[i]] = aux_use[i] * acc[0][i] * (rz * rnyx[i]);
         } else {
 #pragma unroll
-          for (int m = 0; m < kRun; ++m)
-            if (ok[m]) o[o_off[m]] = acc[0][m];
+          for (int i = 0; i < kPts; ++i)
+            if (ok[i]) o[o_off[i]] = acc[0][i];
         }
       }
     }

@@ -201,7 +201,7 @@ def test_average_n_slices_vs_oracle(device):
 # ================================================================ correlation + Richardson-Lucy
 
 
-@pytest.mark.parametrize("pshape", [(1, 1, 1), (3, 3, 3), (9, 7, 7), (5, 3, 9), (15, 15, 15), (3, 1, 5)])
+@pytest.mark.parametrize("pshape", [(1, 1, 1), (3, 3, 3), (9, 7, 7), (5, 3, 9), (15, 15, 15), (3, 1, 5), (11, 5, 13), (13, 9, 3)])
 @pytest.mark.parametrize("vshape", [(20, 40, 70), (3, 5, 4)])
 def test_correlate_sep_and_dense_vs_scipy(device, pshape, vshape):
     from scipy import ndimage

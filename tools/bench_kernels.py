@@ -36,6 +36,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--skip-dense", action="store_true")
+    ap.add_argument("--only-rl", action="store_true", help="skip the affine and deskew sections")
+    ap.add_argument("--rl-grid", default="171,2048,2270", help="Z,Y,X of the RL launch section")
     args = ap.parse_args()
 
     import torch
@@ -49,6 +51,15 @@ def main():
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(3)
 
+    if not args.only_rl:
+        _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_geometry, apply_affine_transform_zyx)
+
+    # ---- RL launches on the config-2 grid: separable (tuned) and dense
+    oshape = tuple(int(v) for v in args.rl_grid.split(","))
+    _rl(args, torch, dev, g, bench, RichardsonLucyPlan, oshape)
+
+
+def _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_geometry, apply_affine_transform_zyx):
     # ---- affine apply, config 3: 2048 x 2048 x 256 volume, rotation 2 deg o scale o translation
     shape = (256, 2048, 2048)
     vol = torch.rand(shape, device=dev, generator=g) * 1000
@@ -79,8 +90,8 @@ def main():
                           "frac_of_8TBps": nbytes / ms / 1e6 / 8000}))
         del raw, dst
 
-    # ---- RL launches on the config-2 grid: separable (tuned) and dense (generic)
-    oshape = (171, 2048, 2270)
+
+def _rl(args, torch, dev, g, bench, RichardsonLucyPlan, oshape):
     y = torch.poisson(torch.full(oshape, 100.0, device=dev), generator=g)
     plans = [("separable 9x7x7", RichardsonLucyPlan(oshape, None, dev, psf_factors=bench.gaussian_factors()), 4)]
     if not args.skip_dense:
