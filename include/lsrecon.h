@@ -171,6 +171,28 @@ int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_fr
                    const float* kx_flipped, int px, const float* nz, const float* ny,
                    const float* nx, int iters, float eps, lsr_stream_t stream);
 
+/*
+ * The same iterations with ONE launch each (rl_fused_sep.hip): ratio = y / (H x + eps) is formed
+ * and consumed inside the workgroup, so an iteration moves 12 bytes per voxel through HBM instead
+ * of 24. Results are bit-identical to lsr_rl_sep_f32. Compiled for PSFs up to 9 x 9 x 9 taps
+ * (lsr_rl_sep_fused_supported: 1 / 0; larger: LSR_E_UNSUPPORTED, use lsr_rl_sep_f32).
+ *
+ * `y` points at the logical (0,0,0) of a padded volume (lsr_sep_padded_shape geometry or larger
+ * strides) whose halo is ZERO: the kernel reads y on the tile grown by the PSF radius.
+ * `x_a`, `x_b` are padded working volumes (allocation start, zero halos, written only inside the
+ * logical window). x_a holds the initial estimate unless `init_from_y` (x0 = y, read in place).
+ * Iteration i reads (i even ? x_a : x_b) and writes the other; the last one writes the dense
+ * (Z, Y, X) `x_out` instead when that is not NULL. With x_out == NULL the result is in x_b for odd
+ * `iters`, in x_a for even.
+ */
+int lsr_rl_sep_fused_supported(int pz, int py, int px);
+int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
+                         float* x_a, float* x_b, float* x_out, int64_t Z, int64_t Y, int64_t X,
+                         const float* kz, const float* kz_flipped, int pz,
+                         const float* ky, const float* ky_flipped, int py, const float* kx,
+                         const float* kx_flipped, int px, const float* nz, const float* ny,
+                         const float* nx, int iters, float eps, lsr_stream_t stream);
+
 int lsr_rl_dense_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X,
                      const float* psf, const float* psf_flipped, int pz, int py, int px,
                      const double* norm_table, int iters, float eps, lsr_stream_t stream);

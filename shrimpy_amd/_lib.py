@@ -61,6 +61,11 @@ SIGNATURES: dict[str, list] = {
         _c_f32p, _i64, _i64, _int, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _c_f32p,
         _c_f32p, _int, _c_f32p, _c_f32p, _int, _c_f32p, _c_f32p, _c_f32p, _int, _f32, _stream,
     ],
+    "lsr_rl_sep_fused_supported": [_int, _int, _int],
+    "lsr_rl_sep_fused_f32": [
+        _c_f32p, _i64, _i64, _int, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _c_f32p,
+        _c_f32p, _int, _c_f32p, _c_f32p, _int, _c_f32p, _c_f32p, _c_f32p, _int, _f32, _stream,
+    ],
     "lsr_dense_taps_count": [_int, _int, _int],
     "lsr_dense_prepare_taps": [ctypes.c_void_p, _int, _int, _int, _int, ctypes.c_void_p],
     "lsr_correlate_dense_padded_f32": [
@@ -145,6 +150,11 @@ def call(name: str, *args) -> None:
         msg = lib.lsr_last_error().decode("utf-8", "replace")
         cls = LsrUnsupported if rc == E_UNSUPPORTED else LsrError
         raise cls(name, rc, msg)
+
+
+def call_value(name: str, *args) -> int:
+    """Invoke an entry point whose return value is an answer (a count, a yes/no), not a status."""
+    return int(getattr(load(), name)(*args))
 
 
 def matrix12(matrix_3x4):

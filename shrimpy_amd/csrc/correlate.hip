@@ -313,17 +313,21 @@ extern "C" int lsr_sep_padded_shape(int64_t Y, int64_t X, int pz, int py, int px
   if (int rc = check_taps(pz, py, px)) return rc;
   int PZ, PYX;
   sep_compiled_taps(pz, py, px, &PZ, &PYX);
-  // the volume must satisfy both tuned kernels: dense (32 x 64 tiles) and separable (wide tiles)
+  // the volume must satisfy every tuned kernel: dense (32 x 64 tiles), separable (32/24 x 128) and
+  // the fused RL iteration (same tiles, twice the halo: two stencils back to back)
   auto up = [](int64_t v, int64_t m) { return lsr::ceil_div(v, m) * m; };
-  // (32-row tiles cover the separable kernel's 32- and 24-row variants only if both are honoured)
   const int64_t rows_a = up(Y, 32), rows_b = up(Y, 24);
-  shape[0] = (rows_a > rows_b ? rows_a : rows_b) + PYX - 1;               // rows
+  const int64_t halo = 2 * (PYX / 2);
+  shape[0] = (rows_a > rows_b ? rows_a : rows_b) + 2 * halo;              // rows
   const int64_t cols_a = (lsr::ceil_div(X, lsr::kSepTileX) - 1) * lsr::kSepTileX + lsr::sep_stage_cols(PYX);
   const int64_t cols_b =
       (lsr::ceil_div(X, lsr::kSepWideTileX) - 1) * lsr::kSepWideTileX + lsr::sep_wide_stage_cols(PYX);
+  const int64_t cols_c = PYX / 2 + up(X, lsr::kSepWideTileX) + lsr::fused_window_halo(PYX);
+  int64_t cols = cols_a > cols_b ? cols_a : cols_b;
+  if (cols_c > cols) cols = cols_c;
   // pitch: a multiple of 32 floats (128-B lines) covering the last tile's staged window
-  shape[1] = up(lsr::kSepOriginCol - PYX / 2 + (cols_a > cols_b ? cols_a : cols_b), 32);
-  shape[2] = PYX / 2;                                                     // row of logical y = 0
+  shape[1] = up(lsr::kSepOriginCol - PYX / 2 + cols, 32);
+  shape[2] = halo;                                                        // row of logical y = 0
   shape[3] = lsr::kSepOriginCol;                                          // col of logical x = 0
   return LSR_OK;
 }
@@ -457,6 +461,107 @@ extern "C" int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, 
                                        last ? X : pitch, last ? Y * X : plane, Z, Y, X, kz, pz, ky,
                                        py, kx, px, LSR_EPI_UPDATE, eps, nz, ny, nx, stream);
     if (rc) return rc;
+  }
+  return LSR_OK;
+}
+
+namespace {
+
+// z split of the fused kernel: one workgroup per CU and 2 * (PZ - 1) extra planes per chunk; pick
+// the chunk count that minimises rounds * planes-per-workgroup on 256 CUs.
+int64_t pick_fused_z_chunk(int64_t Z, int64_t tiles_xy, int PZ) {
+  int64_t best_chunk = Z, best_cost = -1;
+  for (int64_t n = 1; n <= 16 && n <= Z; ++n) {
+    const int64_t chunk = lsr::ceil_div(Z, n);
+    const int64_t wgs = tiles_xy * lsr::ceil_div(Z, chunk);
+    const int64_t cost = lsr::ceil_div(wgs, 256) * (chunk + 2 * (PZ - 1) + 2);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_chunk = chunk; }
+  }
+  return best_chunk;
+}
+
+}  // namespace
+
+extern "C" int lsr_rl_sep_fused_supported(int pz, int py, int px) {
+  if (pz < 1 || py < 1 || px < 1 || !(pz & 1) || !(py & 1) || !(px & 1)) return 0;
+  const int PZ = lsr::sep_round_taps(pz), PYX = lsr::sep_round_taps(py > px ? py : px);
+  return PZ <= lsr::kFusedMaxPZ && PYX <= lsr::kFusedMaxPYX;
+}
+
+extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
+                                    float* x_a, float* x_b, float* x_out, int64_t Z, int64_t Y,
+                                    int64_t X, const float* kz, const float* kz_flipped, int pz,
+                                    const float* ky, const float* ky_flipped, int py,
+                                    const float* kx, const float* kx_flipped, int px,
+                                    const float* nz, const float* ny, const float* nx, int iters,
+                                    float eps, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(y);
+  LSR_REQUIRE_PTR(x_a);
+  LSR_REQUIRE_PTR(x_b);
+  LSR_REQUIRE_PTR(kz); LSR_REQUIRE_PTR(kz_flipped);
+  LSR_REQUIRE_PTR(ky); LSR_REQUIRE_PTR(ky_flipped);
+  LSR_REQUIRE_PTR(kx); LSR_REQUIRE_PTR(kx_flipped);
+  LSR_REQUIRE_PTR(nz); LSR_REQUIRE_PTR(ny); LSR_REQUIRE_PTR(nx);
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
+              (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE(iters >= 1, LSR_E_ARG, "iters %d must be >= 1", iters);
+  LSR_REQUIRE(x_a != x_b, LSR_E_ARG, "x_a and x_b must be distinct");
+  if (int rc = check_taps(pz, py, px)) return rc;
+  LSR_REQUIRE(lsr_rl_sep_fused_supported(pz, py, px), LSR_E_UNSUPPORTED,
+              "the fused RL iteration is compiled for up to %d x %d x %d taps, got (%d,%d,%d)",
+              lsr::kFusedMaxPZ, lsr::kFusedMaxPYX, lsr::kFusedMaxPYX, pz, py, px);
+  int PZ, PYX;
+  sep_compiled_taps(pz, py, px, &PZ, &PYX);
+  int64_t ps[4];
+  if (int rc = lsr_sep_padded_shape(Y, X, pz, py, px, ps)) return rc;
+  const int64_t pitch = ps[1], plane = ps[0] * ps[1];
+  const int64_t origin = ps[2] * pitch + ps[3];
+  LSR_REQUIRE(y_pitch >= pitch && y_plane >= ps[0] * y_pitch, LSR_E_SHAPE,
+              "y strides (%lld,%lld) are smaller than the padded shape (%lld rows x %lld) that "
+              "lsr_sep_padded_shape asks for: y must be a zero-haloed padded volume",
+              (long long)y_pitch, (long long)y_plane, (long long)ps[0], (long long)pitch);
+  LSR_REQUIRE(y_pitch % 4 == 0 && y_plane % 4 == 0, LSR_E_ARG,
+              "pitch and plane stride of the padded y must be multiples of 4 floats");
+  const int64_t lim = int64_t(1) << 29;
+  LSR_REQUIRE(plane < lim && y_plane < lim && Y * X < lim && Z < lim, LSR_E_UNSUPPORTED,
+              "plane strides exceed the kernel's 32-bit in-plane offsets");
+
+  lsr::FusedArgs p{};
+  p.y = y; p.y_pitch = static_cast<int>(y_pitch); p.y_plane = y_plane;
+  p.Z = static_cast<int>(Z); p.Y = static_cast<int>(Y); p.X = static_cast<int>(X);
+  p.kz = kz; p.kz_flipped = kz_flipped; p.ky = ky; p.ky_flipped = ky_flipped;
+  p.kx = kx; p.kx_flipped = kx_flipped;
+  p.pz = pz; p.py = py; p.px = px; p.eps = eps;
+  p.nz = nz; p.ny = ny; p.nx = nx;
+  p.tiles_x = static_cast<int>(lsr::ceil_div(X, lsr::kSepWideTileX));
+  p.tiles_y = static_cast<int>(lsr::ceil_div(Y, 8 * lsr::fused_run(PZ)));
+  p.z_chunk = static_cast<int>(pick_fused_z_chunk(Z, int64_t(p.tiles_x) * p.tiles_y, PZ));
+  const int64_t blocks64 = int64_t(p.tiles_x) * p.tiles_y * lsr::ceil_div(Z, p.z_chunk);
+  LSR_REQUIRE(blocks64 < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
+              (long long)blocks64);
+  const unsigned blocks = static_cast<unsigned>(blocks64);
+  hipStream_t s = lsr::as_stream(stream);
+
+  float* bufs[2] = {x_a + origin, x_b + origin};  // logical (0,0,0) of the two working volumes
+  for (int it = 0; it < iters; ++it) {
+    const bool from_y = init_from_y && it == 0;
+    const bool last = it + 1 == iters && x_out != nullptr;
+    p.x = from_y ? y : bufs[it & 1];
+    p.pitch = static_cast<int>(from_y ? y_pitch : pitch);
+    p.plane = from_y ? y_plane : plane;
+    p.out = last ? x_out : bufs[(it + 1) & 1];
+    p.out_pitch = static_cast<int>(last ? X : pitch);
+    p.out_plane = last ? Y * X : plane;
+    bool ok = false;
+    switch (PZ) {
+      case 3: ok = lsr::launch_fused_pz3(PYX, p, blocks, s); break;
+      case 5: ok = lsr::launch_fused_pz5(PYX, p, blocks, s); break;
+      case 7: ok = lsr::launch_fused_pz7(PYX, p, blocks, s); break;
+      case 9: ok = lsr::launch_fused_pz9(PYX, p, blocks, s); break;
+      default: break;
+    }
+    LSR_REQUIRE(ok, LSR_E_UNSUPPORTED, "no fused specialisation for taps (%d,%d,%d)", pz, py, px);
+    if (int rc = lsr::launch_status("lsr_rl_sep_fused_f32")) return rc;
   }
   return LSR_OK;
 }

@@ -92,6 +92,35 @@ inline int sep_stage_cols(int PX) {
 }
 // floats the separable kernel stages per row: its last x-pass item reads ceil((4+PX-1)/4) 16-byte
 // pieces starting at column tile_x - 4
+// Fused Richardson-Lucy iteration (rl_fused_sep.hip): x, y and x_new are padded volumes that share
+// one geometry (pitch, plane); pointers address the LOGICAL element (0,0,0).
+struct FusedArgs {
+  const float* x;
+  const float* y;
+  float* out;
+  int64_t plane, y_plane, out_plane;  // z strides (floats)
+  int pitch, y_pitch, out_pitch;      // y strides (floats)
+  int Z, Y, X;
+  const float* kz;
+  const float* kz_flipped;
+  const float* ky;
+  const float* ky_flipped;
+  const float* kx;
+  const float* kx_flipped;
+  int pz, py, px;
+  float eps;
+  const float* nz;
+  const float* ny;
+  const float* nx;
+  int tiles_x, tiles_y;
+  int z_chunk;
+};
+// columns staged left and right of a 128-column tile: twice the PSF radius, rounded up to 16 bytes
+constexpr int fused_window_halo(int PYX) { return 4 * ((2 * (PYX / 2) + 3) / 4); }
+// tile rows / 8 of the fused kernel
+constexpr int fused_run(int PZ) { return PZ <= 9 ? 4 : 3; }
+constexpr int kFusedMaxPZ = 9, kFusedMaxPYX = 9;
+
 inline int sep_wide_stage_cols(int PX) { return kSepWideTileX - 4 + 4 * ((4 + PX - 1 + 3) / 4); }
 
 // correlate_sep.hip, compiled once per PZ (-DLSR_SEP_PZ=n).  `pyx` is the (square) in-plane tap
@@ -106,6 +135,15 @@ LSR_DECL_SEP(11)
 LSR_DECL_SEP(13)
 LSR_DECL_SEP(15)
 #undef LSR_DECL_SEP
+
+// rl_fused_sep.hip, compiled once per PZ (-DLSR_FUSED_PZ=n); pyx in {3,5,7,9}.
+#define LSR_DECL_FUSED(n) \
+  bool launch_fused_pz##n(int pyx, const FusedArgs& p, unsigned blocks, hipStream_t s);
+LSR_DECL_FUSED(3)
+LSR_DECL_FUSED(5)
+LSR_DECL_FUSED(7)
+LSR_DECL_FUSED(9)
+#undef LSR_DECL_FUSED
 
 // correlate_dense.hip, compiled once per PZ (-DLSR_DENSE_PZ=n); pyx in {3,5,7,9}, PZ*pyx*pyx <= 900.
 #define LSR_DECL_DENSE(n) \

@@ -1,0 +1,558 @@
+// One Richardson-Lucy iteration in ONE launch for separable PSFs:
+//
+//     x_new = x * H^T( y / (H x + eps) ) / (H^T 1)
+//
+// The two-launch form (correlate_sep.hip: RATIO, then UPDATE) moves 24 bytes per voxel and
+// iteration through HBM (x, y -> ratio;  ratio, x -> x_new); this kernel moves 12 algorithmic bytes
+// (x, y -> x_new) -- the ratio volume never leaves the CU.  It is the same z-marching 2.5-D
+// stencil, run twice back to back inside the workgroup:
+//
+//   stage 1  c = H x on the tile grown by the in-plane PSF radius C   ((TY+2C) x (128+2C) points)
+//            ratio = y * rcp(c + eps), zero outside the volume          -> LDS only
+//   stage 2  u = H^T ratio on the tile (TY x 128), x_new = x * u * rcp(H^T 1) -> HBM
+//
+// All three volumes (x in, y, x out) are padded volumes (lsr_sep_padded_shape) with a ZERO halo of
+// 2C rows / 32 columns, so every load is unconditional and in bounds, and "zero outside the
+// volume" is real memory for stage 1.  Stage 2's zero padding is the explicit mask on `ratio`.
+// Arithmetic per voxel (operation order, FMA placement, rcp refinement) is that of the two-launch
+// kernels, so both paths return bit-identical volumes (tests/test_gpu_parity.py checks equality).
+//
+// A 512-thread workgroup (8 waves, one workgroup per CU) owns a TY x 128 column of output and
+// marches along z.  Iteration p (two workgroup barriers):
+//
+//   phase A   glds: x plane p+2 -> LDS ring slot (p+2)%3   (global_load_lds_dwordx4, no registers)
+//             x1 pass: x plane p,        A[p%3] -> B1      (4 outputs per item, ds_read_b128)
+//             x2 pass: ratio plane p-1-CZ, R    -> B2
+//   phase B   y2/z2 pass: B2 -> stage-2 accumulators; output plane o = p-1-2CZ is complete:
+//             epilogue and store; then request x(o+1), nz(o+1) for the next epilogue
+//             y1/z1 pass: B1 -> stage-1 accumulators; ratio plane q = p-CZ is complete -> R;
+//             then request y(q+1) for the next ratio
+//             wait for this wave's glds of plane p+1, barrier
+//
+// Memory pipeline by hand, as in correlate_sep.hip: global loads are inline asm, every consumer is
+// preceded by a hand-counted `s_waitcnt vmcnt(N)`, N = the number of LOADS this wave issued after
+// the wanted one (MI355X_MICROARCH.md: vector-memory operations retire in issue order, so younger
+// stores can only delay the wait).  Every iteration issues the same loads whether or not its
+// planes are inside the volume (addresses are clamped), which keeps N a compile-time constant.
+//
+// Algorithmic HBM bytes: 12 per voxel and iteration.
+
+#include "common.hpp"
+#include "correlate_common.hpp"
+
+#ifndef LSR_FUSED_PZ
+#error "compile with -DLSR_FUSED_PZ=<odd tap count along z>"
+#endif
+
+namespace {
+
+using lsr::FusedArgs;
+
+constexpr int kTX = lsr::kSepWideTileX;  // 128
+constexpr int kWaves = 8;
+constexpr int kThreads = 64 * kWaves;
+constexpr int kBand = 8;
+constexpr int kRing = 3;                 // LDS ring slots of staged x planes
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <int PZ, int PYX, int RUN>
+struct Geo {
+  static constexpr int C = PYX / 2, CZ = PZ / 2;
+  static constexpr int TY = 8 * RUN;
+  static constexpr int WL = lsr::fused_window_halo(PYX);  // staged columns left/right of the tile
+  static constexpr int AR = TY + 4 * C;                   // staged rows
+  static constexpr int PA = kTX + 2 * WL;                 // staged columns = pitch of A
+  static constexpr int CH = PA / 4;                       // 16-byte chunks per staged row
+  static constexpr int NCH = AR * CH;
+  static constexpr int SL = cdiv(NCH, kThreads);          // glds per thread and plane
+  static constexpr int ASZ = cdiv(NCH, 64) * 64 * 4;      // floats per ring slot (whole waves of chunks)
+  static constexpr int NP = cdiv(4 + 2 * C, 4);           // ds_read_b128 per x-pass item
+  static constexpr int G1 = (kTX + WL) / 4;               // x1 items per row
+  static constexpr int PB1 = 4 * G1;                      // pitch of B1 (linear in the item index)
+  static constexpr int NIT1 = AR * G1;
+  static constexpr int XIT1 = cdiv(NIT1, kThreads);
+  static constexpr int R1 = TY + 2 * C;                   // stage-1 (ratio) rows
+  static constexpr int RUN1 = cdiv(R1, 8);                // ratio rows per thread
+  static constexpr int E = PB1 - kTX;                     // ratio columns beyond the two 64-lane groups
+  static constexpr int NE = R1 * E;                       // "edge" points of the ratio plane
+  static constexpr int EP = cdiv(NE, kThreads);           // edge points per thread
+  static constexpr int SH = WL - 2 * C;                   // B1 column -> ratio column shift (0 or 2)
+  static constexpr int PR = 4 * (kTX / 4 - 1 + NP);       // pitch of R
+  static constexpr int RSZ = 4 + 8 * RUN1 * PR;           // one leading chunk absorbs columns < 0
+  static constexpr int NIT2 = R1 * (kTX / 4);
+  static constexpr int XIT2 = cdiv(NIT2, kThreads);
+  static constexpr int B1SZ = AR * PB1;
+  static constexpr int B2SZ = R1 * kTX;
+  // LDS map (floats): ring | B1 | R | B2.  B1's wasted rows read into R, never past the end.
+  static constexpr int OFF_B1 = kRing * ASZ;
+  static constexpr int OFF_R = OFF_B1 + B1SZ;
+  static constexpr int OFF_B2 = OFF_R + RSZ;
+  static constexpr int OFF_DUMP = OFF_B2 + B2SZ;          // 1 KB: where glds of waves past the window land
+  static constexpr int TOTAL = OFF_DUMP + 256;
+  static constexpr int NY = 2 * RUN1 + EP;                // y loads per thread and iteration
+  static constexpr int NXC = 2 * RUN + 1;                 // x (centre) + nz loads
+  static_assert(TOTAL * 4 <= 160 * 1024, "LDS per workgroup");
+  static_assert(2 * C <= WL && WL <= lsr::kSepOriginCol, "halo columns");
+  static_assert(SL + 2 * (NY + NXC) <= 63, "vmcnt is a 6-bit counter");
+  static_assert(OFF_B1 % 4 == 0 && OFF_R % 4 == 0 && OFF_B2 % 4 == 0, "16-byte aligned buffers");
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float fast_rcp(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+
+// ---- hand-managed memory operations: scalar base + unsigned 32-bit byte offset per lane -------
+// The destination is an in/out operand: a register that is loaded again before its value was used
+// (the prologue does that) must stay the same physical register while the older load is in flight.
+template <int IMM>
+__device__ __forceinline__ void gload(float& dst, const float* sbase, int voff) {
+  asm volatile("global_load_dword %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void gstore(float* sbase, int voff, float v) {
+  asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+}
+// LDS-DMA: 16 bytes per lane, LDS address = m0 + 16 * lane.  One wait state between the write of
+// m0 and the load (s_nop).
+__device__ __forceinline__ void glds_x4(const float* sbase, int voff, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+               : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+// After a wait: pass the loaded registers through an (empty) volatile asm, so that every later use
+// depends on a statement the compiler keeps behind the wait.
+template <int K>
+__device__ __forceinline__ void tie(float (&a)[K]) {
+#pragma unroll
+  for (int i = 0; i < K; ++i) asm volatile("" : "+v"(a[i]));
+}
+__device__ __forceinline__ void tie(float& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int PZ, int PYX, int RUN>
+__global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
+  using T = Geo<PZ, PYX, RUN>;
+  constexpr int C = T::C, CZ = T::CZ, TY = T::TY, RUN1 = T::RUN1, EP = T::EP;
+  constexpr int NP = T::NP, NY = T::NY, NXC = T::NXC, SL = T::SL;
+  __shared__ f32x4 smem4[T::TOTAL / 4];
+  float* const smem = reinterpret_cast<float*>(smem4);
+  f32x4* const B1_4 = smem4 + T::OFF_B1 / 4;
+  const float* const B1 = smem + T::OFF_B1;
+  float* const Rw = smem + T::OFF_R + 4;            // ratio column 0 of row 0
+  const f32x4* const R_4 = smem4 + T::OFF_R / 4 + 1;
+  f32x4* const B2_4 = smem4 + T::OFF_B2 / 4;
+  const float* const B2 = smem + T::OFF_B2;
+  const unsigned lds_base =
+      static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) char*)smem4));
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // XCD-aware tile order (see correlate_sep.hip)
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int per = nblk / 8, rem = nblk % 8;
+    const int xcd = bid % 8, idx = bid / 8;
+    bid = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  }
+  const int tiles_xy = p.tiles_x * p.tiles_y;
+  const int zc = bid / tiles_xy;
+  const int lin = bid - zc * tiles_xy;
+  const int band = lin / (p.tiles_x * kBand);
+  const int lb = lin - band * (p.tiles_x * kBand);
+  const int band_h = min(kBand, p.tiles_y - band * kBand);
+  const int tx = lb / band_h;
+  const int ty = band * kBand + (lb - tx * band_h);
+
+  const int Z = p.Z, Y = p.Y, X = p.X;
+  const int x0 = tx * kTX, y0 = ty * TY;
+  const int zb = zc * p.z_chunk;
+  const int ze = min(zb + p.z_chunk, Z);
+
+  // taps -> SGPRs; the caller's taps sit centred in the compiled extents.  Stage 1 correlates
+  // with the flipped PSF (H), stage 2 with the PSF (H^T).
+  float w1z[PZ], w1y[PYX], w1x[PYX], w2z[PZ], w2y[PYX], w2x[PYX];
+  {
+    const int oz = (PZ - p.pz) / 2, oy = (PYX - p.py) / 2, ox = (PYX - p.px) / 2;
+#pragma unroll
+    for (int i = 0; i < PZ; ++i) {
+      const bool in = i >= oz && i < oz + p.pz;
+      w1z[i] = in ? p.kz_flipped[i - oz] : 0.0f;
+      w2z[i] = in ? p.kz[i - oz] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < PYX; ++i) {
+      const bool iy = i >= oy && i < oy + p.py, ix = i >= ox && i < ox + p.px;
+      w1y[i] = iy ? p.ky_flipped[i - oy] : 0.0f;
+      w2y[i] = iy ? p.ky[i - oy] : 0.0f;
+      w1x[i] = ix ? p.kx_flipped[i - ox] : 0.0f;
+      w2x[i] = ix ? p.kx[i - ox] : 0.0f;
+    }
+  }
+
+  // ---- staging (glds): chunk e = tid + 512 k of the (AR x PA) window whose first element is
+  // (y0 - 2C, x0 - WL); the LDS image of a ring slot is linear in e.
+  const float* const x_tile = p.x + (static_cast<int64_t>(y0 - 2 * C) * p.pitch + (x0 - T::WL));
+  int s_voff[SL];
+#pragma unroll
+  for (int k = 0; k < SL; ++k) {
+    const int e = min(tid + k * kThreads, T::NCH - 1);
+    const int r = e / T::CH, c = e - r * T::CH;
+    s_voff[k] = (r * p.pitch + 4 * c) * 4;
+  }
+  // ---- x1 items: i = tid + 512 k -> (row, g); A chunk = row * CH + g, B1 chunk = i
+  int a1_chunk[T::XIT1];
+#pragma unroll
+  for (int k = 0; k < T::XIT1; ++k) {
+    const int i = min(tid + k * kThreads, T::NIT1 - 1);
+    const int row = i / T::G1;
+    a1_chunk[k] = i + row * (T::CH - T::G1);
+  }
+  // ---- stage-1 points.  Main: ratio columns b = lane + 64 cg (B1 column index), ratio rows
+  // wave * RUN1 + m.  Ratio row r <-> tile row r - C; B1 column b <-> tile column b + C - WL.
+  const int r1_row0 = wave * RUN1;                            // scalar
+  const int y1_col = r1_row0 * T::PB1 + lane;                 // B1 float index of (row0, lane)
+  const int r_col = r1_row0 * T::PR + lane - T::SH;           // R float index of the same point
+  bool in1c[2];
+#pragma unroll
+  for (int cg = 0; cg < 2; ++cg) {
+    const int gx = x0 + lane + 64 * cg + C - T::WL;
+    in1c[cg] = gx >= 0 && gx < X;
+  }
+  // edge points: t = tid + 512 e -> (row t / E, column 128 + t % E)
+  int e_b1[EP], e_r[EP], e_voff[EP];
+  bool e_in[EP];
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    const int t = min(tid + e * kThreads, T::NE - 1);
+    const int er = t / T::E, ec = t - er * T::E;
+    e_b1[e] = er * T::PB1 + kTX + ec;
+    e_r[e] = er * T::PR + kTX + ec - T::SH;
+    const int gy = y0 + er - C, gx = x0 + kTX + ec + C - T::WL;
+    e_in[e] = gy >= 0 && gy < Y && gx >= 0 && gx < X;
+    e_voff[e] = (er * p.y_pitch + kTX + ec) * 4;   // from the y window's first element
+  }
+  const int lane4 = lane * 4;
+  // ---- stage-2 points: tile columns lane + 64 cg, tile rows wave * RUN + m
+  const int y2_col = (wave * RUN) * kTX + lane;
+  bool okc[2];
+#pragma unroll
+  for (int cg = 0; cg < 2; ++cg) okc[cg] = x0 + lane + 64 * cg < X;
+  float rnyx[2 * RUN];
+#pragma unroll
+  for (int cg = 0; cg < 2; ++cg) {
+    const float nxv = p.nx[min(x0 + lane + 64 * cg, X - 1)];
+#pragma unroll
+    for (int m = 0; m < RUN; ++m)
+      rnyx[cg * RUN + m] = fast_rcp(p.ny[min(y0 + wave * RUN + m, Y - 1)] * nxv);
+  }
+
+  float acc1[PZ][2 * RUN1], acc1e[PZ][EP], acc2[PZ][2 * RUN];
+#pragma unroll
+  for (int j = 0; j < PZ; ++j) {
+#pragma unroll
+    for (int i = 0; i < 2 * RUN1; ++i) acc1[j][i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < EP; ++i) acc1e[j][i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2 * RUN; ++i) acc2[j][i] = 0.0f;
+  }
+  float yv[2 * RUN1], ye[EP], xc[2 * RUN], nzv = 1.0f;
+#pragma unroll
+  for (int i = 0; i < 2 * RUN1; ++i) yv[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < EP; ++i) ye[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 2 * RUN; ++i) xc[i] = 0.0f;
+  __builtin_amdgcn_sched_barrier(0);  // setup loads (taps, norms) are consumed above this line
+
+  auto clampz = [&](int z) { return min(max(z, 0), Z - 1); };
+  auto issue_glds = [&](int plane, int slot) {  // SL loads
+    const float* src = x_tile + static_cast<int64_t>(clampz(plane)) * p.plane;
+    const unsigned dst = lds_base + (slot * T::ASZ + wave * 64 * 4) * 4;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+      // every wave issues SL loads (constant vmcnt bookkeeping); a wave whose chunks lie past the
+      // window sends them to the dump area
+      const bool live = wave * 64 + k * kThreads < T::NCH;  // wave-uniform
+      glds_x4(src, s_voff[k], live ? dst + k * kThreads * 16 : lds_base + T::OFF_DUMP * 4);
+    }
+  };
+  auto issue_xc = [&](int o) {  // NXC loads: x at the output points of plane o, and nz[o]
+    const int oc = clampz(o);
+    const float* base = p.x + (static_cast<int64_t>(oc) * p.plane + x0);
+#pragma unroll
+    for (int m = 0; m < RUN; ++m) {
+      const float* row = base + static_cast<int64_t>(y0 + wave * RUN + m) * p.pitch;
+      gload<0>(xc[m], row, lane4);
+      gload<256>(xc[RUN + m], row, lane4);
+    }
+    gload<0>(nzv, p.nz + oc, 0);
+  };
+  auto issue_y = [&](int q) {  // NY loads: y at the ratio points of plane q
+    const float* base = p.y + (static_cast<int64_t>(clampz(q)) * p.y_plane +
+                               static_cast<int64_t>(y0 - C) * p.y_pitch + (x0 + C - T::WL));
+#pragma unroll
+    for (int m = 0; m < RUN1; ++m) {
+      const float* row = base + static_cast<int64_t>(min(r1_row0 + m, T::R1 - 1)) * p.y_pitch;
+      gload<0>(yv[m], row, lane4);
+      gload<256>(yv[RUN1 + m], row, lane4);
+    }
+#pragma unroll
+    for (int e = 0; e < EP; ++e) gload<0>(ye[e], base, e_voff[e]);
+  };
+
+  // planes: x plane p feeds ratio planes p-CZ .. p+CZ; ratio plane q feeds outputs q-CZ .. q+CZ
+  const int q_lo = max(zb - CZ, 0), q_hi = min(ze - 1 + CZ, Z - 1);  // ratio planes that matter
+  const int p_lo = max(q_lo - CZ, 0);
+  const int p_hi = ze + 2 * CZ;  // inclusive: the iteration that completes output plane ze - 1
+
+  // prologue: the same load sequence two iterations would issue
+  int slot = 0;  // ring slot of plane p
+  issue_glds(p_lo, 0);
+  issue_xc(p_lo - 1 - 2 * CZ);
+  issue_y(p_lo - CZ);
+  issue_glds(p_lo + 1, 1);
+  issue_xc(p_lo - 1 - 2 * CZ);
+  issue_y(p_lo - CZ);
+  wait_vm<SL + 2 * (NXC + NY)>();  // this wave's part of plane p_lo has landed
+  lds_barrier();
+
+  for (int pz = p_lo; pz <= p_hi; ++pz) {
+    const int qr = pz - 1 - CZ;      // ratio plane in R (written by the previous iteration)
+    const int o = qr - CZ;           // output plane completed by this iteration
+    const int q = pz - CZ;           // ratio plane completed by this iteration
+    const bool x_live = pz < Z && pz <= q_hi + CZ;        // x plane pz exists and is needed
+    const bool r_live = qr >= q_lo && qr <= q_hi;         // ratio plane qr is non-zero
+    const int slot2 = slot >= 1 ? slot - 1 : 2;           // (slot + 2) % 3
+
+    // ---------------- phase A ----------------
+    issue_glds(pz + 2, slot2);
+    if (x_live) {
+      const f32x4* A_4 = smem4 + slot * (T::ASZ / 4);
+#pragma unroll
+      for (int k = 0; k < T::XIT1; ++k) {
+        if (k + 1 < T::XIT1 || tid + k * kThreads < T::NIT1) {
+          const f32x4* src = A_4 + a1_chunk[k];
+          float w[4 * NP];
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            const f32x4 v = src[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+          }
+          f32x4 ov;
+          ov.x = w1x[0] * w[0];
+          ov.y = w1x[0] * w[1];
+          ov.z = w1x[0] * w[2];
+          ov.w = w1x[0] * w[3];
+#pragma unroll
+          for (int c = 1; c < PYX; ++c) {
+            ov.x = fmaf(w1x[c], w[c], ov.x);
+            ov.y = fmaf(w1x[c], w[c + 1], ov.y);
+            ov.z = fmaf(w1x[c], w[c + 2], ov.z);
+            ov.w = fmaf(w1x[c], w[c + 3], ov.w);
+          }
+          B1_4[tid + k * kThreads] = ov;
+        }
+      }
+    }
+    if (r_live) {
+#pragma unroll
+      for (int k = 0; k < T::XIT2; ++k) {
+        const int j = tid + k * kThreads;
+        if (k + 1 < T::XIT2 || j < T::NIT2) {
+          const int row = j >> 5;
+          const f32x4* src = R_4 + (j + row * (T::PR / 4 - kTX / 4));
+          float w[4 * NP];
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            const f32x4 v = src[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+          }
+          f32x4 ov;
+          ov.x = w2x[0] * w[0];
+          ov.y = w2x[0] * w[1];
+          ov.z = w2x[0] * w[2];
+          ov.w = w2x[0] * w[3];
+#pragma unroll
+          for (int c = 1; c < PYX; ++c) {
+            ov.x = fmaf(w2x[c], w[c], ov.x);
+            ov.y = fmaf(w2x[c], w[c + 1], ov.y);
+            ov.z = fmaf(w2x[c], w[c + 2], ov.z);
+            ov.w = fmaf(w2x[c], w[c + 3], ov.w);
+          }
+          B2_4[j] = ov;
+        }
+      }
+    }
+    lds_barrier();
+
+    // ---------------- phase B ----------------
+    // stage 2: absorb ratio plane qr, finish output plane o
+    {
+      float pl[2 * RUN];
+#pragma unroll
+      for (int i = 0; i < 2 * RUN; ++i) pl[i] = 0.0f;
+      if (r_live) {
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+          const float* colp = B2 + y2_col + 64 * cg;
+          float cv[RUN + 2 * C];
+#pragma unroll
+          for (int j = 0; j < RUN + 2 * C; ++j) cv[j] = colp[j * kTX];
+#pragma unroll
+          for (int m = 0; m < RUN; ++m) {
+            float s = w2y[0] * cv[m];
+#pragma unroll
+            for (int b = 1; b < PYX; ++b) s = fmaf(w2y[b], cv[m + b], s);
+            pl[cg * RUN + m] = s;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PZ - 1; ++j)
+#pragma unroll
+        for (int i = 0; i < 2 * RUN; ++i) acc2[j][i] = fmaf(w2z[PZ - 1 - j], pl[i], acc2[j + 1][i]);
+#pragma unroll
+      for (int i = 0; i < 2 * RUN; ++i) acc2[PZ - 1][i] = w2z[0] * pl[i];
+
+      // x(o), nz(o): requested by the previous iteration; issued since: its y loads, this
+      // iteration's glds
+      wait_vm<NY + SL>();
+      tie(xc);
+      tie(nzv);
+      if (o >= zb && o < ze) {
+        float* obase = p.out + (static_cast<int64_t>(o) * p.out_plane + x0);
+        const float rz = fast_rcp(nzv);
+#pragma unroll
+        for (int m = 0; m < RUN; ++m) {
+          const int gy = y0 + wave * RUN + m;
+          if (gy < Y) {  // wave-uniform
+            float* row = obase + static_cast<int64_t>(gy) * p.out_pitch;
+            if (okc[0]) gstore<0>(row, lane4, xc[m] * acc2[0][m] * (rz * rnyx[m]));
+            if (okc[1]) gstore<256>(row, lane4, xc[RUN + m] * acc2[0][RUN + m] * (rz * rnyx[RUN + m]));
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the refill reuses xc / nzv
+      issue_xc(o + 1);
+    }
+    // stage 1: absorb x plane pz, finish ratio plane q
+    {
+      float pl[2 * RUN1], ple[EP];
+#pragma unroll
+      for (int i = 0; i < 2 * RUN1; ++i) pl[i] = 0.0f;
+#pragma unroll
+      for (int e = 0; e < EP; ++e) ple[e] = 0.0f;
+      if (x_live) {
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+          const float* colp = B1 + y1_col + 64 * cg;
+          float cv[RUN1 + 2 * C];
+#pragma unroll
+          for (int j = 0; j < RUN1 + 2 * C; ++j) cv[j] = colp[j * T::PB1];
+#pragma unroll
+          for (int m = 0; m < RUN1; ++m) {
+            float s = w1y[0] * cv[m];
+#pragma unroll
+            for (int b = 1; b < PYX; ++b) s = fmaf(w1y[b], cv[m + b], s);
+            pl[cg * RUN1 + m] = s;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+          const float* colp = B1 + e_b1[e];
+          float s = w1y[0] * colp[0];
+#pragma unroll
+          for (int b = 1; b < PYX; ++b) s = fmaf(w1y[b], colp[b * T::PB1], s);
+          ple[e] = s;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PZ - 1; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2 * RUN1; ++i) acc1[j][i] = fmaf(w1z[PZ - 1 - j], pl[i], acc1[j + 1][i]);
+#pragma unroll
+        for (int e = 0; e < EP; ++e) acc1e[j][e] = fmaf(w1z[PZ - 1 - j], ple[e], acc1e[j + 1][e]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2 * RUN1; ++i) acc1[PZ - 1][i] = w1z[0] * pl[i];
+#pragma unroll
+      for (int e = 0; e < EP; ++e) acc1e[PZ - 1][e] = w1z[0] * ple[e];
+
+      // y(q): requested by the previous iteration; issued since: this iteration's glds and x loads
+      wait_vm<SL + NXC>();
+      tie(yv);
+      tie(ye);
+      const bool q_in = q >= q_lo && q <= q_hi;  // wave-uniform; planes outside are zero
+#pragma unroll
+      for (int m = 0; m < RUN1; ++m) {
+        const int gy = y0 + r1_row0 + m - C;
+        const bool row_in = q_in && gy >= 0 && gy < Y && r1_row0 + m < T::R1;  // wave-uniform
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+          const int i = cg * RUN1 + m;
+          const float r = yv[i] * fast_rcp(acc1[0][i] + p.eps);
+          Rw[r_col + m * T::PR + 64 * cg] = (row_in && in1c[cg]) ? r : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < EP; ++e) {
+        if (e + 1 < EP || tid + e * kThreads < T::NE) {
+          const float r = ye[e] * fast_rcp(acc1e[0][e] + p.eps);
+          Rw[e_r[e]] = (q_in && e_in[e]) ? r : 0.0f;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the refill reuses yv / ye
+      issue_y(q + 1);
+    }
+    // plane pz+1 (requested one iteration ago); issued since: x, y loads of the previous
+    // iteration, this iteration's glds, x and y loads
+    wait_vm<SL + 2 * (NXC + NY)>();
+    lds_barrier();
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land after the wave has ended
+}
+
+template <int PZ, int PYX>
+bool launch_one(const FusedArgs& p, dim3 grid, hipStream_t s) {
+  constexpr int RUN = lsr::fused_run(PZ);
+  hipLaunchKernelGGL((rl_fused_sep_kernel<PZ, PYX, RUN>), grid, dim3(kThreads), 0, s, p);
+  return true;
+}
+
+}  // namespace
+
+namespace lsr {
+
+#define LSR_CAT2(a, b) a##b
+#define LSR_CAT(a, b) LSR_CAT2(a, b)
+bool LSR_CAT(launch_fused_pz, LSR_FUSED_PZ)(int pyx, const FusedArgs& p, unsigned blocks, hipStream_t s) {
+  constexpr int PZ = LSR_FUSED_PZ;
+  const dim3 grid(blocks);
+  switch (pyx) {
+    case 3: return launch_one<PZ, 3>(p, grid, s);
+    case 5: return launch_one<PZ, 5>(p, grid, s);
+    case 7: return launch_one<PZ, 7>(p, grid, s);
+    case 9: return launch_one<PZ, 9>(p, grid, s);
+    default: return false;
+  }
+}
+
+}  // namespace lsr

@@ -168,9 +168,12 @@ class RichardsonLucyPlan:
     """
 
     def __init__(self, shape_zyx, psf, device, *, separable: str = "auto",
-                 separable_rtol: float = 1e-6, psf_factors=None):
+                 separable_rtol: float = 1e-6, psf_factors=None, fused: str = "auto"):
         import torch
 
+        if fused not in ("auto", "never"):
+            raise ValueError("fused must be 'auto' or 'never'")
+        self._fused_mode = fused
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.LsrError("RichardsonLucyPlan", -1,
@@ -196,7 +199,8 @@ class RichardsonLucyPlan:
                     raise ValueError("psf is not rank-1 within separable_rtol")
 
         def dev(a, dtype=torch.float32):
-            return torch.as_tensor(np.ascontiguousarray(a), device=self.device).to(dtype)
+            # (np.array copies: a reversed 1-element view keeps its negative stride otherwise)
+            return torch.as_tensor(np.array(a, order="C"), device=self.device).to(dtype)
 
         z, y, x = self.shape
         if factors is not None:
@@ -225,6 +229,10 @@ class RichardsonLucyPlan:
         self._ratio = None   # dense path: ratio scratch
         self._x_pad = None   # separable path: zero-haloed working volumes
         self._ratio_pad = None
+        self._y_pad = None   # fused path: padded copy of a dense y
+        # one launch per iteration (rl_fused_sep.hip) where the PSF fits its specialisations
+        self.fused = bool(self._psf.separable and self._fused_mode == "auto"
+                          and _lib.call_value("lsr_rl_sep_fused_supported", *self._psf.shape))
 
     @property
     def separable(self) -> bool:
@@ -254,11 +262,12 @@ class RichardsonLucyPlan:
 
     def release(self) -> None:
         """Drop the scratch volumes."""
-        self._ratio = self._x_pad = self._ratio_pad = None
+        self._ratio = self._x_pad = self._ratio_pad = self._y_pad = None
 
     def __call__(self, y, iterations: int = 20, eps: float = 1e-6, x0=None, out=None, events=None):
         """Run RL.  ``events`` = optional ``(start, end)`` torch events recorded on the launch
-        stream right around the ``2 * iterations`` kernel launches (what ``bench.py`` times)."""
+        stream right around the kernel launches (``iterations`` fused launches, or
+        ``2 * iterations`` ratio / update launches) -- what ``bench.py`` times."""
         import torch
 
         y_padded = None
@@ -299,7 +308,32 @@ class RichardsonLucyPlan:
         ps = self._psf
         with torch.cuda.device(self.device):
             stream = _lib.stream_ptr(self.device)
-            if ps.separable:
+            if ps.separable and self.fused:
+                # one launch per iteration; y must be a zero-haloed padded volume (the kernel
+                # reads it on the tile grown by the PSF radius)
+                x_pad, ratio_pad = self._scratch()
+                if y_padded is None:
+                    if self._y_pad is None:
+                        self._y_pad = PaddedVolume(self.shape, ps.shape, self.device)
+                    self._y_pad.view.copy_(y)
+                    y_padded = self._y_pad
+                    y_ptr, y_pitch, y_plane = y_padded.logical_ptr(), y_padded.pitch, y_padded.plane
+                    from_y = x0 is None
+                if not from_y:
+                    x_pad.view.copy_(init)
+                (kz, ky, kx), (fz, fy, fx) = ps.k, ps.k_flipped
+                nz, ny, nx = self._norm
+                if events:
+                    events[0].record()
+                _lib.call(
+                    "lsr_rl_sep_fused_f32", y_ptr, y_pitch, y_plane, int(from_y),
+                    x_pad.full.data_ptr(), ratio_pad.full.data_ptr(),
+                    x.data_ptr(), z, yy, xx, kz.data_ptr(), fz.data_ptr(), ps.shape[0],
+                    ky.data_ptr(), fy.data_ptr(), ps.shape[1], kx.data_ptr(), fx.data_ptr(),
+                    ps.shape[2], nz.data_ptr(), ny.data_ptr(), nx.data_ptr(), iterations,
+                    ctypes.c_float(eps), stream,
+                )
+            elif ps.separable:
                 # working volumes carry a zero halo: the kernels never bounds-check a load
                 x_pad, ratio_pad = self._scratch()
                 if not from_y:

@@ -283,6 +283,48 @@ def test_rl_20_iterations_vs_oracle(device, separable):
     assert float(x.min()) >= 0
 
 
+@pytest.mark.parametrize("pshape", [(9, 7, 7), (3, 3, 3), (5, 3, 9), (1, 1, 1), (9, 9, 9), (7, 5, 5), (9, 1, 7)])
+@pytest.mark.parametrize("vshape", [(20, 40, 70), (3, 5, 4), (37, 70, 300), (11, 33, 129)])
+def test_rl_fused_equals_two_launch_bit_exact(device, pshape, vshape):
+    """One launch per iteration (rl_fused_sep.hip) keeps the per-voxel arithmetic of the
+    ratio / update launches: the volumes are equal bit for bit, for x0 = y and for a given x0,
+    with a dense y (copied into a padded volume) and with y already padded, for odd and even
+    iteration counts (the working volumes ping-pong)."""
+    import torch
+
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+
+    rng = np.random.default_rng(sum(pshape) * 100 + sum(vshape))
+    factors = [np.abs(rng.normal(1.0, 0.4, n)).astype(np.float32) + 0.05 for n in pshape]
+    factors = [f / f.sum() for f in factors]           # asymmetric taps: flipped != unflipped
+    y = _t((rng.random(vshape) * 80 + 1).astype(np.float32), device)
+    x0 = _t((rng.random(vshape) * 40 + 1).astype(np.float32), device)
+    fused = RichardsonLucyPlan(vshape, None, device, psf_factors=factors)
+    plain = RichardsonLucyPlan(vshape, None, device, psf_factors=factors, fused="never")
+    assert fused.fused and not plain.fused
+    for iters in (1, 2, 5):
+        assert torch.equal(fused(y, iterations=iters), plain(y, iterations=iters))
+    assert torch.equal(fused(y, iterations=3, x0=x0), plain(y, iterations=3, x0=x0))
+    ypad = fused.new_padded_input()
+    ypad.view.copy_(y)
+    assert torch.equal(fused(ypad, iterations=4), plain(y, iterations=4))
+    assert torch.equal(ypad.view, y)                     # y is read, never written
+
+
+def test_rl_fused_unsupported_taps_fall_back(device):
+    from shrimpy_amd import _lib
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+
+    assert _lib.call_value("lsr_rl_sep_fused_supported", 9, 7, 7) == 1
+    assert _lib.call_value("lsr_rl_sep_fused_supported", 11, 7, 7) == 0
+    assert _lib.call_value("lsr_rl_sep_fused_supported", 9, 11, 3) == 0
+    psf, factors = o.gaussian_psf((11, 7, 13), (2.0, 1.2, 2.5))
+    plan = RichardsonLucyPlan((16, 30, 50), None, device, psf_factors=factors)
+    assert plan.separable and not plan.fused
+    y = o.bead_scene((16, 30, 50), seed=5, psf=psf, density=1e-3)
+    _close(plan(_t(y, device), iterations=3).cpu().numpy(), o.richardson_lucy(y, psf, 3), 5e-5, 2e-5)
+
+
 def test_rl_dense_rotated_psf_20_iterations(device):
     from shrimpy_amd.deconvolve import richardson_lucy
 
