@@ -186,12 +186,17 @@ int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_fr
  * `iters`, in x_a for even.
  */
 int lsr_rl_sep_fused_supported(int pz, int py, int px);
+/* `taps`: a DEVICE array of lsr_rl_sep_fused_taps_count() floats; lsr_rl_sep_fused_prepare_taps
+ * fills the HOST image from the three PSF factors (host arrays of pz / py / px taps), the caller
+ * uploads it once per PSF. The kernel reads it through the scalar cache. */
+int lsr_rl_sep_fused_taps_count(void);
+int lsr_rl_sep_fused_prepare_taps(const float* kz_host, int pz, const float* ky_host, int py,
+                                  const float* kx_host, int px, float* taps_host);
 int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
                          float* x_a, float* x_b, float* x_out, int64_t Z, int64_t Y, int64_t X,
-                         const float* kz, const float* kz_flipped, int pz,
-                         const float* ky, const float* ky_flipped, int py, const float* kx,
-                         const float* kx_flipped, int px, const float* nz, const float* ny,
-                         const float* nx, int iters, float eps, lsr_stream_t stream);
+                         const float* taps, int pz, int py, int px, const float* nz,
+                         const float* ny, const float* nx, int iters, float eps,
+                         lsr_stream_t stream);
 
 int lsr_rl_dense_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X,
                      const float* psf, const float* psf_flipped, int pz, int py, int px,

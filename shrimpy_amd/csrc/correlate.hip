@@ -488,19 +488,44 @@ extern "C" int lsr_rl_sep_fused_supported(int pz, int py, int px) {
   return PZ <= lsr::kFusedMaxPZ && PYX <= lsr::kFusedMaxPYX;
 }
 
+extern "C" int lsr_rl_sep_fused_taps_count(void) { return 6 * 16; }
+
+extern "C" int lsr_rl_sep_fused_prepare_taps(const float* kz_host, int pz, const float* ky_host, int py,
+                                             const float* kx_host, int px, float* taps_host) {
+  LSR_REQUIRE_PTR(kz_host);
+  LSR_REQUIRE_PTR(ky_host);
+  LSR_REQUIRE_PTR(kx_host);
+  LSR_REQUIRE_PTR(taps_host);
+  if (int rc = check_taps(pz, py, px)) return rc;
+  LSR_REQUIRE(lsr_rl_sep_fused_supported(pz, py, px), LSR_E_UNSUPPORTED,
+              "the fused RL iteration is compiled for up to %d x %d x %d taps, got (%d,%d,%d)",
+              lsr::kFusedMaxPZ, lsr::kFusedMaxPYX, lsr::kFusedMaxPYX, pz, py, px);
+  int PZ, PYX;
+  sep_compiled_taps(pz, py, px, &PZ, &PYX);
+  // rows: stage 1 (H = correlation with the flipped PSF) x, y, z; stage 2 (H^T, the PSF) x, y, z;
+  // each centred in its compiled extent, zeros elsewhere
+  const float* src[3] = {kx_host, ky_host, kz_host};
+  const int n[3] = {px, py, pz}, N[3] = {PYX, PYX, PZ};
+  for (int i = 0; i < 96; ++i) taps_host[i] = 0.0f;
+  for (int a = 0; a < 3; ++a) {
+    const int off = (N[a] - n[a]) / 2;
+    for (int i = 0; i < n[a]; ++i) {
+      taps_host[a * 16 + off + i] = src[a][n[a] - 1 - i];
+      taps_host[(3 + a) * 16 + off + i] = src[a][i];
+    }
+  }
+  return LSR_OK;
+}
+
 extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
                                     float* x_a, float* x_b, float* x_out, int64_t Z, int64_t Y,
-                                    int64_t X, const float* kz, const float* kz_flipped, int pz,
-                                    const float* ky, const float* ky_flipped, int py,
-                                    const float* kx, const float* kx_flipped, int px,
+                                    int64_t X, const float* taps, int pz, int py, int px,
                                     const float* nz, const float* ny, const float* nx, int iters,
                                     float eps, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(y);
   LSR_REQUIRE_PTR(x_a);
   LSR_REQUIRE_PTR(x_b);
-  LSR_REQUIRE_PTR(kz); LSR_REQUIRE_PTR(kz_flipped);
-  LSR_REQUIRE_PTR(ky); LSR_REQUIRE_PTR(ky_flipped);
-  LSR_REQUIRE_PTR(kx); LSR_REQUIRE_PTR(kx_flipped);
+  LSR_REQUIRE_PTR(taps);
   LSR_REQUIRE_PTR(nz); LSR_REQUIRE_PTR(ny); LSR_REQUIRE_PTR(nx);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
               (long long)Z, (long long)Y, (long long)X);
@@ -529,9 +554,7 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
   lsr::FusedArgs p{};
   p.y = y; p.y_pitch = static_cast<int>(y_pitch); p.y_plane = y_plane;
   p.Z = static_cast<int>(Z); p.Y = static_cast<int>(Y); p.X = static_cast<int>(X);
-  p.kz = kz; p.kz_flipped = kz_flipped; p.ky = ky; p.ky_flipped = ky_flipped;
-  p.kx = kx; p.kx_flipped = kx_flipped;
-  p.pz = pz; p.py = py; p.px = px; p.eps = eps;
+  p.taps = taps; p.eps = eps;
   p.nz = nz; p.ny = ny; p.nx = nx;
   p.tiles_x = static_cast<int>(lsr::ceil_div(X, lsr::kSepWideTileX));
   p.tiles_y = static_cast<int>(lsr::ceil_div(Y, 8 * lsr::fused_run(PZ)));
@@ -552,6 +575,7 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
     p.out = last ? x_out : bufs[(it + 1) & 1];
     p.out_pitch = static_cast<int>(last ? X : pitch);
     p.out_plane = last ? Y * X : plane;
+    p.mask_out = last ? 1 : 0;
     bool ok = false;
     switch (PZ) {
       case 3: ok = lsr::launch_fused_pz3(PYX, p, blocks, s); break;

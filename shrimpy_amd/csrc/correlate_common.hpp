@@ -101,14 +101,9 @@ struct FusedArgs {
   int64_t plane, y_plane, out_plane;  // z strides (floats)
   int pitch, y_pitch, out_pitch;      // y strides (floats)
   int Z, Y, X;
-  const float* kz;
-  const float* kz_flipped;
-  const float* ky;
-  const float* ky_flipped;
-  const float* kx;
-  const float* kx_flipped;
-  int pz, py, px;
+  const float* taps;  // device block from lsr_rl_sep_fused_prepare_taps (6 rows of 16 floats)
   float eps;
+  int mask_out;       // 1: `out` is dense, stores are masked to the volume; 0: padded, unmasked
   const float* nz;
   const float* ny;
   const float* nx;

@@ -240,17 +240,18 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
       o_off[col * kRun + m] = min(gy, Y - 1) * p.out_pitch + gxc;
     }
   }
-  float rnyx[kPts];  // reciprocal of the in-plane part of H^T 1 (UPDATE epilogue)
+  // reciprocals of the in-plane factors of H^T 1 (UPDATE epilogue); the product order
+  // (rz * rny) * rnx is shared with rl_fused_sep.hip, whose results are bit-identical
+  float rny[kRun], rnx[kCols];
 #pragma unroll
-  for (int i = 0; i < kPts; ++i) rnyx[i] = 0.0f;
+  for (int m = 0; m < kRun; ++m) rny[m] = 0.0f;
+#pragma unroll
+  for (int col = 0; col < kCols; ++col) rnx[col] = 0.0f;
   if constexpr (EPI == LSR_EPI_UPDATE) {
 #pragma unroll
-    for (int col = 0; col < kCols; ++col) {
-      const float nxv = p.nx[min(x0 + lane + 64 * col, X - 1)];
+    for (int col = 0; col < kCols; ++col) rnx[col] = fast_rcp(p.nx[min(x0 + lane + 64 * col, X - 1)]);
 #pragma unroll
-      for (int m = 0; m < kRun; ++m)
-        rnyx[col * kRun + m] = fast_rcp(p.ny[min(gy_out0 + m, Y - 1)] * nxv);
-    }
+    for (int m = 0; m < kRun; ++m) rny[m] = fast_rcp(p.ny[min(gy_out0 + m, Y - 1)]);
   }
 
   // pending output planes: acc[j][i] <-> z_out = zi - cz + j once plane zi is absorbed
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
           const float rz = fast_rcp(nz_use);
 #pragma unroll
           for (int i = 0; i < kPts; ++i)
-            if (ok[i]) o[o_off[i]] = aux_use[i] * acc[0][i] * (rz * rnyx[i]);
+            if (ok[i]) o[o_off[i]] = aux_use[i] * acc[0][i] * ((rz * rny[i % kRun]) * rnx[i / kRun]);
         } else {
 #pragma unroll
           for (int i = 0; i < kPts; ++i)

@@ -89,20 +89,52 @@ struct Geo {
   static constexpr int OFF_R = OFF_B1 + B1SZ;
   static constexpr int OFF_B2 = OFF_R + RSZ;
   static constexpr int OFF_DUMP = OFF_B2 + B2SZ;          // 1 KB: where glds of waves past the window land
-  static constexpr int TOTAL = OFF_DUMP + 256;
+  static constexpr int OFF_RNY = OFF_DUMP + 256;          // 1 / ny of the tile rows
+  static constexpr int TOTAL = OFF_RNY + 32;
   static constexpr int NY = 2 * RUN1 + EP;                // y loads per thread and iteration
   static constexpr int NXC = 2 * RUN + 1;                 // x (centre) + nz loads
   static_assert(TOTAL * 4 <= 160 * 1024, "LDS per workgroup");
+  static_assert(PR == PB1, "B1 and R share a pitch");
   static_assert(2 * C <= WL && WL <= lsr::kSepOriginCol, "halo columns");
   static_assert(SL + 2 * (NY + NXC) <= 63, "vmcnt is a 6-bit counter");
   static_assert(OFF_B1 % 4 == 0 && OFF_R % 4 == 0 && OFF_B2 % 4 == 0, "16-byte aligned buffers");
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Two floats in an even-aligned register pair: the operand of the packed fp32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of work per issue slot).  Each component is an
+// ordinary IEEE operation, so packing never changes a result.  The pairs are chosen by hand -- the
+// two column groups of a thread, which ds_read2 delivers in adjacent registers -- because hipcc's
+// own pairing (rows of one column) costs two v_mov per packed instruction.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float fast_rcp(float d) {
   float r = __builtin_amdgcn_rcpf(d);
   return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ f32x2 splat(float a) { return f32x2{a, a}; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 fast_rcp2(f32x2 d) {  // fast_rcp on both components
+  const f32x2 r = f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  return pk_fma(pk_fma(-d, r, splat(1.0f)), r, r);
+}
+// One x-pass item: 4 consecutive outputs from 4 + PX - 1 inputs held in NP 16-byte pieces.
+template <int PX, int NP>
+__device__ __forceinline__ f32x4 xpass_item(const f32x4* src, const float (&wx)[PX]) {
+  float w[4 * NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const f32x4 v = src[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  f32x2 o01 = splat(wx[0]) * f32x2{w[0], w[1]};
+  f32x2 o23 = splat(wx[0]) * f32x2{w[2], w[3]};
+#pragma unroll
+  for (int c = 1; c < PX; ++c) {
+    o01 = pk_fma(splat(wx[c]), f32x2{w[c], w[c + 1]}, o01);
+    o23 = pk_fma(splat(wx[c]), f32x2{w[c + 2], w[c + 3]}, o23);
+  }
+  return f32x4{o01.x, o01.y, o23.x, o23.y};
 }
 
 // ---- hand-managed memory operations: scalar base + unsigned 32-bit byte offset per lane -------
@@ -184,26 +216,20 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
   const int zb = zc * p.z_chunk;
   const int ze = min(zb + p.z_chunk, Z);
 
-  // taps -> SGPRs; the caller's taps sit centred in the compiled extents.  Stage 1 correlates
-  // with the flipped PSF (H), stage 2 with the PSF (H^T).
-  float w1z[PZ], w1y[PYX], w1x[PYX], w2z[PZ], w2y[PYX], w2x[PYX];
-  {
-    const int oz = (PZ - p.pz) / 2, oy = (PYX - p.py) / 2, ox = (PYX - p.px) / 2;
+  // taps: a device block prepared by lsr_rl_sep_fused_prepare_taps -- six rows of 16 floats
+  // (stage 1 = flipped PSF: x, y, z; stage 2 = PSF: x, y, z), centred in the compiled extents, zero
+  // elsewhere.  Each pass reads its taps through the scalar cache right before it runs (an opaque
+  // zero offset keeps hipcc from hoisting all 46 of them into SGPRs for the whole loop, which
+  // spills).
+  typedef const float __attribute__((address_space(4))) cfloat;
+  const cfloat* const taps_base = (const cfloat*)p.taps;
+  auto load_taps = [&](int row, auto& w) {
+    int opaque = 0;
+    asm volatile("" : "+s"(opaque));
+    const cfloat* t = taps_base + row * 16 + opaque;
 #pragma unroll
-    for (int i = 0; i < PZ; ++i) {
-      const bool in = i >= oz && i < oz + p.pz;
-      w1z[i] = in ? p.kz_flipped[i - oz] : 0.0f;
-      w2z[i] = in ? p.kz[i - oz] : 0.0f;
-    }
-#pragma unroll
-    for (int i = 0; i < PYX; ++i) {
-      const bool iy = i >= oy && i < oy + p.py, ix = i >= ox && i < ox + p.px;
-      w1y[i] = iy ? p.ky_flipped[i - oy] : 0.0f;
-      w2y[i] = iy ? p.ky[i - oy] : 0.0f;
-      w1x[i] = ix ? p.kx_flipped[i - ox] : 0.0f;
-      w2x[i] = ix ? p.kx[i - ox] : 0.0f;
-    }
-  }
+    for (int i = 0; i < static_cast<int>(sizeof(w) / sizeof(float)); ++i) w[i] = t[i];
+  };
 
   // ---- staging (glds): chunk e = tid + 512 k of the (AR x PA) window whose first element is
   // (y0 - 2C, x0 - WL); the LDS image of a ring slot is linear in e.
@@ -235,14 +261,13 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
     in1c[cg] = gx >= 0 && gx < X;
   }
   // edge points: t = tid + 512 e -> (row t / E, column 128 + t % E)
-  int e_b1[EP], e_r[EP], e_voff[EP];
+  int e_b1[EP], e_voff[EP];  // (the R index of an edge point is e_b1 - SH: B1 and R share a pitch)
   bool e_in[EP];
 #pragma unroll
   for (int e = 0; e < EP; ++e) {
     const int t = min(tid + e * kThreads, T::NE - 1);
     const int er = t / T::E, ec = t - er * T::E;
     e_b1[e] = er * T::PB1 + kTX + ec;
-    e_r[e] = er * T::PR + kTX + ec - T::SH;
     const int gy = y0 + er - C, gx = x0 + kTX + ec + C - T::WL;
     e_in[e] = gy >= 0 && gy < Y && gx >= 0 && gx < X;
     e_voff[e] = (er * p.y_pitch + kTX + ec) * 4;   // from the y window's first element
@@ -253,32 +278,33 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
   bool okc[2];
 #pragma unroll
   for (int cg = 0; cg < 2; ++cg) okc[cg] = x0 + lane + 64 * cg < X;
-  float rnyx[2 * RUN];
+  // reciprocal in-plane norm factors: 1/nx per column in registers, 1/ny per tile row in LDS
+  float rnx[2];
 #pragma unroll
-  for (int cg = 0; cg < 2; ++cg) {
-    const float nxv = p.nx[min(x0 + lane + 64 * cg, X - 1)];
-#pragma unroll
-    for (int m = 0; m < RUN; ++m)
-      rnyx[cg * RUN + m] = fast_rcp(p.ny[min(y0 + wave * RUN + m, Y - 1)] * nxv);
-  }
+  for (int cg = 0; cg < 2; ++cg) rnx[cg] = fast_rcp(p.nx[min(x0 + lane + 64 * cg, X - 1)]);
+  float* const rny_lds = smem + T::OFF_RNY;
+  if (tid < TY) rny_lds[tid] = fast_rcp(p.ny[min(y0 + tid, Y - 1)]);
 
-  float acc1[PZ][2 * RUN1], acc1e[PZ][EP], acc2[PZ][2 * RUN];
+  // pending planes; a pair = (column group 0, column group 1) of one row
+  f32x2 acc1[PZ][RUN1], acc2[PZ][RUN];
+  float acc1e[PZ][EP];
 #pragma unroll
   for (int j = 0; j < PZ; ++j) {
 #pragma unroll
-    for (int i = 0; i < 2 * RUN1; ++i) acc1[j][i] = 0.0f;
+    for (int i = 0; i < RUN1; ++i) acc1[j][i] = splat(0.0f);
 #pragma unroll
     for (int i = 0; i < EP; ++i) acc1e[j][i] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 2 * RUN; ++i) acc2[j][i] = 0.0f;
+    for (int i = 0; i < RUN; ++i) acc2[j][i] = splat(0.0f);
   }
-  float yv[2 * RUN1], ye[EP], xc[2 * RUN], nzv = 1.0f;
+  float yv[2 * RUN1], ye[EP], xc[2 * RUN], nzv = 1.0f;  // [m] = group 0, [RUN(1) + m] = group 1
 #pragma unroll
   for (int i = 0; i < 2 * RUN1; ++i) yv[i] = 0.0f;
 #pragma unroll
   for (int i = 0; i < EP; ++i) ye[i] = 0.0f;
 #pragma unroll
   for (int i = 0; i < 2 * RUN; ++i) xc[i] = 0.0f;
+  const f32x2 rnx2 = f32x2{rnx[0], rnx[1]};
   __builtin_amdgcn_sched_barrier(0);  // setup loads (taps, norms) are consumed above this line
 
   auto clampz = [&](int z) { return min(max(z, 0), Z - 1); };
@@ -344,92 +370,60 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
     // ---------------- phase A ----------------
     issue_glds(pz + 2, slot2);
     if (x_live) {
+      float w1x[PYX];
+      load_taps(0, w1x);
       const f32x4* A_4 = smem4 + slot * (T::ASZ / 4);
 #pragma unroll
-      for (int k = 0; k < T::XIT1; ++k) {
-        if (k + 1 < T::XIT1 || tid + k * kThreads < T::NIT1) {
-          const f32x4* src = A_4 + a1_chunk[k];
-          float w[4 * NP];
+      for (int k = 0; k < T::XIT1; ++k)
+        if (k + 1 < T::XIT1 || tid + k * kThreads < T::NIT1)
+          B1_4[tid + k * kThreads] = xpass_item<PYX, NP>(A_4 + a1_chunk[k], w1x);
+    } else {  // a plane outside the volume: zeros (a handful of iterations per workgroup)
 #pragma unroll
-          for (int i = 0; i < NP; ++i) {
-            const f32x4 v = src[i];
-            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-          }
-          f32x4 ov;
-          ov.x = w1x[0] * w[0];
-          ov.y = w1x[0] * w[1];
-          ov.z = w1x[0] * w[2];
-          ov.w = w1x[0] * w[3];
-#pragma unroll
-          for (int c = 1; c < PYX; ++c) {
-            ov.x = fmaf(w1x[c], w[c], ov.x);
-            ov.y = fmaf(w1x[c], w[c + 1], ov.y);
-            ov.z = fmaf(w1x[c], w[c + 2], ov.z);
-            ov.w = fmaf(w1x[c], w[c + 3], ov.w);
-          }
-          B1_4[tid + k * kThreads] = ov;
-        }
-      }
+      for (int k = 0; k < T::XIT1; ++k)
+        if (k + 1 < T::XIT1 || tid + k * kThreads < T::NIT1) B1_4[tid + k * kThreads] = f32x4{0, 0, 0, 0};
     }
     if (r_live) {
+      float w2x[PYX];
+      load_taps(3, w2x);
 #pragma unroll
       for (int k = 0; k < T::XIT2; ++k) {
         const int j = tid + k * kThreads;
-        if (k + 1 < T::XIT2 || j < T::NIT2) {
-          const int row = j >> 5;
-          const f32x4* src = R_4 + (j + row * (T::PR / 4 - kTX / 4));
-          float w[4 * NP];
-#pragma unroll
-          for (int i = 0; i < NP; ++i) {
-            const f32x4 v = src[i];
-            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-          }
-          f32x4 ov;
-          ov.x = w2x[0] * w[0];
-          ov.y = w2x[0] * w[1];
-          ov.z = w2x[0] * w[2];
-          ov.w = w2x[0] * w[3];
-#pragma unroll
-          for (int c = 1; c < PYX; ++c) {
-            ov.x = fmaf(w2x[c], w[c], ov.x);
-            ov.y = fmaf(w2x[c], w[c + 1], ov.y);
-            ov.z = fmaf(w2x[c], w[c + 2], ov.z);
-            ov.w = fmaf(w2x[c], w[c + 3], ov.w);
-          }
-          B2_4[j] = ov;
-        }
+        if (k + 1 < T::XIT2 || j < T::NIT2)
+          B2_4[j] = xpass_item<PYX, NP>(R_4 + (j + (j >> 5) * (T::PR / 4 - kTX / 4)), w2x);
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < T::XIT2; ++k)
+        if (k + 1 < T::XIT2 || tid + k * kThreads < T::NIT2) B2_4[tid + k * kThreads] = f32x4{0, 0, 0, 0};
     }
     lds_barrier();
 
     // ---------------- phase B ----------------
     // stage 2: absorb ratio plane qr, finish output plane o
     {
-      float pl[2 * RUN];
+      float w2y[PYX], w2z[PZ];
+      load_taps(4, w2y);
+      load_taps(5, w2z);
+      f32x2 pl[RUN];
+      {
+        const float* colp = B2 + y2_col;
+        f32x2 cv[RUN + 2 * C];
 #pragma unroll
-      for (int i = 0; i < 2 * RUN; ++i) pl[i] = 0.0f;
-      if (r_live) {
+        for (int j = 0; j < RUN + 2 * C; ++j) cv[j] = f32x2{colp[j * kTX], colp[j * kTX + 64]};
 #pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
-          const float* colp = B2 + y2_col + 64 * cg;
-          float cv[RUN + 2 * C];
+        for (int m = 0; m < RUN; ++m) {
+          f32x2 s2 = splat(w2y[0]) * cv[m];
 #pragma unroll
-          for (int j = 0; j < RUN + 2 * C; ++j) cv[j] = colp[j * kTX];
-#pragma unroll
-          for (int m = 0; m < RUN; ++m) {
-            float s = w2y[0] * cv[m];
-#pragma unroll
-            for (int b = 1; b < PYX; ++b) s = fmaf(w2y[b], cv[m + b], s);
-            pl[cg * RUN + m] = s;
-          }
+          for (int b = 1; b < PYX; ++b) s2 = pk_fma(splat(w2y[b]), cv[m + b], s2);
+          pl[m] = s2;
         }
       }
 #pragma unroll
       for (int j = 0; j < PZ - 1; ++j)
 #pragma unroll
-        for (int i = 0; i < 2 * RUN; ++i) acc2[j][i] = fmaf(w2z[PZ - 1 - j], pl[i], acc2[j + 1][i]);
+        for (int i = 0; i < RUN; ++i) acc2[j][i] = pk_fma(splat(w2z[PZ - 1 - j]), pl[i], acc2[j + 1][i]);
 #pragma unroll
-      for (int i = 0; i < 2 * RUN; ++i) acc2[PZ - 1][i] = w2z[0] * pl[i];
+      for (int i = 0; i < RUN; ++i) acc2[PZ - 1][i] = splat(w2z[0]) * pl[i];
 
       // x(o), nz(o): requested by the previous iteration; issued since: its y loads, this
       // iteration's glds
@@ -439,13 +433,26 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
       if (o >= zb && o < ze) {
         float* obase = p.out + (static_cast<int64_t>(o) * p.out_plane + x0);
         const float rz = fast_rcp(nzv);
+        if (!p.mask_out) {
+          // a padded destination: rows and columns past the volume exist, and what lands there is
+          // x * u / n with x = 0 from the zero halo
 #pragma unroll
-        for (int m = 0; m < RUN; ++m) {
-          const int gy = y0 + wave * RUN + m;
-          if (gy < Y) {  // wave-uniform
-            float* row = obase + static_cast<int64_t>(gy) * p.out_pitch;
-            if (okc[0]) gstore<0>(row, lane4, xc[m] * acc2[0][m] * (rz * rnyx[m]));
-            if (okc[1]) gstore<256>(row, lane4, xc[RUN + m] * acc2[0][RUN + m] * (rz * rnyx[RUN + m]));
+          for (int m = 0; m < RUN; ++m) {
+            float* row = obase + static_cast<int64_t>(y0 + wave * RUN + m) * p.out_pitch;
+            const f32x2 v = f32x2{xc[m], xc[RUN + m]} * acc2[0][m] * (splat(rz * rny_lds[wave * RUN + m]) * rnx2);
+            gstore<0>(row, lane4, v.x);
+            gstore<256>(row, lane4, v.y);
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < RUN; ++m) {
+            const int gy = y0 + wave * RUN + m;
+            if (gy < Y) {  // wave-uniform
+              float* row = obase + static_cast<int64_t>(gy) * p.out_pitch;
+              const f32x2 v = f32x2{xc[m], xc[RUN + m]} * acc2[0][m] * (splat(rz * rny_lds[wave * RUN + m]) * rnx2);
+              if (okc[0]) gstore<0>(row, lane4, v.x);
+              if (okc[1]) gstore<256>(row, lane4, v.y);
+            }
           }
         }
       }
@@ -454,44 +461,41 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
     }
     // stage 1: absorb x plane pz, finish ratio plane q
     {
-      float pl[2 * RUN1], ple[EP];
+      float w1y[PYX], w1z[PZ];
+      load_taps(1, w1y);
+      load_taps(2, w1z);
+      f32x2 pl[RUN1];
+      float ple[EP];
+      {
+        const float* colp = B1 + y1_col;
+        f32x2 cv[RUN1 + 2 * C];
 #pragma unroll
-      for (int i = 0; i < 2 * RUN1; ++i) pl[i] = 0.0f;
+        for (int j = 0; j < RUN1 + 2 * C; ++j) cv[j] = f32x2{colp[j * T::PB1], colp[j * T::PB1 + 64]};
 #pragma unroll
-      for (int e = 0; e < EP; ++e) ple[e] = 0.0f;
-      if (x_live) {
+        for (int m = 0; m < RUN1; ++m) {
+          f32x2 s2 = splat(w1y[0]) * cv[m];
 #pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
-          const float* colp = B1 + y1_col + 64 * cg;
-          float cv[RUN1 + 2 * C];
-#pragma unroll
-          for (int j = 0; j < RUN1 + 2 * C; ++j) cv[j] = colp[j * T::PB1];
-#pragma unroll
-          for (int m = 0; m < RUN1; ++m) {
-            float s = w1y[0] * cv[m];
-#pragma unroll
-            for (int b = 1; b < PYX; ++b) s = fmaf(w1y[b], cv[m + b], s);
-            pl[cg * RUN1 + m] = s;
-          }
+          for (int b = 1; b < PYX; ++b) s2 = pk_fma(splat(w1y[b]), cv[m + b], s2);
+          pl[m] = s2;
         }
+      }
 #pragma unroll
-        for (int e = 0; e < EP; ++e) {
-          const float* colp = B1 + e_b1[e];
-          float s = w1y[0] * colp[0];
+      for (int e = 0; e < EP; ++e) {
+        const float* colp = B1 + e_b1[e];
+        float s1 = w1y[0] * colp[0];
 #pragma unroll
-          for (int b = 1; b < PYX; ++b) s = fmaf(w1y[b], colp[b * T::PB1], s);
-          ple[e] = s;
-        }
+        for (int b = 1; b < PYX; ++b) s1 = fmaf(w1y[b], colp[b * T::PB1], s1);
+        ple[e] = s1;
       }
 #pragma unroll
       for (int j = 0; j < PZ - 1; ++j) {
 #pragma unroll
-        for (int i = 0; i < 2 * RUN1; ++i) acc1[j][i] = fmaf(w1z[PZ - 1 - j], pl[i], acc1[j + 1][i]);
+        for (int i = 0; i < RUN1; ++i) acc1[j][i] = pk_fma(splat(w1z[PZ - 1 - j]), pl[i], acc1[j + 1][i]);
 #pragma unroll
         for (int e = 0; e < EP; ++e) acc1e[j][e] = fmaf(w1z[PZ - 1 - j], ple[e], acc1e[j + 1][e]);
       }
 #pragma unroll
-      for (int i = 0; i < 2 * RUN1; ++i) acc1[PZ - 1][i] = w1z[0] * pl[i];
+      for (int i = 0; i < RUN1; ++i) acc1[PZ - 1][i] = splat(w1z[0]) * pl[i];
 #pragma unroll
       for (int e = 0; e < EP; ++e) acc1e[PZ - 1][e] = w1z[0] * ple[e];
 
@@ -504,18 +508,15 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
       for (int m = 0; m < RUN1; ++m) {
         const int gy = y0 + r1_row0 + m - C;
         const bool row_in = q_in && gy >= 0 && gy < Y && r1_row0 + m < T::R1;  // wave-uniform
-#pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
-          const int i = cg * RUN1 + m;
-          const float r = yv[i] * fast_rcp(acc1[0][i] + p.eps);
-          Rw[r_col + m * T::PR + 64 * cg] = (row_in && in1c[cg]) ? r : 0.0f;
-        }
+        const f32x2 r = f32x2{yv[m], yv[RUN1 + m]} * fast_rcp2(acc1[0][m] + splat(p.eps));
+        Rw[r_col + m * T::PR] = (row_in && in1c[0]) ? r.x : 0.0f;
+        Rw[r_col + m * T::PR + 64] = (row_in && in1c[1]) ? r.y : 0.0f;
       }
 #pragma unroll
       for (int e = 0; e < EP; ++e) {
         if (e + 1 < EP || tid + e * kThreads < T::NE) {
           const float r = ye[e] * fast_rcp(acc1e[0][e] + p.eps);
-          Rw[e_r[e]] = (q_in && e_in[e]) ? r : 0.0f;
+          Rw[e_b1[e] - T::SH] = (q_in && e_in[e]) ? r : 0.0f;
         }
       }
       __builtin_amdgcn_sched_barrier(0);  // the refill reuses yv / ye

@@ -233,6 +233,12 @@ class RichardsonLucyPlan:
         # one launch per iteration (rl_fused_sep.hip) where the PSF fits its specialisations
         self.fused = bool(self._psf.separable and self._fused_mode == "auto"
                           and _lib.call_value("lsr_rl_sep_fused_supported", *self._psf.shape))
+        if self.fused:
+            kz, ky, kx = (np.ascontiguousarray(k, dtype=np.float32) for k in factors)
+            block = np.zeros(_lib.call_value("lsr_rl_sep_fused_taps_count"), np.float32)
+            _lib.call("lsr_rl_sep_fused_prepare_taps", kz.ctypes.data, len(kz), ky.ctypes.data, len(ky),
+                      kx.ctypes.data, len(kx), block.ctypes.data)
+            self._fused_taps = dev(block)
 
     @property
     def separable(self) -> bool:
@@ -321,15 +327,13 @@ class RichardsonLucyPlan:
                     from_y = x0 is None
                 if not from_y:
                     x_pad.view.copy_(init)
-                (kz, ky, kx), (fz, fy, fx) = ps.k, ps.k_flipped
                 nz, ny, nx = self._norm
                 if events:
                     events[0].record()
                 _lib.call(
                     "lsr_rl_sep_fused_f32", y_ptr, y_pitch, y_plane, int(from_y),
                     x_pad.full.data_ptr(), ratio_pad.full.data_ptr(),
-                    x.data_ptr(), z, yy, xx, kz.data_ptr(), fz.data_ptr(), ps.shape[0],
-                    ky.data_ptr(), fy.data_ptr(), ps.shape[1], kx.data_ptr(), fx.data_ptr(),
+                    x.data_ptr(), z, yy, xx, self._fused_taps.data_ptr(), ps.shape[0], ps.shape[1],
                     ps.shape[2], nz.data_ptr(), ny.data_ptr(), nx.data_ptr(), iterations,
                     ctypes.c_float(eps), stream,
                 )
