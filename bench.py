@@ -154,6 +154,8 @@ def main():
                     help="separable = the declared default Gaussian (rank-1 path); dense = the "
                          "rotated non-separable PSF through the dense stencil")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rl", default="fused", choices=["fused", "two-launch"],
+                    help="separable PSF: one launch per RL iteration (default) or the ratio / update pair")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -189,7 +191,8 @@ def main():
     config_id = {"config1": 1, "config2": 2, "config4": 4, "small": 0}[args.workload]
     raw = synthetic_raw(raw_shape, seed=1000 * config_id + 7 * rank, device=device)
     if args.psf == "separable":
-        plan = RichardsonLucyPlan(out_shape, None, device, psf_factors=gaussian_factors())
+        plan = RichardsonLucyPlan(out_shape, None, device, psf_factors=gaussian_factors(),
+                                  fused="auto" if args.rl == "fused" else "never")
     else:
         plan = RichardsonLucyPlan(out_shape, rotated_psf(), device, separable="never")
     # the deskew kernel writes straight into the RL kernels' padded, line-aligned input volume
@@ -244,18 +247,22 @@ def main():
     assert torch.isfinite(estimate).all(), "non-finite RL output"
 
     if rank == 0:
-        launches = 2 * RL_ITERS
+        fused = bool(getattr(plan, "fused", False))
+        launches = RL_ITERS if fused else 2 * RL_ITERS
         launch_s = rl_kernels_ms * 1e-3 / launches  # HIP events right around the launches, / count
-        bytes_per_launch = 12.0 * n_o             # in + aux + out, 4 B each
+        # fused iteration: x, y in, x_new out; ratio / update launch: in + aux + out
+        bytes_per_launch = 12.0 * n_o
         achieved = bytes_per_launch / launch_s / 1e9
-        total_bytes = 4.0 * n_in + 4.0 * n_o + 24.0 * RL_ITERS * n_o + 8.0 * n_o
+        total_bytes = 4.0 * n_in + 4.0 * n_o + 12.0 * launches * n_o
         ms_per_step = elapsed / args.steps * 1e3
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
             try:
                 rec = json.loads(tfile.read_text())
-                if rec.get("workload") == args.workload and rec.get("psf") == args.psf:
+                key = "fused" if fused else ("two-launch" if args.psf == "separable" else "dense")
+                rec = rec.get(key, {})
+                if rec.get("workload") == args.workload:
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -283,13 +290,15 @@ def main():
                 "deskew_ms": deskew_ms,
                 "rl_ms": rl_ms,
                 "rl_kernels_ms": rl_kernels_ms,
+                "rl_launches": launches,
                 "algorithmic_bytes_per_step": total_bytes,
                 "whole_step_hbm_frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "parallelism": f"positions x{world} (independent units, no data-path collective)",
             },
             "roofline": (
                 {
-                    "kernel": "correlate_sep_kernel<9,7,7> (RL ratio / update launch)",
+                    "kernel": ("rl_fused_sep_kernel<9,7> (one RL iteration per launch)" if fused
+                               else "correlate_sep_kernel<9,7,7> (RL ratio / update launch)"),
                     "bound": "hbm",
                     "achieved": achieved,
                     "peak": HBM_PEAK_GBS,

@@ -218,17 +218,17 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
 
   // taps: a device block prepared by lsr_rl_sep_fused_prepare_taps -- six rows of 16 floats
   // (stage 1 = flipped PSF: x, y, z; stage 2 = PSF: x, y, z), centred in the compiled extents, zero
-  // elsewhere.  Each pass reads its taps through the scalar cache right before it runs (an opaque
-  // zero offset keeps hipcc from hoisting all 46 of them into SGPRs for the whole loop, which
-  // spills).
-  typedef const float __attribute__((address_space(4))) cfloat;
-  const cfloat* const taps_base = (const cfloat*)p.taps;
+  // elsewhere.  They live across the lanes of two VGPRs; each pass pulls its taps into SGPRs with
+  // v_readlane right before it runs.  (All 46 in SGPRs for the whole loop do not fit next to the
+  // addressing state -- hipcc then spills them to VGPR lanes itself, and more besides; fetching
+  // them per pass from the scalar cache instead costs an exposed s_load round trip per pass.)
+  float tv0 = p.taps[lane], tv1 = p.taps[64 + (lane & 31)];
   auto load_taps = [&](int row, auto& w) {
-    int opaque = 0;
-    asm volatile("" : "+s"(opaque));
-    const cfloat* t = taps_base + row * 16 + opaque;
 #pragma unroll
-    for (int i = 0; i < static_cast<int>(sizeof(w) / sizeof(float)); ++i) w[i] = t[i];
+    for (int i = 0; i < static_cast<int>(sizeof(w) / sizeof(float)); ++i) {
+      const int f = row * 16 + i;
+      w[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f < 64 ? tv0 : tv1), f & 63));
+    }
   };
 
   // ---- staging (glds): chunk e = tid + 512 k of the (AR x PA) window whose first element is
@@ -360,6 +360,7 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
   lds_barrier();
 
   for (int pz = p_lo; pz <= p_hi; ++pz) {
+    asm volatile("" : "+v"(tv0), "+v"(tv1));  // loop-variant for the optimiser: no hoisting of the taps
     const int qr = pz - 1 - CZ;      // ratio plane in R (written by the previous iteration)
     const int o = qr - CZ;           // output plane completed by this iteration
     const int q = pz - CZ;           // ratio plane completed by this iteration
