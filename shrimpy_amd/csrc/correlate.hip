@@ -467,17 +467,36 @@ extern "C" int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, 
 
 namespace {
 
-// z split of the fused kernel: one workgroup per CU and 2 * (PZ - 1) extra planes per chunk; pick
-// the chunk count that minimises rounds * planes-per-workgroup on 256 CUs.
-int64_t pick_fused_z_chunk(int64_t Z, int64_t tiles_xy, int PZ) {
-  int64_t best_chunk = Z, best_cost = -1;
-  for (int64_t n = 1; n <= 16 && n <= Z; ++n) {
-    const int64_t chunk = lsr::ceil_div(Z, n);
-    const int64_t wgs = tiles_xy * lsr::ceil_div(Z, chunk);
-    const int64_t cost = lsr::ceil_div(wgs, 256) * (chunk + 2 * (PZ - 1) + 2);
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_chunk = chunk; }
+int device_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop{};
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
   }
-  return best_chunk;
+  return cus;
+}
+
+// Work split of the fused kernel (one workgroup per CU; a piece of a tile column costs
+// 2 * (PZ - 1) halo planes): whole columns for as many full dispatch rounds as the tiles give,
+// the remaining tiles cut along z so that they fill one more round.
+void plan_fused_split(int64_t tiles_xy, int64_t Z, int PZ, int* n_full, int* pieces, int* z_chunk) {
+  const int64_t cus = device_cu_count();
+  const int64_t min_chunk = 2 * (PZ - 1) > 8 ? 2 * (PZ - 1) : 8;  // halo no more than the payload
+  int64_t full = tiles_xy / cus * cus;
+  int64_t rest = tiles_xy - full;
+  if (full == 0) {  // fewer tiles than CUs: cut every column
+    rest = tiles_xy;
+  }
+  int64_t k = rest > 0 ? cus / rest : 1;
+  if (k < 1) k = 1;
+  int64_t chunk = lsr::ceil_div(Z, k);
+  if (chunk < min_chunk) chunk = min_chunk < Z ? min_chunk : Z;
+  *n_full = static_cast<int>(full);
+  *z_chunk = static_cast<int>(chunk);
+  *pieces = static_cast<int>(lsr::ceil_div(Z, chunk));
 }
 
 }  // namespace
@@ -558,8 +577,9 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
   p.nz = nz; p.ny = ny; p.nx = nx;
   p.tiles_x = static_cast<int>(lsr::ceil_div(X, lsr::kSepWideTileX));
   p.tiles_y = static_cast<int>(lsr::ceil_div(Y, 8 * lsr::fused_run(PZ)));
-  p.z_chunk = static_cast<int>(pick_fused_z_chunk(Z, int64_t(p.tiles_x) * p.tiles_y, PZ));
-  const int64_t blocks64 = int64_t(p.tiles_x) * p.tiles_y * lsr::ceil_div(Z, p.z_chunk);
+  const int64_t tiles_xy = int64_t(p.tiles_x) * p.tiles_y;
+  plan_fused_split(tiles_xy, Z, PZ, &p.n_full, &p.pieces, &p.z_chunk);
+  const int64_t blocks64 = p.n_full + (tiles_xy - p.n_full) * p.pieces;
   LSR_REQUIRE(blocks64 < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
               (long long)blocks64);
   const unsigned blocks = static_cast<unsigned>(blocks64);

@@ -108,6 +108,8 @@ struct FusedArgs {
   const float* ny;
   const float* nx;
   int tiles_x, tiles_y;
+  int n_full;   // tiles [0, n_full) are whole z columns, one workgroup each (dispatched first)
+  int pieces;   // every other tile: `pieces` workgroups of z_chunk planes
   int z_chunk;
 };
 // columns staged left and right of a 128-column tile: twice the PSF radius, rounded up to 16 bytes
