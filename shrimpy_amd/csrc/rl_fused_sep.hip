@@ -92,7 +92,11 @@ struct Geo {
   static constexpr int OFF_RNY = OFF_DUMP + 256;          // 1 / ny of the tile rows
   static constexpr int TOTAL = OFF_RNY + 32;
   static constexpr int NY = 2 * RUN1 + EP;                // y loads per thread and iteration
+#ifdef LSR_FUSED_PROBE_NOXC
+  static constexpr int NXC = 0;  // diagnostic build: the x re-read is dropped (results wrong)
+#else
   static constexpr int NXC = 2 * RUN + 1;                 // x (centre) + nz loads
+#endif
   static_assert(TOTAL * 4 <= 160 * 1024, "LDS per workgroup");
   static_assert(PR == PB1, "B1 and R share a pitch");
   static_assert(2 * C <= WL && WL <= lsr::kSepOriginCol, "halo columns");
@@ -266,30 +270,32 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
   const int r1_row0 = wave * RUN1;                            // scalar
   const int y1_col = r1_row0 * T::PB1 + lane;                 // B1 float index of (row0, lane)
   const int r_col = r1_row0 * T::PR + lane - T::SH;           // R float index of the same point
-  bool in1c[2];
-#pragma unroll
-  for (int cg = 0; cg < 2; ++cg) {
-    const int gx = x0 + lane + 64 * cg + C - T::WL;
-    in1c[cg] = gx >= 0 && gx < X;
-  }
+  // a tile whose grown (ratio) region lies inside the volume needs no in-plane masks (most tiles)
+  const bool interior = x0 - C >= 0 && x0 + kTX + C <= X && y0 - C >= 0 && y0 + TY + C <= Y;
   // edge points: t = tid + 512 e -> (row t / E, column 128 + t % E)
   int e_b1[EP], e_voff[EP];  // (the R index of an edge point is e_b1 - SH: B1 and R share a pitch)
-  bool e_in[EP];
+  int e_rc[EP];              // (row << 16) | column of the edge point in the ratio region
 #pragma unroll
   for (int e = 0; e < EP; ++e) {
     const int t = min(tid + e * kThreads, T::NE - 1);
     const int er = t / T::E, ec = t - er * T::E;
     e_b1[e] = er * T::PB1 + kTX + ec;
-    const int gy = y0 + er - C, gx = x0 + kTX + ec + C - T::WL;
-    e_in[e] = gy >= 0 && gy < Y && gx >= 0 && gx < X;
+    e_rc[e] = (er << 16) | (kTX + ec);
     e_voff[e] = (er * p.y_pitch + kTX + ec) * 4;   // from the y window's first element
   }
   const int lane4 = lane * 4;
   // ---- stage-2 points: tile columns lane + 64 cg, tile rows wave * RUN + m
   const int y2_col = (wave * RUN) * kTX + lane;
-  bool okc[2];
+  // per-row byte offsets of the aux loads and the stores (row term included, so that one scalar
+  // base per stream and plane is all the address arithmetic an iteration does)
+  int xc_voff[RUN], o_voff[RUN], y_voff[RUN1];
 #pragma unroll
-  for (int cg = 0; cg < 2; ++cg) okc[cg] = x0 + lane + 64 * cg < X;
+  for (int m = 0; m < RUN; ++m) {
+    xc_voff[m] = ((wave * RUN + m) * p.pitch + lane) * 4;
+    o_voff[m] = ((wave * RUN + m) * p.out_pitch + lane) * 4;
+  }
+#pragma unroll
+  for (int m = 0; m < RUN1; ++m) y_voff[m] = (min(r1_row0 + m, T::R1 - 1) * p.y_pitch + lane) * 4;
   // reciprocal in-plane norm factors: 1/nx per column in registers, 1/ny per tile row in LDS
   float rnx[2];
 #pragma unroll
@@ -331,25 +337,28 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
       glds_x4(src, s_voff[k], live ? dst + k * kThreads * 16 : lds_base + T::OFF_DUMP * 4);
     }
   };
+  const float* const xc_tile = p.x + (static_cast<int64_t>(y0) * p.pitch + x0);
+  const float* const y_tile = p.y + (static_cast<int64_t>(y0 - C) * p.y_pitch + (x0 + C - T::WL));
+  float* const o_tile = p.out + (static_cast<int64_t>(y0) * p.out_pitch + x0);
   auto issue_xc = [&](int o) {  // NXC loads: x at the output points of plane o, and nz[o]
+#ifdef LSR_FUSED_PROBE_NOXC
+    return;
+#endif
     const int oc = clampz(o);
-    const float* base = p.x + (static_cast<int64_t>(oc) * p.plane + x0);
+    const float* base = xc_tile + static_cast<int64_t>(oc) * p.plane;
 #pragma unroll
     for (int m = 0; m < RUN; ++m) {
-      const float* row = base + static_cast<int64_t>(y0 + wave * RUN + m) * p.pitch;
-      gload<0>(xc[m], row, lane4);
-      gload<256>(xc[RUN + m], row, lane4);
+      gload<0>(xc[m], base, xc_voff[m]);
+      gload<256>(xc[RUN + m], base, xc_voff[m]);
     }
     gload<0>(nzv, p.nz + oc, 0);
   };
   auto issue_y = [&](int q) {  // NY loads: y at the ratio points of plane q
-    const float* base = p.y + (static_cast<int64_t>(clampz(q)) * p.y_plane +
-                               static_cast<int64_t>(y0 - C) * p.y_pitch + (x0 + C - T::WL));
+    const float* base = y_tile + static_cast<int64_t>(clampz(q)) * p.y_plane;
 #pragma unroll
     for (int m = 0; m < RUN1; ++m) {
-      const float* row = base + static_cast<int64_t>(min(r1_row0 + m, T::R1 - 1)) * p.y_pitch;
-      gload<0>(yv[m], row, lane4);
-      gload<256>(yv[RUN1 + m], row, lane4);
+      gload<0>(yv[m], base, y_voff[m]);
+      gload<256>(yv[RUN1 + m], base, y_voff[m]);
     }
 #pragma unroll
     for (int e = 0; e < EP; ++e) gload<0>(ye[e], base, e_voff[e]);
@@ -444,27 +453,25 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
       tie(xc);
       tie(nzv);
       if (o >= zb && o < ze) {
-        float* obase = p.out + (static_cast<int64_t>(o) * p.out_plane + x0);
+        float* obase = o_tile + static_cast<int64_t>(o) * p.out_plane;
         const float rz = fast_rcp(nzv);
         if (!p.mask_out) {
           // a padded destination: rows and columns past the volume exist, and what lands there is
           // x * u / n with x = 0 from the zero halo
 #pragma unroll
           for (int m = 0; m < RUN; ++m) {
-            float* row = obase + static_cast<int64_t>(y0 + wave * RUN + m) * p.out_pitch;
             const f32x2 v = f32x2{xc[m], xc[RUN + m]} * acc2[0][m] * (splat(rz * rny_lds[wave * RUN + m]) * rnx2);
-            gstore<0>(row, lane4, v.x);
-            gstore<256>(row, lane4, v.y);
+            gstore<0>(obase, o_voff[m], v.x);
+            gstore<256>(obase, o_voff[m], v.y);
           }
-        } else {
+        } else {  // the dense result of the last iteration: masked to the volume
+          const bool ok0 = x0 + lane < X, ok1 = x0 + lane + 64 < X;
 #pragma unroll
           for (int m = 0; m < RUN; ++m) {
-            const int gy = y0 + wave * RUN + m;
-            if (gy < Y) {  // wave-uniform
-              float* row = obase + static_cast<int64_t>(gy) * p.out_pitch;
+            if (y0 + wave * RUN + m < Y) {  // wave-uniform
               const f32x2 v = f32x2{xc[m], xc[RUN + m]} * acc2[0][m] * (splat(rz * rny_lds[wave * RUN + m]) * rnx2);
-              if (okc[0]) gstore<0>(row, lane4, v.x);
-              if (okc[1]) gstore<256>(row, lane4, v.y);
+              if (ok0) gstore<0>(obase, o_voff[m], v.x);
+              if (ok1) gstore<256>(obase, o_voff[m], v.y);
             }
           }
         }
@@ -517,19 +524,37 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
       tie(yv);
       tie(ye);
       const bool q_in = q >= q_lo && q <= q_hi;  // wave-uniform; planes outside are zero
+      if (q_in && interior) {
+        // (rows >= R1 of the last wave and the SH leading columns are padding of R: never read)
 #pragma unroll
-      for (int m = 0; m < RUN1; ++m) {
-        const int gy = y0 + r1_row0 + m - C;
-        const bool row_in = q_in && gy >= 0 && gy < Y && r1_row0 + m < T::R1;  // wave-uniform
-        const f32x2 r = f32x2{yv[m], yv[RUN1 + m]} * fast_rcp2(acc1[0][m] + splat(p.eps));
-        Rw[r_col + m * T::PR] = (row_in && in1c[0]) ? r.x : 0.0f;
-        Rw[r_col + m * T::PR + 64] = (row_in && in1c[1]) ? r.y : 0.0f;
-      }
+        for (int m = 0; m < RUN1; ++m) {
+          const f32x2 r = f32x2{yv[m], yv[RUN1 + m]} * fast_rcp2(acc1[0][m] + splat(p.eps));
+          Rw[r_col + m * T::PR] = r.x;
+          Rw[r_col + m * T::PR + 64] = r.y;
+        }
 #pragma unroll
-      for (int e = 0; e < EP; ++e) {
-        if (e + 1 < EP || tid + e * kThreads < T::NE) {
-          const float r = ye[e] * fast_rcp(acc1e[0][e] + p.eps);
-          Rw[e_b1[e] - T::SH] = (q_in && e_in[e]) ? r : 0.0f;
+        for (int e = 0; e < EP; ++e)
+          if (e + 1 < EP || tid + e * kThreads < T::NE)
+            Rw[e_b1[e] - T::SH] = ye[e] * fast_rcp(acc1e[0][e] + p.eps);
+      } else {
+        // border tiles and planes outside the volume: ratio is zero wherever its point is outside
+        const int gx0 = x0 + lane + C - T::WL;
+        const bool in0 = q_in && gx0 >= 0 && gx0 < X, in1 = q_in && gx0 + 64 >= 0 && gx0 + 64 < X;
+#pragma unroll
+        for (int m = 0; m < RUN1; ++m) {
+          const int gy = y0 + r1_row0 + m - C;
+          const bool row_in = gy >= 0 && gy < Y && r1_row0 + m < T::R1;  // wave-uniform
+          const f32x2 r = f32x2{yv[m], yv[RUN1 + m]} * fast_rcp2(acc1[0][m] + splat(p.eps));
+          Rw[r_col + m * T::PR] = (row_in && in0) ? r.x : 0.0f;
+          Rw[r_col + m * T::PR + 64] = (row_in && in1) ? r.y : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+          if (e + 1 < EP || tid + e * kThreads < T::NE) {
+            const int gy = y0 + (e_rc[e] >> 16) - C, gx = x0 + (e_rc[e] & 0xffff) + C - T::WL;
+            const float r = ye[e] * fast_rcp(acc1e[0][e] + p.eps);
+            Rw[e_b1[e] - T::SH] = (q_in && gy >= 0 && gy < Y && gx >= 0 && gx < X) ? r : 0.0f;
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);  // the refill reuses yv / ye
