@@ -11,9 +11,12 @@ resident in HBM.  Workload at N = 1: BASELINE.json configs[1], "2048x2048x512 f3
 over all ranks.
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel (the RL correlation launch): algorithmic 12 B/voxel
-                  (in + aux + out) x N_o voxels / its average launch duration, measured with HIP
-                  events on the launch stream inside the timed steps, vs the 8 TB/s HBM peak.
+  roofline     -- the dominant kernel (one fused RL iteration per launch; with --rl two-launch the
+                  ratio / update launch): algorithmic 12 B/voxel (x, y in, x out; resp. in + aux +
+                  out) x N_o voxels / its average launch duration, measured with HIP events on
+                  the launch stream inside the timed steps, vs the 8 TB/s HBM peak.  SURVEY 8(d)
+                  prices an RL iteration at 24 B/voxel (two kernels); that accounting of the same
+                  launch is added as roofline.survey_8d_iteration.
   cpu_baseline -- oracle/cpu_ref.py (scipy.ndimage port of the same path) timed on the host
                   cores of this box on a bounded sample; rank 0 at N = 1 only.
 """
@@ -253,7 +256,11 @@ def main():
         # fused iteration: x, y in, x_new out; ratio / update launch: in + aux + out
         bytes_per_launch = 12.0 * n_o
         achieved = bytes_per_launch / launch_s / 1e9
-        total_bytes = 4.0 * n_in + 4.0 * n_o + 12.0 * launches * n_o
+        # deskew 4 N_in + 4 N_o; RL 24 B/voxel/iteration (the two-kernel accounting:
+        # x, y -> ratio; ratio, x -> x) + 8 N_o init/copy.  The fused iteration's own minimum is
+        # 12 B/voxel/iteration; both are reported.
+        total_bytes = 4.0 * n_in + 4.0 * n_o + 24.0 * RL_ITERS * n_o + 8.0 * n_o
+        min_bytes = 4.0 * n_in + 4.0 * n_o + 12.0 * launches * n_o
         ms_per_step = elapsed / args.steps * 1e3
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
@@ -293,6 +300,8 @@ def main():
                 "rl_launches": launches,
                 "algorithmic_bytes_per_step": total_bytes,
                 "whole_step_hbm_frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "launched_kernels_min_bytes_per_step": min_bytes,
+                "launched_kernels_hbm_frac": min_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "parallelism": f"positions x{world} (independent units, no data-path collective)",
             },
             "roofline": (
@@ -307,6 +316,12 @@ def main():
                     "traffic": traffic,
                     "launch_ms": launch_s * 1e3,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                    # one launch = one RL iteration, which SURVEY 8(d) prices at 24 B/voxel (two
+                    # kernels, ratio through HBM); `achieved` above uses the fused kernel's own 12
+                    **({"survey_8d_iteration": {"bytes": 24.0 * n_o,
+                                                "achieved": 24.0 * n_o / launch_s / 1e9,
+                                                "frac": 24.0 * n_o / launch_s / 1e9 / HBM_PEAK_GBS}}
+                       if fused else {}),
                 } if args.psf == "separable" else {
                     # a 441-tap dense stencil is fp32-VALU-bound, not HBM-bound
                     "kernel": "correlate_dense_kernel<9,7> (dense RL ratio / update launch)",

@@ -231,6 +231,12 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
   const int tx = lb / band_h;
   const int ty = band * kBand + (lb - tx * band_h);
   const int x0 = tx * kTX, y0 = ty * TY;
+#ifdef LSR_FUSED_LAG
+  if ((tx + ty) & 1) {
+#pragma unroll
+    for (int i = 0; i < LSR_FUSED_LAG; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
 
   // taps: a device block prepared by lsr_rl_sep_fused_prepare_taps -- six rows of 16 floats
   // (stage 1 = flipped PSF: x, y, z; stage 2 = PSF: x, y, z), centred in the compiled extents, zero
@@ -391,7 +397,11 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
 
     // ---------------- phase A ----------------
     issue_glds(pz + 2, slot2);
+#ifdef LSR_FUSED_PROBE_NOCOMPUTE
+    if (false) {
+#else
     if (x_live) {
+#endif
       float w1x[PYX];
       load_taps(0, w1x);
       const f32x4* A_4 = smem4 + slot * (T::ASZ / 4);
@@ -404,7 +414,11 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
       for (int k = 0; k < T::XIT1; ++k)
         if (k + 1 < T::XIT1 || tid + k * kThreads < T::NIT1) B1_4[tid + k * kThreads] = f32x4{0, 0, 0, 0};
     }
+#ifdef LSR_FUSED_PROBE_NOCOMPUTE
+    if (false) {
+#else
     if (r_live) {
+#endif
       float w2x[PYX];
       load_taps(3, w2x);
 #pragma unroll
@@ -427,6 +441,11 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
       load_taps(4, w2y);
       load_taps(5, w2z);
       f32x2 pl[RUN];
+#ifdef LSR_FUSED_PROBE_NOCOMPUTE
+#pragma unroll
+      for (int m = 0; m < RUN; ++m) pl[m] = splat(B2[y2_col + m]);
+      if (false)
+#endif
       {
         const float* colp = B2 + y2_col;
         f32x2 cv[RUN + 2 * C];
@@ -452,7 +471,11 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
       wait_vm<NY + SL>();
       tie(xc);
       tie(nzv);
+#ifdef LSR_FUSED_PROBE_NOSTORE
+      if (o >= zb && o < ze && nzv == 12345.678f) {
+#else
       if (o >= zb && o < ze) {
+#endif
         float* obase = o_tile + static_cast<int64_t>(o) * p.out_plane;
         const float rz = fast_rcp(nzv);
         if (!p.mask_out) {
@@ -486,6 +509,11 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
       load_taps(2, w1z);
       f32x2 pl[RUN1];
       float ple[EP];
+#ifdef LSR_FUSED_PROBE_NOCOMPUTE
+#pragma unroll
+      for (int m = 0; m < RUN1; ++m) pl[m] = splat(B1[y1_col + m]);
+      if (false)
+#endif
       {
         const float* colp = B1 + y1_col;
         f32x2 cv[RUN1 + 2 * C];
@@ -502,6 +530,10 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
 #pragma unroll
       for (int e = 0; e < EP; ++e) {
         const float* colp = B1 + e_b1[e];
+#ifdef LSR_FUSED_PROBE_NOCOMPUTE
+        ple[e] = colp[0];
+        continue;
+#endif
         float s1 = w1y[0] * colp[0];
 #pragma unroll
         for (int b = 1; b < PYX; ++b) s1 = fmaf(w1y[b], colp[b * T::PB1], s1);
