@@ -96,6 +96,30 @@ int lsr_average_slices_f32(const float* in, int64_t Zd, int64_t Y, int64_t X, fl
                            int64_t Zo, int avg_n, lsr_stream_t stream);
 
 /*
+ * Bright-field flat-field correction -- replaces _LabelfreePreprocessor._flat_field_BF
+ * (shrimpy/preprocessing.py:385-404): pattern = median over Z per (y, x) pixel with
+ * torch.quantile(0.5) semantics (exact middle elements; b - (b - a) * 0.5 between the two of an
+ * even count; NaN if the column holds one), out = in / pattern * mean(pattern).
+ *
+ * lsr_flatfield_pattern_f32: `pattern` (Y*X floats) and `mean_out` (one float) are device
+ *   outputs; `scratch` = lsr_flatfield_scratch_bytes() bytes of device memory. Z < 65536.
+ *   Reads `in` at most four times (radix select, csrc/flatfield.hip), writes nothing else.
+ * lsr_flatfield_apply_f32: out = in / pattern * mean_dev[0] (in place allowed).
+ * lsr_deskew_flat_f32: lsr_deskew_f32 with the correction applied to every raw sample on its
+ *   way into the kernel -- bit-identical to apply followed by deskew, without the corrected
+ *   volume's round trip through HBM.
+ */
+int lsr_flatfield_scratch_bytes(void);
+int lsr_flatfield_pattern_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* pattern,
+                              float* mean_out, void* scratch, lsr_stream_t stream);
+int lsr_flatfield_apply_f32(const float* in, const float* pattern, const float* mean_dev,
+                            float* out, int64_t Z, int64_t Y, int64_t X, lsr_stream_t stream);
+int lsr_deskew_flat_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo,
+                        int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd,
+                        const double M[12], int avg_n, const float* flat_pattern,
+                        const float* flat_mean, lsr_stream_t stream);
+
+/*
  * 3-D correlation with zero-padded borders and a fused Richardson-Lucy epilogue:
  *
  *   c[z,y,x] = sum_{a,b,c} w[a,b,c] * in[z+a-pz/2, y+b-py/2, x+c-px/2]      (0 outside)

@@ -42,6 +42,11 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SIGNATURES: dict[str, list] = {
     "lsr_version": [],
     "lsr_deskew_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p, _int, _stream],
+    "lsr_deskew_flat_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p, _int,
+                            _c_f32p, _c_f32p, _stream],
+    "lsr_flatfield_scratch_bytes": [],
+    "lsr_flatfield_pattern_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, ctypes.c_void_p, _stream],
+    "lsr_flatfield_apply_f32": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _stream],
     "lsr_affine_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _f64p, _f32, _int, _stream],
     "lsr_average_slices_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _int, _stream],
     "lsr_correlate_sep_f32": [

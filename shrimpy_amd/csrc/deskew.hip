@@ -41,8 +41,15 @@ struct DeskewArgs {
   int avg_n;
   int tile_x;               // X' handled per workgroup (<= kTileX, chosen so the slab fits)
   int64_t tiles_x, tiles_y; // workgroup grid, flattened: x fastest, then y, then zo
+  const float* flat_pattern;  // FLAT: (Y, X) per-pixel median over Z (flatfield.hip)
+  const float* flat_mean;     // FLAT: its mean, a device scalar
 };
 
+// FLAT fuses the bright-field flat-field correction into the staging pass: every raw sample
+// becomes in / pattern[y][x] * mean (same operations, same order as the separate apply kernel, so
+// the result is bit-identical to flat-field followed by deskew) and the corrected volume is never
+// written to HBM.
+template <bool FLAT>
 __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
   __shared__ float slab[kSlabRows * kPitch];
 
@@ -96,9 +103,17 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
       const bool col_ok = (j < n_yo) && (x_in >= 0) && (x_in < p.X);
       const float* src = p.in + (z_lo * p.Y + y_in) * p.X + x_in;
       const int64_t z_stride = p.Y * p.X;
+      float pat = 1.0f, mean = 1.0f;
+      if constexpr (FLAT) {
+        if (col_ok) pat = p.flat_pattern[y_in * p.X + x_in];
+        mean = p.flat_mean[0];
+      }
       for (int zl = tid >> 6; zl < n_rows; zl += kThreads / 64) {
         float v = 0.0f;
-        if (col_ok) v = src[zl * z_stride];
+        if (col_ok) {
+          v = src[zl * z_stride];
+          if constexpr (FLAT) v = v / pat * mean;
+        }
         slab[zl * kPitch + j] = v;
       }
     }
@@ -163,10 +178,12 @@ bool is_integer(double v) { return v == static_cast<double>(static_cast<int64_t>
 
 }  // namespace
 
-extern "C" int lsr_deskew_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* out,
-                              int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch,
-                              int64_t out_plane, int64_t Zd, const double M[12], int avg_n,
-                              lsr_stream_t stream) {
+namespace {
+
+int deskew_impl(const char* what, const float* in, int64_t Z, int64_t Y, int64_t X, float* out,
+                int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane,
+                int64_t Zd, const double M[12], int avg_n, const float* flat_pattern,
+                const float* flat_mean, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE_PTR(M);
@@ -217,9 +234,36 @@ extern "C" int lsr_deskew_f32(const float* in, int64_t Z, int64_t Y, int64_t X, 
   LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
               (long long)blocks);
 
-  hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
-                     lsr::as_stream(stream), p);
-  return lsr::launch_status("lsr_deskew_f32");
+  p.flat_pattern = flat_pattern;
+  p.flat_mean = flat_mean;
+  if (flat_pattern != nullptr)
+    hipLaunchKernelGGL(deskew_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
+                       lsr::as_stream(stream), p);
+  else
+    hipLaunchKernelGGL(deskew_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
+                       lsr::as_stream(stream), p);
+  return lsr::launch_status(what);
+}
+
+}  // namespace
+
+extern "C" int lsr_deskew_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* out,
+                              int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch,
+                              int64_t out_plane, int64_t Zd, const double M[12], int avg_n,
+                              lsr_stream_t stream) {
+  return deskew_impl("lsr_deskew_f32", in, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M,
+                     avg_n, nullptr, nullptr, stream);
+}
+
+extern "C" int lsr_deskew_flat_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* out,
+                                   int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch,
+                                   int64_t out_plane, int64_t Zd, const double M[12], int avg_n,
+                                   const float* flat_pattern, const float* flat_mean,
+                                   lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(flat_pattern);
+  LSR_REQUIRE_PTR(flat_mean);
+  return deskew_impl("lsr_deskew_flat_f32", in, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd,
+                     M, avg_n, flat_pattern, flat_mean, stream);
 }
 
 extern "C" int lsr_average_slices_f32(const float* in, int64_t Zd, int64_t Y, int64_t X,

@@ -158,7 +158,7 @@ __device__ __forceinline__ void glds_x4(const float* sbase, int voff, unsigned l
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                :
                : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
-               : "memory", "m0");
+               : "memory");  // (m0 is a reserved register: hipcc sets it right at each of its own uses)
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -289,7 +289,6 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
     e_rc[e] = (er << 16) | (kTX + ec);
     e_voff[e] = (er * p.y_pitch + kTX + ec) * 4;   // from the y window's first element
   }
-  const int lane4 = lane * 4;
   // ---- stage-2 points: tile columns lane + 64 cg, tile rows wave * RUN + m
   const int y2_col = (wave * RUN) * kTX + lane;
   // per-row byte offsets of the aux loads and the stores (row term included, so that one scalar

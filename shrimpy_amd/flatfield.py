@@ -1,0 +1,76 @@
+"""Bright-field flat-field correction on MI355X.
+
+Mirrors ``_LabelfreePreprocessor._flat_field_BF`` (reference ``shrimpy/preprocessing.py:385-404``):
+``static_pattern = volume.quantile(0.5, dim=0)``; ``volume / static_pattern * static_pattern.mean()``.
+The median runs as a streaming radix select (``csrc/flatfield.hip``: at most four reads of the
+volume); the division is either its own launch or fused into the deskew kernel's staging pass
+(``deskew_with_matrix(..., flat_field=pattern)``).  Bright field only -- see the reference's note.
+No CPU fallback.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+from . import _lib
+
+__all__ = ["FlatFieldPattern", "flat_field_pattern", "flat_field_bf"]
+
+
+@dataclass
+class FlatFieldPattern:
+    """Per-pixel median over Z (``pattern``, (Y, X) device tensor) and its mean (1-element tensor)."""
+
+    pattern: object
+    mean: object
+
+    def apply(self, volume, out=None):
+        """``volume / pattern * mean`` (new tensor, or into ``out`` -- which may be ``volume``)."""
+        import torch
+
+        vol = _lib.require_device_f32(volume, "volume")
+        if vol.dim() != 3 or tuple(vol.shape[1:]) != tuple(self.pattern.shape):
+            raise ValueError(f"volume must be (Z, {self.pattern.shape[0]}, {self.pattern.shape[1]}), "
+                             f"got {tuple(vol.shape)}")
+        if out is None:
+            out = torch.empty_like(vol)
+        else:
+            _lib.require_device_f32(out, "out")
+            if tuple(out.shape) != tuple(vol.shape) or out.device != vol.device:
+                raise ValueError("out must match volume")
+        z, y, x = (int(v) for v in vol.shape)
+        with torch.cuda.device(vol.device):
+            _lib.call("lsr_flatfield_apply_f32", vol.data_ptr(), self.pattern.data_ptr(),
+                      self.mean.data_ptr(), out.data_ptr(), z, y, x, _lib.stream_ptr(vol.device))
+        return out
+
+
+def flat_field_pattern(volume) -> FlatFieldPattern:
+    """Median over Z of every (y, x) pixel of a (Z, Y, X) float32 device tensor, and its mean."""
+    import torch
+
+    if not isinstance(volume, torch.Tensor):
+        raise TypeError(f"volume must be a torch.Tensor, got {type(volume).__name__}")
+    if volume.dim() != 3:
+        raise ValueError(f"volume must be (Z, Y, X), got shape {tuple(volume.shape)}")
+    if volume.dtype != torch.float32:
+        volume = volume.to(torch.float32)
+    vol = _lib.require_device_f32(volume.contiguous(), "volume")
+    z, y, x = (int(v) for v in vol.shape)
+    pattern = torch.empty((y, x), dtype=torch.float32, device=vol.device)
+    mean = torch.empty((1,), dtype=torch.float32, device=vol.device)
+    scratch = torch.empty((_lib.call_value("lsr_flatfield_scratch_bytes"),), dtype=torch.uint8,
+                          device=vol.device)
+    with torch.cuda.device(vol.device):
+        _lib.call("lsr_flatfield_pattern_f32", vol.data_ptr(), z, y, x, pattern.data_ptr(),
+                  mean.data_ptr(), scratch.data_ptr(), _lib.stream_ptr(vol.device))
+    return FlatFieldPattern(pattern, mean)
+
+
+def flat_field_bf(volume):
+    """The reference's ``_flat_field_BF`` on the device: new corrected (Z, Y, X) tensor."""
+    import torch
+
+    if isinstance(volume, torch.Tensor) and volume.dtype != torch.float32:
+        volume = volume.to(torch.float32)
+    return flat_field_pattern(volume).apply(volume.contiguous())

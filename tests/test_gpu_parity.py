@@ -444,3 +444,90 @@ def test_deskew_into_padded_volume_and_rl_without_copies(device):
         b = plan(dense, iterations=6)
         torch.testing.assert_close(a, b, rtol=1e-6, atol=0)
     _close(a.cpu().numpy(), o.richardson_lucy(dense.cpu().numpy(), o.rotated_psf(), 6), 5e-5, 2e-5)
+
+
+# ================================================================ flat-field
+
+
+def _median_torch_semantics(vol):
+    """Exact middle elements; torch.quantile's lerp between the two of an even count (f32)."""
+    s = np.sort(vol, axis=0)
+    z = vol.shape[0]
+    a, b = s[(z - 1) // 2], s[z // 2]
+    return a if z % 2 else (b - (b - a) * np.float32(0.5)).astype(np.float32)
+
+
+@pytest.mark.parametrize("shape", [(8, 6, 10), (7, 5, 9), (300, 3, 130), (64, 17, 200), (1, 4, 5), (2, 3, 129),
+                                   (1201, 2, 70)])
+@pytest.mark.parametrize("kind", ["counts", "floats", "ties"])
+def test_flatfield_pattern_is_the_exact_median(device, shape, kind):
+    """Radix select returns the exact order statistics: the pattern equals sort-based medians bit
+    for bit (integer camera counts with many ties, signed floats, near-constant columns)."""
+    from shrimpy_amd.flatfield import flat_field_pattern
+
+    rng = np.random.default_rng(hash((shape, kind)) % 2**32)
+    if kind == "counts":
+        vol = rng.integers(80, 600, shape).astype(np.float32)
+    elif kind == "floats":
+        vol = (rng.standard_normal(shape) * 100).astype(np.float32)
+        vol[0, 0, 0] = -0.0
+    else:
+        vol = np.full(shape, 37.5, np.float32)
+        vol[rng.random(shape) < 0.3] = 37.500004
+        vol[rng.random(shape) < 0.1] = -1e30
+    ff = flat_field_pattern(_t(vol, device))
+    pattern = ff.pattern.cpu().numpy()
+    expect = _median_torch_semantics(vol)
+    np.testing.assert_array_equal(pattern, expect)
+    assert float(ff.mean.cpu()[0]) == pytest.approx(float(expect.astype(np.float64).mean()), rel=1e-6)
+    if kind == "counts":
+        out = ff.apply(_t(vol, device)).cpu().numpy()
+        mean = ff.mean.cpu().numpy()[0]
+        np.testing.assert_array_equal(out, vol / pattern * mean)     # same operations, same order
+        np.testing.assert_allclose(out, o.flat_field_bf(vol), rtol=2e-6)
+
+
+def test_flatfield_nan_propagates_per_pixel(device):
+    from shrimpy_amd.flatfield import flat_field_pattern
+
+    rng = np.random.default_rng(12)
+    vol = rng.random((9, 4, 70)).astype(np.float32) + 1
+    vol[3, 2, 5] = np.nan
+    pattern = flat_field_pattern(_t(vol, device)).pattern.cpu().numpy()
+    assert np.isnan(pattern[2, 5]) and np.isnan(pattern).sum() == 1
+    clean = np.delete(pattern.ravel(), 2 * 70 + 5)
+    np.testing.assert_array_equal(clean, np.delete(_median_torch_semantics(vol).ravel(), 2 * 70 + 5))
+
+
+def test_flatfield_fused_into_deskew_is_bit_identical(device):
+    """in / pattern * mean applied inside the deskew kernel == apply, then deskew."""
+    import torch
+
+    from shrimpy_amd.deskew import deskew_with_matrix
+    from shrimpy_amd.flatfield import flat_field_pattern
+    from shrimpy_amd.geometry import deskew_geometry
+
+    rng = np.random.default_rng(77)
+    raw = _t(rng.integers(80, 600, (150, 20, 90)).astype(np.float32), device)
+    geo = deskew_geometry(tuple(raw.shape), 30.0, 0.755, False, 3)
+    ff = flat_field_pattern(raw)
+    two_step = deskew_with_matrix(ff.apply(raw), geo.matrix_3x4, geo.pre_average_shape, 3)
+    fused = deskew_with_matrix(raw, geo.matrix_3x4, geo.pre_average_shape, 3, flat_field=ff)
+    assert torch.equal(fused, two_step)
+    ref = o.deskew(o.flat_field_bf(raw.cpu().numpy()), 30.0, 0.755, False, 3)
+    np.testing.assert_allclose(fused.cpu().numpy(), ref, rtol=3e-6, atol=1e-4)
+
+
+def test_preprocessor_flatfield_then_deskew_on_the_gpu(device):
+    from shrimpy_amd.preprocessing import build_preprocessor
+
+    rng = np.random.default_rng(5)
+    raw = rng.integers(80, 600, (120, 12, 64)).astype(np.float32)
+    settings = dict(pixel_size_um=0.1133, ls_angle_deg=30.0, px_to_scan_ratio=0.755, keep_overhang=False,
+                    average_n_slices=3)
+    pre = build_preprocessor(raw.shape, ["flatfield", "deskew"], deskew=settings)
+    out = pre(raw, label="A/1/0", return_intermediates=True)
+    ref = o.deskew(o.flat_field_bf(raw), 30.0, 0.755, False, 3)
+    np.testing.assert_allclose(out["deskew"].cpu().numpy(), ref, rtol=3e-6, atol=1e-4)
+    only = build_preprocessor(raw.shape, ["flatfield"])(raw)
+    np.testing.assert_allclose(next(iter(only.values())).cpu().numpy(), o.flat_field_bf(raw), rtol=2e-6)

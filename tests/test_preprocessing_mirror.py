@@ -74,8 +74,9 @@ def test_call_runs_flatfield_then_deskew_and_exposes_intermediate(monkeypatch):
 
     order = []
     pre = _bare(deskew_settings=DeskewSettings(**DESKEW), apply_flatfield=True)
-    monkeypatch.setattr(pre, "_flat_field_BF", lambda v: (order.append("flatfield"), v)[1])
-    monkeypatch.setattr(pre, "_deskew", lambda v: (order.append("deskew"), v[:4])[1])
+    # with a deskew behind it the flat-field step computes the pattern; the deskew kernel divides
+    monkeypatch.setattr(pre, "_flat_field_pattern", lambda v: (order.append("flatfield"), "pattern")[1])
+    monkeypatch.setattr(pre, "_deskew", lambda v: (order.append("deskew"), pre._pending_flat_field, v[:4])[2])
     out = pre(np.ones(ZYX, dtype="float32"), label="A/1/0", return_intermediates=True)
     assert order == ["flatfield", "deskew"]
     assert set(out) == {"BF", "deskew"} and out["deskew"] is out["BF"]
@@ -96,13 +97,27 @@ def test_step_logs_and_reraises(caplog):
     assert "[p0] deskew FAILED: bad stack" in caplog.text
 
 
+def test_flatfield_on_a_cpu_tensor_fails_loudly(golden_dir):
+    """The flat-field step is a HIP kernel: a CPU tensor raises instead of running torch's CPU path."""
+    import torch
+
+    from shrimpy_amd._lib import LsrError
+
+    g = np.load(golden_dir / "ref_preprocessing.npz")
+    with pytest.raises(LsrError, match="no CPU fallback"):
+        _bare()._flat_field_BF(torch.as_tensor(g["flatfield_in"]))
+
+
+@pytest.mark.gpu
 def test_flatfield_matches_reference_capture(golden_dir):
-    """Same torch expression as the reference: compare with what the reference produced."""
+    """The HIP flat-field against what the reference's own ``_flat_field_BF`` produced (captured
+    by importing /root/reference/shrimpy/preprocessing.py, ``oracle/make_golden.py``)."""
     import torch
 
     g = np.load(golden_dir / "ref_preprocessing.npz")
-    out = _bare()._flat_field_BF(torch.as_tensor(g["flatfield_in"]))
-    np.testing.assert_allclose(out.numpy(), g["flatfield_out"], rtol=1e-6)
+    for k in ("", "_odd"):
+        out = _bare()._flat_field_BF(torch.as_tensor(g["flatfield_in" + k], device="cuda"))
+        np.testing.assert_allclose(out.cpu().numpy(), g["flatfield_out" + k], rtol=1e-6)
 
 
 def test_warm_up_without_gpu_raises_instead_of_falling_back(monkeypatch):
@@ -111,11 +126,8 @@ def test_warm_up_without_gpu_raises_instead_of_falling_back(monkeypatch):
     monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         build_preprocessor(ZYX, ["deskew"], deskew=DESKEW)
-    # a flat-field-only pipeline has no kernel: the torch expression may run where the tensor is
-    pre = build_preprocessor(ZYX, ["flatfield"])
-    assert pre is not None
-    with pytest.raises(RuntimeError, match="GPU required"):
-        build_preprocessor(ZYX, ["flatfield"], require_gpu=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        build_preprocessor(ZYX, ["flatfield"])
 
 
 def test_warm_up_resolves_deskewed_shape(monkeypatch):

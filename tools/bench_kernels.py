@@ -77,6 +77,30 @@ def _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_ge
                           "voxels_per_s": vol.numel() / (ms * 1e-3)}))
     del vol, out
 
+    # ---- flat-field (median over Z + apply / fused deskew), config 2 raw stack of camera counts
+    from shrimpy_amd.flatfield import flat_field_pattern
+
+    raw_shape = bench.WORKLOADS["config2"]
+    raw = torch.randint(80, 600, raw_shape, device=dev, generator=g).to(torch.float32)
+    raw += torch.rand(raw_shape, device=dev, generator=g)          # continuous values: 4 passes
+    ms = timed(lambda: flat_field_pattern(raw), args.reps)
+    print(json.dumps({"kernel": "flat_median_kernel (+ mean)", "raw": raw_shape, "ms": ms,
+                      "passes_GBps": 4 * 4.0 * raw.numel() / ms / 1e6,
+                      "frac_of_8TBps_at_4_passes": 4 * 4.0 * raw.numel() / ms / 1e6 / 8000}))
+    ff = flat_field_pattern(raw)
+    dst = torch.empty_like(raw)
+    ms = timed(lambda: ff.apply(raw, out=dst), args.reps)
+    print(json.dumps({"kernel": "flat_apply_kernel", "raw": raw_shape, "ms": ms,
+                      "algorithmic_GBps": 8.0 * raw.numel() / ms / 1e6,
+                      "frac_of_8TBps": 8.0 * raw.numel() / ms / 1e6 / 8000}))
+    del dst
+    geo = deskew_geometry(raw_shape, **bench.DESKEW)
+    dsk = torch.empty(geo.output_shape, device=dev)
+    for name, kw in (("deskew_kernel<false>", {}), ("deskew_kernel<true> (flat-field fused)", {"flat_field": ff})):
+        ms = timed(lambda: deskew_with_matrix(raw, geo.matrix_3x4, geo.pre_average_shape, 3, out=dsk, **kw), args.reps)
+        print(json.dumps({"kernel": name, "raw": raw_shape, "ms": ms}))
+    del raw, dsk, ff
+
     # ---- deskew alone, config 2 and config 4 mappings
     for name in ("config2", "config4"):
         raw_shape = bench.WORKLOADS[name]
