@@ -41,6 +41,7 @@ struct AffineArgs {
 struct AxisTap {
   int i0, i1;       // clamped neighbour indices
   double w0, w1;    // scipy weights: w0 = 1 - f, w1 = 1 - w0
+  double f;         // fractional part
   bool out0, out1;  // grid-constant: neighbour is outside the volume -> cval
 };
 
@@ -50,15 +51,37 @@ __device__ __forceinline__ bool axis_tap(double c, int n, AxisTap& t) {
   if (!GRID && (c < 0.0 || c > static_cast<double>(n - 1))) return false;
   const double fl = floor(c);
   const double f = c - fl;
+  t.f = f;
   t.w0 = 1.0 - f;
   t.w1 = 1.0 - t.w0;
-  // indices only matter while a neighbour can be inside; clamp far-away coordinates first
-  const int start = static_cast<int>(fmin(fmax(fl, -2.0), static_cast<double>(n) + 1.0));
-  t.out0 = GRID && (start < 0 || start >= n);
-  t.out1 = GRID && (start + 1 < 0 || start + 1 >= n);
-  t.i0 = min(max(start, 0), n - 1);
-  t.i1 = min(max(start + 1, 0), n - 1);
+  if constexpr (!GRID) {
+    // 0 <= c <= n-1: floor(c) is a valid index; only the upper neighbour can leave the volume
+    // (c == n-1 exactly, where its weight is 0)
+    t.i0 = static_cast<int>(fl);
+    t.i1 = min(t.i0 + 1, n - 1);
+    t.out0 = t.out1 = false;
+  } else {
+    // indices only matter while a neighbour can be inside; clamp far-away coordinates first
+    const int start = static_cast<int>(fmin(fmax(fl, -2.0), static_cast<double>(n) + 1.0));
+    t.out0 = start < 0 || start >= n;
+    t.out1 = start + 1 < 0 || start + 1 >= n;
+    t.i0 = min(max(start, 0), n - 1);
+    t.i1 = min(max(start + 1, 0), n - 1);
+  }
   return true;
+}
+
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load, 4-byte aligned
+
+// mode "constant": both x neighbours of a row in ONE 8-byte load (half the gather instructions;
+// the texture-address unit, not HBM or the ALUs, bounds this kernel).  When the upper neighbour
+// is the clamped one (coordinate exactly on the last column, weight 0) the pair is read one
+// element lower and both values come from its upper half.
+__device__ __forceinline__ void load_x_pair(const float* row, int i0, int n, float& v0, float& v1) {
+  const int base = min(i0, n - 2);
+  const f32x2u pr = *reinterpret_cast<const f32x2u*>(row + base);
+  v0 = base == i0 ? pr.x : pr.y;
+  v1 = pr.y;
 }
 
 template <bool GRID, bool F32>
@@ -77,7 +100,8 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
   const double rz = lsr::dadd(lsr::dmul(zd, p.m[0]), lsr::dmul(yd, p.m[1]));
   const double ry = lsr::dadd(lsr::dmul(zd, p.m[4]), lsr::dmul(yd, p.m[5]));
   const double rx = lsr::dadd(lsr::dmul(zd, p.m[8]), lsr::dmul(yd, p.m[9]));
-  const int64_t sz = static_cast<int64_t>(p.Yi) * p.Xi;
+  // element indices fit 32 bits unsigned (host check); one 64-bit add per load
+  const unsigned sz = static_cast<unsigned>(p.Yi) * static_cast<unsigned>(p.Xi);
   const double cv = static_cast<double>(p.cval);
   float* orow = p.out + (static_cast<int64_t>(zo) * p.Yo + yo) * p.Xo;
 
@@ -97,17 +121,37 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
       if constexpr (F32) {
         // LSR_MODE_F32_INTERP: fp64 coordinates (border decisions unchanged), f32 weights and
         // FMAs -- not bit-identical to scipy (~1e-6 relative), HBM-bound instead of fp64-bound
-        const float wz1 = static_cast<float>(tz.w1), wy1 = static_cast<float>(ty_.w1),
-                    wx1 = static_cast<float>(tx_.w1);
+        const float wz1 = static_cast<float>(tz.f), wy1 = static_cast<float>(ty_.f),
+                    wx1 = static_cast<float>(tx_.f);  // (w1 = 1 - (1 - f) differs from f by <= 1 ulp of fp64)
         float v[2][2][2];
+        if constexpr (!GRID) {
+          if (p.Xi >= 2) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) {
+                const unsigned o = static_cast<unsigned>(a ? tz.i1 : tz.i0) * sz +
+                                   static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * static_cast<unsigned>(p.Xi);
+                load_x_pair(p.in + o, tx_.i0, p.Xi, v[a][b][0], v[a][b][1]);
+              }
+          } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b)
+                v[a][b][0] = v[a][b][1] = p.in[static_cast<unsigned>(a ? tz.i1 : tz.i0) * sz +
+                                               static_cast<unsigned>(b ? ty_.i1 : ty_.i0)];
+          }
+        } else
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-              const int64_t o = (a ? tz.i1 : tz.i0) * sz + static_cast<int64_t>(b ? ty_.i1 : ty_.i0) * p.Xi +
-                                (c ? tx_.i1 : tx_.i0);
+              const unsigned o = static_cast<unsigned>(a ? tz.i1 : tz.i0) * sz +
+                                 static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * static_cast<unsigned>(p.Xi) +
+                                 static_cast<unsigned>(c ? tx_.i1 : tx_.i0);
               float val = p.in[o];
               if (GRID && ((a ? tz.out1 : tz.out0) || (b ? ty_.out1 : ty_.out0) || (c ? tx_.out1 : tx_.out0)))
                 val = p.cval;
@@ -125,19 +169,19 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
       double t = 0.0;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const int64_t oz = (a ? tz.i1 : tz.i0) * sz;
+        const unsigned oz = static_cast<unsigned>(a ? tz.i1 : tz.i0) * sz;
         const double wz = a ? tz.w1 : tz.w0;
         const bool bz = a ? tz.out1 : tz.out0;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const int64_t oy = oz + static_cast<int64_t>(b ? ty_.i1 : ty_.i0) * p.Xi;
+          const unsigned oy = oz + static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * static_cast<unsigned>(p.Xi);
           const double wy = b ? ty_.w1 : ty_.w0;
           const bool by = b ? ty_.out1 : ty_.out0;
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const double wx = c ? tx_.w1 : tx_.w0;
             const bool bx = c ? tx_.out1 : tx_.out0;
-            double coeff = static_cast<double>(p.in[oy + (c ? tx_.i1 : tx_.i0)]);
+            double coeff = static_cast<double>(p.in[oy + static_cast<unsigned>(c ? tx_.i1 : tx_.i0)]);
             if (GRID && (bz || by || bx)) coeff = cv;
             coeff = lsr::dmul(coeff, wz);
             coeff = lsr::dmul(coeff, wy);
@@ -170,6 +214,8 @@ extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t X
   const int64_t lim = int64_t(1) << 30;
   LSR_REQUIRE(Zi < lim && Yi < lim && Xi < lim && Zo < lim && Yo < lim && Xo < lim,
               LSR_E_UNSUPPORTED, "a dimension exceeds 2^30");
+  LSR_REQUIRE(Zi * Yi * Xi <= (int64_t(1) << 32), LSR_E_UNSUPPORTED,
+              "the moving volume has more than 2^32 voxels (32-bit element indices)");
   const bool f32 = (mode & LSR_MODE_F32_INTERP) != 0;
   mode &= ~LSR_MODE_F32_INTERP;
   LSR_REQUIRE(mode == LSR_MODE_CONSTANT || mode == LSR_MODE_GRID_CONSTANT, LSR_E_ARG,
