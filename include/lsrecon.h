@@ -90,6 +90,11 @@ int lsr_deskew_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* out,
 int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
                    int64_t Yo, int64_t Xo, const double M[12], float cval, int mode,
                    lsr_stream_t stream);
+/* Which kernel lsr_affine_f32 runs for this matrix on a (.., Yi, Xi) moving volume: 1 = the
+ * LDS-staged z-marching kernel (csrc/affine_planar.hip: constant mode, z decoupled from the plane,
+ * |M[0]| <= 1.5, Xi a multiple of 4, source box of a 32 x 128 tile within LDS), 0 = the general
+ * gather kernel. Results are identical either way. */
+int lsr_affine_kernel_choice(int64_t Yi, int64_t Xi, const double M[12], int mode);
 
 /* out[zo] = mean_k in[min(zo*avg_n + k, Zd-1)], k < avg_n, f32, ((d0+d1)+...)/avg_n. */
 int lsr_average_slices_f32(const float* in, int64_t Zd, int64_t Y, int64_t X, float* out,

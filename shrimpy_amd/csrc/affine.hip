@@ -199,6 +199,25 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
 
 }  // namespace
 
+namespace lsr {
+// affine_planar.hip: z-decoupled maps in constant mode; false = not applicable
+bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
+                          int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32,
+                          hipStream_t s);
+bool affine_planar_geometry(int64_t Yi, int64_t Xi, const double M[12], int* box_y, int* box_x,
+                            int* slots, int64_t* lds_bytes);
+}  // namespace lsr
+
+extern "C" int lsr_affine_kernel_choice(int64_t Yi, int64_t Xi, const double M[12], int mode) {
+  if (M == nullptr) return 0;
+  int by, bx, sl;
+  int64_t lds;
+  return (mode & ~LSR_MODE_F32_INTERP) == LSR_MODE_CONSTANT &&
+                 lsr::affine_planar_geometry(Yi, Xi, M, &by, &bx, &sl, &lds)
+             ? 1
+             : 0;
+}
+
 extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out,
                               int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval,
                               int mode, lsr_stream_t stream) {
@@ -222,6 +241,10 @@ extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t X
               "unknown border mode %d", mode);
   for (int i = 0; i < 12; ++i)
     LSR_REQUIRE(M[i] == M[i] && M[i] - M[i] == 0.0, LSR_E_ARG, "M[%d] is not finite", i);
+
+  if (mode == LSR_MODE_CONSTANT && in != out &&
+      lsr::launch_affine_planar(in, Zi, Yi, Xi, out, Zo, Yo, Xo, M, cval, f32, lsr::as_stream(stream)))
+    return lsr::launch_status("lsr_affine_f32");
 
   AffineArgs p;
   p.in = in;

@@ -1,0 +1,310 @@
+// Order-1 affine resample for maps whose z axis is decoupled from the plane -- the registration
+// case (label-free <-> fluorescence on one instrument): rotation / scale / shear / translation
+// inside (y, x), scale + translation along z:
+//
+//        | a  0  0  tz |        z_in depends on zo only,
+//   M =  | 0  b  c  ty |        (y_in, x_in) depend on (yo, xo) only.
+//        | 0  d  e  tx |
+//
+// Replaces the same scipy.ndimage.affine_transform(order=1, mode="constant") call as affine.hip
+// (which keeps every other matrix and the grid-constant mode), bit for bit.
+//
+// Why a second kernel: the general one spends ~170 instructions per voxel, half of them fp64
+// coordinate / weight arithmetic, and gathers its 8 taps through the texture-address path
+// (0.25 of the HBM peak at config 3).  With the decoupled structure
+//   * the in-plane taps (LDS index, 4 weights) of an output pixel are the same for EVERY plane: a
+//     thread computes them once for its 8 pixels and keeps them in registers;
+//   * the z taps (2 source planes, 2 weights) of an output plane are wave-uniform scalars;
+// so a 512-thread workgroup takes a 32 x 128 pixel tile and marches along zo.  Source planes come
+// by LDS-DMA (global_load_lds_dwordx4, whole rows of the tile's source box) into a ring of 3 or 4
+// slots, one output plane ahead; the 8 taps are LDS reads; what is left per voxel is scipy's own
+// 8 x ((v * wz) * wy) * wx + accumulate in fp64 (or 7 f32 FMAs with exact = False).
+//
+// Algorithmic HBM bytes: 4 * N_src + 4 * N_out.
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kTY = 32, kTX = 128;
+constexpr int kThreads = 512;
+constexpr int kPts = 8;  // pixels per thread: columns lane, lane + 64; rows wave, wave + 8, ...
+
+struct PlanarArgs {
+  const float* in;
+  float* out;
+  int Zi, Yi, Xi;
+  int Zo, Yo, Xo;
+  double a, tz;          // z_in = zo * a + tz
+  double b, c, ty;       // y_in = (yo * b + xo * c) + ty
+  double d, e, tx;       // x_in = (yo * d + xo * e) + tx
+  float cval;
+  int box_y, box_x;      // LDS box of a source plane (rows, floats per row: a multiple of 4)
+  int slots;             // ring depth: 3 (|a| <= 1) or 4
+  int tiles_x, tiles_y;
+  int z_chunk;           // output planes per workgroup
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void glds_x4(const float* sbase, int voff, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+               : "memory");
+}
+
+// scipy's coordinate ((zo*m0 + yo*m1) + xo*m2) + shift with zo*m0 == 0 (exact: adding +-0 is the
+// identity), i.e. (yo*m1 + xo*m2) + shift
+__device__ __forceinline__ double plane_coord(double yo, double xo, double m1, double m2, double shift) {
+  return lsr::dadd(lsr::dadd(lsr::dmul(yo, m1), lsr::dmul(xo, m2)), shift);
+}
+
+template <bool F32>
+__global__ __launch_bounds__(kThreads) void affine_planar_kernel(PlanarArgs p) {
+  extern __shared__ f32x4 smem4[];
+  const float* const smem = reinterpret_cast<const float*>(smem4);
+  const unsigned lds_base =
+      static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) char*)smem4));
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int tx = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int zc = bid / p.tiles_y;
+  const int x0 = tx * kTX, y0 = ty * kTY;
+  const int zo_begin = zc * p.z_chunk, zo_end = min(zo_begin + p.z_chunk, p.Zo);
+
+  // ---- source box of the tile: extremes of a linear map sit at the tile's corners ------------
+  const int y1 = min(y0 + kTY, p.Yo) - 1, x1 = min(x0 + kTX, p.Xo) - 1;
+  double cy_min = 1e300, cy_max = -1e300, cx_min = 1e300, cx_max = -1e300;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double yo = static_cast<double>((k & 1) ? y1 : y0), xo = static_cast<double>((k & 2) ? x1 : x0);
+    const double cy = plane_coord(yo, xo, p.b, p.c, p.ty), cx = plane_coord(yo, xo, p.d, p.e, p.tx);
+    cy_min = fmin(cy_min, cy); cy_max = fmax(cy_max, cy);
+    cx_min = fmin(cx_min, cx); cx_max = fmax(cx_max, cx);
+  }
+  // one element of slack each side: the per-pixel coordinates are rounded individually
+  const int ylo = static_cast<int>(fmin(fmax(floor(cy_min) - 1.0, 0.0), static_cast<double>(p.Yi - 1)));
+  const int xlo = static_cast<int>(fmin(fmax(floor(cx_min) - 1.0, 0.0), static_cast<double>(p.Xi - 1))) & ~3;
+  const int box_x = p.box_x, box_y = p.box_y;
+  const int slot_floats = (box_y * box_x + 255) & ~255;  // whole waves of 16-byte chunks
+
+  // ---- per-pixel in-plane taps, once ------------------------------------------------------
+  int idx00[kPts];        // LDS float index of (iy0, ix0) inside a slot
+  int step[kPts];         // bit 0: ix1 == ix0 + 1, bit 1: iy1 == iy0 + 1, bit 2: pixel inside
+  double wy0[kPts], wy1[kPts], wx0[kPts], wx1[kPts];
+#pragma unroll
+  for (int i = 0; i < kPts; ++i) {
+    const int yo = y0 + wave + 8 * (i >> 1), xo = x0 + lane + 64 * (i & 1);
+    const double cy = plane_coord(static_cast<double>(yo), static_cast<double>(xo), p.b, p.c, p.ty);
+    const double cx = plane_coord(static_cast<double>(yo), static_cast<double>(xo), p.d, p.e, p.tx);
+    const bool inside = yo < p.Yo && xo < p.Xo && !(cy < 0.0) && !(cy > static_cast<double>(p.Yi - 1)) &&
+                        !(cx < 0.0) && !(cx > static_cast<double>(p.Xi - 1));
+    const double fy = floor(cy), fx = floor(cx);
+    const double ry = cy - fy, rx = cx - fx;
+    wy0[i] = 1.0 - ry; wy1[i] = 1.0 - wy0[i];
+    wx0[i] = 1.0 - rx; wx1[i] = 1.0 - wx0[i];
+    int iy0 = 0, ix0 = 0, st = 0;
+    if (inside) {
+      iy0 = static_cast<int>(fy);
+      ix0 = static_cast<int>(fx);
+      st = 4 | (ix0 + 1 <= p.Xi - 1 ? 1 : 0) | (iy0 + 1 <= p.Yi - 1 ? 2 : 0);
+      // the box covers every inside pixel's taps by construction (host sizes it from |b|,|c|,|d|,|e|)
+      iy0 = min(max(iy0 - ylo, 0), box_y - 2);
+      ix0 = min(max(ix0 - xlo, 0), box_x - 2);
+    }
+    idx00[i] = iy0 * box_x + ix0;
+    step[i] = st;
+  }
+
+  // ---- staging: 16-byte chunks of the box, lane-linear in LDS -------------------------------
+  const int chunks_x = box_x >> 2;
+  const int n_chunks = box_y * chunks_x;
+  constexpr int kMaxLoads = 8;  // host keeps n_chunks <= 8 * 512
+  int s_voff[kMaxLoads];
+#pragma unroll
+  for (int k = 0; k < kMaxLoads; ++k) {
+    const int e = min(tid + k * kThreads, n_chunks - 1);
+    const int r = e / chunks_x, c4 = e - r * chunks_x;
+    const int gy = min(ylo + r, p.Yi - 1);            // rows / columns past the volume: duplicates
+    const int gx = min(xlo + 4 * c4, p.Xi - 4);
+    s_voff[k] = (gy * p.Xi + gx) * 4;
+  }
+  const int n_loads = (n_chunks + kThreads - 1) / kThreads;  // scalar
+  auto issue_plane = [&](int zs, int slot) {
+    const float* src = p.in + static_cast<int64_t>(zs) * p.Yi * p.Xi;
+    const unsigned dst = lds_base + (slot * slot_floats + wave * 64 * 4) * 4;
+#pragma unroll
+    for (int k = 0; k < kMaxLoads; ++k)
+      if (k < n_loads && wave * 64 + k * kThreads < n_chunks) glds_x4(src, s_voff[k], dst + k * kThreads * 16);
+  };
+
+  // ring bookkeeping (scalars): slot s holds source plane resident[s]
+  int resident[4] = {-1, -1, -1, -1};
+  const int slots = p.slots;
+  auto slot_of = [&](int zs) { return zs % slots; };
+  auto z_taps = [&](int zo, int& z0, int& z1, double& wz0, double& wz1) {
+    const double cz = lsr::dadd(lsr::dmul(static_cast<double>(zo), p.a), p.tz);
+    if (cz < 0.0 || cz > static_cast<double>(p.Zi - 1)) return false;
+    const double fz = floor(cz), rz = cz - fz;
+    wz0 = 1.0 - rz;
+    wz1 = 1.0 - wz0;
+    z0 = static_cast<int>(fz);
+    z1 = min(z0 + 1, p.Zi - 1);
+    return true;
+  };
+  auto request = [&](int zs) {  // make plane zs resident (issue its DMA if it is not)
+    const int s = slot_of(zs);
+    bool have = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) have |= (k == s && resident[k] == zs);
+    if (!have) {
+      issue_plane(zs, s);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k == s) resident[k] = zs;
+    }
+  };
+
+  {  // prologue: the first output plane's sources
+    int z0, z1;
+    double w0, w1;
+    if (zo_begin < zo_end && z_taps(zo_begin, z0, z1, w0, w1)) {
+      request(z0);
+      request(z1);
+    }
+  }
+  for (int zo = zo_begin; zo < zo_end; ++zo) {
+    int z0 = 0, z1 = 0;
+    double wz0 = 0.0, wz1 = 0.0;
+    const bool z_in = z_taps(zo, z0, z1, wz0, wz1);
+    // this plane's sources were requested one iteration ago: wait, publish
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // next plane's sources: their slots differ from this plane's (|a| <= 1.5, ring of 3 or 4)
+    {
+      int n0, n1;
+      double u0, u1;
+      if (zo + 1 < zo_end && z_taps(zo + 1, n0, n1, u0, u1)) {
+        request(n0);
+        request(n1);
+      }
+    }
+    float* orow = p.out + (static_cast<int64_t>(zo) * p.Yo + y0) * p.Xo + x0;
+    const float* s0 = smem + slot_of(z0) * slot_floats;
+    const float* s1 = smem + slot_of(z1) * slot_floats;
+#pragma unroll
+    for (int i = 0; i < kPts; ++i) {
+      const int yo = wave + 8 * (i >> 1), xo = lane + 64 * (i & 1);
+      if (y0 + yo >= p.Yo || x0 + xo >= p.Xo) continue;
+      float result = p.cval;
+      if (z_in && (step[i] & 4)) {
+        const int dx = step[i] & 1, dy = (step[i] & 2) ? box_x : 0;
+        const int o00 = idx00[i];
+        const float v000 = s0[o00], v001 = s0[o00 + dx], v010 = s0[o00 + dy], v011 = s0[o00 + dy + dx];
+        const float v100 = s1[o00], v101 = s1[o00 + dx], v110 = s1[o00 + dy], v111 = s1[o00 + dy + dx];
+        if constexpr (F32) {
+          const float fx = static_cast<float>(wx1[i]), fy = static_cast<float>(wy1[i]),
+                      fz = static_cast<float>(wz1);
+          const float a0 = fmaf(fx, v001 - v000, v000), a1 = fmaf(fx, v011 - v010, v010);
+          const float b0 = fmaf(fx, v101 - v100, v100), b1 = fmaf(fx, v111 - v110, v110);
+          const float c0 = fmaf(fy, a1 - a0, a0), c1 = fmaf(fy, b1 - b0, b0);
+          result = fmaf(fz, c1 - c0, c0);
+        } else {
+          // scipy's corner order and product order: ((v * wz) * wy) * wx, summed in sequence
+          double t = 0.0;
+          auto corner = [&](float v, double wz, double wy, double wx) {
+            t = lsr::dadd(t, lsr::dmul(lsr::dmul(lsr::dmul(static_cast<double>(v), wz), wy), wx));
+          };
+          corner(v000, wz0, wy0[i], wx0[i]);
+          corner(v001, wz0, wy0[i], wx1[i]);
+          corner(v010, wz0, wy1[i], wx0[i]);
+          corner(v011, wz0, wy1[i], wx1[i]);
+          corner(v100, wz1, wy0[i], wx0[i]);
+          corner(v101, wz1, wy0[i], wx1[i]);
+          corner(v110, wz1, wy1[i], wx0[i]);
+          corner(v111, wz1, wy1[i], wx1[i]);
+          result = static_cast<float>(t);
+        }
+      }
+      orow[static_cast<int64_t>(yo) * p.Xo + xo] = result;
+    }
+    // (no barrier here: the next iteration's DMAs are issued behind its own barrier, which every
+    // wave reaches only after these reads)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace
+
+namespace lsr {
+
+// Returns true if the planar kernel took the launch; false = not applicable, use the general one.
+// Geometry of the planar path for this matrix and moving volume; false = not applicable.
+bool affine_planar_geometry(int64_t Yi, int64_t Xi, const double M[12], int* box_y_out, int* box_x_out,
+                            int* slots_out, int64_t* lds_bytes_out) {
+  if (M[1] != 0.0 || M[2] != 0.0 || M[4] != 0.0 || M[8] != 0.0) return false;
+  const double a = M[0] < 0 ? -M[0] : M[0];
+  if (a > 1.5 || Xi % 4 != 0 || Xi < 8 || Yi < 2) return false;
+  auto ab = [](double v) { return v < 0 ? -v : v; };
+  // source box of a 32 x 128 tile: extent of the linear map + 2 (floor + upper neighbour) + 2
+  // (slack for per-pixel rounding) [+ 3 for the 16-byte alignment of the first column]
+  const double ey = ab(M[5]) * (kTY - 1) + ab(M[6]) * (kTX - 1), ex = ab(M[9]) * (kTY - 1) + ab(M[10]) * (kTX - 1);
+  if (!(ey < 4096.0) || !(ex < 4096.0)) return false;
+  const int box_y = static_cast<int>(ey) + 5;
+  const int box_x = (static_cast<int>(ex) + 5 + 3 + 3) & ~3;
+  const int slots = a <= 1.0 ? 3 : 4;
+  const int64_t lds_bytes = int64_t(slots) * ((int64_t(box_y) * box_x + 255) & ~int64_t(255)) * 4;
+  if (lds_bytes > 150 * 1024 || int64_t(box_y) * (box_x / 4) > 8 * kThreads) return false;
+  if (Yi * Xi * 4 >= (int64_t(1) << 31)) return false;  // 32-bit in-plane byte offsets
+  *box_y_out = box_y; *box_x_out = box_x; *slots_out = slots; *lds_bytes_out = lds_bytes;
+  return true;
+}
+
+bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
+                          int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32,
+                          hipStream_t s) {
+  int box_y, box_x, slots;
+  int64_t lds_bytes;
+  if (!affine_planar_geometry(Yi, Xi, M, &box_y, &box_x, &slots, &lds_bytes)) return false;
+
+  PlanarArgs p;
+  p.in = in; p.out = out;
+  p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
+  p.Zo = static_cast<int>(Zo); p.Yo = static_cast<int>(Yo); p.Xo = static_cast<int>(Xo);
+  p.a = M[0]; p.tz = M[3];
+  p.b = M[5]; p.c = M[6]; p.ty = M[7];
+  p.d = M[9]; p.e = M[10]; p.tx = M[11];
+  p.cval = cval;
+  p.box_y = box_y; p.box_x = box_x; p.slots = slots;
+  p.tiles_x = static_cast<int>(ceil_div(Xo, kTX));
+  p.tiles_y = static_cast<int>(ceil_div(Yo, kTY));
+  // z split: enough workgroups for ~4 per CU, chunks of at least 16 planes (each chunk refetches
+  // one source plane)
+  const int64_t tiles = int64_t(p.tiles_x) * p.tiles_y;
+  int64_t chunks = ceil_div(256 * 4, tiles);
+  if (chunks < 1) chunks = 1;
+  int64_t chunk = ceil_div(Zo, chunks);
+  if (chunk < 16) chunk = 16;
+  if (chunk > Zo) chunk = Zo;
+  p.z_chunk = static_cast<int>(chunk);
+  const int64_t blocks = tiles * ceil_div(Zo, chunk);
+  if (blocks >= (int64_t(1) << 31)) return false;
+  static bool attr_set[2] = {false, false};
+  auto kernel = f32 ? affine_planar_kernel<true> : affine_planar_kernel<false>;
+  if (!attr_set[f32]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              150 * 1024);
+    attr_set[f32] = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
+                     static_cast<size_t>(lds_bytes), s, p);
+  return true;
+}
+
+}  // namespace lsr

@@ -157,6 +157,51 @@ def test_affine_vs_oracle_bit_exact(device, mode, shape, out_shape):
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
 
 
+def _planar_matrix(theta_deg, scale_zyx, shift_zyx, shear=0.0):
+    th = np.deg2rad(theta_deg)
+    m = np.eye(4)
+    m[1:3, 1:3] = np.array([[np.cos(th), -np.sin(th)], [np.sin(th) + shear, np.cos(th)]]) @ np.diag(scale_zyx[1:])
+    m[0, 0] = scale_zyx[0]
+    m[:3, 3] = shift_zyx
+    return m
+
+
+@pytest.mark.parametrize("case", [
+    dict(shape=(20, 96, 132), theta=2.0, scale=(1.0, 0.98, 1.02), shift=(3.5, -12.25, 20.75)),
+    dict(shape=(9, 40, 72), out=(12, 40, 64), theta=-7.0, scale=(1.0, 1.0, 1.0), shift=(0.0, 3.0, -2.0)),
+    dict(shape=(17, 70, 260), theta=0.0, scale=(-1.0, 1.0, 1.0), shift=(16.0, 0.0, 0.0)),        # z flip, identity plane
+    dict(shape=(17, 70, 260), theta=1.0, scale=(0.5, 1.01, 0.99), shift=(0.25, 0.5, 0.5)),        # z upsampling
+    dict(shape=(30, 33, 68), out=(24, 50, 80), theta=3.0, scale=(1.3, 0.9, 1.1), shift=(-2.5, -6.0, 4.0), shear=0.05),
+    dict(shape=(6, 64, 128), theta=0.0, scale=(0.0, 1.0, 1.0), shift=(2.0, 0.0, 0.0)),            # every plane from z = 2
+    dict(shape=(5, 20, 16), out=(5, 45, 300), theta=30.0, scale=(1.0, 0.4, 0.05), shift=(0.0, 0.0, 0.0)),
+    dict(shape=(4, 300, 2000), out=(4, 20, 140), theta=5.0, scale=(1.0, 9.0, 14.0), shift=(0.0, 3.0, 1.0)),  # box > LDS
+    dict(shape=(8, 48, 96), theta=12.0, scale=(1.0, 1.0, 1.0), shift=(0.0, 500.0, 0.0)),          # everything outside
+])
+@pytest.mark.parametrize("exact", [True, False])
+def test_affine_planar_kernel_vs_oracle(device, case, exact):
+    """z-decoupled maps in constant mode run affine_planar.hip (LDS-staged source boxes, z march):
+    bit-identical to scipy in exact mode, ~1e-6 with f32 interpolation, same border decisions."""
+    from shrimpy_amd import _lib
+    from shrimpy_amd.geometry import as_matrix_3x4
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    planar = _lib.call_value("lsr_affine_kernel_choice", case["shape"][1], case["shape"][2],
+                             _lib.matrix12(as_matrix_3x4(_planar_matrix(case["theta"], case["scale"], case["shift"],
+                                                                        case.get("shear", 0.0)))), _lib.MODE_CONSTANT)
+    assert planar == (0 if case["scale"][2] > 10 else 1)   # 14x decimation: the source box exceeds LDS
+    rng = np.random.default_rng(hash(str(case)) % 2**32)
+    vol = (rng.random(case["shape"]) * 1000 - 100).astype(np.float32)
+    m = _planar_matrix(case["theta"], case["scale"], case["shift"], case.get("shear", 0.0))
+    oshape = case.get("out", case["shape"])
+    ref = o.affine_apply_4x4(vol, m, oshape, cval=-3.0, mode="constant")
+    out = apply_affine_transform_zyx(_t(vol, device), m, oshape, cval=-3.0, exact=exact).cpu().numpy()
+    if exact:
+        np.testing.assert_array_equal(out, ref)
+    else:
+        assert np.array_equal(out == -3.0, ref == -3.0)
+        np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-3)
+
+
 @pytest.mark.parametrize("mode", ["constant", "grid-constant"])
 def test_affine_f32_interpolation_mode_is_close_and_keeps_the_border(device, mode):
     """``exact=False``: f32 interpolation; tolerance 2e-5 of the data range, and the
