@@ -10,7 +10,7 @@
 //     x_in = sx*yo + ox           (integer: raw X <-> output Y', 1:1)
 // so an output plane (Y', X') is a transposed, 1-D-resampled copy of the input slice
 // in[:, y_in, :].  The output-fastest axis X' walks the input's SLOWEST axis, hence a
-// workgroup stages an input slab (z-range x 128 contiguous x) in LDS with coalesced 512-B row
+// workgroup stages an input slab (z-range x 64 contiguous x) in LDS with coalesced 256-B row
 // reads, and emits 256-B coalesced stores along X' -- a resampling transpose through LDS.
 //
 // HBM traffic per launch: 4*N_in (each raw voxel read ~once; neighbouring X' tiles share
@@ -21,13 +21,11 @@
 
 namespace {
 
-constexpr int kTileY = 128;   // output Y' per workgroup == contiguous raw-x run (512-B rows:
-                              // 3.44 -> 3.12 ms against 64-wide tiles with 256 threads)
+constexpr int kTileY = 64;    // output Y' per workgroup == contiguous raw-x run (256 B rows)
 constexpr int kTileX = 64;    // output X' per workgroup (one wave-width of coalesced stores)
 constexpr int kSlabRows = 68; // LDS rows (input z) a workgroup can stage
 constexpr int kPitch = kTileY + 1;  // +1 float: lanes walk z at ~b rows/lane -> distinct banks
-constexpr int kThreads = 4 * kTileY;
-constexpr int kWaves = kThreads / 64;
+constexpr int kThreads = 256;
 constexpr int kRowsPerThread = kTileY * kTileX / kThreads;  // 16 output points per thread
 constexpr int kMaxAvg = 4096;  // sanity bound only
 
@@ -67,9 +65,9 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
   const int n_xo = static_cast<int>(min(static_cast<int64_t>(p.tile_x), p.Xo - xo0));
   const int n_yo = static_cast<int>(min(static_cast<int64_t>(kTileY), p.Yo - yo0));
 
-  // compute-phase mapping: lane -> X' (coalesced stores), the waves stride over Y'
+  // compute-phase mapping: lane -> X' (coalesced stores), 4 waves stride over Y'
   const int li = tid & 63;
-  const int lj0 = tid >> 6;  // 0 .. kWaves-1; rows lj0 + kWaves * m
+  const int lj0 = tid >> 6;
   const double xo_d = static_cast<double>(xo0 + li);
 
   float acc[kRowsPerThread];
@@ -99,7 +97,7 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
     if (k > 0) __syncthreads();  // previous slab fully consumed
     if (row_ok && n_rows > 0) {
       // stage: slab[zl][j] = in[z_lo+zl][y_in][sx*(yo0+j)+ox]; lanes along raw x (coalesced)
-      const int col = tid % kTileY;      // position inside the contiguous raw-x run
+      const int col = tid & 63;          // position inside the contiguous 64-float x run
       const int j = (p.sx > 0) ? col : (kTileY - 1 - col);
       const int64_t x_in = p.sx * (yo0 + j) + p.ox;
       const bool col_ok = (j < n_yo) && (x_in >= 0) && (x_in < p.X);
@@ -110,7 +108,7 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
         if (col_ok) pat = p.flat_pattern[y_in * p.X + x_in];
         mean = p.flat_mean[0];
       }
-      for (int zl = tid / kTileY; zl < n_rows; zl += kThreads / kTileY) {
+      for (int zl = tid >> 6; zl < n_rows; zl += kThreads / 64) {
         float v = 0.0f;
         if (col_ok) {
           v = src[zl * z_stride];
@@ -136,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
       const float* s1 = slab + r1 * kPitch;
 #pragma unroll
       for (int m = 0; m < kRowsPerThread; ++m) {
-        const int j = lj0 + kWaves * m;
+        const int j = lj0 + 4 * m;
         double t = lsr::dadd(0.0, lsr::dmul(static_cast<double>(s0[j]), w0));
         t = lsr::dadd(t, lsr::dmul(static_cast<double>(s1[j]), w1));
         const float d = static_cast<float>(t);
@@ -150,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
     float* dst = p.out + zo * p.out_plane + yo0 * p.out_pitch + xo0 + li;
 #pragma unroll
     for (int m = 0; m < kRowsPerThread; ++m) {
-      const int j = lj0 + kWaves * m;
+      const int j = lj0 + 4 * m;
       if (j < n_yo) dst[static_cast<int64_t>(j) * p.out_pitch] = (p.avg_n > 1) ? acc[m] / denom : acc[m];
     }
   }
