@@ -259,6 +259,32 @@ int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane, in
                             const double* norm_table, float norm_full, int iters, float eps,
                             lsr_stream_t stream);
 
+/*
+ * Reductions and filters behind the DynaTrack shift estimators that run on the deskewed volume
+ * (shrimpy/dynatrack/tracking.py). `scratch` = lsr_reduce_scratch_bytes() bytes of
+ * device memory; outputs are device arrays; sums are fp64, reduced in a fixed order.
+ *
+ *   lsr_minmax_f32            out2 = {min, max} of n floats                         (:533-535, :583)
+ *   lsr_histogram_f32         torch.histc(in, nbins, vmin, vmax) as uint32 counts   (:465, :586)
+ *   lsr_weighted_centroid_f32 out4 = {sum w, sum w z, sum w y, sum w x}, w = max(v - background, 0)
+ *                             (_intensity_center_of_mass, :596-649)
+ *   lsr_mask_centroid_f32     the same with w = (v > threshold)  (_center_of_mass of a mask, :545-569)
+ *   lsr_blur_reflect_f32      one axis (0 = z, 1 = y, 2 = x) of _gaussian_blur_3d (:386-422):
+ *                             correlation with 2*radius+1 device taps, reflect borders
+ *                             (index -k -> k; radius < axis length, radius <= 64); div != 0 maps
+ *                             the input through (v - sub) / div first (the [0, 1] rescale, :533-535)
+ */
+int lsr_reduce_scratch_bytes(void);
+int lsr_minmax_f32(const float* in, int64_t n, float* out2, void* scratch, lsr_stream_t stream);
+int lsr_histogram_f32(const float* in, int64_t n, float vmin, float vmax, int nbins, unsigned* counts,
+                      lsr_stream_t stream);
+int lsr_weighted_centroid_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float background,
+                              double* out4, void* scratch, lsr_stream_t stream);
+int lsr_mask_centroid_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float threshold,
+                          double* out4, void* scratch, lsr_stream_t stream);
+int lsr_blur_reflect_f32(const float* in, float* out, int64_t Z, int64_t Y, int64_t X, int axis,
+                         const float* taps, int radius, float sub, float div, lsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

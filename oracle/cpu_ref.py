@@ -275,3 +275,113 @@ def bead_scene(shape, seed, psf=None, density=2e-5, background=100.0):
         vol = ndimage.convolve(vol, np.asarray(psf, np.float32), mode="constant")
     vol = vol + np.float32(background)
     return rng.poisson(vol).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------
+# Next row f-3: DynaTrack shift estimators on the deskewed volume
+# (shrimpy/dynatrack/tracking.py:386-707, 759-787).  Pinned by tests/golden/ref_dynatrack.npz,
+# which oracle/make_golden.py captured by running the reference's own functions.
+# --------------------------------------------------------------------------------------------
+
+
+def dt_histc(img, nbins, vmin, vmax):
+    """``torch.histc``: bin = int((x - min) * nbins / (max - min)) in float32 (``tracking.py:465, 586``)."""
+    x = np.asarray(img, np.float32).ravel()
+    lo, hi = np.float32(vmin), np.float32(vmax)
+    x = x[(x >= lo) & (x <= hi)]
+    b = ((x - lo) * np.float32(nbins) / (hi - lo)).astype(np.int64)
+    return np.bincount(np.minimum(b, nbins - 1), minlength=nbins).astype(np.float32)
+
+
+def dt_percentile(img, percentile, nbins=256):
+    """``_percentile`` (``tracking.py:572-593``): upper edge of the bin where the CDF reaches p."""
+    vmin, vmax = float(np.min(img)), float(np.max(img))
+    if vmax <= vmin:
+        return vmin
+    cdf = np.cumsum(dt_histc(img, nbins, vmin, vmax), dtype=np.float32)
+    cdf = cdf / cdf[-1]
+    idx = min(int(np.searchsorted(cdf, np.float32(percentile / 100.0), side="left")), nbins - 1)
+    return vmin + (idx + 1) * (vmax - vmin) / nbins
+
+
+def dt_intensity_center_of_mass(img, background=0.0):
+    """``_intensity_center_of_mass`` (``tracking.py:596-649``)."""
+    w = np.maximum(np.asarray(img, np.float32) - np.float32(background), 0).astype(np.float64)
+    total = w.sum()
+    if total <= 0:
+        return np.array([(s - 1) / 2.0 for s in w.shape], np.float32)
+    return np.array([(w.sum(axis=tuple(d for d in range(3) if d != a)) * np.arange(w.shape[a])).sum() / total
+                     for a in range(3)], np.float32)
+
+
+def dt_gaussian_blur_3d(img, sigma):
+    """``_gaussian_blur_3d`` (``tracking.py:386-422``): three 1-D passes, reflect padding without
+    repeating the edge sample (scipy's "mirror"), radius ``int(4 sigma + 0.5)`` clamped to n - 1."""
+    vol = np.asarray(img, np.float32)
+    if sigma <= 0:
+        return vol
+    max_radius = int(4 * sigma + 0.5)
+    for axis in range(3):
+        r = min(max_radius, vol.shape[axis] - 1)
+        x = np.arange(-r, r + 1, dtype=np.float32)
+        k = np.exp(np.float32(-0.5) * (x / np.float32(sigma)) ** 2).astype(np.float32)
+        k = (k / k.sum(dtype=np.float32)).astype(np.float32)
+        vol = ndimage.correlate1d(vol, k, axis=axis, mode="mirror").astype(np.float32)
+    return vol
+
+
+def dt_multiotsu_threshold(img_blur, otsu_component=0, nbins=256):
+    """``_multiotsu_threshold`` (``tracking.py:425-501``), float32 like the reference."""
+    v = np.asarray(img_blur, np.float32)
+    vmin, vmax = float(v.min()), float(v.max())
+    if vmin == vmax:
+        return vmin
+    hist = dt_histc(v, nbins, vmin, vmax)
+    hist = (hist / hist.sum(dtype=np.float32)).astype(np.float32)
+    step = (np.float32(vmax) - np.float32(vmin)) / np.float32(nbins - 1)
+    i = np.arange(nbins, dtype=np.float32)
+    centers = np.where(np.arange(nbins) < nbins // 2, np.float32(vmin) + step * i,
+                       np.float32(vmax) - step * (np.float32(nbins - 1) - i)).astype(np.float32)
+    cw = np.cumsum(hist, dtype=np.float32)
+    cm = np.cumsum(hist * centers, dtype=np.float32)
+    mu, eps = cm[-1], np.float32(1e-10)
+    w0, w1, w2 = cw[:, None], cw[None, :] - cw[:, None], np.float32(1) - cw[None, :]
+    m0 = cm[:, None] / np.maximum(w0, eps)
+    m1 = (cm[None, :] - cm[:, None]) / np.maximum(w1, eps)
+    m2 = (mu - cm[None, :]) / np.maximum(w2, eps)
+    sig = w0 * (m0 - mu) ** 2 + w1 * (m1 - mu) ** 2 + w2 * (m2 - mu) ** 2
+    b = np.arange(nbins)
+    ok = (b[None, :] > b[:, None]) & (b[None, :] <= nbins - 2) & (w0 > eps) & (w1 > eps) & (w2 > eps)
+    a_, b_ = divmod(int(np.argmax(np.where(ok, sig, np.float32(-1)))), nbins)
+    return (float(centers[a_ + 1]), float(centers[b_ + 1]))[min(otsu_component, 1)]
+
+
+def dt_binary_mask(img, sigma=5.0, otsu_component=0):
+    """``_binary_mask`` (``tracking.py:504-542``)."""
+    v = np.asarray(img, np.float32)
+    vmin, vmax = v.min(), v.max()
+    if not vmax > vmin:
+        return np.zeros(v.shape, bool)
+    blur = dt_gaussian_blur_3d((v - vmin) / (vmax - vmin), sigma)
+    return blur > dt_multiotsu_threshold(blur, otsu_component)
+
+
+def dt_center_of_mass(mask):
+    """``_center_of_mass`` (``tracking.py:545-569``)."""
+    c = np.argwhere(mask)
+    return c.mean(axis=0).astype(np.float32) if len(c) else np.zeros(mask.ndim, np.float32)
+
+
+def dt_roi_shift(img, background_percentile=None, blur_sigma=0.0):
+    """``_intensity_center_of_mass_to_roi_center`` (``tracking.py:652-707``)."""
+    v = np.asarray(img, np.float32)
+    if blur_sigma and blur_sigma > 0:
+        v = dt_gaussian_blur_3d(v, blur_sigma)
+    bg = dt_percentile(v, background_percentile) if background_percentile is not None else 0.0
+    return dt_intensity_center_of_mass(v, bg) - np.array([(s - 1) / 2.0 for s in v.shape], np.float32)
+
+
+def dt_multiotsu_center_of_mass(ref_img, mov_img, sigma=5.0, otsu_component=0):
+    """``_multiotsu_center_of_mass`` (``tracking.py:759-787``)."""
+    return (dt_center_of_mass(dt_binary_mask(mov_img, sigma, otsu_component))
+            - dt_center_of_mass(dt_binary_mask(ref_img, sigma, otsu_component)))

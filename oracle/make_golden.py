@@ -111,6 +111,58 @@ def capture_reference_fixtures():
     print("captured ref_preprocessing.npz from", ref)
 
 
+def dynatrack_scene(seed, shape=(12, 40, 48), shift=(0.0, 0.0, 0.0)):
+    """A bright blob on a noisy pedestal (the kind of volume DynaTrack centres on)."""
+    rng = np.random.default_rng(seed)
+    zz, yy, xx = np.meshgrid(*(np.arange(n, dtype=np.float32) for n in shape), indexing="ij")
+    c = [(n - 1) / 2 + 0.15 * n + s for n, s in zip(shape, shift)]
+    blob = np.exp(-0.5 * (((zz - c[0]) / 2.0) ** 2 + ((yy - c[1]) / 5.0) ** 2 + ((xx - c[2]) / 6.0) ** 2))
+    return (100 + 900 * blob + 20 * rng.standard_normal(shape)).astype(np.float32)
+
+
+def capture_dynatrack_fixtures():
+    """Run the reference's own estimator functions (shrimpy/dynatrack/tracking.py) on seeded
+    volumes and record inputs + outputs (the importable oracle of the f-3 row)."""
+    ref = Path("/root/reference")
+    if not ref.exists():
+        print("reference absent: ref_dynatrack.npz not regenerated")
+        return
+    if str(ref) not in sys.path:
+        sys.path.insert(0, str(ref))
+    sys.dont_write_bytecode = True
+    import torch
+
+    from shrimpy.dynatrack import tracking as t
+
+    a = dynatrack_scene(11)
+    b = dynatrack_scene(12, shift=(1.0, -3.0, 2.5))
+    thin = dynatrack_scene(13, shape=(3, 9, 70))          # axes shorter than the blur radius
+    ta, tb, tt = (torch.as_tensor(v) for v in (a, b, thin))
+    out = {"a": a, "b": b, "thin": thin}
+    out["percentile_a"] = np.array([t._percentile(ta, p) for p in (1.0, 50.0, 90.0, 99.5)])
+    out["percentile_p"] = np.array([1.0, 50.0, 90.0, 99.5])
+    out["icom_a_bg0"] = t._intensity_center_of_mass(ta).numpy()
+    out["icom_a_bg300"] = t._intensity_center_of_mass(ta, background=300.0).numpy()
+    out["icom_blank"] = t._intensity_center_of_mass(torch.zeros(4, 5, 6)).numpy()
+    out["roi_shift_a"] = np.array(t._intensity_center_of_mass_to_roi_center(ta))
+    out["roi_shift_a_p50"] = np.array(t._intensity_center_of_mass_to_roi_center(ta, background_percentile=50.0))
+    out["roi_shift_b_p90_blur"] = np.array(
+        t._intensity_center_of_mass_to_roi_center(tb, background_percentile=90.0, blur_sigma=1.5))
+    out["blur_a_s1"] = t._gaussian_blur_3d(ta, 1.0).numpy()
+    out["blur_a_s2p5"] = t._gaussian_blur_3d(ta, 2.5).numpy()
+    out["blur_thin_s2"] = t._gaussian_blur_3d(tt, 2.0).numpy()
+    blur = t._gaussian_blur_3d((ta - ta.min()) / (ta.max() - ta.min()), 2.0)
+    out["otsu_blur_a"] = np.array([t._multiotsu_threshold(blur, 0), t._multiotsu_threshold(blur, 1)])
+    mask = t._binary_mask(ta, sigma=2.0, otsu_component=0)
+    out["mask_a_s2"] = mask.numpy()
+    out["com_mask_a_s2"] = t._center_of_mass(mask).numpy()
+    out["com_empty"] = t._center_of_mass(torch.zeros(3, 4, 5, dtype=torch.bool)).numpy()
+    out["motsu_shift_ab_s2"] = np.array(t._multiotsu_center_of_mass(ta, tb, sigma=2.0, otsu_component=0))
+    out["motsu_shift_ab_s2_c1"] = np.array(t._multiotsu_center_of_mass(ta, tb, sigma=2.0, otsu_component=1))
+    np.savez_compressed(GOLD / "ref_dynatrack.npz", **out)
+    print("captured ref_dynatrack.npz from", ref)
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     for name, case in deskew_cases().items():
@@ -118,6 +170,7 @@ def main():
     np.savez_compressed(GOLD / "affine_rot2deg.npz", **affine_case())
     np.savez_compressed(GOLD / "rl_5iter.npz", **rl_cases())
     capture_reference_fixtures()
+    capture_dynatrack_fixtures()
     for f in sorted(GOLD.glob("*.npz")):
         print(f.name, f.stat().st_size)
 

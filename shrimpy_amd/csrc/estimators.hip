@@ -1,0 +1,382 @@
+// Reductions and filters behind the DynaTrack shift estimators that consume the deskewed volume
+// (reference shrimpy/dynatrack/tracking.py, root /root/reference):
+//
+//   lsr_minmax_f32             img.min(), img.max()                      (:533-535, :460-463, :583)
+//   lsr_histogram_f32          torch.histc(img, bins, min, max)          (:465, :586)
+//   lsr_weighted_centroid_f32  _intensity_center_of_mass                 (:596-649)
+//   lsr_mask_centroid_f32      _center_of_mass(img > threshold)          (:545-569, :540)
+//   lsr_blur_reflect_f32       one axis of _gaussian_blur_3d             (:386-422; F.pad reflect + conv3d)
+//
+// All of them stream the volume once at HBM speed; the sums are accumulated in fp64 and reduced in a
+// fixed order (two launches, no float atomics), so results do not depend on scheduling.
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kBlocks = 2048;   // partial results of the two-stage reductions
+constexpr int kThreads = 256;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Grid-stride walk over a flat array: 16-byte loads, four of them in flight per thread, where the
+// pointer is 16-byte aligned (torch allocations are); the tail and unaligned arrays go scalar.
+template <typename F>
+__device__ __forceinline__ void for_each_flat(const float* __restrict__ in, int64_t n, F&& f) {
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  const int64_t nthreads = static_cast<int64_t>(gridDim.x) * kThreads;
+  int64_t done = 0;
+  if ((reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+    const int64_t n4 = n >> 2;
+    const f32x4* in4 = reinterpret_cast<const f32x4*>(in);
+    int64_t i = tid;
+    for (; i + 3 * nthreads < n4; i += 4 * nthreads) {
+      const f32x4 a = in4[i], b = in4[i + nthreads], c = in4[i + 2 * nthreads], d = in4[i + 3 * nthreads];
+      f(a.x); f(a.y); f(a.z); f(a.w); f(b.x); f(b.y); f(b.z); f(b.w);
+      f(c.x); f(c.y); f(c.z); f(c.w); f(d.x); f(d.y); f(d.z); f(d.w);
+    }
+    for (; i < n4; i += nthreads) {
+      const f32x4 a = in4[i];
+      f(a.x); f(a.y); f(a.z); f(a.w);
+    }
+    done = n4 << 2;
+  }
+  for (int64_t i = done + tid; i < n; i += nthreads) f(in[i]);
+}
+
+// ---------------------------------------------------------------------------------- min / max
+__global__ __launch_bounds__(kThreads) void minmax_partial_kernel(const float* __restrict__ in, int64_t n,
+                                                                  float* __restrict__ partial) {
+  __shared__ float s_lo[kThreads], s_hi[kThreads];
+  float lo = INFINITY, hi = -INFINITY;
+  for_each_flat(in, n, [&](float v) {
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  });
+  s_lo[threadIdx.x] = lo;
+  s_hi[threadIdx.x] = hi;
+  __syncthreads();
+  for (int w = kThreads / 2; w > 0; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w) {
+      s_lo[threadIdx.x] = fminf(s_lo[threadIdx.x], s_lo[threadIdx.x + w]);
+      s_hi[threadIdx.x] = fmaxf(s_hi[threadIdx.x], s_hi[threadIdx.x + w]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = s_lo[0];
+    partial[2 * blockIdx.x + 1] = s_hi[0];
+  }
+}
+__global__ __launch_bounds__(kThreads) void minmax_final_kernel(const float* __restrict__ partial, int nb,
+                                                                float* __restrict__ out) {
+  __shared__ float s_lo[kThreads], s_hi[kThreads];
+  float lo = INFINITY, hi = -INFINITY;
+  for (int i = threadIdx.x; i < nb; i += kThreads) {
+    lo = fminf(lo, partial[2 * i]);
+    hi = fmaxf(hi, partial[2 * i + 1]);
+  }
+  s_lo[threadIdx.x] = lo;
+  s_hi[threadIdx.x] = hi;
+  __syncthreads();
+  for (int w = kThreads / 2; w > 0; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w) {
+      s_lo[threadIdx.x] = fminf(s_lo[threadIdx.x], s_lo[threadIdx.x + w]);
+      s_hi[threadIdx.x] = fmaxf(s_hi[threadIdx.x], s_hi[threadIdx.x + w]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = s_lo[0];
+    out[1] = s_hi[0];
+  }
+}
+
+// ---------------------------------------------------------------------------------- histogram
+// torch.histc: bin = (int)((x - min) * nbins / (max - min)) in float32, x == max goes to the last
+// bin, x outside [min, max] (and NaN) is dropped.
+constexpr int kMaxBins = 4096;
+__global__ __launch_bounds__(kThreads) void histogram_kernel(const float* __restrict__ in, int64_t n,
+                                                             float vmin, float vmax, int nbins,
+                                                             unsigned* __restrict__ counts) {
+  extern __shared__ unsigned s_hist[];
+  for (int b = threadIdx.x; b < nbins; b += kThreads) s_hist[b] = 0;
+  __syncthreads();
+  const float range = vmax - vmin, fb = static_cast<float>(nbins);
+  for_each_flat(in, n, [&](float v) {
+    if (v >= vmin && v <= vmax) {
+      int bin = static_cast<int>((v - vmin) * fb / range);
+      bin = bin >= nbins ? nbins - 1 : bin;
+      atomicAdd(&s_hist[bin], 1u);
+    }
+  });
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbins; b += kThreads)
+    if (s_hist[b]) atomicAdd(&counts[b], s_hist[b]);  // integer adds: order-independent
+}
+
+// ---------------------------------------------------------------------------------- centroids
+// One workgroup walks rows (z, y); a thread accumulates w and w * x over its x positions; the row
+// totals feed sum(w), sum(w z), sum(w y), sum(w x) in fp64.  MASK: w = v > threshold, else
+// w = max(v - background, 0) evaluated in f32 like the reference.
+template <bool MASK>
+__global__ __launch_bounds__(kThreads) void centroid_partial_kernel(const float* __restrict__ in, int Z, int Y,
+                                                                    int X, float param,
+                                                                    double* __restrict__ partial) {
+  __shared__ double red[4][kThreads];
+  double sw = 0.0, sz = 0.0, sy = 0.0, sx = 0.0;
+  const int64_t rows = static_cast<int64_t>(Z) * Y;
+  auto weight = [&](float v) {
+    if constexpr (MASK) return v > param ? 1.0f : 0.0f;
+    else return fmaxf(v - param, 0.0f);
+  };
+  // four rows per step: four independent loads in flight per thread
+  for (int64_t r0 = static_cast<int64_t>(blockIdx.x) * 4; r0 < rows; r0 += static_cast<int64_t>(gridDim.x) * 4) {
+    double w_row[4] = {0.0, 0.0, 0.0, 0.0}, wx_row[4] = {0.0, 0.0, 0.0, 0.0};
+    const int nr = static_cast<int>(min(static_cast<int64_t>(4), rows - r0));
+    for (int x = threadIdx.x; x < X; x += kThreads) {
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = in[(r0 + min(k, nr - 1)) * X + x];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double w = static_cast<double>(weight(v[k]));
+        w_row[k] += w;
+        wx_row[k] += w * static_cast<double>(x);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < nr) {
+        const int64_t r = r0 + k;
+        const int z = static_cast<int>(r / Y), y = static_cast<int>(r - static_cast<int64_t>(z) * Y);
+        sw += w_row[k];
+        sz += w_row[k] * static_cast<double>(z);
+        sy += w_row[k] * static_cast<double>(y);
+        sx += wx_row[k];
+      }
+    }
+  }
+  red[0][threadIdx.x] = sw; red[1][threadIdx.x] = sz; red[2][threadIdx.x] = sy; red[3][threadIdx.x] = sx;
+  __syncthreads();
+  for (int w = kThreads / 2; w > 0; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) partial[4 * blockIdx.x + threadIdx.x] = red[threadIdx.x][0];
+}
+__global__ __launch_bounds__(kThreads) void sum4_final_kernel(const double* __restrict__ partial, int nb,
+                                                              double* __restrict__ out) {
+  __shared__ double red[4][kThreads];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nb; i += kThreads)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] += partial[4 * i + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int w = kThreads / 2; w > 0; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) out[threadIdx.x] = red[threadIdx.x][0];
+}
+
+// ---------------------------------------------------------------------------------- reflect blur
+// out = correlate1d(in, taps) along one axis with F.pad(mode="reflect") borders (index -k -> k,
+// n-1+k -> n-1-k; needs radius < n).  The volume is viewed as (outer, L, inner): the filtered axis
+// has length L and stride `inner`.  A workgroup stages (64 + 2r) x 64 values -- 64 positions of the
+// axis plus halo, 64 consecutive `inner` elements -- in LDS and each thread produces 16 outputs of
+// one inner column; LDS reads are conflict-free (lanes = consecutive inner elements).  For the
+// contiguous axis (inner == 1) the roles swap: lanes run along the axis itself.
+// Optional input map (v - sub) / div fused into staging (the reference rescales to [0, 1] first).
+constexpr int kBlurMaxR = 64;
+constexpr int kSeg = 64;
+
+struct BlurArgs {
+  const float* in;
+  float* out;
+  const float* taps;  // device, 2r+1 floats
+  int64_t outer, L, inner;
+  int r;
+  float sub, div;     // div == 0: no map
+};
+
+__device__ __forceinline__ int reflect(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+__global__ __launch_bounds__(kThreads) void blur_strided_kernel(BlurArgs p) {
+  extern __shared__ float tile[];  // [(kSeg + 2r)][64]
+  __shared__ float s_taps[2 * kBlurMaxR + 1];
+  const int r = p.r;
+  const int64_t inner_tiles = (p.inner + 63) / 64, seg_tiles = (p.L + kSeg - 1) / kSeg;
+  int64_t bid = blockIdx.x;
+  const int64_t it = bid % inner_tiles;
+  bid /= inner_tiles;
+  const int64_t st = bid % seg_tiles;
+  const int64_t o = bid / seg_tiles;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i0 = it * 64 + lane;
+  const bool col_ok = i0 < p.inner;
+  const int64_t a0 = st * kSeg;
+  // positions of this segment that exist, plus halo: reflect() is only valid within r of the axis
+  const int n_out = static_cast<int>(min(static_cast<int64_t>(kSeg), p.L - a0));
+  const int rows = n_out + 2 * r;
+  const float* base = p.in + o * p.L * p.inner + (col_ok ? i0 : 0);
+  for (int t = threadIdx.x; t < 2 * r + 1; t += kThreads) s_taps[t] = p.taps[t];
+  for (int row = grp; row < rows; row += kThreads / 64) {
+    const int a = reflect(static_cast<int>(a0) + row - r, static_cast<int>(p.L));
+    float v = col_ok ? base[static_cast<int64_t>(a) * p.inner] : 0.0f;
+    if (p.div != 0.0f) v = (v - p.sub) / p.div;
+    tile[row * 64 + lane] = v;
+  }
+  __syncthreads();
+  float* obase = p.out + o * p.L * p.inner + i0;
+  for (int k = grp; k < n_out; k += kThreads / 64) {
+    const int64_t a = a0 + k;
+    float acc = 0.0f;
+    for (int t = 0; t < 2 * r + 1; ++t) acc = fmaf(s_taps[t], tile[(k + t) * 64 + lane], acc);
+    if (col_ok) obase[a * p.inner] = acc;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void blur_contiguous_kernel(BlurArgs p) {
+  extern __shared__ float tile[];  // [kThreads + 2r]
+  __shared__ float s_taps[2 * kBlurMaxR + 1];
+  const int r = p.r;
+  const int64_t seg_tiles = (p.L + kThreads - 1) / kThreads;
+  const int64_t st = blockIdx.x % seg_tiles, row = blockIdx.x / seg_tiles;  // row over outer
+  const int64_t a0 = st * kThreads;
+  const float* base = p.in + row * p.L;
+  for (int t = threadIdx.x; t < 2 * r + 1; t += kThreads) s_taps[t] = p.taps[t];
+  const int n_out = static_cast<int>(min(static_cast<int64_t>(kThreads), p.L - a0));
+  for (int t = threadIdx.x; t < n_out + 2 * r; t += kThreads) {
+    const int a = reflect(static_cast<int>(a0) + t - r, static_cast<int>(p.L));
+    float v = base[a];
+    if (p.div != 0.0f) v = (v - p.sub) / p.div;
+    tile[t] = v;
+  }
+  __syncthreads();
+  const int64_t a = a0 + threadIdx.x;
+  if (a < p.L) {
+    float acc = 0.0f;
+    for (int t = 0; t < 2 * r + 1; ++t) acc = fmaf(s_taps[t], tile[threadIdx.x + t], acc);
+    p.out[row * p.L + a] = acc;
+  }
+}
+
+int check_volume(const float* in, int64_t Z, int64_t Y, int64_t X) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
+              (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE(Z < (int64_t(1) << 30) && Y < (int64_t(1) << 30) && X < (int64_t(1) << 30), LSR_E_UNSUPPORTED,
+              "a dimension exceeds 2^30");
+  return LSR_OK;
+}
+
+int grid_for(int64_t work_items) {
+  const int64_t b = lsr::ceil_div(work_items, static_cast<int64_t>(kThreads));
+  return static_cast<int>(b < kBlocks ? (b < 1 ? 1 : b) : kBlocks);
+}
+
+}  // namespace
+
+extern "C" int lsr_reduce_scratch_bytes(void) { return kBlocks * 4 * static_cast<int>(sizeof(double)); }
+
+extern "C" int lsr_minmax_f32(const float* in, int64_t n, float* out2, void* scratch, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(out2);
+  LSR_REQUIRE_PTR(scratch);
+  LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  const int nb = grid_for(n);
+  hipStream_t s = lsr::as_stream(stream);
+  float* partial = static_cast<float*>(scratch);
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb), dim3(kThreads), 0, s, in, n, partial);
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(kThreads), 0, s, partial, nb, out2);
+  return lsr::launch_status("lsr_minmax_f32");
+}
+
+extern "C" int lsr_histogram_f32(const float* in, int64_t n, float vmin, float vmax, int nbins,
+                                 unsigned* counts, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(counts);
+  LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  LSR_REQUIRE(nbins >= 1 && nbins <= kMaxBins, LSR_E_ARG, "nbins %d outside [1, %d]", nbins, kMaxBins);
+  LSR_REQUIRE(vmax > vmin, LSR_E_ARG, "histogram range [%g, %g] is empty", vmin, vmax);
+  hipStream_t s = lsr::as_stream(stream);
+  if (hipMemsetAsync(counts, 0, sizeof(unsigned) * nbins, s) != hipSuccess)
+    return lsr::launch_status("lsr_histogram_f32");
+  hipLaunchKernelGGL(histogram_kernel, dim3(grid_for(n)), dim3(kThreads), sizeof(unsigned) * nbins, s, in,
+                     n, vmin, vmax, nbins, counts);
+  return lsr::launch_status("lsr_histogram_f32");
+}
+
+namespace {
+template <bool MASK>
+int centroid(const char* what, const float* in, int64_t Z, int64_t Y, int64_t X, float param, double* out4,
+             void* scratch, lsr_stream_t stream) {
+  if (int rc = check_volume(in, Z, Y, X)) return rc;
+  LSR_REQUIRE_PTR(out4);
+  LSR_REQUIRE_PTR(scratch);
+  const int64_t rows = Z * Y, groups = lsr::ceil_div(rows, int64_t(4));
+  const int nb = static_cast<int>(groups < kBlocks ? groups : kBlocks);
+  hipStream_t s = lsr::as_stream(stream);
+  double* partial = static_cast<double*>(scratch);
+  hipLaunchKernelGGL(centroid_partial_kernel<MASK>, dim3(nb), dim3(kThreads), 0, s, in, static_cast<int>(Z),
+                     static_cast<int>(Y), static_cast<int>(X), param, partial);
+  hipLaunchKernelGGL(sum4_final_kernel, dim3(1), dim3(kThreads), 0, s, partial, nb, out4);
+  return lsr::launch_status(what);
+}
+}  // namespace
+
+extern "C" int lsr_weighted_centroid_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float background,
+                                         double* out4, void* scratch, lsr_stream_t stream) {
+  return centroid<false>("lsr_weighted_centroid_f32", in, Z, Y, X, background, out4, scratch, stream);
+}
+
+extern "C" int lsr_mask_centroid_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float threshold,
+                                     double* out4, void* scratch, lsr_stream_t stream) {
+  return centroid<true>("lsr_mask_centroid_f32", in, Z, Y, X, threshold, out4, scratch, stream);
+}
+
+extern "C" int lsr_blur_reflect_f32(const float* in, float* out, int64_t Z, int64_t Y, int64_t X, int axis,
+                                    const float* taps, int radius, float sub, float div,
+                                    lsr_stream_t stream) {
+  if (int rc = check_volume(in, Z, Y, X)) return rc;
+  LSR_REQUIRE_PTR(out);
+  LSR_REQUIRE_PTR(taps);
+  LSR_REQUIRE(in != out, LSR_E_ARG, "out must not alias in");
+  LSR_REQUIRE(axis >= 0 && axis <= 2, LSR_E_ARG, "axis %d must be 0 (z), 1 (y) or 2 (x)", axis);
+  LSR_REQUIRE(radius >= 0 && radius <= kBlurMaxR, LSR_E_UNSUPPORTED, "radius %d outside [0, %d]", radius,
+              kBlurMaxR);
+  const int64_t dims[3] = {Z, Y, X};
+  LSR_REQUIRE(radius < dims[axis], LSR_E_ARG, "reflect padding needs radius %d < axis length %lld", radius,
+              (long long)dims[axis]);
+  BlurArgs p;
+  p.in = in; p.out = out; p.taps = taps; p.r = radius; p.sub = sub; p.div = div;
+  p.L = dims[axis];
+  p.outer = axis == 0 ? 1 : (axis == 1 ? Z : Z * Y);
+  p.inner = axis == 0 ? Y * X : (axis == 1 ? X : 1);
+  hipStream_t s = lsr::as_stream(stream);
+  if (axis == 2) {
+    const int64_t blocks = p.outer * lsr::ceil_div(p.L, static_cast<int64_t>(kThreads));
+    LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
+                (long long)blocks);
+    hipLaunchKernelGGL(blur_contiguous_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
+                       sizeof(float) * (kThreads + 2 * radius), s, p);
+  } else {
+    const int64_t blocks = p.outer * lsr::ceil_div(p.L, static_cast<int64_t>(kSeg)) * lsr::ceil_div(p.inner, int64_t(64));
+    LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
+                (long long)blocks);
+    hipLaunchKernelGGL(blur_strided_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
+                       sizeof(float) * (kSeg + 2 * radius) * 64, s, p);
+  }
+  return lsr::launch_status("lsr_blur_reflect_f32");
+}

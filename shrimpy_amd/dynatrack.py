@@ -1,0 +1,276 @@
+"""DynaTrack shift estimators on the deskewed volume, on MI355X.
+
+Mirrors the private estimator functions of the reference's ``shrimpy/dynatrack/tracking.py`` --
+same names, arguments, return types and corner-case behaviour -- for the estimators that need no
+FFT.  The arithmetic runs as HIP kernels (``csrc/estimators.hip``: min / max, ``torch.histc``-exact
+histograms, fp64 centroid sums, LDS-tiled reflect-padded Gaussian passes); the 256-bin searches
+(percentile, multi-Otsu) are a few hundred flops of host logic on the histogram, like the
+reference's own ``float(...)`` / ``int(...)`` round trips.
+
+=========================================  =====================================  ==========
+reference (``tracking.py``)                here                                   kernels
+=========================================  =====================================  ==========
+``_gaussian_blur_3d`` ``:386-422``         :func:`_gaussian_blur_3d`              blur x3
+``_multiotsu_threshold`` ``:425-501``      :func:`_multiotsu_threshold`           minmax, histogram
+``_binary_mask`` ``:504-542``              :func:`_binary_mask`                   minmax, blur x3, histogram
+``_center_of_mass`` ``:545-569``           :func:`_center_of_mass`                mask centroid
+``_percentile`` ``:572-593``               :func:`_percentile`                    minmax, histogram
+``_intensity_center_of_mass`` ``:596-649`` :func:`_intensity_center_of_mass`      weighted centroid
+``..._to_roi_center`` ``:652-707``         same name                              the above
+``_multiotsu_center_of_mass`` ``:759-787`` same name                              the above
+``_phase_cross_corr`` and the ``*_pcc``    raise ``NotImplementedError``          (FFT: not in this package)
+=========================================  =====================================  ==========
+
+``_binary_mask`` / ``_center_of_mass`` never materialise the boolean mask unless asked to: the
+centroid kernel thresholds on the fly.  No CPU fallback: tensors must live on the GPU.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import logging
+
+import numpy as np
+
+from . import _lib
+
+logger = logging.getLogger(__name__)
+
+__all__ = [
+    "_gaussian_blur_3d", "_multiotsu_threshold", "_binary_mask", "_center_of_mass", "_percentile",
+    "_intensity_center_of_mass", "_intensity_center_of_mass_to_roi_center", "_multiotsu_center_of_mass",
+    "_phase_cross_corr",
+]
+
+
+def _volume(img, name="img"):
+    import torch
+
+    if not isinstance(img, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(img).__name__}")
+    if img.dtype != torch.float32:
+        img = img.to(dtype=torch.float32)
+    return _lib.require_device_f32(img.contiguous(), name)
+
+
+def _scratch(device):
+    import torch
+
+    return torch.empty((_lib.call_value("lsr_reduce_scratch_bytes"),), dtype=torch.uint8, device=device)
+
+
+def _minmax(img) -> tuple[float, float]:
+    """``(float(img.min()), float(img.max()))`` -- one pass, one host round trip (the reference's
+    ``float(vmin)`` / ``float(vmax)`` synchronise too)."""
+    import torch
+
+    out = torch.empty((2,), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        _lib.call("lsr_minmax_f32", img.data_ptr(), img.numel(), out.data_ptr(), _scratch(img.device).data_ptr(),
+                  _lib.stream_ptr(img.device))
+    lo, hi = out.cpu().tolist()
+    return lo, hi
+
+
+def _histc(img, nbins: int, vmin: float, vmax: float) -> np.ndarray:
+    """``torch.histc(img, bins=nbins, min=vmin, max=vmax)`` as a host float32 array."""
+    import torch
+
+    counts = torch.empty((nbins,), dtype=torch.int32, device=img.device)
+    with torch.cuda.device(img.device):
+        _lib.call("lsr_histogram_f32", img.data_ptr(), img.numel(), ctypes.c_float(vmin), ctypes.c_float(vmax),
+                  int(nbins), counts.data_ptr(), _lib.stream_ptr(img.device))
+    return counts.cpu().numpy().astype(np.float32)
+
+
+def _gaussian_blur_3d(img, sigma: float, _rescale: tuple[float, float] | None = None):
+    """Separable 3-D Gaussian blur with reflect padding (``tracking.py:386-422``).
+
+    ``_rescale = (vmin, vmax)`` fuses the reference's ``(img - vmin) / (vmax - vmin)`` into the
+    first pass.
+    """
+    import torch
+
+    vol = _volume(img)
+    if vol.dim() != 3:
+        raise ValueError(f"img must be (Z, Y, X), got shape {tuple(vol.shape)}")
+    if sigma <= 0:
+        if _rescale is not None:
+            return (vol - _rescale[0]) / (_rescale[1] - _rescale[0])
+        return vol
+    max_radius = int(4 * sigma + 0.5)
+    z, y, x = (int(v) for v in vol.shape)
+    src = vol
+    sub, div = (0.0, 0.0) if _rescale is None else (float(_rescale[0]), float(np.float32(_rescale[1]) - np.float32(_rescale[0])))
+    with torch.cuda.device(vol.device):
+        stream = _lib.stream_ptr(vol.device)
+        for axis, n in enumerate((z, y, x)):
+            r = min(max_radius, n - 1)   # reflect padding requires pad < dim (reference :403-404)
+            xs = torch.arange(-r, r + 1, device=vol.device, dtype=torch.float32)
+            k1d = torch.exp(-0.5 * (xs / sigma) ** 2)
+            k1d = (k1d / k1d.sum()).contiguous()
+            dst = torch.empty_like(vol)
+            _lib.call("lsr_blur_reflect_f32", src.data_ptr(), dst.data_ptr(), z, y, x, axis, k1d.data_ptr(), r,
+                      ctypes.c_float(sub), ctypes.c_float(div), stream)
+            src, sub, div = dst, 0.0, 0.0
+    return src
+
+
+def _otsu_from_hist(hist: np.ndarray, vmin: float, vmax: float, otsu_component: int) -> float:
+    """The 3-class search of ``tracking.py:466-501`` on a host histogram (float32 throughout)."""
+    nbins = hist.shape[0]
+    hist = (hist / hist.sum(dtype=np.float32)).astype(np.float32)
+    # torch.linspace(start, end, steps) in float32: start + i * step for the first half,
+    # end - (steps - 1 - i) * step for the second (ATen's symmetric formula)
+    step = (np.float32(vmax) - np.float32(vmin)) / np.float32(nbins - 1)
+    idx = np.arange(nbins, dtype=np.float32)
+    half = nbins // 2
+    centers = np.where(np.arange(nbins) < half, np.float32(vmin) + step * idx,
+                       np.float32(vmax) - step * (np.float32(nbins - 1) - idx)).astype(np.float32)
+    cum_w = np.cumsum(hist, dtype=np.float32)
+    cum_wm = np.cumsum(hist * centers, dtype=np.float32)
+    total_mean = cum_wm[-1]
+    eps = np.float32(1e-10)
+    w0 = cum_w[:, None]
+    w1 = cum_w[None, :] - cum_w[:, None]
+    w2 = np.float32(1.0) - cum_w[None, :]
+    m0 = cum_wm[:, None] / np.maximum(w0, eps)
+    m1 = (cum_wm[None, :] - cum_wm[:, None]) / np.maximum(w1, eps)
+    m2 = (total_mean - cum_wm[None, :]) / np.maximum(w2, eps)
+    sigma = w0 * (m0 - total_mean) ** 2 + w1 * (m1 - total_mean) ** 2 + w2 * (m2 - total_mean) ** 2
+    bins = np.arange(nbins)
+    valid = ((bins[None, :] > bins[:, None]) & (bins[None, :] <= nbins - 2)
+             & (w0 > eps) & (w1 > eps) & (w2 > eps))
+    sigma = np.where(valid, sigma, np.float32(-1.0)).astype(np.float32)
+    best_a, best_b = divmod(int(np.argmax(sigma)), nbins)
+    thresholds = (float(centers[best_a + 1]), float(centers[best_b + 1]))
+    logger.debug("multi-Otsu thresholds: %s (using component %d)", thresholds, otsu_component)
+    return thresholds[min(otsu_component, 1)]
+
+
+def _multiotsu_threshold(img_blur, otsu_component: int = 0, nbins: int = 256) -> float:
+    """Multi-Otsu threshold of a (pre-blurred) device volume (``tracking.py:425-501``)."""
+    vol = _volume(img_blur, "img_blur")
+    vmin, vmax = _minmax(vol)
+    if vmin == vmax:
+        return float(vmin)
+    return _otsu_from_hist(_histc(vol, nbins, vmin, vmax), vmin, vmax, otsu_component)
+
+
+def _binary_mask(img, sigma: float = 5.0, otsu_component: int = 0):
+    """Rescale to [0, 1], blur, multi-Otsu threshold (``tracking.py:504-542``) -> boolean mask."""
+    import torch
+
+    vol = _volume(img)
+    blurred, threshold = _blurred_and_threshold(vol, sigma, otsu_component)
+    if blurred is None:
+        return torch.zeros_like(vol, dtype=torch.bool)
+    return blurred > threshold
+
+
+def _blurred_and_threshold(vol, sigma: float, otsu_component: int):
+    vmin, vmax = _minmax(vol)
+    if not vmax > vmin:
+        return None, 0.0
+    blurred = _gaussian_blur_3d(vol, sigma, _rescale=(vmin, vmax))
+    return blurred, _multiotsu_threshold(blurred, otsu_component)
+
+
+def _centroid(kernel: str, vol, param: float):
+    import torch
+
+    z, y, x = (int(v) for v in vol.shape)
+    out = torch.empty((4,), dtype=torch.float64, device=vol.device)
+    with torch.cuda.device(vol.device):
+        _lib.call(kernel, vol.data_ptr(), z, y, x, ctypes.c_float(param), out.data_ptr(),
+                  _scratch(vol.device).data_ptr(), _lib.stream_ptr(vol.device))
+    return out.cpu().numpy()
+
+
+def _center_of_mass(mask, _threshold: float | None = None):
+    """Centre of mass of a boolean mask (``tracking.py:545-569``): every True voxel counts once.
+
+    Given a float volume and ``_threshold`` it is the centroid of ``volume > _threshold`` without
+    the mask ever being written.
+    """
+    import torch
+
+    if _threshold is None:
+        if mask.dtype != torch.bool:
+            raise TypeError("mask must be a boolean tensor")
+        vol, thr = _volume(mask.to(torch.float32), "mask"), 0.5
+    else:
+        vol, thr = _volume(mask, "mask"), float(_threshold)
+    if vol.dim() != 3:
+        raise ValueError(f"mask must be (Z, Y, X), got shape {tuple(vol.shape)}")
+    s = _centroid("lsr_mask_centroid_f32", vol, thr)
+    if s[0] == 0:
+        return torch.zeros(3, device=vol.device)
+    return torch.as_tensor((s[1:] / s[0]).astype(np.float32), device=vol.device)
+
+
+def _percentile(img, percentile: float, nbins: int = 256) -> float:
+    """Percentile (0-100) from a 256-bin histogram: upper edge of the selected bin (``:572-593``)."""
+    vol = _volume(img)
+    vmin, vmax = _minmax(vol)
+    if vmax <= vmin:
+        return vmin
+    hist = _histc(vol, nbins, vmin, vmax)
+    cdf = np.cumsum(hist, dtype=np.float32)
+    cdf = cdf / cdf[-1]
+    idx = int(np.searchsorted(cdf, np.float32(percentile / 100.0), side="left"))
+    idx = min(idx, nbins - 1)
+    return vmin + (idx + 1) * (vmax - vmin) / nbins
+
+
+def _intensity_center_of_mass(img, background: float = 0.0):
+    """Intensity-weighted centre of mass, weights ``max(img - background, 0)`` (``:596-649``)."""
+    import torch
+
+    vol = _volume(img)
+    if vol.dim() != 3:
+        raise ValueError(f"img must be (Z, Y, X), got shape {tuple(vol.shape)}")
+    s = _centroid("lsr_weighted_centroid_f32", vol, float(background))
+    if s[0] <= 0:
+        # no positive mass: the geometric centre, so that a ROI-centre shift is zero (:631-640)
+        return torch.tensor([(n - 1) / 2.0 for n in vol.shape], device=vol.device, dtype=torch.float32)
+    return torch.as_tensor((s[1:] / s[0]).astype(np.float32), device=vol.device)
+
+
+def _intensity_center_of_mass_to_roi_center(current_img, background_percentile: float | None = None,
+                                            blur_sigma: float = 0.0) -> tuple[float, ...]:
+    """Shift from the ROI centre to the intensity-weighted centroid, ZYX pixels (``:652-707``)."""
+    img = _volume(current_img, "current_img")
+    if blur_sigma and blur_sigma > 0:
+        img = _gaussian_blur_3d(img, blur_sigma)
+    background = _percentile(img, background_percentile) if background_percentile is not None else 0.0
+    com = _intensity_center_of_mass(img, background=background).cpu().numpy()
+    roi_center = np.array([(s - 1) / 2.0 for s in img.shape], dtype=np.float32)
+    shift = com - roi_center
+    logger.debug("intensity_center_of_mass: com=%s roi_center=%s background=%.4g blur_sigma=%.2g shift=%s",
+                 com.tolist(), roi_center.tolist(), background, blur_sigma, shift.tolist())
+    return tuple(float(s) for s in shift)
+
+
+def _multiotsu_center_of_mass(ref_img, mov_img, sigma: float = 5.0, otsu_component: int = 0) -> tuple[float, ...]:
+    """Shift between the multi-Otsu mask centroids of two volumes, ZYX pixels (``:759-787``)."""
+    centers = []
+    for img in (ref_img, mov_img):
+        vol = _volume(img)
+        blurred, threshold = _blurred_and_threshold(vol, sigma, otsu_component)
+        if blurred is None:
+            centers.append(np.zeros(3, np.float32))        # empty mask -> origin (:559-560)
+        else:
+            centers.append(_center_of_mass(blurred, _threshold=threshold).cpu().numpy())
+    shift = centers[1] - centers[0]
+    logger.debug("multiotsu_center_of_mass: ref_center=%s mov_center=%s shift=%s", centers[0].tolist(),
+                 centers[1].tolist(), shift.tolist())
+    return tuple(float(s) for s in shift)
+
+
+def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0):
+    """FFT phase cross-correlation (``tracking.py:309-378``) is not part of this package."""
+    raise NotImplementedError(
+        "phase cross-correlation needs a 3-D FFT, which this package does not implement; "
+        "use the reference's torch.fft path for tracking_method 'pcc' / '*_pcc'"
+    )

@@ -1,0 +1,138 @@
+"""the DynaTrack estimators as HIP kernels (``shrimpy_amd.dynatrack``) against
+(i) what the reference's own functions produced (``tests/golden/ref_dynatrack.npz``, captured by
+``oracle/make_golden.py`` from /root/reference/shrimpy/dynatrack/tracking.py) and (ii) the numpy
+oracle on larger volumes."""
+
+from __future__ import annotations
+
+import sys
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from oracle import cpu_ref as o  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(Path(__file__).resolve().parent / "golden" / "ref_dynatrack.npz")
+
+
+def _t(a, device):
+    import torch
+
+    return torch.as_tensor(np.ascontiguousarray(a), device=device)
+
+
+def test_percentile_and_histogram_match_the_reference(device, golden):
+    from shrimpy_amd import dynatrack as d
+
+    a = _t(golden["a"], device)
+    for p, want in zip(golden["percentile_p"], golden["percentile_a"]):
+        assert d._percentile(a, float(p)) == pytest.approx(float(want), rel=1e-6)
+    # the histogram itself is torch.histc bit for bit (integer counts)
+    rng = np.random.default_rng(3)
+    for vol in (rng.integers(80, 600, (9, 33, 70)).astype(np.float32),
+                (rng.standard_normal((20, 64, 130)) * 50).astype(np.float32)):
+        lo, hi = d._minmax(_t(vol, device))
+        assert (lo, hi) == (float(vol.min()), float(vol.max()))
+        for nbins in (256, 17, 1000):
+            np.testing.assert_array_equal(d._histc(_t(vol, device), nbins, lo, hi), o.dt_histc(vol, nbins, lo, hi))
+    assert d._percentile(_t(np.full((3, 4, 5), 7.0, np.float32), device), 50.0) == 7.0
+
+
+def test_intensity_center_of_mass_matches_the_reference(device, golden):
+    import torch
+
+    from shrimpy_amd import dynatrack as d
+
+    a, b = _t(golden["a"], device), _t(golden["b"], device)
+    np.testing.assert_allclose(d._intensity_center_of_mass(a).cpu().numpy(), golden["icom_a_bg0"], atol=2e-4)
+    np.testing.assert_allclose(d._intensity_center_of_mass(a, 300.0).cpu().numpy(), golden["icom_a_bg300"], atol=2e-4)
+    blank = d._intensity_center_of_mass(torch.zeros(4, 5, 6, device=device))
+    np.testing.assert_array_equal(blank.cpu().numpy(), golden["icom_blank"])
+    np.testing.assert_allclose(d._intensity_center_of_mass_to_roi_center(a), golden["roi_shift_a"], atol=2e-4)
+    np.testing.assert_allclose(d._intensity_center_of_mass_to_roi_center(a, background_percentile=50.0),
+                               golden["roi_shift_a_p50"], atol=2e-4)
+    np.testing.assert_allclose(d._intensity_center_of_mass_to_roi_center(b, background_percentile=90.0, blur_sigma=1.5),
+                               golden["roi_shift_b_p90_blur"], atol=1e-3)
+
+
+def test_gaussian_blur_matches_the_reference(device, golden):
+    from shrimpy_amd import dynatrack as d
+
+    a, thin = _t(golden["a"], device), _t(golden["thin"], device)
+    np.testing.assert_allclose(d._gaussian_blur_3d(a, 1.0).cpu().numpy(), golden["blur_a_s1"], rtol=2e-6, atol=1e-4)
+    np.testing.assert_allclose(d._gaussian_blur_3d(a, 2.5).cpu().numpy(), golden["blur_a_s2p5"], rtol=2e-6, atol=1e-4)
+    np.testing.assert_allclose(d._gaussian_blur_3d(thin, 2.0).cpu().numpy(), golden["blur_thin_s2"], rtol=2e-6, atol=1e-4)
+    assert d._gaussian_blur_3d(a, 0.0) is a
+
+
+def test_multiotsu_mask_and_centroid_match_the_reference(device, golden):
+    import torch
+
+    from shrimpy_amd import dynatrack as d
+
+    a, b = _t(golden["a"], device), _t(golden["b"], device)
+    an = golden["a"]
+    blur = d._gaussian_blur_3d(_t((an - an.min()) / (an.max() - an.min()), device), 2.0)
+    got = [d._multiotsu_threshold(blur, c) for c in (0, 1)]
+    assert got == pytest.approx(golden["otsu_blur_a"].tolist(), rel=1e-5)
+    mask = d._binary_mask(a, sigma=2.0, otsu_component=0)
+    assert mask.dtype == torch.bool and int((mask.cpu().numpy() != golden["mask_a_s2"]).sum()) <= 2
+    np.testing.assert_allclose(d._center_of_mass(_t(golden["mask_a_s2"], device)).cpu().numpy(),
+                               golden["com_mask_a_s2"], atol=1e-4)
+    np.testing.assert_array_equal(d._center_of_mass(torch.zeros(3, 4, 5, dtype=torch.bool, device=device)).cpu().numpy(),
+                                  golden["com_empty"])
+    np.testing.assert_allclose(d._multiotsu_center_of_mass(a, b, sigma=2.0, otsu_component=0),
+                               golden["motsu_shift_ab_s2"], atol=2e-2)
+    np.testing.assert_allclose(d._multiotsu_center_of_mass(a, b, sigma=2.0, otsu_component=1),
+                               golden["motsu_shift_ab_s2_c1"], atol=2e-2)
+    flat = torch.full((4, 6, 8), 3.0, device=device)
+    assert not bool(d._binary_mask(flat).any())
+    with pytest.raises(NotImplementedError):
+        d._phase_cross_corr(a, b)
+
+
+@pytest.mark.parametrize("shape,sigma", [((40, 130, 300), 5.0), ((7, 300, 65), 3.0), ((171, 96, 257), 1.0)])
+def test_estimators_vs_oracle_on_larger_volumes(device, shape, sigma):
+    """Every axis longer / shorter than the 64-long blur segments and the 41-tap kernel."""
+    from oracle.make_golden import dynatrack_scene
+    from shrimpy_amd import dynatrack as d
+
+    vol = dynatrack_scene(sum(shape), shape=shape)
+    t = _t(vol, device)
+    np.testing.assert_allclose(d._gaussian_blur_3d(t, sigma).cpu().numpy(), o.dt_gaussian_blur_3d(vol, sigma),
+                               rtol=3e-6, atol=2e-4)
+    assert d._percentile(t, 75.0) == pytest.approx(o.dt_percentile(vol, 75.0), rel=1e-6)
+    np.testing.assert_allclose(d._intensity_center_of_mass(t, 150.0).cpu().numpy(),
+                               o.dt_intensity_center_of_mass(vol, 150.0), atol=1e-3)
+    np.testing.assert_allclose(d._intensity_center_of_mass_to_roi_center(t, 60.0, sigma), o.dt_roi_shift(vol, 60.0, sigma),
+                               atol=2e-3)
+    other = dynatrack_scene(sum(shape) + 1, shape=shape, shift=(0.5, 2.0, -3.0))
+    np.testing.assert_allclose(d._multiotsu_center_of_mass(t, _t(other, device), sigma=sigma),
+                               o.dt_multiotsu_center_of_mass(vol, other, sigma), atol=5e-2)
+
+
+def test_cpu_tensors_fail_loudly(device):
+    import torch
+
+    from shrimpy_amd import dynatrack as d
+    from shrimpy_amd._lib import LsrError
+
+    with pytest.raises(LsrError, match="no CPU fallback"):
+        d._percentile(torch.zeros(2, 3, 4), 50.0)

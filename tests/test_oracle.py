@@ -168,3 +168,28 @@ def test_separable_rl_matches_dense_rl_for_asymmetric_factors():
     y = (rng.random((9, 12, 15)) * 50 + 1).astype(np.float32)
     np.testing.assert_allclose(o.richardson_lucy_separable(y, ks, 4), o.richardson_lucy(y, psf, 4),
                                rtol=2e-5)
+
+
+def test_dynatrack_oracle_matches_reference_capture(golden_dir):
+    """The f-3 row's oracle against what the reference's own estimator functions produced."""
+    g = np.load(golden_dir / "ref_dynatrack.npz")
+    a, b, thin = g["a"], g["b"], g["thin"]
+    for p, want in zip(g["percentile_p"], g["percentile_a"]):
+        assert o.dt_percentile(a, float(p)) == pytest.approx(float(want), rel=1e-6)
+    np.testing.assert_allclose(o.dt_intensity_center_of_mass(a), g["icom_a_bg0"], atol=2e-4)
+    np.testing.assert_allclose(o.dt_intensity_center_of_mass(a, 300.0), g["icom_a_bg300"], atol=2e-4)
+    np.testing.assert_allclose(o.dt_intensity_center_of_mass(np.zeros((4, 5, 6))), g["icom_blank"])
+    np.testing.assert_allclose(o.dt_gaussian_blur_3d(a, 1.0), g["blur_a_s1"], rtol=2e-6, atol=1e-4)
+    np.testing.assert_allclose(o.dt_gaussian_blur_3d(a, 2.5), g["blur_a_s2p5"], rtol=2e-6, atol=1e-4)
+    np.testing.assert_allclose(o.dt_gaussian_blur_3d(thin, 2.0), g["blur_thin_s2"], rtol=2e-6, atol=1e-4)
+    blur = o.dt_gaussian_blur_3d((a - a.min()) / (a.max() - a.min()), 2.0)
+    assert [o.dt_multiotsu_threshold(blur, c) for c in (0, 1)] == pytest.approx(g["otsu_blur_a"].tolist(), rel=1e-5)
+    mask = o.dt_binary_mask(a, sigma=2.0)
+    assert (mask != g["mask_a_s2"]).sum() <= 2            # voxels within 1e-7 of the threshold
+    np.testing.assert_allclose(o.dt_center_of_mass(g["mask_a_s2"]), g["com_mask_a_s2"], atol=1e-4)
+    np.testing.assert_allclose(o.dt_center_of_mass(np.zeros((3, 4, 5), bool)), g["com_empty"])
+    np.testing.assert_allclose(o.dt_roi_shift(a), g["roi_shift_a"], atol=2e-4)
+    np.testing.assert_allclose(o.dt_roi_shift(a, 50.0), g["roi_shift_a_p50"], atol=2e-4)
+    np.testing.assert_allclose(o.dt_roi_shift(b, 90.0, 1.5), g["roi_shift_b_p90_blur"], atol=1e-3)
+    np.testing.assert_allclose(o.dt_multiotsu_center_of_mass(a, b, 2.0, 0), g["motsu_shift_ab_s2"], atol=2e-2)
+    np.testing.assert_allclose(o.dt_multiotsu_center_of_mass(a, b, 2.0, 1), g["motsu_shift_ab_s2_c1"], atol=2e-2)

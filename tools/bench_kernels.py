@@ -56,6 +56,8 @@ def main():
 
     # ---- RL launches on the config-2 grid: separable (tuned) and dense
     oshape = tuple(int(v) for v in args.rl_grid.split(","))
+    if not args.only_rl:
+        _estimators(args, torch, dev, g, oshape)
     _rl(args, torch, dev, g, bench, RichardsonLucyPlan, oshape)
 
 
@@ -113,6 +115,24 @@ def _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_ge
                           "out": geo.output_shape, "ms": ms, "algorithmic_GBps": nbytes / ms / 1e6,
                           "frac_of_8TBps": nbytes / ms / 1e6 / 8000}))
         del raw, dst
+
+
+def _estimators(args, torch, dev, g, oshape):
+    """DynaTrack estimators on a deskewed-size volume."""
+    from shrimpy_amd import dynatrack as d
+
+    vol = torch.rand(oshape, device=dev, generator=g) * 900 + 100
+    n = vol.numel()
+    for name, fn, passes in (
+        ("_percentile (minmax + histogram)", lambda: d._percentile(vol, 90.0), 2),
+        ("_intensity_center_of_mass", lambda: d._intensity_center_of_mass(vol, 150.0), 1),
+        ("_gaussian_blur_3d sigma=2 (3 passes, 17 taps)", lambda: d._gaussian_blur_3d(vol, 2.0), 6),
+        ("_gaussian_blur_3d sigma=5 (3 passes, 41 taps)", lambda: d._gaussian_blur_3d(vol, 5.0), 6),
+        ("_multiotsu_center_of_mass sigma=2 (two volumes)", lambda: d._multiotsu_center_of_mass(vol, vol, 2.0), 20),
+    ):
+        ms = timed(fn, max(1, args.reps // 2))
+        print(json.dumps({"kernel": name, "grid": oshape, "ms": ms, "volume_traversals": passes,
+                          "traversal_GBps": passes * 4.0 * n / ms / 1e6}))
 
 
 def _rl(args, torch, dev, g, bench, RichardsonLucyPlan, oshape):
