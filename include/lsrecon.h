@@ -203,8 +203,9 @@ int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_fr
 /*
  * The same iterations with ONE launch each (rl_fused_sep.hip): ratio = y / (H x + eps) is formed
  * and consumed inside the workgroup, so an iteration moves 12 bytes per voxel through HBM instead
- * of 24. Results are bit-identical to lsr_rl_sep_f32. Compiled for PSFs up to 9 x 9 x 9 taps
- * (lsr_rl_sep_fused_supported: 1 / 0; larger: LSR_E_UNSUPPORTED, use lsr_rl_sep_f32).
+ * of 24. Results are bit-identical to lsr_rl_sep_f32. Compiled for every odd tap count up to 15 per
+ * axis except 15 z taps with 11+ in-plane taps (lsr_rl_sep_fused_supported: 1 / 0; otherwise
+ * LSR_E_UNSUPPORTED: use lsr_rl_sep_f32).
  *
  * `y` points at the logical (0,0,0) of a padded volume (lsr_sep_padded_shape geometry or larger
  * strides) whose halo is ZERO: the kernel reads y on the tile grown by the PSF radius.

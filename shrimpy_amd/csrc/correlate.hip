@@ -504,7 +504,7 @@ void plan_fused_split(int64_t tiles_xy, int64_t Z, int PZ, int* n_full, int* pie
 extern "C" int lsr_rl_sep_fused_supported(int pz, int py, int px) {
   if (pz < 1 || py < 1 || px < 1 || !(pz & 1) || !(py & 1) || !(px & 1)) return 0;
   const int PZ = lsr::sep_round_taps(pz), PYX = lsr::sep_round_taps(py > px ? py : px);
-  return PZ <= lsr::kFusedMaxPZ && PYX <= lsr::kFusedMaxPYX;
+  return lsr::fused_compiled(PZ, PYX) ? 1 : 0;
 }
 
 extern "C" int lsr_rl_sep_fused_taps_count(void) { return 6 * 16; }
@@ -517,8 +517,9 @@ extern "C" int lsr_rl_sep_fused_prepare_taps(const float* kz_host, int pz, const
   LSR_REQUIRE_PTR(taps_host);
   if (int rc = check_taps(pz, py, px)) return rc;
   LSR_REQUIRE(lsr_rl_sep_fused_supported(pz, py, px), LSR_E_UNSUPPORTED,
-              "the fused RL iteration is compiled for up to %d x %d x %d taps, got (%d,%d,%d)",
-              lsr::kFusedMaxPZ, lsr::kFusedMaxPYX, lsr::kFusedMaxPYX, pz, py, px);
+              "no fused RL specialisation for taps (%d,%d,%d) (up to %d x %d x %d, not 15 z taps with "
+              "11+ in-plane taps): use lsr_rl_sep_f32",
+              pz, py, px, lsr::kFusedMaxPZ, lsr::kFusedMaxPYX, lsr::kFusedMaxPYX);
   int PZ, PYX;
   sep_compiled_taps(pz, py, px, &PZ, &PYX);
   // rows: stage 1 (H = correlation with the flipped PSF) x, y, z; stage 2 (H^T, the PSF) x, y, z;
@@ -552,8 +553,9 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
   LSR_REQUIRE(x_a != x_b, LSR_E_ARG, "x_a and x_b must be distinct");
   if (int rc = check_taps(pz, py, px)) return rc;
   LSR_REQUIRE(lsr_rl_sep_fused_supported(pz, py, px), LSR_E_UNSUPPORTED,
-              "the fused RL iteration is compiled for up to %d x %d x %d taps, got (%d,%d,%d)",
-              lsr::kFusedMaxPZ, lsr::kFusedMaxPYX, lsr::kFusedMaxPYX, pz, py, px);
+              "no fused RL specialisation for taps (%d,%d,%d) (up to %d x %d x %d, not 15 z taps with "
+              "11+ in-plane taps): use lsr_rl_sep_f32",
+              pz, py, px, lsr::kFusedMaxPZ, lsr::kFusedMaxPYX, lsr::kFusedMaxPYX);
   int PZ, PYX;
   sep_compiled_taps(pz, py, px, &PZ, &PYX);
   int64_t ps[4];
@@ -576,7 +578,7 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
   p.taps = taps; p.eps = eps;
   p.nz = nz; p.ny = ny; p.nx = nx;
   p.tiles_x = static_cast<int>(lsr::ceil_div(X, lsr::kSepWideTileX));
-  p.tiles_y = static_cast<int>(lsr::ceil_div(Y, 8 * lsr::fused_run(PZ)));
+  p.tiles_y = static_cast<int>(lsr::ceil_div(Y, 8 * lsr::fused_run(PZ, PYX)));
   const int64_t tiles_xy = int64_t(p.tiles_x) * p.tiles_y;
   plan_fused_split(tiles_xy, Z, PZ, &p.n_full, &p.pieces, &p.z_chunk);
   const int64_t blocks64 = p.n_full + (tiles_xy - p.n_full) * p.pieces;
@@ -602,6 +604,9 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
       case 5: ok = lsr::launch_fused_pz5(PYX, p, blocks, s); break;
       case 7: ok = lsr::launch_fused_pz7(PYX, p, blocks, s); break;
       case 9: ok = lsr::launch_fused_pz9(PYX, p, blocks, s); break;
+      case 11: ok = lsr::launch_fused_pz11(PYX, p, blocks, s); break;
+      case 13: ok = lsr::launch_fused_pz13(PYX, p, blocks, s); break;
+      case 15: ok = lsr::launch_fused_pz15(PYX, p, blocks, s); break;
       default: break;
     }
     LSR_REQUIRE(ok, LSR_E_UNSUPPORTED, "no fused specialisation for taps (%d,%d,%d)", pz, py, px);

@@ -114,9 +114,20 @@ struct FusedArgs {
 };
 // columns staged left and right of a 128-column tile: twice the PSF radius, rounded up to 16 bytes
 constexpr int fused_window_halo(int PYX) { return 4 * ((2 * (PYX / 2) + 3) / 4); }
-// tile rows / 8 of the fused kernel
-constexpr int fused_run(int PZ) { return PZ <= 9 ? 4 : 3; }
-constexpr int kFusedMaxPZ = 9, kFusedMaxPYX = 9;
+// tile rows / 8 of the fused kernel: as large as the accumulators (PZ planes of both stencils, 256
+// VGPRs per thread) and the staged windows (160 KB of LDS) allow
+constexpr int fused_run(int PZ, int PYX) {
+  if (PZ >= 11 && PYX >= 11) return 2;
+  const int by_z = PZ <= 9 ? 4 : (PZ <= 11 ? 3 : 2);
+  const int by_yx = PYX <= 9 ? 4 : (PYX <= 11 ? 3 : 2);
+  return by_z < by_yx ? by_z : by_yx;
+}
+constexpr int kFusedMaxPZ = 15, kFusedMaxPYX = 15;
+// ... except 15 z taps with 11+ in-plane taps: the accumulators spill even on the smallest tile
+// (and a spill costs a full vmcnt drain per plane); those PSFs take the two-launch kernels
+constexpr bool fused_compiled(int PZ, int PYX) {
+  return PZ <= kFusedMaxPZ && PYX <= kFusedMaxPYX && !(PZ >= 15 && PYX >= 11);
+}
 
 inline int sep_wide_stage_cols(int PX) { return kSepWideTileX - 4 + 4 * ((4 + PX - 1 + 3) / 4); }
 
@@ -133,13 +144,16 @@ LSR_DECL_SEP(13)
 LSR_DECL_SEP(15)
 #undef LSR_DECL_SEP
 
-// rl_fused_sep.hip, compiled once per PZ (-DLSR_FUSED_PZ=n); pyx in {3,5,7,9}.
+// rl_fused_sep.hip, compiled once per PZ (-DLSR_FUSED_PZ=n); pyx in {3,...,15}.
 #define LSR_DECL_FUSED(n) \
   bool launch_fused_pz##n(int pyx, const FusedArgs& p, unsigned blocks, hipStream_t s);
 LSR_DECL_FUSED(3)
 LSR_DECL_FUSED(5)
 LSR_DECL_FUSED(7)
 LSR_DECL_FUSED(9)
+LSR_DECL_FUSED(11)
+LSR_DECL_FUSED(13)
+LSR_DECL_FUSED(15)
 #undef LSR_DECL_FUSED
 
 // correlate_dense.hip, compiled once per PZ (-DLSR_DENSE_PZ=n); pyx in {3,5,7,9}, PZ*pyx*pyx <= 900.

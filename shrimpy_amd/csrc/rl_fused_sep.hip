@@ -602,9 +602,13 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
 
 template <int PZ, int PYX>
 bool launch_one(const FusedArgs& p, dim3 grid, hipStream_t s) {
-  constexpr int RUN = lsr::fused_run(PZ);
-  hipLaunchKernelGGL((rl_fused_sep_kernel<PZ, PYX, RUN>), grid, dim3(kThreads), 0, s, p);
-  return true;
+  if constexpr (lsr::fused_compiled(PZ, PYX)) {
+    constexpr int RUN = lsr::fused_run(PZ, PYX);
+    hipLaunchKernelGGL((rl_fused_sep_kernel<PZ, PYX, RUN>), grid, dim3(kThreads), 0, s, p);
+    return true;
+  } else {
+    return false;
+  }
 }
 
 }  // namespace
@@ -621,6 +625,9 @@ bool LSR_CAT(launch_fused_pz, LSR_FUSED_PZ)(int pyx, const FusedArgs& p, unsigne
     case 5: return launch_one<PZ, 5>(p, grid, s);
     case 7: return launch_one<PZ, 7>(p, grid, s);
     case 9: return launch_one<PZ, 9>(p, grid, s);
+    case 11: return launch_one<PZ, 11>(p, grid, s);
+    case 13: return launch_one<PZ, 13>(p, grid, s);
+    case 15: return launch_one<PZ, 15>(p, grid, s);
     default: return false;
   }
 }

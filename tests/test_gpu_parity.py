@@ -328,7 +328,8 @@ def test_rl_20_iterations_vs_oracle(device, separable):
     assert float(x.min()) >= 0
 
 
-@pytest.mark.parametrize("pshape", [(9, 7, 7), (3, 3, 3), (5, 3, 9), (1, 1, 1), (9, 9, 9), (7, 5, 5), (9, 1, 7)])
+@pytest.mark.parametrize("pshape", [(9, 7, 7), (3, 3, 3), (5, 3, 9), (1, 1, 1), (9, 9, 9), (7, 5, 5), (9, 1, 7),
+                                    (11, 7, 13), (13, 15, 15), (15, 9, 3), (9, 11, 5), (3, 15, 11), (11, 11, 11)])
 @pytest.mark.parametrize("vshape", [(20, 40, 70), (3, 5, 4), (37, 70, 300), (11, 33, 129)])
 def test_rl_fused_equals_two_launch_bit_exact(device, pshape, vshape):
     """One launch per iteration (rl_fused_sep.hip) keeps the per-voxel arithmetic of the
@@ -356,16 +357,20 @@ def test_rl_fused_equals_two_launch_bit_exact(device, pshape, vshape):
     assert torch.equal(ypad.view, y)                     # y is read, never written
 
 
-def test_rl_fused_unsupported_taps_fall_back(device):
+def test_rl_fused_covers_every_separable_psf(device):
+    """Every odd tap count up to 15 per axis has a fused specialisation (smaller tiles for the
+    larger PSFs); the two-launch kernels stay as the cross-check (fused="never")."""
     from shrimpy_amd import _lib
     from shrimpy_amd.deconvolve import RichardsonLucyPlan
 
-    assert _lib.call_value("lsr_rl_sep_fused_supported", 9, 7, 7) == 1
-    assert _lib.call_value("lsr_rl_sep_fused_supported", 11, 7, 7) == 0
-    assert _lib.call_value("lsr_rl_sep_fused_supported", 9, 11, 3) == 0
+    for taps in ((9, 7, 7), (11, 7, 7), (9, 11, 3), (13, 15, 15), (15, 9, 9), (1, 1, 1)):
+        assert _lib.call_value("lsr_rl_sep_fused_supported", *taps) == 1
+    assert _lib.call_value("lsr_rl_sep_fused_supported", 15, 15, 15) == 0   # would spill: two-launch path
+    assert _lib.call_value("lsr_rl_sep_fused_supported", 17, 3, 3) == 0
+    assert _lib.call_value("lsr_rl_sep_fused_supported", 4, 3, 3) == 0
     psf, factors = o.gaussian_psf((11, 7, 13), (2.0, 1.2, 2.5))
     plan = RichardsonLucyPlan((16, 30, 50), None, device, psf_factors=factors)
-    assert plan.separable and not plan.fused
+    assert plan.separable and plan.fused
     y = o.bead_scene((16, 30, 50), seed=5, psf=psf, density=1e-3)
     _close(plan(_t(y, device), iterations=3).cpu().numpy(), o.richardson_lucy(y, psf, 3), 5e-5, 2e-5)
 
