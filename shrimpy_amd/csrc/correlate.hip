@@ -659,7 +659,7 @@ extern "C" int lsr_dense_taps_count(int pz, int py, int px) {
               "the tuned dense kernel covers pz <= 11 and py, px <= 9 (got %d,%d,%d): use "
               "lsr_correlate_dense_f32",
               pz, py, px);
-  return PZ * PYX * PYX;
+  return 2 * PZ * PYX * PYX;  // every tap twice: {w, w} pairs for the packed FMAs
 }
 
 extern "C" int lsr_dense_prepare_taps(const float* psf_host, int pz, int py, int px, int flip,
@@ -679,7 +679,8 @@ extern "C" int lsr_dense_prepare_taps(const float* psf_host, int pz, int py, int
         const float v = flip ? psf_host[((pz - 1 - a) * py + (py - 1 - b)) * px + (px - 1 - c)]
                              : psf_host[(a * py + b) * px + c];
         const int A = a + oz, B = b + oy, C = c + ox;
-        taps_host[(C * PYX + B) * PZ + (PZ - 1 - A)] = v;  // [c][b][j], j = PZ-1-a
+        const int t = (C * PYX + B) * PZ + (PZ - 1 - A);  // [c][b][j], j = PZ-1-a
+        taps_host[2 * t] = taps_host[2 * t + 1] = v;
       }
   return LSR_OK;
 }

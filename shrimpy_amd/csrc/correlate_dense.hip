@@ -51,10 +51,19 @@ struct Tile {
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float fast_rcp(float d) {
   float r = __builtin_amdgcn_rcpf(d);
   return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+// A wave-uniform pointer the register allocator must keep in SGPRs (under SGPR pressure hipcc
+// otherwise hands the "s" operand of the asm loads a VGPR pair, which does not assemble).
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+  return reinterpret_cast<const float*>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 __device__ __forceinline__ void gload_x4(f32x4& dst, const float* sbase, int voff_bytes) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
@@ -165,11 +174,13 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
   typedef const float __attribute__((address_space(4))) cfloat;  // constant AS: scalar loads
   const cfloat* const taps_base = (const cfloat*)p.taps;
 
-  float acc[PZ][kRun];
+  // pending output planes as packed pairs (rows 2q, 2q+1 of the thread's column): v_pk_fma_f32
+  static_assert(kRun % 2 == 0, "rows are paired");
+  f32x2 acc[PZ][kRun / 2];
 #pragma unroll
   for (int j = 0; j < PZ; ++j)
 #pragma unroll
-    for (int m = 0; m < kRun; ++m) acc[j][m] = 0.0f;
+    for (int q = 0; q < kRun / 2; ++q) acc[j][q] = f32x2{0.0f, 0.0f};
   float aux0[kRun], aux1[kRun];
 #pragma unroll
   for (int m = 0; m < kRun; ++m) aux0[m] = aux1[m] = 0.0f;
@@ -178,13 +189,13 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
   const int zi_end = ze + cz;
 
   auto fetch = [&](int zplane, f32x4 (&st)[T::SL]) {
-    const float* src = in_tile + static_cast<int64_t>(min(max(zplane, 0), Z - 1)) * p.in_plane;
+    const float* src = uniform_ptr(in_tile + static_cast<int64_t>(min(max(zplane, 0), Z - 1)) * p.in_plane);
     gload_x4(st[0], src, s_voff[0]);
     gload_x4(st[1], src, s_voff[1]);
   };
   auto fetch_aux = [&](int zout, float (&aux)[kRun]) {
     if constexpr (EPI != LSR_EPI_NONE) {
-      const float* a = p.aux + static_cast<int64_t>(min(max(zout, 0), Z - 1)) * p.aux_plane;
+      const float* a = uniform_ptr(p.aux + static_cast<int64_t>(min(max(zout, 0), Z - 1)) * p.aux_plane);
 #pragma unroll
       for (int m = 0; m < kRun; ++m) gload_x1(aux[m], a, a_voff[m]);
     }
@@ -205,21 +216,20 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
 
     const int zcur = zi + 1;
     if (zcur >= zi_begin && zcur < zi_end) {  // wave-uniform
-      // pending planes move up by one: acc[j] <-> z_out = zcur - cz + j
-#pragma unroll
-      for (int j = 0; j < PZ - 1; ++j)
-#pragma unroll
-        for (int m = 0; m < kRun; ++m) acc[j][m] = acc[j + 1][m];
-#pragma unroll
-      for (int m = 0; m < kRun; ++m) acc[PZ - 1][m] = 0.0f;
-
+      // Pending planes move up by one (acc[j] <-> z_out = zcur - cz + j) -- folded into the first
+      // tap group's FMAs (acc[j] = w * v + acc[j+1], ascending j), so no register moves.
       if (zcur < Z) {
         int opaque = 0;
         asm volatile("" : "+s"(opaque));  // loop-variant for the optimiser, always 0
         const cfloat* taps = taps_base + opaque;
-        float wq[2][PZ];
+        // every tap is stored twice: an aligned SGPR pair {w, w} is the packed FMA's scalar
+        // operand as it is (no s_mov to realign odd taps)
+        // two SGPR sets (the next group's taps load while this group's FMAs issue) while 2 * 2 * PZ
+        // scalars fit; one set from 11 z taps up
+        constexpr int NBUF = PZ <= 9 ? 2 : 1;
+        f32x2 wq[NBUF][PZ];
 #pragma unroll
-        for (int j = 0; j < PZ; ++j) wq[0][j] = taps[j];
+        for (int j = 0; j < PZ; ++j) wq[0][j] = f32x2{taps[2 * j], taps[2 * j + 1]};
 #pragma unroll
         for (int c = 0; c < PYX; ++c) {
           float cv[kRun + PYX - 1];
@@ -229,27 +239,48 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
           for (int b = 0; b < PYX; ++b) {
             constexpr int G = PYX * PYX;
             const int g = c * PYX + b;
-            // taps of the NEXT (b, c) group -> the other SGPR set
-            if (g + 1 < G) {
+            if constexpr (NBUF == 2) {  // taps of the NEXT (b, c) group -> the other SGPR set
+              if (g + 1 < G) {
 #pragma unroll
-              for (int j = 0; j < PZ; ++j) wq[(g + 1) & 1][j] = taps[(g + 1) * PZ + j];
+                for (int j = 0; j < PZ; ++j)
+                  wq[(g + 1) & 1][j] = f32x2{taps[2 * ((g + 1) * PZ + j)], taps[2 * ((g + 1) * PZ + j) + 1]};
+              }
+            } else if (g > 0) {
+#pragma unroll
+              for (int j = 0; j < PZ; ++j) wq[0][j] = f32x2{taps[2 * (g * PZ + j)], taps[2 * (g * PZ + j) + 1]};
             }
 #pragma unroll
-            for (int j = 0; j < PZ; ++j)
+            for (int q = 0; q < kRun / 2; ++q) {
+              const f32x2 v = f32x2{cv[2 * q + b], cv[2 * q + 1 + b]};
+              if (g == 0) {
 #pragma unroll
-              for (int m = 0; m < kRun; ++m) acc[j][m] = fmaf(wq[g & 1][j], cv[m + b], acc[j][m]);
+                for (int j = 0; j < PZ - 1; ++j) acc[j][q] = __builtin_elementwise_fma(wq[0][j], v, acc[j + 1][q]);
+                acc[PZ - 1][q] = wq[0][PZ - 1] * v;
+              } else {
+#pragma unroll
+                for (int j = 0; j < PZ; ++j) acc[j][q] = __builtin_elementwise_fma(wq[g & (NBUF - 1)][j], v, acc[j][q]);
+              }
+            }
           }
         }
+      } else {  // a plane past the volume contributes nothing: shift only
+#pragma unroll
+        for (int j = 0; j < PZ - 1; ++j)
+#pragma unroll
+          for (int q = 0; q < kRun / 2; ++q) acc[j][q] = acc[j + 1][q];
+#pragma unroll
+        for (int q = 0; q < kRun / 2; ++q) acc[PZ - 1][q] = f32x2{0.0f, 0.0f};
       }
 
       const int z_out = zcur - cz;
+      auto acc0 = [&](int m) { return (m & 1) ? acc[0][m >> 1].y : acc[0][m >> 1].x; };
       if (z_out >= zb) {  // wave-uniform
         float* o = p.out + static_cast<int64_t>(z_out) * p.out_plane;
         if constexpr (EPI != LSR_EPI_NONE) wait_loads<2 + NA>(aux_use);
         if constexpr (EPI == LSR_EPI_RATIO) {
 #pragma unroll
           for (int m = 0; m < kRun; ++m)
-            if (ok[m]) o[o_off[m]] = aux_use[m] * fast_rcp(acc[0][m] + p.eps);
+            if (ok[m]) o[o_off[m]] = aux_use[m] * fast_rcp(acc0(m) + p.eps);
         } else if constexpr (EPI == LSR_EPI_UPDATE) {
           const int rz = p.pz / 2;
           const bool z_inside = z_out >= rz && z_out < Z - rz;
@@ -258,13 +289,13 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
             if (ok[m]) {
               const float nrm = (z_inside && yx_inside[m]) ? p.norm_full
                                                            : dense_norm(p, z_out, gy_out0 + m, gx_out);
-              o[o_off[m]] = aux_use[m] * acc[0][m] * fast_rcp(nrm);
+              o[o_off[m]] = aux_use[m] * acc0(m) * fast_rcp(nrm);
             }
           }
         } else {
 #pragma unroll
           for (int m = 0; m < kRun; ++m)
-            if (ok[m]) o[o_off[m]] = acc[0][m];
+            if (ok[m]) o[o_off[m]] = acc0(m);
         }
       }
     }
