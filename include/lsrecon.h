@@ -285,6 +285,18 @@ int lsr_mask_centroid_f32(const float* in, int64_t Z, int64_t Y, int64_t X, floa
                           double* out4, void* scratch, lsr_stream_t stream);
 int lsr_blur_reflect_f32(const float* in, float* out, int64_t Z, int64_t Y, int64_t X, int axis,
                          const float* taps, int radius, float sub, float div, lsr_stream_t stream);
+/*
+ * Element-wise steps of _phase_cross_corr (:266-378); the FFTs between them are library calls.
+ *   lsr_match_shape_f32       _match_shape: per axis reflect-pad (left = d / 2) or centre-crop to the FFT shape
+ *   lsr_cross_power_c64       a <- a * conj(b) over n complex64 values (interleaved re, im)
+ *   lsr_peak_abs_shifted_f32  argmax(fftshift(|in|)) as a flat index into the SHIFTED (Z, Y, X) array,
+ *                             first maximum in that order (torch.argmax), without writing either
+ */
+int lsr_match_shape_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
+                        int64_t Yo, int64_t Xo, lsr_stream_t stream);
+int lsr_cross_power_c64(float* a, const float* b, int64_t n, lsr_stream_t stream);
+int lsr_peak_abs_shifted_f32(const float* in, int64_t Z, int64_t Y, int64_t X, long long* out_index,
+                             void* scratch, lsr_stream_t stream);
 
 #ifdef __cplusplus
 }

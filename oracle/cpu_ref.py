@@ -385,3 +385,36 @@ def dt_multiotsu_center_of_mass(ref_img, mov_img, sigma=5.0, otsu_component=0):
     """``_multiotsu_center_of_mass`` (``tracking.py:759-787``)."""
     return (dt_center_of_mass(dt_binary_mask(mov_img, sigma, otsu_component))
             - dt_center_of_mass(dt_binary_mask(ref_img, sigma, otsu_component)))
+
+
+def dt_next_fast_len(n):
+    """``_next_fast_len`` (``tracking.py:248-263``)."""
+    n = max(int(n), 1)
+    while True:
+        m = n
+        for p in (2, 3, 5):
+            while m % p == 0:
+                m //= p
+        if m == 1:
+            return n
+        n += 1
+
+
+def dt_match_shape(t, shape):
+    """``_match_shape`` (``tracking.py:266-306``): reflect-pad (left = d // 2), then centre-crop."""
+    t = np.asarray(t, np.float32)
+    pad = [((max(s - a, 0)) // 2, max(s - a, 0) - max(s - a, 0) // 2) for s, a in zip(shape, t.shape)]
+    t = np.pad(t, pad, mode="reflect")
+    sl = tuple(slice((a - s) // 2, (a - s) // 2 + s) for s, a in zip(shape, t.shape))
+    return t[sl]
+
+
+def dt_phase_cross_corr(ref, mov, maximum_shift=1.0):
+    """``_phase_cross_corr`` (``tracking.py:309-378``)."""
+    ref, mov = np.asarray(ref, np.float32), np.asarray(mov, np.float32)
+    shape = tuple(dt_next_fast_len(int(max(a, b) * maximum_shift)) for a, b in zip(ref.shape, mov.shape))
+    f1 = np.fft.rfftn(dt_match_shape(ref, shape))
+    f2 = np.fft.rfftn(dt_match_shape(mov, shape))
+    corr = np.fft.fftshift(np.abs(np.fft.irfftn(f1 * np.conj(f2), s=shape, axes=(0, 1, 2))))
+    peak = np.unravel_index(int(np.argmax(corr)), corr.shape)
+    return tuple(int(s // 2) - int(p) for s, p in zip(corr.shape, peak))

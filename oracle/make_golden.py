@@ -159,6 +159,22 @@ def capture_dynatrack_fixtures():
     out["com_empty"] = t._center_of_mass(torch.zeros(3, 4, 5, dtype=torch.bool)).numpy()
     out["motsu_shift_ab_s2"] = np.array(t._multiotsu_center_of_mass(ta, tb, sigma=2.0, otsu_component=0))
     out["motsu_shift_ab_s2_c1"] = np.array(t._multiotsu_center_of_mass(ta, tb, sigma=2.0, otsu_component=1))
+    # phase cross-correlation (tracking.py:309-378): known rolls, the reference's own test input
+    # (tests/test_dynatrack.py:102-111: rng(42).random((8,32,32)) rolled by (1,2,-3)), odd shapes
+    pcc_ref = np.random.default_rng(42).random((8, 32, 32)).astype(np.float32)
+    pcc_mov = np.roll(pcc_ref, (1, 2, -3), axis=(0, 1, 2))
+    out["pcc_ref"], out["pcc_mov"] = pcc_ref, pcc_mov
+    out["pcc_shift"] = np.array(t._phase_cross_corr(torch.as_tensor(pcc_ref), torch.as_tensor(pcc_mov)))
+    out["pcc_shift_ab"] = np.array(t._phase_cross_corr(ta, tb))
+    odd = dynatrack_scene(14, shape=(7, 33, 49))
+    odd_mov = np.roll(odd, (-2, 5, 7), axis=(0, 1, 2))
+    out["pcc_odd"], out["pcc_odd_mov"] = odd, odd_mov
+    out["pcc_shift_odd"] = np.array(t._phase_cross_corr(torch.as_tensor(odd), torch.as_tensor(odd_mov)))
+    out["pcc_shift_odd_half"] = np.array(t._phase_cross_corr(torch.as_tensor(odd), torch.as_tensor(odd_mov), 0.5))
+    out["match_shape_odd_pad"] = t._match_shape(torch.as_tensor(odd), (8, 36, 50)).numpy()
+    out["match_shape_odd_mixed"] = t._match_shape(torch.as_tensor(odd), (4, 36, 25)).numpy()
+    out["roi_pcc_b"] = np.array(t._roi_center_pcc(tb, blob_sigma=4.0))
+    out["motsu_pcc_ab"] = np.array(t._multiotsu_pcc(ta, tb, sigma=2.0))
     np.savez_compressed(GOLD / "ref_dynatrack.npz", **out)
     print("captured ref_dynatrack.npz from", ref)
 

@@ -6,6 +6,8 @@
 //   lsr_weighted_centroid_f32  _intensity_center_of_mass                 (:596-649)
 //   lsr_mask_centroid_f32      _center_of_mass(img > threshold)          (:545-569, :540)
 //   lsr_blur_reflect_f32       one axis of _gaussian_blur_3d             (:386-422; F.pad reflect + conv3d)
+//   lsr_match_shape_f32, lsr_cross_power_c64, lsr_peak_abs_shifted_f32
+//                              the element-wise steps of _phase_cross_corr (:266-378)
 //
 // All of them stream the volume once at HBM speed; the sums are accumulated in fp64 and reduced in a
 // fixed order (two launches, no float atomics), so results do not depend on scheduling.
@@ -272,6 +274,100 @@ __global__ __launch_bounds__(kThreads) void blur_contiguous_kernel(BlurArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------- phase cross-correlation
+// The element-wise steps around the two FFTs of _phase_cross_corr (tracking.py:309-378); the FFTs
+// themselves are library calls (rocFFT through torch.fft, like a plain library GEMM).
+
+// _match_shape (:266-306): per axis, pad to the FFT length with F.pad "reflect" (left = d // 2) or
+// crop the centre (start = d // 2).
+struct MatchArgs {
+  const float* in;
+  float* out;
+  int Zi, Yi, Xi, Zo, Yo, Xo;
+};
+__device__ __forceinline__ int match_index(int o, int ni, int no) {
+  if (no > ni) return reflect(o - (no - ni) / 2, ni);
+  return o + (ni - no) / 2;
+}
+__global__ __launch_bounds__(kThreads) void match_shape_kernel(MatchArgs p) {
+  const int64_t rows = static_cast<int64_t>(p.Zo) * p.Yo;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int zo = static_cast<int>(r / p.Yo), yo = static_cast<int>(r - static_cast<int64_t>(zo) * p.Yo);
+    const float* src = p.in + (static_cast<int64_t>(match_index(zo, p.Zi, p.Zo)) * p.Yi + match_index(yo, p.Yi, p.Yo)) * p.Xi;
+    float* dst = p.out + r * p.Xo;
+    for (int xo = threadIdx.x; xo < p.Xo; xo += kThreads) dst[xo] = src[match_index(xo, p.Xi, p.Xo)];
+  }
+}
+
+// prod = f1 * conj(f2), in place in f1 (complex64 as float pairs)
+__global__ __launch_bounds__(kThreads) void cross_power_kernel(float* __restrict__ a, const float* __restrict__ b,
+                                                               int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+    const float ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
+    // (ar + i ai)(br - i bi), the products and sums torch's complex multiply performs
+    a[2 * i] = ar * br + ai * bi;
+    a[2 * i + 1] = ai * br - ar * bi;
+  }
+}
+
+// argmax(fftshift(|corr|)) without materialising either: the largest |v|, ties resolved by the
+// smallest flat index in fftshift order (torch.argmax returns the first maximum).
+struct PeakArgs {
+  const float* in;
+  int Z, Y, X;
+  float* pval;                   // partial maxima
+  unsigned long long* pidx;      // their shifted flat indices
+};
+__device__ __forceinline__ void peak_merge(float& v, unsigned long long& i, float v2, unsigned long long i2) {
+  if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+}
+__global__ __launch_bounds__(kThreads) void peak_partial_kernel(PeakArgs p) {
+  __shared__ float s_v[kThreads];
+  __shared__ unsigned long long s_i[kThreads];
+  float best = -1.0f;
+  unsigned long long best_i = ~0ull;
+  const int64_t rows = static_cast<int64_t>(p.Z) * p.Y;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int z = static_cast<int>(r / p.Y), y = static_cast<int>(r - static_cast<int64_t>(z) * p.Y);
+    const int zs = (z + p.Z / 2) % p.Z, ys = (y + p.Y / 2) % p.Y;   // fftshift: index i -> (i + n/2) % n
+    const float* row = p.in + r * p.X;
+    const unsigned long long base = (static_cast<unsigned long long>(zs) * p.Y + ys) * p.X;
+    for (int x = threadIdx.x; x < p.X; x += kThreads) {
+      const float v = fabsf(row[x]);
+      peak_merge(best, best_i, v, base + static_cast<unsigned>((x + p.X / 2) % p.X));
+    }
+  }
+  s_v[threadIdx.x] = best;
+  s_i[threadIdx.x] = best_i;
+  __syncthreads();
+  for (int w = kThreads / 2; w > 0; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w) peak_merge(s_v[threadIdx.x], s_i[threadIdx.x], s_v[threadIdx.x + w], s_i[threadIdx.x + w]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    p.pval[blockIdx.x] = s_v[0];
+    p.pidx[blockIdx.x] = s_i[0];
+  }
+}
+__global__ __launch_bounds__(kThreads) void peak_final_kernel(const float* __restrict__ pval,
+                                                              const unsigned long long* __restrict__ pidx, int nb,
+                                                              long long* __restrict__ out) {
+  __shared__ float s_v[kThreads];
+  __shared__ unsigned long long s_i[kThreads];
+  float best = -1.0f;
+  unsigned long long best_i = ~0ull;
+  for (int i = threadIdx.x; i < nb; i += kThreads) peak_merge(best, best_i, pval[i], pidx[i]);
+  s_v[threadIdx.x] = best;
+  s_i[threadIdx.x] = best_i;
+  __syncthreads();
+  for (int w = kThreads / 2; w > 0; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w) peak_merge(s_v[threadIdx.x], s_i[threadIdx.x], s_v[threadIdx.x + w], s_i[threadIdx.x + w]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = static_cast<long long>(s_i[0]);
+}
+
 int check_volume(const float* in, int64_t Z, int64_t Y, int64_t X) {
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
@@ -379,4 +475,47 @@ extern "C" int lsr_blur_reflect_f32(const float* in, float* out, int64_t Z, int6
                        sizeof(float) * (kSeg + 2 * radius) * 64, s, p);
   }
   return lsr::launch_status("lsr_blur_reflect_f32");
+}
+
+extern "C" int lsr_match_shape_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
+                                   int64_t Yo, int64_t Xo, lsr_stream_t stream) {
+  if (int rc = check_volume(in, Zi, Yi, Xi)) return rc;
+  if (int rc = check_volume(out, Zo, Yo, Xo)) return rc;
+  LSR_REQUIRE(in != out, LSR_E_ARG, "out must not alias in");
+  const int64_t si[3] = {Zi, Yi, Xi}, so[3] = {Zo, Yo, Xo};
+  for (int a = 0; a < 3; ++a)
+    LSR_REQUIRE(so[a] <= si[a] || (so[a] - si[a] + 1) / 2 < si[a], LSR_E_ARG,
+                "axis %d: reflect padding %lld -> %lld needs a pad smaller than the axis", a,
+                (long long)si[a], (long long)so[a]);
+  MatchArgs p{in, out, static_cast<int>(Zi), static_cast<int>(Yi), static_cast<int>(Xi), static_cast<int>(Zo),
+              static_cast<int>(Yo), static_cast<int>(Xo)};
+  const int64_t rows = Zo * Yo;
+  hipLaunchKernelGGL(match_shape_kernel, dim3(static_cast<unsigned>(rows < 65536 ? rows : 65536)), dim3(kThreads), 0,
+                     lsr::as_stream(stream), p);
+  return lsr::launch_status("lsr_match_shape_f32");
+}
+
+extern "C" int lsr_cross_power_c64(float* a, const float* b, int64_t n, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(a);
+  LSR_REQUIRE_PTR(b);
+  LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  hipLaunchKernelGGL(cross_power_kernel, dim3(grid_for(n) * 4), dim3(kThreads), 0, lsr::as_stream(stream), a, b, n);
+  return lsr::launch_status("lsr_cross_power_c64");
+}
+
+extern "C" int lsr_peak_abs_shifted_f32(const float* in, int64_t Z, int64_t Y, int64_t X, long long* out_index,
+                                        void* scratch, lsr_stream_t stream) {
+  if (int rc = check_volume(in, Z, Y, X)) return rc;
+  LSR_REQUIRE_PTR(out_index);
+  LSR_REQUIRE_PTR(scratch);
+  const int64_t rows = Z * Y;
+  const int nb = static_cast<int>(rows < kBlocks ? rows : kBlocks);
+  PeakArgs p;
+  p.in = in; p.Z = static_cast<int>(Z); p.Y = static_cast<int>(Y); p.X = static_cast<int>(X);
+  p.pidx = static_cast<unsigned long long*>(scratch);                       // kBlocks * 8 bytes
+  p.pval = reinterpret_cast<float*>(static_cast<char*>(scratch) + sizeof(unsigned long long) * kBlocks);
+  hipStream_t s = lsr::as_stream(stream);
+  hipLaunchKernelGGL(peak_partial_kernel, dim3(nb), dim3(kThreads), 0, s, p);
+  hipLaunchKernelGGL(peak_final_kernel, dim3(1), dim3(kThreads), 0, s, p.pval, p.pidx, nb, out_index);
+  return lsr::launch_status("lsr_peak_abs_shifted_f32");
 }

@@ -1,11 +1,11 @@
 """DynaTrack shift estimators on the deskewed volume, on MI355X.
 
 Mirrors the private estimator functions of the reference's ``shrimpy/dynatrack/tracking.py`` --
-same names, arguments, return types and corner-case behaviour -- for the estimators that need no
-FFT.  The arithmetic runs as HIP kernels (``csrc/estimators.hip``: min / max, ``torch.histc``-exact
+same names, arguments, return types and corner-case behaviour.  The arithmetic runs as HIP kernels (``csrc/estimators.hip``: min / max, ``torch.histc``-exact
 histograms, fp64 centroid sums, LDS-tiled reflect-padded Gaussian passes); the 256-bin searches
 (percentile, multi-Otsu) are a few hundred flops of host logic on the histogram, like the
-reference's own ``float(...)`` / ``int(...)`` round trips.
+reference's own ``float(...)`` / ``int(...)`` round trips; the three FFTs of the phase
+cross-correlation are rocFFT library calls through ``torch.fft``.
 
 =========================================  =====================================  ==========
 reference (``tracking.py``)                here                                   kernels
@@ -18,7 +18,9 @@ reference (``tracking.py``)                here                                 
 ``_intensity_center_of_mass`` ``:596-649`` :func:`_intensity_center_of_mass`      weighted centroid
 ``..._to_roi_center`` ``:652-707``         same name                              the above
 ``_multiotsu_center_of_mass`` ``:759-787`` same name                              the above
-``_phase_cross_corr`` and the ``*_pcc``    raise ``NotImplementedError``          (FFT: not in this package)
+``_match_shape`` ``:266-306``              :func:`_match_shape`                   match shape
+``_phase_cross_corr`` ``:309-378``         :func:`_phase_cross_corr`              match shape, cross power, peak (+ rocFFT)
+``_roi_center_pcc`` / ``_multiotsu_pcc``   same names                             the above
 =========================================  =====================================  ==========
 
 ``_binary_mask`` / ``_center_of_mass`` never materialise the boolean mask unless asked to: the
@@ -39,7 +41,8 @@ logger = logging.getLogger(__name__)
 __all__ = [
     "_gaussian_blur_3d", "_multiotsu_threshold", "_binary_mask", "_center_of_mass", "_percentile",
     "_intensity_center_of_mass", "_intensity_center_of_mass_to_roi_center", "_multiotsu_center_of_mass",
-    "_phase_cross_corr",
+    "_next_fast_len", "_match_shape", "_phase_cross_corr", "_centered_gaussian_blob", "_roi_center_pcc",
+    "_multiotsu_pcc",
 ]
 
 
@@ -268,9 +271,93 @@ def _multiotsu_center_of_mass(ref_img, mov_img, sigma: float = 5.0, otsu_compone
     return tuple(float(s) for s in shift)
 
 
-def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0):
-    """FFT phase cross-correlation (``tracking.py:309-378``) is not part of this package."""
-    raise NotImplementedError(
-        "phase cross-correlation needs a 3-D FFT, which this package does not implement; "
-        "use the reference's torch.fft path for tracking_method 'pcc' / '*_pcc'"
-    )
+def _next_fast_len(n: int) -> int:
+    """Smallest 5-smooth integer >= n (``tracking.py:248-263``)."""
+    if n <= 1:
+        return 1
+    while True:
+        m = n
+        for p in (2, 3, 5):
+            while m % p == 0:
+                m //= p
+        if m == 1:
+            return n
+        n += 1
+
+
+def _match_shape(t, shape):
+    """Reflect-pad or centre-crop ``t`` to ``shape``, per axis (``tracking.py:266-306``)."""
+    import torch
+
+    vol = _volume(t, "t")
+    shape = tuple(int(v) for v in shape)
+    if tuple(vol.shape) == shape:
+        return vol
+    out = torch.empty(shape, dtype=torch.float32, device=vol.device)
+    with torch.cuda.device(vol.device):
+        _lib.call("lsr_match_shape_f32", vol.data_ptr(), *(int(v) for v in vol.shape), out.data_ptr(), *shape,
+                  _lib.stream_ptr(vol.device))
+    return out
+
+
+def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0) -> tuple[int, ...]:
+    """FFT phase cross-correlation, pixel shifts in ZYX order (``tracking.py:309-378``).
+
+    The two forward FFTs and the inverse one are rocFFT library calls (through ``torch.fft``); the
+    steps around them -- shape matching, ``f1 * conj(f2)``, ``argmax(fftshift(|corr|))`` -- are HIP
+    kernels that write nothing but their result.
+    """
+    import torch
+
+    ref_t, mov_t = _volume(ref_img, "ref_img"), _volume(mov_img, "mov_img")
+    if ref_t.dim() != 3 or mov_t.dim() != 3:
+        raise ValueError("phase cross-correlation is implemented for (Z, Y, X) volumes")
+    shape = tuple(_next_fast_len(int(max(s1, s2) * maximum_shift)) for s1, s2 in zip(ref_t.shape, mov_t.shape))
+    logger.debug("phase cross corr: fft shape %s for arrays %s and %s (max_shift=%.2f)", shape,
+                 tuple(ref_t.shape), tuple(mov_t.shape), maximum_shift)
+    fimg1 = torch.fft.rfftn(_match_shape(ref_t, shape))
+    fimg2 = torch.fft.rfftn(_match_shape(mov_t, shape))
+    with torch.cuda.device(fimg1.device):
+        stream = _lib.stream_ptr(fimg1.device)
+        _lib.call("lsr_cross_power_c64", fimg1.data_ptr(), fimg2.data_ptr(), fimg1.numel(), stream)
+        del fimg2
+        corr = torch.fft.irfftn(fimg1, s=shape).contiguous()
+        del fimg1
+        peak_index = torch.empty((1,), dtype=torch.int64, device=corr.device)
+        _lib.call("lsr_peak_abs_shifted_f32", corr.data_ptr(), *shape, peak_index.data_ptr(),
+                  _scratch(corr.device).data_ptr(), stream)
+    peak = np.unravel_index(int(peak_index.item()), shape)
+    result = tuple(int(s // 2) - int(p) for s, p in zip(shape, peak))
+    logger.debug("phase cross corr: peak at %s (device=%s)", result, corr.device)
+    return result
+
+
+def _centered_gaussian_blob(shape, sigma: float, device):
+    """Separable Gaussian blob centred on the geometric centre (``tracking.py:710-732``)."""
+    import torch
+
+    axes_1d = []
+    for n in shape:
+        idx = torch.arange(n, device=device, dtype=torch.float32)
+        axes_1d.append(torch.exp(-0.5 * ((idx - (n - 1) / 2.0) / sigma) ** 2))
+    blob = axes_1d[0]
+    for g in axes_1d[1:]:
+        blob = blob.unsqueeze(-1) * g
+    return blob
+
+
+def _roi_center_pcc(current_img, blob_sigma: float = 10.0, maximum_shift: float = 1.0) -> tuple[int, ...]:
+    """Shift of the bright structure from the ROI centre: PCC against a centred blob (``:735-756``)."""
+    img = _volume(current_img, "current_img")
+    blob = _centered_gaussian_blob(tuple(img.shape), blob_sigma, img.device)
+    return _phase_cross_corr(blob, img, maximum_shift)
+
+
+def _multiotsu_pcc(ref_img, mov_img, sigma: float = 5.0, otsu_component: int = 0,
+                   maximum_shift: float = 1.0) -> tuple[int, ...]:
+    """PCC on the multi-Otsu masks of two volumes (``tracking.py:790-815``)."""
+    import torch
+
+    ref_mask = _binary_mask(ref_img, sigma=sigma, otsu_component=otsu_component).to(dtype=torch.float32)
+    mov_mask = _binary_mask(mov_img, sigma=sigma, otsu_component=otsu_component).to(dtype=torch.float32)
+    return _phase_cross_corr(ref_mask, mov_mask, maximum_shift)

@@ -104,8 +104,35 @@ def test_multiotsu_mask_and_centroid_match_the_reference(device, golden):
                                golden["motsu_shift_ab_s2_c1"], atol=2e-2)
     flat = torch.full((4, 6, 8), 3.0, device=device)
     assert not bool(d._binary_mask(flat).any())
-    with pytest.raises(NotImplementedError):
-        d._phase_cross_corr(a, b)
+
+
+def test_phase_cross_correlation_matches_the_reference(device, golden):
+    """Shifts are integers: equality with what the reference returned (its own test case
+    rng(42) rolled by (1, 2, -3) included), odd shapes, a cropping maximum_shift, and the two
+    methods built on it."""
+    from shrimpy_amd import dynatrack as d
+
+    g = golden
+    a, b = _t(g["a"], device), _t(g["b"], device)
+    assert d._phase_cross_corr(_t(g["pcc_ref"], device), _t(g["pcc_mov"], device)) == (1, 2, -3)
+    assert d._phase_cross_corr(a, b) == tuple(g["pcc_shift_ab"])
+    odd, odd_mov = _t(g["pcc_odd"], device), _t(g["pcc_odd_mov"], device)
+    assert d._phase_cross_corr(odd, odd_mov) == tuple(g["pcc_shift_odd"])
+    assert d._phase_cross_corr(odd, odd_mov, 0.5) == tuple(g["pcc_shift_odd_half"])
+    np.testing.assert_array_equal(d._match_shape(odd, (8, 36, 50)).cpu().numpy(), g["match_shape_odd_pad"])
+    np.testing.assert_array_equal(d._match_shape(odd, (4, 36, 25)).cpu().numpy(), g["match_shape_odd_mixed"])
+    assert d._roi_center_pcc(b, blob_sigma=4.0) == tuple(g["roi_pcc_b"])
+    assert d._multiotsu_pcc(a, b, sigma=2.0) == tuple(g["motsu_pcc_ab"])
+    assert [d._next_fast_len(n) for n in (1, 7, 11, 49, 171, 2270)] == [o.dt_next_fast_len(n) for n in (1, 7, 11, 49, 171, 2270)]
+
+
+def test_phase_cross_correlation_on_a_larger_volume(device):
+    from oracle.make_golden import dynatrack_scene
+    from shrimpy_amd import dynatrack as d
+
+    ref = dynatrack_scene(5, shape=(40, 130, 300))
+    mov = np.roll(ref, (3, -11, 25), axis=(0, 1, 2))
+    assert d._phase_cross_corr(_t(ref, device), _t(mov, device)) == o.dt_phase_cross_corr(ref, mov) == (3, -11, 25)
 
 
 @pytest.mark.parametrize("shape,sigma", [((40, 130, 300), 5.0), ((7, 300, 65), 3.0), ((171, 96, 257), 1.0)])

@@ -193,3 +193,13 @@ def test_dynatrack_oracle_matches_reference_capture(golden_dir):
     np.testing.assert_allclose(o.dt_roi_shift(b, 90.0, 1.5), g["roi_shift_b_p90_blur"], atol=1e-3)
     np.testing.assert_allclose(o.dt_multiotsu_center_of_mass(a, b, 2.0, 0), g["motsu_shift_ab_s2"], atol=2e-2)
     np.testing.assert_allclose(o.dt_multiotsu_center_of_mass(a, b, 2.0, 1), g["motsu_shift_ab_s2_c1"], atol=2e-2)
+
+
+def test_dynatrack_pcc_oracle_matches_reference_capture(golden_dir):
+    g = np.load(golden_dir / "ref_dynatrack.npz")
+    assert o.dt_phase_cross_corr(g["pcc_ref"], g["pcc_mov"]) == tuple(g["pcc_shift"]) == (1, 2, -3)
+    assert o.dt_phase_cross_corr(g["a"], g["b"]) == tuple(g["pcc_shift_ab"])
+    assert o.dt_phase_cross_corr(g["pcc_odd"], g["pcc_odd_mov"]) == tuple(g["pcc_shift_odd"])
+    assert o.dt_phase_cross_corr(g["pcc_odd"], g["pcc_odd_mov"], 0.5) == tuple(g["pcc_shift_odd_half"])
+    np.testing.assert_array_equal(o.dt_match_shape(g["pcc_odd"], (8, 36, 50)), g["match_shape_odd_pad"])
+    np.testing.assert_array_equal(o.dt_match_shape(g["pcc_odd"], (4, 36, 25)), g["match_shape_odd_mixed"])
