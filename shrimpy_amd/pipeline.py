@@ -64,7 +64,8 @@ def gaussian_psf_factors(shape_zyx=(9, 7, 7), sigma_zyx=(2.0, 1.2, 1.2)):
 
 
 class VolumeReconstructor:
-    """Deskew -> (affine register) -> (Richardson-Lucy) for volumes of one raw shape on one device.
+    """(Flat-field) -> deskew -> (affine register) -> (Richardson-Lucy) for volumes of one raw shape
+    on one device.
 
     Plans (PSF taps, border normalisation, padded working volumes) are built once and reused for
     every unit the rank owns.
@@ -119,6 +120,13 @@ class VolumeReconstructor:
         vol = torch.as_tensor(raw, device=self.device, dtype=torch.float32).contiguous()
         if tuple(vol.shape) != self.raw_shape:
             raise ValueError(f"expected raw shape {self.raw_shape}, got {tuple(vol.shape)}")
+        flat = None
+        if getattr(self.settings, "flatfield", False):
+            from .flatfield import flat_field_pattern
+
+            flat = flat_field_pattern(vol)
+            if self._geo is None:
+                vol = flat.apply(vol)
         if self._geo is not None:
             target = None
             if self._plan is not None and self._register is None and (
@@ -127,8 +135,9 @@ class VolumeReconstructor:
                 if self._y_pad is None:
                     self._y_pad = self._plan.new_padded_input()
                 target = self._y_pad
+            # (with flat-field on, its division rides along inside the deskew kernel)
             vol = deskew_with_matrix(vol, self._geo.matrix_3x4, self._geo.pre_average_shape,
-                                     self.settings.deskew.average_n_slices, out=target)
+                                     self.settings.deskew.average_n_slices, out=target, flat_field=flat)
         if self._register is not None:
             r = self._register
             vol = apply_affine_transform_zyx(vol, np.asarray(r.affine_transform_zyx), self.output_shape,

@@ -143,8 +143,10 @@ class DeconvolveSettings(_StrictModel):
 
 
 class ReconstructSettings(_StrictModel):
-    """Whole per-volume pipeline: deskew -> (register) -> (deconvolve)."""
+    """Whole per-volume pipeline: (flat-field) -> deskew -> (register) -> (deconvolve)."""
 
+    flatfield: bool = False  # bright-field only: divide out the per-pixel median over Z (reference
+    #                          ``RECON_STEPS[0]``, ``shrimpy/preprocessing.py:320-327``)
     deskew: Optional[DeskewSettings] = None
     registration: Optional[RegisterSettings] = None
     deconvolution: Optional[DeconvolveSettings] = None

@@ -132,6 +132,29 @@ def test_volume_reconstructor_matches_oracle(device):
     assert torch.cuda.is_available()
 
 
+@pytest.mark.gpu
+def test_volume_reconstructor_with_flatfield_matches_oracle(device):
+    """flatfield: true -> the median kernel, its division fused into the deskew, then RL."""
+    from oracle import cpu_ref as o
+    from shrimpy_amd.pipeline import VolumeReconstructor
+    from shrimpy_amd.settings import DeconvolveSettings, DeskewSettings, ReconstructSettings
+
+    psf, _ = o.gaussian_psf((9, 7, 7), (2.0, 1.2, 1.2))
+    rng = np.random.default_rng(9)
+    raw = (o.bead_scene((96, 24, 80), seed=78, psf=psf, density=1e-3)
+           * (0.7 + 0.6 * rng.random((1, 24, 80)))).astype(np.float32)       # uneven illumination
+    settings = ReconstructSettings(
+        flatfield=True,
+        deskew=DeskewSettings(pixel_size_um=0.1133, ls_angle_deg=30, scan_step_um=0.15),
+        deconvolution=DeconvolveSettings(iterations=5),
+    )
+    out = VolumeReconstructor(raw.shape, settings, device)(raw).cpu().numpy().astype(np.float64)
+    ref = o.richardson_lucy(o.deskew(o.flat_field_bf(raw), 30.0, 0.755, False, 3), psf, 5).astype(np.float64)
+    assert np.all(np.abs(out - ref) <= 1e-4 * np.abs(ref) + 5e-5 * np.abs(ref).max())
+    only = VolumeReconstructor(raw.shape, ReconstructSettings(flatfield=True), device)(raw).cpu().numpy()
+    np.testing.assert_allclose(only, o.flat_field_bf(raw), rtol=2e-6)
+
+
 def test_run_sharded_overlaps_io_with_compute_and_keeps_order():
     """Loads run one unit ahead and stores one unit behind, on background threads; results are
     the same as the serial loop and errors in a store surface."""
