@@ -249,28 +249,38 @@ __global__ __launch_bounds__(kThreads) void blur_strided_kernel(BlurArgs p) {
   }
 }
 
+constexpr int kRowSeg = 4 * kThreads;  // outputs per row segment of the contiguous-axis kernel
 __global__ __launch_bounds__(kThreads) void blur_contiguous_kernel(BlurArgs p) {
-  extern __shared__ float tile[];  // [kThreads + 2r]
+  extern __shared__ float tile[];  // [kRowSeg + 2r]
   __shared__ float s_taps[2 * kBlurMaxR + 1];
   const int r = p.r;
-  const int64_t seg_tiles = (p.L + kThreads - 1) / kThreads;
-  const int64_t st = blockIdx.x % seg_tiles, row = blockIdx.x / seg_tiles;  // row over outer
-  const int64_t a0 = st * kThreads;
-  const float* base = p.in + row * p.L;
+  const int64_t seg_tiles = (p.L + kRowSeg - 1) / kRowSeg;
+  const int64_t items = p.outer * seg_tiles;  // (row, segment) pairs; a workgroup walks several
   for (int t = threadIdx.x; t < 2 * r + 1; t += kThreads) s_taps[t] = p.taps[t];
-  const int n_out = static_cast<int>(min(static_cast<int64_t>(kThreads), p.L - a0));
-  for (int t = threadIdx.x; t < n_out + 2 * r; t += kThreads) {
-    const int a = reflect(static_cast<int>(a0) + t - r, static_cast<int>(p.L));
-    float v = base[a];
-    if (p.div != 0.0f) v = (v - p.sub) / p.div;
-    tile[t] = v;
-  }
-  __syncthreads();
-  const int64_t a = a0 + threadIdx.x;
-  if (a < p.L) {
-    float acc = 0.0f;
-    for (int t = 0; t < 2 * r + 1; ++t) acc = fmaf(s_taps[t], tile[threadIdx.x + t], acc);
-    p.out[row * p.L + a] = acc;
+  for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+    const int64_t st = item % seg_tiles, row = item / seg_tiles;
+    const int64_t a0 = st * kRowSeg;
+    const float* base = p.in + row * p.L;
+    const int n_out = static_cast<int>(min(static_cast<int64_t>(kRowSeg), p.L - a0));
+    __syncthreads();  // the previous item's reads are done (and the taps are in place)
+    for (int t = threadIdx.x; t < n_out + 2 * r; t += kThreads) {
+      const int a = reflect(static_cast<int>(a0) + t - r, static_cast<int>(p.L));
+      float v = base[a];
+      if (p.div != 0.0f) v = (v - p.sub) / p.div;
+      tile[t] = v;
+    }
+    __syncthreads();
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = 0; t < 2 * r + 1; ++t) {
+      const float w = s_taps[t];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = fmaf(w, tile[threadIdx.x + k * kThreads + t], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t a = a0 + threadIdx.x + k * kThreads;
+      if (a < p.L) p.out[row * p.L + a] = acc[k];
+    }
   }
 }
 
@@ -462,11 +472,10 @@ extern "C" int lsr_blur_reflect_f32(const float* in, float* out, int64_t Z, int6
   p.inner = axis == 0 ? Y * X : (axis == 1 ? X : 1);
   hipStream_t s = lsr::as_stream(stream);
   if (axis == 2) {
-    const int64_t blocks = p.outer * lsr::ceil_div(p.L, static_cast<int64_t>(kThreads));
-    LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
-                (long long)blocks);
+    const int64_t items = p.outer * lsr::ceil_div(p.L, static_cast<int64_t>(kRowSeg));
+    const int64_t blocks = items < 16384 ? items : 16384;
     hipLaunchKernelGGL(blur_contiguous_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
-                       sizeof(float) * (kThreads + 2 * radius), s, p);
+                       sizeof(float) * (kRowSeg + 2 * radius), s, p);
   } else {
     const int64_t blocks = p.outer * lsr::ceil_div(p.L, static_cast<int64_t>(kSeg)) * lsr::ceil_div(p.inner, int64_t(64));
     LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
