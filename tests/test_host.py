@@ -250,3 +250,24 @@ def test_prepare_psf_pads_even_axes_and_bounds_size():
         prepare_psf(np.ones((17, 3, 3), np.float32))
     with pytest.raises(ValueError):
         prepare_psf(np.ones((3, 3), np.float32))
+
+
+def test_dynatrack_host_logic_matches_the_oracle(golden_dir):
+    """The 256-bin searches of shrimpy_amd.dynatrack run on the host: check them without a GPU
+    (histograms from the oracle) against the oracle, which is pinned to the reference's output."""
+    import sys
+
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from oracle import cpu_ref as o
+    from shrimpy_amd import dynatrack as d
+
+    g = np.load(golden_dir / "ref_dynatrack.npz")
+    a = g["a"]
+    blur = o.dt_gaussian_blur_3d((a - a.min()) / (a.max() - a.min()), 2.0)
+    vmin, vmax = float(blur.min()), float(blur.max())
+    hist = o.dt_histc(blur, 256, vmin, vmax)
+    for comp, want in zip((0, 1), g["otsu_blur_a"]):
+        assert d._otsu_from_hist(hist, vmin, vmax, comp) == pytest.approx(float(want), rel=1e-5)
+    assert [d._next_fast_len(n) for n in (0, 1, 7, 11, 13, 171, 2049)] == [1, 1, 8, 12, 15, 180, 2160]
