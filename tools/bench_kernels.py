@@ -77,6 +77,17 @@ def _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_ge
         print(json.dumps({"kernel": f"affine_kernel ({mode}, {'exact fp64' if exact else 'f32 interp'})", "shape": shape, "ms": ms,
                           "algorithmic_GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / 8000,
                           "voxels_per_s": vol.numel() / (ms * 1e-3)}))
+    # a map that couples z with the plane (tilt about y): the general gather kernel
+    tilt = np.eye(4)
+    c, sn = np.cos(np.deg2rad(1.5)), np.sin(np.deg2rad(1.5))
+    tilt[0, 0], tilt[0, 2], tilt[2, 0], tilt[2, 2] = c, -sn, sn, c
+    tilt[:3, 3] = [2.0, 0.5, -3.25]
+    for exact in (True, False):
+        ms = timed(lambda: apply_affine_transform_zyx(vol, tilt, out=out, exact=exact), args.reps)
+        nbytes = 8.0 * vol.numel()
+        print(json.dumps({"kernel": f"affine_kernel (tilted map, gather, {'exact fp64' if exact else 'f32 interp'})",
+                          "shape": shape, "ms": ms, "algorithmic_GBps": nbytes / ms / 1e6,
+                          "frac_of_8TBps": nbytes / ms / 1e6 / 8000}))
     del vol, out
 
     # ---- flat-field (median over Z + apply / fused deskew), config 2 raw stack of camera counts
