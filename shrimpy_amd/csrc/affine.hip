@@ -45,25 +45,30 @@ struct AxisTap {
   bool out0, out1;  // grid-constant: neighbour is outside the volume -> cval
 };
 
-// Taps of one axis.  Returns false if (mode constant) the coordinate is outside [0, n-1] -> the
-// whole sample is cval; the indices are valid (clamped) either way, so that the caller can issue
-// its loads unconditionally -- under a per-lane condition hipcc waits for each load before issuing
-// the next one, which is what kept this kernel (and the deskew) latency-bound.
+// Returns false if (mode constant) the coordinate is outside [0, n-1] -> whole sample is cval.
 template <bool GRID>
 __device__ __forceinline__ bool axis_tap(double c, int n, AxisTap& t) {
-  const bool inside = GRID || !(c < 0.0 || c > static_cast<double>(n - 1));
+  if (!GRID && (c < 0.0 || c > static_cast<double>(n - 1))) return false;
   const double fl = floor(c);
   const double f = c - fl;
   t.f = f;
   t.w0 = 1.0 - f;
   t.w1 = 1.0 - t.w0;
-  // indices only matter while a neighbour can be inside; clamp far-away coordinates first
-  const int start = static_cast<int>(fmin(fmax(fl, -2.0), static_cast<double>(n) + 1.0));
-  t.out0 = GRID && (start < 0 || start >= n);
-  t.out1 = GRID && (start + 1 < 0 || start + 1 >= n);
-  t.i0 = min(max(start, 0), n - 1);
-  t.i1 = min(max(start + 1, 0), n - 1);
-  return inside;
+  if constexpr (!GRID) {
+    // 0 <= c <= n-1: floor(c) is a valid index; only the upper neighbour can leave the volume
+    // (c == n-1 exactly, where its weight is 0)
+    t.i0 = static_cast<int>(fl);
+    t.i1 = min(t.i0 + 1, n - 1);
+    t.out0 = t.out1 = false;
+  } else {
+    // indices only matter while a neighbour can be inside; clamp far-away coordinates first
+    const int start = static_cast<int>(fmin(fmax(fl, -2.0), static_cast<double>(n) + 1.0));
+    t.out0 = start < 0 || start >= n;
+    t.out1 = start + 1 < 0 || start + 1 >= n;
+    t.i0 = min(max(start, 0), n - 1);
+    t.i1 = min(max(start + 1, 0), n - 1);
+  }
+  return true;
 }
 
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load, 4-byte aligned
@@ -97,77 +102,98 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
   const double rx = lsr::dadd(lsr::dmul(zd, p.m[8]), lsr::dmul(yd, p.m[9]));
   // element indices fit 32 bits unsigned (host check); one 64-bit add per load
   const unsigned sz = static_cast<unsigned>(p.Yi) * static_cast<unsigned>(p.Xi);
+  const double cv = static_cast<double>(p.cval);
   float* orow = p.out + (static_cast<int64_t>(zo) * p.Yo + yo) * p.Xo;
 
 #pragma unroll
   for (int k = 0; k < kPerThread; ++k) {
     const int xo = x_first + k * kLanesX;
-    const double xd = static_cast<double>(min(xo, p.Xo - 1));  // lanes past the row: a duplicate, not stored
+    if (xo >= p.Xo) break;
+    const double xd = static_cast<double>(xo);
     const double cz = lsr::dadd(lsr::dadd(rz, lsr::dmul(xd, p.m[2])), p.m[3]);
     const double cy = lsr::dadd(lsr::dadd(ry, lsr::dmul(xd, p.m[6])), p.m[7]);
     const double cx = lsr::dadd(lsr::dadd(rx, lsr::dmul(xd, p.m[10])), p.m[11]);
 
     AxisTap tz, ty_, tx_;
-    const bool iz = axis_tap<GRID>(cz, p.Zi, tz), iy = axis_tap<GRID>(cy, p.Yi, ty_), ix = axis_tap<GRID>(cx, p.Xi, tx_);
-    const bool inside = iz && iy && ix;
-
-    // all eight taps, unconditionally (clamped indices are always valid)
-    float v[2][2][2];
+    float result = p.cval;
+    if (axis_tap<GRID>(cz, p.Zi, tz) && axis_tap<GRID>(cy, p.Yi, ty_) &&
+        axis_tap<GRID>(cx, p.Xi, tx_)) {
+      if constexpr (F32) {
+        // LSR_MODE_F32_INTERP: fp64 coordinates (border decisions unchanged), f32 weights and
+        // FMAs -- not bit-identical to scipy (~1e-6 relative), HBM-bound instead of fp64-bound
+        const float wz1 = static_cast<float>(tz.f), wy1 = static_cast<float>(ty_.f),
+                    wx1 = static_cast<float>(tx_.f);  // (w1 = 1 - (1 - f) differs from f by <= 1 ulp of fp64)
+        float v[2][2][2];
+        if constexpr (!GRID) {
+          if (p.Xi >= 2) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const unsigned o = static_cast<unsigned>(a ? tz.i1 : tz.i0) * sz +
-                           static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * static_cast<unsigned>(p.Xi);
-        if (!GRID && F32 && p.Xi >= 2) {  // wave-uniform
-          load_x_pair(p.in + o, tx_.i0, p.Xi, v[a][b][0], v[a][b][1]);
-        } else {
-          v[a][b][0] = p.in[o + static_cast<unsigned>(tx_.i0)];
-          v[a][b][1] = p.in[o + static_cast<unsigned>(tx_.i1)];
-        }
-      }
-    if constexpr (GRID) {
+              for (int b = 0; b < 2; ++b) {
+                const unsigned o = static_cast<unsigned>(a ? tz.i1 : tz.i0) * sz +
+                                   static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * static_cast<unsigned>(p.Xi);
+                load_x_pair(p.in + o, tx_.i0, p.Xi, v[a][b][0], v[a][b][1]);
+              }
+          } else {
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+              for (int b = 0; b < 2; ++b)
+                v[a][b][0] = v[a][b][1] = p.in[static_cast<unsigned>(a ? tz.i1 : tz.i0) * sz +
+                                               static_cast<unsigned>(b ? ty_.i1 : ty_.i0)];
+          }
+        } else
 #pragma unroll
-          for (int c = 0; c < 2; ++c)
-            if ((a ? tz.out1 : tz.out0) || (b ? ty_.out1 : ty_.out0) || (c ? tx_.out1 : tx_.out0)) v[a][b][c] = p.cval;
-    }
-
-    float result;
-    if constexpr (F32) {
-      // LSR_MODE_F32_INTERP: fp64 coordinates (border decisions unchanged), f32 weights and
-      // FMAs -- not bit-identical to scipy (~1e-6 relative)
-      const float wz1 = static_cast<float>(tz.f), wy1 = static_cast<float>(ty_.f),
-                  wx1 = static_cast<float>(tx_.f);  // (w1 = 1 - (1 - f) differs from f by <= 1 ulp of fp64)
-      float r2[2][2];
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+          for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) r2[a][b] = fmaf(wx1, v[a][b][1] - v[a][b][0], v[a][b][0]);
-      const float r10 = fmaf(wy1, r2[0][1] - r2[0][0], r2[0][0]);
-      const float r11 = fmaf(wy1, r2[1][1] - r2[1][0], r2[1][0]);
-      result = fmaf(wz1, r11 - r10, r10);
-    } else {
-      // scipy's corner order and product order: ((v * wz) * wy) * wx, summed in sequence
+            for (int c = 0; c < 2; ++c) {
+              const unsigned o = static_cast<unsigned>(a ? tz.i1 : tz.i0) * sz +
+                                 static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * static_cast<unsigned>(p.Xi) +
+                                 static_cast<unsigned>(c ? tx_.i1 : tx_.i0);
+              float val = p.in[o];
+              if (GRID && ((a ? tz.out1 : tz.out0) || (b ? ty_.out1 : ty_.out0) || (c ? tx_.out1 : tx_.out0)))
+                val = p.cval;
+              v[a][b][c] = val;
+            }
+        float r2[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) r2[a][b] = fmaf(wx1, v[a][b][1] - v[a][b][0], v[a][b][0]);
+        const float r10 = fmaf(wy1, r2[0][1] - r2[0][0], r2[0][0]);
+        const float r11 = fmaf(wy1, r2[1][1] - r2[1][0], r2[1][0]);
+        result = fmaf(wz1, r11 - r10, r10);
+      } else {
       double t = 0.0;
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a) {
+        const unsigned oz = static_cast<unsigned>(a ? tz.i1 : tz.i0) * sz;
+        const double wz = a ? tz.w1 : tz.w0;
+        const bool bz = a ? tz.out1 : tz.out0;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
+          const unsigned oy = oz + static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * static_cast<unsigned>(p.Xi);
+          const double wy = b ? ty_.w1 : ty_.w0;
+          const bool by = b ? ty_.out1 : ty_.out0;
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
-            double coeff = static_cast<double>(v[a][b][c]);
-            coeff = lsr::dmul(coeff, a ? tz.w1 : tz.w0);
-            coeff = lsr::dmul(coeff, b ? ty_.w1 : ty_.w0);
-            coeff = lsr::dmul(coeff, c ? tx_.w1 : tx_.w0);
+            const double wx = c ? tx_.w1 : tx_.w0;
+            const bool bx = c ? tx_.out1 : tx_.out0;
+            double coeff = static_cast<double>(p.in[oy + static_cast<unsigned>(c ? tx_.i1 : tx_.i0)]);
+            if (GRID && (bz || by || bx)) coeff = cv;
+            coeff = lsr::dmul(coeff, wz);
+            coeff = lsr::dmul(coeff, wy);
+            coeff = lsr::dmul(coeff, wx);
             t = lsr::dadd(t, coeff);
           }
+        }
+      }
       result = static_cast<float>(t);
+      }
     }
-    if (xo < p.Xo) orow[xo] = inside ? result : p.cval;
+    orow[xo] = result;
   }
 }
 
