@@ -233,11 +233,21 @@ __global__ __launch_bounds__(kThreads) void blur_strided_kernel(BlurArgs p) {
   const int rows = n_out + 2 * r;
   const float* base = p.in + o * p.L * p.inner + (col_ok ? i0 : 0);
   for (int t = threadIdx.x; t < 2 * r + 1; t += kThreads) s_taps[t] = p.taps[t];
-  for (int row = grp; row < rows; row += kThreads / 64) {
-    const int a = reflect(static_cast<int>(a0) + row - r, static_cast<int>(p.L));
-    float v = col_ok ? base[static_cast<int64_t>(a) * p.inner] : 0.0f;
-    if (p.div != 0.0f) v = (v - p.sub) / p.div;
-    tile[row * 64 + lane] = v;
+  // unconditional loads (columns past the volume read column 0 and are never stored), eight in
+  // flight per thread
+  constexpr int kStep = kThreads / 64, kBatch = 8;
+  for (int row0 = grp; row0 < rows; row0 += kStep * kBatch) {
+    float v[kBatch];
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      const int a = reflect(static_cast<int>(a0) + min(row0 + i * kStep, rows - 1) - r, static_cast<int>(p.L));
+      v[i] = base[static_cast<int64_t>(a) * p.inner];
+    }
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      const int row = row0 + i * kStep;
+      if (row < rows) tile[row * 64 + lane] = p.div != 0.0f ? (v[i] - p.sub) / p.div : v[i];
+    }
   }
   __syncthreads();
   float* obase = p.out + o * p.L * p.inner + i0;
@@ -263,11 +273,17 @@ __global__ __launch_bounds__(kThreads) void blur_contiguous_kernel(BlurArgs p) {
     const float* base = p.in + row * p.L;
     const int n_out = static_cast<int>(min(static_cast<int64_t>(kRowSeg), p.L - a0));
     __syncthreads();  // the previous item's reads are done (and the taps are in place)
-    for (int t = threadIdx.x; t < n_out + 2 * r; t += kThreads) {
-      const int a = reflect(static_cast<int>(a0) + t - r, static_cast<int>(p.L));
-      float v = base[a];
-      if (p.div != 0.0f) v = (v - p.sub) / p.div;
-      tile[t] = v;
+    const int n_stage = n_out + 2 * r;
+    for (int t0 = threadIdx.x; t0 < n_stage; t0 += kThreads * 5) {  // five loads in flight per thread
+      float v[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        v[i] = base[reflect(static_cast<int>(a0) + min(t0 + i * kThreads, n_stage - 1) - r, static_cast<int>(p.L))];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int t = t0 + i * kThreads;
+        if (t < n_stage) tile[t] = p.div != 0.0f ? (v[i] - p.sub) / p.div : v[i];
+      }
     }
     __syncthreads();
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
