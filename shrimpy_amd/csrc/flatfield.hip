@@ -23,12 +23,14 @@
 
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int kCols = 128;     // pixels per workgroup
 constexpr int kZGroups = 4;    // z phases per pixel (waves 2g, 2g+1 take z = g mod 4)
 constexpr int kThreads = kCols * kZGroups;
-constexpr int kUnroll = 8;     // loads in flight per thread
+constexpr int kUnroll = 16;    // loads in flight per thread
 constexpr int kReduceBlocks = 256;
 
 enum Mode : int { kShared = 0, kSplit = 1, kDone = 2 };
@@ -83,41 +85,69 @@ __global__ __launch_bounds__(kThreads) void flat_median_kernel(MedianArgs p) {
     __syncthreads();
     const int mode = s_mode[c];
     const unsigned pre0 = s_prefix0[c], pre1 = s_prefix1[c];
-    if (mode != kDone) {
-      bool saw_nan = false;
-      unsigned vmax = 0, vmin = 0xffffffffu;
-      for (int z0 = g; z0 < Z; z0 += kZGroups * kUnroll) {
+    // The streaming loop is VALU-bound (every sample: key, prefix test, bin, LDS add), so it is
+    // specialised per pass kind, walks the column by pointer increments and keeps the bounds
+    // check out of the full batches.
+    bool saw_nan = false;
+    unsigned vmax = 0, vmin = 0xffffffffu;
+    // first pass: the top key byte (sign + 7 exponent bits) of a pixel hardly changes along z, so
+    // runs of equal bins are counted in registers and cost one LDS add each (the LDS atomics, not
+    // HBM, bound this kernel: one ds_add per sample was ~8 ms at config 2)
+    unsigned run_bin = 0xffffffffu, run_len = 0;
+    auto flush_run = [&]() {
+      if (run_len) atomicAdd(&hist[(run_bin >> 1) * kCols + c], run_len << (16 * (run_bin & 1)));
+    };
+    auto visit = [&](float v, auto kind) {
+      constexpr int KIND = decltype(kind)::value;  // 0: first pass, 1: later histogram pass, 2: min/max pass
+      const unsigned key = key_of(v);
+      if constexpr (KIND == 0) {
+        saw_nan |= v != v;
+        const unsigned bin = key >> 24;
+        if (bin == run_bin) {
+          ++run_len;
+        } else {
+          flush_run();
+          run_bin = bin;
+          run_len = 1;
+        }
+      } else if constexpr (KIND == 1) {
+        if ((key >> (shift + 8)) == pre0) {
+          const unsigned bin = (key >> shift) & 255u;
+          atomicAdd(&hist[(bin >> 1) * kCols + c], 1u << (16 * (bin & 1)));
+        }
+      } else {
+        const unsigned top = key >> (shift + 8);
+        if (top == pre0) vmax = max(vmax, key);
+        if (top == pre1) vmin = min(vmin, key);
+      }
+    };
+    auto stream = [&](auto kind) {
+      const int64_t step = static_cast<int64_t>(kZGroups) * p.plane;
+      const float* q = src + static_cast<int64_t>(g) * p.plane;
+      int z = g;
+      for (; z + (kUnroll - 1) * kZGroups < Z; z += kUnroll * kZGroups) {  // full batches
         float v[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          const int z = min(z0 + u * kZGroups, Z - 1);
-          v[u] = src[static_cast<int64_t>(z) * p.plane];
-        }
+        for (int u = 0; u < kUnroll; ++u) v[u] = q[u * step];
+        q += kUnroll * step;
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          if (z0 + u * kZGroups < Z) {
-            const unsigned key = key_of(v[u]);
-            saw_nan |= v[u] != v[u];
-            // keys whose higher bytes equal the selected prefix (all of them in the first pass)
-            const unsigned top = level == 0 ? 0u : key >> (shift + 8);
-            if (mode == kShared) {
-              if (top == pre0) {
-                const unsigned bin = (key >> shift) & 255u;
-                atomicAdd(&hist[(bin >> 1) * kCols + c], 1u << (16 * (bin & 1)));
-              }
-            } else {  // split: rank k0 is the largest key under prefix 0, k1 the smallest under 1
-              if (top == pre0) vmax = max(vmax, key);
-              if (top == pre1) vmin = min(vmin, key);
-            }
-          }
-        }
+        for (int u = 0; u < kUnroll; ++u) visit(v[u], kind);
       }
-      if (level == 0 && saw_nan) s_nan[c] = 1;
-      if (mode == kSplit) {
-        atomicMax(&s_hi[c], vmax);
-        atomicMin(&s_lo[c], vmin);
+      for (; z < Z; z += kZGroups, q += step) visit(*q, kind);
+    };
+    if (mode == kShared) {
+      if (level == 0) {
+        stream(std::integral_constant<int, 0>{});
+        flush_run();
+      } else {
+        stream(std::integral_constant<int, 1>{});
       }
+    } else if (mode == kSplit) {
+      stream(std::integral_constant<int, 2>{});
+      atomicMax(&s_hi[c], vmax);
+      atomicMin(&s_lo[c], vmin);
     }
+    if (level == 0 && saw_nan) s_nan[c] = 1;
     __syncthreads();
     if (tid < kCols && s_mode[tid] != kDone) {
       if (s_mode[tid] == kSplit) {
