@@ -168,7 +168,11 @@ class RichardsonLucyPlan:
     """
 
     def __init__(self, shape_zyx, psf, device, *, separable: str = "auto",
-                 separable_rtol: float = 1e-6, psf_factors=None, fused: str = "auto"):
+                 separable_rtol: float = 1e-6, psf_factors=None, fused: str = "auto",
+                 y_window: tuple[int, int] | None = None):
+        """``y_window = (first_row, total_rows)``: this plan's volume is the row slab
+        ``[first_row, first_row + shape_zyx[1])`` of a taller volume of ``total_rows`` rows; the
+        border normalisation along y is then the taller volume's (``shrimpy_amd.slab``)."""
         import torch
 
         if fused not in ("auto", "never"):
@@ -211,7 +215,13 @@ class RichardsonLucyPlan:
                 k=(dev(kz), dev(ky), dev(kx)),
                 k_flipped=(dev(kz[::-1]), dev(ky[::-1]), dev(kx[::-1])),
             )
-            self._norm = (dev(_axis_norm(kz, z)), dev(_axis_norm(ky, y)), dev(_axis_norm(kx, x)))
+            ny = _axis_norm(ky, y)
+            if y_window is not None:
+                first, total = (int(v) for v in y_window)
+                if first < 0 or first + y > total:
+                    raise ValueError(f"y_window {y_window} does not contain {y} rows")
+                ny = _axis_norm(ky, total)[first:first + y]
+            self._norm = (dev(_axis_norm(kz, z)), dev(ny), dev(_axis_norm(kx, x)))
         else:
             w = self.psf
             self._psf = _DevicePsf(
@@ -265,6 +275,35 @@ class RichardsonLucyPlan:
         """A zero-haloed volume in this plan's geometry, for a producer (the deskew kernel) to write
         ``y`` into; pass it to ``plan(...)`` to skip both the pad copy and the ``x0 = y`` copy."""
         return PaddedVolume(self.shape, self._psf.shape, self.device)
+
+    def iterate_padded(self, y_pad: "PaddedVolume", src: "PaddedVolume", dst: "PaddedVolume",
+                       eps: float = 1e-6) -> None:
+        """One fused RL iteration between padded volumes of this plan's geometry: reads ``src``
+        (and ``y_pad``), writes the logical window of ``dst``; no copies, no allocation.  The
+        building block of the slab split (``shrimpy_amd.slab``), where halo rows are refreshed
+        between iterations."""
+        import torch
+
+        if not self.fused:
+            raise _lib.LsrUnsupported("iterate_padded", _lib.E_UNSUPPORTED,
+                                      "needs the fused separable path (PSF within its specialisations)")
+        geo = self.padded_geometry()[:2]
+        for v, name in ((y_pad, "y_pad"), (src, "src"), (dst, "dst")):
+            if (v.pitch, v.plane) != geo or tuple(v.view.shape) != self.shape:
+                raise ValueError(f"{name} does not have this plan's padded geometry")
+        if src is dst:
+            raise ValueError("src and dst must be different volumes")
+        z, yy, xx = self.shape
+        ps = self._psf
+        nz, ny, nx = self._norm
+        with torch.cuda.device(self.device):
+            # x_a = src (iteration 0 reads it), x_b = dst (iteration 0 writes it)
+            _lib.call(
+                "lsr_rl_sep_fused_f32", y_pad.logical_ptr(), y_pad.pitch, y_pad.plane, 0,
+                src.full.data_ptr(), dst.full.data_ptr(), None, z, yy, xx, self._fused_taps.data_ptr(),
+                ps.shape[0], ps.shape[1], ps.shape[2], nz.data_ptr(), ny.data_ptr(), nx.data_ptr(), 1,
+                ctypes.c_float(eps), _lib.stream_ptr(self.device),
+            )
 
     def release(self) -> None:
         """Drop the scratch volumes."""
