@@ -14,7 +14,8 @@
 // then walks its histogram to the bin holding the wanted rank.  For an even Z the two middle ranks
 // k-1, k share a prefix until, at some byte, they fall into different bins; from there on rank k-1
 // is the MAXIMUM of its bin and rank k the MINIMUM of its own, so the next pass is a min/max
-// reduction and the pixel is done.  No pass is ever added: <= 4 reads of the volume, nothing else
+// reduction and the pixel is done.  No pass is ever added: <= 4 reads of the volume (2 for stacks
+// of integer camera counts, whose keys are 16-bit integers -- see the kernel), nothing else
 // is written but the (Y, X) pattern.  Results are the exact middle elements; the interpolation
 // between them is torch's: lerp(a, b, 0.5) = b - (b - a) * 0.5 in f32.
 //
@@ -66,16 +67,27 @@ __global__ __launch_bounds__(kThreads) void flat_median_kernel(MedianArgs p) {
   const float* src = p.in + col;
   const int Z = p.Z;
 
-  if (tid < kCols) {
-    s_prefix0[tid] = 0;
-    s_prefix1[tid] = 0;
-    s_r0[tid] = (Z - 1) / 2;  // 0-based ranks of the two middle elements (equal for odd Z)
-    s_r1[tid] = Z / 2;
-    s_mode[tid] = kShared;
-    s_nan[tid] = 0;
-  }
+  // Camera stacks are integer counts below 65536 stored as f32: their keys are 16-bit integers
+  // and the select needs two passes, not four.  The workgroup tries that when its first samples
+  // look like counts and falls back to the float keys (from scratch) should any sample of its 128
+  // pixels turn out not to be one.
+  auto is_count = [](float v) { return v >= 0.0f && v < 65536.0f && v == truncf(v); };
+  bool int_mode = __syncthreads_and(is_count(src[static_cast<int64_t>(min(g, Z - 1)) * p.plane]) ? 1 : 0) != 0;
 
-  for (int level = 0; level < 4; ++level) {
+  auto reset_state = [&]() {
+    if (tid < kCols) {
+      s_prefix0[tid] = 0;
+      s_prefix1[tid] = 0;
+      s_r0[tid] = (Z - 1) / 2;  // 0-based ranks of the two middle elements (equal for odd Z)
+      s_r1[tid] = Z / 2;
+      s_mode[tid] = kShared;
+      s_nan[tid] = 0;
+    }
+  };
+  reset_state();
+
+  for (int level = int_mode ? 2 : 0; level < 4; ++level) {
+    const bool first_pass = level == (int_mode ? 2 : 0);
     const int shift = 24 - 8 * level;
     for (int i = tid; i < 128 * kCols; i += kThreads) hist[i] = 0;
     if (tid < kCols) {
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(kThreads) void flat_median_kernel(MedianArgs p) {
     // The streaming loop is VALU-bound (every sample: key, prefix test, bin, LDS add), so it is
     // specialised per pass kind, walks the column by pointer increments and keeps the bounds
     // check out of the full batches.
-    bool saw_nan = false;
+    bool saw_nan = false, not_count = false;
     unsigned vmax = 0, vmin = 0xffffffffu;
     // first pass: the top key byte (sign + 7 exponent bits) of a pixel hardly changes along z, so
     // runs of equal bins are counted in registers and cost one LDS add each (the LDS atomics, not
@@ -99,10 +111,11 @@ __global__ __launch_bounds__(kThreads) void flat_median_kernel(MedianArgs p) {
     };
     auto visit = [&](float v, auto kind) {
       constexpr int KIND = decltype(kind)::value;  // 0: first pass, 1: later histogram pass, 2: min/max pass
-      const unsigned key = key_of(v);
+      const unsigned key = int_mode ? static_cast<unsigned>(v) : key_of(v);
       if constexpr (KIND == 0) {
         saw_nan |= v != v;
-        const unsigned bin = key >> 24;
+        not_count |= !is_count(v);
+        const unsigned bin = (key >> shift) & 255u;  // (the higher bytes are all zero / all wanted)
         if (bin == run_bin) {
           ++run_len;
         } else {
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(kThreads) void flat_median_kernel(MedianArgs p) {
       for (; z < Z; z += kZGroups, q += step) visit(*q, kind);
     };
     if (mode == kShared) {
-      if (level == 0) {
+      if (first_pass) {
         stream(std::integral_constant<int, 0>{});
         flush_run();
       } else {
@@ -147,8 +160,17 @@ __global__ __launch_bounds__(kThreads) void flat_median_kernel(MedianArgs p) {
       atomicMax(&s_hi[c], vmax);
       atomicMin(&s_lo[c], vmin);
     }
-    if (level == 0 && saw_nan) s_nan[c] = 1;
-    __syncthreads();
+    if (first_pass && !int_mode && saw_nan) s_nan[c] = 1;
+    if (first_pass && int_mode) {
+      if (__syncthreads_or(not_count ? 1 : 0)) {  // not a stack of counts after all: float keys, from scratch
+        int_mode = false;
+        reset_state();
+        level = -1;
+        continue;
+      }
+    } else {
+      __syncthreads();
+    }
     if (tid < kCols && s_mode[tid] != kDone) {
       if (s_mode[tid] == kSplit) {
         s_prefix0[tid] = s_hi[tid];  // full keys now
@@ -181,7 +203,8 @@ __global__ __launch_bounds__(kThreads) void flat_median_kernel(MedianArgs p) {
   }
 
   if (tid < kCols && col0 + tid < p.plane) {
-    const float a = value_of(s_prefix0[tid]), b = value_of(s_prefix1[tid]);
+    const float a = int_mode ? static_cast<float>(s_prefix0[tid]) : value_of(s_prefix0[tid]);
+    const float b = int_mode ? static_cast<float>(s_prefix1[tid]) : value_of(s_prefix1[tid]);
     // torch.quantile(0.5): lerp(a, b, w) with w = 0.5 for an even count (the branch of
     // at::native::lerp for |w| >= 0.5), w = 0 for an odd one
     float med = (Z & 1) ? a : b - (b - a) * 0.5f;

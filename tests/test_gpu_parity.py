@@ -537,6 +537,23 @@ def test_flatfield_pattern_is_the_exact_median(device, shape, kind):
         np.testing.assert_allclose(out, o.flat_field_bf(vol), rtol=2e-6)
 
 
+def test_flatfield_count_fast_path_falls_back_when_a_late_sample_is_not_a_count(device):
+    """Stacks of integer camera counts take the two-pass 16-bit select; a workgroup that meets a
+    non-count later in z (fraction, negative, >= 65536, NaN) restarts with the float keys."""
+    from shrimpy_amd.flatfield import flat_field_pattern
+
+    rng = np.random.default_rng(21)
+    base = rng.integers(0, 65536, (33, 3, 300)).astype(np.float32)
+    np.testing.assert_array_equal(flat_field_pattern(_t(base, device)).pattern.cpu().numpy(),
+                                  _median_torch_semantics(base))
+    for bad in (0.5, -3.0, 65536.0, 1e9):
+        vol = base.copy()
+        vol[31, 1, 7] = bad            # first workgroup (pixels 0..127 of row 0 ... ) restarts
+        vol[17, 2, 299] = bad          # and the last one
+        np.testing.assert_array_equal(flat_field_pattern(_t(vol, device)).pattern.cpu().numpy(),
+                                      _median_torch_semantics(vol))
+
+
 def test_flatfield_nan_propagates_per_pixel(device):
     from shrimpy_amd.flatfield import flat_field_pattern
 
