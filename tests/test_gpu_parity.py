@@ -357,6 +357,30 @@ def test_rl_fused_equals_two_launch_bit_exact(device, pshape, vshape):
     assert torch.equal(ypad.view, y)                     # y is read, never written
 
 
+def test_rl_fused_equals_two_launch_on_random_shapes(device):
+    """Seeded sweep over awkward sizes: volumes thinner than the PSF, one-plane volumes, extents
+    one off a tile multiple, every tile-size class of the fused kernel."""
+    import torch
+
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+
+    rng = np.random.default_rng(20260101)
+    odd = np.array([1, 3, 5, 7, 9, 11, 13, 15])
+    for case in range(24):
+        pshape = tuple(int(v) for v in rng.choice(odd, 3))
+        if pshape[0] >= 15 and max(pshape[1:]) >= 11:
+            pshape = (13,) + pshape[1:]
+        vshape = (int(rng.integers(1, 40)), int(rng.choice([1, 2, 15, 16, 17, 31, 33, 47, 49, 64, 65])),
+                  int(rng.choice([1, 3, 63, 64, 65, 127, 128, 129, 200, 257])))
+        factors = [np.abs(rng.normal(1.0, 0.4, n)).astype(np.float32) + 0.05 for n in pshape]
+        factors = [f / f.sum() for f in factors]
+        y = _t((rng.random(vshape) * 80 + 1).astype(np.float32), device)
+        iters = int(rng.integers(1, 4))
+        a = RichardsonLucyPlan(vshape, None, device, psf_factors=factors)(y, iterations=iters)
+        b = RichardsonLucyPlan(vshape, None, device, psf_factors=factors, fused="never")(y, iterations=iters)
+        assert torch.equal(a, b), (case, pshape, vshape, iters)
+
+
 def test_rl_fused_covers_every_separable_psf(device):
     """Every odd tap count up to 15 per axis has a fused specialisation (smaller tiles for the
     larger PSFs); the two-launch kernels stay as the cross-check (fused="never")."""
