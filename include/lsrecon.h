@@ -81,6 +81,13 @@ const char* lsr_last_error(void);
 int lsr_deskew_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo,
                    int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd,
                    const double M[12], int avg_n, lsr_stream_t stream);
+/* The same with the raw stack as the camera's uint16 counts: the conversion to float32 (exact)
+ * happens on the way into the kernel, so neither the host nor HBM ever holds a float copy of the
+ * stack -- half the PCIe upload, half the HBM read. Results equal lsr_deskew_f32 on the converted
+ * stack bit for bit. */
+int lsr_deskew_u16(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo,
+                   int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd,
+                   const double M[12], int avg_n, lsr_stream_t stream);
 
 /*
  * General order-1 (trilinear) affine resample; any 3x4 matrix.

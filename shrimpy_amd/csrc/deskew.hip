@@ -19,6 +19,8 @@
 
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int kTileY = 64;    // output Y' per workgroup == contiguous raw-x run (256 B rows)
@@ -30,7 +32,7 @@ constexpr int kRowsPerThread = kTileY * kTileX / kThreads;  // 16 output points 
 constexpr int kMaxAvg = 4096;  // sanity bound only
 
 struct DeskewArgs {
-  const float* in;
+  const void* in;           // raw stack: float32, or (U16) uint16 camera counts
   float* out;
   int64_t Z, Y, X;          // raw
   int64_t Zo, Yo, Xo, Zd;   // output, and pre-average depth
@@ -49,8 +51,11 @@ struct DeskewArgs {
 // becomes in / pattern[y][x] * mean (same operations, same order as the separate apply kernel, so
 // the result is bit-identical to flat-field followed by deskew) and the corrected volume is never
 // written to HBM.
-template <bool FLAT>
+// U16: the raw stack is the camera's uint16 counts; they become float32 in the staging pass (exact),
+// so the 8.6 GB float copy of the stack never exists -- half the HBM read, half the PCIe upload.
+template <bool FLAT, bool U16 = false>
 __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
+  using raw_t = std::conditional_t<U16, unsigned short, float>;
   __shared__ float slab[kSlabRows * kPitch];
 
   const int tid = threadIdx.x;
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
       // waits for every load before issuing the next, which left this kernel latency-bound
       // (81 % of wave cycles waiting at 3.5 TB/s).
       const int64_t x_safe = min(max(x_in, static_cast<int64_t>(0)), p.X - 1);
-      const float* src = p.in + (z_lo * p.Y + y_in) * p.X + x_safe;
+      const raw_t* src = static_cast<const raw_t*>(p.in) + (z_lo * p.Y + y_in) * p.X + x_safe;
       const int64_t z_stride = p.Y * p.X;
       float pat = 1.0f, mean = 1.0f;
       if constexpr (FLAT) {
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
       for (int zl0 = tid >> 6; zl0 < n_rows; zl0 += kStep * kBatch) {
         float v[kBatch];
 #pragma unroll
-        for (int i = 0; i < kBatch; ++i) v[i] = src[min(zl0 + i * kStep, n_rows - 1) * z_stride];
+        for (int i = 0; i < kBatch; ++i) v[i] = static_cast<float>(src[min(zl0 + i * kStep, n_rows - 1) * z_stride]);
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
           const int zl = zl0 + i * kStep;
@@ -193,7 +198,7 @@ bool is_integer(double v) { return v == static_cast<double>(static_cast<int64_t>
 
 namespace {
 
-int deskew_impl(const char* what, const float* in, int64_t Z, int64_t Y, int64_t X, float* out,
+int deskew_impl(const char* what, const void* in, bool u16, int64_t Z, int64_t Y, int64_t X, float* out,
                 int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane,
                 int64_t Zd, const double M[12], int avg_n, const float* flat_pattern,
                 const float* flat_mean, lsr_stream_t stream) {
@@ -249,12 +254,11 @@ int deskew_impl(const char* what, const float* in, int64_t Z, int64_t Y, int64_t
 
   p.flat_pattern = flat_pattern;
   p.flat_mean = flat_mean;
-  if (flat_pattern != nullptr)
-    hipLaunchKernelGGL(deskew_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
-                       lsr::as_stream(stream), p);
-  else
-    hipLaunchKernelGGL(deskew_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
-                       lsr::as_stream(stream), p);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(kThreads);
+  hipStream_t s = lsr::as_stream(stream);
+  if (u16) hipLaunchKernelGGL((deskew_kernel<false, true>), grid, block, 0, s, p);
+  else if (flat_pattern != nullptr) hipLaunchKernelGGL((deskew_kernel<true, false>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((deskew_kernel<false, false>), grid, block, 0, s, p);
   return lsr::launch_status(what);
 }
 
@@ -264,7 +268,15 @@ extern "C" int lsr_deskew_f32(const float* in, int64_t Z, int64_t Y, int64_t X, 
                               int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch,
                               int64_t out_plane, int64_t Zd, const double M[12], int avg_n,
                               lsr_stream_t stream) {
-  return deskew_impl("lsr_deskew_f32", in, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M,
+  return deskew_impl("lsr_deskew_f32", in, false, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M,
+                     avg_n, nullptr, nullptr, stream);
+}
+
+extern "C" int lsr_deskew_u16(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* out,
+                              int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch,
+                              int64_t out_plane, int64_t Zd, const double M[12], int avg_n,
+                              lsr_stream_t stream) {
+  return deskew_impl("lsr_deskew_u16", in, true, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M,
                      avg_n, nullptr, nullptr, stream);
 }
 
@@ -275,7 +287,7 @@ extern "C" int lsr_deskew_flat_f32(const float* in, int64_t Z, int64_t Y, int64_
                                    lsr_stream_t stream) {
   LSR_REQUIRE_PTR(flat_pattern);
   LSR_REQUIRE_PTR(flat_mean);
-  return deskew_impl("lsr_deskew_flat_f32", in, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd,
+  return deskew_impl("lsr_deskew_flat_f32", in, false, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd,
                      M, avg_n, flat_pattern, flat_mean, stream);
 }
 

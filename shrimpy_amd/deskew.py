@@ -65,7 +65,18 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
     """
     import torch
 
-    raw = _lib.require_device_f32(raw_data, "raw_data")
+    # uint16 camera counts are deskewed as they are (converted to float32 inside the kernel, exact):
+    # half the HBM read and, upstream, half the PCIe upload of a float32 stack
+    u16 = isinstance(raw_data, torch.Tensor) and raw_data.dtype == torch.uint16
+    if u16:
+        if raw_data.device.type != "cuda" or not raw_data.is_contiguous():
+            raise _lib.LsrError("require_device", -1, "raw_data must be a contiguous tensor on a HIP device "
+                                "(MI355X). There is no CPU fallback.")
+        raw = raw_data
+        if flat_field is not None:
+            raw, u16 = raw.to(torch.float32), False     # the flat-field pattern is defined on floats
+    else:
+        raw = _lib.require_device_f32(raw_data, "raw_data")
     if raw.dim() != 3:
         raise ValueError(f"raw_data must be (Z, Y, X), got shape {tuple(raw.shape)}")
     m = as_matrix_3x4(matrix_3x4)
@@ -106,12 +117,14 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
                 )
             else:
                 _lib.call(
-                    "lsr_deskew_f32", raw.data_ptr(), z, y, x, out_ptr, zo, yo, xo, out_pitch, out_plane,
-                    zd, _lib.matrix12(m), avg, stream,
+                    "lsr_deskew_u16" if u16 else "lsr_deskew_f32", raw.data_ptr(), z, y, x, out_ptr, zo, yo, xo,
+                    out_pitch, out_plane, zd, _lib.matrix12(m), avg, stream,
                 )
         except _lib.LsrUnsupported:
             if hasattr(out, "logical_ptr"):
                 raise
+            if u16:
+                raw = raw.to(torch.float32)
             if flat_field is not None:  # general matrix: correct first, then resample
                 raw = flat_field.apply(raw)
             # general matrix: trilinear gather, then average
@@ -165,7 +178,7 @@ def fast_deskew_zyx(
         raise TypeError(f"raw_data must be a torch.Tensor, got {type(raw_data).__name__}")
     if raw_data.dim() != 3:
         raise ValueError(f"raw_data must be (Z, Y, X), got shape {tuple(raw_data.shape)}")
-    if raw_data.dtype != torch.float32:
+    if raw_data.dtype not in (torch.float32, torch.uint16):   # uint16 counts go in as they are
         raw_data = raw_data.to(torch.float32)
     raw_data = raw_data.contiguous()
     geo = deskew_geometry(

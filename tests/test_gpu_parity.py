@@ -622,3 +622,29 @@ def test_preprocessor_flatfield_then_deskew_on_the_gpu(device):
     np.testing.assert_allclose(out["deskew"].cpu().numpy(), ref, rtol=3e-6, atol=1e-4)
     only = build_preprocessor(raw.shape, ["flatfield"])(raw)
     np.testing.assert_allclose(next(iter(only.values())).cpu().numpy(), o.flat_field_bf(raw), rtol=2e-6)
+
+
+def test_deskew_uint16_stack_equals_the_float_path(device):
+    """Camera counts as uint16 in, float32 out: the same bits as deskewing the float32 copy, into
+    a dense tensor and into a padded RL input; the preprocessor uploads uint16 stacks unconverted."""
+    import torch
+
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+    from shrimpy_amd.deskew import deskew_with_matrix, fast_deskew_zyx
+    from shrimpy_amd.geometry import deskew_geometry
+    from shrimpy_amd.preprocessing import build_preprocessor
+
+    rng = np.random.default_rng(8)
+    raw = rng.integers(0, 65536, (150, 20, 90)).astype(np.uint16)
+    kw = dict(ls_angle_deg=30.0, px_to_scan_ratio=0.755, keep_overhang=False, average_n_slices=3)
+    as_f32 = fast_deskew_zyx(raw_data=_t(raw.astype(np.float32), device), **kw)
+    as_u16 = fast_deskew_zyx(raw_data=torch.as_tensor(raw, device=device), **kw)
+    assert as_u16.dtype == torch.float32 and torch.equal(as_u16, as_f32)
+    geo = deskew_geometry(raw.shape, 30.0, 0.755, False, 3)
+    _, factors = o.gaussian_psf((9, 7, 7), (2.0, 1.2, 1.2))
+    ypad = RichardsonLucyPlan(geo.output_shape, None, device, psf_factors=factors).new_padded_input()
+    deskew_with_matrix(torch.as_tensor(raw, device=device), geo.matrix_3x4, geo.pre_average_shape, 3, out=ypad)
+    assert torch.equal(ypad.view, as_f32)
+    pre = build_preprocessor(raw.shape, ["deskew"], deskew=dict(pixel_size_um=0.1133, **kw))
+    out = pre(raw)
+    assert torch.equal(next(iter(out.values())), as_f32)
