@@ -117,7 +117,14 @@ class VolumeReconstructor:
         from .deskew import deskew_with_matrix
         from .register import apply_affine_transform_zyx
 
-        vol = torch.as_tensor(raw, device=self.device, dtype=torch.float32).contiguous()
+        # uint16 camera stacks that go straight into the deskew are uploaded as they are (half the
+        # PCIe bytes; the kernel converts exactly)
+        keep_u16 = (self._geo is not None and not getattr(self.settings, "flatfield", False)
+                    and getattr(raw, "dtype", None) in (np.uint16, np.dtype("uint16"), torch.uint16))
+        if keep_u16:
+            vol = torch.as_tensor(raw, device=self.device).contiguous()
+        else:
+            vol = torch.as_tensor(raw, device=self.device, dtype=torch.float32).contiguous()
         if tuple(vol.shape) != self.raw_shape:
             raise ValueError(f"expected raw shape {self.raw_shape}, got {tuple(vol.shape)}")
         flat = None

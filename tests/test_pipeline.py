@@ -153,6 +153,14 @@ def test_volume_reconstructor_with_flatfield_matches_oracle(device):
     assert np.all(np.abs(out - ref) <= 1e-4 * np.abs(ref) + 5e-5 * np.abs(ref).max())
     only = VolumeReconstructor(raw.shape, ReconstructSettings(flatfield=True), device)(raw).cpu().numpy()
     np.testing.assert_allclose(only, o.flat_field_bf(raw), rtol=2e-6)
+    # uint16 stacks: uploaded unconverted, same result as their float32 copy
+    import torch
+
+    counts = rng.integers(0, 4000, raw.shape).astype(np.uint16)
+    s16 = ReconstructSettings(deskew=DeskewSettings(pixel_size_um=0.1133, ls_angle_deg=30, scan_step_um=0.15),
+                              deconvolution=DeconvolveSettings(iterations=3))
+    rec = VolumeReconstructor(raw.shape, s16, device)
+    assert torch.equal(rec(counts).clone(), rec(counts.astype(np.float32)))
 
 
 def test_run_sharded_overlaps_io_with_compute_and_keeps_order():
