@@ -126,6 +126,16 @@ int lsr_flatfield_pattern_f32(const float* in, int64_t Z, int64_t Y, int64_t X, 
                               float* mean_out, void* scratch, lsr_stream_t stream);
 int lsr_flatfield_apply_f32(const float* in, const float* pattern, const float* mean_dev,
                             float* out, int64_t Z, int64_t Y, int64_t X, lsr_stream_t stream);
+/* The same three for a raw stack of uint16 camera counts (converted exactly inside the kernels;
+ * the median then always takes the two-pass select on 16-bit keys). */
+int lsr_flatfield_pattern_u16(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* pattern,
+                              float* mean_out, void* scratch, lsr_stream_t stream);
+int lsr_flatfield_apply_u16(const uint16_t* in, const float* pattern, const float* mean_dev,
+                            float* out, int64_t Z, int64_t Y, int64_t X, lsr_stream_t stream);
+int lsr_deskew_flat_u16(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo,
+                        int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd,
+                        const double M[12], int avg_n, const float* flat_pattern,
+                        const float* flat_mean, lsr_stream_t stream);
 int lsr_deskew_flat_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo,
                         int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd,
                         const double M[12], int avg_n, const float* flat_pattern,

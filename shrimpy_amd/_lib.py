@@ -45,6 +45,10 @@ SIGNATURES: dict[str, list] = {
     "lsr_deskew_u16": [ctypes.c_void_p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p, _int, _stream],
     "lsr_deskew_flat_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p, _int,
                             _c_f32p, _c_f32p, _stream],
+    "lsr_deskew_flat_u16": [ctypes.c_void_p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p, _int,
+                            _c_f32p, _c_f32p, _stream],
+    "lsr_flatfield_pattern_u16": [ctypes.c_void_p, _i64, _i64, _i64, _c_f32p, _c_f32p, ctypes.c_void_p, _stream],
+    "lsr_flatfield_apply_u16": [ctypes.c_void_p, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _stream],
     "lsr_flatfield_scratch_bytes": [],
     "lsr_flatfield_pattern_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, ctypes.c_void_p, _stream],
     "lsr_flatfield_apply_f32": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _stream],

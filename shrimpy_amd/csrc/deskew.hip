@@ -256,7 +256,8 @@ int deskew_impl(const char* what, const void* in, bool u16, int64_t Z, int64_t Y
   p.flat_mean = flat_mean;
   const dim3 grid(static_cast<unsigned>(blocks)), block(kThreads);
   hipStream_t s = lsr::as_stream(stream);
-  if (u16) hipLaunchKernelGGL((deskew_kernel<false, true>), grid, block, 0, s, p);
+  if (u16 && flat_pattern != nullptr) hipLaunchKernelGGL((deskew_kernel<true, true>), grid, block, 0, s, p);
+  else if (u16) hipLaunchKernelGGL((deskew_kernel<false, true>), grid, block, 0, s, p);
   else if (flat_pattern != nullptr) hipLaunchKernelGGL((deskew_kernel<true, false>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((deskew_kernel<false, false>), grid, block, 0, s, p);
   return lsr::launch_status(what);
@@ -278,6 +279,17 @@ extern "C" int lsr_deskew_u16(const uint16_t* in, int64_t Z, int64_t Y, int64_t 
                               lsr_stream_t stream) {
   return deskew_impl("lsr_deskew_u16", in, true, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M,
                      avg_n, nullptr, nullptr, stream);
+}
+
+extern "C" int lsr_deskew_flat_u16(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* out,
+                                   int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch,
+                                   int64_t out_plane, int64_t Zd, const double M[12], int avg_n,
+                                   const float* flat_pattern, const float* flat_mean,
+                                   lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(flat_pattern);
+  LSR_REQUIRE_PTR(flat_mean);
+  return deskew_impl("lsr_deskew_flat_u16", in, true, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd,
+                     M, avg_n, flat_pattern, flat_mean, stream);
 }
 
 extern "C" int lsr_deskew_flat_f32(const float* in, int64_t Z, int64_t Y, int64_t X, float* out,

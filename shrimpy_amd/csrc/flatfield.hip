@@ -45,13 +45,15 @@ __device__ __forceinline__ float value_of(unsigned k) {
 }
 
 struct MedianArgs {
-  const float* in;
+  const void* in;   // float32, or (U16) the camera's uint16 counts
   float* pattern;
   int Z;
   int64_t plane;  // Y * X
 };
 
+template <bool U16>
 __global__ __launch_bounds__(kThreads) void flat_median_kernel(MedianArgs p) {
+  using raw_t = std::conditional_t<U16, unsigned short, float>;
   __shared__ unsigned hist[128 * kCols];  // [bin >> 1][pixel], two 16-bit counters per word
   __shared__ unsigned s_prefix0[kCols], s_prefix1[kCols];  // selected key prefixes (rank k0 / k1)
   __shared__ unsigned s_lo[kCols], s_hi[kCols];            // split mode: min of bin 1, max of bin 0
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(kThreads) void flat_median_kernel(MedianArgs p) {
   const int g = tid / kCols;
   const int64_t col0 = static_cast<int64_t>(blockIdx.x) * kCols;
   const int64_t col = min(col0 + c, p.plane - 1);  // clamped: loads stay in bounds
-  const float* src = p.in + col;
+  const raw_t* src = static_cast<const raw_t*>(p.in) + col;
   const int Z = p.Z;
 
   // Camera stacks are integer counts below 65536 stored as f32: their keys are 16-bit integers
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(kThreads) void flat_median_kernel(MedianArgs p) {
   // look like counts and falls back to the float keys (from scratch) should any sample of its 128
   // pixels turn out not to be one.
   auto is_count = [](float v) { return v >= 0.0f && v < 65536.0f && v == truncf(v); };
-  bool int_mode = __syncthreads_and(is_count(src[static_cast<int64_t>(min(g, Z - 1)) * p.plane]) ? 1 : 0) != 0;
+  bool int_mode = U16 || __syncthreads_and(is_count(static_cast<float>(src[static_cast<int64_t>(min(g, Z - 1)) * p.plane])) ? 1 : 0) != 0;
 
   auto reset_state = [&]() {
     if (tid < kCols) {
@@ -136,17 +138,17 @@ __global__ __launch_bounds__(kThreads) void flat_median_kernel(MedianArgs p) {
     };
     auto stream = [&](auto kind) {
       const int64_t step = static_cast<int64_t>(kZGroups) * p.plane;
-      const float* q = src + static_cast<int64_t>(g) * p.plane;
+      const raw_t* q = src + static_cast<int64_t>(g) * p.plane;
       int z = g;
       for (; z + (kUnroll - 1) * kZGroups < Z; z += kUnroll * kZGroups) {  // full batches
         float v[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = q[u * step];
+        for (int u = 0; u < kUnroll; ++u) v[u] = static_cast<float>(q[u * step]);
         q += kUnroll * step;
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) visit(v[u], kind);
       }
-      for (; z < Z; z += kZGroups, q += step) visit(*q, kind);
+      for (; z < Z; z += kZGroups, q += step) visit(static_cast<float>(*q), kind);
     };
     if (mode == kShared) {
       if (first_pass) {
@@ -243,6 +245,18 @@ __global__ __launch_bounds__(256) void flat_mean_kernel(const double* __restrict
 
 // out = in / pattern * mean, four voxels per thread
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <typename raw_t>
+__global__ __launch_bounds__(256) void flat_apply_any_kernel(const raw_t* __restrict__ in,
+                                                             const float* __restrict__ pattern,
+                                                             const float* __restrict__ mean_dev,
+                                                             float* __restrict__ out, int64_t plane,
+                                                             int64_t total) {
+  const float mean = mean_dev[0];
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride)
+    out[i] = static_cast<float>(in[i]) / pattern[i % plane] * mean;
+}
+
 __global__ __launch_bounds__(256) void flat_apply_kernel(const float* __restrict__ in,
                                                          const float* __restrict__ pattern,
                                                          const float* __restrict__ mean_dev,
@@ -268,9 +282,9 @@ __global__ __launch_bounds__(256) void flat_apply_kernel(const float* __restrict
 
 extern "C" int lsr_flatfield_scratch_bytes(void) { return kReduceBlocks * static_cast<int>(sizeof(double)); }
 
-extern "C" int lsr_flatfield_pattern_f32(const float* in, int64_t Z, int64_t Y, int64_t X,
-                                         float* pattern, float* mean_out, void* scratch,
-                                         lsr_stream_t stream) {
+namespace {
+int flatfield_pattern(const char* what, const void* in, bool u16, int64_t Z, int64_t Y, int64_t X,
+                      float* pattern, float* mean_out, void* scratch, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(pattern);
   LSR_REQUIRE_PTR(mean_out);
@@ -285,12 +299,42 @@ extern "C" int lsr_flatfield_pattern_f32(const float* in, int64_t Z, int64_t Y, 
               (long long)plane);
   hipStream_t s = lsr::as_stream(stream);
   MedianArgs p{in, pattern, static_cast<int>(Z), plane};
-  hipLaunchKernelGGL(flat_median_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kThreads), 0, s, p);
+  if (u16) hipLaunchKernelGGL(flat_median_kernel<true>, dim3(static_cast<unsigned>(tiles)), dim3(kThreads), 0, s, p);
+  else hipLaunchKernelGGL(flat_median_kernel<false>, dim3(static_cast<unsigned>(tiles)), dim3(kThreads), 0, s, p);
   double* partial = static_cast<double*>(scratch);
   const int nb = static_cast<int>(plane < kReduceBlocks ? plane : kReduceBlocks);
   hipLaunchKernelGGL(flat_sum_kernel, dim3(nb), dim3(256), 0, s, pattern, plane, partial);
   hipLaunchKernelGGL(flat_mean_kernel, dim3(1), dim3(256), 0, s, partial, nb, plane, mean_out);
-  return lsr::launch_status("lsr_flatfield_pattern_f32");
+  return lsr::launch_status(what);
+}
+}  // namespace
+
+extern "C" int lsr_flatfield_pattern_f32(const float* in, int64_t Z, int64_t Y, int64_t X,
+                                         float* pattern, float* mean_out, void* scratch,
+                                         lsr_stream_t stream) {
+  return flatfield_pattern("lsr_flatfield_pattern_f32", in, false, Z, Y, X, pattern, mean_out, scratch, stream);
+}
+
+extern "C" int lsr_flatfield_pattern_u16(const uint16_t* in, int64_t Z, int64_t Y, int64_t X,
+                                         float* pattern, float* mean_out, void* scratch,
+                                         lsr_stream_t stream) {
+  return flatfield_pattern("lsr_flatfield_pattern_u16", in, true, Z, Y, X, pattern, mean_out, scratch, stream);
+}
+
+extern "C" int lsr_flatfield_apply_u16(const uint16_t* in, const float* pattern, const float* mean_dev,
+                                       float* out, int64_t Z, int64_t Y, int64_t X, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(pattern);
+  LSR_REQUIRE_PTR(mean_dev);
+  LSR_REQUIRE_PTR(out);
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
+              (long long)Z, (long long)Y, (long long)X);
+  const int64_t plane = Y * X, total = Z * plane;
+  int64_t blocks = lsr::ceil_div(total, static_cast<int64_t>(256));
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(flat_apply_any_kernel<unsigned short>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                     lsr::as_stream(stream), in, pattern, mean_dev, out, plane, total);
+  return lsr::launch_status("lsr_flatfield_apply_u16");
 }
 
 extern "C" int lsr_flatfield_apply_f32(const float* in, const float* pattern, const float* mean_dev,

@@ -73,8 +73,6 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
             raise _lib.LsrError("require_device", -1, "raw_data must be a contiguous tensor on a HIP device "
                                 "(MI355X). There is no CPU fallback.")
         raw = raw_data
-        if flat_field is not None:
-            raw, u16 = raw.to(torch.float32), False     # the flat-field pattern is defined on floats
     else:
         raw = _lib.require_device_f32(raw_data, "raw_data")
     if raw.dim() != 3:
@@ -111,7 +109,7 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
         try:
             if flat_field is not None:
                 _lib.call(
-                    "lsr_deskew_flat_f32", raw.data_ptr(), z, y, x, out_ptr, zo, yo, xo, out_pitch,
+                    "lsr_deskew_flat_u16" if u16 else "lsr_deskew_flat_f32", raw.data_ptr(), z, y, x, out_ptr, zo, yo, xo, out_pitch,
                     out_plane, zd, _lib.matrix12(m), avg, flat_field.pattern.data_ptr(),
                     flat_field.mean.data_ptr(), stream,
                 )
@@ -123,10 +121,10 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
         except _lib.LsrUnsupported:
             if hasattr(out, "logical_ptr"):
                 raise
-            if u16:
-                raw = raw.to(torch.float32)
             if flat_field is not None:  # general matrix: correct first, then resample
                 raw = flat_field.apply(raw)
+            elif u16:
+                raw = raw.to(torch.float32)
             # general matrix: trilinear gather, then average
             pre = out if avg == 1 else torch.empty((zd, yo, xo), dtype=torch.float32, device=raw.device)
             _lib.call(

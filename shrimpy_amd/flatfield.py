@@ -28,41 +28,56 @@ class FlatFieldPattern:
         """``volume / pattern * mean`` (new tensor, or into ``out`` -- which may be ``volume``)."""
         import torch
 
-        vol = _lib.require_device_f32(volume, "volume")
+        u16 = isinstance(volume, torch.Tensor) and volume.dtype == torch.uint16
+        vol = _require_raw(volume, "volume") if u16 else _lib.require_device_f32(volume, "volume")
         if vol.dim() != 3 or tuple(vol.shape[1:]) != tuple(self.pattern.shape):
             raise ValueError(f"volume must be (Z, {self.pattern.shape[0]}, {self.pattern.shape[1]}), "
                              f"got {tuple(vol.shape)}")
         if out is None:
-            out = torch.empty_like(vol)
+            out = torch.empty(tuple(vol.shape), dtype=torch.float32, device=vol.device)
         else:
             _lib.require_device_f32(out, "out")
             if tuple(out.shape) != tuple(vol.shape) or out.device != vol.device:
                 raise ValueError("out must match volume")
         z, y, x = (int(v) for v in vol.shape)
         with torch.cuda.device(vol.device):
-            _lib.call("lsr_flatfield_apply_f32", vol.data_ptr(), self.pattern.data_ptr(),
+            _lib.call("lsr_flatfield_apply_u16" if u16 else "lsr_flatfield_apply_f32", vol.data_ptr(), self.pattern.data_ptr(),
                       self.mean.data_ptr(), out.data_ptr(), z, y, x, _lib.stream_ptr(vol.device))
         return out
 
 
+def _require_raw(t, name):
+    import torch
+
+    if t.device.type != "cuda":
+        raise _lib.LsrError("require_device", -1, f"{name} is on {t.device}; this path runs only on a HIP "
+                            "device (MI355X). There is no CPU fallback.")
+    return t.contiguous()
+
+
 def flat_field_pattern(volume) -> FlatFieldPattern:
-    """Median over Z of every (y, x) pixel of a (Z, Y, X) float32 device tensor, and its mean."""
+    """Median over Z of every (y, x) pixel of a (Z, Y, X) device tensor -- float32, or the camera's
+    uint16 counts as they are -- and its mean."""
     import torch
 
     if not isinstance(volume, torch.Tensor):
         raise TypeError(f"volume must be a torch.Tensor, got {type(volume).__name__}")
     if volume.dim() != 3:
         raise ValueError(f"volume must be (Z, Y, X), got shape {tuple(volume.shape)}")
-    if volume.dtype != torch.float32:
-        volume = volume.to(torch.float32)
-    vol = _lib.require_device_f32(volume.contiguous(), "volume")
+    u16 = volume.dtype == torch.uint16
+    if u16:
+        vol = _require_raw(volume, "volume")
+    else:
+        if volume.dtype != torch.float32:
+            volume = volume.to(torch.float32)
+        vol = _lib.require_device_f32(volume.contiguous(), "volume")
     z, y, x = (int(v) for v in vol.shape)
     pattern = torch.empty((y, x), dtype=torch.float32, device=vol.device)
     mean = torch.empty((1,), dtype=torch.float32, device=vol.device)
     scratch = torch.empty((_lib.call_value("lsr_flatfield_scratch_bytes"),), dtype=torch.uint8,
                           device=vol.device)
     with torch.cuda.device(vol.device):
-        _lib.call("lsr_flatfield_pattern_f32", vol.data_ptr(), z, y, x, pattern.data_ptr(),
+        _lib.call("lsr_flatfield_pattern_u16" if u16 else "lsr_flatfield_pattern_f32", vol.data_ptr(), z, y, x, pattern.data_ptr(),
                   mean.data_ptr(), scratch.data_ptr(), _lib.stream_ptr(vol.device))
     return FlatFieldPattern(pattern, mean)
 
@@ -71,6 +86,6 @@ def flat_field_bf(volume):
     """The reference's ``_flat_field_BF`` on the device: new corrected (Z, Y, X) tensor."""
     import torch
 
-    if isinstance(volume, torch.Tensor) and volume.dtype != torch.float32:
+    if isinstance(volume, torch.Tensor) and volume.dtype not in (torch.float32, torch.uint16):
         volume = volume.to(torch.float32)
     return flat_field_pattern(volume).apply(volume.contiguous())

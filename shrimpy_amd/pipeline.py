@@ -117,9 +117,9 @@ class VolumeReconstructor:
         from .deskew import deskew_with_matrix
         from .register import apply_affine_transform_zyx
 
-        # uint16 camera stacks that go straight into the deskew are uploaded as they are (half the
-        # PCIe bytes; the kernel converts exactly)
-        keep_u16 = (self._geo is not None and not getattr(self.settings, "flatfield", False)
+        # uint16 camera stacks are uploaded as they are (half the PCIe bytes; the flat-field and
+        # deskew kernels convert exactly)
+        keep_u16 = ((self._geo is not None or getattr(self.settings, "flatfield", False))
                     and getattr(raw, "dtype", None) in (np.uint16, np.dtype("uint16"), torch.uint16))
         if keep_u16:
             vol = torch.as_tensor(raw, device=self.device).contiguous()

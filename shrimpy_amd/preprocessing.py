@@ -162,11 +162,11 @@ class _LabelfreePreprocessor:
         channels: dict[str, torch.Tensor] = {}
 
         # one host->device copy; every step then stays on the device (reference :316).  A uint16
-        # camera stack that only gets deskewed is uploaded as it is -- half the PCIe bytes of the
-        # reference's float32 copy -- and converted (exactly) inside the deskew kernel.
+        # camera stack is uploaded as it is -- half the PCIe bytes of the reference's float32 copy --
+        # and converted (exactly) inside the flat-field / deskew kernels.
         arr = np.asarray(volume_bf) if not isinstance(volume_bf, torch.Tensor) else None
-        if (arr is not None and arr.dtype == np.uint16 and self._deskew_settings is not None
-                and not self._apply_flatfield):
+        if arr is not None and arr.dtype == np.uint16 and (self._deskew_settings is not None
+                                                           or self._apply_flatfield):
             volume = torch.as_tensor(arr, device=self._device)
         else:
             volume = torch.as_tensor(volume_bf, device=self._device, dtype=torch.float32)

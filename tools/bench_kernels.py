@@ -120,7 +120,14 @@ def _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_ge
     ms = timed(lambda: deskew_with_matrix(raw16, geo.matrix_3x4, geo.pre_average_shape, 3, out=dsk), args.reps)
     print(json.dumps({"kernel": "deskew_kernel<false, U16> (uint16 camera counts in)", "raw": raw_shape, "ms": ms,
                       "algorithmic_GBps": (2.0 * raw16.numel() + 4.0 * dsk.numel()) / ms / 1e6}))
-    del raw, raw16, dsk, ff
+    ms = timed(lambda: flat_field_pattern(raw16), args.reps)
+    print(json.dumps({"kernel": "flat_median_kernel<U16> (+ mean)", "raw": raw_shape, "ms": ms,
+                      "passes_GBps": 2 * 2.0 * raw16.numel() / ms / 1e6}))
+    ff16 = flat_field_pattern(raw16)
+    ms = timed(lambda: deskew_with_matrix(raw16, geo.matrix_3x4, geo.pre_average_shape, 3, out=dsk, flat_field=ff16),
+               args.reps)
+    print(json.dumps({"kernel": "deskew_kernel<true, U16> (flat-field fused, uint16 in)", "raw": raw_shape, "ms": ms}))
+    del raw, raw16, dsk, ff, ff16
 
     # ---- deskew alone, config 2 and config 4 mappings
     for name in ("config2", "config4"):
