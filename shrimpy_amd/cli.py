@@ -72,8 +72,11 @@ def _distributed():
 
 
 def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings, positions=(),
-              zarr_version: str = "0.4", reconstructor_factory=None) -> dict:
+              zarr_version: str = "0.4", reconstructor_factory=None, stage_through_pinned: bool = True) -> dict:
     """Apply ``settings`` to every (position, t, c) volume of ``input_path`` -> ``output_path``.
+
+    On a GPU the volumes pass through pinned staging slots and copy streams
+    (``staging.VolumeStager``) so that reading, upload, kernels, download and writing overlap.
 
     ``reconstructor_factory(raw_shape, settings, device)`` defaults to
     :class:`shrimpy_amd.pipeline.VolumeReconstructor` (tests inject a stand-in).
@@ -126,13 +129,21 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
 
     units = enumerate_units(keys, nt, range(nc))
 
-    def load(u: Unit):
-        return src_positions[u.position]["0"].read_volume(u.t, u.c)
+    def load(u: Unit, out=None):
+        return src_positions[u.position]["0"].read_volume(u.t, u.c, out=out)
 
     def store(u: Unit, vol):
-        dst_positions[u.position]["0"].write_volume(u.t, u.c, vol.cpu().numpy())
+        host = vol if isinstance(vol, np.ndarray) else vol.cpu().numpy()
+        dst_positions[u.position]["0"].write_volume(u.t, u.c, host)
 
-    report = run_sharded(units, load, rec, store, synchronize=torch.cuda.synchronize)
+    stager = None
+    raw_dtype = np.dtype(first["0"].dtype)
+    if (stage_through_pinned and torch.device(device).type == "cuda"
+            and raw_dtype in (np.dtype("uint16"), np.dtype("float32")) and len(units) > world):
+        from .staging import VolumeStager
+
+        stager = VolumeStager((nz, ny, nx), raw_dtype, (oz, oy, ox), device)
+    report = run_sharded(units, load, rec, store, synchronize=torch.cuda.synchronize, stager=stager)
     nvox = len(report.units) * nz * ny * nx
     logger.info("rank %d: %d units, %.3g input voxels/s (job %.2fs)", rank, len(report.units),
                 nvox / max(report.seconds, 1e-9), report.max_seconds)

@@ -192,8 +192,9 @@ class ZarrArray:
         ranges = [range(-(-self.shape[d] // self.chunks[d])) for d in range(k, n)]
         return itertools.product(*ranges)
 
-    def read_volume(self, *lead: int) -> np.ndarray:
-        """The (Z, Y, X) volume at leading indices (t, c) as a C-contiguous array."""
+    def read_volume(self, *lead: int, out: np.ndarray | None = None) -> np.ndarray:
+        """The (Z, Y, X) volume at leading indices (t, c) as a C-contiguous array; with ``out``
+        (same shape and dtype, e.g. a pinned staging buffer) the chunks are decoded into it."""
         k = len(self.shape) - 3
         if len(lead) != k:
             raise IndexError(f"expected {k} leading indices, got {len(lead)}")
@@ -201,7 +202,12 @@ class ZarrArray:
             if not 0 <= i < n:
                 raise IndexError(f"index {lead} out of range for shape {self.shape}")
         vshape, vchunks = self.shape[k:], self.chunks[k:]
-        out = np.full(vshape, self.fill_value, dtype=self.dtype)
+        if out is None:
+            out = np.full(vshape, self.fill_value, dtype=self.dtype)
+        else:
+            if tuple(out.shape) != tuple(vshape) or out.dtype != self.dtype:
+                raise ValueError(f"out must be {tuple(vshape)} {self.dtype}, got {out.shape} {out.dtype}")
+            out[...] = self.fill_value
         for cidx in self._grid(tuple(lead)):
             block = self._read_chunk(tuple(lead) + cidx)
             if block is None:

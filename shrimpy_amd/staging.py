@@ -1,0 +1,132 @@
+"""Host <-> HBM staging for whole volumes: pinned double buffers and one HIP copy stream each way.
+
+At config-2 size one unit is 4.3 GB of camera counts in (8.6 GB as float32) and 3.2 GB out, against
+~55 ms of kernels: over PCIe the copies take longer than the arithmetic, so the steady state of a
+run over many units is set by whichever of {upload, kernels, download} is slowest -- provided they
+overlap.  The reference uploads synchronously from pageable memory inside the step
+(``torch.as_tensor(volume, device=...)``, ``shrimpy/preprocessing.py:316``) and downloads with
+``.cpu()``; here the three run concurrently:
+
+* ``up`` stream: pinned host slot -> device slot (``hipMemcpyAsync`` through torch), unit k+1;
+* compute stream (the caller's current stream): kernels of unit k;
+* ``down`` stream: result of unit k-1 -> pinned host slot.
+
+Ordering is carried by HIP events only (no device-wide synchronise): a device slot is not
+overwritten before the kernels that read it have finished, a host slot not before its copy has.
+PyTorch is the plumbing here (pinned allocations, streams, events); there is no kernel in this file.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["VolumeStager"]
+
+
+class VolumeStager:
+    """``depth`` pinned host slots + device slots for raw stacks, ``depth`` pinned slots for results.
+
+    Threading: ``stage_in`` may be called from a loader thread, ``acquire``/``release``/
+    ``stage_out`` from the thread that launches the kernels, ``collect`` from a writer thread.
+    Slot ``k`` serves units ``k, k + depth, ...``; calls for one slot must come in unit order.
+    """
+
+    def __init__(self, raw_shape, raw_dtype, out_shape, device, depth: int = 2):
+        import torch
+
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise _lib.LsrError("VolumeStager", -1, f"device {self.device}: staging needs a HIP device "
+                                "(pinned host memory and copy streams). There is no CPU fallback.")
+        if depth < 2:
+            raise ValueError("depth must be at least 2 (one slot in flight, one being filled)")
+        self.depth = int(depth)
+        self.raw_shape = tuple(int(v) for v in raw_shape)
+        self.out_shape = tuple(int(v) for v in out_shape)
+        dt = {np.dtype("uint16"): torch.uint16, np.dtype("float32"): torch.float32}.get(np.dtype(raw_dtype))
+        if dt is None:
+            raise TypeError(f"raw dtype {raw_dtype}: uint16 (camera counts) or float32")
+        self._host_in = [torch.empty(self.raw_shape, dtype=dt, pin_memory=True) for _ in range(depth)]
+        self._dev_in = [torch.empty(self.raw_shape, dtype=dt, device=self.device) for _ in range(depth)]
+        self._host_out = [torch.empty(self.out_shape, dtype=torch.float32, pin_memory=True) for _ in range(depth)]
+        self._up = torch.cuda.Stream(self.device)
+        self._down = torch.cuda.Stream(self.device)
+        self._uploaded = [None] * depth      # recorded on `up` after the H2D copy of the slot
+        self._consumed = [None] * depth      # recorded on the compute stream when the raw slot is dead
+        self._downloaded = [None] * depth    # recorded on `down` after the D2H copy of the slot
+
+    # ---- host -> device --------------------------------------------------------------------
+    def host_in(self, slot: int) -> np.ndarray:
+        """The slot's pinned input buffer as a numpy view, once its previous upload has finished
+        (loaders fill it in place: a copy into it costs more than the PCIe transfer)."""
+        ev = self._uploaded[slot]
+        if ev is not None:
+            ev.synchronize()
+        return self._host_in[slot].numpy()
+
+    def stage_in(self, slot: int, data=None):
+        """Enqueue the upload of the slot (after copying ``data`` into it, if given and not the
+        slot's own buffer).  Returns at once; ``acquire`` makes the compute stream wait for it."""
+        import torch
+
+        view = self.host_in(slot)
+        if data is not None and not (isinstance(data, np.ndarray) and np.shares_memory(data, view)):
+            arr = np.asarray(data)
+            if arr.shape != view.shape:
+                raise ValueError(f"expected raw shape {view.shape}, got {arr.shape}")
+            np.copyto(view, arr, casting="same_kind")
+        with torch.cuda.stream(self._up):
+            if self._consumed[slot] is not None:
+                self._up.wait_event(self._consumed[slot])
+            self._dev_in[slot].copy_(self._host_in[slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._up)
+        self._uploaded[slot] = ev
+        return slot
+
+    def acquire(self, slot: int):
+        """Device tensor of the slot; the current stream waits (on the GPU) for its upload."""
+        import torch
+
+        torch.cuda.current_stream(self.device).wait_event(self._uploaded[slot])
+        return self._dev_in[slot]
+
+    def release(self, slot: int) -> None:
+        """The kernels enqueued so far on the current stream are the last readers of the slot."""
+        import torch
+
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._consumed[slot] = ev
+
+    # ---- device -> host --------------------------------------------------------------------
+    def stage_out(self, slot: int, result) -> None:
+        """Enqueue the download of ``result`` (as of now on the current stream) into the slot."""
+        import torch
+
+        if tuple(result.shape) != self.out_shape:
+            raise ValueError(f"expected result shape {self.out_shape}, got {tuple(result.shape)}")
+        prev = self._downloaded[slot]
+        if prev is not None:
+            prev.synchronize()                  # the writer may still be reading the host slot
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._down):
+            self._down.wait_event(done)
+            self._host_out[slot].copy_(result, non_blocking=True)
+            result.record_stream(self._down)    # keep the allocator from recycling it under the copy
+            ev = torch.cuda.Event()
+            ev.record(self._down)
+        self._downloaded[slot] = ev
+
+    def collect(self, slot: int) -> np.ndarray:
+        """The slot's result on the host (pinned numpy view), after its download has finished.
+        Valid until the slot's next ``stage_out``."""
+        self._downloaded[slot].synchronize()
+        return self._host_out[slot].numpy()
+
+    def drain(self) -> None:
+        self._up.synchronize()
+        self._down.synchronize()

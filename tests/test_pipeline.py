@@ -203,3 +203,50 @@ def test_run_sharded_overlaps_io_with_compute_and_keeps_order():
 
     with pytest.raises(OSError, match="disk full"):
         run_sharded(list(range(3)), lambda u: u, lambda v: v, bad_store)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_place", [True, False])
+def test_run_sharded_staged_through_pinned_slots_matches_direct_calls(device, in_place):
+    """Upload / kernels / download on three streams with two slots: every unit's result equals the
+    synchronous call's, in order, whether the loader fills the pinned slot or returns its own array."""
+    import torch
+
+    from shrimpy_amd.pipeline import VolumeReconstructor, run_sharded
+    from shrimpy_amd.settings import DeconvolveSettings, DeskewSettings, ReconstructSettings
+    from shrimpy_amd.staging import VolumeStager
+
+    rng = np.random.default_rng(21)
+    raw_shape = (96, 24, 70)
+    vols = [rng.integers(90, 900, raw_shape).astype(np.uint16) for _ in range(7)]
+    settings = ReconstructSettings(
+        deskew=DeskewSettings(pixel_size_um=0.1133, ls_angle_deg=30.0, px_to_scan_ratio=0.755,
+                              keep_overhang=False, average_n_slices=3),
+        deconvolution=DeconvolveSettings(iterations=4, gaussian_shape_zyx=(5, 5, 5), gaussian_sigma_zyx=(1.2, 1.0, 1.0)),
+        flatfield=True)
+    rec = VolumeReconstructor(raw_shape, settings, device)
+    want = [rec(v).cpu().numpy() for v in vols]
+    stager = VolumeStager(raw_shape, np.uint16, rec.output_shape, device)
+    got = {}
+
+    if in_place:
+        def load(u, out=None):
+            out[...] = vols[u]
+            return out
+    else:
+        def load(u):
+            return vols[u]
+
+    rep = run_sharded(list(range(len(vols))), load, rec, lambda u, v: got.__setitem__(u, v.copy()),
+                      synchronize=torch.cuda.synchronize, stager=stager)
+    assert rep.units == list(range(len(vols)))
+    for u, w in enumerate(want):
+        np.testing.assert_array_equal(got[u], w)
+
+
+def test_stager_refuses_cpu_devices():
+    from shrimpy_amd._lib import LsrError
+    from shrimpy_amd.staging import VolumeStager
+
+    with pytest.raises(LsrError, match="no CPU fallback"):
+        VolumeStager((4, 4, 4), np.uint16, (4, 4, 4), "cpu")
