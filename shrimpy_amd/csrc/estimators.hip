@@ -191,13 +191,16 @@ __global__ __launch_bounds__(kThreads) void sum4_final_kernel(const double* __re
 // ---------------------------------------------------------------------------------- reflect blur
 // out = correlate1d(in, taps) along one axis with F.pad(mode="reflect") borders (index -k -> k,
 // n-1+k -> n-1-k; needs radius < n).  The volume is viewed as (outer, L, inner): the filtered axis
-// has length L and stride `inner`.  A workgroup stages (64 + 2r) x 64 values -- 64 positions of the
-// axis plus halo, 64 consecutive `inner` elements -- in LDS and each thread produces 16 outputs of
-// one inner column; LDS reads are conflict-free (lanes = consecutive inner elements).  For the
-// contiguous axis (inner == 1) the roles swap: lanes run along the axis itself.
+// has length L and stride `inner`.  A workgroup stages (SEG + 2r) x 64 values -- SEG positions of
+// the axis plus halo, 64 consecutive `inner` elements -- in LDS; a thread owns OPT consecutive
+// positions of one inner column and walks the taps eight at a time over a register window of
+// OPT + 7 staged values, so an LDS value is read once per eight taps instead of once per tap
+// (the per-tap form was LDS-issue-bound at 2 reads per FMA).  Taps are applied in ascending order,
+// one FMA each, whatever the blocking.  For the contiguous axis (inner == 1) lanes run along the
+// axis itself: four consecutive outputs per thread, 16-byte LDS reads.
 // Optional input map (v - sub) / div fused into staging (the reference rescales to [0, 1] first).
 constexpr int kBlurMaxR = 64;
-constexpr int kSeg = 64;
+constexpr int kTapBlock = 8;
 
 struct BlurArgs {
   const float* in;
@@ -214,10 +217,12 @@ __device__ __forceinline__ int reflect(int i, int n) {
   return i;
 }
 
+template <int OPT>  // outputs per thread; segment = 4 * OPT positions
 __global__ __launch_bounds__(kThreads) void blur_strided_kernel(BlurArgs p) {
-  extern __shared__ float tile[];  // [(kSeg + 2r)][64]
+  constexpr int kSeg = (kThreads / 64) * OPT;
+  extern __shared__ float tile[];  // [(kSeg + 2r + kTapBlock)][64]; the last rows are never used in an FMA
   __shared__ float s_taps[2 * kBlurMaxR + 1];
-  const int r = p.r;
+  const int r = p.r, ntaps = 2 * r + 1;
   const int64_t inner_tiles = (p.inner + 63) / 64, seg_tiles = (p.L + kSeg - 1) / kSeg;
   int64_t bid = blockIdx.x;
   const int64_t it = bid % inner_tiles;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(kThreads) void blur_strided_kernel(BlurArgs p) {
   const int n_out = static_cast<int>(min(static_cast<int64_t>(kSeg), p.L - a0));
   const int rows = n_out + 2 * r;
   const float* base = p.in + o * p.L * p.inner + (col_ok ? i0 : 0);
-  for (int t = threadIdx.x; t < 2 * r + 1; t += kThreads) s_taps[t] = p.taps[t];
+  for (int t = threadIdx.x; t < ntaps; t += kThreads) s_taps[t] = p.taps[t];
   // unconditional loads (columns past the volume read column 0 and are never stored), eight in
   // flight per thread
   constexpr int kStep = kThreads / 64, kBatch = 8;
@@ -250,23 +255,51 @@ __global__ __launch_bounds__(kThreads) void blur_strided_kernel(BlurArgs p) {
     }
   }
   __syncthreads();
-  float* obase = p.out + o * p.L * p.inner + i0;
-  for (int k = grp; k < n_out; k += kThreads / 64) {
-    const int64_t a = a0 + k;
-    float acc = 0.0f;
-    for (int t = 0; t < 2 * r + 1; ++t) acc = fmaf(s_taps[t], tile[(k + t) * 64 + lane], acc);
-    if (col_ok) obase[a * p.inner] = acc;
+  const int k0 = grp * OPT;
+  if (k0 >= n_out) return;
+  float acc[OPT];
+#pragma unroll
+  for (int k = 0; k < OPT; ++k) acc[k] = 0.0f;
+  const float* col = tile + k0 * 64 + lane;
+  for (int t0 = 0; t0 < ntaps; t0 += kTapBlock) {
+    float win[OPT + kTapBlock - 1];
+#pragma unroll
+    for (int j = 0; j < OPT + kTapBlock - 1; ++j) win[j] = col[(t0 + j) * 64];
+    if (t0 + kTapBlock <= ntaps) {
+#pragma unroll
+      for (int tt = 0; tt < kTapBlock; ++tt) {
+        const float w = s_taps[t0 + tt];
+#pragma unroll
+        for (int k = 0; k < OPT; ++k) acc[k] = fmaf(w, win[k + tt], acc[k]);
+      }
+    } else {
+#pragma unroll
+      for (int tt = 0; tt < kTapBlock; ++tt) {
+        if (t0 + tt < ntaps) {  // uniform
+          const float w = s_taps[t0 + tt];
+#pragma unroll
+          for (int k = 0; k < OPT; ++k) acc[k] = fmaf(w, win[k + tt], acc[k]);
+        }
+      }
+    }
+  }
+  if (col_ok) {
+    float* obase = p.out + o * p.L * p.inner + i0;
+#pragma unroll
+    for (int k = 0; k < OPT; ++k)
+      if (k0 + k < n_out) obase[(a0 + k0 + k) * p.inner] = acc[k];
   }
 }
 
 constexpr int kRowSeg = 4 * kThreads;  // outputs per row segment of the contiguous-axis kernel
 __global__ __launch_bounds__(kThreads) void blur_contiguous_kernel(BlurArgs p) {
-  extern __shared__ float tile[];  // [kRowSeg + 2r]
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [kRowSeg + 2r + kTapBlock + 4]
   __shared__ float s_taps[2 * kBlurMaxR + 1];
-  const int r = p.r;
+  const int r = p.r, ntaps = 2 * r + 1;
   const int64_t seg_tiles = (p.L + kRowSeg - 1) / kRowSeg;
   const int64_t items = p.outer * seg_tiles;  // (row, segment) pairs; a workgroup walks several
-  for (int t = threadIdx.x; t < 2 * r + 1; t += kThreads) s_taps[t] = p.taps[t];
+  for (int t = threadIdx.x; t < ntaps; t += kThreads) s_taps[t] = p.taps[t];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
   for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
     const int64_t st = item % seg_tiles, row = item / seg_tiles;
     const int64_t a0 = st * kRowSeg;
@@ -286,16 +319,28 @@ __global__ __launch_bounds__(kThreads) void blur_contiguous_kernel(BlurArgs p) {
       }
     }
     __syncthreads();
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int t = 0; t < 2 * r + 1; ++t) {
-      const float w = s_taps[t];
+    const int k0 = 4 * threadIdx.x;  // four consecutive outputs
+    if (k0 < n_out) {
+      float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int t0 = 0; t0 < ntaps; t0 += kTapBlock) {
+        float win[12];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] = fmaf(w, tile[threadIdx.x + k * kThreads + t], acc[k]);
-    }
+        for (int q = 0; q < 3; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(tile + k0 + t0 + 4 * q);
+          win[4 * q] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+        }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int64_t a = a0 + threadIdx.x + k * kThreads;
-      if (a < p.L) p.out[row * p.L + a] = acc[k];
+        for (int tt = 0; tt < kTapBlock; ++tt) {
+          if (t0 + tt < ntaps) {  // uniform; false only in the last block
+            const float w = s_taps[t0 + tt];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(w, win[k + tt], acc[k]);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (a0 + k0 + k < p.L) p.out[row * p.L + a0 + k0 + k] = acc[k];
     }
   }
 }
@@ -491,13 +536,19 @@ extern "C" int lsr_blur_reflect_f32(const float* in, float* out, int64_t Z, int6
     const int64_t items = p.outer * lsr::ceil_div(p.L, static_cast<int64_t>(kRowSeg));
     const int64_t blocks = items < 16384 ? items : 16384;
     hipLaunchKernelGGL(blur_contiguous_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
-                       sizeof(float) * (kRowSeg + 2 * radius), s, p);
+                       sizeof(float) * (kRowSeg + 2 * radius + kTapBlock + 4), s, p);
   } else {
-    const int64_t blocks = p.outer * lsr::ceil_div(p.L, static_cast<int64_t>(kSeg)) * lsr::ceil_div(p.inner, int64_t(64));
+    // 128-position segments (less halo per output) while the tile stays within 64 KB of LDS
+    const bool wide = (128 + 2 * radius + kTapBlock) * 64 * sizeof(float) <= 65536 && p.L > 64;
+    const int seg = wide ? 128 : 64;
+    const int64_t blocks = p.outer * lsr::ceil_div(p.L, static_cast<int64_t>(seg)) * lsr::ceil_div(p.inner, int64_t(64));
     LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
                 (long long)blocks);
-    hipLaunchKernelGGL(blur_strided_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
-                       sizeof(float) * (kSeg + 2 * radius) * 64, s, p);
+    const size_t lds = sizeof(float) * (seg + 2 * radius + kTapBlock) * 64;
+    if (wide)
+      hipLaunchKernelGGL(blur_strided_kernel<32>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), lds, s, p);
+    else
+      hipLaunchKernelGGL(blur_strided_kernel<16>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), lds, s, p);
   }
   return lsr::launch_status("lsr_blur_reflect_f32");
 }
