@@ -537,6 +537,12 @@ extern "C" int lsr_rl_sep_fused_prepare_taps(const float* kz_host, int pz, const
   return LSR_OK;
 }
 
+#ifdef LSR_FUSED_PROBE_TIME
+static unsigned long long* g_fused_probe = nullptr;
+// diagnostic build only: device buffer of 4 * grid uint64 that every fused launch overwrites
+extern "C" void lsr_debug_set_fused_probe(void* dev) { g_fused_probe = static_cast<unsigned long long*>(dev); }
+#endif
+
 extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
                                     float* x_a, float* x_b, float* x_out, int64_t Z, int64_t Y,
                                     int64_t X, const float* taps, int pz, int py, int px,
@@ -573,6 +579,9 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
               "plane strides exceed the kernel's 32-bit in-plane offsets");
 
   lsr::FusedArgs p{};
+#ifdef LSR_FUSED_PROBE_TIME
+  p.probe = g_fused_probe;
+#endif
   p.y = y; p.y_pitch = static_cast<int>(y_pitch); p.y_plane = y_plane;
   p.Z = static_cast<int>(Z); p.Y = static_cast<int>(Y); p.X = static_cast<int>(X);
   p.taps = taps; p.eps = eps;

@@ -111,6 +111,9 @@ struct FusedArgs {
   int n_full;   // tiles [0, n_full) are whole z columns, one workgroup each (dispatched first)
   int pieces;   // every other tile: `pieces` workgroups of z_chunk planes
   int z_chunk;
+#ifdef LSR_FUSED_PROBE_TIME
+  unsigned long long* probe;  // diagnostic build: 4 timestamps per workgroup (tools/fused_drift.py)
+#endif
 };
 // columns staged left and right of a 128-column tile: twice the PSF radius, rounded up to 16 bytes
 constexpr int fused_window_halo(int PYX) { return 4 * ((2 * (PYX / 2) + 3) / 4); }

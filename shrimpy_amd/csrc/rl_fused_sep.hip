@@ -388,8 +388,15 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
   wait_vm<SL + 2 * (NXC + NY)>();  // this wave's part of plane p_lo has landed
   lds_barrier();
 
+#ifdef LSR_FUSED_PROBE_TIME
+  if (p.probe && tid == 0) p.probe[4 * blockIdx.x] = wall_clock64();
+#endif
   for (int pz = p_lo; pz <= p_hi; ++pz) {
     asm volatile("" : "+v"(tv0), "+v"(tv1));  // loop-variant for the optimiser: no hoisting of the taps
+#ifdef LSR_FUSED_PROBE_TIME
+    if (p.probe && tid == 0 && (pz == p_lo + 40 || pz == p_lo + 120))
+      p.probe[4 * blockIdx.x + (pz == p_lo + 40 ? 1 : 2)] = wall_clock64();
+#endif
     const int qr = pz - 1 - CZ;      // ratio plane in R (written by the previous iteration)
     const int o = qr - CZ;           // output plane completed by this iteration
     const int q = pz - CZ;           // ratio plane completed by this iteration
@@ -601,6 +608,9 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
     slot = slot == 2 ? 0 : slot + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land after the wave has ended
+#ifdef LSR_FUSED_PROBE_TIME
+  if (p.probe && tid == 0) p.probe[4 * blockIdx.x + 3] = wall_clock64();
+#endif
 }
 
 template <int PZ, int PYX>
