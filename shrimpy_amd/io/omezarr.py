@@ -28,6 +28,7 @@ from __future__ import annotations
 import gzip
 import itertools
 import json
+import os
 import zlib
 
 from pathlib import Path
@@ -192,6 +193,34 @@ class ZarrArray:
         ranges = [range(-(-self.shape[d] // self.chunks[d])) for d in range(k, n)]
         return itertools.product(*ranges)
 
+    # Chunks of one volume are independent files: they are read / written by a small thread pool
+    # (file I/O and zlib release the GIL), and an uncompressed chunk that is a whole contiguous
+    # z-range of the volume -- the layout the acquisition writes, chunks (1, 1, <=32, ny, nx),
+    # ``shrimpy/dynatrack/tracking.py:1337-1367`` -- moves between the file and the caller's
+    # buffer (e.g. a pinned staging slot) without an intermediate copy.
+    _POOL_MIN_BYTES = 8 << 20
+
+    def _map_chunks(self, fn, cidxs, nbytes):
+        workers = min(16, os.cpu_count() or 1, len(cidxs))
+        if workers <= 1 or nbytes < self._POOL_MIN_BYTES:
+            for c in cidxs:
+                fn(c)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(workers, "lsr-zarr") as pool:
+            list(pool.map(fn, cidxs))  # list(): re-raise the first worker exception
+
+    def _slab_view(self, vol: np.ndarray, sl) -> memoryview | None:
+        """``vol[sl]`` as bytes when that block is a full chunk and contiguous in ``vol``."""
+        vchunks = self.chunks[len(self.shape) - 3:]
+        full = all(s.stop - s.start == c for s, c in zip(sl, vchunks))
+        if not full or self._compress is not None or vol.dtype != self.dtype or not vol.flags.c_contiguous:
+            return None
+        if (sl[1].start, sl[1].stop, sl[2].start, sl[2].stop) != (0, vol.shape[1], 0, vol.shape[2]):
+            return None
+        return memoryview(vol[sl]).cast("B")
+
     def read_volume(self, *lead: int, out: np.ndarray | None = None) -> np.ndarray:
         """The (Z, Y, X) volume at leading indices (t, c) as a C-contiguous array; with ``out``
         (same shape and dtype, e.g. a pinned staging buffer) the chunks are decoded into it."""
@@ -203,18 +232,35 @@ class ZarrArray:
                 raise IndexError(f"index {lead} out of range for shape {self.shape}")
         vshape, vchunks = self.shape[k:], self.chunks[k:]
         if out is None:
-            out = np.full(vshape, self.fill_value, dtype=self.dtype)
-        else:
-            if tuple(out.shape) != tuple(vshape) or out.dtype != self.dtype:
-                raise ValueError(f"out must be {tuple(vshape)} {self.dtype}, got {out.shape} {out.dtype}")
-            out[...] = self.fill_value
-        for cidx in self._grid(tuple(lead)):
-            block = self._read_chunk(tuple(lead) + cidx)
-            if block is None:
-                continue
-            block = block.reshape(self.chunks[k:]) if k else block
+            out = np.empty(vshape, dtype=self.dtype)
+        elif tuple(out.shape) != tuple(vshape) or out.dtype != self.dtype:
+            raise ValueError(f"out must be {tuple(vshape)} {self.dtype}, got {out.shape} {out.dtype}")
+        lead = tuple(lead)
+
+        def read_one(cidx):
             sl = tuple(slice(c * s, min((c + 1) * s, n)) for c, s, n in zip(cidx, vchunks, vshape))
+            path = self._chunk_path(lead + cidx)
+            view = self._slab_view(out, sl)
+            if view is not None:
+                try:
+                    with open(path, "rb", buffering=0) as f:
+                        got = 0
+                        while got < len(view):
+                            n = f.readinto(view[got:])
+                            if not n:
+                                raise OSError(f"chunk {path} is shorter than {len(view)} bytes")
+                            got += n
+                except FileNotFoundError:
+                    out[sl] = self.fill_value
+                return
+            block = self._read_chunk(lead + cidx)
+            if block is None:
+                out[sl] = self.fill_value
+                return
+            block = block.reshape(vchunks)
             out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
+
+        self._map_chunks(read_one, list(self._grid(lead)), out.nbytes)
         return out
 
     def write_volume(self, *args) -> None:
@@ -227,11 +273,24 @@ class ZarrArray:
         if len(lead) != k or tuple(vol.shape) != tuple(self.shape[k:]):
             raise ValueError(f"expected {k} indices and a volume of shape {self.shape[k:]}, got {vol.shape}")
         vchunks = self.chunks[k:]
-        for cidx in self._grid(tuple(lead)):
+        lead = tuple(lead)
+
+        def write_one(cidx):
             sl = tuple(slice(c * s, min((c + 1) * s, n)) for c, s, n in zip(cidx, vchunks, vol.shape))
+            view = self._slab_view(vol, sl)
+            if view is not None:
+                path = self._chunk_path(lead + cidx)
+                path.parent.mkdir(parents=True, exist_ok=True)
+                with open(path, "wb", buffering=0) as f:
+                    done = 0
+                    while done < len(view):
+                        done += f.write(view[done:])
+                return
             block = np.zeros(self.chunks, dtype=self.dtype)
             block.reshape(vchunks)[tuple(slice(0, s.stop - s.start) for s in sl)] = vol[sl]
-            self._write_chunk(tuple(lead) + cidx, block)
+            self._write_chunk(lead + cidx, block)
+
+        self._map_chunks(write_one, list(self._grid(lead)), vol.nbytes)
 
     def __getitem__(self, key):
         """Convenience for tests: ``arr[t, c]`` -> volume; ``arr[:]`` -> everything."""
