@@ -1,0 +1,170 @@
+"""Parity at BASELINE config 2's full size: raw (2048, 512, 2048) -> (171, 2048, 2270) -> 20-iteration RL.
+
+The oracle cannot run the whole volume in test time, so it runs where the domain lets a part stand
+for the whole: the deskew is independent per raw-X column (Y' is raw X reversed; the reference
+chunks along it, ``scripts/measure_psf.py:221-249``), and after n RL iterations a voxel depends
+only on the input within n * 2 * (PSF radius) of it -- so the oracle deskews column slabs and
+deconvolves crops with that margin, and the device result of the full-size run must match there.
+The rest are properties that hold at any size: the one-launch and two-launch RL agree bit for bit,
+flux weighted by the border normalisation is conserved, the uint16 input path equals the float one.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as o
+
+pytestmark = pytest.mark.gpu
+
+RAW_SHAPE = (2048, 512, 2048)
+DESKEW = dict(ls_angle_deg=30.0, px_to_scan_ratio=0.755, keep_overhang=False, average_n_slices=3)
+PSF_SHAPE, PSF_SIGMA = (9, 7, 7), (2.0, 1.2, 1.2)
+
+
+@pytest.fixture(scope="module")
+def scene(device):
+    """Raw bead scene (seed per SURVEY 8(d): 1000 * config + 7 * position) and its deskew, on the device."""
+    import torch
+
+    import bench
+    from shrimpy_amd.deskew import fast_deskew_zyx
+
+    raw = bench.synthetic_raw(RAW_SHAPE, seed=2000, device=device)
+    deskewed = fast_deskew_zyx(raw_data=raw, **DESKEW)
+    assert tuple(deskewed.shape) == (171, 2048, 2270)
+    yield raw, deskewed
+    del raw, deskewed
+    torch.cuda.empty_cache()
+
+
+def test_deskew_full_size_matches_the_oracle_on_raw_x_slabs(scene):
+    raw, deskewed = scene
+    X = RAW_SHAPE[2]
+    for a, b in ((0, 3), (1021, 1025), (X - 2, X)):
+        slab = raw[:, :, a:b].contiguous().cpu().numpy()
+        want = o.deskew(slab, DESKEW["ls_angle_deg"], DESKEW["px_to_scan_ratio"], DESKEW["keep_overhang"],
+                        DESKEW["average_n_slices"])
+        got = deskewed[:, X - b:X - a, :].cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+
+
+def test_deskew_full_size_uint16_input_gives_the_same_bits(scene, device):
+    import torch
+
+    from shrimpy_amd.deskew import fast_deskew_zyx
+
+    raw, deskewed = scene
+    assert float(raw.max()) < 65536 and bool((raw == raw.round()).all())  # Poisson counts
+    raw16 = raw.to(torch.uint16)
+    assert torch.equal(fast_deskew_zyx(raw_data=raw16, **DESKEW), deskewed)
+
+
+@pytest.fixture(scope="module")
+def deconvolved(scene, device):
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+
+    _, deskewed = scene
+    factors = o.gaussian_psf(PSF_SHAPE, PSF_SIGMA)[1]
+    plan = RichardsonLucyPlan(tuple(deskewed.shape), None, device, psf_factors=factors)
+    assert plan.fused
+    out = plan(deskewed, iterations=20)
+    return plan, factors, out
+
+
+def test_rl_full_size_one_launch_equals_two_launch_bit_for_bit(scene, deconvolved, device):
+    import torch
+
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+
+    _, deskewed = scene
+    _, factors, fused = deconvolved
+    plan = RichardsonLucyPlan(tuple(deskewed.shape), None, device, psf_factors=factors, fused="never")
+    two = plan(deskewed, iterations=20)
+    plan.release()
+    assert torch.equal(fused, two)
+
+
+def test_rl_full_size_is_finite_non_negative_and_conserves_weighted_flux(scene, deconvolved):
+    """sum_v x_new(v) * (H^T 1)(v) = sum_u y(u) * (Hx)(u) / ((Hx)(u) + eps) ~= sum y."""
+    import torch
+
+    _, deskewed = scene
+    plan, _, x = deconvolved
+    assert bool(torch.isfinite(x).all()) and float(x.min()) >= 0
+    nz, ny, nx = (n.double() for n in plan._norm)
+    flux = torch.einsum("zyx,z,y,x->", x.double(), nz, ny, nx)
+    total = deskewed.double().sum()
+    assert abs(float(flux / total) - 1.0) < 1e-4
+
+
+@pytest.mark.parametrize("where", ["interior", "corner"])
+def test_rl_full_size_matches_the_oracle_on_a_crop_with_full_margin(scene, deconvolved, where):
+    """20 iterations reach 20 * 2 * (4, 3, 3) = (160, 120, 120) voxels: all of z, 120 in the plane."""
+    _, deskewed = scene
+    _, factors, x = deconvolved
+    margin, core = 120, 48
+    if where == "interior":
+        y0, x0 = 900, 1300
+        crop = (slice(None), slice(y0 - margin, y0 + core + margin), slice(x0 - margin, x0 + core + margin))
+        inner = (slice(None), slice(margin, margin + core), slice(margin, margin + core))
+        full = (slice(None), slice(y0, y0 + core), slice(x0, x0 + core))
+    else:  # the volume's own (y, x) = (0, 0) corner: real borders on two sides, margin on the others
+        crop = (slice(None), slice(0, core + margin), slice(0, core + margin))
+        inner = (slice(None), slice(0, core), slice(0, core))
+        full = inner
+    y_crop = deskewed[crop].contiguous().cpu().numpy()
+    want = o.richardson_lucy_separable(y_crop, factors, iterations=20)[inner].astype(np.float64)
+    got = x[full].cpu().numpy().astype(np.float64)
+    tol = 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max()   # the RL bar of tests/test_gpu_parity.py
+    assert np.all(np.abs(got - want) <= tol), float(np.max(np.abs(got - want) / tol))
+
+
+# ---------------------------------------------------------------- config 3: registration apply
+
+
+def _config3_matrix():
+    """rotation 2 deg about Z, scale (1, .98, 1.02), translation (3.5,-12.25,20.75)."""
+    th = np.deg2rad(2.0)
+    rot = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]])
+    m = np.eye(4)
+    m[:3, :3] = rot @ np.diag([1.0, 0.98, 1.02])
+    m[:3, 3] = [3.5, -12.25, 20.75]
+    return m
+
+
+def test_affine_full_size_matches_the_oracle_on_output_blocks(device):
+    """(256, 2048, 2048) moving volume, config-3 matrix: scipy evaluates output blocks from the
+    source box they reach (cropped where that box is inside the volume, cut at the volume's own
+    faces where it is not).  The block-local coordinates differ from the whole-grid ones in the last
+    fp64 bit, so a float32 result may round the other way: one ulp is allowed."""
+    import torch
+
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    shape = (256, 2048, 2048)
+    g = torch.Generator(device=device).manual_seed(3000)
+    moving = torch.rand(shape, device=device, generator=g) * 1000 - 100
+    m = _config3_matrix()
+    out = apply_affine_transform_zyx(moving, m, shape, cval=-3.0)
+    blocks = [((100, 1000, 900), (8, 40, 60)),      # interior
+              ((0, 0, 0), (8, 40, 60)),             # source coordinates below 0 in y: cval region
+              ((250, 2000, 1980), (6, 48, 68))]     # far corner: beyond the last source voxels
+    for origin, size in blocks:
+        origin, size = np.array(origin), np.array(size)
+        corners = np.array([[origin[i] + (size[i] - 1) * ((c >> i) & 1) for i in range(3)] for c in range(8)])
+        src = corners @ m[:3, :3].T + m[:3, 3]
+        lo = np.maximum(np.floor(src.min(0)).astype(int) - 2, 0)
+        hi = np.minimum(np.ceil(src.max(0)).astype(int) + 3, np.array(shape))
+        if np.any(hi - lo < 2):   # the block sees nothing of the volume
+            assert bool((out[tuple(slice(a, a + n) for a, n in zip(origin, size))] == -3.0).all())
+            continue
+        crop = moving[tuple(slice(a, b) for a, b in zip(lo, hi))].contiguous().cpu().numpy()
+        offset = m[:3, :3] @ origin + m[:3, 3] - lo
+        # cut faces of the crop that are not faces of the volume must be out of the block's reach
+        assert np.all((lo == 0) | (src.min(0) - lo >= 1)) and np.all((hi == shape) | (hi - 1 - src.max(0) >= 1))
+        want = o.affine_apply(crop, m[:3, :3], offset, tuple(size), cval=-3.0)
+        got = out[tuple(slice(a, a + n) for a, n in zip(origin, size))].cpu().numpy()
+        np.testing.assert_array_max_ulp(got, want, maxulp=1)
+        assert np.mean(got == want) > 0.95
+    del moving, out
+    torch.cuda.empty_cache()
