@@ -168,3 +168,34 @@ def test_affine_full_size_matches_the_oracle_on_output_blocks(device):
         assert np.mean(got == want) > 0.95
     del moving, out
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------- the rows either side, full size
+
+
+def test_flatfield_full_size_median_is_exact_on_row_slabs(scene):
+    """Per-pixel median over 2048 raw planes: numpy sorts the columns of a few (y) rows."""
+    from shrimpy_amd.flatfield import flat_field_pattern
+
+    raw, _ = scene
+    ff = flat_field_pattern(raw)
+    pattern = ff.pattern.cpu().numpy()
+    for y in (0, 255, 511):
+        col = raw[:, y, :].cpu().numpy()
+        srt = np.sort(col, axis=0)
+        a, b = srt[col.shape[0] // 2 - 1], srt[col.shape[0] // 2]    # even Z: torch.quantile lerps
+        np.testing.assert_array_equal(pattern[y], b - (b - a) * np.float32(0.5))
+    assert float(ff.mean) == pytest.approx(float(pattern.astype(np.float64).mean()), rel=1e-6)
+
+
+def test_estimators_full_size_match_the_oracle(scene):
+    """Histogram percentile and intensity centroid of the whole (171, 2048, 2270) deskewed volume."""
+    from shrimpy_amd import dynatrack as d
+
+    _, deskewed = scene
+    host = deskewed.cpu().numpy()
+    for p in (50.0, 99.0):
+        assert d._percentile(deskewed, p) == pytest.approx(o.dt_percentile(host, p), rel=1e-6)
+    bg = o.dt_percentile(host, 90.0)
+    np.testing.assert_allclose(d._intensity_center_of_mass(deskewed, bg).cpu().numpy(),
+                               o.dt_intensity_center_of_mass(host, bg), atol=2e-3)
