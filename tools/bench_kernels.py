@@ -159,6 +159,15 @@ def _estimators(args, torch, dev, g, oshape):
         ms = timed(fn, max(1, args.reps // 2))
         print(json.dumps({"kernel": name, "grid": oshape, "ms": ms, "volume_traversals": passes,
                           "traversal_GBps": passes * 4.0 * n / ms / 1e6}))
+    # the reference's default tracker (dynatrack_demo.yaml:107): phase cross-correlation
+    mov = torch.roll(vol, shifts=(2, -5, 7), dims=(0, 1, 2))
+    shift = d._phase_cross_corr(vol, mov)
+    assert shift in ((2, -5, 7), (-2, 5, -7)), shift
+    ms = timed(lambda: d._phase_cross_corr(vol, mov), max(1, args.reps // 2))
+    print(json.dumps({"kernel": "_phase_cross_corr (2 rfftn + irfftn via rocFFT, 3 kernels)", "grid": oshape, "ms": ms,
+                      "rolled_by": [2, -5, 7], "found": list(shift)}))
+    ms = timed(lambda: torch.fft.rfftn(vol), max(1, args.reps // 2))
+    print(json.dumps({"kernel": "torch.fft.rfftn alone (rocFFT)", "grid": oshape, "ms": ms}))
 
 
 def _rl(args, torch, dev, g, bench, RichardsonLucyPlan, oshape):
