@@ -312,6 +312,9 @@ int lsr_blur_reflect_f32(const float* in, float* out, int64_t Z, int64_t Y, int6
 int lsr_match_shape_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
                         int64_t Yo, int64_t Xo, lsr_stream_t stream);
 int lsr_cross_power_c64(float* a, const float* b, int64_t n, lsr_stream_t stream);
+/* b <- a * conj(b): the same product written over the second operand, so that `a` (the spectrum of
+ * a reference volume that is compared against many timepoints) can be kept. */
+int lsr_cross_power_into_c64(const float* a, float* b, int64_t n, lsr_stream_t stream);
 int lsr_peak_abs_shifted_f32(const float* in, int64_t Z, int64_t Y, int64_t X, long long* out_index,
                              void* scratch, lsr_stream_t stream);
 

@@ -370,15 +370,20 @@ __global__ __launch_bounds__(kThreads) void match_shape_kernel(MatchArgs p) {
   }
 }
 
-// prod = f1 * conj(f2), in place in f1 (complex64 as float pairs)
-__global__ __launch_bounds__(kThreads) void cross_power_kernel(float* __restrict__ a, const float* __restrict__ b,
+// prod = f1 * conj(f2) (complex64 as float pairs), written over f1 (INTO_B = false) or over f2
+// (INTO_B = true: f1, e.g. a cached spectrum of the reference volume, stays intact)
+template <bool INTO_B>
+__global__ __launch_bounds__(kThreads) void cross_power_kernel(float* __restrict__ a, float* __restrict__ b,
                                                                int64_t n) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  f32x2* a2 = reinterpret_cast<f32x2*>(a);
+  f32x2* b2 = reinterpret_cast<f32x2*>(b);
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
-    const float ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
+    const f32x2 va = a2[i], vb = b2[i];
     // (ar + i ai)(br - i bi), the products and sums torch's complex multiply performs
-    a[2 * i] = ar * br + ai * bi;
-    a[2 * i + 1] = ai * br - ar * bi;
+    const f32x2 r = {va.x * vb.x + va.y * vb.y, va.y * vb.x - va.x * vb.y};
+    (INTO_B ? b2 : a2)[i] = r;
   }
 }
 
@@ -575,8 +580,22 @@ extern "C" int lsr_cross_power_c64(float* a, const float* b, int64_t n, lsr_stre
   LSR_REQUIRE_PTR(a);
   LSR_REQUIRE_PTR(b);
   LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
-  hipLaunchKernelGGL(cross_power_kernel, dim3(grid_for(n) * 4), dim3(kThreads), 0, lsr::as_stream(stream), a, b, n);
+  LSR_REQUIRE((reinterpret_cast<uintptr_t>(a) & 7) == 0 && (reinterpret_cast<uintptr_t>(b) & 7) == 0, LSR_E_ARG,
+              "complex64 arrays must be 8-byte aligned");
+  hipLaunchKernelGGL(cross_power_kernel<false>, dim3(grid_for(n) * 4), dim3(kThreads), 0, lsr::as_stream(stream), a,
+                     const_cast<float*>(b), n);
   return lsr::launch_status("lsr_cross_power_c64");
+}
+
+extern "C" int lsr_cross_power_into_c64(const float* a, float* b, int64_t n, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(a);
+  LSR_REQUIRE_PTR(b);
+  LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  LSR_REQUIRE((reinterpret_cast<uintptr_t>(a) & 7) == 0 && (reinterpret_cast<uintptr_t>(b) & 7) == 0, LSR_E_ARG,
+              "complex64 arrays must be 8-byte aligned");
+  hipLaunchKernelGGL(cross_power_kernel<true>, dim3(grid_for(n) * 4), dim3(kThreads), 0, lsr::as_stream(stream),
+                     const_cast<float*>(a), b, n);
+  return lsr::launch_status("lsr_cross_power_into_c64");
 }
 
 extern "C" int lsr_peak_abs_shifted_f32(const float* in, int64_t Z, int64_t Y, int64_t X, long long* out_index,

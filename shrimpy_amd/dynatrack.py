@@ -42,7 +42,7 @@ __all__ = [
     "_gaussian_blur_3d", "_multiotsu_threshold", "_binary_mask", "_center_of_mass", "_percentile",
     "_intensity_center_of_mass", "_intensity_center_of_mass_to_roi_center", "_multiotsu_center_of_mass",
     "_next_fast_len", "_match_shape", "_phase_cross_corr", "_centered_gaussian_blob", "_roi_center_pcc",
-    "_multiotsu_pcc",
+    "_multiotsu_pcc", "set_spectrum_cache_bytes",
 ]
 
 
@@ -271,6 +271,71 @@ def _multiotsu_center_of_mass(ref_img, mov_img, sigma: float = 5.0, otsu_compone
     return tuple(float(s) for s in shift)
 
 
+class _SpectrumCache:
+    """Spectra of reference volumes, kept between timepoints.
+
+    The updater compares every timepoint of a position with one stored reference tensor
+    (``tracking.py:1119-1151``), so one of the two forward FFTs of ``_phase_cross_corr`` -- a third of
+    its time -- repeats identical work.  Entries are keyed by the tensor OBJECT (weak reference;
+    the entry goes when the tensor does) and checked against its version counter, storage and
+    shape, so an in-place edit or a different tensor is a miss, never a stale hit.  Byte-bounded
+    LRU; ``set_spectrum_cache_bytes(0)`` turns it off.
+    """
+
+    def __init__(self, max_bytes: int):
+        from collections import OrderedDict
+
+        self.max_bytes = int(max_bytes)
+        self._entries: "OrderedDict[int, tuple]" = OrderedDict()
+        self._bytes = 0
+        self.hits = self.misses = 0
+
+    def _drop(self, key):
+        e = self._entries.pop(key, None)
+        if e is not None:
+            self._bytes -= e[-1].numel() * e[-1].element_size()
+
+    def clear(self):
+        self._entries.clear()
+        self._bytes = 0
+
+    def get(self, t, fft_shape):
+        e = self._entries.get(id(t))
+        if e is not None:
+            ref, version, ptr, shape, fshape, spec = e
+            if ref() is t and version == t._version and ptr == t.data_ptr() and shape == tuple(t.shape) \
+                    and fshape == tuple(fft_shape):
+                self._entries.move_to_end(id(t))
+                self.hits += 1
+                return spec
+            self._drop(id(t))
+        self.misses += 1
+        return None
+
+    def put(self, t, fft_shape, spec):
+        import weakref
+
+        nbytes = spec.numel() * spec.element_size()
+        if nbytes > self.max_bytes:
+            return
+        key = id(t)
+        self._drop(key)
+        while self._entries and self._bytes + nbytes > self.max_bytes:
+            self._drop(next(iter(self._entries)))
+        self._entries[key] = (weakref.ref(t, lambda _r, k=key: self._drop(k)), t._version, t.data_ptr(),
+                              tuple(t.shape), tuple(fft_shape), spec)
+        self._bytes += nbytes
+
+
+_spectra = _SpectrumCache(8 << 30)
+
+
+def set_spectrum_cache_bytes(n: int) -> None:
+    """Upper bound on device memory held by cached reference spectra (default 8 GiB; 0 = off)."""
+    _spectra.max_bytes = int(n)
+    _spectra.clear()
+
+
 def _next_fast_len(n: int) -> int:
     """Smallest 5-smooth integer >= n (``tracking.py:248-263``)."""
     if n <= 1:
@@ -315,14 +380,21 @@ def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0) -> tuple[int
     shape = tuple(_next_fast_len(int(max(s1, s2) * maximum_shift)) for s1, s2 in zip(ref_t.shape, mov_t.shape))
     logger.debug("phase cross corr: fft shape %s for arrays %s and %s (max_shift=%.2f)", shape,
                  tuple(ref_t.shape), tuple(mov_t.shape), maximum_shift)
-    fimg1 = torch.fft.rfftn(_match_shape(ref_t, shape))
+    # the reference's spectrum is reused while the caller keeps comparing against the same tensor
+    cacheable = ref_t is ref_img and _spectra.max_bytes > 0
+    fimg1 = _spectra.get(ref_t, shape) if cacheable else None
+    if fimg1 is None:
+        fimg1 = torch.fft.rfftn(_match_shape(ref_t, shape))
+        if cacheable:
+            _spectra.put(ref_t, shape, fimg1)
     fimg2 = torch.fft.rfftn(_match_shape(mov_t, shape))
-    with torch.cuda.device(fimg1.device):
-        stream = _lib.stream_ptr(fimg1.device)
-        _lib.call("lsr_cross_power_c64", fimg1.data_ptr(), fimg2.data_ptr(), fimg1.numel(), stream)
-        del fimg2
-        corr = torch.fft.irfftn(fimg1, s=shape).contiguous()
+    with torch.cuda.device(fimg2.device):
+        stream = _lib.stream_ptr(fimg2.device)
+        # f1 * conj(f2), written over f2: f1 may be the cached spectrum
+        _lib.call("lsr_cross_power_into_c64", fimg1.data_ptr(), fimg2.data_ptr(), fimg2.numel(), stream)
         del fimg1
+        corr = torch.fft.irfftn(fimg2, s=shape).contiguous()
+        del fimg2
         peak_index = torch.empty((1,), dtype=torch.int64, device=corr.device)
         _lib.call("lsr_peak_abs_shifted_f32", corr.data_ptr(), *shape, peak_index.data_ptr(),
                   _scratch(corr.device).data_ptr(), stream)

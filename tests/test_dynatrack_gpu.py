@@ -163,3 +163,41 @@ def test_cpu_tensors_fail_loudly(device):
 
     with pytest.raises(LsrError, match="no CPU fallback"):
         d._percentile(torch.zeros(2, 3, 4), 50.0)
+
+
+def test_phase_cross_corr_reuses_the_reference_spectrum_safely(device):
+    """Same reference tensor across timepoints: one forward FFT is skipped, the shifts do not change;
+    an in-place edit of the reference or another tensor is a miss."""
+    import torch
+
+    from shrimpy_amd import dynatrack as d
+
+    rng = np.random.default_rng(77)
+    ref = torch.as_tensor(rng.random((12, 40, 36)).astype(np.float32), device=device)
+    d.set_spectrum_cache_bytes(1 << 30)
+    d._spectra.hits = d._spectra.misses = 0
+    want = []
+    for k, shift in enumerate(((1, 2, -3), (0, -4, 5), (-2, 0, 1))):
+        mov = torch.roll(ref, shifts=shift, dims=(0, 1, 2))
+        got = d._phase_cross_corr(ref, mov)
+        want.append(got)
+        assert got == shift
+    assert (d._spectra.hits, d._spectra.misses) == (2, 1)
+    d.set_spectrum_cache_bytes(0)                      # off: same answers without the cache
+    for shift, w in zip(((1, 2, -3), (0, -4, 5), (-2, 0, 1)), want):
+        assert d._phase_cross_corr(ref, torch.roll(ref, shifts=shift, dims=(0, 1, 2))) == w
+    d.set_spectrum_cache_bytes(1 << 30)
+    d._spectra.hits = d._spectra.misses = 0
+    d._phase_cross_corr(ref, ref)
+    ref.mul_(2.0).add_(torch.roll(ref, 1, 0))          # in-place edit bumps the version: a miss
+    assert d._phase_cross_corr(ref, torch.roll(ref, shifts=(1, 1, 1), dims=(0, 1, 2))) == (1, 1, 1)
+    assert d._spectra.hits == 0 and d._spectra.misses == 2
+    other = ref.clone()
+    assert d._phase_cross_corr(other, torch.roll(other, shifts=(0, 2, 0), dims=(0, 1, 2))) == (0, 2, 0)
+    assert d._spectra.misses == 3
+    n_before = len(d._spectra._entries)
+    del other
+    import gc
+    gc.collect()
+    assert len(d._spectra._entries) == n_before - 1   # the entry went with its tensor
+    d.set_spectrum_cache_bytes(8 << 30)

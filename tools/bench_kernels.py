@@ -163,9 +163,15 @@ def _estimators(args, torch, dev, g, oshape):
     mov = torch.roll(vol, shifts=(2, -5, 7), dims=(0, 1, 2))
     shift = d._phase_cross_corr(vol, mov)
     assert shift in ((2, -5, 7), (-2, 5, -7)), shift
+    d.set_spectrum_cache_bytes(0)
     ms = timed(lambda: d._phase_cross_corr(vol, mov), max(1, args.reps // 2))
     print(json.dumps({"kernel": "_phase_cross_corr (2 rfftn + irfftn via rocFFT, 3 kernels)", "grid": oshape, "ms": ms,
                       "rolled_by": [2, -5, 7], "found": list(shift)}))
+    d.set_spectrum_cache_bytes(8 << 30)
+    ms = timed(lambda: d._phase_cross_corr(vol, mov), max(1, args.reps // 2))
+    print(json.dumps({"kernel": "_phase_cross_corr, reference spectrum cached (rfftn + irfftn, 3 kernels)",
+                      "grid": oshape, "ms": ms}))
+    d.set_spectrum_cache_bytes(0)
     ms = timed(lambda: torch.fft.rfftn(vol), max(1, args.reps // 2))
     print(json.dumps({"kernel": "torch.fft.rfftn alone (rocFFT)", "grid": oshape, "ms": ms}))
 
