@@ -258,80 +258,97 @@ def _intensity_center_of_mass_to_roi_center(current_img, background_percentile: 
 def _multiotsu_center_of_mass(ref_img, mov_img, sigma: float = 5.0, otsu_component: int = 0) -> tuple[float, ...]:
     """Shift between the multi-Otsu mask centroids of two volumes, ZYX pixels (``:759-787``)."""
     centers = []
-    for img in (ref_img, mov_img):
+    for k, img in enumerate((ref_img, mov_img)):
         vol = _volume(img)
-        blurred, threshold = _blurred_and_threshold(vol, sigma, otsu_component)
-        if blurred is None:
-            centers.append(np.zeros(3, np.float32))        # empty mask -> origin (:559-560)
-        else:
-            centers.append(_center_of_mass(blurred, _threshold=threshold).cpu().numpy())
+        tag = ("multiotsu_center", float(sigma), int(otsu_component))
+        cacheable = k == 0 and vol is img and _spectra.max_bytes > 0   # the stored reference tensor
+        center = _spectra.get(vol, tag) if cacheable else None
+        if center is None:
+            blurred, threshold = _blurred_and_threshold(vol, sigma, otsu_component)
+            if blurred is None:
+                center = np.zeros(3, np.float32)        # empty mask -> origin (:559-560)
+            else:
+                center = _center_of_mass(blurred, _threshold=threshold).cpu().numpy()
+            if cacheable:
+                _spectra.put(vol, tag, center)
+        centers.append(center)
     shift = centers[1] - centers[0]
     logger.debug("multiotsu_center_of_mass: ref_center=%s mov_center=%s shift=%s", centers[0].tolist(),
                  centers[1].tolist(), shift.tolist())
     return tuple(float(s) for s in shift)
 
 
-class _SpectrumCache:
-    """Spectra of reference volumes, kept between timepoints.
+class _ReferenceCache:
+    """Results derived from a reference volume, kept between timepoints.
 
     The updater compares every timepoint of a position with one stored reference tensor
-    (``tracking.py:1119-1151``), so one of the two forward FFTs of ``_phase_cross_corr`` -- a third of
-    its time -- repeats identical work.  Entries are keyed by the tensor OBJECT (weak reference;
-    the entry goes when the tensor does) and checked against its version counter, storage and
-    shape, so an in-place edit or a different tensor is a miss, never a stale hit.  Byte-bounded
-    LRU; ``set_spectrum_cache_bytes(0)`` turns it off.
+    (``tracking.py:1119-1151``), so whatever an estimator computes from the reference alone -- its
+    spectrum (a third of ``_phase_cross_corr``), its multi-Otsu mask or that mask's centroid (half
+    of ``_multiotsu_center_of_mass``) -- repeats identical work.  Entries are keyed by the tensor
+    OBJECT (weak reference; the entries go when the tensor does) plus a tag, and checked against
+    the tensor's version counter, storage and shape, so an in-place edit or a different tensor is a
+    miss, never a stale hit.  Byte-bounded LRU over the device tensors it holds;
+    ``set_spectrum_cache_bytes(0)`` turns it off.
     """
 
     def __init__(self, max_bytes: int):
         from collections import OrderedDict
 
         self.max_bytes = int(max_bytes)
-        self._entries: "OrderedDict[int, tuple]" = OrderedDict()
+        self._entries: "OrderedDict[tuple, tuple]" = OrderedDict()
         self._bytes = 0
         self.hits = self.misses = 0
+
+    @staticmethod
+    def _nbytes(value) -> int:
+        return value.numel() * value.element_size() if hasattr(value, "element_size") else 0
 
     def _drop(self, key):
         e = self._entries.pop(key, None)
         if e is not None:
-            self._bytes -= e[-1].numel() * e[-1].element_size()
+            self._bytes -= self._nbytes(e[-1])
+
+    def _drop_tensor(self, tid):
+        for key in [k for k in self._entries if k[0] == tid]:
+            self._drop(key)
 
     def clear(self):
         self._entries.clear()
         self._bytes = 0
 
-    def get(self, t, fft_shape):
-        e = self._entries.get(id(t))
+    def get(self, t, tag):
+        key = (id(t), tag)
+        e = self._entries.get(key)
         if e is not None:
-            ref, version, ptr, shape, fshape, spec = e
-            if ref() is t and version == t._version and ptr == t.data_ptr() and shape == tuple(t.shape) \
-                    and fshape == tuple(fft_shape):
-                self._entries.move_to_end(id(t))
+            ref, version, ptr, shape, value = e
+            if ref() is t and version == t._version and ptr == t.data_ptr() and shape == tuple(t.shape):
+                self._entries.move_to_end(key)
                 self.hits += 1
-                return spec
-            self._drop(id(t))
+                return value
+            self._drop_tensor(id(t))
         self.misses += 1
         return None
 
-    def put(self, t, fft_shape, spec):
+    def put(self, t, tag, value):
         import weakref
 
-        nbytes = spec.numel() * spec.element_size()
-        if nbytes > self.max_bytes:
+        nbytes = self._nbytes(value)
+        if self.max_bytes <= 0 or nbytes > self.max_bytes:
             return
-        key = id(t)
+        key = (id(t), tag)
         self._drop(key)
         while self._entries and self._bytes + nbytes > self.max_bytes:
             self._drop(next(iter(self._entries)))
-        self._entries[key] = (weakref.ref(t, lambda _r, k=key: self._drop(k)), t._version, t.data_ptr(),
-                              tuple(t.shape), tuple(fft_shape), spec)
+        self._entries[key] = (weakref.ref(t, lambda _r, tid=id(t): self._drop_tensor(tid)), t._version,
+                              t.data_ptr(), tuple(t.shape), value)
         self._bytes += nbytes
 
 
-_spectra = _SpectrumCache(8 << 30)
+_spectra = _ReferenceCache(8 << 30)
 
 
 def set_spectrum_cache_bytes(n: int) -> None:
-    """Upper bound on device memory held by cached reference spectra (default 8 GiB; 0 = off)."""
+    """Upper bound on device memory held by cached reference results (default 8 GiB; 0 = off)."""
     _spectra.max_bytes = int(n)
     _spectra.clear()
 
@@ -382,11 +399,11 @@ def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0) -> tuple[int
                  tuple(ref_t.shape), tuple(mov_t.shape), maximum_shift)
     # the reference's spectrum is reused while the caller keeps comparing against the same tensor
     cacheable = ref_t is ref_img and _spectra.max_bytes > 0
-    fimg1 = _spectra.get(ref_t, shape) if cacheable else None
+    fimg1 = _spectra.get(ref_t, ("rfftn", shape)) if cacheable else None
     if fimg1 is None:
         fimg1 = torch.fft.rfftn(_match_shape(ref_t, shape))
         if cacheable:
-            _spectra.put(ref_t, shape, fimg1)
+            _spectra.put(ref_t, ("rfftn", shape), fimg1)
     fimg2 = torch.fft.rfftn(_match_shape(mov_t, shape))
     with torch.cuda.device(fimg2.device):
         stream = _lib.stream_ptr(fimg2.device)
@@ -418,10 +435,19 @@ def _centered_gaussian_blob(shape, sigma: float, device):
     return blob
 
 
+_blobs: dict = {}
+
+
 def _roi_center_pcc(current_img, blob_sigma: float = 10.0, maximum_shift: float = 1.0) -> tuple[int, ...]:
     """Shift of the bright structure from the ROI centre: PCC against a centred blob (``:735-756``)."""
     img = _volume(current_img, "current_img")
-    blob = _centered_gaussian_blob(tuple(img.shape), blob_sigma, img.device)
+    # one blob object per (shape, sigma, device): its spectrum is then reused like a reference's
+    key = (tuple(img.shape), float(blob_sigma), str(img.device))
+    blob = _blobs.get(key)
+    if blob is None:
+        if len(_blobs) >= 2:
+            _blobs.pop(next(iter(_blobs)))
+        blob = _blobs[key] = _centered_gaussian_blob(tuple(img.shape), blob_sigma, img.device)
     return _phase_cross_corr(blob, img, maximum_shift)
 
 
@@ -430,6 +456,12 @@ def _multiotsu_pcc(ref_img, mov_img, sigma: float = 5.0, otsu_component: int = 0
     """PCC on the multi-Otsu masks of two volumes (``tracking.py:790-815``)."""
     import torch
 
-    ref_mask = _binary_mask(ref_img, sigma=sigma, otsu_component=otsu_component).to(dtype=torch.float32)
+    tag = ("multiotsu_mask", float(sigma), int(otsu_component))
+    cacheable = isinstance(ref_img, torch.Tensor) and _spectra.max_bytes > 0
+    ref_mask = _spectra.get(ref_img, tag) if cacheable else None
+    if ref_mask is None:
+        ref_mask = _binary_mask(ref_img, sigma=sigma, otsu_component=otsu_component).to(dtype=torch.float32)
+        if cacheable:   # the same mask object next time: its spectrum is then cached as well
+            _spectra.put(ref_img, tag, ref_mask)
     mov_mask = _binary_mask(mov_img, sigma=sigma, otsu_component=otsu_component).to(dtype=torch.float32)
     return _phase_cross_corr(ref_mask, mov_mask, maximum_shift)

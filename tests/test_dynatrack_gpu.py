@@ -201,3 +201,28 @@ def test_phase_cross_corr_reuses_the_reference_spectrum_safely(device):
     gc.collect()
     assert len(d._spectra._entries) == n_before - 1   # the entry went with its tensor
     d.set_spectrum_cache_bytes(8 << 30)
+
+
+def test_reference_results_are_reused_by_every_two_volume_tracker(device):
+    """multiotsu centre / mask of the stored reference and the ROI blob are computed once; the
+    shifts equal the uncached ones."""
+    import torch
+
+    from shrimpy_amd import dynatrack as d
+
+    rng = np.random.default_rng(9)
+    base = np.zeros((24, 72, 80), np.float32)
+    base[8:15, 20:44, 30:58] = 50.0
+    ref = torch.as_tensor(base + rng.random(base.shape).astype(np.float32), device=device)
+    movs = [torch.roll(ref, shifts=s, dims=(0, 1, 2)) for s in ((1, 3, -2), (0, -5, 4))]
+    d.set_spectrum_cache_bytes(0)
+    want = [(d._multiotsu_center_of_mass(ref, m, 2.0), d._multiotsu_pcc(ref, m, 2.0), d._roi_center_pcc(m, 6.0))
+            for m in movs]
+    d.set_spectrum_cache_bytes(1 << 30)
+    d._spectra.hits = d._spectra.misses = 0
+    got = [(d._multiotsu_center_of_mass(ref, m, 2.0), d._multiotsu_pcc(ref, m, 2.0), d._roi_center_pcc(m, 6.0))
+           for m in movs]
+    assert got == want
+    # second timepoint: centre, mask, the mask's spectrum and the blob's spectrum all hit
+    assert d._spectra.hits == 4
+    d.set_spectrum_cache_bytes(8 << 30)
