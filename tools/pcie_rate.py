@@ -73,6 +73,26 @@ def main():
         line(mode, time.perf_counter() - t0, n, host_GB=host.nbytes / 1e9)
         del res, host
 
+    # the two halves of the synchronous hand-over, separately
+    torch.as_tensor(raw16, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        d16 = torch.as_tensor(raw16, device=dev)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print(json.dumps({"copy": "torch.as_tensor(pageable uint16 stack)", "GB": raw16.nbytes / 1e9, "s": dt,
+                      "GBps": raw16.nbytes / dt / 1e9}), flush=True)
+    res = rec(d16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        host = res.cpu()
+    dt = (time.perf_counter() - t0) / 3
+    print(json.dumps({"copy": "result.cpu() (fresh pageable array each time)", "GB": host.numel() * 4 / 1e9, "s": dt,
+                      "GBps": host.numel() * 4 / dt / 1e9}), flush=True)
+    del d16, res, host
+
     stager = VolumeStager(raw_shape, np.uint16, rec.output_shape, dev)
     for k in range(stager.depth):
         stager.host_in(k)[...] = raw16          # camera frames land in the pinned slots
