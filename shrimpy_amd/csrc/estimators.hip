@@ -291,6 +291,96 @@ __global__ __launch_bounds__(kThreads) void blur_strided_kernel(BlurArgs p) {
   }
 }
 
+// Marching form of the strided blur for radii whose ring fits LDS: a workgroup owns 256 consecutive
+// `inner` elements (1 KB rows) of one `outer` index and walks a segment of the axis 16 positions at
+// a time, keeping the last 2r + 16 rows in an LDS ring -- every source row is read once (the tiled
+// form above re-reads 2r rows per 128) and in 1 KB pieces instead of 256-byte ones.  Same taps in
+// the same order, one FMA each: bit-identical to the tiled form.
+constexpr int kMarchRows = 16;
+constexpr int kMarchCols = kThreads;
+// up to 40 KB of ring: four workgroups per CU.  Beyond that the tiled form is faster (measured at
+// r = 20: 3.0 ms against 2.1-2.5 ms per axis; at r = 8: 1.54-1.64 ms against 1.80-2.02 ms)
+constexpr int kMarchMaxR = 12;
+struct BlurMarchArgs {
+  BlurArgs b;
+  int seg_len;   // positions per workgroup along the axis
+  int segs;      // segments per column strip
+};
+__global__ __launch_bounds__(kThreads) void blur_march_kernel(BlurMarchArgs q) {
+  const BlurArgs& p = q.b;
+  extern __shared__ float ring[];  // [2r + 16][256]
+  __shared__ float s_taps[2 * kBlurMaxR + 1];
+  const int r = p.r, ntaps = 2 * r + 1, RR = 2 * r + kMarchRows;
+  const int64_t strips = (p.inner + kMarchCols - 1) / kMarchCols;
+  int64_t bid = blockIdx.x;
+  const int seg = static_cast<int>(bid % q.segs);
+  bid /= q.segs;
+  const int64_t strip = bid % strips;
+  const int64_t o = bid / strips;
+  const int L = static_cast<int>(p.L);
+  const int a_begin = seg * q.seg_len, a_end = min(a_begin + q.seg_len, L);
+  const int64_t col = strip * kMarchCols + threadIdx.x;
+  const bool col_ok = col < p.inner;
+  const float* base = p.in + o * p.L * p.inner + (col_ok ? col : p.inner - 1);
+  float* obase = p.out + o * p.L * p.inner + col;
+  for (int t = threadIdx.x; t < ntaps; t += kThreads) s_taps[t] = p.taps[t];
+  float* mine = ring + threadIdx.x;
+  auto put = [&](int j, float v) {  // source position j (may lie outside [0, L): reflected by the loader)
+    int slot = (j + r) % RR;        // j >= -r always
+    mine[slot * kMarchCols] = p.div != 0.0f ? (v - p.sub) / p.div : v;
+  };
+  // fill: positions a_begin - r .. a_begin + r - 1 (the first step adds the next 16)
+  for (int j0 = a_begin - r; j0 < a_begin + r; j0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = base[static_cast<int64_t>(reflect(min(j0 + i, a_begin + r - 1), L)) * p.inner];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (j0 + i < a_begin + r) put(j0 + i, v[i]);
+  }
+  for (int a = a_begin; a < a_end; a += kMarchRows) {
+    // rows a + r .. a + r + 15 replace the oldest 16 (their readers finished before the barrier
+    // that ended the previous step)
+    float v[kMarchRows];
+    const int last = min(a_end - 1 + r, L - 1 + r);  // nothing beyond is needed; reflect() needs j <= L-1+r
+#pragma unroll
+    for (int i = 0; i < kMarchRows; ++i)
+      v[i] = base[static_cast<int64_t>(reflect(min(a + r + i, last), L)) * p.inner];
+#pragma unroll
+    for (int i = 0; i < kMarchRows; ++i) put(a + r + i, v[i]);
+    __syncthreads();
+    float acc[kMarchRows];
+#pragma unroll
+    for (int k = 0; k < kMarchRows; ++k) acc[k] = 0.0f;
+    int slot0 = (a - r + r) % RR;  // ring slot of source position a - r (tap 0 of output a)
+    for (int t0 = 0; t0 < ntaps; t0 += kTapBlock) {
+      float win[kMarchRows + kTapBlock - 1];
+      int slot = slot0;
+#pragma unroll
+      for (int j = 0; j < kMarchRows + kTapBlock - 1; ++j) {
+        win[j] = mine[slot * kMarchCols];
+        slot = slot + 1 == RR ? 0 : slot + 1;
+      }
+#pragma unroll
+      for (int tt = 0; tt < kTapBlock; ++tt) {
+        if (t0 + tt < ntaps) {  // uniform; false only in the last block
+          const float w = s_taps[t0 + tt];
+#pragma unroll
+          for (int k = 0; k < kMarchRows; ++k) acc[k] = fmaf(w, win[k + tt], acc[k]);
+        }
+      }
+      slot0 += kTapBlock;
+      if (slot0 >= RR) slot0 -= RR;
+    }
+    if (col_ok) {
+#pragma unroll
+      for (int k = 0; k < kMarchRows; ++k)
+        if (a + k < a_end) obase[static_cast<int64_t>(a + k) * p.inner] = acc[k];
+    }
+    __syncthreads();
+  }
+}
+
 constexpr int kRowSeg = 4 * kThreads;  // outputs per row segment of the contiguous-axis kernel
 __global__ __launch_bounds__(kThreads) void blur_contiguous_kernel(BlurArgs p) {
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [kRowSeg + 2r + kTapBlock + 4]
@@ -542,6 +632,16 @@ extern "C" int lsr_blur_reflect_f32(const float* in, float* out, int64_t Z, int6
     const int64_t blocks = items < 16384 ? items : 16384;
     hipLaunchKernelGGL(blur_contiguous_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
                        sizeof(float) * (kRowSeg + 2 * radius + kTapBlock + 4), s, p);
+  } else if (radius <= kMarchMaxR && p.L >= 2 * kMarchRows) {
+    BlurMarchArgs q;
+    q.b = p;
+    q.seg_len = p.L > 768 ? 512 : static_cast<int>(p.L);
+    q.segs = static_cast<int>(lsr::ceil_div(p.L, static_cast<int64_t>(q.seg_len)));
+    const int64_t blocks = p.outer * lsr::ceil_div(p.inner, static_cast<int64_t>(kMarchCols)) * q.segs;
+    LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
+                (long long)blocks);
+    hipLaunchKernelGGL(blur_march_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
+                       sizeof(float) * (2 * radius + kMarchRows) * kMarchCols, s, q);
   } else {
     // 128-position segments (less halo per output) while the tile stays within 64 KB of LDS
     const bool wide = (128 + 2 * radius + kTapBlock) * 64 * sizeof(float) <= 65536 && p.L > 64;

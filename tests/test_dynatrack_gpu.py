@@ -226,3 +226,33 @@ def test_reference_results_are_reused_by_every_two_volume_tracker(device):
     # second timepoint: centre, mask, the mask's spectrum and the blob's spectrum all hit
     assert d._spectra.hits == 4
     d.set_spectrum_cache_bytes(8 << 30)
+
+
+@pytest.mark.parametrize("shape,axis,r", [
+    ((40, 70, 300), 0, 3), ((40, 70, 300), 1, 12), ((40, 70, 300), 1, 13), ((40, 70, 300), 2, 12),
+    ((1000, 5, 260), 0, 8),      # marching form, two segments along the axis
+    ((3, 1030, 129), 1, 5),      # marching form, segments and a partial column strip
+    ((33, 2, 7), 0, 0), ((33, 2, 7), 0, 12), ((20, 9, 11), 0, 12),
+])
+def test_blur_axis_kernels_match_a_mirror_correlate(device, shape, axis, r):
+    """Every form of the one-axis reflect blur (tiled, marching, contiguous) against
+    ``scipy.ndimage.correlate1d(mode="mirror")`` -- F.pad's "reflect" -- with the [0, 1] map fused."""
+    import ctypes
+
+    import torch
+    from scipy import ndimage
+
+    from shrimpy_amd import _lib
+
+    rng = np.random.default_rng(sum(shape) + 7 * axis + r)
+    vol = (rng.random(shape) * 900 + 100).astype(np.float32)
+    taps = rng.random(2 * r + 1).astype(np.float32)
+    taps /= taps.sum()
+    sub, div = float(vol.min()), float(vol.max() - vol.min())
+    want = ndimage.correlate1d(((vol - np.float32(sub)) / np.float32(div)).astype(np.float64), taps.astype(np.float64),
+                               axis=axis, mode="mirror")
+    src, out = _t(vol, device), torch.empty(shape, dtype=torch.float32, device=device)
+    dt = _t(taps, device)
+    _lib.call("lsr_blur_reflect_f32", src.data_ptr(), out.data_ptr(), *shape, axis, dt.data_ptr(), r,
+              ctypes.c_float(sub), ctypes.c_float(div), _lib.stream_ptr(device))
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-6, atol=2e-6)
