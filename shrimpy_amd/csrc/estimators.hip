@@ -291,6 +291,79 @@ __global__ __launch_bounds__(kThreads) void blur_strided_kernel(BlurArgs p) {
   }
 }
 
+// The same tiling with two adjacent columns per lane: 128-column tiles (512-byte rows), 8-byte LDS
+// reads and packed FMAs (v_pk_fma_f32), for the long kernels where the arithmetic is what bounds
+// the pass (41 taps at sigma = 5).  Each column sees its taps in the same order, one FMA each.
+// Needs an even `inner` and 8-byte aligned arrays (the two columns travel as one float2).
+typedef float bf32x2 __attribute__((ext_vector_type(2)));
+template <int OPT>
+__global__ __launch_bounds__(kThreads) void blur_strided_pk_kernel(BlurArgs p) {
+  constexpr int kSeg = (kThreads / 64) * OPT;
+  extern __shared__ __attribute__((aligned(8))) float tile[];  // [(kSeg + 2r + kTapBlock)][128]
+  __shared__ float s_taps[2 * kBlurMaxR + 1];
+  bf32x2* tile2 = reinterpret_cast<bf32x2*>(tile);             // [rows][64] pairs
+  const int r = p.r, ntaps = 2 * r + 1;
+  const int64_t inner_tiles = (p.inner + 127) / 128, seg_tiles = (p.L + kSeg - 1) / kSeg;
+  int64_t bid = blockIdx.x;
+  const int64_t it = bid % inner_tiles;
+  bid /= inner_tiles;
+  const int64_t st = bid % seg_tiles;
+  const int64_t o = bid / seg_tiles;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i0 = it * 128 + 2 * lane;
+  const bool col_ok = i0 < p.inner;  // inner is even: both columns or none
+  const int64_t a0 = st * kSeg;
+  const int n_out = static_cast<int>(min(static_cast<int64_t>(kSeg), p.L - a0));
+  const int rows = n_out + 2 * r;
+  const float* base = p.in + o * p.L * p.inner + (col_ok ? i0 : 0);
+  for (int t = threadIdx.x; t < ntaps; t += kThreads) s_taps[t] = p.taps[t];
+  constexpr int kStep = kThreads / 64, kBatch = 8;
+  for (int row0 = grp; row0 < rows; row0 += kStep * kBatch) {
+    bf32x2 v[kBatch];
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      const int a = reflect(static_cast<int>(a0) + min(row0 + i * kStep, rows - 1) - r, static_cast<int>(p.L));
+      v[i] = *reinterpret_cast<const bf32x2*>(base + static_cast<int64_t>(a) * p.inner);
+    }
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      const int row = row0 + i * kStep;
+      if (row < rows) {
+        bf32x2 w = v[i];
+        if (p.div != 0.0f) { w.x = (w.x - p.sub) / p.div; w.y = (w.y - p.sub) / p.div; }
+        tile2[row * 64 + lane] = w;
+      }
+    }
+  }
+  __syncthreads();
+  const int k0 = grp * OPT;
+  if (k0 >= n_out) return;
+  bf32x2 acc[OPT];
+#pragma unroll
+  for (int k = 0; k < OPT; ++k) acc[k] = bf32x2{0.0f, 0.0f};
+  const bf32x2* col = tile2 + k0 * 64 + lane;
+  for (int t0 = 0; t0 < ntaps; t0 += kTapBlock) {
+    bf32x2 win[OPT + kTapBlock - 1];
+#pragma unroll
+    for (int j = 0; j < OPT + kTapBlock - 1; ++j) win[j] = col[(t0 + j) * 64];
+#pragma unroll
+    for (int tt = 0; tt < kTapBlock; ++tt) {
+      if (t0 + tt < ntaps) {  // uniform; false only in the last block
+        const float w = s_taps[t0 + tt];
+        const bf32x2 w2 = {w, w};
+#pragma unroll
+        for (int k = 0; k < OPT; ++k) acc[k] = __builtin_elementwise_fma(w2, win[k + tt], acc[k]);
+      }
+    }
+  }
+  if (col_ok) {
+    float* obase = p.out + o * p.L * p.inner + i0;
+#pragma unroll
+    for (int k = 0; k < OPT; ++k)
+      if (k0 + k < n_out) *reinterpret_cast<bf32x2*>(obase + (a0 + k0 + k) * p.inner) = acc[k];
+  }
+}
+
 // Marching form of the strided blur for radii whose ring fits LDS: a workgroup owns 256 consecutive
 // `inner` elements (1 KB rows) of one `outer` index and walks a segment of the axis 16 positions at
 // a time, keeping the last 2r + 16 rows in an LDS ring -- every source row is read once (the tiled
@@ -642,6 +715,15 @@ extern "C" int lsr_blur_reflect_f32(const float* in, float* out, int64_t Z, int6
                 (long long)blocks);
     hipLaunchKernelGGL(blur_march_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
                        sizeof(float) * (2 * radius + kMarchRows) * kMarchCols, s, q);
+  } else if (radius > kMarchMaxR && p.inner % 2 == 0 && p.L > 32 &&
+             ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 7) == 0 &&
+             (64 + 2 * radius + kTapBlock) * 128 * sizeof(float) <= 65536) {
+    // long kernels: two columns per lane, packed FMAs
+    const int64_t blocks = p.outer * lsr::ceil_div(p.L, int64_t(64)) * lsr::ceil_div(p.inner, int64_t(128));
+    LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large",
+                (long long)blocks);
+    hipLaunchKernelGGL(blur_strided_pk_kernel<16>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
+                       sizeof(float) * (64 + 2 * radius + kTapBlock) * 128, s, p);
   } else {
     // 128-position segments (less halo per output) while the tile stays within 64 KB of LDS
     const bool wide = (128 + 2 * radius + kTapBlock) * 64 * sizeof(float) <= 65536 && p.L > 64;

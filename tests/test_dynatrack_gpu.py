@@ -233,6 +233,7 @@ def test_reference_results_are_reused_by_every_two_volume_tracker(device):
     ((1000, 5, 260), 0, 8),      # marching form, two segments along the axis
     ((3, 1030, 129), 1, 5),      # marching form, segments and a partial column strip
     ((33, 2, 7), 0, 0), ((33, 2, 7), 0, 12), ((20, 9, 11), 0, 12),
+    ((90, 6, 134), 0, 20), ((5, 150, 260), 1, 20), ((70, 4, 131), 0, 20),   # packed two-column form / odd inner
 ])
 def test_blur_axis_kernels_match_a_mirror_correlate(device, shape, axis, r):
     """Every form of the one-axis reflect blur (tiled, marching, contiguous) against
