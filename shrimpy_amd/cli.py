@@ -142,7 +142,11 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
             and raw_dtype in (np.dtype("uint16"), np.dtype("float32")) and len(units) > world):
         from .staging import VolumeStager
 
-        stager = VolumeStager((nz, ny, nx), raw_dtype, (oz, oy, ox), device)
+        try:
+            stager = VolumeStager((nz, ny, nx), raw_dtype, (oz, oy, ox), device)
+        except (RuntimeError, MemoryError) as exc:   # not enough pinnable host memory for the slots
+            logger.warning("staging slots unavailable (%s): volumes are handed over synchronously", exc)
+            stager = None
     report = run_sharded(units, load, rec, store, synchronize=torch.cuda.synchronize, stager=stager)
     nvox = len(report.units) * nz * ny * nx
     logger.info("rank %d: %d units, %.3g input voxels/s (job %.2fs)", rank, len(report.units),
