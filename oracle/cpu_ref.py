@@ -418,3 +418,35 @@ def dt_phase_cross_corr(ref, mov, maximum_shift=1.0):
     corr = np.fft.fftshift(np.abs(np.fft.irfftn(f1 * np.conj(f2), s=shape, axes=(0, 1, 2))))
     peak = np.unravel_index(int(np.argmax(corr)), corr.shape)
     return tuple(int(s // 2) - int(p) for s, p in zip(corr.shape, peak))
+
+
+def dt_limit_shifts_zyx(shifts_zyx, limits):
+    """``_limit_shifts_zyx`` (``tracking.py:822-868``): deadband below min, clip above max."""
+    v = np.array(shifts_zyx, dtype=float)
+    for i, axis in enumerate("zyx"):
+        if axis in limits:
+            lo, hi = limits[axis]
+            if abs(v[i]) < lo:
+                v[i] = 0.0
+            elif abs(v[i]) > hi:
+                v[i] = np.sign(v[i]) * hi
+    return v
+
+
+def dt_compute_shift(ref, mov, method, scale_z, scale_yx, maximum=1.0, limits=None, dampening=None,
+                     otsu_sigma=5.0, otsu_component=0, blob_sigma=10.0, background_percentile=None, blur_sigma=0.0):
+    """``DynaTrackUpdater._compute_shift`` (``tracking.py:1224-1312``) over the ``dt_*`` estimators."""
+    if method == "pcc":
+        px = dt_phase_cross_corr(ref, mov, maximum)
+    elif method == "intensity_center_of_mass":
+        px = dt_roi_shift(mov, background_percentile, blur_sigma)
+    elif method == "multiotsu_center_of_mass":
+        px = dt_multiotsu_center_of_mass(ref, mov, otsu_sigma, otsu_component)
+    else:
+        raise ValueError(method)
+    um = np.array([px[0] * scale_z, px[1] * scale_yx, px[2] * scale_yx], dtype=float)
+    if limits is not None:
+        um = dt_limit_shifts_zyx(um, limits)
+    if dampening is not None:
+        um = um * np.array(dampening, dtype=float)
+    return float(um[2]), float(um[1]), float(um[0])

@@ -175,6 +175,25 @@ def capture_dynatrack_fixtures():
     out["match_shape_odd_mixed"] = t._match_shape(torch.as_tensor(odd), (4, 36, 25)).numpy()
     out["roi_pcc_b"] = np.array(t._roi_center_pcc(tb, blob_sigma=4.0))
     out["motsu_pcc_ab"] = np.array(t._multiotsu_pcc(ta, tb, sigma=2.0))
+    # the dispatcher on top of them (DynaTrackUpdater._compute_shift, tracking.py:1224-1312): method
+    # selection, pixels -> microns, limits (deadband / clip), dampening, (z, y, x) -> (x, y, z)
+    import types
+
+    methods = ("pcc", "intensity_center_of_mass", "roi_center_pcc", "multiotsu_center_of_mass", "multiotsu_pcc")
+    for variant, shift in (("plain", dict(maximum=1.0)),
+                           ("limited", dict(maximum=1.0, limits={"z": (0.5, 2.0), "y": (0.1, 100.0), "x": (0.2, 0.9)},
+                                            dampening=(0.5, 1.0, 0.8)))):
+        rows = []
+        for method in methods:
+            cfg = t.DynaTrackConfig(tracking_method=method, input_channel="BF", tracking_channel="BF", shift=shift,
+                                    segmentation=dict(otsu_sigma=2.0, otsu_component=0),
+                                    roi_center=dict(blob_sigma=4.0, background_percentile=50.0, blur_sigma=1.5))
+            me = types.SimpleNamespace(_config=cfg, _scale_z=0.17, _scale_yx=0.1133)
+            rows.append(t.DynaTrackUpdater._compute_shift(me, ta, tb))
+        out[f"compute_shift_{variant}_xyz_um"] = np.array(rows, dtype=np.float64)
+    out["limit_shifts_in"] = np.array([[0.3, -5.0, 0.95], [-0.6, 0.05, -0.2], [2.5, 120.0, 0.19]])
+    out["limit_shifts_out"] = np.array([t._limit_shifts_zyx(v, {"z": (0.5, 2.0), "y": (0.1, 100.0), "x": (0.2, 0.9)})
+                                        for v in out["limit_shifts_in"]])
     np.savez_compressed(GOLD / "ref_dynatrack.npz", **out)
     print("captured ref_dynatrack.npz from", ref)
 

@@ -42,7 +42,8 @@ __all__ = [
     "_gaussian_blur_3d", "_multiotsu_threshold", "_binary_mask", "_center_of_mass", "_percentile",
     "_intensity_center_of_mass", "_intensity_center_of_mass_to_roi_center", "_multiotsu_center_of_mass",
     "_next_fast_len", "_match_shape", "_phase_cross_corr", "_centered_gaussian_blob", "_roi_center_pcc",
-    "_multiotsu_pcc", "set_spectrum_cache_bytes",
+    "_multiotsu_pcc", "set_spectrum_cache_bytes", "ShiftSettings", "SegmentationSettings", "RoiCenterSettings",
+    "_limit_shifts_zyx", "compute_shift", "TRACKING_METHODS",
 ]
 
 
@@ -465,3 +466,96 @@ def _multiotsu_pcc(ref_img, mov_img, sigma: float = 5.0, otsu_component: int = 0
             _spectra.put(ref_img, tag, ref_mask)
     mov_mask = _binary_mask(mov_img, sigma=sigma, otsu_component=otsu_component).to(dtype=torch.float32)
     return _phase_cross_corr(ref_mask, mov_mask, maximum_shift)
+
+
+# ---------------------------------------------------------------------------------------------
+# The dispatcher on top of the estimators (DynaTrackUpdater._compute_shift, tracking.py:1224-1312)
+# ---------------------------------------------------------------------------------------------
+
+from pydantic import BaseModel, ConfigDict  # noqa: E402
+
+
+class ShiftSettings(BaseModel):
+    """How the raw shift estimate is searched, bounded and scaled (``tracking.py:45-66``)."""
+
+    model_config = ConfigDict(extra="forbid")
+
+    maximum: float = 1.0
+    limits: dict[str, tuple[float, float]] | None = None
+    dampening: tuple[float, float, float] | None = None
+
+
+class SegmentationSettings(BaseModel):
+    """Parameters of the ``multiotsu_*`` methods (``tracking.py:69-83``)."""
+
+    model_config = ConfigDict(extra="forbid")
+
+    otsu_sigma: float = 5.0
+    otsu_component: int = 0
+
+
+class RoiCenterSettings(BaseModel):
+    """Parameters of the referenceless ROI-centre methods (``tracking.py:86-112``)."""
+
+    model_config = ConfigDict(extra="forbid")
+
+    blob_sigma: float = 10.0
+    background_percentile: float | None = None
+    blur_sigma: float = 0.0
+
+
+TRACKING_METHODS = ("pcc", "intensity_center_of_mass", "roi_center_pcc", "multiotsu_center_of_mass",
+                    "multiotsu_pcc")
+
+
+def _limit_shifts_zyx(shifts_zyx, shift_limits: dict) -> np.ndarray:
+    """Per-axis deadband and clip in microns (``tracking.py:822-868``): below the minimum -> 0, above
+    the maximum -> the maximum with the shift's sign."""
+    shifts_zyx = np.array(shifts_zyx, dtype=float)
+    for i, axis in enumerate(("z", "y", "x")):
+        if axis not in shift_limits:
+            continue
+        min_limit, max_limit = shift_limits[axis]
+        if abs(shifts_zyx[i]) < min_limit:
+            shifts_zyx[i] = 0.0
+        elif abs(shifts_zyx[i]) > max_limit:
+            shifts_zyx[i] = np.sign(shifts_zyx[i]) * max_limit
+    return shifts_zyx
+
+
+def compute_shift(reference_zyx, current_zyx, tracking_method: str = "pcc", *,
+                  shift: ShiftSettings | dict | None = None,
+                  segmentation: SegmentationSettings | dict | None = None,
+                  roi_center: RoiCenterSettings | dict | None = None,
+                  scale_z: float = 1.0, scale_yx: float = 1.0) -> tuple[float, float, float]:
+    """Shift of ``current_zyx`` against ``reference_zyx`` as (x, y, z) in microns: the body of
+    ``DynaTrackUpdater._compute_shift`` (``tracking.py:1224-1312``) -- method dispatch, pixels to
+    microns, limits, dampening, (z, y, x) -> (x, y, z) -- on device tensors."""
+    def model(cls, v):
+        return v if isinstance(v, cls) else cls(**(v or {}))
+
+    sh, seg, roi = model(ShiftSettings, shift), model(SegmentationSettings, segmentation), \
+        model(RoiCenterSettings, roi_center)
+    method = tracking_method
+    if method == "pcc":
+        px = _phase_cross_corr(reference_zyx, current_zyx, sh.maximum)
+    elif method == "intensity_center_of_mass":
+        px = _intensity_center_of_mass_to_roi_center(current_zyx, background_percentile=roi.background_percentile,
+                                                     blur_sigma=roi.blur_sigma)
+    elif method == "roi_center_pcc":
+        px = _roi_center_pcc(current_zyx, blob_sigma=roi.blob_sigma, maximum_shift=sh.maximum)
+    elif method == "multiotsu_center_of_mass":
+        px = _multiotsu_center_of_mass(reference_zyx, current_zyx, sigma=seg.otsu_sigma,
+                                       otsu_component=seg.otsu_component)
+    elif method == "multiotsu_pcc":
+        px = _multiotsu_pcc(reference_zyx, current_zyx, sigma=seg.otsu_sigma, otsu_component=seg.otsu_component,
+                            maximum_shift=sh.maximum)
+    else:
+        raise ValueError(f"Unknown tracking_method={method!r}. Use 'pcc', 'intensity_center_of_mass', "
+                         "'roi_center_pcc', 'multiotsu_center_of_mass', or 'multiotsu_pcc'.")
+    um = np.array([px[0] * scale_z, px[1] * scale_yx, px[2] * scale_yx], dtype=float)
+    if sh.limits is not None:
+        um = _limit_shifts_zyx(um, sh.limits)
+    if sh.dampening is not None:
+        um = um * np.array(sh.dampening, dtype=float)
+    return float(um[2]), float(um[1]), float(um[0])

@@ -257,3 +257,25 @@ def test_blur_axis_kernels_match_a_mirror_correlate(device, shape, axis, r):
     _lib.call("lsr_blur_reflect_f32", src.data_ptr(), out.data_ptr(), *shape, axis, dt.data_ptr(), r,
               ctypes.c_float(sub), ctypes.c_float(div), _lib.stream_ptr(device))
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-6, atol=2e-6)
+
+
+def test_compute_shift_dispatcher_matches_the_reference_updater(device, golden):
+    """Every tracking method through ``compute_shift`` (method dispatch, pixels -> microns, limits,
+    dampening, axis order) against ``DynaTrackUpdater._compute_shift`` run on the same volumes."""
+    from shrimpy_amd import dynatrack as d
+
+    a, b = _t(golden["a"], device), _t(golden["b"], device)
+    limits = {"z": (0.5, 2.0), "y": (0.1, 100.0), "x": (0.2, 0.9)}
+    for vin, vout in zip(golden["limit_shifts_in"], golden["limit_shifts_out"]):
+        np.testing.assert_array_equal(d._limit_shifts_zyx(vin, limits), vout)
+    common = dict(segmentation=dict(otsu_sigma=2.0, otsu_component=0), scale_z=0.17, scale_yx=0.1133,
+                  roi_center=dict(blob_sigma=4.0, background_percentile=50.0, blur_sigma=1.5))
+    for variant, shift in (("plain", dict(maximum=1.0)),
+                           ("limited", dict(maximum=1.0, limits=limits, dampening=(0.5, 1.0, 0.8)))):
+        for method, want in zip(d.TRACKING_METHODS, golden[f"compute_shift_{variant}_xyz_um"]):
+            got = d.compute_shift(a, b, method, shift=shift, **common)
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-4, err_msg=f"{variant} {method}")
+    with pytest.raises(ValueError, match="Unknown tracking_method"):
+        d.compute_shift(a, b, "nope")
+    with pytest.raises(Exception):
+        d.ShiftSettings(maximum=1.0, typo=1)

@@ -203,3 +203,20 @@ def test_dynatrack_pcc_oracle_matches_reference_capture(golden_dir):
     assert o.dt_phase_cross_corr(g["pcc_odd"], g["pcc_odd_mov"], 0.5) == tuple(g["pcc_shift_odd_half"])
     np.testing.assert_array_equal(o.dt_match_shape(g["pcc_odd"], (8, 36, 50)), g["match_shape_odd_pad"])
     np.testing.assert_array_equal(o.dt_match_shape(g["pcc_odd"], (4, 36, 25)), g["match_shape_odd_mixed"])
+
+
+def test_dynatrack_dispatcher_oracle_matches_reference_capture(golden_dir):
+    """``dt_compute_shift`` / ``dt_limit_shifts_zyx`` against the reference's own
+    ``DynaTrackUpdater._compute_shift`` and ``_limit_shifts_zyx`` outputs (captured fixture)."""
+    g = np.load(golden_dir / "ref_dynatrack.npz")
+    limits = {"z": (0.5, 2.0), "y": (0.1, 100.0), "x": (0.2, 0.9)}
+    for vin, vout in zip(g["limit_shifts_in"], g["limit_shifts_out"]):
+        np.testing.assert_array_equal(o.dt_limit_shifts_zyx(vin, limits), vout)
+    methods = ("pcc", "intensity_center_of_mass", "roi_center_pcc", "multiotsu_center_of_mass", "multiotsu_pcc")
+    kw = dict(scale_z=0.17, scale_yx=0.1133, otsu_sigma=2.0, blob_sigma=4.0, background_percentile=50.0, blur_sigma=1.5)
+    for variant, extra in (("plain", {}), ("limited", dict(limits=limits, dampening=(0.5, 1.0, 0.8)))):
+        for method, want in zip(methods, g[f"compute_shift_{variant}_xyz_um"]):
+            if method in ("roi_center_pcc", "multiotsu_pcc"):
+                continue  # (their estimators are covered by the PCC and mask fixtures)
+            np.testing.assert_allclose(o.dt_compute_shift(g["a"], g["b"], method, **kw, **extra), want,
+                                       rtol=0, atol=2e-4)
