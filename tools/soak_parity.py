@@ -1,0 +1,170 @@
+"""Randomised parity soak: many seeded random cases per kernel against the oracle (or against the
+other device path where the bar is bit-equality), for a bounded time.  Not part of the test suite --
+a one-off sweep for shapes and parameters nobody wrote a case for.  Prints one JSON line per family
+(cases run, failures with their seeds) and exits non-zero if anything failed.
+
+    python tools/soak_parity.py --seconds 240 --seed 1
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import cpu_ref as o  # noqa: E402  (a checker, like the tests)
+
+
+def main():
+    import torch
+    from scipy import ndimage
+
+    from shrimpy_amd import _lib
+    from shrimpy_amd import dynatrack as d
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+    from shrimpy_amd.deskew import fast_deskew_zyx
+    from shrimpy_amd.flatfield import flat_field_pattern
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(args.seed)
+
+    def t(a):
+        return torch.as_tensor(np.ascontiguousarray(a), device=dev)
+
+    def deskew_case(r):
+        shape = (int(r.integers(2, 160)), int(r.integers(1, 48)), int(r.integers(1, 90)))
+        angle = float(r.uniform(8.0, 45.0))
+        ratio = float(np.round(r.uniform(0.25, 2.0), 3))
+        keep, avg = bool(r.integers(0, 2)), int(r.integers(1, 6))
+        u16 = bool(r.integers(0, 2))
+        try:
+            want_shape = o.deskewed_shape(shape, angle, ratio, keep, avg)[0]
+        except Exception:
+            return None
+        if min(want_shape) <= 0:
+            return None
+        raw = r.integers(0, 60000, shape).astype(np.uint16) if u16 else (r.random(shape) * 4000 - 500).astype(np.float32)
+        want = o.deskew(raw.astype(np.float32), angle, ratio, keep, avg)
+        got = fast_deskew_zyx(raw_data=t(raw), ls_angle_deg=angle, px_to_scan_ratio=ratio, keep_overhang=keep,
+                              average_n_slices=avg).cpu().numpy()
+        return got.shape == want.shape and np.array_equal(got, want), (shape, angle, ratio, keep, avg, u16)
+
+    def affine_case(r):
+        shape = (int(r.integers(1, 24)), int(r.integers(2, 90)), int(r.integers(2, 140)))
+        oshape = shape if r.integers(0, 2) else (int(r.integers(1, 24)), int(r.integers(2, 90)), int(r.integers(2, 140)))
+        th = np.deg2rad(r.uniform(-25, 25))
+        m = np.eye(4)
+        planar = bool(r.integers(0, 2))
+        rot = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]])
+        m[:3, :3] = rot @ np.diag(r.uniform(0.6, 1.5, 3) * r.choice([1.0, 1.0, -1.0], 3))
+        if not planar:
+            m[0, 1:3] = r.uniform(-0.2, 0.2, 2)
+            m[1:3, 0] = r.uniform(-0.2, 0.2, 2)
+        m[:3, 3] = r.uniform(-10, 10, 3) + np.where(m.diagonal()[:3] < 0, np.array(shape) - 1.0, 0.0)
+        mode = "constant" if r.integers(0, 3) else "grid-constant"
+        vol = (r.random(shape) * 1000 - 100).astype(np.float32)
+        want = o.affine_apply_4x4(vol, m, oshape, cval=-3.0, mode=mode)
+        got = apply_affine_transform_zyx(t(vol), m, oshape, mode=mode, cval=-3.0).cpu().numpy()
+        return np.array_equal(got, want), (shape, oshape, mode, planar, m[:3].round(4).tolist())
+
+    odd = np.array([1, 3, 5, 7, 9, 11, 13, 15])
+
+    def rl_case(r):
+        pshape = tuple(int(v) for v in r.choice(odd, 3))
+        if pshape[0] >= 15 and max(pshape[1:]) >= 11:
+            pshape = (13,) + pshape[1:]
+        vshape = (int(r.integers(1, 48)), int(r.integers(1, 100)), int(r.integers(1, 300)))
+        factors = [np.abs(r.normal(1.0, 0.4, n)).astype(np.float32) + 0.05 for n in pshape]
+        factors = [f / f.sum() for f in factors]
+        y = t((r.random(vshape) * 80 + 1).astype(np.float32))
+        iters = int(r.integers(1, 4))
+        a = RichardsonLucyPlan(vshape, None, dev, psf_factors=factors)(y, iterations=iters)
+        b = RichardsonLucyPlan(vshape, None, dev, psf_factors=factors, fused="never")(y, iterations=iters)
+        ok = bool(torch.equal(a, b))
+        if ok and np.prod(vshape) < 200000 and max(pshape) <= 9:   # and against the oracle, where it is quick
+            want = o.richardson_lucy_separable(y.cpu().numpy(), factors, iterations=iters).astype(np.float64)
+            got = a.cpu().numpy().astype(np.float64)
+            ok = bool(np.all(np.abs(got - want) <= 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max()))
+        return ok, (pshape, vshape, iters)
+
+    def flat_case(r):
+        shape = (int(r.integers(1, 300)), int(r.integers(1, 20)), int(r.integers(1, 200)))
+        kind = int(r.integers(0, 3))
+        if kind == 0:
+            vol = r.integers(0, 40, shape).astype(np.float32)          # counts with many ties
+        elif kind == 1:
+            vol = r.integers(0, 65535, shape).astype(np.uint16)
+        else:
+            vol = (r.normal(0, 50, shape)).astype(np.float32)
+        srt = np.sort(vol.astype(np.float32), axis=0)
+        n = shape[0]
+        a, b = srt[(n - 1) // 2], srt[n // 2]
+        want = b - (b - a) * np.float32(0.5)
+        got = flat_field_pattern(t(vol)).pattern.cpu().numpy()
+        return np.array_equal(got, want), (shape, kind)
+
+    def blur_case(r):
+        shape = (int(r.integers(1, 120)), int(r.integers(1, 70)), int(r.integers(1, 300)))
+        axis = int(r.integers(0, 3))
+        rad = int(r.integers(0, min(shape[axis], 40)))
+        vol = (r.random(shape) * 900 + 100).astype(np.float32)
+        taps = r.random(2 * rad + 1).astype(np.float32)
+        taps /= taps.sum()
+        want = ndimage.correlate1d(vol.astype(np.float64), taps.astype(np.float64), axis=axis, mode="mirror")
+        src, out, dt = t(vol), torch.empty(shape, dtype=torch.float32, device=dev), t(taps)
+        _lib.call("lsr_blur_reflect_f32", src.data_ptr(), out.data_ptr(), *shape, axis, dt.data_ptr(), rad,
+                  ctypes.c_float(0.0), ctypes.c_float(0.0), _lib.stream_ptr(dev))
+        return bool(np.allclose(out.cpu().numpy(), want, rtol=2e-6, atol=2e-4)), (shape, axis, rad)
+
+    def estimator_case(r):
+        shape = (int(r.integers(1, 40)), int(r.integers(1, 60)), int(r.integers(1, 120)))
+        vol = (r.gamma(2.0, 100.0, shape)).astype(np.float32)
+        p = float(r.uniform(1, 99.9))
+        ok = abs(d._percentile(t(vol), p) - o.dt_percentile(vol, p)) <= 1e-5 * abs(o.dt_percentile(vol, p)) + 1e-6
+        bg = float(r.uniform(0, 300))
+        ok = ok and np.allclose(d._intensity_center_of_mass(t(vol), bg).cpu().numpy(),
+                                o.dt_intensity_center_of_mass(vol, bg), atol=2e-3)
+        shift = tuple(int(v) for v in (r.integers(-2, 3), r.integers(-5, 6), r.integers(-5, 6)))
+        if min(shape) >= 8:
+            mov = np.roll(vol, shift, axis=(0, 1, 2))
+            ok = ok and d._phase_cross_corr(t(vol), t(mov)) == o.dt_phase_cross_corr(vol, mov)
+        return bool(ok), (shape, p, bg, shift)
+
+    families = {"deskew": deskew_case, "affine": affine_case, "rl": rl_case, "flatfield": flat_case,
+                "blur": blur_case, "estimators": estimator_case}
+    d.set_spectrum_cache_bytes(0)
+    stats = {k: {"cases": 0, "failures": []} for k in families}
+    t_end = time.time() + args.seconds
+    i = 0
+    names = list(families)
+    while time.time() < t_end:
+        name = names[i % len(names)]
+        seed = int(rng.integers(0, 2**31))
+        res = families[name](np.random.default_rng(seed))
+        i += 1
+        if res is None:
+            continue
+        ok, desc = res
+        stats[name]["cases"] += 1
+        if not ok and len(stats[name]["failures"]) < 10:
+            stats[name]["failures"].append({"seed": seed, "case": repr(desc)})
+        if i % 60 == 0:
+            print(json.dumps({"progress": {k: v["cases"] for k, v in stats.items()}}), flush=True)
+    bad = 0
+    for k, v in stats.items():
+        bad += len(v["failures"])
+        print(json.dumps({"family": k, **v}), flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
