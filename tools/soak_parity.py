@@ -33,6 +33,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--large", action="store_true", help="large-shape families only (work split, big grids)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(args.seed)
@@ -139,8 +140,43 @@ def main():
             ok = ok and d._phase_cross_corr(t(vol), t(mov)) == o.dt_phase_cross_corr(vol, mov)
         return bool(ok), (shape, p, bg, shift)
 
+    def rl_large_case(r):
+        """More tiles than CUs: the whole-column / z-piece work split of the fused kernel."""
+        pshape = tuple(int(v) for v in r.choice(odd[:6], 3))
+        vshape = (int(r.integers(1, 70)), int(r.integers(150, 1400)), int(r.integers(400, 2600)))
+        factors = [np.abs(r.normal(1.0, 0.4, n)).astype(np.float32) + 0.05 for n in pshape]
+        factors = [f / f.sum() for f in factors]
+        g = torch.Generator(device=dev).manual_seed(int(r.integers(0, 2**31)))
+        y = torch.rand(vshape, device=dev, generator=g) * 80 + 1
+        iters = int(r.integers(1, 3))
+        pa = RichardsonLucyPlan(vshape, None, dev, psf_factors=factors)
+        pb = RichardsonLucyPlan(vshape, None, dev, psf_factors=factors, fused="never")
+        ok = bool(torch.equal(pa(y, iterations=iters), pb(y, iterations=iters)))
+        pa.release(), pb.release()
+        return ok, (pshape, vshape, iters)
+
+    def deskew_large_case(r):
+        """Bigger stacks: uint16 path against float path, and the oracle on a raw-X slab."""
+        shape = (int(r.integers(100, 900)), int(r.integers(20, 300)), int(r.integers(200, 1500)))
+        angle, ratio = float(r.uniform(15.0, 45.0)), float(np.round(r.uniform(0.4, 1.5), 3))
+        keep, avg = bool(r.integers(0, 2)), int(r.integers(1, 5))
+        if min(o.deskewed_shape(shape, angle, ratio, keep, avg)[0]) <= 0:
+            return None
+        raw = torch.randint(0, 60000, shape, device=dev, generator=torch.Generator(device=dev).manual_seed(
+            int(r.integers(0, 2**31)))).to(torch.uint16)
+        kw = dict(ls_angle_deg=angle, px_to_scan_ratio=ratio, keep_overhang=keep, average_n_slices=avg)
+        a = fast_deskew_zyx(raw_data=raw, **kw)
+        b = fast_deskew_zyx(raw_data=raw.to(torch.float32), **kw)
+        ok = bool(torch.equal(a, b))
+        x0 = int(r.integers(0, shape[2] - 2))
+        want = o.deskew(raw[:, :, x0:x0 + 2].to(torch.float32).cpu().numpy(), angle, ratio, keep, avg)
+        ok = ok and np.array_equal(a[:, shape[2] - x0 - 2:shape[2] - x0, :].cpu().numpy(), want)
+        return ok, (shape, angle, ratio, keep, avg, x0)
+
     families = {"deskew": deskew_case, "affine": affine_case, "rl": rl_case, "flatfield": flat_case,
                 "blur": blur_case, "estimators": estimator_case}
+    if args.large:
+        families = {"rl_large": rl_large_case, "deskew_large": deskew_large_case}
     d.set_spectrum_cache_bytes(0)
     stats = {k: {"cases": 0, "failures": []} for k in families}
     t_end = time.time() + args.seconds
