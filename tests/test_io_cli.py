@@ -244,3 +244,57 @@ def test_cli_reconstruct_end_to_end_on_gpu(tmp_path):
             ref = o.richardson_lucy(d, psf, 3).astype(np.float64)
             assert got.shape == ref.shape
             assert np.all(np.abs(got - ref) <= 5e-5 * np.abs(ref) + 2e-5 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("version", ["0.4", "0.5"])
+def test_cli_deskew_register_deconvolve_chain_on_gpu(tmp_path, version):
+    """The three single-step commands chained store to store (two timepoints, two channels), each
+    stage compared with the oracle: deskew and register bit for bit, deconvolve within the RL bar."""
+    from click.testing import CliRunner
+
+    from oracle import cpu_ref as o
+    from shrimpy_amd.cli import cli
+
+    rng = np.random.default_rng(8)
+    raw = tmp_path / "raw.zarr"
+    vols = {}
+    with open_ome_zarr(raw, layout="hcs", mode="w", channel_names=["LS1", "LS2"], version=version,
+                       prefer_iohub=False) as plate:
+        for key in KEYS:
+            pos = plate.create_position(*key.split("/"))
+            arr = pos.create_zeros("0", shape=(2, 2, 48, 12, 34), dtype="uint16", scale=(1, 1, 0.15, 0.1133, 0.1133))
+            for t in range(2):
+                for c in range(2):
+                    vols[key, t, c] = rng.integers(80, 900, (48, 12, 34)).astype(np.uint16)
+                    arr.write_volume(t, c, vols[key, t, c])
+    th = np.deg2rad(3.0)
+    m = np.eye(4)
+    m[:3, :3] = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]]) @ np.diag([1.0, 0.97, 1.03])
+    m[:3, 3] = [0.5, -2.25, 3.75]
+    (tmp_path / "deskew.yml").write_text(yaml.safe_dump(dict(
+        pixel_size_um=0.1133, ls_angle_deg=30.0, scan_step_um=0.15, keep_overhang=False, average_n_slices=2)))
+    (tmp_path / "register.yml").write_text(yaml.safe_dump(dict(affine_transform_zyx=m.tolist(), cval=0.0)))
+    (tmp_path / "deconvolve.yml").write_text(yaml.safe_dump(dict(
+        iterations=4, gaussian_shape_zyx=[3, 5, 5], gaussian_sigma_zyx=[0.8, 1.0, 1.0])))
+    stages = [("deskew", raw, tmp_path / "d.zarr"), ("register", tmp_path / "d.zarr", tmp_path / "r.zarr"),
+              ("deconvolve", tmp_path / "r.zarr", tmp_path / "x.zarr")]
+    for cmd, src, dst in stages:
+        r = CliRunner().invoke(cli, [cmd, "-i", str(src), "-c", str(tmp_path / f"{cmd}.yml"), "-o", str(dst),
+                                     "--zarr-version", version])
+        assert r.exit_code == 0, (cmd, r.output, r.exception)
+    psf, _ = o.gaussian_psf((3, 5, 5), (0.8, 1.0, 1.0))
+    stores = {name: open_ome_zarr(path, prefer_iohub=False) for name, _, path in stages}
+    try:
+        pos = {name: dict(st.positions()) for name, st in stores.items()}
+        for (key, t, c), v in vols.items():
+            d = o.deskew(v.astype(np.float32), 30.0, 0.755, False, 2)
+            np.testing.assert_array_equal(pos["deskew"][key]["0"].read_volume(t, c), d)
+            reg = o.affine_apply_4x4(d, m, d.shape)
+            np.testing.assert_array_equal(pos["register"][key]["0"].read_volume(t, c), reg)
+            ref = o.richardson_lucy(reg, psf, 4).astype(np.float64)
+            got = pos["deconvolve"][key]["0"].read_volume(t, c).astype(np.float64)
+            assert np.all(np.abs(got - ref) <= 2e-4 * np.abs(ref) + 1e-4 * np.abs(ref).max())
+    finally:
+        for st in stores.values():
+            st.close()
