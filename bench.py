@@ -153,9 +153,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
-    ap.add_argument("--psf", default="separable", choices=["separable", "dense"],
+    ap.add_argument("--psf", default="separable", choices=["separable", "dense", "rotated"],
                     help="separable = the declared default Gaussian (rank-1 path); dense = the "
-                         "rotated non-separable PSF through the dense stencil")
+                         "rotated non-separable PSF through the 441-tap dense stencil; rotated = the "
+                         "same PSF with the plan free to split it (it separates along y: a (z, x) "
+                         "stencil plus a y pass per correlation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rl", default="fused", choices=["fused", "two-launch"],
                     help="separable PSF: one launch per RL iteration (default) or the ratio / update pair")
@@ -196,10 +198,12 @@ def main():
     if args.psf == "separable":
         plan = RichardsonLucyPlan(out_shape, None, device, psf_factors=gaussian_factors(),
                                   fused="auto" if args.rl == "fused" else "never")
+    elif args.psf == "rotated":
+        plan = RichardsonLucyPlan(out_shape, rotated_psf(), device)
     else:
         plan = RichardsonLucyPlan(out_shape, rotated_psf(), device, separable="never")
     # the deskew kernel writes straight into the RL kernels' padded, line-aligned input volume
-    deskewed = plan.new_padded_input() if (plan.separable or args.psf == "dense") else torch.empty(out_shape, dtype=torch.float32, device=device)
+    deskewed = plan.new_padded_input()
     estimate = torch.empty(out_shape, dtype=torch.float32, device=device)
 
     from shrimpy_amd.deskew import deskew_with_matrix
@@ -251,7 +255,8 @@ def main():
 
     if rank == 0:
         fused = bool(getattr(plan, "fused", False))
-        launches = RL_ITERS if fused else 2 * RL_ITERS
+        ysep = plan.path == "y-separable"
+        launches = RL_ITERS if fused else (4 * RL_ITERS if ysep else 2 * RL_ITERS)
         launch_s = rl_kernels_ms * 1e-3 / launches  # HIP events right around the launches, / count
         # fused iteration: x, y in, x_new out; ratio / update launch: in + aux + out
         bytes_per_launch = 12.0 * n_o
@@ -267,7 +272,7 @@ def main():
         if tfile.exists():
             try:
                 rec = json.loads(tfile.read_text())
-                key = "fused" if fused else ("two-launch" if args.psf == "separable" else "dense")
+                key = "fused" if fused else ("two-launch" if args.psf == "separable" else args.psf)
                 rec = rec.get(key, {})
                 if rec.get("workload") == args.workload:
                     traffic = rec.get("hbm_bytes_per_launch")
@@ -293,6 +298,7 @@ def main():
                 "raw_shape": list(raw_shape),
                 "deskewed_shape": list(out_shape),
                 "psf": args.psf,
+                "rl_path": plan.path,
                 "rl_iterations": RL_ITERS,
                 "deskew_ms": deskew_ms,
                 "rl_ms": rl_ms,
@@ -322,7 +328,19 @@ def main():
                                                 "achieved": 24.0 * n_o / launch_s / 1e9,
                                                 "frac": 24.0 * n_o / launch_s / 1e9 / HBM_PEAK_GBS}}
                        if fused else {}),
-                } if args.psf == "separable" else {
+                } if args.psf == "separable" else ({
+                    # per correlation: a 63-tap (z, x) stencil launch (in + out = 8 B/voxel) and a
+                    # 7-tap y pass carrying the epilogue (in + aux + out = 12 B/voxel)
+                    "kernel": "correlate_dense_kernel<9,7,*,YS> + correlate_sep_kernel<3,7,3> (4 launches per RL iteration)",
+                    "bound": "hbm",
+                    "achieved": 10.0 * n_o / launch_s / 1e9,
+                    "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s",
+                    "frac": 10.0 * n_o / launch_s / 1e9 / HBM_PEAK_GBS,
+                    "traffic": traffic,
+                    "launch_ms": launch_s * 1e3,
+                    "algorithmic_bytes_per_launch": 10.0 * n_o,
+                } if ysep else {
                     # a 441-tap dense stencil is fp32-VALU-bound, not HBM-bound
                     "kernel": "correlate_dense_kernel<9,7> (dense RL ratio / update launch)",
                     "bound": "valu-fp32",
@@ -334,7 +352,7 @@ def main():
                     "launch_ms": launch_s * 1e3,
                     "algorithmic_flop_per_launch": 2.0 * 441 * n_o,
                     "hbm_algorithmic_GBps": achieved,
-                }
+                })
             ),
         }
         if cpu is not None:

@@ -55,6 +55,8 @@ extern "C" {
 #define LSR_EPI_NONE 0   /* out = corr(in)                                  (plain correlation) */
 #define LSR_EPI_RATIO 1  /* out = aux / (corr(in) + eps)       aux = y      (ratio = y/(Hx+eps)) */
 #define LSR_EPI_UPDATE 2 /* out = aux * corr(in) / norm        aux = x      (x <- x*H^T(ratio)/H^T1) */
+#define LSR_EPI_SCALE 3  /* out = corr(in) / norm   (lsr_correlate_dense_padded_f32 only: the (z, x) half
+                            of a PSF that separates along y, whose y half runs as a separable pass) */
 
 typedef void* lsr_stream_t; /* a hipStream_t; NULL = the default stream */
 

@@ -29,6 +29,7 @@ MODE_F32_INTERP = 256
 EPI_NONE = 0
 EPI_RATIO = 1
 EPI_UPDATE = 2
+EPI_SCALE = 3
 E_UNSUPPORTED = -3
 
 _c_f32p = ctypes.c_void_p

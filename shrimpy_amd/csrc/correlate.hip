@@ -708,10 +708,12 @@ extern "C" int lsr_correlate_dense_padded_f32(
   int PZ, PYX;
   LSR_REQUIRE(dense_compiled_taps(pz, py, px, &PZ, &PYX), LSR_E_UNSUPPORTED,
               "the tuned dense kernel covers pz <= 11 and py, px <= 9 (got %d,%d,%d)", pz, py, px);
-  LSR_REQUIRE(epilogue == LSR_EPI_NONE || epilogue == LSR_EPI_RATIO || epilogue == LSR_EPI_UPDATE,
+  LSR_REQUIRE(epilogue == LSR_EPI_NONE || epilogue == LSR_EPI_RATIO || epilogue == LSR_EPI_UPDATE ||
+                  epilogue == LSR_EPI_SCALE,
               LSR_E_ARG, "unknown epilogue %d", epilogue);
-  if (epilogue != LSR_EPI_NONE) LSR_REQUIRE_PTR(aux);
-  if (epilogue == LSR_EPI_UPDATE) LSR_REQUIRE_PTR(norm_table);
+  const bool has_aux = epilogue == LSR_EPI_RATIO || epilogue == LSR_EPI_UPDATE;
+  if (has_aux) LSR_REQUIRE_PTR(aux);
+  if (epilogue == LSR_EPI_UPDATE || epilogue == LSR_EPI_SCALE) LSR_REQUIRE_PTR(norm_table);
   LSR_REQUIRE(in != out, LSR_E_ARG, "out must not alias in");
   int64_t need[4];
   lsr_sep_padded_shape(Y, X, pz, py, px, need);
@@ -723,10 +725,11 @@ extern "C" int lsr_correlate_dense_padded_f32(
   const int64_t lim = int64_t(1) << 30;
   LSR_REQUIRE(in_plane < lim && aux_plane < lim && out_plane < lim && Z < lim, LSR_E_UNSUPPORTED,
               "plane strides exceed the kernel's 32-bit in-plane offsets");
-  LSR_REQUIRE(out_pitch >= X && (epilogue == LSR_EPI_NONE || aux_pitch >= X), LSR_E_SHAPE,
+  LSR_REQUIRE(out_pitch >= X && (!has_aux || aux_pitch >= X), LSR_E_SHAPE,
               "aux/out pitch smaller than X");
 
   lsr::DenseArgs p{};
+  p.ysep = py == 1 ? 1 : 0;
   p.in = in; p.aux = aux; p.out = out;
   p.in_plane = in_plane; p.aux_plane = aux_plane; p.out_plane = out_plane;
   p.in_pitch = static_cast<int>(in_pitch);

@@ -68,6 +68,7 @@ struct DenseArgs {
   int tiles_x, tiles_y;
   int z_chunk;
   const float* taps;
+  int ysep;                  // 1: the caller's PSF has a single y tap -- the (z, x)-stencil specialisation
 };
 
 // Tile geometry of the tuned kernels, needed by the host to size the halo (lsr_sep_padded_shape).

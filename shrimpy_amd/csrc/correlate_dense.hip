@@ -101,15 +101,20 @@ __device__ float dense_norm(const DenseArgs& p, const double* P, int z, int y, i
                              (P[a1 * sa + b0 * sb + c0] - P[a0 * sa + b0 * sb + c0])));
 }
 
-template <int PZ, int PYX, int EPI>
+// YS: the caller's PSF has one tap along y (a (z, x) stencil: the dense half of a PSF that separates
+// along y, see deconvolve.py) -- only the centre row of the compiled PYX x PYX footprint is visited,
+// PZ * PYX FMAs per voxel instead of PZ * PYX * PYX.
+template <int PZ, int PYX, int EPI, bool YS>
 __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) {
   using T = Tile<PYX>;
   __shared__ f32x4 bufA4[2 * T::ASZ / 4];
-  constexpr int NA = EPI == LSR_EPI_NONE ? 0 : kRun;  // aux loads per iteration
-  // UPDATE: the (pz+1)(py+1)(px+1) prefix sums of the PSF, for the border normalisation
-  constexpr int kNormTable = EPI == LSR_EPI_UPDATE ? 12 * 10 * 10 : 1;
+  constexpr bool kAux = EPI == LSR_EPI_RATIO || EPI == LSR_EPI_UPDATE;
+  constexpr bool kNorm = EPI == LSR_EPI_UPDATE || EPI == LSR_EPI_SCALE;
+  constexpr int NA = kAux ? kRun : 0;  // aux loads per iteration
+  // UPDATE / SCALE: the (pz+1)(py+1)(px+1) prefix sums of the PSF, for the border normalisation
+  constexpr int kNormTable = kNorm ? 12 * 10 * 10 : 1;
   __shared__ double s_norm[kNormTable];
-  if constexpr (EPI == LSR_EPI_UPDATE) {
+  if constexpr (kNorm) {
     const int n = (p.pz + 1) * (p.py + 1) * (p.px + 1);
     for (int i = threadIdx.x; i < n; i += kThreads) s_norm[i] = p.norm_table[i];
     __syncthreads();
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
     gload_x4(st[1], src, s_voff[1]);
   };
   auto fetch_aux = [&](int zout, float (&aux)[kRun]) {
-    if constexpr (EPI != LSR_EPI_NONE) {
+    if constexpr (kAux) {
       const float* a = uniform_ptr(p.aux + static_cast<int64_t>(min(max(zout, 0), Z - 1)) * p.aux_plane);
 #pragma unroll
       for (int m = 0; m < kRun; ++m) gload_x1(aux[m], a, a_voff[m]);
@@ -238,29 +243,37 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
         constexpr int NBUF = PZ <= 9 ? 2 : 1;
         f32x2 wq[NBUF][PZ];
 #pragma unroll
-        for (int j = 0; j < PZ; ++j) wq[0][j] = f32x2{taps[2 * j], taps[2 * j + 1]};
+        for (int j = 0; j < PZ; ++j) {
+          constexpr int t0 = YS ? cyx * PZ : 0;  // first visited group: (c = 0, b = centre) or (0, 0)
+          wq[0][j] = f32x2{taps[2 * (t0 + j)], taps[2 * (t0 + j) + 1]};
+        }
 #pragma unroll
         for (int c = 0; c < PYX; ++c) {
-          float cv[kRun + PYX - 1];
+          // column values: all kRun + PYX - 1 rows the y taps reach, or just the output rows
+          constexpr int R0 = YS ? cyx : 0, NR = YS ? kRun : kRun + PYX - 1;
+          float cv[NR];
 #pragma unroll
-          for (int j = 0; j < kRun + PYX - 1; ++j) cv[j] = A_c[j * T::PA + c];
+          for (int j = 0; j < NR; ++j) cv[j] = A_c[(j + R0) * T::PA + c];
+          constexpr int B0 = YS ? cyx : 0, B1 = YS ? cyx + 1 : PYX;
 #pragma unroll
-          for (int b = 0; b < PYX; ++b) {
-            constexpr int G = PYX * PYX;
-            const int g = c * PYX + b;
-            if constexpr (NBUF == 2) {  // taps of the NEXT (b, c) group -> the other SGPR set
+          for (int b = B0; b < B1; ++b) {
+            constexpr int G = YS ? PYX : PYX * PYX;             // tap groups this kernel visits
+            const int g = YS ? c : c * PYX + b;                 // ... and this one's place among them
+            auto tap_group = [](int gi) { return YS ? gi * PYX + cyx : gi; };  // its index in the tap block
+            if constexpr (NBUF == 2) {  // taps of the NEXT group -> the other SGPR set
               if (g + 1 < G) {
 #pragma unroll
                 for (int j = 0; j < PZ; ++j)
-                  wq[(g + 1) & 1][j] = f32x2{taps[2 * ((g + 1) * PZ + j)], taps[2 * ((g + 1) * PZ + j) + 1]};
+                  wq[(g + 1) & 1][j] = f32x2{taps[2 * (tap_group(g + 1) * PZ + j)], taps[2 * (tap_group(g + 1) * PZ + j) + 1]};
               }
             } else if (g > 0) {
 #pragma unroll
-              for (int j = 0; j < PZ; ++j) wq[0][j] = f32x2{taps[2 * (g * PZ + j)], taps[2 * (g * PZ + j) + 1]};
+              for (int j = 0; j < PZ; ++j)
+                wq[0][j] = f32x2{taps[2 * (tap_group(g) * PZ + j)], taps[2 * (tap_group(g) * PZ + j) + 1]};
             }
 #pragma unroll
             for (int q = 0; q < kRun / 2; ++q) {
-              const f32x2 v = f32x2{cv[2 * q + b], cv[2 * q + 1 + b]};
+              const f32x2 v = f32x2{cv[2 * q + b - R0], cv[2 * q + 1 + b - R0]};
               if (g == 0) {
 #pragma unroll
                 for (int j = 0; j < PZ - 1; ++j) acc[j][q] = __builtin_elementwise_fma(wq[0][j], v, acc[j + 1][q]);
@@ -285,12 +298,12 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
       auto acc0 = [&](int m) { return (m & 1) ? acc[0][m >> 1].y : acc[0][m >> 1].x; };
       if (z_out >= zb) {  // wave-uniform
         float* o = p.out + static_cast<int64_t>(z_out) * p.out_plane;
-        if constexpr (EPI != LSR_EPI_NONE) wait_loads<2 + NA>(aux_use);
+        if constexpr (kAux) wait_loads<2 + NA>(aux_use);
         if constexpr (EPI == LSR_EPI_RATIO) {
 #pragma unroll
           for (int m = 0; m < kRun; ++m)
             if (ok[m]) o[o_off[m]] = aux_use[m] * fast_rcp(acc0(m) + p.eps);
-        } else if constexpr (EPI == LSR_EPI_UPDATE) {
+        } else if constexpr (kNorm) {
           const int rz = p.pz / 2;
           const bool z_inside = z_out >= rz && z_out < Z - rz;
 #pragma unroll
@@ -298,7 +311,10 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
             if (ok[m]) {
               const float nrm = (z_inside && yx_inside[m]) ? p.norm_full
                                                            : dense_norm(p, s_norm, z_out, gy_out0 + m, gx_out);
-              o[o_off[m]] = aux_use[m] * acc0(m) * fast_rcp(nrm);
+              if constexpr (EPI == LSR_EPI_UPDATE)
+                o[o_off[m]] = aux_use[m] * acc0(m) * fast_rcp(nrm);
+              else
+                o[o_off[m]] = acc0(m) * fast_rcp(nrm);
             }
           }
         } else {
@@ -327,15 +343,30 @@ template <int PZ, int PYX>
 bool launch_one(const DenseArgs& p, dim3 grid, hipStream_t s) {
   {
     const dim3 block(kThreads);
+    if (p.ysep) {  // a (z, x) stencil: plain or normalised output (the y factor runs as its own pass)
+      switch (p.epilogue) {
+        case LSR_EPI_NONE:
+          hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_NONE, true>), grid, block, 0, s, p);
+          return true;
+        case LSR_EPI_SCALE:
+          hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_SCALE, true>), grid, block, 0, s, p);
+          return true;
+        default:
+          break;  // RATIO / UPDATE of a one-row PSF: the general kernel below (zero taps included)
+      }
+    }
     switch (p.epilogue) {
       case LSR_EPI_NONE:
-        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_NONE>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_NONE, false>), grid, block, 0, s, p);
         return true;
       case LSR_EPI_RATIO:
-        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_RATIO>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_RATIO, false>), grid, block, 0, s, p);
         return true;
       case LSR_EPI_UPDATE:
-        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_UPDATE>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_UPDATE, false>), grid, block, 0, s, p);
+        return true;
+      case LSR_EPI_SCALE:
+        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_SCALE, false>), grid, block, 0, s, p);
         return true;
       default:
         return false;

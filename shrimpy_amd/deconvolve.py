@@ -82,6 +82,32 @@ def factor_psf(psf, rtol: float = 1e-6):
     return kz.astype(np.float32), ky.astype(np.float32), kx.astype(np.float32)
 
 
+def factor_psf_y(psf: np.ndarray, rtol: float = 1e-6):
+    """``(ky, kzx)`` with ``psf[z, y, x] == ky[y] * kzx[z, x]`` to within ``rtol * max|psf|``, or ``None``.
+
+    The PSF of an oblique light sheet is tilted in the (z, x) plane and Gaussian along y: it does not
+    factor into three 1-D kernels, but it does factor into a y kernel and a dense (z, x) stencil.
+    ``ky`` is normalised to sum 1 (the scale stays in ``kzx``).
+    """
+    p = np.asarray(psf, dtype=np.float64)
+    pz, py, px = p.shape
+    peak = np.abs(p).max()
+    if peak == 0 or py == 1:
+        return None
+    m = p.transpose(1, 0, 2).reshape(py, pz * px)
+    u, sv, vt = np.linalg.svd(m, full_matrices=False)
+    ky, kzx = u[:, 0] * sv[0], vt[0].reshape(pz, px)
+    if ky.sum() < 0:
+        ky, kzx = -ky, -kzx
+    sy = ky.sum()
+    if sy == 0:
+        return None
+    ky, kzx = ky / sy, kzx * sy
+    if np.abs(ky[None, :, None] * kzx[:, None, :] - p).max() > rtol * peak:
+        return None
+    return ky.astype(np.float32), kzx.astype(np.float32)
+
+
 def _axis_norm(k: np.ndarray, n: int) -> np.ndarray:
     """sum of the taps of a 1-D correlation kernel that land inside [0, n), per position."""
     p = len(k)
@@ -224,6 +250,21 @@ class RichardsonLucyPlan:
             self._norm = (dev(_axis_norm(kz, z)), dev(ny), dev(_axis_norm(kx, x)))
         else:
             w = self.psf
+            ysep = factor_psf_y(w, separable_rtol) if separable == "auto" and y_window is None else None
+            self._ysep = None
+            if ysep is not None and len(ysep[0]) <= MAX_TAPS:
+                ky, kzx = ysep
+                zx = np.ascontiguousarray(kzx[:, None, :])                     # a (pz, 1, px) PSF
+                zx_taps = prepared_dense_taps(zx)
+                if zx_taps is not None:                                        # pz <= 11, px <= 9
+                    one = dev(np.ones(1, np.float32))
+                    self._ysep = dict(
+                        ky=dev(ky), ky_flipped=dev(ky[::-1]), one=one, py=len(ky), zx_shape=zx.shape,
+                        taps=dev(zx_taps[0]), taps_flipped=dev(zx_taps[1]),
+                        norm_table=dev(_prefix_table(zx).ravel(), torch.float64),
+                        norm_full=float(zx.astype(np.float64).sum()),
+                        ny=dev(_axis_norm(ky, y)), ones_z=dev(np.ones(z, np.float32)),
+                        ones_x=dev(np.ones(x, np.float32)))
             self._psf = _DevicePsf(
                 separable=False,
                 shape=tuple(w.shape),
@@ -232,10 +273,13 @@ class RichardsonLucyPlan:
                 norm_table=dev(_prefix_table(w).ravel(), torch.float64),
                 norm_full=float(w.astype(np.float64).sum()),
             )
-            taps = prepared_dense_taps(w)
+            taps = prepared_dense_taps(w) if self._ysep is None else None
             if taps is not None:  # PSF small enough for the tuned dense kernel
                 self._psf.taps, self._psf.taps_flipped = dev(taps[0]), dev(taps[1])
             self._norm = None
+        if factors is not None:
+            self._ysep = None
+        self._t_pad = None   # y-separable path: the intermediate between the (z, x) and the y pass
         self._ratio = None   # dense path: ratio scratch
         self._x_pad = None   # separable path: zero-haloed working volumes
         self._ratio_pad = None
@@ -254,10 +298,20 @@ class RichardsonLucyPlan:
     def separable(self) -> bool:
         return self._psf.separable
 
+    @property
+    def path(self) -> str:
+        """Which kernels an iteration runs: ``fused`` (one launch), ``separable`` (ratio / update
+        pair), ``y-separable`` ((z, x) stencil + y pass, twice), ``dense`` or ``generic``."""
+        if self._psf.separable:
+            return "fused" if self.fused else "separable"
+        if self._ysep is not None:
+            return "y-separable"
+        return "dense" if self._psf.taps is not None else "generic"
+
     def _scratch(self):
         import torch
 
-        if self._psf.separable or self._psf.taps is not None:
+        if self._psf.separable or self._psf.taps is not None or self._ysep is not None:
             if self._x_pad is None:
                 self._x_pad = PaddedVolume(self.shape, self._psf.shape, self.device)
                 self._ratio_pad = PaddedVolume(self.shape, self._psf.shape, self.device)
@@ -305,9 +359,46 @@ class RichardsonLucyPlan:
                 ctypes.c_float(eps), _lib.stream_ptr(self.device),
             )
 
+    def _iterate_ysep(self, y_ptr, y_pitch, y_plane, init, x_out, iterations, eps, stream, events):
+        """RL with ``psf = ky (x) kzx``: each correlation is the dense (z, x) stencil (PZ * PX FMAs per
+        voxel instead of PZ * PY * PX) followed by the y pass that carries the epilogue --
+        ``H x = Y~(ZX~(x))`` with ``ratio = y / (. + eps)`` in the y pass; ``H^T r = Y(ZX(r))`` with the
+        (z, x) border normalisation in the stencil launch (``LSR_EPI_SCALE``) and ``x * . / ny`` in
+        the y pass.  Four launches per iteration, all on zero-haloed padded volumes."""
+        q = self._ysep
+        x_pad, ratio_pad = self._scratch()
+        if self._t_pad is None:
+            self._t_pad = PaddedVolume(self.shape, self._psf.shape, self.device)
+        t_pad = self._t_pad
+        x_pad.view.copy_(init)
+        z, yy, xx = self.shape
+        pz, _, px = q["zx_shape"]
+        pitch, plane = x_pad.pitch, x_pad.plane
+        one, f0 = q["one"].data_ptr(), ctypes.c_float(0.0)
+        ceps = ctypes.c_float(eps)
+        if events:
+            events[0].record()
+        for it in range(iterations):
+            last = it + 1 == iterations
+            _lib.call("lsr_correlate_dense_padded_f32", x_pad.logical_ptr(), pitch, plane, None, 0, 0,
+                      t_pad.logical_ptr(), pitch, plane, z, yy, xx, q["taps_flipped"].data_ptr(), pz, 1, px,
+                      _lib.EPI_NONE, f0, None, ctypes.c_float(1.0), stream)
+            _lib.call("lsr_correlate_sep_strided_f32", t_pad.logical_ptr(), pitch, plane, y_ptr, y_pitch, y_plane,
+                      ratio_pad.logical_ptr(), pitch, plane, z, yy, xx, one, 1, q["ky_flipped"].data_ptr(), q["py"],
+                      one, 1, _lib.EPI_RATIO, ceps, None, None, None, stream)
+            _lib.call("lsr_correlate_dense_padded_f32", ratio_pad.logical_ptr(), pitch, plane, None, 0, 0,
+                      t_pad.logical_ptr(), pitch, plane, z, yy, xx, q["taps"].data_ptr(), pz, 1, px,
+                      _lib.EPI_SCALE, f0, q["norm_table"].data_ptr(), ctypes.c_float(q["norm_full"]), stream)
+            out_ptr, out_pitch, out_plane = ((x_out.data_ptr(), xx, yy * xx) if last
+                                             else (x_pad.logical_ptr(), pitch, plane))
+            _lib.call("lsr_correlate_sep_strided_f32", t_pad.logical_ptr(), pitch, plane, x_pad.logical_ptr(), pitch,
+                      plane, out_ptr, out_pitch, out_plane, z, yy, xx, one, 1, q["ky"].data_ptr(), q["py"], one, 1,
+                      _lib.EPI_UPDATE, ceps, q["ones_z"].data_ptr(), q["ny"].data_ptr(), q["ones_x"].data_ptr(),
+                      stream)
+
     def release(self) -> None:
         """Drop the scratch volumes."""
-        self._ratio = self._x_pad = self._ratio_pad = self._y_pad = None
+        self._ratio = self._x_pad = self._ratio_pad = self._y_pad = self._t_pad = None
 
     def __call__(self, y, iterations: int = 20, eps: float = 1e-6, x0=None, out=None, events=None):
         """Run RL.  ``events`` = optional ``(start, end)`` torch events recorded on the launch
@@ -317,7 +408,7 @@ class RichardsonLucyPlan:
 
         y_padded = None
         if isinstance(y, PaddedVolume):  # e.g. written in place by the deskew kernel
-            if not (self._psf.separable or self._psf.taps is not None):
+            if not (self._psf.separable or self._psf.taps is not None or self._ysep is not None):
                 y = y.view.contiguous()
             else:
                 y_padded, y = y, y.view
@@ -393,6 +484,8 @@ class RichardsonLucyPlan:
                     ps.shape[2], nz.data_ptr(), ny.data_ptr(), nx.data_ptr(), iterations,
                     ctypes.c_float(eps), stream,
                 )
+            elif self._ysep is not None:
+                self._iterate_ysep(y_ptr, y_pitch, y_plane, init, x, iterations, eps, stream, events)
             elif ps.taps is not None:
                 x_pad, ratio_pad = self._scratch()
                 if not from_y:

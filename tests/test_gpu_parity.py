@@ -674,3 +674,56 @@ def test_flatfield_and_fused_deskew_on_uint16_stacks(device):
                     average_n_slices=3)
     pre = build_preprocessor(raw.shape, ["flatfield", "deskew"], deskew=settings)
     assert torch.equal(next(iter(pre(raw).values())), b)
+
+
+def test_rl_y_separable_psf_takes_the_stencil_plus_y_pass_and_matches_dense(device):
+    """A PSF tilted in (z, x) and Gaussian along y (the oblique light sheet's, and the rotated PSF of
+    the secondary benchmark) factors as ky (x) kzx: the plan then runs a (z, x) stencil and a y pass
+    per correlation.  Same result as the 441-tap dense kernel and the oracle, within the RL bar."""
+    import torch
+
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan, factor_psf_y
+
+    psf = o.rotated_psf((9, 7, 7), (2.0, 1.2, 1.2), 30.0)
+    ky, kzx = factor_psf_y(psf)
+    assert ky.shape == (7,) and kzx.shape == (9, 7) and abs(float(ky.sum()) - 1.0) < 1e-6
+    shape = (21, 70, 150)
+    rng = np.random.default_rng(44)
+    y = (rng.poisson(100 + 3000 * (rng.random(shape) > 0.999)).astype(np.float32))
+    auto = RichardsonLucyPlan(shape, psf, device)
+    dense = RichardsonLucyPlan(shape, psf, device, separable="never")
+    assert (auto.path, dense.path) == ("y-separable", "dense")
+    a, b = auto(_t(y, device), iterations=8), dense(_t(y, device), iterations=8)
+    ref = o.richardson_lucy(y, psf, 8)
+    for got in (a, b):
+        _close(got.cpu().numpy(), ref, 2e-4, 1e-4)
+    # x0, a padded y written by a producer, zero iterations, one-plane and thin volumes
+    x0 = _t(np.full(shape, 50.0, np.float32), device)
+    _close(auto(_t(y, device), iterations=3, x0=x0).cpu().numpy(), o.richardson_lucy(y, psf, 3, x0=x0.cpu().numpy()),
+           2e-4, 1e-4)
+    ypad = auto.new_padded_input()
+    ypad.view.copy_(_t(y, device))
+    assert torch.equal(auto(ypad, iterations=8), a)
+    for thin in ((1, 9, 40), (3, 2, 5), (12, 33, 65)):
+        yt = (rng.random(thin) * 50 + 1).astype(np.float32)
+        p = RichardsonLucyPlan(thin, psf, device)
+        assert p.path == "y-separable"
+        _close(p(_t(yt, device), iterations=2).cpu().numpy(), o.richardson_lucy(yt, psf, 2), 2e-4, 1e-4)
+
+
+def test_rl_y_separable_random_psf_shapes(device):
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+
+    rng = np.random.default_rng(45)
+    for case in range(10):
+        pz, py, px = int(rng.choice([3, 5, 7, 9, 11])), int(rng.choice([3, 5, 9, 13, 15])), int(rng.choice([3, 5, 7, 9]))
+        kzx = np.abs(rng.normal(1.0, 0.5, (pz, px))) + 0.05
+        ky = np.abs(rng.normal(1.0, 0.4, py)) + 0.05
+        psf = (ky[None, :, None] * kzx[:, None, :]).astype(np.float32)
+        psf /= psf.sum()
+        shape = (int(rng.integers(1, 30)), int(rng.integers(1, 80)), int(rng.integers(1, 200)))
+        y = (rng.random(shape) * 80 + 1).astype(np.float32)
+        plan = RichardsonLucyPlan(shape, psf, device)
+        assert plan.path == "y-separable", (case, psf.shape)
+        iters = int(rng.integers(1, 4))
+        _close(plan(_t(y, device), iterations=iters).cpu().numpy(), o.richardson_lucy(y, psf, iters), 2e-4, 1e-4)
