@@ -199,3 +199,33 @@ def test_estimators_full_size_match_the_oracle(scene):
     bg = o.dt_percentile(host, 90.0)
     np.testing.assert_allclose(d._intensity_center_of_mass(deskewed, bg).cpu().numpy(),
                                o.dt_intensity_center_of_mass(host, bg), atol=2e-3)
+
+
+def test_rl_full_size_y_separable_path_agrees_with_the_dense_kernel(scene, device):
+    """The secondary PSF (rotated 30 deg about Y) at config-2 size: (z, x) stencil + y pass against the
+    441-tap dense kernel over the whole volume, and against the oracle on a crop with full margin."""
+    import torch
+
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+
+    _, deskewed = scene
+    psf = o.rotated_psf(PSF_SHAPE, PSF_SIGMA, 30.0)
+    iters = 6
+    split = RichardsonLucyPlan(tuple(deskewed.shape), psf, device)
+    assert split.path == "y-separable"
+    a = split(deskewed, iterations=iters)
+    split.release()
+    dense = RichardsonLucyPlan(tuple(deskewed.shape), psf, device, separable="never")
+    assert dense.path == "dense"
+    b = dense(deskewed, iterations=iters)
+    dense.release()
+    tol = 2e-4 * b.abs() + 1e-4 * float(b.max())
+    assert bool(((a - b).abs() <= tol).all())
+    margin, core = iters * 2 * 3, 40          # 6 iterations reach 36 voxels in the plane, all of z
+    y0, x0 = 700, 1100
+    crop = deskewed[:, y0 - margin:y0 + core + margin, x0 - margin:x0 + core + margin].contiguous().cpu().numpy()
+    want = o.richardson_lucy(crop, psf, iters)[:, margin:margin + core, margin:margin + core].astype(np.float64)
+    got = a[:, y0:y0 + core, x0:x0 + core].cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(got - want) <= 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max())
+    del a, b
+    torch.cuda.empty_cache()
