@@ -255,8 +255,8 @@ def main():
 
     if rank == 0:
         fused = bool(getattr(plan, "fused", False))
-        ysep = plan.path == "y-separable"
-        launches = RL_ITERS if fused else (4 * RL_ITERS if ysep else 2 * RL_ITERS)
+        ysep = plan.path.startswith("y-separable")
+        launches = RL_ITERS if fused else (4 * RL_ITERS if plan.path.endswith("(4 launches)") else 2 * RL_ITERS)
         launch_s = rl_kernels_ms * 1e-3 / launches  # HIP events right around the launches, / count
         # fused iteration: x, y in, x_new out; ratio / update launch: in + aux + out
         bytes_per_launch = 12.0 * n_o
@@ -329,17 +329,17 @@ def main():
                                                 "frac": 24.0 * n_o / launch_s / 1e9 / HBM_PEAK_GBS}}
                        if fused else {}),
                 } if args.psf == "separable" else ({
-                    # per correlation: a 63-tap (z, x) stencil launch (in + out = 8 B/voxel) and a
-                    # 7-tap y pass carrying the epilogue (in + aux + out = 12 B/voxel)
-                    "kernel": "correlate_dense_kernel<9,7,*,YS> + correlate_sep_kernel<3,7,3> (4 launches per RL iteration)",
+                    # one launch per correlation: y pass (7 taps) + (z, x) stencil (63 taps) on the
+                    # staged plane, in + aux + out = 12 B/voxel
+                    "kernel": "correlate_dense_kernel<9,7,*,2> (ky (x) kzx, RL ratio / update launch)",
                     "bound": "hbm",
-                    "achieved": 10.0 * n_o / launch_s / 1e9,
+                    "achieved": achieved,
                     "peak": HBM_PEAK_GBS,
                     "unit": "GB/s",
-                    "frac": 10.0 * n_o / launch_s / 1e9 / HBM_PEAK_GBS,
+                    "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic,
                     "launch_ms": launch_s * 1e3,
-                    "algorithmic_bytes_per_launch": 10.0 * n_o,
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
                 } if ysep else {
                     # a 441-tap dense stencil is fp32-VALU-bound, not HBM-bound
                     "kernel": "correlate_dense_kernel<9,7> (dense RL ratio / update launch)",

@@ -273,6 +273,20 @@ int lsr_correlate_dense_padded_f32(const float* in, int64_t in_pitch, int64_t in
                                    int epilogue, float eps, const double* norm_table,
                                    float norm_full, lsr_stream_t stream);
 
+/*
+ * One launch for a PSF that separates along y, psf[z][y][x] = ky[y] * kzx[z][x] (the tilted
+ * light-sheet PSF): out = epilogue(correlate(in, psf), aux) with LSR_EPI_RATIO or LSR_EPI_UPDATE.
+ * `taps_zx` = lsr_dense_prepare_taps of the pz x py x px array that holds kzx in its centre y row and
+ * zeros elsewhere (flip = 1 for H x); `ky` = the py y taps on the device (reversed for H x);
+ * norm_table / norm_full = those of the full PSF.  pz*px + py FMAs per voxel instead of pz*py*px.
+ * Volumes and strides as lsr_correlate_dense_padded_f32.
+ */
+int lsr_correlate_zxy_padded_f32(const float* in, int64_t in_pitch, int64_t in_plane,
+                                 const float* aux, int64_t aux_pitch, int64_t aux_plane, float* out,
+                                 int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y, int64_t X,
+                                 const float* taps_zx, const float* ky, int pz, int py, int px,
+                                 int epilogue, float eps, const double* norm_table, float norm_full,
+                                 lsr_stream_t stream);
 int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
                             float* x_pad, float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X,
                             const float* taps, const float* taps_flipped, int pz, int py, int px,

@@ -93,6 +93,10 @@ SIGNATURES: dict[str, list] = {
     ],
     "lsr_dense_taps_count": [_int, _int, _int],
     "lsr_dense_prepare_taps": [ctypes.c_void_p, _int, _int, _int, _int, ctypes.c_void_p],
+    "lsr_correlate_zxy_padded_f32": [
+        _c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64,
+        _c_f32p, _c_f32p, _int, _int, _int, _int, _f32, ctypes.c_void_p, _f32, _stream,
+    ],
     "lsr_correlate_dense_padded_f32": [
         _c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64,
         _c_f32p, _int, _int, _int, _int, _f32, ctypes.c_void_p, _f32, _stream,

@@ -694,7 +694,10 @@ extern "C" int lsr_dense_prepare_taps(const float* psf_host, int pz, int py, int
   return LSR_OK;
 }
 
-extern "C" int lsr_correlate_dense_padded_f32(
+namespace {
+// mode 0 / 1: lsr_correlate_dense_padded_f32 (1 = the caller's PSF has a single y tap);
+// mode 2: lsr_correlate_zxy_padded_f32 (taps = the (z, x) stencil in the layout of the full PSF, ky = y taps)
+int dense_padded_launch(const char* what, int mode, const float* ky,
     const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch,
     int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y,
     int64_t X, const float* taps, int pz, int py, int px, int epilogue, float eps,
@@ -729,7 +732,13 @@ extern "C" int lsr_correlate_dense_padded_f32(
               "aux/out pitch smaller than X");
 
   lsr::DenseArgs p{};
-  p.ysep = py == 1 ? 1 : 0;
+  p.ysep = mode == 2 ? 2 : (py == 1 ? 1 : 0);
+  p.ky = ky;
+  if (mode == 2) {
+    LSR_REQUIRE_PTR(ky);
+    LSR_REQUIRE(epilogue == LSR_EPI_RATIO || epilogue == LSR_EPI_UPDATE, LSR_E_ARG,
+                "the one-launch ky (x) kzx correlation carries the RL epilogues only (got %d)", epilogue);
+  }
   p.in = in; p.aux = aux; p.out = out;
   p.in_plane = in_plane; p.aux_plane = aux_plane; p.out_plane = out_plane;
   p.in_pitch = static_cast<int>(in_pitch);
@@ -759,7 +768,28 @@ extern "C" int lsr_correlate_dense_padded_f32(
     default: break;
   }
   LSR_REQUIRE(ok, LSR_E_UNSUPPORTED, "no dense specialisation for taps (%d,%d,%d)", pz, py, px);
-  return lsr::launch_status("lsr_correlate_dense_padded_f32");
+  return lsr::launch_status(what);
+}
+}  // namespace
+
+extern "C" int lsr_correlate_dense_padded_f32(
+    const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch,
+    int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y,
+    int64_t X, const float* taps, int pz, int py, int px, int epilogue, float eps,
+    const double* norm_table, float norm_full, lsr_stream_t stream) {
+  return dense_padded_launch("lsr_correlate_dense_padded_f32", 0, nullptr, in, in_pitch, in_plane, aux, aux_pitch,
+                             aux_plane, out, out_pitch, out_plane, Z, Y, X, taps, pz, py, px, epilogue, eps,
+                             norm_table, norm_full, stream);
+}
+
+extern "C" int lsr_correlate_zxy_padded_f32(
+    const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch,
+    int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y,
+    int64_t X, const float* taps_zx, const float* ky, int pz, int py, int px, int epilogue, float eps,
+    const double* norm_table, float norm_full, lsr_stream_t stream) {
+  return dense_padded_launch("lsr_correlate_zxy_padded_f32", 2, ky, in, in_pitch, in_plane, aux, aux_pitch,
+                             aux_plane, out, out_pitch, out_plane, Z, Y, X, taps_zx, pz, py, px, epilogue, eps,
+                             norm_table, norm_full, stream);
 }
 
 extern "C" int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane,

@@ -68,7 +68,8 @@ struct DenseArgs {
   int tiles_x, tiles_y;
   int z_chunk;
   const float* taps;
-  int ysep;                  // 1: the caller's PSF has a single y tap -- the (z, x)-stencil specialisation
+  int ysep;                  // 1: a single y tap -- the (z, x)-stencil specialisation; 2: ky (x) kzx in one launch
+  const float* ky;           // ysep == 2: the py y taps (device)
 };
 
 // Tile geometry of the tuned kernels, needed by the host to size the halo (lsr_sep_padded_shape).

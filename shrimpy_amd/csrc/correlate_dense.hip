@@ -101,10 +101,14 @@ __device__ float dense_norm(const DenseArgs& p, const double* P, int z, int y, i
                              (P[a1 * sa + b0 * sb + c0] - P[a0 * sa + b0 * sb + c0])));
 }
 
-// YS: the caller's PSF has one tap along y (a (z, x) stencil: the dense half of a PSF that separates
-// along y, see deconvolve.py) -- only the centre row of the compiled PYX x PYX footprint is visited,
-// PZ * PYX FMAs per voxel instead of PZ * PYX * PYX.
-template <int PZ, int PYX, int EPI, bool YS>
+// MODE 0: the full PZ x PYX x PYX stencil.
+// MODE 1: the caller's PSF has one tap along y (a (z, x) stencil: the dense half of a PSF that
+//         separates along y, see deconvolve.py) -- only the centre row of the compiled PYX x PYX
+//         footprint is visited, PZ * PYX FMAs per voxel instead of PZ * PYX * PYX.
+// MODE 2: the whole PSF ky (x) kzx in one launch: every wave first filters its own four rows of the
+//         staged plane along y (PYX taps, LDS -> LDS, rows only that wave reads: no barrier), then
+//         runs the (z, x) stencil of MODE 1 on the filtered rows.  PZ * PYX + PYX FMAs per voxel.
+template <int PZ, int PYX, int EPI, int MODE>
 __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) {
   using T = Tile<PYX>;
   __shared__ f32x4 bufA4[2 * T::ASZ / 4];
@@ -114,6 +118,8 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
   // UPDATE / SCALE: the (pz+1)(py+1)(px+1) prefix sums of the PSF, for the border normalisation
   constexpr int kNormTable = kNorm ? 12 * 10 * 10 : 1;
   __shared__ double s_norm[kNormTable];
+  constexpr bool YS = MODE != 0;
+  __shared__ float bufB[MODE == 2 ? kTY * T::PA : 1];  // y-filtered rows of the plane being absorbed
   if constexpr (kNorm) {
     const int n = (p.pz + 1) * (p.py + 1) * (p.px + 1);
     for (int i = threadIdx.x; i < n; i += kThreads) s_norm[i] = p.norm_table[i];
@@ -187,6 +193,16 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
 
   typedef const float __attribute__((address_space(4))) cfloat;  // constant AS: scalar loads
   const cfloat* const taps_base = (const cfloat*)p.taps;
+  float kyv[PYX];  // MODE 2: the caller's py y taps, centred in the compiled extent
+#pragma unroll
+  for (int b = 0; b < PYX; ++b) kyv[b] = 0.0f;
+  if constexpr (MODE == 2) {
+    const cfloat* const ky = (const cfloat*)p.ky;
+    const int off = (PYX - p.py) / 2;
+#pragma unroll
+    for (int b = 0; b < PYX; ++b)
+      if (b >= off && b < off + p.py) kyv[b] = ky[b - off];
+  }
 
   // pending output planes as packed pairs (rows 2q, 2q+1 of the thread's column): v_pk_fma_f32
   static_assert(kRun % 2 == 0, "rows are paired");
@@ -233,6 +249,29 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
       // Pending planes move up by one (acc[j] <-> z_out = zcur - cz + j) -- folded into the first
       // tap group's FMAs (acc[j] = w * v + acc[j+1], ascending j), so no register moves.
       if (zcur < Z) {
+        if constexpr (MODE == 2) {
+          // y pass of this wave's rows: columns lane and (for the x halo) lane + 64
+          const float* Ay = reinterpret_cast<const float*>(bufA4 + (par ^ 1) * (T::ASZ / 4)) + (wave * kRun) * T::PA;
+          float* Bw = bufB + (wave * kRun) * T::PA;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int col = lane + 64 * h;
+            if (h == 0 || col < T::AC) {
+              float cy[kRun + PYX - 1];
+#pragma unroll
+              for (int j = 0; j < kRun + PYX - 1; ++j) cy[j] = Ay[j * T::PA + col];
+#pragma unroll
+              for (int m = 0; m < kRun; ++m) {
+                float sy = kyv[0] * cy[m];
+#pragma unroll
+                for (int b = 1; b < PYX; ++b) sy = fmaf(kyv[b], cy[m + b], sy);
+                Bw[m * T::PA + col] = sy;
+              }
+            }
+          }
+        }
+        // (LDS operations of one wave execute in order: the reads below see the rows just written)
+        const float* const S_c = MODE == 2 ? bufB + acol : A_c;   // MODE 2: row j of S is output row j
         int opaque = 0;
         asm volatile("" : "+s"(opaque));  // loop-variant for the optimiser, always 0
         const cfloat* taps = taps_base + opaque;
@@ -251,9 +290,10 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
         for (int c = 0; c < PYX; ++c) {
           // column values: all kRun + PYX - 1 rows the y taps reach, or just the output rows
           constexpr int R0 = YS ? cyx : 0, NR = YS ? kRun : kRun + PYX - 1;
+          constexpr int RS = MODE == 2 ? 0 : R0;   // first row to read in the source plane
           float cv[NR];
 #pragma unroll
-          for (int j = 0; j < NR; ++j) cv[j] = A_c[(j + R0) * T::PA + c];
+          for (int j = 0; j < NR; ++j) cv[j] = S_c[(j + RS) * T::PA + c];
           constexpr int B0 = YS ? cyx : 0, B1 = YS ? cyx + 1 : PYX;
 #pragma unroll
           for (int b = B0; b < B1; ++b) {
@@ -343,13 +383,25 @@ template <int PZ, int PYX>
 bool launch_one(const DenseArgs& p, dim3 grid, hipStream_t s) {
   {
     const dim3 block(kThreads);
-    if (p.ysep) {  // a (z, x) stencil: plain or normalised output (the y factor runs as its own pass)
+    if (p.ysep == 2) {  // ky (x) kzx in one launch (RL ratio / update)
+      switch (p.epilogue) {
+        case LSR_EPI_RATIO:
+          hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_RATIO, 2>), grid, block, 0, s, p);
+          return true;
+        case LSR_EPI_UPDATE:
+          hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_UPDATE, 2>), grid, block, 0, s, p);
+          return true;
+        default:
+          return false;
+      }
+    }
+    if (p.ysep == 1) {  // a (z, x) stencil: plain or normalised output (the y factor runs as its own pass)
       switch (p.epilogue) {
         case LSR_EPI_NONE:
-          hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_NONE, true>), grid, block, 0, s, p);
+          hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_NONE, 1>), grid, block, 0, s, p);
           return true;
         case LSR_EPI_SCALE:
-          hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_SCALE, true>), grid, block, 0, s, p);
+          hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_SCALE, 1>), grid, block, 0, s, p);
           return true;
         default:
           break;  // RATIO / UPDATE of a one-row PSF: the general kernel below (zero taps included)
@@ -357,16 +409,16 @@ bool launch_one(const DenseArgs& p, dim3 grid, hipStream_t s) {
     }
     switch (p.epilogue) {
       case LSR_EPI_NONE:
-        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_NONE, false>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_NONE, 0>), grid, block, 0, s, p);
         return true;
       case LSR_EPI_RATIO:
-        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_RATIO, false>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_RATIO, 0>), grid, block, 0, s, p);
         return true;
       case LSR_EPI_UPDATE:
-        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_UPDATE, false>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_UPDATE, 0>), grid, block, 0, s, p);
         return true;
       case LSR_EPI_SCALE:
-        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_SCALE, false>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_SCALE, 0>), grid, block, 0, s, p);
         return true;
       default:
         return false;

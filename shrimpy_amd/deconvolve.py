@@ -258,7 +258,15 @@ class RichardsonLucyPlan:
                 zx_taps = prepared_dense_taps(zx)
                 if zx_taps is not None:                                        # pz <= 11, px <= 9
                     one = dev(np.ones(1, np.float32))
+                    emb = np.zeros(w.shape, np.float32)                        # kzx in the centre y row
+                    emb[:, w.shape[1] // 2, :] = kzx
+                    fused_taps = prepared_dense_taps(emb)                      # also needs py <= 9
                     self._ysep = dict(
+                        fused=None if fused_taps is None else dict(
+                            taps=dev(fused_taps[0]), taps_flipped=dev(fused_taps[1]),
+                            norm_table=dev(_prefix_table(ky[None, :, None] * kzx[:, None, :]).ravel(), torch.float64),
+                            norm_full=float((ky.astype(np.float64)[None, :, None]
+                                             * kzx.astype(np.float64)[:, None, :]).sum())),
                         ky=dev(ky), ky_flipped=dev(ky[::-1]), one=one, py=len(ky), zx_shape=zx.shape,
                         taps=dev(zx_taps[0]), taps_flipped=dev(zx_taps[1]),
                         norm_table=dev(_prefix_table(zx).ravel(), torch.float64),
@@ -305,7 +313,7 @@ class RichardsonLucyPlan:
         if self._psf.separable:
             return "fused" if self.fused else "separable"
         if self._ysep is not None:
-            return "y-separable"
+            return "y-separable" if self._ysep["fused"] is not None else "y-separable (4 launches)"
         return "dense" if self._psf.taps is not None else "generic"
 
     def _scratch(self):
@@ -367,6 +375,30 @@ class RichardsonLucyPlan:
         the y pass.  Four launches per iteration, all on zero-haloed padded volumes."""
         q = self._ysep
         x_pad, ratio_pad = self._scratch()
+        if q["fused"] is not None:
+            # both factors in one launch per correlation (lsr_correlate_zxy_padded_f32): the y pass
+            # runs inside the stencil kernel, wave by wave, on the staged plane
+            f = q["fused"]
+            x_pad.view.copy_(init)
+            z, yy, xx = self.shape
+            pz, py, px = self._psf.shape
+            pitch, plane = x_pad.pitch, x_pad.plane
+            ceps = ctypes.c_float(eps)
+            if events:
+                events[0].record()
+            for it in range(iterations):
+                last = it + 1 == iterations
+                _lib.call("lsr_correlate_zxy_padded_f32", x_pad.logical_ptr(), pitch, plane, y_ptr, y_pitch, y_plane,
+                          ratio_pad.logical_ptr(), pitch, plane, z, yy, xx, f["taps_flipped"].data_ptr(),
+                          q["ky_flipped"].data_ptr(), pz, py, px, _lib.EPI_RATIO, ceps, None,
+                          ctypes.c_float(1.0), stream)
+                out_ptr, out_pitch, out_plane = ((x_out.data_ptr(), xx, yy * xx) if last
+                                                 else (x_pad.logical_ptr(), pitch, plane))
+                _lib.call("lsr_correlate_zxy_padded_f32", ratio_pad.logical_ptr(), pitch, plane, x_pad.logical_ptr(),
+                          pitch, plane, out_ptr, out_pitch, out_plane, z, yy, xx, f["taps"].data_ptr(),
+                          q["ky"].data_ptr(), pz, py, px, _lib.EPI_UPDATE, ceps, f["norm_table"].data_ptr(),
+                          ctypes.c_float(f["norm_full"]), stream)
+            return
         if self._t_pad is None:
             self._t_pad = PaddedVolume(self.shape, self._psf.shape, self.device)
         t_pad = self._t_pad

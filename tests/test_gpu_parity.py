@@ -724,6 +724,6 @@ def test_rl_y_separable_random_psf_shapes(device):
         shape = (int(rng.integers(1, 30)), int(rng.integers(1, 80)), int(rng.integers(1, 200)))
         y = (rng.random(shape) * 80 + 1).astype(np.float32)
         plan = RichardsonLucyPlan(shape, psf, device)
-        assert plan.path == "y-separable", (case, psf.shape)
+        assert plan.path == ("y-separable" if py <= 9 else "y-separable (4 launches)"), (case, psf.shape)
         iters = int(rng.integers(1, 4))
         _close(plan(_t(y, device), iterations=iters).cpu().numpy(), o.richardson_lucy(y, psf, iters), 2e-4, 1e-4)
