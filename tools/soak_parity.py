@@ -33,6 +33,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", default="", help="comma-separated family names")
     ap.add_argument("--large", action="store_true", help="large-shape families only (work split, big grids)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -140,6 +141,24 @@ def main():
             ok = ok and d._phase_cross_corr(t(vol), t(mov)) == o.dt_phase_cross_corr(vol, mov)
         return bool(ok), (shape, p, bg, shift)
 
+    def rl_ysep_case(r):
+        """PSFs that separate along y only: one-launch and four-launch forms against the oracle."""
+        pz, py, px = int(r.choice([3, 5, 7, 9, 11])), int(r.choice([3, 5, 7, 9, 11, 15])), int(r.choice([3, 5, 7, 9]))
+        kzx = np.abs(r.normal(1.0, 0.5, (pz, px))) + 0.05
+        ky = np.abs(r.normal(1.0, 0.4, py)) + 0.05
+        psf = (ky[None, :, None] * kzx[:, None, :]).astype(np.float32)
+        psf /= psf.sum()
+        shape = (int(r.integers(1, 24)), int(r.integers(1, 90)), int(r.integers(1, 160)))
+        y = (r.random(shape) * 80 + 1).astype(np.float32)
+        plan = RichardsonLucyPlan(shape, psf, dev)
+        if not plan.path.startswith("y-separable"):
+            return False, (psf.shape, shape, plan.path)
+        iters = int(r.integers(1, 4))
+        got = plan(t(y), iterations=iters).cpu().numpy().astype(np.float64)
+        want = o.richardson_lucy(y, psf, iters).astype(np.float64)
+        ok = bool(np.all(np.abs(got - want) <= 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max()))
+        return ok, (psf.shape, shape, iters, plan.path)
+
     def rl_large_case(r):
         """More tiles than CUs: the whole-column / z-piece work split of the fused kernel."""
         pshape = tuple(int(v) for v in r.choice(odd[:6], 3))
@@ -174,7 +193,9 @@ def main():
         return ok, (shape, angle, ratio, keep, avg, x0)
 
     families = {"deskew": deskew_case, "affine": affine_case, "rl": rl_case, "flatfield": flat_case,
-                "blur": blur_case, "estimators": estimator_case}
+                "blur": blur_case, "estimators": estimator_case, "rl_ysep": rl_ysep_case}
+    if args.only:
+        families = {k: v for k, v in families.items() if k in args.only.split(",")}
     if args.large:
         families = {"rl_large": rl_large_case, "deskew_large": deskew_large_case}
     d.set_spectrum_cache_bytes(0)
