@@ -136,8 +136,7 @@ class VolumeReconstructor:
                 vol = flat.apply(vol)
         if self._geo is not None:
             target = None
-            if self._plan is not None and self._register is None and (
-                    self._plan.separable or self._plan._psf.taps is not None):
+            if self._plan is not None and self._register is None and self._plan.path != "generic":
                 # deskew straight into the RL kernels' padded, line-aligned input volume
                 if self._y_pad is None:
                     self._y_pad = self._plan.new_padded_input()
