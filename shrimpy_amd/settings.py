@@ -124,6 +124,13 @@ class DeconvolveSettings(_StrictModel):
 
     The PSF comes from ``psf_path`` (``.npy`` ZYX array) or, when absent, is the separable
     anisotropic Gaussian ``gaussian_sigma_zyx`` truncated to ``gaussian_shape_zyx``.
+
+    ``separable="auto"`` picks the cheapest exact form of the PSF: three 1-D kernels (one fused launch
+    per iteration), else ``ky (x) kzx`` -- a y kernel times a dense (z, x) stencil, the shape of a
+    tilted light-sheet PSF -- else the dense stencil.  A factorisation is accepted when it reproduces
+    the PSF to ``separable_rtol`` of its peak: the default only admits PSFs that factor exactly; a
+    measured PSF can be run in a factored form by raising it (the PSF used is then the factored
+    one).  ``"force"`` insists on three 1-D kernels, ``"never"`` on the dense stencil.
     """
 
     iterations: NonNegativeInt = 20
