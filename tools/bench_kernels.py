@@ -178,7 +178,10 @@ def _estimators(args, torch, dev, g, oshape):
 
 def _rl(args, torch, dev, g, bench, RichardsonLucyPlan, oshape):
     y = torch.poisson(torch.full(oshape, 100.0, device=dev), generator=g)
-    plans = [("separable 9x7x7", RichardsonLucyPlan(oshape, None, dev, psf_factors=bench.gaussian_factors()), 4)]
+    plans = [("separable 9x7x7, one launch per iteration", RichardsonLucyPlan(oshape, None, dev, psf_factors=bench.gaussian_factors()), 4),
+             ("separable 9x7x7, ratio / update launches",
+              RichardsonLucyPlan(oshape, None, dev, psf_factors=bench.gaussian_factors(), fused="never"), 4),
+             ("rotated 9x7x7 as ky (x) kzx, ratio / update launches", RichardsonLucyPlan(oshape, bench.rotated_psf(), dev), 4)]
     if not args.skip_dense:
         plans.append(("dense 9x7x7 (rotated)", RichardsonLucyPlan(oshape, bench.rotated_psf(), dev, separable="never"), 1))
     for name, plan, iters in plans:
@@ -187,10 +190,12 @@ def _rl(args, torch, dev, g, bench, RichardsonLucyPlan, oshape):
         torch.cuda.synchronize()
         plan(y, iterations=iters, events=ev)
         torch.cuda.synchronize()
-        ms = ev[0].elapsed_time(ev[1]) / (2 * iters)
+        launches = {"fused": 1, "y-separable (4 launches)": 4}.get(plan.path, 2) * iters
+        ms = ev[0].elapsed_time(ev[1]) / launches
         nbytes = 12.0 * y.numel()
-        taps = 23 if plan.separable else 441
-        print(json.dumps({"kernel": f"RL launch, {name}", "grid": oshape, "ms_per_launch": ms,
+        taps = {"fused": 46, "separable": 23, "y-separable": 70}.get(plan.path, 441)
+        plan.release()
+        print(json.dumps({"kernel": f"RL launch, {name}", "path": plan.path, "grid": oshape, "ms_per_launch": ms,
                           "algorithmic_GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / 8000,
                           "fma_TFLOPs": 2.0 * taps * y.numel() / ms / 1e9}))
 
