@@ -7,5 +7,5 @@ OUT=$R/gpurun_out/$1
 shift
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "rl_fused|correlate_sep|deskew_kernel" --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/$c.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "rl_fused|correlate_sep|correlate_dense|deskew_kernel" --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/$c.log 2>&1
 done
