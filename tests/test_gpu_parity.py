@@ -727,3 +727,37 @@ def test_rl_y_separable_random_psf_shapes(device):
         assert plan.path == ("y-separable" if py <= 9 else "y-separable (4 launches)"), (case, psf.shape)
         iters = int(rng.integers(1, 4))
         _close(plan(_t(y, device), iterations=iters).cpu().numpy(), o.richardson_lucy(y, psf, iters), 2e-4, 1e-4)
+
+
+def test_zxy_entry_rejects_what_it_does_not_cover(device):
+    """The one-launch ky (x) kzx entry carries the RL epilogues only, needs its y taps, and shares the
+    dense kernel's tap range; errors come back as status codes with a message, nothing is launched."""
+    import ctypes
+
+    import torch
+
+    from shrimpy_amd import _lib
+    from shrimpy_amd.deconvolve import PaddedVolume
+
+    shape, pshape = (6, 20, 40), (5, 5, 5)
+    a, b = PaddedVolume(shape, pshape, device), PaddedVolume(shape, pshape, device)
+    taps = torch.zeros(_lib.call_value("lsr_dense_taps_count", *pshape), device=device)
+    ky = torch.ones(5, device=device) / 5
+    table = torch.zeros(6 * 6 * 6, dtype=torch.float64, device=device)
+    z, y, x = shape
+
+    def call(epi, ky_ptr=ky.data_ptr(), p=pshape, table_ptr=table.data_ptr()):
+        _lib.call("lsr_correlate_zxy_padded_f32", a.logical_ptr(), a.pitch, a.plane, a.logical_ptr(), a.pitch, a.plane,
+                  b.logical_ptr(), b.pitch, b.plane, z, y, x, taps.data_ptr(), ky_ptr, *p, epi, ctypes.c_float(1e-6),
+                  table_ptr, ctypes.c_float(1.0), _lib.stream_ptr(device))
+
+    with pytest.raises(_lib.LsrError, match="RL epilogues only"):
+        call(_lib.EPI_NONE)
+    with pytest.raises(_lib.LsrError):
+        call(_lib.EPI_RATIO, ky_ptr=None)
+    with pytest.raises(_lib.LsrError):
+        call(_lib.EPI_UPDATE, table_ptr=None)
+    with pytest.raises(_lib.LsrUnsupported):
+        call(_lib.EPI_RATIO, p=(5, 11, 5))      # y taps beyond the dense kernel's nine
+    call(_lib.EPI_RATIO)                         # and the valid call goes through
+    torch.cuda.synchronize()
