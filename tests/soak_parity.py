@@ -1,9 +1,10 @@
 """Randomised parity soak: many seeded random cases per kernel against the oracle (or against the
 other device path where the bar is bit-equality), for a bounded time.  Not part of the test suite --
-a one-off sweep for shapes and parameters nobody wrote a case for.  Prints one JSON line per family
+a one-off sweep for shapes and parameters nobody wrote a case for (it lives under tests/ because it
+uses the oracle as its checker; pytest does not collect it).  Prints one JSON line per family
 (cases run, failures with their seeds) and exits non-zero if anything failed.
 
-    python tools/soak_parity.py --seconds 240 --seed 1
+    python tests/soak_parity.py --seconds 240 --seed 1
 """
 import argparse
 import ctypes
