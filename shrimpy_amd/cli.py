@@ -61,13 +61,22 @@ def _distributed():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise click.ClickException("no HIP device: this path runs only on a GPU (MI355X); there is no CPU fallback")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    n_dev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    torch.cuda.set_device(local % n_dev)
+    device = torch.device("cuda", local % n_dev)
     if world > 1:
         import torch.distributed as dist
 
         if not dist.is_initialized():
-            dist.init_process_group("nccl", device_id=device)
+            # one rank per GPU: RCCL.  More ranks than GPUs on the node (ranks share a card, e.g. a
+            # rehearsal on a one-GPU box): RCCL refuses duplicate devices, gloo carries the barrier
+            # and the timing reduction instead -- the data path has no collective either way.
+            backend = os.environ.get("LSR_DIST_BACKEND") or ("nccl" if local_world <= n_dev else "gloo")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(backend)
     return rank, world, device
 
 
