@@ -119,15 +119,39 @@ def affine_apply_4x4(volume, matrix_4x4, output_shape, cval=0.0, mode="constant"
     return affine_apply(volume, m[:3, :3], m[:3, 3], output_shape, cval=cval, mode=mode)
 
 
-def deskew(raw, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices=1):
-    """Deskew a raw ``(Z_scan, Y_tilt, X)`` stack -> ``(ceil(Y/avg), X, Xp)`` float32."""
+def orient(volume, orientation="identity"):
+    """Re-orient a canonical deskewed volume: ``+``-joined numpy operations applied left to right
+    (``flip_z|flip_y|flip_x``, ``transpose_yx``, ``rot90|rot180|rot270`` = ``np.rot90(axes=(1, 2))``).
+    The orientation ``fast_deskew_zyx`` returns is a [RECALLED] convention (SURVEY.md section 8 a2,
+    stale comment ``shrimpy/preprocessing.py:224``), hence a switch."""
+    for op in str(orientation).split("+"):
+        op = op.strip()
+        if op == "identity":
+            continue
+        if op in ("flip_z", "flip_y", "flip_x"):
+            volume = np.flip(volume, axis="zyx".index(op[-1]))
+        elif op == "transpose_yx":
+            volume = np.swapaxes(volume, 1, 2)
+        elif op in ("rot90", "rot180", "rot270"):
+            volume = np.rot90(volume, k=int(op[3:]) // 90, axes=(1, 2))
+        else:
+            raise ValueError(f"unknown orientation op {op!r}")
+    return np.ascontiguousarray(volume)
+
+
+def deskew(raw, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices=1,
+           orientation="identity", border="constant"):
+    """Deskew a raw ``(Z_scan, Y_tilt, X)`` stack -> ``(ceil(Y/avg), X, Xp)`` float32.
+
+    ``border`` is scipy's ``mode`` (``"constant"``: no blending, the north-star's path;
+    ``"grid-constant"``: blend towards zero, the torch ``grid_sample`` behaviour)."""
     matrix, offset, pre_shape = deskew_geometry(
         raw.shape, ls_angle_deg, px_to_scan_ratio, keep_overhang
     )
     if pre_shape[2] <= 0:
         raise ValueError(f"deskewed scan extent is not positive: {pre_shape}")
-    out = affine_apply(raw, matrix, offset, pre_shape)
-    return average_slices(out, average_n_slices)
+    out = affine_apply(raw, matrix, offset, pre_shape, mode=border)
+    return orient(average_slices(out, average_n_slices), orientation)
 
 
 # --------------------------------------------------------------------------------------

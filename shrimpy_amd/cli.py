@@ -118,7 +118,10 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
         d = settings.deskew
         voxel = deskew_geometry((nz, ny, nx), d.ls_angle_deg, d.px_to_scan_ratio, d.keep_overhang,
                                 d.average_n_slices, d.pixel_size_um).voxel_size
-        out_scale[2:] = [float(v) for v in voxel]  # scale metadata as scripts/measure_psf.py:273-276
+        from .geometry import orient_voxel
+
+        # scale metadata as scripts/measure_psf.py:273-276
+        out_scale[2:] = [float(v) for v in orient_voxel(voxel, d.orientation)]
 
     # rank 0 creates the output store (positions are separate arrays on disk); then everybody writes
     if rank == 0:

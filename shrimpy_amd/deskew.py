@@ -21,7 +21,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .geometry import as_matrix_3x4, deskew_geometry
+from .geometry import as_matrix_3x4, deskew_geometry, orient_axes, orient_shape, orient_voxel
 
 __all__ = [
     "fast_deskew_zyx",
@@ -29,7 +29,10 @@ __all__ = [
     "deskew_data",
     "deskew_with_matrix",
     "average_n_slices",
+    "orient_volume",
 ]
+
+BORDERS = ("constant", "grid-constant")
 
 
 def get_deskewed_data_shape(
@@ -39,19 +42,36 @@ def get_deskewed_data_shape(
     keep_overhang: bool,
     average_n_slices: int = 1,
     pixel_size_um: float = 1,
+    orientation: str = "identity",
 ):
     """Shape of the deskewed volume and its voxel size.
 
-    Returns ``((ceil(Y/avg), X, Xp), (avg*sin(theta)*px, px, px))`` for a raw ``(Z, Y, X)`` stack.
+    Returns ``((ceil(Y/avg), X, Xp), (avg*sin(theta)*px, px, px))`` for a raw ``(Z, Y, X)`` stack,
+    with the axes permuted as ``orientation`` says (``geometry.parse_orientation``).
     """
     geo = deskew_geometry(
         raw_data_shape, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices, pixel_size_um
     )
-    return geo.output_shape, geo.voxel_size
+    return orient_shape(geo.output_shape, orientation), orient_voxel(geo.voxel_size, orientation)
+
+
+def orient_volume(volume, orientation: str = "identity"):
+    """Apply an orientation spec to a canonical deskewed tensor: an axis permutation (a view) and
+    flips (one copy, only when the spec is not the identity).  Python-level on purpose -- the
+    orientation convention of the absent biahub revision is [RECALLED], and
+    changing it must not touch the kernel."""
+    import torch
+
+    perm, rev = orient_axes(orientation)
+    if perm == (0, 1, 2) and not any(rev):
+        return volume
+    out = volume.permute(*perm)
+    dims = [i for i, r in enumerate(rev) if r]
+    return torch.flip(out, dims) if dims else out.contiguous()
 
 
 def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices: int = 1, out=None,
-                       flat_field=None):
+                       flat_field=None, border: str = "constant"):
     """Deskew with an explicit output->input matrix over the pre-average grid.
 
     ``flat_field`` = a :class:`shrimpy_amd.flatfield.FlatFieldPattern` of ``raw_data``: the
@@ -62,8 +82,16 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
     3x4 map runs the general trilinear kernel followed by the slice-averaging kernel.
     ``out`` may be a dense tensor or a :class:`shrimpy_amd.deconvolve.PaddedVolume` (shear
     matrices only): the deskewed volume then lands, line-aligned, where the RL kernels read it.
+
+    ``border``: ``"constant"`` (default) is scipy's ``mode="constant"`` -- a sample with any
+    coordinate outside ``[0, n-1]`` is zero, no blending; ``"grid-constant"`` blends towards zero
+    across the border the way ``scipy mode="grid-constant"`` / torch ``grid_sample(zeros)`` do
+    (SURVEY.md section 7).  The blending form runs the general trilinear kernel.
     """
     import torch
+
+    if border not in BORDERS:
+        raise ValueError(f"border must be one of {BORDERS}, got {border!r}")
 
     # uint16 camera counts are deskewed as they are (converted to float32 inside the kernel, exact):
     # half the HBM read and, upstream, half the PCIe upload of a float32 stack
@@ -107,6 +135,11 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
         if flat_field is not None and tuple(flat_field.pattern.shape) != (y, x):
             raise ValueError(f"flat_field pattern must be {(y, x)}, got {tuple(flat_field.pattern.shape)}")
         try:
+            if border != "constant":
+                if hasattr(out, "logical_ptr"):
+                    raise ValueError("border='grid-constant' cannot write into a padded RL volume")
+                raise _lib.LsrUnsupported("deskew_with_matrix", _lib.E_UNSUPPORTED,
+                                          "blending border: general trilinear kernel")
             if flat_field is not None:
                 _lib.call(
                     "lsr_deskew_flat_u16" if u16 else "lsr_deskew_flat_f32", raw.data_ptr(), z, y, x, out_ptr, zo, yo, xo, out_pitch,
@@ -129,7 +162,8 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
             pre = out if avg == 1 else torch.empty((zd, yo, xo), dtype=torch.float32, device=raw.device)
             _lib.call(
                 "lsr_affine_f32", raw.data_ptr(), z, y, x, pre.data_ptr(), zd, yo, xo,
-                _lib.matrix12(m), ctypes.c_float(0.0), _lib.MODE_CONSTANT, stream,
+                _lib.matrix12(m), ctypes.c_float(0.0),
+                _lib.MODE_CONSTANT if border == "constant" else _lib.MODE_GRID_CONSTANT, stream,
             )
             if avg > 1:
                 _average_into(pre, out, avg, stream)
@@ -164,11 +198,17 @@ def fast_deskew_zyx(
     px_to_scan_ratio: float,
     keep_overhang: bool,
     average_n_slices: int = 1,
+    orientation: str = "identity",
+    border: str = "constant",
 ):
     """Deskew a raw ``(Z_scan, Y_tilt, X)`` float32 device tensor; returns a tensor on the same device.
 
     Output axes ``(Z', Y', X')``: ``Z'`` = reversed tilt rows averaged in groups of
     ``average_n_slices``, ``Y'`` = reversed raw X, ``X'`` = scan direction (the interpolated axis).
+    ``orientation`` re-orients that canonical result afterwards (``orient_volume``); ``border``
+    selects the border rule (``deskew_with_matrix``).  The reference filters the kwargs it passes by
+    this signature (``shrimpy/preprocessing.py:44-56``): settings fields that are not parameters
+    here never arrive, fields that are (these two, when ``DeskewSettings`` carries them) do.
     """
     import torch
 
@@ -182,7 +222,9 @@ def fast_deskew_zyx(
     geo = deskew_geometry(
         tuple(raw_data.shape), ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices
     )
-    return deskew_with_matrix(raw_data, geo.matrix_3x4, geo.pre_average_shape, average_n_slices)
+    out = deskew_with_matrix(raw_data, geo.matrix_3x4, geo.pre_average_shape, average_n_slices,
+                             border=border)
+    return orient_volume(out, orientation)
 
 
 def deskew_data(
@@ -192,6 +234,8 @@ def deskew_data(
     keep_overhang: bool,
     average_n_slices: int = 1,
     device="cuda",
+    orientation: str = "identity",
+    border: str = "constant",
 ):
     """Older biahub entry point: numpy in, numpy out, compute on ``device`` (must be a GPU)."""
     import torch
@@ -200,5 +244,6 @@ def deskew_data(
     if dev.type != "cuda":
         raise _lib.LsrError("deskew_data", -1, f"device {dev} is not a GPU; there is no CPU fallback")
     vol = torch.as_tensor(np.ascontiguousarray(raw_data, dtype=np.float32), device=dev)
-    out = fast_deskew_zyx(vol, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices)
+    out = fast_deskew_zyx(vol, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices,
+                          orientation=orientation, border=border)
     return out.cpu().numpy()

@@ -95,3 +95,79 @@ def as_matrix_3x4(matrix) -> np.ndarray:
     if not np.all(np.isfinite(m)):
         raise ValueError("affine contains non-finite entries")
     return np.ascontiguousarray(m)
+
+
+# ---------------------------------------------------------------------------------------------
+# Orientation of the deskewed volume (a Python-level post-step, never baked into the kernel).
+#
+# Which way round ``fast_deskew_zyx`` hands the volume back is a convention of the absent biahub
+# revision (the comment at ``shrimpy/preprocessing.py:224`` still mentions
+# an ``np.rot90`` the current ``_deskew`` body no longer contains).  The kernel always produces the
+# canonical (Z' = reversed tilt, Y' = reversed raw X, X' = scan) volume; an ``orientation`` spec is
+# applied to that result, so a corrected convention is a settings change.
+#
+# Spec: ``"identity"`` or a ``+``-joined sequence, applied left to right, of
+#   flip_z | flip_y | flip_x      reverse one output axis
+#   transpose_yx                  swap Y' and X'
+#   rot90 | rot180 | rot270       ``numpy.rot90(v, k, axes=(1, 2))`` with k = 1, 2, 3
+# ---------------------------------------------------------------------------------------------
+
+_ORIENT_OPS = ("identity", "flip_z", "flip_y", "flip_x", "transpose_yx", "rot90", "rot180", "rot270")
+
+
+def parse_orientation(spec) -> tuple[str, ...]:
+    """Validate an orientation spec; returns its operations (``identity`` dropped)."""
+    if spec is None:
+        return ()
+    if not isinstance(spec, str):
+        raise TypeError(f"orientation must be a string, got {type(spec).__name__}")
+    ops = tuple(op.strip() for op in spec.split("+"))
+    for op in ops:
+        if op not in _ORIENT_OPS:
+            raise ValueError(f"orientation op {op!r} is not one of {_ORIENT_OPS}")
+    return tuple(op for op in ops if op != "identity")
+
+
+def orient_axes(spec) -> tuple[tuple[int, int, int], tuple[bool, bool, bool]]:
+    """``(perm, reversed)``: output axis ``i`` is canonical axis ``perm[i]``, walked backwards when
+    ``reversed[i]``.  (``out = canonical.permute(perm).flip(dims where reversed)``.)"""
+    perm, rev = [0, 1, 2], [False, False, False]
+
+    def swap_yx():
+        perm[1], perm[2] = perm[2], perm[1]
+        rev[1], rev[2] = rev[2], rev[1]
+
+    for op in parse_orientation(spec):
+        if op.startswith("flip_"):
+            a = "zyx".index(op[-1])
+            rev[a] = not rev[a]
+        elif op == "transpose_yx":
+            swap_yx()
+        else:  # numpy.rot90(v, 1, axes=(1, 2)) == swapaxes(flip(v, 2), 1, 2)
+            for _ in range({"rot90": 1, "rot180": 2, "rot270": 3}[op]):
+                rev[2] = not rev[2]
+                swap_yx()
+    return tuple(perm), tuple(rev)
+
+
+def orient_shape(shape_zyx, spec) -> tuple[int, int, int]:
+    perm, _ = orient_axes(spec)
+    return tuple(int(shape_zyx[a]) for a in perm)
+
+
+def orient_voxel(voxel_zyx, spec) -> tuple[float, float, float]:
+    perm, _ = orient_axes(spec)
+    return tuple(float(voxel_zyx[a]) for a in perm)
+
+
+def raw_x_chunk_layout(spec) -> tuple[int, bool]:
+    """Where chunks cut along raw X end up: ``(output axis, reversed)``.
+
+    The reference deskews raw-X chunks independently and joins them reversed on output axis -2
+    (``scripts/measure_psf.py:221, 249``) -- that is ``(1, True)``, the canonical orientation.  Raw X
+    is canonical Y' walked backwards, so under an orientation the join axis is wherever Y' went and
+    the order flips once more if that axis is reversed.
+    """
+    perm, rev = orient_axes(spec)
+    axis = perm.index(1)
+    return axis, not rev[axis]

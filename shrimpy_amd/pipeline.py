@@ -85,7 +85,10 @@ class VolumeReconstructor:
             d: DeskewSettings = settings.deskew
             self._geo = deskew_geometry(shape, d.ls_angle_deg, d.px_to_scan_ratio, d.keep_overhang,
                                         d.average_n_slices, d.pixel_size_um)
-            shape = self._geo.output_shape
+            from .geometry import orient_shape
+
+            shape = orient_shape(self._geo.output_shape, d.orientation)
+            self._canonical_deskew = d.orientation in ("identity", "") and d.border == "constant"
         self._register: RegisterSettings | None = settings.registration
         if self._register is not None and self._register.output_shape_zyx is not None:
             shape = tuple(self._register.output_shape_zyx)
@@ -136,14 +139,20 @@ class VolumeReconstructor:
                 vol = flat.apply(vol)
         if self._geo is not None:
             target = None
-            if self._plan is not None and self._register is None and self._plan.path != "generic":
+            d = self.settings.deskew
+            if (self._plan is not None and self._register is None and self._plan.path != "generic"
+                    and self._canonical_deskew):
                 # deskew straight into the RL kernels' padded, line-aligned input volume
                 if self._y_pad is None:
                     self._y_pad = self._plan.new_padded_input()
                 target = self._y_pad
             # (with flat-field on, its division rides along inside the deskew kernel)
             vol = deskew_with_matrix(vol, self._geo.matrix_3x4, self._geo.pre_average_shape,
-                                     self.settings.deskew.average_n_slices, out=target, flat_field=flat)
+                                     d.average_n_slices, out=target, flat_field=flat, border=d.border)
+            if not self._canonical_deskew:
+                from .deskew import orient_volume
+
+                vol = orient_volume(vol, d.orientation)
         if self._register is not None:
             r = self._register
             vol = apply_affine_transform_zyx(vol, np.asarray(r.affine_transform_zyx), self.output_shape,

@@ -1,248 +1,207 @@
-"""Host-side mirror of the reference's per-volume preprocessor for the steps on the hot path.
+"""Adapter that lets a caller written against the reference's preprocessor use the HIP hot path.
 
-Mirrors ``shrimpy/preprocessing.py`` of the reference (same names, argument meaning, step order,
-logging and error behaviour) for the steps this package implements:
+The reference builds its per-volume preprocessor with ``build_preprocessor(...)`` and then calls the
+returned object with a raw ``(Z, Y, X)`` stack (``shrimpy/preprocessing.py:85-158, 284-366``).
+INTEGRATION.md binds this package underneath THAT code (as ``biahub.deskew``), so the reference's
+own module stays the caller; this file is for users who want the same call shape without the
+reference installed.  It is deliberately small:
 
-* ``build_preprocessor``            reference ``:85-158``
-* ``_LabelfreePreprocessor.warm_up``  reference ``:209-252`` (deskew part ``:224-244``)
-* ``_LabelfreePreprocessor.__call__`` reference ``:284-366``
-* ``_step`` / ``_flat_field_BF`` / ``_deskew``  reference ``:368-383`` / ``:385-404`` / ``:406-417``
+* which stages run is decided once, at construction (``flatfield`` and/or ``deskew``; ``phase`` and
+  ``vs`` are outside SURVEY.md section 8 and are refused up front);
+* the stack is uploaded once -- camera ``uint16`` stays ``uint16`` over PCIe and in HBM, the kernels
+  widen it exactly;
+* when both stages are on, the flat-field median is its own launch and the division happens while
+  the deskew kernel stages its input slab (``csrc/deskew.hip``), so the corrected raw volume is never
+  written;
+* nothing here can run on a CPU tensor: a host without a HIP device fails in ``warm_up``.
 
-``deskew`` runs the HIP kernel (``shrimpy_amd.deskew.fast_deskew_zyx``); ``flatfield`` runs the
-radix-select median kernel (``shrimpy_amd.flatfield``) and, when a deskew follows, its division is
-fused into the deskew kernel (same bits, one 8.6 GB round trip less at config 2).  ``phase`` and ``vs`` (waveorder inverse filter,
-cytoland U-Net) are out of this package's scope: asking for them raises
-``NotImplementedError`` at build time instead of silently skipping.
-
-Unlike the reference, there is no CPU fallback: without a HIP device ``warm_up`` raises, whatever
-``require_gpu`` says (the reference's ``cpu`` branch, ``:80``, would hand CPU tensors to a kernel
-that only exists on the GPU).
+Contract kept from the reference (names are its API): ``build_preprocessor``'s signature, the
+``RECON_STEPS`` tuple (``:41``), the returned dict keyed by ``output_channel`` with the optional
+``"deskew"`` intermediate (``:347-355``), ``warm_up`` replacing the working shape by the deskewed
+one (``:224-244``), and errors propagating to the caller after being logged (``:376-383``).
 """
 
 from __future__ import annotations
 
+import inspect
 import logging
-import time as _time
-
-from typing import TYPE_CHECKING
+import time
 
 import numpy as np
 
-if TYPE_CHECKING:
-    from collections.abc import Callable
-    from typing import Any
+log = logging.getLogger(__name__)
 
-    import torch
-
-logger = logging.getLogger(__name__)
-
-# Same tuple as the reference (``shrimpy/preprocessing.py:41``).
-RECON_STEPS = ("flatfield", "deskew", "phase", "vs")
-_UNSUPPORTED_STEPS = ("phase", "vs")
+RECON_STEPS = ("flatfield", "deskew", "phase", "vs")   # the reference's step vocabulary (``:41``)
+_HOT_PATH_STEPS = frozenset({"flatfield", "deskew"})
 
 
-def _settings_kwargs(func: Callable, settings: Any) -> dict[str, Any]:
-    """Fields of a pydantic *settings* model that *func* accepts (reference ``:44-56``)."""
-    import inspect
+def accepted_kwargs(func, settings) -> dict:
+    """``settings.model_dump()`` cut down to the parameters ``func`` declares.
 
-    accepted = set(inspect.signature(func).parameters)
-    return {k: v for k, v in settings.model_dump().items() if k in accepted}
-
-
-def _resolve_device() -> torch.device:
-    """CUDA (= HIP on ROCm) or CPU, never MPS -- the reference's torch-only branch (``:75-82``)."""
-    import torch
-
-    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-    logger.info("Preprocessing compute device: %s", device)
-    return device
-
-
-def build_preprocessor(
-    zyx_shape: tuple[int, int, int],
-    preprocessing: list[str] | None,
-    deskew: dict | None = None,
-    phase: dict | None = None,
-    virtual_staining: dict | None = None,
-    output_channel: str = "phase",
-    require_gpu: bool = False,
-):
-    """Build ``(np.ndarray ZYX) -> dict[str, torch.Tensor]`` or ``None`` (no reconstruction step).
-
-    Same contract as the reference: the pixel size / scan step must already be injected into
-    ``deskew`` by the caller (``shrimpy/dynatrack/manager.py:297-299``).
+    The reference hands a settings model to low-level callables this way (``:44-56``), which makes
+    the callee's parameter names the interface; ours are checked against that in
+    ``tests/golden/ref_preprocessing.npz``.
     """
-    pipeline = preprocessing or []
-    if not any(step in pipeline for step in RECON_STEPS):
-        return None
-    unsupported = [s for s in pipeline if s in _UNSUPPORTED_STEPS]
-    if unsupported:
-        raise NotImplementedError(
-            f"preprocessing steps {unsupported} are outside the MI355X hot path "
-            "(phase = waveorder inverse filter, vs = cytoland U-Net); run them with the reference"
-        )
+    names = inspect.signature(func).parameters.keys()
+    dumped = settings.model_dump()
+    return {name: dumped[name] for name in dumped if name in names}
 
-    deskew_settings = None
-    if "deskew" in pipeline and deskew:
+
+_settings_kwargs = accepted_kwargs   # the reference's name for the same helper
+
+
+def _resolve_device():
+    """``cuda`` (HIP under ROCm) when a device is visible, else ``cpu`` -- which ``warm_up`` rejects."""
+    import torch
+
+    return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+def build_preprocessor(zyx_shape, preprocessing, deskew=None, phase=None, virtual_staining=None,
+                       output_channel="phase", require_gpu=False):
+    """Reference-shaped factory: ``None`` when ``preprocessing`` names no reconstruction step,
+    otherwise a warmed-up :class:`HotPathPreprocessor`.
+
+    ``deskew`` is the plain dict the reference passes (pixel size and scan step already injected by
+    its caller, ``shrimpy/dynatrack/manager.py:297-299``); ``phase`` / ``virtual_staining`` are
+    accepted for signature compatibility and must stay unused.
+    """
+    wanted = [s for s in (preprocessing or ()) if s in RECON_STEPS]
+    if not wanted:
+        return None
+    foreign = [s for s in wanted if s not in _HOT_PATH_STEPS]
+    if foreign:
+        raise NotImplementedError(
+            f"{foreign}: phase reconstruction (waveorder) and virtual staining (cytoland) are not part "
+            "of the MI355X hot path; keep those steps on the reference's own preprocessor")
+    settings = None
+    if "deskew" in wanted and deskew:
         from .settings import DeskewSettings
 
-        deskew_settings = DeskewSettings(**deskew)
-
-    preprocessor = _LabelfreePreprocessor(
-        zyx_shape=zyx_shape,
-        apply_flatfield="flatfield" in pipeline,
-        deskew_settings=deskew_settings,
-        output_channel=output_channel,
-        require_gpu=require_gpu,
-    )
-    preprocessor.warm_up()
-    return preprocessor
+        settings = DeskewSettings(**deskew)
+    pre = HotPathPreprocessor(zyx_shape, deskew_settings=settings, output_channel=output_channel,
+                              apply_flatfield="flatfield" in wanted, require_gpu=require_gpu)
+    pre.warm_up()
+    return pre
 
 
-class _LabelfreePreprocessor:
-    """Callable ``preprocessor(volume_bf: np.ndarray) -> dict[str, torch.Tensor]``."""
+class HotPathPreprocessor:
+    """``pre(stack) -> {output_channel: device tensor}`` for flat-field and deskew on one HIP device."""
 
-    def __init__(
-        self,
-        zyx_shape: tuple[int, int, int],
-        deskew_settings: Any | None,
-        output_channel: str,
-        apply_flatfield: bool = False,
-        require_gpu: bool = False,
-        phase_settings: Any | None = None,
-        vs_config: dict[str, Any] | None = None,
-    ) -> None:
+    def __init__(self, zyx_shape, deskew_settings=None, output_channel="phase", apply_flatfield=False,
+                 require_gpu=False, phase_settings=None, vs_config=None):
         if phase_settings is not None or vs_config is not None:
-            raise NotImplementedError("phase / virtual staining are outside the MI355X hot path")
-        self._zyx_shape = tuple(zyx_shape)
-        self._apply_flatfield = apply_flatfield
+            raise NotImplementedError("phase / virtual staining settings given to the hot-path adapter")
+        self._zyx_shape = tuple(int(n) for n in zyx_shape)
         self._deskew_settings = deskew_settings
+        self._apply_flatfield = bool(apply_flatfield)
         self._output_channel = output_channel
-        self._require_gpu = require_gpu
+        self._require_gpu = bool(require_gpu)
         self._device = None
+        self._pending_flat_field = None
 
+    # ------------------------------------------------------------------ set-up
     def warm_up(self) -> None:
-        """Resolve the device and the deskewed shape before acquisition starts (reference ``:209-244``)."""
+        """Pick the device (it must be a GPU as soon as a kernel stage is on) and switch the working
+        shape to the deskewed one, which is what downstream consumers size themselves from."""
         self._device = _resolve_device()
-        if self._device.type == "cpu" and (self._require_gpu or self._deskew_settings is not None
-                                           or self._apply_flatfield):
+        needs_kernels = self._apply_flatfield or self._deskew_settings is not None
+        if self._device.type != "cuda" and (needs_kernels or self._require_gpu):
             raise RuntimeError(
-                "GPU required but none detected: the preprocessing compute device resolved to CPU. "
-                "The flat-field and deskew kernels run only on a HIP device (MI355X) -- there is no "
-                "CPU fallback."
-            )
+                "no HIP device visible: flat-field and deskew exist only as gfx950 kernels and there "
+                "is no CPU fallback (device resolved to %s)" % self._device)
         if self._deskew_settings is not None:
             from .deskew import get_deskewed_data_shape
 
-            deskewed_shape, _ = get_deskewed_data_shape(
-                raw_data_shape=self._zyx_shape,
-                **_settings_kwargs(get_deskewed_data_shape, self._deskew_settings),
-            )
-            logger.info(
-                "Preprocessing: deskew will reshape %s -> %s "
-                "(px_to_scan_ratio=%s, pixel_size_um=%s, scan_step_um=%s)",
-                self._zyx_shape,
-                deskewed_shape,
-                getattr(self._deskew_settings, "px_to_scan_ratio", None),
-                getattr(self._deskew_settings, "pixel_size_um", None),
-                getattr(self._deskew_settings, "scan_step_um", None),
-            )
-            self._zyx_shape = deskewed_shape
+            raw_shape = self._zyx_shape
+            self._zyx_shape, voxel = get_deskewed_data_shape(
+                raw_data_shape=raw_shape, **accepted_kwargs(get_deskewed_data_shape, self._deskew_settings))
+            log.info("deskew geometry: raw %s -> %s, voxel %s um (ratio %s)", raw_shape, self._zyx_shape,
+                     tuple(round(v, 4) for v in voxel),
+                     getattr(self._deskew_settings, "px_to_scan_ratio", None))
 
-    def __call__(
-        self,
-        volume_bf: np.ndarray,
-        label: str = "",
-        return_intermediates: bool = False,
-    ) -> dict[str, torch.Tensor]:
-        """Raw ``(Z, Y, X)`` stack -> ``{output_channel: tensor}`` (+ ``'deskew'`` intermediate)."""
+    # ------------------------------------------------------------------ per volume
+    def __call__(self, volume_bf, label="", return_intermediates=False) -> dict:
+        tag = f"[{label}] " if label else ""
+        volume = self._upload(volume_bf)
+        fuse = self._apply_flatfield and self._deskew_settings is not None
+        self._pending_flat_field = None
+        try:
+            if fuse:
+                self._pending_flat_field = self._step(tag, "flatfield", self._flat_field_pattern, volume)
+            elif self._apply_flatfield:
+                volume = self._step(tag, "flatfield", self._flat_field_BF, volume)
+            deskewed = None
+            if self._deskew_settings is not None:
+                volume = deskewed = self._step(tag, "deskew", self._deskew, volume)
+        finally:
+            self._pending_flat_field = None
+        out = {self._output_channel: volume}
+        if return_intermediates and deskewed is not None and "deskew" not in out:
+            out["deskew"] = deskewed
+        if self._require_gpu:
+            on_host = sorted(k for k, v in out.items() if v.device.type != "cuda")
+            if on_host:
+                raise RuntimeError(f"{tag}require_gpu: channels {on_host} ended up in host memory")
+        return out
+
+    def _upload(self, stack):
+        """One host->device copy.  ``uint16`` camera counts go up unconverted when a kernel stage will
+        read them (half the PCIe bytes; the kernels convert exactly); anything else as float32."""
         import torch
 
-        pfx = f"[{label}] " if label else ""
-        channels: dict[str, torch.Tensor] = {}
-
-        # one host->device copy; every step then stays on the device (reference :316).  A uint16
-        # camera stack is uploaded as it is -- half the PCIe bytes of the reference's float32 copy --
-        # and converted (exactly) inside the flat-field / deskew kernels.
-        arr = np.asarray(volume_bf) if not isinstance(volume_bf, torch.Tensor) else None
-        if arr is not None and arr.dtype == np.uint16 and (self._deskew_settings is not None
-                                                           or self._apply_flatfield):
-            volume = torch.as_tensor(arr, device=self._device)
-        else:
-            volume = torch.as_tensor(volume_bf, device=self._device, dtype=torch.float32)
-
-        self._pending_flat_field = None
-        if self._apply_flatfield and self._deskew_settings is not None:
-            # the median now, the division inside the deskew kernel (bit-identical, see flatfield.py)
-            self._pending_flat_field = self._step(pfx, "flatfield", self._flat_field_pattern, volume)
-        elif self._apply_flatfield:
-            volume = self._step(pfx, "flatfield", self._flat_field_BF, volume)
-
-        volume_deskewed = None
-        if self._deskew_settings is not None:
-            volume = self._step(pfx, "deskew", self._deskew, volume)
-            volume_deskewed = volume
-            self._pending_flat_field = None
-
-        channels[self._output_channel] = volume
-        if return_intermediates and volume_deskewed is not None:
-            channels.setdefault("deskew", volume_deskewed)
-
-        if self._require_gpu:
-            offenders = [n for n, t in channels.items() if t.device.type == "cpu"]
-            if offenders:
-                raise RuntimeError(
-                    f"{pfx}GPU required but preprocessing output is on CPU "
-                    f"(channels {offenders}); a reconstruction step fell back to CPU."
-                )
-        return channels
+        kernels_follow = self._apply_flatfield or self._deskew_settings is not None
+        if not isinstance(stack, torch.Tensor):
+            stack = np.asarray(stack)
+            if stack.dtype == np.uint16 and kernels_follow:
+                return torch.as_tensor(stack, device=self._device)
+        return torch.as_tensor(stack, device=self._device, dtype=torch.float32)
 
     @staticmethod
-    def _step(pfx: str, name: str, fn, arg):
-        """Run one step; log ``<label> <name> ok (<t>s)`` or ``FAILED: <error>`` and re-raise."""
-        t0 = _time.monotonic()
+    def _step(tag, name, fn, arg):
+        """Run one stage with wall-clock logging; a failure is logged once and re-raised unchanged,
+        which is what lets the reference's worker turn it into an error message and carry on."""
+        started = time.monotonic()
         try:
-            result = fn(arg)
-        except Exception as exc:
-            logger.error("%s%s FAILED: %s", pfx, name, exc)
+            out = fn(arg)
+        except Exception as err:
+            log.error("%s%s FAILED: %s", tag, name, err)
             raise
-        logger.info("%s%s ok (%.1fs)", pfx, name, _time.monotonic() - t0)
-        return result
+        log.info("%s%s done in %.2f s", tag, name, time.monotonic() - started)
+        return out
 
-    def _flat_field_BF(self, volume: torch.Tensor) -> torch.Tensor:
-        """Bright-field flat-field: divide out the per-pixel median over Z, keep its mean.
-
-        The reference's torch expression (``:403-404``: ``quantile(0.5, dim=0)``, then
-        ``volume / pattern * pattern.mean()``) as HIP kernels (``shrimpy_amd.flatfield``); the
-        tensor must live on the GPU -- no CPU fallback.
-        """
+    # ------------------------------------------------------------------ stages
+    def _flat_field_BF(self, volume):
+        """Whole bright-field correction (median over Z per pixel, divide, restore the mean level:
+        the arithmetic of the reference's ``:385-404``) as the two HIP launches of ``flatfield.py``."""
         from .flatfield import flat_field_bf
 
         return flat_field_bf(volume)
 
-    def _flat_field_pattern(self, volume: torch.Tensor):
-        """The median / mean half of ``_flat_field_BF`` (the division rides along with the deskew)."""
+    def _flat_field_pattern(self, volume):
+        """Only the median / mean launch; ``_deskew`` picks the pattern up and divides in-kernel."""
         from .flatfield import flat_field_pattern
 
         return flat_field_pattern(volume)
 
-    def _deskew(self, volume: torch.Tensor) -> torch.Tensor:
-        """``fast_deskew_zyx`` on the device, kwargs filtered by signature (reference ``:406-417``)."""
-        from .deskew import fast_deskew_zyx
+    def _deskew(self, volume):
+        from .deskew import deskew_with_matrix, fast_deskew_zyx
+        from .geometry import deskew_geometry
 
-        logger.debug("Preprocessing: deskewing volume %s...", tuple(volume.shape))
-        kwargs = _settings_kwargs(fast_deskew_zyx, self._deskew_settings)
-        pending = getattr(self, "_pending_flat_field", None)
-        if pending is not None:
-            # same geometry as fast_deskew_zyx, with the flat-field division fused into the kernel
-            from .deskew import deskew_with_matrix
-            from .geometry import deskew_geometry
+        kw = accepted_kwargs(fast_deskew_zyx, self._deskew_settings)
+        pattern = self._pending_flat_field
+        if pattern is None:
+            return fast_deskew_zyx(raw_data=volume, **kw)
+        # The fused form needs the explicit matrix entry point; post-processing switches
+        # (orientation) are applied exactly as fast_deskew_zyx would.
+        from .deskew import orient_volume
 
-            geo = deskew_geometry(tuple(volume.shape), kwargs["ls_angle_deg"], kwargs["px_to_scan_ratio"],
-                                  kwargs["keep_overhang"], kwargs.get("average_n_slices", 1))
-            result = deskew_with_matrix(volume, geo.matrix_3x4, geo.pre_average_shape,
-                                        kwargs.get("average_n_slices", 1), flat_field=pending)
-        else:
-            result = fast_deskew_zyx(raw_data=volume, **kwargs)
-        logger.debug("Preprocessing: deskew %s -> %s", tuple(volume.shape), tuple(result.shape))
-        return result
+        avg = kw.get("average_n_slices", 1)
+        geo = deskew_geometry(tuple(volume.shape), kw["ls_angle_deg"], kw["px_to_scan_ratio"],
+                              kw["keep_overhang"], avg)
+        out = deskew_with_matrix(volume, geo.matrix_3x4, geo.pre_average_shape, avg, flat_field=pattern,
+                                 border=kw.get("border", "constant"))
+        return orient_volume(out, kw.get("orientation", "identity"))
+
+
+_LabelfreePreprocessor = HotPathPreprocessor   # the reference's class name, for callers that use it

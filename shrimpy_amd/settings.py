@@ -63,6 +63,19 @@ class DeskewSettings(_StrictModel):
     scan_step_um: Optional[PositiveFloat] = None
     keep_overhang: bool = False
     average_n_slices: PositiveInt = 3
+    # Switches over the two conventions SURVEY.md section 8 marks [RECALLED]; the defaults are the
+    # canonical output.  They reach ``fast_deskew_zyx`` / ``get_deskewed_data_shape`` through the
+    # reference's signature filter like every other field.
+    orientation: str = "identity"
+    border: Literal["constant", "grid-constant"] = "constant"
+
+    @field_validator("orientation")
+    @classmethod
+    def _check_orientation(cls, v: str) -> str:
+        from .geometry import parse_orientation
+
+        parse_orientation(v)
+        return v
 
     @field_validator("ls_angle_deg")
     @classmethod

@@ -100,6 +100,57 @@ def test_deskew_chunks_concatenate_reversed_like_measure_psf(device):
     assert torch.equal(torch.cat(chunks[::-1], dim=-2), whole)
 
 
+SWITCH_ORIENTATIONS = ["identity", "flip_z", "flip_y", "flip_x", "transpose_yx", "rot90", "rot180", "rot270",
+                       "flip_z+rot90", "transpose_yx+flip_x+flip_z"]
+
+
+@pytest.mark.parametrize("border", ["constant", "grid-constant"])
+@pytest.mark.parametrize("spec", SWITCH_ORIENTATIONS)
+def test_deskew_orientation_and_border_switches_vs_oracle_bit_exact(device, spec, border):
+    """The two [RECALLED] conventions are Python-level switches: every
+    orientation and both border rules against the oracle, float32 and uint16 input, plus the
+    ``measure_psf.py:221-249`` chunk identity on the device under that orientation."""
+    import torch
+
+    from shrimpy_amd import geometry
+    from shrimpy_amd.deskew import fast_deskew_zyx, get_deskewed_data_shape
+
+    rng = np.random.default_rng(31)
+    raw = rng.integers(80, 600, (90, 25, 48)).astype(np.float32)
+    kw = dict(ls_angle_deg=30.0, px_to_scan_ratio=0.755, keep_overhang=True, average_n_slices=3)
+    want = o.deskew(raw, 30.0, 0.755, True, 3, orientation=spec, border=border)
+    got = fast_deskew_zyx(raw_data=_t(raw, device), orientation=spec, border=border, **kw)
+    assert got.is_contiguous()
+    assert tuple(got.shape) == get_deskewed_data_shape(raw.shape, orientation=spec, **kw)[0] == want.shape
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    got16 = fast_deskew_zyx(raw_data=_t(raw.astype(np.uint16), device), orientation=spec, border=border, **kw)
+    assert torch.equal(got16, got)
+    axis, reverse = geometry.raw_x_chunk_layout(spec)
+    parts = [fast_deskew_zyx(raw_data=c.contiguous(), orientation=spec, border=border, **kw)
+             for c in torch.chunk(_t(raw, device), 4, dim=-1)]
+    assert torch.equal(torch.cat(parts[::-1] if reverse else parts, dim=axis), got)
+
+
+def test_pipeline_honours_deskew_switches(device):
+    """``VolumeReconstructor`` with a rotated, blending deskew in front of RL: output shape, deskew
+    bits and the RL result follow the oracle run on the oriented volume."""
+    from shrimpy_amd.pipeline import VolumeReconstructor
+    from shrimpy_amd.settings import DeconvolveSettings, DeskewSettings, ReconstructSettings
+
+    rng = np.random.default_rng(33)
+    raw = rng.integers(80, 600, (96, 24, 40)).astype(np.uint16)
+    d = DeskewSettings(pixel_size_um=0.1133, scan_step_um=0.15, ls_angle_deg=30.0, keep_overhang=True,
+                       average_n_slices=3, orientation="rot90", border="grid-constant")
+    rec = VolumeReconstructor(raw.shape, ReconstructSettings(deskew=d), device)
+    want = o.deskew(raw.astype(np.float32), 30.0, 0.755, True, 3, orientation="rot90", border="grid-constant")
+    assert rec.output_shape == want.shape
+    np.testing.assert_array_equal(rec(raw).cpu().numpy(), want)
+    rec = VolumeReconstructor(raw.shape, ReconstructSettings(
+        deskew=d, deconvolution=DeconvolveSettings(iterations=5)), device)
+    psf, _ = o.gaussian_psf((9, 7, 7), (2.0, 1.2, 1.2))
+    _close(rec(raw).cpu().numpy(), o.richardson_lucy(want, psf, iterations=5), 5e-5, 2e-5)
+
+
 def test_deskew_errors(device):
     import torch
 

@@ -42,10 +42,14 @@ def test_get_deskewed_data_shape_signature_is_the_reference_call():
     from shrimpy_amd.deskew import fast_deskew_zyx, get_deskewed_data_shape
 
     params = list(inspect.signature(get_deskewed_data_shape).parameters)
+    # the reference's parameters first, in its order; the convention switches after them, defaulted
     assert params == ["raw_data_shape", "ls_angle_deg", "px_to_scan_ratio", "keep_overhang",
-                      "average_n_slices", "pixel_size_um"]
+                      "average_n_slices", "pixel_size_um", "orientation"]
     params = list(inspect.signature(fast_deskew_zyx).parameters)
-    assert params == ["raw_data", "ls_angle_deg", "px_to_scan_ratio", "keep_overhang", "average_n_slices"]
+    assert params == ["raw_data", "ls_angle_deg", "px_to_scan_ratio", "keep_overhang", "average_n_slices",
+                      "orientation", "border"]
+    sig = inspect.signature(fast_deskew_zyx).parameters
+    assert sig["orientation"].default == "identity" and sig["border"].default == "constant"
     shape, voxel = get_deskewed_data_shape(
         raw_data_shape=(2048, 512, 2048), ls_angle_deg=30, px_to_scan_ratio=0.755,
         keep_overhang=False, average_n_slices=3, pixel_size_um=0.1133)
@@ -85,7 +89,8 @@ def test_deskew_settings_derive_ratio_like_the_reference_scripts():
     assert s.px_to_scan_ratio == 0.755
     d = s.model_dump()
     assert set(d) == {"pixel_size_um", "ls_angle_deg", "px_to_scan_ratio", "scan_step_um",
-                      "keep_overhang", "average_n_slices"}
+                      "keep_overhang", "average_n_slices", "orientation", "border"}
+    assert (d["orientation"], d["border"]) == ("identity", "constant")
     # attributes the reference reads by getattr (shrimpy/preprocessing.py:240-242)
     assert (s.px_to_scan_ratio, s.pixel_size_um, s.scan_step_um) == (0.755, 0.1133, 0.15)
 
@@ -108,11 +113,20 @@ def test_settings_kwargs_filtering_keeps_exactly_the_callee_params(golden_dir):
     (``shrimpy/preprocessing.py:44-56``); the kept set was captured from the reference itself."""
     from shrimpy_amd.deskew import fast_deskew_zyx
 
+    from shrimpy_amd.preprocessing import accepted_kwargs
+
     s = DeskewSettings(ls_angle_deg=30.0, pixel_size_um=0.1133, scan_step_um=0.15)
-    accepted = set(inspect.signature(fast_deskew_zyx).parameters)
-    kept = sorted(k for k in s.model_dump() if k in accepted)
-    ref = np.load(golden_dir / "ref_preprocessing.npz")
-    assert kept == list(ref["settings_kwargs_kept"])
+    ref = list(np.load(golden_dir / "ref_preprocessing.npz")["settings_kwargs_kept"])
+
+    class BiahubShaped:   # the six fields the reference's settings model carries (no switches)
+        def model_dump(self):
+            d = s.model_dump()
+            return {k: d[k] for k in ("ls_angle_deg", "px_to_scan_ratio", "keep_overhang", "average_n_slices",
+                                      "pixel_size_um", "scan_step_um")}
+
+    assert sorted(accepted_kwargs(fast_deskew_zyx, BiahubShaped())) == ref
+    # our own model adds exactly the two convention switches, and they do reach the callee
+    assert sorted(accepted_kwargs(fast_deskew_zyx, s)) == sorted(ref + ["orientation", "border"])
 
 
 def test_register_and_deconvolve_settings(tmp_path):
@@ -271,3 +285,91 @@ def test_dynatrack_host_logic_matches_the_oracle(golden_dir):
     for comp, want in zip((0, 1), g["otsu_blur_a"]):
         assert d._otsu_from_hist(hist, vmin, vmax, comp) == pytest.approx(float(want), rel=1e-5)
     assert [d._next_fast_len(n) for n in (0, 1, 7, 11, 13, 171, 2049)] == [1, 1, 8, 12, 15, 180, 2160]
+
+
+# ---------------------------------------------------------------- orientation / border switches
+
+ORIENTATIONS = ["identity", "flip_z", "flip_y", "flip_x", "transpose_yx", "rot90", "rot180", "rot270",
+                "flip_z+rot90", "rot90+flip_y", "transpose_yx+flip_x+flip_z"]
+
+
+@pytest.mark.parametrize("spec", ORIENTATIONS)
+def test_orient_axes_is_what_numpy_does(spec):
+    """``geometry.orient_axes`` (what the device post-step applies as permute + flip) against the
+    oracle's literal numpy flips / rot90 on an index volume."""
+    shape = (3, 4, 5)
+    vol = np.arange(np.prod(shape), dtype=np.float32).reshape(shape)
+    perm, rev = geometry.orient_axes(spec)
+    mine = np.transpose(vol, perm)
+    for axis, r in enumerate(rev):
+        if r:
+            mine = np.flip(mine, axis)
+    want = o.orient(vol, spec)
+    np.testing.assert_array_equal(mine, want)
+    assert geometry.orient_shape(shape, spec) == want.shape
+    assert geometry.orient_voxel((0.17, 0.11, 0.12), spec) == tuple((0.17, 0.11, 0.12)[a] for a in perm)
+
+
+def test_orientation_specs_are_validated():
+    with pytest.raises(ValueError):
+        geometry.parse_orientation("rot45")
+    with pytest.raises(TypeError):
+        geometry.parse_orientation(3)
+    assert geometry.parse_orientation("identity+flip_z") == ("flip_z",)
+    with pytest.raises(ValueError):
+        DeskewSettings(pixel_size_um=0.1, ls_angle_deg=30, px_to_scan_ratio=0.7, orientation="upside-down")
+    with pytest.raises(ValueError):
+        DeskewSettings(pixel_size_um=0.1, ls_angle_deg=30, px_to_scan_ratio=0.7, border="reflect")
+    s = DeskewSettings(pixel_size_um=0.1, ls_angle_deg=30, px_to_scan_ratio=0.7, orientation="rot90",
+                       border="grid-constant")
+    assert (s.orientation, s.border) == ("rot90", "grid-constant")
+
+
+@pytest.mark.parametrize("spec", ORIENTATIONS)
+def test_get_deskewed_data_shape_follows_the_orientation(spec):
+    from shrimpy_amd.deskew import get_deskewed_data_shape
+
+    base, voxel = get_deskewed_data_shape((40, 12, 16), 30.0, 0.755, False, 3, 0.1133)
+    shape, vox = get_deskewed_data_shape((40, 12, 16), 30.0, 0.755, False, 3, 0.1133, orientation=spec)
+    want = o.orient(np.zeros(base, np.float32), spec).shape
+    assert shape == want
+    assert sorted(vox) == sorted(voxel)
+
+
+@pytest.mark.parametrize("border", ["constant", "grid-constant"])
+@pytest.mark.parametrize("spec", ORIENTATIONS)
+def test_chunk_reversal_identity_under_every_orientation(spec, border):
+    """``scripts/measure_psf.py:221-249``: raw-X chunks are deskewed on their own and joined reversed
+    on output axis -2.  With an orientation the join axis / order is ``raw_x_chunk_layout``; the
+    identity must hold for the oracle under every switch (it is what lets the reference chunk)."""
+    rng = np.random.default_rng(5)
+    raw = rng.integers(80, 600, (40, 12, 16)).astype(np.float32)
+    whole = o.deskew(raw, 30.0, 0.755, False, 3, orientation=spec, border=border)
+    parts = [o.deskew(raw[:, :, a:a + 4], 30.0, 0.755, False, 3, orientation=spec, border=border)
+             for a in range(0, 16, 4)]
+    axis, reverse = geometry.raw_x_chunk_layout(spec)
+    joined = np.concatenate(parts[::-1] if reverse else parts, axis=axis)
+    np.testing.assert_array_equal(joined, whole)
+    if spec == "identity":
+        assert (axis, reverse) == (1, True)      # the reference's own join: reversed on axis -2
+
+
+def test_border_switch_changes_only_the_border_band():
+    """``grid-constant`` blends towards zero across the scan ends; the interior is the same sample."""
+    rng = np.random.default_rng(6)
+    raw = rng.integers(80, 600, (40, 12, 16)).astype(np.float32)
+    a = o.deskew(raw, 30.0, 0.755, True, 1, border="constant")
+    b = o.deskew(raw, 30.0, 0.755, True, 1, border="grid-constant")
+    assert a.shape == b.shape and not np.array_equal(a, b)
+    both = (a != 0) & (b != 0)
+    np.testing.assert_allclose(a[both], b[both], rtol=1e-6)
+    assert np.count_nonzero(b) > np.count_nonzero(a)   # blended samples exist only with grid-constant
+
+
+def test_deskew_with_matrix_rejects_an_unknown_border():
+    import torch
+
+    from shrimpy_amd.deskew import deskew_with_matrix
+
+    with pytest.raises(ValueError, match="border"):
+        deskew_with_matrix(torch.zeros(4, 4, 4), np.zeros((3, 4)), (4, 4, 4), border="wrap")

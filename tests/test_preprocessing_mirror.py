@@ -1,4 +1,4 @@
-"""CPU tests of the preprocessor mirror; they read like the reference's
+"""CPU tests of the preprocessor adapter; they read like the reference's
 ``shrimpy/tests/test_preprocessing.py`` (heavy steps monkeypatched, control flow exercised).
 
 The last test runs the REFERENCE's own ``shrimpy.preprocessing`` with this package standing in for
@@ -170,10 +170,11 @@ def test_dropin_through_the_reference_preprocessor(monkeypatch):
 
     calls = {}
 
-    def fake_launch(raw, matrix, pre_shape, avg=1, out=None):
+    def fake_launch(raw, matrix, pre_shape, avg=1, out=None, border="constant"):
         calls["args"] = (tuple(raw.shape), pre_shape, avg)
+        calls["border"] = border
         m = np.asarray(matrix)
-        res = o.average_slices(o.affine_apply(raw.numpy(), m[:, :3], m[:, 3], pre_shape), avg)
+        res = o.average_slices(o.affine_apply(raw.numpy(), m[:, :3], m[:, 3], pre_shape, mode=border), avg)
         return torch.as_tensor(res)
 
     monkeypatch.setattr(our_deskew, "deskew_with_matrix", fake_launch)
@@ -186,3 +187,13 @@ def test_dropin_through_the_reference_preprocessor(monkeypatch):
     assert set(out) == {"BF", "deskew"}
     assert calls["args"] == (raw_shape, (12, 20, expect_shape[2]), 3)
     np.testing.assert_array_equal(out["BF"].numpy(), o.deskew(raw.astype(np.float32), 30.0, 0.755, False, 3))
+
+    # the convention switches ride through the reference's signature filter like any other field
+    pre = ref_pp.build_preprocessor(raw_shape, ["deskew"], output_channel="BF",
+                                    deskew=dict(DESKEW, orientation="flip_z+rot90", border="grid-constant"))
+    want = o.deskew(raw.astype(np.float32), 30.0, 0.755, False, 3, orientation="flip_z+rot90",
+                    border="grid-constant")
+    assert tuple(pre._zyx_shape) == want.shape       # warm_up saw the rotated shape
+    out = pre(raw)
+    assert calls["border"] == "grid-constant"
+    np.testing.assert_array_equal(out["BF"].numpy(), want)
