@@ -17,10 +17,12 @@ module implements the subset of that surface the reconstruction CLI needs, with 
         for key, pos in plate.positions():
             zyx = pos["0"].read_volume(t, c)
 
-Chunks are stored raw (``bytes`` codec / no compressor) or zlib/gzip-compressed.  Blosc and the
-sharding codec (what the acquisition engine writes, ``shrimpy/mantis/mantis_engine.py:474-481``)
-need numcodecs/zarr: when ``iohub`` is importable, ``open_ome_zarr`` here simply returns iohub's
-object, which handles them.
+Chunk codecs: raw (``bytes`` / no compressor), zlib / gzip, zstd, blosc 1.x frames, and the Zarr v3
+``sharding_indexed`` codec with its CRC-32C protected index -- i.e. what the acquisition engine
+writes (sharded blosc-zstd, ``shrimpy/mantis/mantis_engine.py:474-481``) is read and written here
+(``io/codecs.py``; zstd itself comes from numcodecs / zstandard / pyarrow / the system libzstd,
+whichever is present).  ``open_ome_zarr(prefer_iohub=True)`` returns iohub's own object when that
+package is importable; ``as_volume_array`` gives either kind the whole-volume interface the CLI uses.
 """
 
 from __future__ import annotations
@@ -92,30 +94,187 @@ class _Node:
             _write_json(self.path / ".zattrs", attrs)
 
 
+class _BlockCodec:
+    """bytes <-> one chunk-shaped block.  ``kind``: None (raw little-endian), ``gzip`` / ``zlib``,
+    ``zstd`` (bare frames) or ``blosc`` (c-blosc 1.x frames, ``io/codecs.py``)."""
+
+    def __init__(self, kind=None, **params):
+        self.kind, self.params = kind, params
+
+    # -- metadata ---------------------------------------------------------------------------
+    @classmethod
+    def from_v3(cls, codecs: list, where) -> "_BlockCodec":
+        out = cls(None)
+        for codec in codecs:
+            name = codec["name"] if isinstance(codec, dict) else codec
+            conf = codec.get("configuration", {}) if isinstance(codec, dict) else {}
+            if name == "bytes":
+                if conf.get("endian", "little") != "little":
+                    raise UnsupportedCodec(f"big-endian chunks in {where}")
+            elif name in ("gzip", "zlib"):
+                out = cls(name, level=int(conf.get("level", 1)))
+            elif name == "zstd":
+                out = cls("zstd", level=int(conf.get("level", 1)))
+            elif name == "blosc":
+                shuffle = {"noshuffle": 0, "shuffle": 1, "bitshuffle": 2}.get(conf.get("shuffle", "shuffle"), 1)
+                out = cls("blosc", cname=conf.get("cname", "zstd"), clevel=int(conf.get("clevel", 1)),
+                          shuffle=shuffle, typesize=int(conf.get("typesize", 0)),
+                          blocksize=int(conf.get("blocksize", 0)))
+            elif name == "crc32c":
+                out.params["crc32c"] = True
+            else:
+                raise UnsupportedCodec(
+                    f"codec {name!r} in {where}: this reader handles bytes, gzip, zstd, blosc, crc32c and "
+                    "sharding_indexed; install iohub (zarr/numcodecs) to read anything else")
+        return out
+
+    @classmethod
+    def from_v2(cls, comp: dict | None, where) -> "_BlockCodec":
+        if comp is None:
+            return cls(None)
+        cid = comp.get("id")
+        if cid in ("zlib", "gzip"):
+            return cls(cid, level=int(comp.get("level", 1)))
+        if cid == "zstd":
+            return cls("zstd", level=int(comp.get("level", 1)))
+        if cid == "blosc":
+            return cls("blosc", cname=comp.get("cname", "lz4"), clevel=int(comp.get("clevel", 5)),
+                       shuffle=int(comp.get("shuffle", 1)) if int(comp.get("shuffle", 1)) >= 0 else 1,
+                       typesize=0, blocksize=int(comp.get("blocksize", 0)))
+        raise UnsupportedCodec(f"compressor {cid!r} in {where}: this reader handles zlib, gzip, zstd and blosc; "
+                               "install iohub (zarr/numcodecs) to read anything else")
+
+    def to_v3(self) -> list:
+        codecs = [{"name": "bytes", "configuration": {"endian": "little"}}]
+        if self.kind in ("gzip", "zlib"):
+            codecs.append({"name": "gzip", "configuration": {"level": self.params.get("level", 1)}})
+        elif self.kind == "zstd":
+            codecs.append({"name": "zstd", "configuration": {"level": self.params.get("level", 1),
+                                                             "checksum": False}})
+        elif self.kind == "blosc":
+            codecs.append({"name": "blosc", "configuration": {
+                "cname": self.params["cname"], "clevel": self.params["clevel"],
+                "shuffle": ["noshuffle", "shuffle", "bitshuffle"][self.params["shuffle"]],
+                "typesize": self.params["typesize"], "blocksize": self.params.get("blocksize", 0)}})
+        return codecs
+
+    def to_v2(self) -> dict | None:
+        if self.kind in ("gzip", "zlib"):
+            return {"id": "zlib", "level": self.params.get("level", 1)}
+        if self.kind == "zstd":
+            return {"id": "zstd", "level": self.params.get("level", 1)}
+        if self.kind == "blosc":
+            return {"id": "blosc", "cname": self.params["cname"], "clevel": self.params["clevel"],
+                    "shuffle": self.params["shuffle"], "blocksize": self.params.get("blocksize", 0)}
+        return None
+
+    @classmethod
+    def named(cls, name: str | None, dtype: np.dtype) -> "_BlockCodec":
+        """``None`` | "gzip" | "zlib" | "zstd" | "blosc-zstd" (the acquisition's) | "blosc-lz4"."""
+        if name in (None, "", "raw", "none"):
+            return cls(None)
+        if name in ("gzip", "zlib"):
+            return cls(name, level=1)
+        if name == "zstd":
+            return cls("zstd", level=1)
+        if name.startswith("blosc"):
+            cname = name.split("-", 1)[1] if "-" in name else "zstd"
+            return cls("blosc", cname=cname, clevel=1, shuffle=1, typesize=int(np.dtype(dtype).itemsize),
+                       blocksize=0)
+        raise ValueError(f"unknown compression {name!r}")
+
+    # -- data -------------------------------------------------------------------------------
+    def decode(self, raw, shape, dtype, out: np.ndarray | None = None) -> np.ndarray:
+        """Decode one block; into ``out`` (C-contiguous, chunk-shaped) when given."""
+        from . import codecs
+
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if self.params.get("crc32c"):
+            raw = memoryview(raw)[:-4]
+        if self.kind == "blosc":
+            if out is not None and out.flags.c_contiguous and out.dtype == dtype and out.nbytes == nbytes:
+                codecs.blosc_decode(raw, out=out)
+                return out
+            data = codecs.blosc_decode(raw)
+        elif self.kind == "gzip":
+            data = gzip.decompress(bytes(raw))
+        elif self.kind == "zlib":
+            data = zlib.decompress(bytes(raw))
+        elif self.kind == "zstd":
+            data = codecs.zstd_decompress(raw, nbytes)
+        else:
+            data = raw
+        block = np.frombuffer(data, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        if out is not None:
+            out[...] = block
+            return out
+        return block
+
+    def encode(self, block: np.ndarray) -> bytes:
+        from . import codecs
+
+        block = np.ascontiguousarray(block)
+        if self.kind == "blosc":
+            raw = codecs.blosc_encode(block, self.params.get("typesize") or block.dtype.itemsize,
+                                      self.params["cname"], self.params["clevel"], self.params["shuffle"],
+                                      self.params.get("blocksize", 0))
+        elif self.kind == "gzip":
+            raw = gzip.compress(block.tobytes(), compresslevel=self.params.get("level", 1))
+        elif self.kind == "zlib":
+            raw = zlib.compress(block.tobytes(), self.params.get("level", 1))
+        elif self.kind == "zstd":
+            raw = codecs.zstd_compress(block.tobytes(), self.params.get("level", 1))
+        else:
+            raw = block.tobytes()
+        if self.params.get("crc32c"):
+            raw += int(codecs.crc32c(raw)).to_bytes(4, "little")
+        return raw
+
+
+_MISSING = 0xFFFFFFFFFFFFFFFF   # (offset, nbytes) of an absent inner chunk in a shard index
+
+
 class ZarrArray:
-    """One N-D array; whole ``(t, c)`` volumes are the unit of I/O."""
+    """One N-D array; whole ``(t, c)`` volumes are the unit of I/O.
+
+    ``chunks`` is the shape of one encoded block; with the Zarr v3 ``sharding_indexed`` codec
+    (what the acquisition writes, ``shrimpy/mantis/mantis_engine.py:474-481``) several blocks share
+    one file of shape ``shards`` and an index of (offset, nbytes) pairs, CRC-32C protected, at its end
+    or start.  Without sharding ``shards`` is ``None`` and every block is its own file.
+    """
 
     def __init__(self, path: Path, version: str, mode: str):
         self.path, self.version, self.mode = Path(path), version, mode
+        self.shards = None
+        self._index_location, self._index_crc = "end", True
         if version == "0.5":
             meta = _read_json(self.path / "zarr.json")
             self.shape = tuple(meta["shape"])
-            self.chunks = tuple(meta["chunk_grid"]["configuration"]["chunk_shape"])
+            grid = tuple(meta["chunk_grid"]["configuration"]["chunk_shape"])
             self.dtype = np.dtype(_V3_DTYPES.get(meta["data_type"], meta["data_type"]))
             self.fill_value = meta.get("fill_value", 0) or 0
             enc = meta.get("chunk_key_encoding", {"name": "default"})
-            self._sep = enc.get("configuration", {}).get("separator", "/")
+            self._sep = enc.get("configuration", {}).get("separator", "/" if enc.get("name", "default") == "default" else ".")
             self._prefix = "c" + self._sep if enc.get("name", "default") == "default" else ""
-            self._compress = None
-            for codec in meta.get("codecs", []):
-                name = codec["name"] if isinstance(codec, dict) else codec
-                if name == "bytes":
-                    if codec.get("configuration", {}).get("endian", "little") != "little":
-                        raise UnsupportedCodec("big-endian chunks")
-                elif name in ("gzip", "zlib"):
-                    self._compress = name
-                else:
-                    raise UnsupportedCodec(f"codec {name!r} in {self.path} needs zarr/numcodecs (iohub)")
+            codecs = meta.get("codecs", [])
+            names = [c["name"] if isinstance(c, dict) else c for c in codecs]
+            if "sharding_indexed" in names:
+                if names != ["sharding_indexed"]:
+                    raise UnsupportedCodec(f"codecs {names} around sharding_indexed in {self.path}")
+                conf = codecs[0]["configuration"]
+                self.shards = grid
+                self.chunks = tuple(conf["chunk_shape"])
+                if len(self.chunks) != len(grid) or any(s % c for s, c in zip(grid, self.chunks)):
+                    raise UnsupportedCodec(f"shard shape {grid} is not a multiple of its chunk shape {self.chunks}")
+                self._index_location = conf.get("index_location", "end")
+                inames = [c["name"] if isinstance(c, dict) else c for c in conf.get("index_codecs", [])]
+                if [n for n in inames if n not in ("bytes", "crc32c")]:
+                    raise UnsupportedCodec(f"shard index codecs {inames} in {self.path} (bytes / crc32c are handled)")
+                self._index_crc = "crc32c" in inames
+                self._codec = _BlockCodec.from_v3(conf.get("codecs", []), self.path)
+            else:
+                self.chunks = grid
+                self._codec = _BlockCodec.from_v3(codecs, self.path)
         else:
             meta = _read_json(self.path / ".zarray")
             self.shape = tuple(meta["shape"])
@@ -124,80 +283,94 @@ class ZarrArray:
             self.fill_value = meta.get("fill_value", 0) or 0
             self._sep = meta.get("dimension_separator", ".")
             self._prefix = ""
-            comp = meta.get("compressor")
-            if comp is None:
-                self._compress = None
-            elif comp.get("id") in ("zlib", "gzip"):
-                self._compress = comp["id"]
-            else:
-                raise UnsupportedCodec(f"compressor {comp.get('id')!r} in {self.path} needs numcodecs (iohub)")
+            self._codec = _BlockCodec.from_v2(meta.get("compressor"), self.path)
             if meta.get("order", "C") != "C" or meta.get("filters"):
                 raise UnsupportedCodec("only C-order arrays without filters are supported")
+        if self._codec.kind == "blosc" and not self._codec.params.get("typesize"):
+            self._codec.params["typesize"] = self.dtype.itemsize
+        self._compress = self._codec.kind   # (kept: "is this array stored raw?")
 
     # -- creation ---------------------------------------------------------------------------
     @classmethod
-    def create(cls, path: Path, version: str, shape, chunks, dtype, compress: str | None = None):
+    def create(cls, path: Path, version: str, shape, chunks, dtype, compress: str | None = None,
+               shards=None):
+        """``compress``: see ``_BlockCodec.named``.  ``shards`` (NGFF 0.5 only): shape of the files,
+        a multiple of ``chunks`` -- ``compress="blosc-zstd"`` with shards is the acquisition's layout."""
         path = Path(path)
         dtype = np.dtype(dtype)
+        codec = _BlockCodec.named(compress, dtype)
         if version == "0.5":
-            codecs = [{"name": "bytes", "configuration": {"endian": "little"}}]
-            if compress:
-                codecs.append({"name": "gzip", "configuration": {"level": 1}})
+            inner = codec.to_v3()
+            if shards is not None:
+                shards = tuple(int(s) for s in shards)
+                if len(shards) != len(chunks) or any(s % c for s, c in zip(shards, chunks)):
+                    raise ValueError(f"shards {shards} must be a multiple of chunks {tuple(chunks)}")
+                codecs = [{"name": "sharding_indexed", "configuration": {
+                    "chunk_shape": list(chunks), "codecs": inner,
+                    "index_codecs": [{"name": "bytes", "configuration": {"endian": "little"}},
+                                     {"name": "crc32c"}],
+                    "index_location": "end"}}]
+                grid = list(shards)
+            else:
+                codecs, grid = inner, list(chunks)
             _write_json(path / "zarr.json", {
                 "zarr_format": 3, "node_type": "array", "shape": list(shape), "data_type": dtype.name,
-                "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": list(chunks)}},
+                "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": grid}},
                 "chunk_key_encoding": {"name": "default", "configuration": {"separator": "/"}},
                 "fill_value": 0, "codecs": codecs,
                 "dimension_names": [a["name"] for a in AXES][-len(shape):],
             })
         else:
+            if shards is not None:
+                raise ValueError("sharding needs NGFF 0.5 (Zarr v3)")
             _write_json(path / ".zarray", {
                 "zarr_format": 2, "shape": list(shape), "chunks": list(chunks), "dtype": dtype.str,
-                "compressor": {"id": "zlib", "level": 1} if compress else None, "fill_value": 0,
+                "compressor": codec.to_v2(), "fill_value": 0,
                 "order": "C", "filters": None, "dimension_separator": "/",
             })
         return cls(path, version, "w")
 
-    # -- chunk I/O --------------------------------------------------------------------------
-    def _chunk_path(self, idx: Sequence[int]) -> Path:
+    # -- file / block addressing ------------------------------------------------------------
+    def _file_path(self, idx: Sequence[int]) -> Path:
         return self.path / (self._prefix + self._sep.join(str(i) for i in idx))
 
+    _chunk_path = _file_path   # (unsharded arrays: one file per chunk)
+
     def _read_chunk(self, idx) -> np.ndarray | None:
-        p = self._chunk_path(idx)
+        p = self._file_path(idx)
         if not p.exists():
             return None
-        raw = p.read_bytes()
-        if self._compress == "gzip":
-            raw = gzip.decompress(raw)
-        elif self._compress == "zlib":
-            raw = zlib.decompress(raw)
-        return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks)
+        return self._codec.decode(p.read_bytes(), self.chunks, self.dtype)
 
     def _write_chunk(self, idx, block: np.ndarray) -> None:
-        raw = np.ascontiguousarray(block, dtype=self.dtype).tobytes()
-        if self._compress == "gzip":
-            raw = gzip.compress(raw, compresslevel=1)
-        elif self._compress == "zlib":
-            raw = zlib.compress(raw, 1)
-        p = self._chunk_path(idx)
+        p = self._file_path(idx)
         p.parent.mkdir(parents=True, exist_ok=True)
-        p.write_bytes(raw)
+        p.write_bytes(self._codec.encode(np.ascontiguousarray(block, dtype=self.dtype)))
 
-    def _grid(self, lead: tuple[int, ...]):
-        """Chunk indices covering the trailing (Z, Y, X) block at leading indices ``lead``."""
-        n = len(self.shape)
-        k = len(lead)
-        for i, c in zip(lead, self.chunks[:k]):
+    def _check_lead(self, lead) -> tuple[int, ...]:
+        k = len(self.shape) - 3
+        if len(lead) != k:
+            raise IndexError(f"expected {k} leading indices, got {len(lead)}")
+        for i, n in zip(lead, self.shape):
+            if not 0 <= i < n:
+                raise IndexError(f"index {tuple(lead)} out of range for shape {self.shape}")
+        for c in self.chunks[:k]:
             if c != 1:
                 raise UnsupportedCodec("leading (T, C) chunk sizes other than 1 are not supported")
-        ranges = [range(-(-self.shape[d] // self.chunks[d])) for d in range(k, n)]
+        return tuple(int(i) for i in lead)
+
+    def _grid(self, lead: tuple[int, ...]):
+        """File indices (trailing three dims) covering the (Z, Y, X) volume at ``lead``."""
+        k = len(lead)
+        files = self.shards or self.chunks
+        ranges = [range(-(-self.shape[d] // files[d])) for d in range(k, len(self.shape))]
         return itertools.product(*ranges)
 
-    # Chunks of one volume are independent files: they are read / written by a small thread pool
-    # (file I/O and zlib release the GIL), and an uncompressed chunk that is a whole contiguous
-    # z-range of the volume -- the layout the acquisition writes, chunks (1, 1, <=32, ny, nx),
-    # ``shrimpy/dynatrack/tracking.py:1337-1367`` -- moves between the file and the caller's
-    # buffer (e.g. a pinned staging slot) without an intermediate copy.
+    # Files of one volume are independent: they are read / written by a small thread pool (file
+    # I/O, zlib and the C codecs release the GIL), and a block that is a whole contiguous z-range of
+    # the volume -- the layout the acquisition writes, chunks (1, 1, <=32, ny, nx),
+    # ``shrimpy/dynatrack/tracking.py:1337-1367`` -- moves between the file and the caller's buffer
+    # (e.g. a pinned staging slot) without an intermediate copy.
     _POOL_MIN_BYTES = 8 << 20
 
     def _map_chunks(self, fn, cidxs, nbytes):
@@ -211,35 +384,146 @@ class ZarrArray:
         with ThreadPoolExecutor(workers, "lsr-zarr") as pool:
             list(pool.map(fn, cidxs))  # list(): re-raise the first worker exception
 
-    def _slab_view(self, vol: np.ndarray, sl) -> memoryview | None:
-        """``vol[sl]`` as bytes when that block is a full chunk and contiguous in ``vol``."""
-        vchunks = self.chunks[len(self.shape) - 3:]
-        full = all(s.stop - s.start == c for s, c in zip(sl, vchunks))
-        if not full or self._compress is not None or vol.dtype != self.dtype or not vol.flags.c_contiguous:
+    def _slab(self, vol: np.ndarray, sl, block_shape) -> np.ndarray | None:
+        """``vol[sl]`` when that is a whole block and contiguous in ``vol`` (decode / encode in place)."""
+        full = all(s.stop - s.start == c for s, c in zip(sl, block_shape))
+        if not full or vol.dtype != self.dtype or not vol.flags.c_contiguous:
             return None
         if (sl[1].start, sl[1].stop, sl[2].start, sl[2].stop) != (0, vol.shape[1], 0, vol.shape[2]):
             return None
-        return memoryview(vol[sl]).cast("B")
+        return vol[sl]
 
+    def _slab_view(self, vol: np.ndarray, sl) -> memoryview | None:
+        view = self._slab(vol, sl, self.chunks[len(self.shape) - 3:]) if self._codec.kind is None else None
+        return None if view is None else memoryview(view).cast("B")
+
+    # -- shards -----------------------------------------------------------------------------
+    def _shard_counts(self) -> tuple[int, ...]:
+        return tuple(s // c for s, c in zip(self.shards, self.chunks))
+
+    def _read_shard_index(self, f, size: int) -> np.ndarray:
+        """(n_inner..., 2) uint64 array of (offset, nbytes) from an open shard file."""
+        from .codecs import crc32c
+
+        counts = self._shard_counts()
+        n = int(np.prod(counts))
+        ilen = 16 * n + (4 if self._index_crc else 0)
+        if size < ilen:
+            raise OSError(f"shard {f.name} is shorter than its index ({size} < {ilen} bytes)")
+        f.seek(size - ilen if self._index_location == "end" else 0)
+        raw = f.read(ilen)
+        if self._index_crc:
+            want = int.from_bytes(raw[-4:], "little")
+            if crc32c(raw[:-4]) != want:
+                raise OSError(f"shard {f.name}: index checksum mismatch (file truncated or corrupt)")
+            raw = raw[:-4]
+        return np.frombuffer(raw, dtype="<u8").reshape(counts + (2,))
+
+    def _inner_of(self, lead, fidx):
+        """Inner-chunk coordinates of shard ``fidx`` that belong to the volume at ``lead``:
+        yields (index into the shard's chunk grid, slices into the volume)."""
+        k = len(lead)
+        counts = self._shard_counts()
+        vshape, vchunks, vshard = self.shape[k:], self.chunks[k:], self.shards[k:]
+        head = tuple(i % s for i, s in zip(lead, self.shards[:k]))
+        for inner in itertools.product(*[range(c) for c in counts[k:]]):
+            lo = [f * s + i * c for f, s, i, c in zip(fidx, vshard, inner, vchunks)]
+            if any(a >= n for a, n in zip(lo, vshape)):
+                continue
+            yield head + inner, tuple(slice(a, min(a + c, n)) for a, c, n in zip(lo, vchunks, vshape))
+
+    def _read_shard(self, lead, fidx, out: np.ndarray) -> None:
+        k = len(lead)
+        vchunks = self.chunks[k:]
+        path = self._file_path(tuple(i // s for i, s in zip(lead, self.shards[:k])) + tuple(fidx))
+        try:
+            f = open(path, "rb", buffering=0)
+        except FileNotFoundError:
+            for _, sl in self._inner_of(lead, fidx):
+                out[sl] = self.fill_value
+            return
+        with f:
+            size = os.fstat(f.fileno()).st_size
+            index = self._read_shard_index(f, size)
+            for inner, sl in self._inner_of(lead, fidx):
+                off, nb = (int(v) for v in index[inner])
+                if off == _MISSING and nb == _MISSING:
+                    out[sl] = self.fill_value
+                    continue
+                if off + nb > size:
+                    raise OSError(f"shard {path}: chunk {inner} runs past the end of the file")
+                f.seek(off)
+                raw = f.read(nb)
+                dest = self._slab(out, sl, vchunks)
+                if dest is not None:
+                    self._codec.decode(raw, dest.shape, self.dtype, out=dest)
+                else:
+                    block = self._codec.decode(raw, vchunks, self.dtype)
+                    out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
+
+    def _write_shard(self, lead, fidx, vol: np.ndarray) -> None:
+        from .codecs import crc32c
+
+        k = len(lead)
+        vchunks = self.chunks[k:]
+        counts = self._shard_counts()
+        path = self._file_path(tuple(i // s for i, s in zip(lead, self.shards[:k])) + tuple(fidx))
+        blobs: dict[tuple, bytes] = {}
+        if path.exists() and any(s > 1 for s in self.shards[:k]):
+            # the shard also holds other (t, c) volumes: keep their encoded chunks as they are
+            with open(path, "rb", buffering=0) as f:
+                size = os.fstat(f.fileno()).st_size
+                old = self._read_shard_index(f, size)
+                for inner in itertools.product(*[range(c) for c in counts]):
+                    off, nb = (int(v) for v in old[inner])
+                    if off != _MISSING:
+                        f.seek(off)
+                        blobs[inner] = f.read(nb)
+        for inner, sl in self._inner_of(lead, fidx):
+            block = self._slab(vol, sl, vchunks)
+            if block is None:
+                block = np.zeros(vchunks, dtype=self.dtype)
+                block[tuple(slice(0, s.stop - s.start) for s in sl)] = vol[sl]
+            blobs[inner] = self._codec.encode(np.ascontiguousarray(block, dtype=self.dtype))
+        index = np.full(counts + (2,), _MISSING, dtype="<u8")
+        ilen = index.nbytes + (4 if self._index_crc else 0)
+        pos = ilen if self._index_location == "start" else 0
+        order = sorted(blobs)
+        for inner in order:
+            index[inner] = (pos, len(blobs[inner]))
+            pos += len(blobs[inner])
+        ibytes = index.tobytes()
+        if self._index_crc:
+            ibytes += int(crc32c(ibytes)).to_bytes(4, "little")
+        path.parent.mkdir(parents=True, exist_ok=True)
+        tmp = path.with_name(path.name + ".partial")
+        with open(tmp, "wb") as f:
+            if self._index_location == "start":
+                f.write(ibytes)
+            for inner in order:
+                f.write(blobs[inner])
+            if self._index_location != "start":
+                f.write(ibytes)
+        os.replace(tmp, path)   # a killed run never leaves a shard with a stale index behind
+
+    # -- volumes ----------------------------------------------------------------------------
     def read_volume(self, *lead: int, out: np.ndarray | None = None) -> np.ndarray:
         """The (Z, Y, X) volume at leading indices (t, c) as a C-contiguous array; with ``out``
         (same shape and dtype, e.g. a pinned staging buffer) the chunks are decoded into it."""
-        k = len(self.shape) - 3
-        if len(lead) != k:
-            raise IndexError(f"expected {k} leading indices, got {len(lead)}")
-        for i, n in zip(lead, self.shape):
-            if not 0 <= i < n:
-                raise IndexError(f"index {lead} out of range for shape {self.shape}")
+        lead = self._check_lead(lead)
+        k = len(lead)
         vshape, vchunks = self.shape[k:], self.chunks[k:]
         if out is None:
             out = np.empty(vshape, dtype=self.dtype)
         elif tuple(out.shape) != tuple(vshape) or out.dtype != self.dtype:
             raise ValueError(f"out must be {tuple(vshape)} {self.dtype}, got {out.shape} {out.dtype}")
-        lead = tuple(lead)
 
         def read_one(cidx):
+            if self.shards is not None:
+                self._read_shard(lead, cidx, out)
+                return
             sl = tuple(slice(c * s, min((c + 1) * s, n)) for c, s, n in zip(cidx, vchunks, vshape))
-            path = self._chunk_path(lead + cidx)
+            path = self._file_path(lead + cidx)
             view = self._slab_view(out, sl)
             if view is not None:
                 try:
@@ -253,11 +537,16 @@ class ZarrArray:
                 except FileNotFoundError:
                     out[sl] = self.fill_value
                 return
-            block = self._read_chunk(lead + cidx)
-            if block is None:
+            try:
+                raw = path.read_bytes()
+            except FileNotFoundError:
                 out[sl] = self.fill_value
                 return
-            block = block.reshape(vchunks)
+            dest = self._slab(out, sl, vchunks)
+            if dest is not None:
+                self._codec.decode(raw, dest.shape, self.dtype, out=dest)
+                return
+            block = self._codec.decode(raw, vchunks, self.dtype)
             out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
 
         self._map_chunks(read_one, list(self._grid(lead)), out.nbytes)
@@ -272,22 +561,27 @@ class ZarrArray:
         vol = np.asarray(vol)
         if len(lead) != k or tuple(vol.shape) != tuple(self.shape[k:]):
             raise ValueError(f"expected {k} indices and a volume of shape {self.shape[k:]}, got {vol.shape}")
+        lead = self._check_lead(lead)
         vchunks = self.chunks[k:]
-        lead = tuple(lead)
 
         def write_one(cidx):
+            if self.shards is not None:
+                self._write_shard(lead, cidx, vol)
+                return
             sl = tuple(slice(c * s, min((c + 1) * s, n)) for c, s, n in zip(cidx, vchunks, vol.shape))
             view = self._slab_view(vol, sl)
             if view is not None:
-                path = self._chunk_path(lead + cidx)
+                path = self._file_path(lead + cidx)
                 path.parent.mkdir(parents=True, exist_ok=True)
                 with open(path, "wb", buffering=0) as f:
                     done = 0
                     while done < len(view):
                         done += f.write(view[done:])
                 return
-            block = np.zeros(self.chunks, dtype=self.dtype)
-            block.reshape(vchunks)[tuple(slice(0, s.stop - s.start) for s in sl)] = vol[sl]
+            block = self._slab(vol, sl, vchunks)
+            if block is None:
+                block = np.zeros(self.chunks[k:], dtype=self.dtype)
+                block[tuple(slice(0, s.stop - s.start) for s in sl)] = vol[sl]
             self._write_chunk(lead + cidx, block)
 
         self._map_chunks(write_one, list(self._grid(lead)), vol.nbytes)
@@ -335,15 +629,22 @@ class Position(_Node):
         return self["0"]
 
     def create_zeros(self, name: str, shape, dtype="float32", chunks=None, scale=None,
-                     compress: str | None = None) -> ZarrArray:
+                     compress: str | None = None, shards=None) -> ZarrArray:
         """Create level ``name`` (TCZYX).  Default chunks follow the reference:
-        ``(1, 1, min(32, nz), ny, nx)`` (``shrimpy/dynatrack/tracking.py:1362``)."""
+        ``(1, 1, min(32, nz), ny, nx)`` (``shrimpy/dynatrack/tracking.py:1362``).
+        ``compress="blosc-zstd"`` with ``shards="volume"`` (one shard file per (t, c) volume) or an
+        explicit shard shape reproduces the acquisition's layout
+        (``shrimpy/mantis/mantis_engine.py:474-481``, NGFF 0.5 only)."""
         shape = tuple(int(s) for s in shape)
         if len(shape) != 5:
             raise ValueError(f"expected a 5-D TCZYX shape, got {shape}")
         if chunks is None:
             chunks = (1, 1, min(32, shape[2]), shape[3], shape[4])
-        arr = ZarrArray.create(self.path / name, self.version, shape, chunks, dtype, compress)
+        if isinstance(shards, str):
+            if shards != "volume":
+                raise ValueError("shards must be a shape or 'volume'")
+            shards = (1, 1) + tuple(-(-n // c) * c for n, c in zip(shape[2:], chunks[2:]))
+        arr = ZarrArray.create(self.path / name, self.version, shape, chunks, dtype, compress, shards)
         scale = [float(s) for s in (scale if scale is not None else (1, 1, 1, 1, 1))]
         attrs = {
             "multiscales": [{

@@ -103,12 +103,12 @@ def test_store_errors(tmp_path):
             arr.write_volume(0, 0, np.zeros((N_Z, N_Y, N_X)))
         with pytest.raises(IndexError):
             arr.read_volume(5, 0)
-    # a blosc-compressed array is reported, not mis-read
+    # an array with a codec this reader does not implement is reported (with the fix), not mis-read
     meta = path / "0" / "0" / "000" / "0" / ".zarray"
     m = json.loads(meta.read_text())
-    m["compressor"] = {"id": "blosc", "cname": "zstd"}
+    m["compressor"] = {"id": "lzma"}
     meta.write_text(json.dumps(m))
-    with open_ome_zarr(path, prefer_iohub=False) as plate, pytest.raises(UnsupportedCodec):
+    with open_ome_zarr(path, prefer_iohub=False) as plate, pytest.raises(UnsupportedCodec, match="install iohub"):
         dict(plate.positions())[KEYS[0]]["0"]
 
 

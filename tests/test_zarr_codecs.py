@@ -1,0 +1,233 @@
+"""The store format on either side of the hot path: Zarr v3 shards with a
+CRC-32C index around blosc-zstd chunks -- what the acquisition engine writes
+(``shrimpy/mantis/mantis_engine.py:474-481``, asserted in
+``shrimpy/tests/test_mantis_integration.py:153-196``) -- plus bare zstd / gzip / blosc chunks.
+
+The blosc frame codec is checked three ways: against frames a real c-blosc 1.21.0 produced
+(committed under ``tests/golden/blosc_frames.npz`` with the script that made them,
+``oracle/make_blosc_golden.py``), live against ``libblosc`` where one is loadable, and by round trip.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from shrimpy_amd.io import codecs
+from shrimpy_amd.io.omezarr import UnsupportedCodec, ZarrArray, open_ome_zarr
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 appendix B.4 test patterns + the classic check value
+    assert codecs.crc32c(b"123456789") == 0xE3069283
+    assert codecs.crc32c(bytes(32)) == 0x8A9136AA
+    assert codecs.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert codecs.crc32c(bytes(range(32))) == 0x46DD794E
+    assert codecs.crc32c(b"") == 0
+
+
+def test_blosc_decoder_reads_frames_made_by_c_blosc(golden_dir):
+    """Frames from libblosc 1.21.0 (zstd / lz4 / zlib; no-, byte- and bit-shuffle; split and
+    unsplit blocks; a leftover block; the memcpyed form) through the pure-Python decoder."""
+    g = np.load(golden_dir / "blosc_frames.npz")
+    names = sorted({k.rsplit(".", 1)[0] for k in g.files})
+    assert len(names) >= 12
+    for name in names:
+        frame, want = g[name + ".frame"].tobytes(), g[name + ".data"]
+        out = np.empty(want.nbytes, np.uint8)
+        codecs._py_blosc_decode(frame, out)
+        np.testing.assert_array_equal(out.view(want.dtype), want.reshape(-1), err_msg=name)
+        np.testing.assert_array_equal(codecs.blosc_decode(frame).view(want.dtype), want.reshape(-1))
+
+
+@pytest.mark.parametrize("cname", ["zstd", "zlib"])
+@pytest.mark.parametrize("shuffle", [0, 1, 2])
+@pytest.mark.parametrize("dtype,n", [("uint16", 70001), ("float32", 4096), ("uint8", 5), ("uint16", 0)])
+def test_blosc_python_encoder_round_trips(cname, shuffle, dtype, n):
+    rng = np.random.default_rng(n + shuffle)
+    a = rng.integers(80, 600, n).astype(dtype)
+    frame = codecs._py_blosc_encode(a.view(np.uint8), a.itemsize, cname, 1, shuffle, 0)
+    h = codecs.blosc_header(frame)
+    assert (h["nbytes"], h["typesize"], h["compressor"], h["cbytes"]) == (a.nbytes, a.itemsize, cname, len(frame))
+    out = np.empty(a.nbytes, np.uint8)
+    codecs._py_blosc_decode(frame, out)
+    np.testing.assert_array_equal(out.view(dtype), a)
+
+
+@pytest.fixture
+def libblosc(monkeypatch):
+    """A real c-blosc through ctypes when the host has one (the build image: /opt/conda/lib)."""
+    for cand in (os.environ.get("LSR_LIBBLOSC"), "/opt/conda/lib/libblosc.so.1"):
+        if cand and os.path.exists(cand):
+            monkeypatch.setenv("LSR_LIBBLOSC", cand)
+            break
+    monkeypatch.setattr(codecs, "_libblosc_tried", False)
+    monkeypatch.setattr(codecs, "_libblosc", None)
+    if codecs._blosc_lib() is None:
+        pytest.skip("no libblosc on this host")
+    yield
+    codecs._libblosc_tried, codecs._libblosc = False, None
+
+
+def test_blosc_python_codec_agrees_with_libblosc_both_ways(libblosc):
+    rng = np.random.default_rng(2)
+    for dtype, n, cname, shuffle in [("uint16", 33333, "zstd", 1), ("uint16", 565, "zstd", 2),
+                                     ("float32", 300001, "lz4", 1), ("float64", 1000, "zlib", 2),
+                                     ("uint8", 100000, "zstd", 0)]:
+        a = rng.integers(0, 600, n).astype(dtype)
+        frame = codecs.blosc_encode(a, a.itemsize, cname, 1, shuffle, backend="libblosc")
+        out = np.empty(a.nbytes, np.uint8)
+        codecs._py_blosc_decode(frame, out)
+        np.testing.assert_array_equal(out.view(dtype), a)
+        if cname != "lz4":
+            mine = codecs._py_blosc_encode(a.view(np.uint8), a.itemsize, cname, 1, shuffle, 0)
+            np.testing.assert_array_equal(codecs.blosc_decode(mine, backend="libblosc").view(dtype), a)
+
+
+def test_blosc_decode_into_a_caller_buffer_and_errors():
+    a = np.arange(5000, dtype=np.uint16)
+    frame = codecs._py_blosc_encode(a.view(np.uint8), 2, "zstd", 1, 1, 0)
+    dest = np.zeros((50, 100), np.uint16)
+    assert codecs.blosc_decode(frame, out=dest) is dest
+    np.testing.assert_array_equal(dest.reshape(-1), a)
+    with pytest.raises(ValueError):
+        codecs.blosc_decode(frame, out=np.zeros(10, np.uint16))
+    with pytest.raises(ValueError):
+        codecs.blosc_decode(frame[:8])
+    with pytest.raises(ValueError):
+        codecs.blosc_decode(frame, out=np.zeros((100, 100), np.uint16)[:, ::2])
+
+
+# ------------------------------------------------------------------ arrays
+
+ENGINE = dict(compress="blosc-zstd", shards="volume")   # mantis_engine.py:474-481
+
+
+def _plate(path, version, shape=(2, 2, 40, 12, 20), dtype="uint16", chunks=None, **kw):
+    rng = np.random.default_rng(7)
+    data = rng.integers(80, 600, shape).astype(dtype)
+    with open_ome_zarr(path, layout="hcs", mode="w", channel_names=["BF", "GFP"], version=version,
+                       prefer_iohub=False) as plate:
+        pos = plate.create_position("A", "1", "fov0")
+        arr = pos.create_zeros("0", shape=shape, dtype=dtype, chunks=chunks, **kw)
+        for t in range(shape[0]):
+            for c in range(shape[1]):
+                arr.write_volume(t, c, data[t, c])
+    return data
+
+
+def test_engine_layout_round_trips_and_declares_what_the_engine_declares(tmp_path):
+    """Zarr v3, NGFF 0.5, position key ``A/1/fov0``, ``sharding_indexed`` around ``blosc`` with
+    ``cname=zstd``, z-chunk != 1: the properties ``test_mantis_integration.py:153-196`` asserts."""
+    path = tmp_path / "acq.ome.zarr"
+    data = _plate(path, "0.5", chunks=(1, 1, 16, 12, 20), **ENGINE)
+    meta = json.loads((path / "A" / "1" / "fov0" / "0" / "zarr.json").read_text())
+    assert meta["zarr_format"] == 3
+    (sh,) = meta["codecs"]
+    assert sh["name"] == "sharding_indexed" and sh["configuration"]["index_location"] == "end"
+    inner = {c["name"]: c.get("configuration", {}) for c in sh["configuration"]["codecs"]}
+    assert inner["blosc"]["cname"] == "zstd" and inner["blosc"]["typesize"] == 2
+    assert [c["name"] for c in sh["configuration"]["index_codecs"]] == ["bytes", "crc32c"]
+    assert meta["chunk_grid"]["configuration"]["chunk_shape"] == [1, 1, 48, 12, 20]   # shard = padded volume
+    with open_ome_zarr(path, prefer_iohub=False) as plate:
+        assert plate.version == "0.5"
+        (key, pos), = plate.positions()
+        assert key == "A/1/fov0"
+        arr = pos["0"]
+        assert arr.chunks == (1, 1, 16, 12, 20) and arr.shards == (1, 1, 48, 12, 20) and arr.chunks[-3] != 1
+        for t in range(2):
+            for c in range(2):
+                np.testing.assert_array_equal(arr.read_volume(t, c), data[t, c])
+        out = np.empty((40, 12, 20), np.uint16)          # decode straight into a caller (pinned) buffer
+        assert arr.read_volume(1, 0, out=out) is out
+        np.testing.assert_array_equal(out, data[1, 0])
+    # one file per (t, c) volume: index (3 chunks x 16 B + crc) at its end
+    shard = path / "A" / "1" / "fov0" / "0" / "c" / "1" / "0" / "0" / "0" / "0"
+    raw = shard.read_bytes()
+    index = np.frombuffer(raw[-52:-4], "<u8").reshape(3, 2)
+    assert codecs.crc32c(raw[-52:-4]) == int.from_bytes(raw[-4:], "little")
+    assert index[0, 0] == 0 and index[1, 0] == index[0, 1] and int(index[:, 1].sum()) == len(raw) - 52
+    assert codecs.blosc_header(raw[:16])["compressor"] == "zstd"
+
+
+@pytest.mark.parametrize("kw", [
+    dict(compress="blosc-zstd", shards=(1, 1, 32, 12, 20)),        # two shards along z, ragged tail
+    dict(compress="blosc-zstd", shards=(2, 2, 48, 16, 20)),        # a shard that holds all four (t, c) volumes
+    dict(compress=None, shards=(1, 1, 48, 12, 20)),                # sharded, inner chunks raw
+    dict(compress="gzip", shards=(1, 2, 16, 12, 40)),
+    dict(compress="zstd"), dict(compress="blosc-zstd"), dict(compress="gzip"),   # unsharded
+])
+def test_sharded_and_compressed_v3_arrays_round_trip(tmp_path, kw):
+    chunks = (1, 1, 16, 4, 20) if kw.get("shards") == (2, 2, 48, 16, 20) else (1, 1, 16, 12, 20)
+    data = _plate(tmp_path / "p.zarr", "0.5", chunks=chunks, **kw)
+    with open_ome_zarr(tmp_path / "p.zarr", prefer_iohub=False) as plate:
+        arr = plate["A/1/fov0"]["0"]
+        np.testing.assert_array_equal(arr[:], data)
+
+
+def test_engine_layout_through_libblosc_equals_the_python_codec(tmp_path, libblosc):
+    """With a C library doing the frames (the fast path on a real host) the store reads back the same,
+    and a store written by either codec is readable by the other."""
+    assert codecs.blosc_backend() == "libblosc"
+    data = _plate(tmp_path / "c.zarr", "0.5", chunks=(1, 1, 16, 12, 20), **ENGINE)
+    codecs._libblosc = None                         # read it back with the pure-Python decoder
+    assert codecs.blosc_backend() == "python"
+    with open_ome_zarr(tmp_path / "c.zarr", prefer_iohub=False) as plate:
+        np.testing.assert_array_equal(plate["A/1/fov0"]["0"][:], data)
+    data2 = _plate(tmp_path / "py.zarr", "0.5", chunks=(1, 1, 16, 12, 20), **ENGINE)
+    codecs._libblosc_tried = False
+    assert codecs.blosc_backend() == "libblosc"
+    with open_ome_zarr(tmp_path / "py.zarr", prefer_iohub=False) as plate:
+        np.testing.assert_array_equal(plate["A/1/fov0"]["0"][:], data2)
+
+
+@pytest.mark.parametrize("compress", ["blosc-zstd", "zstd", "zlib"])
+def test_v2_compressors_round_trip(tmp_path, compress):
+    data = _plate(tmp_path / "p.zarr", "0.4", chunks=(1, 1, 16, 12, 20), compress=compress)
+    meta = json.loads((tmp_path / "p.zarr" / "A" / "1" / "fov0" / "0" / ".zarray").read_text())
+    assert meta["compressor"]["id"] == compress.split("-")[0]
+    with open_ome_zarr(tmp_path / "p.zarr", prefer_iohub=False) as plate:
+        np.testing.assert_array_equal(plate["A/1/fov0"]["0"][:], data)
+
+
+def test_missing_inner_chunks_and_shards_read_as_fill(tmp_path):
+    with open_ome_zarr(tmp_path / "z.zarr", layout="hcs", mode="w", version="0.5", prefer_iohub=False) as plate:
+        arr = plate.create_position("A", "1", "0").create_zeros(
+            "0", shape=(1, 2, 40, 12, 20), dtype="uint16", chunks=(1, 1, 16, 12, 20), compress="blosc-zstd",
+            shards=(1, 2, 48, 12, 20))
+        vol = np.full((40, 12, 20), 7, np.uint16)
+        arr.write_volume(0, 1, vol)                      # channel 0 of the shared shard stays absent
+    with open_ome_zarr(tmp_path / "z.zarr", prefer_iohub=False) as plate:
+        arr = plate["A/1/0"]["0"]
+        assert not arr.read_volume(0, 0).any()           # the autofocus-failed all-zero volume case
+        np.testing.assert_array_equal(arr.read_volume(0, 1), vol)
+
+
+def test_corrupt_shard_index_is_detected(tmp_path):
+    _plate(tmp_path / "p.zarr", "0.5", shape=(1, 1, 40, 12, 20), chunks=(1, 1, 16, 12, 20), **ENGINE)
+    shard = tmp_path / "p.zarr" / "A" / "1" / "fov0" / "0" / "c" / "0" / "0" / "0" / "0" / "0"
+    raw = bytearray(shard.read_bytes())
+    raw[-10] ^= 0x40
+    shard.write_bytes(bytes(raw))
+    with open_ome_zarr(tmp_path / "p.zarr", prefer_iohub=False) as plate:
+        with pytest.raises(OSError, match="checksum"):
+            plate["A/1/fov0"]["0"].read_volume(0, 0)
+    shard.write_bytes(bytes(raw[:20]))
+    with open_ome_zarr(tmp_path / "p.zarr", prefer_iohub=False) as plate:
+        with pytest.raises(OSError, match="shorter"):
+            plate["A/1/fov0"]["0"].read_volume(0, 0)
+
+
+def test_unknown_codecs_name_the_fix(tmp_path):
+    _plate(tmp_path / "p.zarr", "0.5", shape=(1, 1, 8, 4, 4), chunks=(1, 1, 8, 4, 4))
+    meta_path = tmp_path / "p.zarr" / "A" / "1" / "fov0" / "0" / "zarr.json"
+    meta = json.loads(meta_path.read_text())
+    meta["codecs"].append({"name": "pcodec"})
+    meta_path.write_text(json.dumps(meta))
+    with pytest.raises(UnsupportedCodec, match="install iohub"):
+        ZarrArray(meta_path.parent, "0.5", "r")
+    with pytest.raises(ValueError, match="multiple"):
+        ZarrArray.create(tmp_path / "bad", "0.5", (1, 1, 8, 4, 4), (1, 1, 3, 4, 4), "uint16", None, (1, 1, 8, 4, 4))
+    with pytest.raises(ValueError, match="0.5"):
+        ZarrArray.create(tmp_path / "bad2", "0.4", (1, 1, 8, 4, 4), (1, 1, 4, 4, 4), "uint16", None, (1, 1, 8, 4, 4))
