@@ -44,16 +44,27 @@ def _common(fn):
                       type=click.Path(exists=True, dir_okay=False, path_type=Path),
                       help="YAML settings file.")(fn)
     fn = click.option("-o", "--output-dirpath", "output_path", required=True,
-                      type=click.Path(path_type=Path), help="Output OME-Zarr store (must not exist).")(fn)
+                      type=click.Path(path_type=Path),
+                      help="Output OME-Zarr store (must not exist, unless --resume).")(fn)
     fn = click.option("-p", "--position", "positions", multiple=True,
                       help='Restrict to these position keys ("row/col/fov"); repeatable.')(fn)
     fn = click.option("--zarr-version", type=click.Choice(["0.4", "0.5"]), default="0.4", show_default=True,
                       help="NGFF version of the output store.")(fn)
+    fn = click.option("--resume", is_flag=True,
+                      help="Continue an interrupted run: units already completed in the output store "
+                           "(same input and settings) are skipped, unfinished ones are rewritten.")(fn)
+    fn = click.option("--io", "io_backend", type=click.Choice(["auto", "native", "iohub"]), default="auto",
+                      show_default=True,
+                      help="Store access: this package's reader/writer, iohub, or native with iohub as the "
+                           "fallback for codecs it does not implement.")(fn)
+    fn = click.option("--compression", type=click.Choice(["none", "gzip", "zstd", "blosc-zstd"]),
+                      default="none", show_default=True, help="Chunk compression of the output (native writer).")(fn)
     return fn
 
 
 def _distributed():
-    """(rank, world, device) from the torchrun environment; initialises the process group for N>1."""
+    """(rank, world, device, created): ranks from the torchrun environment; the process group is
+    initialised here for N > 1 (``created`` tells the caller to destroy it again)."""
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,6 +76,7 @@ def _distributed():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     torch.cuda.set_device(local % n_dev)
     device = torch.device("cuda", local % n_dev)
+    created = False
     if world > 1:
         import torch.distributed as dist
 
@@ -77,11 +89,132 @@ def _distributed():
                 dist.init_process_group("nccl", device_id=device)
             else:
                 dist.init_process_group(backend)
-    return rank, world, device
+            created = True
+    return rank, world, device, created
+
+
+def _agree(error: str | None) -> None:
+    """Every rank learns whether rank 0's set-up step failed, and all of them stop together --
+    a bare barrier would leave the others waiting for the collective timeout."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        box = [error]
+        dist.broadcast_object_list(box, src=0)
+        error = box[0]
+    if error:
+        raise click.ClickException(error)
+
+
+def _open_source(path: Path, io_backend: str):
+    """``(store, {key: position})`` of the input, through the native reader or iohub.
+
+    ``auto`` = native first (it reads chunks straight into pinned staging slots); when an array uses
+    a codec it does not implement and iohub is importable, the whole store is reopened with iohub."""
+    from .io.omezarr import UnsupportedCodec, open_ome_zarr
+
+    def positions_of(store):
+        return dict(store.positions()) if hasattr(store, "positions") else {"0/0/0": store}
+
+    if io_backend in ("auto", "native"):
+        store = open_ome_zarr(path, layout="auto", mode="r", prefer_iohub=False)
+        pos = positions_of(store)
+        try:
+            for p in pos.values():
+                p["0"]          # parses the array metadata: raises on an unknown codec
+            return store, pos
+        except UnsupportedCodec as exc:
+            if io_backend == "native":
+                raise click.ClickException(str(exc)) from exc
+            try:
+                import iohub  # noqa: F401
+            except ImportError:
+                raise click.ClickException(f"{exc} (iohub is not installed either)") from exc
+    try:
+        from iohub import open_ome_zarr as iohub_open
+    except ImportError as exc:
+        raise click.ClickException("--io iohub: iohub is not installed") from exc
+    store = iohub_open(str(path), layout="auto", mode="r")
+    return store, positions_of(store)
+
+
+def _channel_plan(settings: ReconstructSettings, names: list[str], nc: int) -> list[bool]:
+    """Per channel: does the registration step apply?  ``source_channel_names`` empty = every channel
+    (the single-modality case); otherwise only the named ones are warped and every other channel --
+    the target included -- goes through the remaining steps unwarped."""
+    reg = settings.registration
+    if reg is None:
+        return [False] * nc
+    if not reg.source_channel_names:
+        if reg.target_channel_name is not None and nc > 1:
+            raise click.ClickException(
+                "registration names a target channel but no source_channel_names: list the channels to warp")
+        return [True] * nc
+    known = list(names) or [str(i) for i in range(nc)]
+    wanted = list(reg.source_channel_names) + ([reg.target_channel_name] if reg.target_channel_name else [])
+    missing = [n for n in wanted if n not in known]
+    if missing:
+        raise click.ClickException(f"channels {missing} not in the store (it has {known})")
+    if reg.target_channel_name in reg.source_channel_names:
+        raise click.ClickException(f"target channel {reg.target_channel_name!r} is also listed as a source")
+    return [known[c] in reg.source_channel_names for c in range(nc)]
+
+
+def _fingerprint(input_path: Path, settings: ReconstructSettings, shape, dtype, keys) -> str:
+    import hashlib
+    import json
+
+    doc = {"input": str(Path(input_path).resolve()), "settings": settings.model_dump(mode="json"),
+           "shape": list(shape), "dtype": str(dtype), "positions": list(keys)}
+    return hashlib.sha256(json.dumps(doc, sort_keys=True).encode()).hexdigest()
+
+
+class _DoneLedger:
+    """Per-unit completion records of an output store: one small file per (position, t, c) under
+    ``<store>/.lsr_done/``, written only after the unit's chunks are.
+
+    The reference never overwrites an acquisition and appends its CSV row by row
+    (``shrimpy/mantis/mantis_engine.py:458, 480``, ``shrimpy/dynatrack/tracking.py:887-914``); the
+    unit of resumption here is likewise the per-(p, t, c) volume.  A record carries
+    the fingerprint of (input, settings, geometry): a store written with other settings is never
+    silently continued."""
+
+    def __init__(self, store_path: Path, fingerprint: str):
+        self.dir = Path(store_path) / ".lsr_done"
+        self.fingerprint = fingerprint
+
+    def _file(self, u) -> Path:
+        return self.dir / u.position.replace("/", "__") / f"t{u.t}_c{u.c}"
+
+    def begin(self) -> None:
+        self.dir.mkdir(parents=True, exist_ok=True)
+        tag = self.dir / "fingerprint"
+        if tag.exists():
+            if tag.read_text().strip() != self.fingerprint:
+                raise click.ClickException(
+                    f"{self.dir.parent} was written from a different input or with different settings; "
+                    "--resume only continues the same run")
+        else:
+            tag.write_text(self.fingerprint + "\n")
+
+    def is_done(self, u) -> bool:
+        f = self._file(u)
+        try:
+            return f.read_text().strip() == self.fingerprint
+        except FileNotFoundError:
+            return False
+
+    def mark(self, u) -> None:
+        f = self._file(u)
+        f.parent.mkdir(parents=True, exist_ok=True)
+        tmp = f.with_name(f.name + ".tmp")
+        tmp.write_text(self.fingerprint + "\n")
+        os.replace(tmp, f)
 
 
 def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings, positions=(),
-              zarr_version: str = "0.4", reconstructor_factory=None, stage_through_pinned: bool = True) -> dict:
+              zarr_version: str = "0.4", reconstructor_factory=None, stage_through_pinned: bool = True,
+              resume: bool = False, io_backend: str = "auto", compression: str | None = None) -> dict:
     """Apply ``settings`` to every (position, t, c) volume of ``input_path`` -> ``output_path``.
 
     On a GPU the volumes pass through pinned staging slots and copy streams
@@ -89,16 +222,29 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
 
     ``reconstructor_factory(raw_shape, settings, device)`` defaults to
     :class:`shrimpy_amd.pipeline.VolumeReconstructor` (tests inject a stand-in).
+    ``resume``: the output may exist; units recorded as complete (``_DoneLedger``) are skipped.
     """
+    rank, world, device, created = _distributed()
+    try:
+        return _run_store(input_path, output_path, settings, positions, zarr_version, reconstructor_factory,
+                          stage_through_pinned, resume, io_backend, compression, rank, world, device)
+    finally:
+        if created:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
+
+
+def _run_store(input_path, output_path, settings, positions, zarr_version, reconstructor_factory,
+               stage_through_pinned, resume, io_backend, compression, rank, world, device) -> dict:
     import torch
 
-    from .io.omezarr import open_ome_zarr
+    from .io.omezarr import as_volume_array, create_level, open_ome_zarr, position_scale
     from .pipeline import Unit, VolumeReconstructor, enumerate_units, run_sharded
 
-    rank, world, device = _distributed()
     factory = reconstructor_factory or VolumeReconstructor
-    src = open_ome_zarr(input_path, layout="auto", mode="r")
-    src_positions = dict(src.positions())
+    src, src_positions = _open_source(input_path, io_backend)
+    use_iohub_out = io_backend == "iohub"
     keys = [k for k in src_positions if not positions or k in positions]
     missing = [p for p in positions if p not in src_positions]
     if missing:
@@ -106,52 +252,105 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
     if not keys:
         raise click.ClickException("no positions to process")
 
+    # every selected position must have the first one's geometry: checked before anything is written
+    arrays = {k: as_volume_array(src_positions[k]["0"]) for k in keys}
     first = src_positions[keys[0]]
-    nt, nc, nz, ny, nx = first["0"].shape
+    shape5, raw_dtype = tuple(arrays[keys[0]].shape), np.dtype(arrays[keys[0]].dtype)
+    if len(shape5) != 5:
+        raise click.ClickException(f"position {keys[0]}: expected 5-D TCZYX data, got shape {shape5}")
+    odd = {k: (tuple(a.shape), str(a.dtype)) for k, a in arrays.items()
+           if tuple(a.shape) != shape5 or np.dtype(a.dtype) != raw_dtype}
+    if odd:
+        raise click.ClickException(f"positions differ from {keys[0]} {shape5} {raw_dtype}: {odd}; "
+                                   "run them separately (-p)")
+    nt, nc, nz, ny, nx = shape5
+    channel_names = list(first.channel_names)
+    warp = _channel_plan(settings, channel_names, nc)
+
     rec = factory((nz, ny, nx), settings, device)
+    rec_unwarped = rec
+    if settings.registration is not None and not all(warp):
+        rec_unwarped = factory((nz, ny, nx), settings.model_copy(update={"registration": None}), device)
+        if tuple(rec_unwarped.output_shape) != tuple(rec.output_shape):
+            raise click.ClickException(
+                f"registered channels come out as {tuple(rec.output_shape)} but the unwarped ones as "
+                f"{tuple(rec_unwarped.output_shape)}: drop output_shape_zyx or warp every channel")
     oz, oy, ox = rec.output_shape
-    in_scale = first.scale
-    out_scale = list(in_scale)
+    out_scale = list(position_scale(first))
     if settings.deskew is not None:
-        from .geometry import deskew_geometry
+        from .geometry import deskew_geometry, orient_voxel
 
         d = settings.deskew
         voxel = deskew_geometry((nz, ny, nx), d.ls_angle_deg, d.px_to_scan_ratio, d.keep_overhang,
                                 d.average_n_slices, d.pixel_size_um).voxel_size
-        from .geometry import orient_voxel
-
         # scale metadata as scripts/measure_psf.py:273-276
         out_scale[2:] = [float(v) for v in orient_voxel(voxel, d.orientation)]
 
-    # rank 0 creates the output store (positions are separate arrays on disk); then everybody writes
-    if rank == 0:
-        dst = open_ome_zarr(output_path, layout="hcs", mode="w", channel_names=first.channel_names,
-                            version=zarr_version, prefer_iohub=False)
-        for key in keys:
-            row, col, fov = key.split("/")
-            pos = dst.create_position(row, col, fov)
-            pos.create_zeros("0", shape=(nt, nc, oz, oy, ox), dtype="float32", scale=out_scale)
-        dst.close()
-    if world > 1:
-        import torch.distributed as dist
+    ledger = _DoneLedger(output_path, _fingerprint(input_path, settings, shape5, raw_dtype, keys))
+    out_shape5 = (nt, nc, oz, oy, ox)
 
-        dist.barrier()
-    dst = open_ome_zarr(output_path, layout="hcs", mode="a", prefer_iohub=False)
-    dst_positions = dict(dst.positions())
+    def open_output(mode):
+        if use_iohub_out:
+            from iohub import open_ome_zarr as iohub_open
+
+            kw = dict(layout="hcs", mode=mode)
+            if mode == "w":
+                kw.update(channel_names=channel_names, version=zarr_version)
+            return iohub_open(str(output_path), **kw)
+        return open_ome_zarr(output_path, layout="hcs", mode=mode, channel_names=channel_names,
+                             version=zarr_version, prefer_iohub=False)
+
+    # rank 0 creates (or, resuming, checks and completes) the output store; positions are separate
+    # arrays on disk, so afterwards every rank writes its own units with no coordination
+    error = None
+    if rank == 0:
+        try:
+            exists = Path(output_path).exists() and any(Path(output_path).iterdir())
+            if exists and not resume:
+                raise FileExistsError(f"{output_path} exists (never overwritten, like the reference); "
+                                      "use --resume to continue an interrupted run")
+            dst = open_output("a" if exists else "w")
+            have = dict(dst.positions()) if exists else {}
+            for key in keys:
+                if key in have:
+                    got = tuple(as_volume_array(have[key]["0"]).shape)
+                    if got != out_shape5:
+                        raise ValueError(f"{output_path}: position {key} has shape {got}, this run writes {out_shape5}")
+                    continue
+                row, col, fov = key.split("/")
+                pos = dst.create_position(row, col, fov)
+                extra = {} if use_iohub_out or compression in (None, "none") else {"compress": compression}
+                create_level(pos, out_shape5, "float32", out_scale, **extra)
+            dst.close()
+            ledger.begin()
+        except click.ClickException as exc:
+            error = exc.message
+        except Exception as exc:  # noqa: BLE001 -- reported on every rank, see _agree
+            error = f"{type(exc).__name__}: {exc}"
+    _agree(error)
+    dst = open_output("a")
+    dst_arrays = {k: as_volume_array(p["0"]) for k, p in dict(dst.positions()).items() if k in keys}
 
     units = enumerate_units(keys, nt, range(nc))
+    todo = [u for u in units if not (resume and ledger.is_done(u))]
+    skipped = len(units) - len(todo)
+    if skipped:
+        logger.info("resume: %d of %d units already complete", skipped, len(units))
 
     def load(u: Unit, out=None):
-        return src_positions[u.position]["0"].read_volume(u.t, u.c, out=out)
+        return arrays[u.position].read_volume(u.t, u.c, out=out)
 
     def store(u: Unit, vol):
         host = vol if isinstance(vol, np.ndarray) else vol.cpu().numpy()
-        dst_positions[u.position]["0"].write_volume(u.t, u.c, host)
+        dst_arrays[u.position].write_volume(u.t, u.c, host)
+        ledger.mark(u)
+
+    def process(data, unit: Unit):
+        return (rec if warp[unit.c] else rec_unwarped)(data)
 
     stager = None
-    raw_dtype = np.dtype(first["0"].dtype)
     if (stage_through_pinned and torch.device(device).type == "cuda"
-            and raw_dtype in (np.dtype("uint16"), np.dtype("float32")) and len(units) > world):
+            and raw_dtype in (np.dtype("uint16"), np.dtype("float32")) and len(todo) > world):
         from .staging import VolumeStager
 
         try:
@@ -159,12 +358,22 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
         except (RuntimeError, MemoryError) as exc:   # not enough pinnable host memory for the slots
             logger.warning("staging slots unavailable (%s): volumes are handed over synchronously", exc)
             stager = None
-    report = run_sharded(units, load, rec, store, synchronize=torch.cuda.synchronize, stager=stager)
+    try:
+        report = run_sharded(todo, load, process, store, synchronize=torch.cuda.synchronize, stager=stager,
+                             process_takes_unit=True)
+    finally:
+        if stager is not None:
+            stager.close()
+        for s in (src, dst):
+            close = getattr(s, "close", None)
+            if close:
+                close()
     nvox = len(report.units) * nz * ny * nx
     logger.info("rank %d: %d units, %.3g input voxels/s (job %.2fs)", rank, len(report.units),
                 nvox / max(report.seconds, 1e-9), report.max_seconds)
     return {"rank": rank, "world_size": world, "units": len(report.units), "units_total": len(units),
-            "seconds": report.seconds, "job_seconds": report.max_seconds, "output_shape": (oz, oy, ox)}
+            "units_skipped": skipped, "seconds": report.seconds, "job_seconds": report.max_seconds,
+            "output_shape": (oz, oy, ox)}
 
 
 @click.group(context_settings=CONTEXT)
@@ -177,36 +386,40 @@ def cli(verbose: bool):
 
 @cli.command()
 @_common
-def deskew(input_path, config, output_path, positions, zarr_version):
+def deskew(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression):
     """Deskew oblique-plane stacks (config: DeskewSettings YAML)."""
     s = ReconstructSettings(deskew=DeskewSettings.from_yaml(config))
-    click.echo(run_store(input_path, output_path, s, positions, zarr_version))
+    click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
+                         io_backend=io_backend, compression=compression))
 
 
 @cli.command()
 @_common
-def register(input_path, config, output_path, positions, zarr_version):
+def register(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression):
     """Apply an affine registration (config: RegisterSettings YAML with affine_transform_zyx)."""
     s = ReconstructSettings(registration=RegisterSettings.from_yaml(config))
-    click.echo(run_store(input_path, output_path, s, positions, zarr_version))
+    click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
+                         io_backend=io_backend, compression=compression))
 
 
 @cli.command()
 @_common
-def deconvolve(input_path, config, output_path, positions, zarr_version):
+def deconvolve(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression):
     """Richardson-Lucy deconvolution (config: DeconvolveSettings YAML)."""
     s = ReconstructSettings(deconvolution=DeconvolveSettings.from_yaml(config))
-    click.echo(run_store(input_path, output_path, s, positions, zarr_version))
+    click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
+                         io_backend=io_backend, compression=compression))
 
 
 @cli.command()
 @_common
-def reconstruct(input_path, config, output_path, positions, zarr_version):
+def reconstruct(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression):
     """deskew -> register -> deconvolve in one pass (config: ReconstructSettings YAML)."""
     s = ReconstructSettings.from_yaml(config)
     if s.deskew is None and s.registration is None and s.deconvolution is None:
         raise click.ClickException("the config enables no step")
-    click.echo(run_store(input_path, output_path, s, positions, zarr_version))
+    click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
+                         io_backend=io_backend, compression=compression))
 
 
 def main():

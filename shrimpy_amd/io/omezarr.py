@@ -38,7 +38,8 @@ from typing import Iterator, Sequence
 
 import numpy as np
 
-__all__ = ["open_ome_zarr", "Plate", "Position", "ZarrArray", "UnsupportedCodec"]
+__all__ = ["open_ome_zarr", "Plate", "Position", "ZarrArray", "UnsupportedCodec", "as_volume_array",
+           "create_level", "position_scale"]
 
 AXES = [
     {"name": "T", "type": "time", "unit": "second"},
@@ -789,3 +790,79 @@ def open_ome_zarr(store_path, layout: str = "auto", mode: str = "r", channel_nam
     path.mkdir(parents=True, exist_ok=True)
     cls = Plate if layout == "hcs" else Position
     return cls(path, version, "w", channel_names)
+
+
+# ---------------------------------------------------------------------------------------------
+# One whole-volume interface over this module's arrays AND iohub's (``ImageArray`` is a zarr array:
+# numpy indexing and assignment, ``shape`` / ``dtype`` / ``chunks``; read surface
+# ``shrimpy/replay_camera.py:176-268``, write surface ``shrimpy/dynatrack/tracking.py:1337-1367``).
+# ---------------------------------------------------------------------------------------------
+
+
+class _IndexedVolumes:
+    """``read_volume`` / ``write_volume`` on top of any array that indexes like numpy."""
+
+    def __init__(self, array):
+        self._a = array
+        self.shape = tuple(int(n) for n in array.shape)
+        self.dtype = np.dtype(array.dtype)
+        self.chunks = tuple(getattr(array, "chunks", None) or self.shape)
+
+    def _lead(self, lead):
+        k = len(self.shape) - 3
+        if len(lead) != k:
+            raise IndexError(f"expected {k} leading indices, got {len(lead)}")
+        for i, n in zip(lead, self.shape):
+            if not 0 <= i < n:
+                raise IndexError(f"index {tuple(lead)} out of range for shape {self.shape}")
+        return tuple(int(i) for i in lead)
+
+    def read_volume(self, *lead, out=None):
+        vol = np.asarray(self._a[self._lead(lead)])
+        if out is None:
+            return np.ascontiguousarray(vol)
+        if tuple(out.shape) != vol.shape or out.dtype != vol.dtype:
+            raise ValueError(f"out must be {vol.shape} {vol.dtype}, got {out.shape} {out.dtype}")
+        np.copyto(out, vol)
+        return out
+
+    def write_volume(self, *args):
+        *lead, vol = args
+        self._a[self._lead(lead)] = np.asarray(vol, dtype=self.dtype)
+
+
+def as_volume_array(array):
+    """``array`` itself when it already moves whole volumes (this module's ``ZarrArray``), else a
+    wrapper that does so through numpy indexing (iohub / zarr / dask / numpy arrays)."""
+    if hasattr(array, "read_volume") and hasattr(array, "write_volume"):
+        return array
+    return _IndexedVolumes(array)
+
+
+def position_scale(position) -> tuple[float, ...]:
+    """(T, C, Z, Y, X) scale of a position's level 0, from either kind of object -- the metadata walk
+    of ``shrimpy/replay_camera.py:256-266``."""
+    scale = getattr(position, "scale", None)
+    if scale is not None and not callable(scale):
+        return tuple(float(v) for v in scale)
+    ms = position.zattrs.get("multiscales", [{}])
+    ds = ms[0].get("datasets", [{}]) if ms else [{}]
+    for t in ds[0].get("coordinateTransformations", []):
+        if t.get("type") == "scale":
+            return tuple(float(v) for v in t["scale"])
+    return (1.0,) * 5
+
+
+def create_level(position, shape, dtype, scale, chunks=None, name: str = "0", **kw):
+    """``position.create_zeros`` with the scale metadata, for this module's ``Position`` (``scale=``)
+    and for iohub's (``transform=[TransformationMeta(type="scale", ...)]``,
+    ``scripts/measure_psf.py:273-287``)."""
+    shape = tuple(int(n) for n in shape)
+    if chunks is None:
+        chunks = (1, 1, min(32, shape[2]), shape[3], shape[4])   # tracking.py:1362
+    if isinstance(position, Position):
+        return position.create_zeros(name, shape=shape, dtype=dtype, chunks=chunks, scale=scale, **kw)
+    from iohub.ngff.models import TransformationMeta
+
+    transform = [TransformationMeta(type="scale", scale=[float(v) for v in scale])]
+    return position.create_zeros(name, shape=shape, dtype=dtype, chunks=chunks, transform=transform)

@@ -188,6 +188,7 @@ def run_sharded(
     synchronize: Callable[[], None] | None = None,
     overlap_io: bool = True,
     stager=None,
+    process_takes_unit: bool = False,
 ) -> ShardReport:
     """Run ``store(unit, process(load(unit)))`` for this rank's share of ``units``.
 
@@ -205,6 +206,10 @@ def run_sharded(
     of unit k-1 run on their own HIP streams beside the kernels of unit k, ``process`` receives the
     device tensor and ``store`` the result as a (pinned) numpy array.  Events order the three
     streams; there is no device-wide synchronise inside the loop.
+
+    ``process_takes_unit``: call ``process(data, unit)`` (the CLI picks a per-channel reconstructor).
+    An exception from ``load``, ``process`` or ``store`` propagates after the worker threads have
+    stopped and the stager's copy streams have drained; units finished before it stay written.
     """
     import torch
 
@@ -213,13 +218,18 @@ def run_sharded(
     world = dist.get_world_size() if dist else 1
     mine = shard_units(list(units), rank, world)
     sync = synchronize or (lambda: None)
+    if process_takes_unit:
+        run = process
+    else:
+        def run(data, unit):
+            return process(data)
 
     if dist:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     if stager is not None and mine:
-        _run_staged(mine, load, process, store, stager)
+        _run_staged(mine, load, run, store, stager)
     elif overlap_io and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor
 
@@ -230,7 +240,7 @@ def run_sharded(
                 data = nxt.result()
                 if i + 1 < len(mine):
                     nxt = loader.submit(load, mine[i + 1])
-                result = process(data)
+                result = run(data, unit)
                 sync()  # the result must be complete before another thread reads it
                 if pending_store is not None:
                     pending_store.result()  # surface store errors, keep at most one in flight
@@ -239,7 +249,7 @@ def run_sharded(
                 pending_store.result()
     else:
         for unit in mine:
-            store(unit, process(load(unit)))
+            store(unit, run(load(unit), unit))
     sync()
     seconds = time.perf_counter() - t0
     max_seconds = seconds
@@ -257,7 +267,7 @@ def run_sharded(
 
 def _run_staged(mine, load, process, store, stager) -> None:
     """The ``stager`` branch of ``run_sharded``: loader thread -> up stream -> kernels -> down
-    stream -> writer thread, slot ``i % depth`` for the i-th unit."""
+    stream -> writer thread, slot ``i % depth`` for the i-th unit.  ``process(data, unit)``."""
     import inspect
 
     from concurrent.futures import ThreadPoolExecutor
@@ -277,14 +287,14 @@ def _run_staged(mine, load, process, store, stager) -> None:
     def write(i):
         store(mine[i], stager.collect(i % depth))
 
-    with ThreadPoolExecutor(1, "lsr-load") as loader, ThreadPoolExecutor(1, "lsr-store") as storer:
-        pending_store = None
+    loader, storer = ThreadPoolExecutor(1, "lsr-load"), ThreadPoolExecutor(1, "lsr-store")
+    pending_store = nxt = None
+    try:
         nxt = loader.submit(stage, 0)
         for i in range(len(mine)):
             slot = nxt.result()
-            if i + 1 < len(mine):
-                nxt = loader.submit(stage, i + 1)
-            result = process(stager.acquire(slot))
+            nxt = loader.submit(stage, i + 1) if i + 1 < len(mine) else None
+            result = process(stager.acquire(slot), mine[i])
             stager.release(slot)
             if pending_store is not None:
                 pending_store.result()         # at most one write in flight: slot i-2 is free again
@@ -292,7 +302,19 @@ def _run_staged(mine, load, process, store, stager) -> None:
             pending_store = storer.submit(write, i)
         if pending_store is not None:
             pending_store.result()
-    stager.drain()
+            pending_store = None
+    finally:
+        # whatever happened: no thread is left filling a slot, no copy is left in flight on the
+        # up / down streams, before the caller sees the exception (or the result)
+        for fut in (nxt, pending_store):
+            if fut is not None and not fut.cancel():
+                try:
+                    fut.result()
+                except Exception:  # noqa: BLE001 -- the first failure is the one that propagates
+                    pass
+        loader.shutdown(wait=True)
+        storer.shutdown(wait=True)
+        stager.drain()
 
 
 def gather_to_rank0(local: Iterable, n_total: int):

@@ -109,6 +109,10 @@ class RegisterSettings(_StrictModel):
 
     ``affine_transform_zyx`` is a homogeneous 4x4 in ZYX voxel units mapping TARGET (output)
     coordinates to SOURCE (moving) coordinates -- the ``scipy.ndimage.affine_transform`` convention.
+
+    ``source_channel_names``: the channels the transform is applied to (empty = every channel);
+    any other channel -- ``target_channel_name`` among them -- passes through unwarped
+    (``cli._channel_plan``).
     """
 
     source_channel_names: list[str] = []
@@ -118,6 +122,14 @@ class RegisterSettings(_StrictModel):
     mode: Literal["constant", "grid-constant"] = "constant"
     cval: float = 0.0
     keep_overhang: bool = False
+
+    @field_validator("keep_overhang")
+    @classmethod
+    def _no_overhang_yet(cls, v):
+        if v:
+            raise ValueError("keep_overhang=True (output grown to the union of both volumes) is not "
+                             "implemented; give output_shape_zyx and fold the shift into the matrix")
+        return v
 
     @field_validator("affine_transform_zyx")
     @classmethod

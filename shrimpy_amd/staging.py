@@ -33,7 +33,14 @@ class VolumeStager:
     Slot ``k`` serves units ``k, k + depth, ...``; calls for one slot must come in unit order.
     """
 
-    def __init__(self, raw_shape, raw_dtype, out_shape, device, depth: int = 2):
+    def __init__(self, raw_shape, raw_dtype, out_shape, device, depth: int = 2, pin: str = "exact"):
+        """``depth`` slots each way (default 2; more only helps when load times vary a lot).
+
+        ``pin``: ``"exact"`` page-locks plain allocations of exactly the slot size with
+        ``hipHostRegister`` -- torch's caching host allocator rounds every pinned block up to a power
+        of two (a 4.3 GB raw slot becomes 8 GB, a 3.2 GB result slot 4 GB: ~24 GB per rank instead of
+        ~15 GB at config 2); ``"torch"`` uses ``pin_memory=True``; ``"none"`` keeps the slots
+        pageable (copies are then synchronous: correct, slower)."""
         import torch
 
         self.device = torch.device(device)
@@ -48,14 +55,49 @@ class VolumeStager:
         dt = {np.dtype("uint16"): torch.uint16, np.dtype("float32"): torch.float32}.get(np.dtype(raw_dtype))
         if dt is None:
             raise TypeError(f"raw dtype {raw_dtype}: uint16 (camera counts) or float32")
-        self._host_in = [torch.empty(self.raw_shape, dtype=dt, pin_memory=True) for _ in range(depth)]
+        if pin not in ("exact", "torch", "none"):
+            raise ValueError("pin must be 'exact', 'torch' or 'none'")
+        self._registered: list = []
+        self._host_in = [self._host_slot(self.raw_shape, dt, pin) for _ in range(depth)]
         self._dev_in = [torch.empty(self.raw_shape, dtype=dt, device=self.device) for _ in range(depth)]
-        self._host_out = [torch.empty(self.out_shape, dtype=torch.float32, pin_memory=True) for _ in range(depth)]
+        self._host_out = [self._host_slot(self.out_shape, torch.float32, pin) for _ in range(depth)]
         self._up = torch.cuda.Stream(self.device)
         self._down = torch.cuda.Stream(self.device)
         self._uploaded = [None] * depth      # recorded on `up` after the H2D copy of the slot
         self._consumed = [None] * depth      # recorded on the compute stream when the raw slot is dead
         self._downloaded = [None] * depth    # recorded on `down` after the D2H copy of the slot
+
+    def _host_slot(self, shape, dtype, pin: str):
+        import torch
+
+        if pin == "torch":
+            return torch.empty(shape, dtype=dtype, pin_memory=True)
+        t = torch.empty(shape, dtype=dtype)
+        if pin == "exact" and t.numel():
+            rt = torch.cuda.cudart()
+            err = rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)
+            if int(err) != 0 or not t.is_pinned():
+                if int(err) == 0:
+                    rt.cudaHostUnregister(t.data_ptr())
+                return torch.empty(shape, dtype=dtype, pin_memory=True)   # fall back to torch's allocator
+            self._registered.append(t)
+        return t
+
+    def close(self) -> None:
+        """Drain the copy streams and give the page-locked slots back."""
+        import torch
+
+        self.drain()
+        rt = torch.cuda.cudart()
+        while self._registered:
+            rt.cudaHostUnregister(self._registered.pop().data_ptr())
+
+    def __del__(self):
+        try:
+            if getattr(self, "_registered", None):
+                self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
     # ---- host -> device --------------------------------------------------------------------
     def host_in(self, slot: int) -> np.ndarray:
@@ -111,6 +153,13 @@ class VolumeStager:
         prev = self._downloaded[slot]
         if prev is not None:
             prev.synchronize()                  # the writer may still be reading the host slot
+        for dev_slot in self._dev_in:
+            # a pipeline that hands its input back (e.g. zero RL iterations on a float32 stack):
+            # the raw slot was released before this download was queued, so the upload two units on
+            # could overwrite it under the copy -- detach the result from the slot first
+            if result.untyped_storage().data_ptr() == dev_slot.untyped_storage().data_ptr():
+                result = result.clone()
+                break
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._down):

@@ -135,7 +135,7 @@ def cpu_cli(monkeypatch):
 
     import shrimpy_amd.cli as cli
 
-    monkeypatch.setattr(cli, "_distributed", lambda: (0, 1, torch.device("cpu")))
+    monkeypatch.setattr(cli, "_distributed", lambda: (0, 1, torch.device("cpu"), False))
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     return cli
 
@@ -169,8 +169,10 @@ def test_cli_commands_parse_configs_and_positions(tmp_path, cpu_cli, monkeypatch
     src = _make_plate(tmp_path / "raw.zarr", "0.4")
     seen = {}
 
-    def fake_run_store(input_path, output_path, settings, positions, zarr_version):
-        seen.update(settings=settings, positions=positions, version=zarr_version)
+    def fake_run_store(input_path, output_path, settings, positions, zarr_version, resume=False,
+                       io_backend="auto", compression=None):
+        seen.update(settings=settings, positions=positions, version=zarr_version, resume=resume,
+                    io_backend=io_backend, compression=compression)
         return {"ok": True}
 
     monkeypatch.setattr(cpu_cli, "run_store", fake_run_store)
@@ -189,6 +191,11 @@ def test_cli_commands_parse_configs_and_positions(tmp_path, cpu_cli, monkeypatch
                                     "--zarr-version", "0.5"])
     assert r.exit_code == 0, r.output
     assert seen["settings"].deconvolution.iterations == 7 and seen["version"] == "0.5"
+    assert (seen["resume"], seen["io_backend"], seen["compression"]) == (False, "auto", "none")
+    r = runner.invoke(cpu_cli.cli, ["deconvolve", "-i", str(src), "-c", str(dec), "-o", str(tmp_path / "o2"),
+                                    "--resume", "--io", "native", "--compression", "blosc-zstd"])
+    assert r.exit_code == 0, r.output
+    assert (seen["resume"], seen["io_backend"], seen["compression"]) == (True, "native", "blosc-zstd")
 
     bad = tmp_path / "bad.yml"
     bad.write_text(yaml.safe_dump(dict(iterations=7, bogus=1)))  # extra="forbid"
@@ -208,6 +215,434 @@ def test_cli_unknown_position_is_an_error(tmp_path, cpu_cli):
     with pytest.raises(click.ClickException, match="not found"):
         cpu_cli.run_store(src, tmp_path / "o", ReconstructSettings(deconvolution=DeconvolveSettings()),
                           positions=("9/9/9",), reconstructor_factory=_FakeReconstructor)
+
+
+# ------------------------------------------------------------------ resume (streamed runs, config 5)
+
+
+def _settings():
+    from shrimpy_amd.settings import DeconvolveSettings, ReconstructSettings
+
+    return ReconstructSettings(deconvolution=DeconvolveSettings(iterations=3))
+
+
+def _read_all(path):
+    with open_ome_zarr(path, prefer_iohub=False) as plate:
+        return {k: p["0"][:] for k, p in plate.positions()}
+
+
+@pytest.mark.parametrize("version", ["0.4", "0.5"])
+def test_resume_after_a_failed_store_equals_an_uninterrupted_run(tmp_path, cpu_cli, monkeypatch, version):
+    """A run dies in ``store`` after k of n units (disk full, node lost ...).  ``--resume`` skips the
+    units recorded as complete, rewrites the rest -- the half-written one included -- and the store
+    then equals the one an uninterrupted run writes.  Unit = one (position, t, c) volume, the
+    reference's own granularity (``mantis_engine.py:458, 480``: never overwrite; ``tracking.py:887-914``:
+    row-by-row append)."""
+    import click
+
+    from shrimpy_amd.io.omezarr import ZarrArray
+
+    src = _make_plate(tmp_path / "raw.zarr", version)
+    n = len(KEYS) * N_T * N_C
+    want = tmp_path / "whole.zarr"
+    cpu_cli.run_store(src, want, _settings(), zarr_version=version, reconstructor_factory=_FakeReconstructor)
+
+    out = tmp_path / "out.zarr"
+    real_write = ZarrArray.write_volume
+    written = []
+
+    def flaky_write(self, *args):
+        if len(written) == 5:
+            # the sixth unit: leave a partial volume behind, then die
+            half = np.array(args[-1], copy=True)
+            half[half.shape[0] // 2:] = -1
+            real_write(self, *args[:-1], half)
+            raise OSError("No space left on device")
+        real_write(self, *args)
+        written.append(args[:-1])
+
+    monkeypatch.setattr(ZarrArray, "write_volume", flaky_write)
+    with pytest.raises(OSError, match="No space"):
+        cpu_cli.run_store(src, out, _settings(), zarr_version=version, reconstructor_factory=_FakeReconstructor)
+    monkeypatch.setattr(ZarrArray, "write_volume", real_write)
+    assert len(written) == 5
+    assert any(not np.array_equal(a, b) for a, b in zip(_read_all(out).values(), _read_all(want).values()))
+
+    with pytest.raises(click.ClickException, match="--resume"):       # without the flag: never overwrite
+        cpu_cli.run_store(src, out, _settings(), zarr_version=version, reconstructor_factory=_FakeReconstructor)
+
+    calls = []
+
+    class Counting(_FakeReconstructor):
+        def __call__(self, raw):
+            calls.append(1)
+            return super().__call__(raw)
+
+    res = cpu_cli.run_store(src, out, _settings(), zarr_version=version, reconstructor_factory=Counting,
+                            resume=True)
+    assert res["units_skipped"] == 5 and res["units"] == n - 5 == len(calls)
+    got, ref = _read_all(out), _read_all(want)
+    assert list(got) == list(ref)
+    for k in ref:
+        np.testing.assert_array_equal(got[k], ref[k])
+    # a second --resume has nothing left to do
+    res = cpu_cli.run_store(src, out, _settings(), zarr_version=version, reconstructor_factory=Counting, resume=True)
+    assert res["units_skipped"] == n and res["units"] == 0
+
+
+def test_resume_refuses_a_store_written_with_other_settings(tmp_path, cpu_cli):
+    import click
+
+    from shrimpy_amd.settings import DeconvolveSettings, ReconstructSettings
+
+    src = _make_plate(tmp_path / "raw.zarr", "0.4")
+    out = tmp_path / "out.zarr"
+    cpu_cli.run_store(src, out, _settings(), reconstructor_factory=_FakeReconstructor)
+    other = ReconstructSettings(deconvolution=DeconvolveSettings(iterations=4))
+    with pytest.raises(click.ClickException, match="different settings"):
+        cpu_cli.run_store(src, out, other, reconstructor_factory=_FakeReconstructor, resume=True)
+    # --resume on a fresh path is simply a fresh run
+    res = cpu_cli.run_store(src, tmp_path / "new.zarr", _settings(), reconstructor_factory=_FakeReconstructor,
+                            resume=True)
+    assert res["units_skipped"] == 0 and res["units"] == res["units_total"]
+
+
+def test_resume_with_a_subset_of_positions_then_the_rest(tmp_path, cpu_cli):
+    """``-p`` runs are their own run (the fingerprint covers the positions): a store holding one
+    position is not silently extended by a run over different ones."""
+    import click
+
+    src = _make_plate(tmp_path / "raw.zarr", "0.4")
+    out = tmp_path / "out.zarr"
+    cpu_cli.run_store(src, out, _settings(), positions=(KEYS[0],), reconstructor_factory=_FakeReconstructor)
+    with pytest.raises(click.ClickException, match="different input or with different settings"):
+        cpu_cli.run_store(src, out, _settings(), reconstructor_factory=_FakeReconstructor, resume=True)
+
+
+def test_staged_run_drains_the_stager_when_a_loader_fails():
+    """``_run_staged`` with a loader that raises mid-run: the exception propagates, nothing is left
+    in flight (``drain`` ran, no worker thread is still filling a slot), finished units stay stored."""
+    import threading
+
+    from shrimpy_amd.pipeline import run_sharded
+
+    class Stager:
+        depth = 2
+
+        def __init__(self):
+            self.events, self.slots = [], [np.zeros(4, np.float32) for _ in range(2)]
+
+        def host_in(self, slot):
+            return self.slots[slot]
+
+        def stage_in(self, slot, data):
+            self.events.append(("in", slot))
+            return slot
+
+        def acquire(self, slot):
+            return self.slots[slot].copy()
+
+        def release(self, slot):
+            pass
+
+        def stage_out(self, slot, result):
+            self.slots[slot] = np.asarray(result)
+
+        def collect(self, slot):
+            return self.slots[slot]
+
+        def drain(self):
+            self.events.append("drain")
+
+    for fail_in in ("load", "process", "store"):
+        st, stored = Stager(), []
+
+        def load(u, out=None):
+            if fail_in == "load" and u == 3:
+                raise OSError("chunk vanished")
+            out[:] = u
+            return out
+
+        def process(v):
+            if fail_in == "process" and int(v[0]) == 3:
+                raise RuntimeError("kernel failed")
+            return v + 100
+
+        def store(u, vol):
+            if fail_in == "store" and u == 3:
+                raise OSError("disk full")
+            stored.append((u, float(vol[0])))
+
+        before = threading.active_count()
+        with pytest.raises((OSError, RuntimeError)):
+            run_sharded(list(range(6)), load, process, store, stager=st)
+        assert st.events[-1] == "drain"
+        assert threading.active_count() == before
+        assert stored == [(0, 100.0), (1, 101.0), (2, 102.0)]
+
+
+# ------------------------------------------------------------------ channels, plates, backends
+
+
+def test_register_warps_only_the_source_channels(tmp_path, cpu_cli):
+    """``source_channel_names`` / ``target_channel_name`` are honoured: the named sources go through
+    the registration, every other channel (the target) through the same pipeline without it."""
+    import click
+
+    from shrimpy_amd.settings import ReconstructSettings, RegisterSettings
+
+    src = _make_plate(tmp_path / "raw.zarr", "0.4")
+    seen = []
+
+    class Rec:
+        def __init__(self, raw_shape, settings, device):
+            self.output_shape = tuple(raw_shape)
+            self.warps = settings.registration is not None
+
+        def __call__(self, raw):
+            import torch
+
+            seen.append(self.warps)
+            return torch.as_tensor(np.asarray(raw, dtype=np.float32) + (1000.0 if self.warps else 0.0))
+
+    eye = np.eye(4).tolist()
+    s = ReconstructSettings(registration=RegisterSettings(
+        affine_transform_zyx=eye, source_channel_names=[CHANNELS[1]], target_channel_name=CHANNELS[0]))
+    cpu_cli.run_store(src, tmp_path / "o.zarr", s, reconstructor_factory=Rec)
+    got = _read_all(tmp_path / "o.zarr")
+    for p, key in enumerate(KEYS):
+        np.testing.assert_array_equal(got[key][:, 0], _encoded(p)[:, 0].astype(np.float32))           # target: as is
+        np.testing.assert_array_equal(got[key][:, 1], _encoded(p)[:, 1].astype(np.float32) + 1000.0)  # source: warped
+    assert sum(seen) == len(seen) // 2
+
+    for bad, msg in [(dict(source_channel_names=["nope"]), "not in the store"),
+                     (dict(source_channel_names=[CHANNELS[0]], target_channel_name=CHANNELS[0]), "also listed"),
+                     (dict(target_channel_name=CHANNELS[0]), "no source_channel_names")]:
+        s = ReconstructSettings(registration=RegisterSettings(affine_transform_zyx=eye, **bad))
+        with pytest.raises(click.ClickException, match=msg):
+            cpu_cli.run_store(src, tmp_path / "bad.zarr", s, reconstructor_factory=Rec)
+        assert not (tmp_path / "bad.zarr").exists()
+    # a changed output shape cannot be mixed with unwarped channels
+    s = ReconstructSettings(registration=RegisterSettings(
+        affine_transform_zyx=eye, source_channel_names=[CHANNELS[1]], output_shape_zyx=(4, 4, 4)))
+
+    class Reshaping(Rec):
+        def __init__(self, raw_shape, settings, device):
+            super().__init__(raw_shape, settings, device)
+            if settings.registration is not None:
+                self.output_shape = (4, 4, 4)
+
+    with pytest.raises(click.ClickException, match="output_shape_zyx"):
+        cpu_cli.run_store(src, tmp_path / "bad.zarr", s, reconstructor_factory=Reshaping)
+    with pytest.raises(ValueError, match="keep_overhang"):
+        RegisterSettings(affine_transform_zyx=eye, keep_overhang=True)
+
+
+def test_heterogeneous_plates_are_refused_before_anything_is_written(tmp_path, cpu_cli):
+    import click
+
+    path = tmp_path / "mixed.zarr"
+    with open_ome_zarr(path, layout="hcs", mode="w", channel_names=["BF"], prefer_iohub=False) as plate:
+        plate.create_position("A", "1", "0").create_zeros("0", shape=(1, 1, 8, 4, 6), dtype="uint16")
+        plate.create_position("A", "2", "0").create_zeros("0", shape=(1, 1, 8, 4, 7), dtype="uint16")
+        plate.create_position("A", "3", "0").create_zeros("0", shape=(1, 1, 8, 4, 6), dtype="float32")
+    with pytest.raises(click.ClickException, match="differ from A/1/0"):
+        cpu_cli.run_store(path, tmp_path / "o.zarr", _settings(), reconstructor_factory=_FakeReconstructor)
+    assert not (tmp_path / "o.zarr").exists()
+    res = cpu_cli.run_store(path, tmp_path / "o.zarr", _settings(), positions=("A/1/0",),
+                            reconstructor_factory=_FakeReconstructor)
+    assert res["units"] == 1
+
+
+def test_cli_reads_the_engine_format_and_writes_it_back(tmp_path, cpu_cli):
+    """Input in the acquisition's own layout (NGFF 0.5, sharded blosc-zstd, position ``A/1/fov0``,
+    ``mantis_engine.py:474-481``) -> ``run_store`` -> output compressed the same way."""
+    rng = np.random.default_rng(3)
+    src = tmp_path / "acq.ome.zarr"
+    vols = rng.integers(80, 600, (2, 1, 40, 12, 20)).astype(np.uint16)
+    with open_ome_zarr(src, layout="hcs", mode="w", channel_names=["BF"], version="0.5", prefer_iohub=False) as plate:
+        arr = plate.create_position("A", "1", "fov0").create_zeros(
+            "0", shape=vols.shape, dtype="uint16", chunks=(1, 1, 16, 12, 20), compress="blosc-zstd", shards="volume")
+        for t in range(2):
+            arr.write_volume(t, 0, vols[t, 0])
+    res = cpu_cli.run_store(src, tmp_path / "o.zarr", _settings(), zarr_version="0.5",
+                            reconstructor_factory=_FakeReconstructor, compression="blosc-zstd", io_backend="native")
+    assert res["units"] == 2
+    with open_ome_zarr(tmp_path / "o.zarr", prefer_iohub=False) as plate:
+        arr = plate["A/1/fov0"]["0"]
+        assert arr._codec.kind == "blosc" and arr._codec.params["cname"] == "zstd"
+        for t in range(2):
+            np.testing.assert_array_equal(arr.read_volume(t, 0), vols[t, 0, ::2].astype(np.float32) + 0.5)
+
+
+class _FakeIohub:
+    """A stand-in ``iohub`` package with the surface the reference uses (``replay_camera.py:176-268``,
+    ``tracking.py:1337-1367``, ``measure_psf.py:273-287``): ``open_ome_zarr(path, layout=, mode=
+    [, channel_names=, version=])``, ``positions()`` -> ``(key, Position)``, ``Position["0"]`` /
+    ``.data`` as an array with numpy indexing only (NO read_volume / write_volume),
+    ``.channel_names``, ``.zattrs``, ``create_position``, ``create_zeros(name, shape, dtype, chunks,
+    transform=[TransformationMeta])``.  Data lives in ``.npy`` files so that separate opens see it."""
+
+    class TransformationMeta:
+        def __init__(self, type, scale=None, translation=None):
+            self.type, self.scale = type, scale
+
+    class _Array:
+        def __init__(self, path):
+            self._path = path
+            self._a = np.load(path, mmap_mode="r+")
+            self.shape, self.dtype, self.chunks = self._a.shape, self._a.dtype, (1, 1) + self._a.shape[2:]
+
+        def __getitem__(self, key):
+            return np.array(self._a[key])
+
+        def __setitem__(self, key, value):
+            self._a[key] = value
+            self._a.flush()
+
+    class _Position:
+        def __init__(self, root, key):
+            self._dir = root / key
+            self._meta = self._dir / "meta.json"
+
+        @property
+        def _m(self):
+            return json.loads(self._meta.read_text())
+
+        @property
+        def channel_names(self):
+            return self._m["channel_names"]
+
+        @property
+        def zattrs(self):
+            return {"multiscales": [{"datasets": [{"coordinateTransformations": [
+                {"type": "scale", "scale": self._m["scale"]}]}]}]}
+
+        def __getitem__(self, name):
+            return _FakeIohub._Array(self._dir / f"{name}.npy")
+
+        @property
+        def data(self):
+            return self["0"]
+
+        def create_zeros(self, name, shape, dtype, chunks=None, transform=None):
+            np.save(self._dir / f"{name}.npy", np.zeros(shape, dtype))
+            m = self._m
+            m["scale"] = list(transform[0].scale) if transform else [1.0] * 5
+            self._meta.write_text(json.dumps(m))
+            return self[name]
+
+    class _Plate:
+        def __init__(self, path, mode, channel_names=None, version="0.4"):
+            from pathlib import Path
+
+            self.path, self.mode = Path(path), mode
+            if mode == "w":
+                if self.path.exists() and any(self.path.iterdir()):
+                    raise FileExistsError(str(path))
+                self.path.mkdir(parents=True, exist_ok=True)
+                (self.path / "plate.json").write_text(json.dumps(
+                    {"channel_names": list(channel_names or []), "version": version, "positions": []}))
+            self.opened_with = dict(mode=mode, channel_names=channel_names, version=version)
+
+        @property
+        def _m(self):
+            return json.loads((self.path / "plate.json").read_text())
+
+        def positions(self):
+            for key in self._m["positions"]:
+                yield key, _FakeIohub._Position(self.path, key)
+
+        def create_position(self, row, col, fov):
+            key = f"{row}/{col}/{fov}"
+            m = self._m
+            m["positions"].append(key)
+            (self.path / "plate.json").write_text(json.dumps(m))
+            (self.path / key).mkdir(parents=True)
+            (self.path / key / "meta.json").write_text(json.dumps(
+                {"channel_names": m["channel_names"], "scale": [1.0] * 5}))
+            return _FakeIohub._Position(self.path, key)
+
+        def close(self):
+            pass
+
+    opened = []
+
+    @classmethod
+    def install(cls, monkeypatch):
+        import sys
+        import types
+
+        cls.opened = []
+
+        def open_ome_zarr(store_path, layout="auto", mode="r", channel_names=None, version="0.4", **kw):
+            plate = cls._Plate(store_path, mode, channel_names, version)
+            cls.opened.append((str(store_path), layout, mode))
+            return plate
+
+        iohub = types.ModuleType("iohub")
+        iohub.open_ome_zarr = open_ome_zarr
+        ngff = types.ModuleType("iohub.ngff")
+        ngff.open_ome_zarr = open_ome_zarr
+        models = types.ModuleType("iohub.ngff.models")
+        models.TransformationMeta = cls.TransformationMeta
+        ngff.models = models
+        iohub.ngff = ngff
+        for name, mod in (("iohub", iohub), ("iohub.ngff", ngff), ("iohub.ngff.models", models)):
+            monkeypatch.setitem(sys.modules, name, mod)
+
+
+def test_run_store_works_through_the_iohub_surface(tmp_path, cpu_cli, monkeypatch):
+    """With ``iohub`` importable (a stand-in with the reference's call surface and NOTHING of this
+    package's own array interface), ``open_ome_zarr(prefer_iohub=True)`` delegates and
+    ``run_store(io_backend="iohub")`` reads, reconstructs and writes through it."""
+    from shrimpy_amd.io.omezarr import Plate, as_volume_array
+
+    _FakeIohub.install(monkeypatch)
+    rng = np.random.default_rng(9)
+    src = tmp_path / "in.store"
+    plate = open_ome_zarr(src, layout="hcs", mode="w", channel_names=["BF", "GFP"], version="0.5")
+    assert not isinstance(plate, Plate) and _FakeIohub.opened[-1] == (str(src), "hcs", "w")
+    vols = {}
+    for key in ("A/1/fov0", "A/2/fov0"):
+        pos = plate.create_position(*key.split("/"))
+        arr = pos.create_zeros("0", shape=(2, 2, 8, 4, 6), dtype="uint16",
+                               transform=[_FakeIohub.TransformationMeta(type="scale", scale=[1, 1, 0.15, 0.11, 0.11])])
+        assert not hasattr(arr, "read_volume")
+        vols[key] = rng.integers(80, 600, (2, 2, 8, 4, 6)).astype(np.uint16)
+        arr[...] = vols[key]
+        np.testing.assert_array_equal(as_volume_array(arr).read_volume(1, 0), vols[key][1, 0])
+    res = cpu_cli.run_store(src, tmp_path / "out.store", _settings(), zarr_version="0.5",
+                            reconstructor_factory=_FakeReconstructor, io_backend="iohub")
+    assert res["units"] == 8
+    assert (str(tmp_path / "out.store"), "hcs", "w") in _FakeIohub.opened
+    out = open_ome_zarr(tmp_path / "out.store", layout="hcs", mode="r")
+    for key, pos in out.positions():
+        assert pos.channel_names == ["BF", "GFP"]
+        assert pos.zattrs["multiscales"][0]["datasets"][0]["coordinateTransformations"][0]["scale"][2:] == [0.15, 0.11, 0.11]
+        np.testing.assert_array_equal(pos.data[...], vols[key][:, :, ::2].astype(np.float32) + 0.5)
+    # resume goes through the same surface
+    res = cpu_cli.run_store(src, tmp_path / "out.store", _settings(), zarr_version="0.5",
+                            reconstructor_factory=_FakeReconstructor, io_backend="iohub", resume=True)
+    assert res["units_skipped"] == 8
+
+
+def test_auto_backend_falls_back_to_iohub_only_for_codecs_the_native_reader_lacks(tmp_path, cpu_cli, monkeypatch):
+    import click
+
+    src = _make_plate(tmp_path / "raw.zarr", "0.4")
+    res = cpu_cli.run_store(src, tmp_path / "o1.zarr", _settings(), reconstructor_factory=_FakeReconstructor)
+    assert res["units"] == res["units_total"]                   # native: iohub never needed
+    meta = src / "0" / "0" / "000" / "0" / ".zarray"
+    m = json.loads(meta.read_text())
+    m["compressor"] = {"id": "lzma"}
+    meta.write_text(json.dumps(m))
+    with pytest.raises(click.ClickException, match="install iohub"):
+        cpu_cli.run_store(src, tmp_path / "o2.zarr", _settings(), reconstructor_factory=_FakeReconstructor)
+    _FakeIohub.install(monkeypatch)
+    with pytest.raises(FileNotFoundError):    # auto now reaches iohub (the stand-in cannot parse a real store)
+        cpu_cli.run_store(src, tmp_path / "o3.zarr", _settings(), reconstructor_factory=_FakeReconstructor)
+    assert _FakeIohub.opened and _FakeIohub.opened[-1][0] == str(src)
 
 
 @pytest.mark.gpu
