@@ -306,8 +306,9 @@ def _run_staged(mine, load, process, store, stager) -> None:
     finally:
         # whatever happened: no thread is left filling a slot, no copy is left in flight on the
         # up / down streams, before the caller sees the exception (or the result)
+        # (a queued load is dropped; a queued write belongs to a finished unit and is completed)
         for fut in (nxt, pending_store):
-            if fut is not None and not fut.cancel():
+            if fut is not None and not (fut is nxt and fut.cancel()):
                 try:
                     fut.result()
                 except Exception:  # noqa: BLE001 -- the first failure is the one that propagates
