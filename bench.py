@@ -10,21 +10,31 @@ resident in HBM.  Workload at N = 1: BASELINE.json configs[1], "2048x2048x512 f3
 (Z_scan=2048, Y_tilt=512, X=2048) (SURVEY.md section 8 preamble).  ``value`` = input voxels / s
 over all ranks.
 
+``--workload config4 | config5`` run the plate / time-lapse configurations at their real per-unit
+size and print the same schema: ``value`` is again the kernels-resident rate of one unit per GPU
+(config 4: uint16 raw (2048, 256, 2048), deskew + RL; config 5: uint16 raw (2048, 200, 2048),
+deskew -> affine registration -> RL), and ``config.store_to_store`` holds the rate of the same units
+going OME-Zarr store -> ``cli.run_store`` (pinned staging, copy streams) -> OME-Zarr store.
+
 Extra objects on the JSON line:
   roofline     -- the dominant kernel (one fused RL iteration per launch; with --rl two-launch the
                   ratio / update launch): algorithmic 12 B/voxel (x, y in, x out; resp. in + aux +
                   out) x N_o voxels / its average launch duration, measured with HIP events on
-                  the launch stream inside the timed steps, vs the 8 TB/s HBM peak.  SURVEY 8(d)
-                  prices an RL iteration at 24 B/voxel (two kernels); that accounting of the same
-                  launch is added as roofline.survey_8d_iteration.
+                  the launch stream inside the timed steps, vs the 8 TB/s HBM peak.
+                  ``traffic`` = HBM bytes per launch from the PMC counters (profiles/traffic.json),
+                  reported only while that record's kernel-source fingerprint equals this
+                  checkout's (``_lib.kernel_source_sha16``) -- null otherwise.
   cpu_baseline -- oracle/cpu_ref.py (scipy.ndimage port of the same path) timed on the host
-                  cores of this box on a bounded sample; rank 0 at N = 1 only.
+                  cores of this box on a bounded sample; rank 0 at N = 1 only (BASELINE.md section 4:
+                  all host cores on independent positions, plus a single-core leg labelled
+                  extrapolated).
 """
 
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -43,12 +53,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 
 WORKLOADS = {
-    # name: raw (Z_scan, Y_tilt, X)
-    "config2": (2048, 512, 2048),   # BASELINE configs[1]: 2048x2048x512 f32, the headline
-    "config4": (2048, 256, 2048),   # one position of the 96-position plate
-    "config1": (256, 64, 256),      # the CPU-runnable plumbing case
-    "small": (512, 128, 512),
+    # name: (config id for the seeds, raw (Z_scan, Y_tilt, X))
+    "config2": (2, (2048, 512, 2048)),   # BASELINE configs[1]: 2048x2048x512 f32, the headline
+    "config4": (4, (2048, 256, 2048)),   # one position of the 96-position plate (uint16 counts)
+    "config5": (5, (2048, 200, 2048)),   # one (t, p) unit of the time-lapse: deskew -> register -> RL
+    "config1": (1, (256, 64, 256)),      # the CPU-runnable plumbing case
+    "small": (0, (512, 128, 512)),
 }
+PLATE_WORKLOADS = ("config4", "config5")
 DESKEW = dict(ls_angle_deg=30.0, px_to_scan_ratio=0.755, keep_overhang=False, average_n_slices=3)
 PSF_SHAPE, PSF_SIGMA = (9, 7, 7), (2.0, 1.2, 1.2)
 RL_ITERS = 20
@@ -66,8 +78,6 @@ def gaussian_factors():
 
 def rotated_psf():
     """Secondary, non-separable PSF: the Gaussian rotated 30 deg about Y."""
-    import math
-
     import numpy as np
 
     cz, cy, cx = (n // 2 for n in PSF_SHAPE)
@@ -77,6 +87,18 @@ def rotated_psf():
     zr, xr = math.cos(a) * z + math.sin(a) * x, -math.sin(a) * z + math.cos(a) * x
     g = np.exp(-0.5 * ((zr / PSF_SIGMA[0]) ** 2 + (y / PSF_SIGMA[1]) ** 2 + (xr / PSF_SIGMA[2]) ** 2))
     return (g / g.sum()).astype(np.float32)
+
+
+def registration_matrix():
+    """rotation 2 deg about Z, scale (1, .98, 1.02), translation (3.5, -12.25, 20.75)."""
+    import numpy as np
+
+    th = np.deg2rad(2.0)
+    rot = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]])
+    m = np.eye(4)
+    m[:3, :3] = rot @ np.diag([1.0, 0.98, 1.02])
+    m[:3, 3] = [3.5, -12.25, 20.75]
+    return m
 
 
 def synthetic_raw(shape, seed, device):
@@ -101,16 +123,15 @@ def synthetic_raw(shape, seed, device):
 
 
 def _cpu_worker(args):
-    """One independent position through the oracle (runs in a spawned process, no GPU)."""
+    """One independent position through the oracle (runs in a spawned process, no GPU): the bead
+    scene of SURVEY 8(d) with that position's seed, then deskew + RL, timed."""
     shape, seed = args
     os.environ["OMP_NUM_THREADS"] = "1"
-    import numpy as np
 
     from oracle import cpu_ref as o
 
-    psf, factors = o.gaussian_psf(PSF_SHAPE, PSF_SIGMA)
-    rng = np.random.default_rng(seed)
-    raw = rng.poisson(100.0, size=shape).astype(np.float32)
+    _, factors = o.gaussian_psf(PSF_SHAPE, PSF_SIGMA)
+    raw = o.bead_scene(shape, seed, psf_factors=factors)
     t0 = time.perf_counter()
     d = o.deskew(raw, DESKEW["ls_angle_deg"], DESKEW["px_to_scan_ratio"], DESKEW["keep_overhang"],
                  DESKEW["average_n_slices"])
@@ -119,86 +140,157 @@ def _cpu_worker(args):
     return dt, float(x.mean())
 
 
-def cpu_baseline(sample_shape=(640, 128, 640), max_procs=16):
-    """Oracle (kind "port": scipy.ndimage deskew + separable correlate1d RL) on the host cores."""
-    import multiprocessing as mp
+def host_cores() -> int:
+    """Cores this process may use: the affinity mask, cut down to a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    procs = max(1, min(max_procs, avail))
+
+def cpu_baseline(config_id=2, all_core_shape=(640, 128, 640), single_shape=(512, 128, 512), max_procs=None):
+    """Oracle (kind "port": scipy.ndimage deskew + separable correlate1d RL) on the host cores,
+    per BASELINE.md section 4: (ii) every host core runs one independent position (aggregate rate,
+    core count stated); (i) one core runs the reduced (512, 128, 512) volume, three samples, median,
+    scaled linearly in voxels to config 2 and labelled extrapolated."""
+    import multiprocessing as mp
+    import statistics
+
+    cores = host_cores()
+    procs = cores if max_procs is None else max(1, min(cores, int(max_procs)))
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with ctx.Pool(procs) as pool:
-        res = pool.map(_cpu_worker, [(sample_shape, 9000 + i) for i in range(procs)])
+        res = pool.map(_cpu_worker, [(all_core_shape, 1000 * config_id + 7 * i) for i in range(procs)])
     wall = time.perf_counter() - t0
     busy = max(r[0] for r in res)
-    voxels = procs * sample_shape[0] * sample_shape[1] * sample_shape[2]
+    voxels = procs * all_core_shape[0] * all_core_shape[1] * all_core_shape[2]
+    with ctx.Pool(min(3, cores)) as pool:   # three single-core samples side by side on an idle machine
+        single = pool.map(_cpu_worker, [(single_shape, 1000 * config_id + 7 * i) for i in range(3)])
+    s_med = statistics.median(r[0] for r in single)
+    n_single = single_shape[0] * single_shape[1] * single_shape[2]
+    n_cfg2 = 2048 * 512 * 2048
+    shp = "x".join(str(v) for v in all_core_shape)
     return {
         "value": voxels / busy,
         "unit": "voxels/s",
         "cores": procs,
         "kind": "port",
-        "sample": (f"{procs} independent raw {sample_shape[0]}x{sample_shape[1]}x{sample_shape[2]} f32 "
-                   f"positions, one per process (scipy.ndimage affine_transform deskew avg3 + "
-                   f"{RL_ITERS}-iter RL as separable correlate1d passes), slowest worker "
-                   f"{busy:.1f}s, pool wall {wall:.1f}s"),
+        "sample": (f"{procs} independent raw {shp} f32 bead-scene positions (seeds 1000*{config_id}+7*p), one per "
+                   f"process on every host core (scipy.ndimage affine_transform deskew avg3 + {RL_ITERS}-iter RL "
+                   f"as separable correlate1d passes), slowest worker {busy:.1f}s, pool wall {wall:.1f}s"),
+        "single_core": {
+            "value": n_single / s_med,
+            "unit": "voxels/s",
+            "cores": 1,
+            "sample": f"raw {'x'.join(str(v) for v in single_shape)}, median of 3: {s_med:.1f}s",
+            "config2_seconds_extrapolated": s_med * n_cfg2 / n_single,
+            "label": "extrapolated (linear in voxels)",
+        },
     }
 
 
-# ------------------------------------------------------------------------------------ GPU leg
+# ------------------------------------------------------------------------------------ helpers
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
-    ap.add_argument("--psf", default="separable", choices=["separable", "dense", "rotated"],
-                    help="separable = the declared default Gaussian (rank-1 path); dense = the "
-                         "rotated non-separable PSF through the 441-tap dense stencil; rotated = the "
-                         "same PSF with the plan free to split it (it separates along y: a (z, x) "
-                         "stencil plus a y pass per correlation)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--rl", default="fused", choices=["fused", "two-launch"],
-                    help="separable PSF: one launch per RL iteration (default) or the ratio / update pair")
-    args = ap.parse_args()
+def pmc_traffic(key, workload, kernel_symbol):
+    """HBM bytes per launch from the committed PMC record -- only if that record was taken from THIS
+    build of the kernels (same source fingerprint, same kernel symbol, same workload)."""
+    from shrimpy_amd._lib import kernel_source_sha16
+
+    tfile = ROOT / "profiles" / "traffic.json"
+    if not tfile.exists():
+        return None, "no profiles/traffic.json"
+    try:
+        rec = json.loads(tfile.read_text()).get(key, {})
+    except Exception as exc:  # noqa: BLE001
+        return None, f"unreadable traffic.json: {exc}"
+    if rec.get("workload") != workload:
+        return None, f"record is for workload {rec.get('workload')!r}"
+    have = kernel_source_sha16()
+    if rec.get("source_sha16") != have:
+        return None, f"stale: record {rec.get('source_sha16')} != build {have}"
+    if rec.get("kernel") and kernel_symbol and not kernel_symbol.startswith(rec["kernel"].split("(")[0][:24]):
+        return None, f"record is for kernel {rec.get('kernel')!r}"
+    return rec.get("hbm_bytes_per_launch"), f"{rec.get('source')} @ {rec.get('git_head', '?')}"
+
+
+def dist_setup(args):
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-
-    # CPU baseline first (rank 0, N = 1 only), in spawned processes that never touch the GPU.
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
-
-    import torch
-    import torch.distributed as dist
-
-    from shrimpy_amd.deconvolve import RichardsonLucyPlan
-    from shrimpy_amd.deskew import fast_deskew_zyx, get_deskewed_data_shape
-
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
     n_dev = torch.cuda.device_count()
     shared = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) > n_dev   # rehearsal: ranks share a card
     torch.cuda.set_device(local_rank % n_dev)
     device = torch.device("cuda", local_rank % n_dev)
+    backend = None
     if world > 1:
         if shared:   # RCCL refuses duplicate devices; gloo carries the barrier / max (no data-path collective)
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+        backend = dist.get_backend()
+    return rank, world, device, shared, backend
 
-    raw_shape = WORKLOADS[args.workload]
+
+def timed_steps(step, args, world, shared, device):
+    """W untimed warm-ups, then exactly K steps between barrier + synchronize, max over ranks."""
+    import torch
+    import torch.distributed as dist
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if (world > 1 and shared) else device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), events
+
+
+def parallelism_note(world, shared):
+    return (f"positions x{world} (independent units, no data-path collective)"
+            + (" -- REHEARSAL: ranks share one GPU, gloo barrier" if (world > 1 and shared) else ""))
+
+
+# ------------------------------------------------------------------------------------ config 2 (headline)
+
+
+def run_resident(args, rank, world, device, shared, backend, cpu):
+    import torch
+
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+    from shrimpy_amd.deskew import deskew_with_matrix, fast_deskew_zyx, get_deskewed_data_shape
+    from shrimpy_amd.geometry import deskew_geometry
+
+    config_id, raw_shape = WORKLOADS[args.workload]
     out_shape, _ = get_deskewed_data_shape(raw_shape, **DESKEW)
     n_in = raw_shape[0] * raw_shape[1] * raw_shape[2]
     n_o = out_shape[0] * out_shape[1] * out_shape[2]
 
     # unit = (position, timepoint); rank r owns position r (weak scaling). Seeds per SURVEY 8(d).
-    config_id = {"config1": 1, "config2": 2, "config4": 4, "small": 0}[args.workload]
     raw = synthetic_raw(raw_shape, seed=1000 * config_id + 7 * rank, device=device)
     if args.psf == "separable":
         plan = RichardsonLucyPlan(out_shape, None, device, psf_factors=gaussian_factors(),
@@ -210,10 +302,6 @@ def main():
     # the deskew kernel writes straight into the RL kernels' padded, line-aligned input volume
     deskewed = plan.new_padded_input()
     estimate = torch.empty(out_shape, dtype=torch.float32, device=device)
-
-    from shrimpy_amd.deskew import deskew_with_matrix
-    from shrimpy_amd.geometry import deskew_geometry
-
     geo = deskew_geometry(raw_shape, **DESKEW)
 
     def step(ev=None):
@@ -232,139 +320,261 @@ def main():
         padded = deskew_with_matrix(raw, geo.matrix_3x4, geo.pre_average_shape, 3, out=plan.new_padded_input())
         assert torch.equal(fast_deskew_zyx(raw_data=raw, **DESKEW), padded.view)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(events[i])
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if (world > 1 and shared) else device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
+    elapsed, events = timed_steps(step, args, world, shared, device)
     deskew_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
     rl_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps          # incl. x0 = y copy
     rl_kernels_ms = sum(e[3].elapsed_time(e[4]) for e in events) / args.steps  # the 2*iters launches
     assert torch.isfinite(estimate).all(), "non-finite RL output"
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        fused = bool(getattr(plan, "fused", False))
-        ysep = plan.path.startswith("y-separable")
-        launches = RL_ITERS if fused else (4 * RL_ITERS if plan.path.endswith("(4 launches)") else 2 * RL_ITERS)
-        launch_s = rl_kernels_ms * 1e-3 / launches  # HIP events right around the launches, / count
-        # fused iteration: x, y in, x_new out; ratio / update launch: in + aux + out
-        bytes_per_launch = 12.0 * n_o
-        achieved = bytes_per_launch / launch_s / 1e9
-        # deskew 4 N_in + 4 N_o; RL 24 B/voxel/iteration (the two-kernel accounting:
-        # x, y -> ratio; ratio, x -> x) + 8 N_o init/copy.  The fused iteration's own minimum is
-        # 12 B/voxel/iteration; both are reported.
-        total_bytes = 4.0 * n_in + 4.0 * n_o + 24.0 * RL_ITERS * n_o + 8.0 * n_o
-        min_bytes = 4.0 * n_in + 4.0 * n_o + 12.0 * launches * n_o
-        ms_per_step = elapsed / args.steps * 1e3
-        traffic = None
-        tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
-            try:
-                rec = json.loads(tfile.read_text())
-                key = "fused" if fused else ("two-launch" if args.psf == "separable" else args.psf)
-                rec = rec.get(key, {})
-                if rec.get("workload") == args.workload:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        line = {
-            "metric": METRIC,
-            "value": world * args.steps * n_in / elapsed,
-            "unit": "voxels/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": (f"{args.workload}: raw (Z_scan,Y_tilt,X)={raw_shape} f32 -> deskew 30deg "
-                             f"r=0.755 no-overhang avg3 -> {tuple(out_shape)} -> {RL_ITERS}-iter RL, "
-                             f"{args.psf} 9x7x7 PSF; one position per GPU"),
-                "raw_shape": list(raw_shape),
-                "deskewed_shape": list(out_shape),
-                "psf": args.psf,
-                "rl_path": plan.path,
-                "rl_iterations": RL_ITERS,
-                "deskew_ms": deskew_ms,
-                "rl_ms": rl_ms,
-                "rl_kernels_ms": rl_kernels_ms,
-                "rl_launches": launches,
-                "algorithmic_bytes_per_step": total_bytes,
-                "whole_step_hbm_frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "launched_kernels_min_bytes_per_step": min_bytes,
-                "launched_kernels_hbm_frac": min_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "parallelism": f"positions x{world} (independent units, no data-path collective)"
-                               + (" -- REHEARSAL: ranks share one GPU, gloo barrier" if (world > 1 and shared) else ""),
-            },
-            "roofline": (
-                {
-                    "kernel": ("rl_fused_sep_kernel<9,7> (one RL iteration per launch)" if fused
-                               else "correlate_sep_kernel<9,7,7> (RL ratio / update launch)"),
-                    "bound": "hbm",
-                    "achieved": achieved,
-                    "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic,
-                    "launch_ms": launch_s * 1e3,
-                    "algorithmic_bytes_per_launch": bytes_per_launch,
-                    # one launch = one RL iteration, which SURVEY 8(d) prices at 24 B/voxel (two
-                    # kernels, ratio through HBM); `achieved` above uses the fused kernel's own 12
-                    **({"survey_8d_iteration": {"bytes": 24.0 * n_o,
-                                                "achieved": 24.0 * n_o / launch_s / 1e9,
-                                                "frac": 24.0 * n_o / launch_s / 1e9 / HBM_PEAK_GBS}}
-                       if fused else {}),
-                } if args.psf == "separable" else ({
-                    # one launch per correlation: y pass (7 taps) + (z, x) stencil (63 taps) on the
-                    # staged plane, in + aux + out = 12 B/voxel
-                    "kernel": "correlate_dense_kernel<9,7,*,2> (ky (x) kzx, RL ratio / update launch)",
-                    "bound": "hbm",
-                    "achieved": achieved,
-                    "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic,
-                    "launch_ms": launch_s * 1e3,
-                    "algorithmic_bytes_per_launch": bytes_per_launch,
-                } if ysep else {
-                    # a 441-tap dense stencil is fp32-VALU-bound, not HBM-bound
-                    "kernel": "correlate_dense_kernel<9,7> (dense RL ratio / update launch)",
-                    "bound": "valu-fp32",
-                    "achieved": 2.0 * 441 * n_o / launch_s / 1e12,
-                    "peak": FP32_VALU_PEAK_TFLOPS,
-                    "unit": "TFLOP/s",
-                    "frac": 2.0 * 441 * n_o / launch_s / 1e12 / FP32_VALU_PEAK_TFLOPS,
-                    "traffic": traffic,
-                    "launch_ms": launch_s * 1e3,
-                    "algorithmic_flop_per_launch": 2.0 * 441 * n_o,
-                    "hbm_algorithmic_GBps": achieved,
-                })
-            ),
+    fused = bool(getattr(plan, "fused", False))
+    ysep = plan.path.startswith("y-separable")
+    launches = RL_ITERS if fused else (4 * RL_ITERS if plan.path.endswith("(4 launches)") else 2 * RL_ITERS)
+    launch_s = rl_kernels_ms * 1e-3 / launches  # HIP events right around the launches, / count
+    # fused iteration: x, y in, x_new out; ratio / update launch: in + aux + out
+    bytes_per_launch = 12.0 * n_o
+    achieved = bytes_per_launch / launch_s / 1e9
+    # deskew 4 N_in + 4 N_o; RL 24 B/voxel/iteration (the two-kernel accounting:
+    # x, y -> ratio; ratio, x -> x) + 8 N_o init/copy.  The fused iteration's own minimum is
+    # 12 B/voxel/iteration; both are reported, the second is what the launched kernels can reach.
+    survey_bytes = 4.0 * n_in + 4.0 * n_o + 24.0 * RL_ITERS * n_o + 8.0 * n_o
+    min_bytes = 4.0 * n_in + 4.0 * n_o + 12.0 * launches * n_o
+    ms_per_step = elapsed / args.steps * 1e3
+    if args.psf == "separable":
+        kernel = ("rl_fused_sep_kernel<9,7> (one RL iteration per launch)" if fused
+                  else "correlate_sep_kernel<9,7,7> (RL ratio / update launch)")
+        symbol = "rl_fused_sep_kernel" if fused else "correlate_sep_kernel"
+    elif ysep:
+        kernel, symbol = "correlate_dense_kernel<9,7,*,2> (ky (x) kzx, RL ratio / update launch)", "correlate_dense_kernel"
+    else:
+        kernel, symbol = "correlate_dense_kernel<9,7> (dense RL ratio / update launch)", "correlate_dense_kernel"
+    key = "fused" if fused else ("two-launch" if args.psf == "separable" else args.psf)
+    traffic, traffic_note = pmc_traffic(key, args.workload, symbol)
+    if args.psf == "separable" or ysep:
+        roofline = {
+            "kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_record": traffic_note,
+            "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
         }
-        if cpu is not None:
-            line["cpu_baseline"] = cpu
+    else:
+        # a 441-tap dense stencil is fp32-VALU-bound, not HBM-bound
+        flop = 2.0 * 441 * n_o
+        roofline = {
+            "kernel": kernel, "bound": "valu-fp32", "achieved": flop / launch_s / 1e12,
+            "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / launch_s / 1e12 / FP32_VALU_PEAK_TFLOPS,
+            "traffic": traffic, "traffic_record": traffic_note, "launch_ms": launch_s * 1e3,
+            "algorithmic_flop_per_launch": flop, "hbm_algorithmic_GBps": achieved,
+        }
+    line = {
+        "metric": METRIC,
+        "value": world * args.steps * n_in / elapsed,
+        "unit": "voxels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"{args.workload}: raw (Z_scan,Y_tilt,X)={raw_shape} f32 -> deskew 30deg "
+                         f"r=0.755 no-overhang avg3 -> {tuple(out_shape)} -> {RL_ITERS}-iter RL, "
+                         f"{args.psf} 9x7x7 PSF; one position per GPU"),
+            "raw_shape": list(raw_shape),
+            "deskewed_shape": list(out_shape),
+            "psf": args.psf,
+            "rl_path": plan.path,
+            "rl_iterations": RL_ITERS,
+            "deskew_ms": deskew_ms,
+            "rl_ms": rl_ms,
+            "rl_kernels_ms": rl_kernels_ms,
+            "rl_launches": launches,
+            "launched_kernels_min_bytes_per_step": min_bytes,
+            "launched_kernels_hbm_frac": min_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # SURVEY 8(d) prices the step as if every RL iteration were two kernels (24 B/voxel);
+            # the fused launch no longer moves those bytes -- kept for comparison with the survey's
+            # 50 ms floor only, it is NOT an achieved-bandwidth figure
+            "survey_8d_two_kernel_accounting": {
+                "bytes_per_step": survey_bytes,
+                "frac_if_those_bytes_moved": survey_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "parallelism": parallelism_note(world, shared),
+            "collective_backend": backend,
+        },
+        "roofline": roofline,
+    }
+    if cpu is not None:
+        line["cpu_baseline"] = cpu
+    return line
+
+
+# ------------------------------------------------------------------------------------ configs 4 and 5
+
+
+def plate_settings(workload):
+    from shrimpy_amd.settings import DeconvolveSettings, DeskewSettings, ReconstructSettings, RegisterSettings
+
+    return ReconstructSettings(
+        deskew=DeskewSettings(pixel_size_um=0.1133, scan_step_um=0.15, ls_angle_deg=30.0, keep_overhang=False,
+                              average_n_slices=3),
+        registration=(RegisterSettings(affine_transform_zyx=registration_matrix().tolist())
+                      if workload == "config5" else None),
+        deconvolution=DeconvolveSettings(iterations=RL_ITERS))
+
+
+def run_plate(args, rank, world, device, shared, backend, cpu):
+    """Configs 4 / 5: (a) one unit per GPU with its uint16 stack resident in HBM through the
+    production pipeline object (``VolumeReconstructor``); (b) the same kind of units store to store."""
+    import shutil
+    import tempfile
+
+    import torch
+    import torch.distributed as dist
+
+    from shrimpy_amd import cli
+    from shrimpy_amd.io.omezarr import open_ome_zarr
+    from shrimpy_amd.pipeline import VolumeReconstructor
+
+    config_id, raw_shape = WORKLOADS[args.workload]
+    settings = plate_settings(args.workload)
+    rec = VolumeReconstructor(raw_shape, settings, device)
+    out_shape = rec.output_shape
+    n_in = raw_shape[0] * raw_shape[1] * raw_shape[2]
+    n_o = out_shape[0] * out_shape[1] * out_shape[2]
+    raw16 = synthetic_raw(raw_shape, seed=1000 * config_id + 7 * rank, device=device).to(torch.uint16)
+    result = {}
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        result["x"] = rec(raw16, rl_events=(ev[3], ev[4]) if ev else None)
+        if ev:
+            ev[2].record()
+
+    elapsed, events = timed_steps(step, args, world, shared, device)
+    step_ms = sum(e[0].elapsed_time(e[2]) for e in events) / args.steps
+    rl_kernels_ms = sum(e[3].elapsed_time(e[4]) for e in events) / args.steps
+    assert torch.isfinite(result["x"]).all(), "non-finite RL output"
+    launch_s = rl_kernels_ms * 1e-3 / RL_ITERS
+    del result
+
+    # ---- store to store: T x P units through cli.run_store (staged path) ----
+    store = None
+    if not args.no_store_leg:
+        n_t, n_p = (1, max(4, 2 * world)) if args.workload == "config4" else (3, max(2, world))
+        scratch = Path(tempfile.mkdtemp(prefix="lsr_bench_", dir=args.scratch))
+        root = [str(scratch)]
+        if world > 1:
+            dist.broadcast_object_list(root, src=0)
+        root = Path(root[0])
+        try:
+            keys = [f"A/{p + 1}/0" for p in range(n_p)]
+            if rank == 0:
+                with open_ome_zarr(root / "in.zarr", layout="hcs", mode="w", channel_names=["LS"],
+                                   prefer_iohub=False) as plate:
+                    for p, key in enumerate(keys):
+                        arr = plate.create_position(*key.split("/")).create_zeros(
+                            "0", shape=(n_t, 1) + tuple(raw_shape), dtype="uint16",
+                            scale=(1, 1, 0.15, 0.1133, 0.1133))
+                        for t in range(n_t):
+                            v = synthetic_raw(raw_shape, seed=1000 * config_id + 7 * p + t, device=device)
+                            arr.write_volume(t, 0, v.to(torch.uint16).cpu().numpy())
+                            del v
+            torch.cuda.empty_cache()
+            if world > 1:
+                dist.barrier()
+            res = cli.run_store(root / "in.zarr", root / "out.zarr", settings)
+            units = res["units_total"]
+            store = {
+                "positions": n_p, "timepoints": n_t, "units": units, "seconds": res["job_seconds"],
+                "s_per_unit": res["job_seconds"] / max(units, 1) * world,
+                "voxels_per_s": units * n_in / res["job_seconds"],
+                "io": (f"native OME-Zarr reader/writer, uncompressed chunks (1,1,32,ny,nx), scratch {root.parent}, "
+                       "input from the page cache; pinned staging slots + copy streams (cli.run_store)"),
+            }
+            if world > 1:
+                dist.barrier()
+        finally:
+            if rank == 0:
+                shutil.rmtree(root, ignore_errors=True)
+    if rank != 0:
+        return None
+    achieved = 12.0 * n_o / launch_s / 1e9
+    traffic, traffic_note = pmc_traffic("fused", args.workload, "rl_fused_sep_kernel")
+    chain = "deskew -> affine register (config-3 matrix) -> " if args.workload == "config5" else "deskew -> "
+    line = {
+        "metric": METRIC,
+        "value": world * args.steps * n_in / elapsed,
+        "unit": "voxels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"{args.workload}: one unit per GPU, raw (Z_scan,Y_tilt,X)={raw_shape} uint16 resident in HBM "
+                         f"-> {chain}{RL_ITERS}-iter RL (separable 9x7x7 PSF) -> {tuple(out_shape)} f32, through "
+                         "pipeline.VolumeReconstructor"),
+            "raw_shape": list(raw_shape),
+            "output_shape": list(out_shape),
+            "rl_iterations": RL_ITERS,
+            "kernels_resident": {"ms_per_unit": step_ms, "rl_kernels_ms": rl_kernels_ms,
+                                 "voxels_per_s_per_gpu": n_in / (step_ms * 1e-3)},
+            "store_to_store": store,
+            "parallelism": parallelism_note(world, shared),
+            "collective_backend": backend,
+        },
+        "roofline": {
+            "kernel": "rl_fused_sep_kernel<9,7> (one RL iteration per launch)", "bound": "hbm",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_record": traffic_note, "launch_ms": launch_s * 1e3,
+            "algorithmic_bytes_per_launch": 12.0 * n_o,
+        },
+    }
+    if cpu is not None:
+        line["cpu_baseline"] = cpu
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--psf", default="separable", choices=["separable", "dense", "rotated"],
+                    help="separable = the declared default Gaussian (rank-1 path); dense = the "
+                         "rotated non-separable PSF through the 441-tap dense stencil; rotated = the "
+                         "same PSF with the plan free to split it (it separates along y: a (z, x) "
+                         "stencil plus a y pass per correlation)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=None, help="cap the CPU baseline's worker count (default: all host cores)")
+    ap.add_argument("--rl", default="fused", choices=["fused", "two-launch"],
+                    help="separable PSF: one launch per RL iteration (default) or the ratio / update pair")
+    ap.add_argument("--no-store-leg", action="store_true", help="config4/5: skip the store-to-store leg")
+    ap.add_argument("--scratch", default=None, help="config4/5: directory for the temporary plates (default: TMPDIR)")
+    args = ap.parse_args()
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    # CPU baseline first (rank 0, N = 1 only), in spawned processes that never touch the GPU.
+    cpu = None
+    if world_env == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(config_id=WORKLOADS[args.workload][0], max_procs=args.cpu_procs)
+
+    rank, world, device, shared, backend = dist_setup(args)
+    runner = run_plate if args.workload in PLATE_WORKLOADS else run_resident
+    line = runner(args, rank, world, device, shared, backend, cpu)
+    if rank == 0:
         print(json.dumps(line))
     if world > 1:
+        import torch.distributed as dist
+
         dist.destroy_process_group()
 
 

@@ -112,6 +112,21 @@ SIGNATURES: dict[str, list] = {
 }
 
 
+def kernel_source_sha16() -> str:
+    """Fingerprint of the device code this checkout builds (every ``csrc/*.hip|*.hpp``, the Makefile
+    and the C-ABI header).  Measurements that belong to a particular build of the kernels -- the PMC
+    traffic record ``bench.py`` reports -- carry it, so a stale record is recognisable after the
+    kernels change (the GPU box has no ``.git`` to ask)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(list(CSRC_DIR.glob("*.hip")) + list(CSRC_DIR.glob("*.hpp")) + [CSRC_DIR / "Makefile", HEADER_PATH])
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 class LsrError(RuntimeError):
     """A liblsrecon call failed (argument error or HIP launch error)."""
 

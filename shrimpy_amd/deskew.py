@@ -67,7 +67,7 @@ def orient_volume(volume, orientation: str = "identity"):
         return volume
     out = volume.permute(*perm)
     dims = [i for i, r in enumerate(rev) if r]
-    return torch.flip(out, dims) if dims else out.contiguous()
+    return (torch.flip(out, dims) if dims else out).contiguous()
 
 
 def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices: int = 1, out=None,

@@ -113,8 +113,9 @@ class VolumeReconstructor:
                 else:
                     self._plan = RichardsonLucyPlan(self.output_shape, None, self.device, psf_factors=factors)
 
-    def __call__(self, raw):
-        """``raw``: (Z, Y, X) numpy array or tensor -> reconstructed float32 tensor on ``device``."""
+    def __call__(self, raw, rl_events=None):
+        """``raw``: (Z, Y, X) numpy array or tensor -> reconstructed float32 tensor on ``device``.
+        ``rl_events``: optional ``(start, end)`` events recorded right around the RL launches."""
         import torch
 
         from .deskew import deskew_with_matrix
@@ -159,7 +160,7 @@ class VolumeReconstructor:
                                              mode=r.mode, cval=r.cval)
         if self._plan is not None:
             dec = self.settings.deconvolution
-            vol = self._plan(vol, iterations=dec.iterations, eps=dec.eps)
+            vol = self._plan(vol, iterations=dec.iterations, eps=dec.eps, events=rl_events)
         return vol
 
 
