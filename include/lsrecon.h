@@ -104,6 +104,11 @@ int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* o
  * |M[0]| <= 1.5, Xi a multiple of 4, source box of a 32 x 128 tile within LDS), 0 = the general
  * gather kernel. Results are identical either way. */
 int lsr_affine_kernel_choice(int64_t Yi, int64_t Xi, const double M[12], int mode);
+/* The same question with all three kernels: 1 = csrc/affine_planar.hip (as above); 2 =
+ * csrc/affine_box.hip (constant mode, any matrix -- maps that couple z with the plane included --
+ * whose source box of an 8 x 16 x 64 output block fits in 150 KB of LDS, Xi a multiple of 4);
+ * 0 = the general gather kernel. Results are identical whichever runs. */
+int lsr_affine_path(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int mode);
 
 /* out[zo] = mean_k in[min(zo*avg_n + k, Zd-1)], k < avg_n, f32, ((d0+d1)+...)/avg_n. */
 int lsr_average_slices_f32(const float* in, int64_t Zd, int64_t Y, int64_t X, float* out,

@@ -206,6 +206,12 @@ bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, f
                           hipStream_t s);
 bool affine_planar_geometry(int64_t Yi, int64_t Xi, const double M[12], int* box_y, int* box_x,
                             int* slots, int64_t* lds_bytes);
+// affine_box.hip: any map whose per-block source box fits in LDS (z-coupled maps included),
+// constant mode; false = not applicable
+bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
+                       int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32, hipStream_t s);
+bool affine_box_geometry(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int* box_z, int* box_y,
+                         int* box_x, int64_t* lds_bytes);
 }  // namespace lsr
 
 extern "C" int lsr_affine_kernel_choice(int64_t Yi, int64_t Xi, const double M[12], int mode) {
@@ -216,6 +222,16 @@ extern "C" int lsr_affine_kernel_choice(int64_t Yi, int64_t Xi, const double M[1
                  lsr::affine_planar_geometry(Yi, Xi, M, &by, &bx, &sl, &lds)
              ? 1
              : 0;
+}
+
+extern "C" int lsr_affine_path(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int mode) {
+  if (M == nullptr) return 0;
+  if ((mode & ~LSR_MODE_F32_INTERP) != LSR_MODE_CONSTANT) return 0;
+  int a, b, c;
+  int64_t lds;
+  if (lsr::affine_planar_geometry(Yi, Xi, M, &a, &b, &c, &lds)) return 1;
+  if (lsr::affine_box_geometry(Zi, Yi, Xi, M, &a, &b, &c, &lds)) return 2;
+  return 0;
 }
 
 extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out,
@@ -243,7 +259,8 @@ extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t X
     LSR_REQUIRE(M[i] == M[i] && M[i] - M[i] == 0.0, LSR_E_ARG, "M[%d] is not finite", i);
 
   if (mode == LSR_MODE_CONSTANT && in != out &&
-      lsr::launch_affine_planar(in, Zi, Yi, Xi, out, Zo, Yo, Xo, M, cval, f32, lsr::as_stream(stream)))
+      (lsr::launch_affine_planar(in, Zi, Yi, Xi, out, Zo, Yo, Xo, M, cval, f32, lsr::as_stream(stream)) ||
+       lsr::launch_affine_box(in, Zi, Yi, Xi, out, Zo, Yo, Xo, M, cval, f32, lsr::as_stream(stream))))
     return lsr::launch_status("lsr_affine_f32");
 
   AffineArgs p;

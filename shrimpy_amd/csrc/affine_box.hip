@@ -1,0 +1,443 @@
+// Order-1 affine resample for ANY 3x4 map whose source footprint per block fits in LDS -- in
+// particular the maps that couple z with the plane (a label-free <-> light-sheet registration of an
+// oblique system is tilted: z_in depends on (yo, xo), and (y_in, x_in) on zo), which
+// affine_planar.hip cannot take and which used to fall to the 8-tap global gather of affine.hip
+// (0.24-0.29 of the HBM peak: ~170 instructions per voxel and gathers through the texture path).
+//
+// Same scipy.ndimage.affine_transform(order=1, mode="constant") arithmetic, bit for bit (exact) or
+// with f32 interpolation (LSR_MODE_F32_INTERP): coordinates ((zo*m0 + yo*m1) + xo*m2) + shift in
+// fp64, the border rule on them, weights w0 = 1 - f, w1 = 1 - w0, corners summed in scipy's order.
+//
+// Structure: a 512-thread workgroup owns a TZ x TY x TX block of 8192 OUTPUT voxels (the host picks
+// the shape that makes the source box smallest for this matrix: a tilt about y wants a short TX, a
+// tilt about x a short TY).  The source voxels the block can touch lie in the bounding box of its 8
+// corners' coordinates -- the map is linear and every rounding in the coordinate expression is
+// monotone, so the corner values, evaluated with the same expression, ARE the extremes: no slack.
+// The workgroup stages that box into LDS with LDS-DMA (global_load_lds_dwordx4: whole
+// 16-byte-aligned row pieces, no staging registers), waits once, and then every tap is an LDS read.
+// Two workgroups fit on a CU when the box is under 80 KB (near-identity maps: ~45 KB), so one
+// computes while the other's box is in flight; there is no ring and no per-plane barrier.
+//
+// A thread owns 16 / TZ output pixels (yo, xo) and walks them along zo: yo*m1 and xo*m2 are per
+// pixel, zo*m0 per plane -- scipy's sum order makes those prefixes exact to hoist -- so a voxel costs
+// 9 fp64 adds for its coordinates, then v_fract / v_cvt for the taps.  The voxel body is branch-free
+// (out-of-range voxels read clamped taps and drop the result), so hipcc interleaves the independent
+// voxels of a thread and the fp64 / LDS latencies overlap.
+//
+// Workgroups are numbered so that the ones resident on an XCD together form a 4 x 4 x 4 patch of
+// blocks: neighbouring boxes overlap by their halo, and the overlap is then an L2 hit, not a second
+// HBM read.
+//
+// Algorithmic HBM bytes: 4 * N_src + 4 * N_out.
+
+#include "common.hpp"
+
+#include <cstdlib>
+
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kBlockVoxels = 8192;
+constexpr int kMaxLoads = 20;                // 16-byte chunks per thread: boxes up to 160 KB
+constexpr int kPatch = 4;                    // blocks per patch edge
+
+struct BoxArgs {
+  const float* in;
+  float* out;
+  int Zi, Yi, Xi;
+  int Zo, Yo, Xo;
+  double m[12];
+  float cval;
+  int ty, tx, tx_shift;      // block rows / columns (powers of two; TZ is the template parameter)
+  int box_z, box_y, box_x;   // staged box (planes, rows, floats per row: a multiple of 4)
+  int n_loads;               // ceil(box chunks / 512)
+  float inv_cx, inv_by;      // 1 / (box_x / 4), 1 / box_y  (index -> (plane, row, chunk) without a divide)
+  int tz_n, ty_n, tx_n;      // blocks per axis
+  int pz_n, py_n, px_n;      // patches per axis
+  int per_xcd;               // workgroups per XCD (padded grid / 8)
+  int probe;                 // diagnostics (-DLSR_BOX_PROBES, env LSR_BOX_PROBE): 1 = no staging, 3 = staging + stores only
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void glds_x4(const float* sbase, unsigned voff, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+               : "memory");
+}
+
+// extremes of one coordinate over the block.  The coordinate expression is monotone in each index
+// (every product and every rounded sum is), so the minimum sits at the corner that takes, per axis,
+// the low index where the coefficient is >= 0 and the high index where it is negative -- evaluated
+// with the voxels' own expression, it IS the smallest value any voxel of the block computes.
+__device__ __forceinline__ void corner_range(const double* m, const int lo[3], const int hi[3], double& cmin,
+                                             double& cmax) {
+  double a[3], b[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const bool up = !(m[k] < 0.0);
+    a[k] = static_cast<double>(up ? lo[k] : hi[k]);
+    b[k] = static_cast<double>(up ? hi[k] : lo[k]);
+  }
+  cmin = lsr::affine_coord(a[0], a[1], a[2], m[0], m[1], m[2], m[3]);
+  cmax = lsr::affine_coord(b[0], b[1], b[2], m[0], m[1], m[2], m[3]);
+}
+
+// One axis of one voxel: is the coordinate inside [0, n - 1] (scipy's test, on the fp64 value), its
+// lower tap and its fraction.
+struct Tap {
+  int i;        // floor(c) for an inside coordinate (trunc(c) = floor(c) for c >= 0)
+  double f;     // c - floor(c), exact (v_fract_f64)
+  bool inside;
+};
+__device__ __forceinline__ Tap axis_tap(double c, double last) {
+  Tap t;
+  t.f = __builtin_amdgcn_fract(c);
+  t.i = static_cast<int>(c);   // v_cvt_i32_f64: towards zero, saturating
+  // (bitwise on purpose: short-circuit evaluation would turn every voxel into its own exec-masked
+  // region and keep the independent voxels of a thread from overlapping)
+  t.inside = static_cast<bool>(static_cast<int>(!(c < 0.0)) & static_cast<int>(!(c > last)));
+  return t;
+}
+
+// DEP: bit k set = source coordinate k (z, y, x) depends on zo.  A coordinate that does not is
+// worked out once per pixel instead of once per voxel (a tilt about y leaves y_in free of zo, a tilt
+// about x leaves x_in).
+template <bool F32, int TZ, int DEP>
+__global__ __launch_bounds__(kThreads, 4) void affine_box_kernel(BoxArgs p) {
+  constexpr int P = kBlockVoxels / TZ / kThreads;   // output pixels per thread
+  static_assert(P >= 1 && P * TZ * kThreads == kBlockVoxels, "block shape");
+  extern __shared__ f32x4 smem4[];
+  const float* const smem = reinterpret_cast<const float*>(smem4);
+  const unsigned lds_base =
+      static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) char*)smem4));
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- which block: workgroups b, b + 8, ... share an XCD (round-robin dispatch); give every XCD
+  // a contiguous run of the patch-major order, z fastest inside a patch
+  const int b = blockIdx.x;
+  const int g = (b & 7) * p.per_xcd + (b >> 3);
+  const int patch = g >> 6, inner = g & 63;
+  const int pz = patch % p.pz_n, py = (patch / p.pz_n) % p.py_n, px = patch / (p.pz_n * p.py_n);
+  const int bz = pz * kPatch + (inner & 3), by = py * kPatch + ((inner >> 2) & 3), bx = px * kPatch + (inner >> 4);
+  if (bz >= p.tz_n || by >= p.ty_n || bx >= p.tx_n) return;   // padding of the patch grid (wave-uniform)
+  const int z0 = bz * TZ, y0 = by * p.ty, x0 = bx * p.tx;
+
+  // ---- source box of the block -------------------------------------------------------------
+  const int lo[3] = {z0, y0, x0};
+  const int hi[3] = {min(z0 + TZ, p.Zo) - 1, min(y0 + p.ty, p.Yo) - 1, min(x0 + p.tx, p.Xo) - 1};
+  double zmin, zmax, ymin, ymax, xmin, xmax;
+  corner_range(p.m + 0, lo, hi, zmin, zmax);
+  corner_range(p.m + 4, lo, hi, ymin, ymax);
+  corner_range(p.m + 8, lo, hi, xmin, xmax);
+  const double Zl = static_cast<double>(p.Zi - 1), Yl = static_cast<double>(p.Yi - 1), Xl = static_cast<double>(p.Xi - 1);
+  const int zlo = static_cast<int>(fmin(fmax(floor(zmin), 0.0), Zl));
+  const int ylo = static_cast<int>(fmin(fmax(floor(ymin), 0.0), Yl));
+  const int xlo = static_cast<int>(fmin(fmax(floor(xmin), 0.0), Xl)) & ~3;
+  // a block that sees nothing of the volume: every voxel is cval, nothing to stage
+  const bool blind = zmax < 0.0 || zmin > Zl || ymax < 0.0 || ymin > Yl || xmax < 0.0 || xmin > Xl;
+
+  const int box_x = p.box_x, box_y = p.box_y, box_z = p.box_z;
+  const int plane_floats = box_y * box_x;
+
+  // ---- staging: chunk e = tid + 512 k of the box, LDS image linear in e ---------------------
+#ifdef LSR_BOX_PROBES
+  const int probe = p.probe;
+#else
+  constexpr int probe = 0;
+#endif
+  if (!blind && probe != 1) {
+    const int chunks_x = box_x >> 2;
+    const int n_chunks = box_z * box_y * chunks_x;
+    const unsigned plane_i = static_cast<unsigned>(p.Yi) * static_cast<unsigned>(p.Xi);
+    // 32-bit byte offsets are taken from the box's first source plane (host: box_z planes < 4 GiB)
+    const float* const src = p.in + static_cast<int64_t>(zlo) * plane_i;
+    for (int k = 0; k < p.n_loads; ++k) {
+      const int e = min(tid + k * kThreads, n_chunks - 1);
+      // e -> (plane, row, chunk); the reciprocals are exact enough for e < 2^20 with the fix-up
+      int row = static_cast<int>((static_cast<float>(e) + 0.5f) * p.inv_cx);
+      row -= (row * chunks_x > e);
+      row += ((row + 1) * chunks_x <= e);
+      const int c4 = e - row * chunks_x;
+      int pl = static_cast<int>((static_cast<float>(row) + 0.5f) * p.inv_by);
+      pl -= (pl * box_y > row);
+      pl += ((pl + 1) * box_y <= row);
+      const int r = row - pl * box_y;
+      const unsigned gz = static_cast<unsigned>(min(zlo + pl, p.Zi - 1) - zlo);   // past the volume: duplicates
+      const unsigned gy = static_cast<unsigned>(min(ylo + r, p.Yi - 1));
+      const unsigned gx = static_cast<unsigned>(min(xlo + 4 * c4, p.Xi - 4));
+      const unsigned voff = (gz * plane_i + gy * static_cast<unsigned>(p.Xi) + gx) * 4u;
+      if (wave * 64 + k * kThreads < n_chunks)   // wave-uniform: whole waves of chunks
+        glds_x4(src, voff, lds_base + static_cast<unsigned>((k * kThreads + wave * 64) * 16));
+    }
+  }
+
+  // ---- per-pixel constants while the box is in flight ----------------------------------------
+  // pixel q = tid + 512 j of the block's TY x TX plane: consecutive lanes are consecutive xo
+  unsigned pix[P];   // yo * Xo + xo: the output offset inside a plane (host: Yo * Xo < 2^31)
+  double tzy[P], tyy[P], txy[P], tzx[P], tyx[P], txx[P];
+  bool ok[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const int q = tid + j * kThreads;
+    const int yo = y0 + (q >> p.tx_shift), xo = x0 + (q & (p.tx - 1));
+    ok[j] = yo < p.Yo && xo < p.Xo;
+    pix[j] = static_cast<unsigned>(yo) * static_cast<unsigned>(p.Xo) + static_cast<unsigned>(xo);
+    const double yd = static_cast<double>(yo), xd = static_cast<double>(xo);
+    tzy[j] = lsr::dmul(yd, p.m[1]); tyy[j] = lsr::dmul(yd, p.m[5]); txy[j] = lsr::dmul(yd, p.m[9]);
+    tzx[j] = lsr::dmul(xd, p.m[2]); tyx[j] = lsr::dmul(xd, p.m[6]); txx[j] = lsr::dmul(xd, p.m[10]);
+  }
+
+  // coordinates that do not depend on zo: their taps, once per pixel (zo * 0 is an exact zero, so
+  // any plane's expression gives the value every plane computes)
+  Tap hz[P], hy[P], hx[P];
+  {
+    const double zd = static_cast<double>(z0);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      hz[j] = axis_tap(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[0]), tzy[j]), tzx[j]), p.m[3]), Zl);
+      hy[j] = axis_tap(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[4]), tyy[j]), tyx[j]), p.m[7]), Yl);
+      hx[j] = axis_tap(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[8]), txy[j]), txx[j]), p.m[11]), Xl);
+    }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const bool live = !blind;
+  // The upper neighbour of a tap is always read one element / row / plane further on, also when it
+  // lies past the volume (coordinate exactly on the last index): its weight is then exactly 0, and
+  // what the staging put there is a duplicate of in-volume data, so the product is the same zero the
+  // lower neighbour would give (finite inputs).  That keeps the eight taps at fixed strides:
+  // four ds_read2_b32 with offsets (0, 1).
+  const int row_b = box_x * 4, plane_b = plane_floats * 4;
+  const int o_max = (box_z * plane_floats - plane_floats - box_x - 2) * 4;   // clamp for dropped voxels
+  const char* const smem_b = reinterpret_cast<const char*>(smem);
+  typedef float f32x2 __attribute__((ext_vector_type(2), aligned(4)));
+  // G = 4 voxels at a time (P pixels x U planes): their coordinate chains, LDS reads and
+  // interpolations are independent, and nothing in between is conditional, so they overlap
+  constexpr int U = P >= 4 ? 1 : 4 / P;
+  constexpr int G = P * U;
+  const int nz = min(TZ, p.Zo - z0);   // uniform
+  if (probe == 3) {   // diagnostics: staging + stores only
+    for (int dz = 0; dz < nz; ++dz)
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+        if (ok[j]) p.out[static_cast<int64_t>(z0 + dz) * p.Yo * p.Xo + pix[j]] = smem[tid];
+    return;
+  }
+  for (int dz = 0; dz < nz; dz += U) {
+    Tap az[G], ay[G], ax[G];
+    f32x2 v[G][4];
+    bool inside[G];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int zo = min(z0 + dz + u, p.Zo - 1);   // (a plane past the volume repeats the last one; not stored)
+      const double zd = static_cast<double>(zo);
+      const double tzz = lsr::dmul(zd, p.m[0]), tyz = lsr::dmul(zd, p.m[4]), txz = lsr::dmul(zd, p.m[8]);
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int g = u * P + j;
+        // scipy's order: ((zo*m0 + yo*m1) + xo*m2) + shift
+        if constexpr (DEP & 1) az[g] = axis_tap(lsr::dadd(lsr::dadd(lsr::dadd(tzz, tzy[j]), tzx[j]), p.m[3]), Zl);
+        else az[g] = hz[j];
+        if constexpr (DEP & 2) ay[g] = axis_tap(lsr::dadd(lsr::dadd(lsr::dadd(tyz, tyy[j]), tyx[j]), p.m[7]), Yl);
+        else ay[g] = hy[j];
+        if constexpr (DEP & 4) ax[g] = axis_tap(lsr::dadd(lsr::dadd(lsr::dadd(txz, txy[j]), txx[j]), p.m[11]), Xl);
+        else ax[g] = hx[j];
+        inside[g] = static_cast<bool>(static_cast<int>(live) & static_cast<int>(az[g].inside) &
+                                      static_cast<int>(ay[g].inside) & static_cast<int>(ax[g].inside));
+        // the box covers every inside voxel's taps by construction; the clamp keeps an out-of-range
+        // voxel (whose result is dropped) inside the LDS image
+        int o = (__mul24(az[g].i - zlo, plane_floats) + __mul24(ay[g].i - ylo, box_x) + (ax[g].i - xlo)) * 4;
+        o = min(max(o, 0), o_max);
+        v[g][0] = *reinterpret_cast<const f32x2*>(smem_b + o);
+        v[g][1] = *reinterpret_cast<const f32x2*>(smem_b + o + row_b);
+        v[g][2] = *reinterpret_cast<const f32x2*>(smem_b + o + plane_b);
+        v[g][3] = *reinterpret_cast<const f32x2*>(smem_b + o + plane_b + row_b);
+      }
+    }
+    // every LDS read of the group is issued before the first interpolation waits for one
+    __builtin_amdgcn_sched_barrier(0);
+    float res[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float result;
+      if constexpr (F32) {
+        const float gx = static_cast<float>(ax[g].f), gy = static_cast<float>(ay[g].f), gz = static_cast<float>(az[g].f);
+        const float a0 = fmaf(gx, v[g][0].y - v[g][0].x, v[g][0].x), a1 = fmaf(gx, v[g][1].y - v[g][1].x, v[g][1].x);
+        const float b0 = fmaf(gx, v[g][2].y - v[g][2].x, v[g][2].x), b1 = fmaf(gx, v[g][3].y - v[g][3].x, v[g][3].x);
+        const float c0 = fmaf(gy, a1 - a0, a0), c1 = fmaf(gy, b1 - b0, b0);
+        result = fmaf(gz, c1 - c0, c0);
+      } else {
+        const double wz0 = 1.0 - az[g].f, wy0 = 1.0 - ay[g].f, wx0 = 1.0 - ax[g].f;
+        const double wz1 = 1.0 - wz0, wy1 = 1.0 - wy0, wx1 = 1.0 - wx0;
+        // scipy's corner order and product order: ((v * wz) * wy) * wx, summed in sequence
+        double t = 0.0;
+        auto corner = [&](float val, double wz, double wy, double wx) {
+          t = lsr::dadd(t, lsr::dmul(lsr::dmul(lsr::dmul(static_cast<double>(val), wz), wy), wx));
+        };
+        corner(v[g][0].x, wz0, wy0, wx0);
+        corner(v[g][0].y, wz0, wy0, wx1);
+        corner(v[g][1].x, wz0, wy1, wx0);
+        corner(v[g][1].y, wz0, wy1, wx1);
+        corner(v[g][2].x, wz1, wy0, wx0);
+        corner(v[g][2].y, wz1, wy0, wx1);
+        corner(v[g][3].x, wz1, wy1, wx0);
+        corner(v[g][3].y, wz1, wy1, wx1);
+        result = static_cast<float>(t);
+      }
+      res[g] = inside[g] ? result : p.cval;
+      // (an opaque use: the value exists whether or not the store below runs, so hipcc cannot sink
+      // the whole voxel into the store's condition and serialise the group again)
+      asm volatile("" : "+v"(res[g]));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int zo = z0 + dz + u;
+      if (zo >= p.Zo) break;   // uniform
+      float* const oplane = p.out + static_cast<int64_t>(zo) * p.Yo * p.Xo;   // scalar
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+        if (ok[j]) oplane[pix[j]] = res[u * P + j];
+    }
+  }
+}
+
+struct BoxShape {
+  int tz, ty, tx;
+  int bz, by, bx;
+  int64_t lds_bytes;
+};
+
+// box of a tz x ty x tx block under M: span of floor() over the block + the upper neighbour
+// [+ 3 + 3 in x: 16-byte alignment of the first column, rows rounded up to whole chunks]
+bool box_of(const double M[12], int tz, int ty, int tx, BoxShape* s) {
+  auto ab = [](double v) { return v < 0 ? -v : v; };
+  const double e[3] = {ab(M[0]) * (tz - 1) + ab(M[1]) * (ty - 1) + ab(M[2]) * (tx - 1),
+                       ab(M[4]) * (tz - 1) + ab(M[5]) * (ty - 1) + ab(M[6]) * (tx - 1),
+                       ab(M[8]) * (tz - 1) + ab(M[9]) * (ty - 1) + ab(M[10]) * (tx - 1)};
+  for (double v : e)
+    if (!(v < 2048.0)) return false;
+  // floor(cmax) - floor(cmin) <= floor(e) + 1 (e is summed here in another order than on the
+  // device: 1e-6 absorbs that), + 1 for the upper neighbour, + 1 for the count
+  s->tz = tz; s->ty = ty; s->tx = tx;
+  s->bz = static_cast<int>(e[0] + 1e-6) + 3;
+  s->by = static_cast<int>(e[1] + 1e-6) + 3;
+  s->bx = (static_cast<int>(e[2] + 1e-6) + 3 + 3 + 3) & ~3;
+  const int64_t floats = int64_t(s->bz) * s->by * s->bx;
+  s->lds_bytes = ((floats + 255) & ~int64_t(255)) * 4;
+  return true;
+}
+
+// Block shape and box of the box path for this matrix and moving volume; false = not applicable.
+bool pick_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], BoxShape* best) {
+  if (Xi % 4 != 0 || Xi < 8 || Yi < 2 || Zi < 2) return false;
+  // 8192 voxels, tx >= 32 (stores stay 128-byte runs), tz in {8, 16} (the compiled walks)
+  static const int shapes[][3] = {{8, 16, 64}, {16, 16, 32}, {8, 32, 32}, {16, 8, 64}, {8, 8, 128}, {16, 4, 128}};
+  bool found = false;
+  for (const auto& sh : shapes) {
+    BoxShape s;
+    if (!box_of(M, sh[0], sh[1], sh[2], &s)) continue;
+    if (s.lds_bytes > 150 * 1024 || lsr::ceil_div(s.lds_bytes / 16, kThreads) > kMaxLoads) continue;
+    if (int64_t(s.bz) * Yi * Xi * 4 >= (int64_t(1) << 32)) continue;   // 32-bit byte offsets inside a box
+    // two workgroups per CU (box <= 78 KB) beat any single-workgroup shape; then the smaller box
+    // (first listed wins a tie: pricing the 160-byte rows of tx = 32 shapes higher than their byte
+    // count picked 16x8x64 over 16x16x32 at equal bytes and ran 12 % slower)
+    const bool two = s.lds_bytes <= 78 * 1024, best_two = found && best->lds_bytes <= 78 * 1024;
+    if (!found || (two && !best_two) || (two == best_two && s.lds_bytes < best->lds_bytes)) {
+      *best = s;
+      found = true;
+    }
+  }
+  return found;
+}
+
+template <bool F32, int TZ, int DEP>
+void launch_one(const BoxArgs& p, unsigned blocks, size_t lds_bytes, hipStream_t s) {
+  static bool attr_set = false;
+  auto kernel = affine_box_kernel<F32, TZ, DEP>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds_bytes, s, p);
+}
+
+template <bool F32, int TZ>
+void launch_shape(const BoxArgs& p, unsigned blocks, size_t lds_bytes, hipStream_t s) {
+  // the compiled walks: everything depends on zo / y_in does not (tilt about y) / x_in does not
+  // (tilt about x); other patterns run the general walk (their zo * 0 terms are exact zeros)
+  const bool dz = p.m[0] != 0.0, dy = p.m[4] != 0.0, dx = p.m[8] != 0.0;
+  if (dz && !dy && dx) launch_one<F32, TZ, 5>(p, blocks, lds_bytes, s);
+  else if (dz && dy && !dx) launch_one<F32, TZ, 3>(p, blocks, lds_bytes, s);
+  else launch_one<F32, TZ, 7>(p, blocks, lds_bytes, s);
+}
+
+}  // namespace
+
+namespace lsr {
+
+bool affine_box_geometry(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int* box_z, int* box_y,
+                         int* box_x, int64_t* lds_bytes) {
+  BoxShape s;
+  if (!pick_shape(Zi, Yi, Xi, M, &s)) return false;
+  *box_z = s.bz; *box_y = s.by; *box_x = s.bx; *lds_bytes = s.lds_bytes;
+  return true;
+}
+
+bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
+                       int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32, hipStream_t s) {
+  BoxShape sh;
+  if (!pick_shape(Zi, Yi, Xi, M, &sh)) return false;
+  BoxArgs p;
+  p.in = in; p.out = out;
+  p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
+  p.Zo = static_cast<int>(Zo); p.Yo = static_cast<int>(Yo); p.Xo = static_cast<int>(Xo);
+  for (int i = 0; i < 12; ++i) p.m[i] = M[i];
+  p.cval = cval;
+  p.ty = sh.ty; p.tx = sh.tx;
+  p.tx_shift = sh.tx == 32 ? 5 : (sh.tx == 64 ? 6 : 7);
+  p.box_z = sh.bz; p.box_y = sh.by; p.box_x = sh.bx;
+  const int chunks = sh.bz * sh.by * (sh.bx / 4);
+  p.n_loads = static_cast<int>(ceil_div(chunks, kThreads));
+  p.inv_cx = 1.0f / static_cast<float>(sh.bx / 4);
+  p.inv_by = 1.0f / static_cast<float>(sh.by);
+  p.tz_n = static_cast<int>(ceil_div(Zo, sh.tz));
+  p.ty_n = static_cast<int>(ceil_div(Yo, sh.ty));
+  p.tx_n = static_cast<int>(ceil_div(Xo, sh.tx));
+  p.pz_n = static_cast<int>(ceil_div(p.tz_n, kPatch));
+  p.py_n = static_cast<int>(ceil_div(p.ty_n, kPatch));
+  p.px_n = static_cast<int>(ceil_div(p.tx_n, kPatch));
+  const int64_t padded = int64_t(p.pz_n) * p.py_n * p.px_n * (kPatch * kPatch * kPatch);
+  const int64_t per_xcd = ceil_div(padded, 8);
+  if (per_xcd * 8 >= (int64_t(1) << 31)) return false;
+  p.per_xcd = static_cast<int>(per_xcd);
+  // (blocks past `padded` decode to a patch index >= the patch count: px >= px_n -> bx >= tx_n -> exit)
+  p.probe = 0;
+#ifdef LSR_BOX_PROBES
+  {
+    const char* pe = getenv("LSR_BOX_PROBE");
+    p.probe = pe ? atoi(pe) : 0;
+    if (getenv("LSR_BOX_VERBOSE"))
+      fprintf(stderr, "affine_box: block %dx%dx%d box %dx%dx%d (%lld bytes)\n", sh.tz, sh.ty, sh.tx, sh.bz, sh.by,
+              sh.bx, (long long)sh.lds_bytes);
+  }
+#endif
+  const unsigned blocks = static_cast<unsigned>(per_xcd * 8);
+  const size_t lds = static_cast<size_t>(sh.lds_bytes);
+  if (Yo * Xo >= (int64_t(1) << 31)) return false;   // 32-bit output offsets inside a plane
+  switch (sh.tz * 2 + (f32 ? 1 : 0)) {
+    case 8 * 2 + 1: launch_shape<true, 8>(p, blocks, lds, s); break;
+    case 8 * 2 + 0: launch_shape<false, 8>(p, blocks, lds, s); break;
+    case 16 * 2 + 1: launch_shape<true, 16>(p, blocks, lds, s); break;
+    default: launch_shape<false, 16>(p, blocks, lds, s); break;
+  }
+  return true;
+}
+
+}  // namespace lsr

@@ -253,6 +253,103 @@ def test_affine_planar_kernel_vs_oracle(device, case, exact):
         np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-3)
 
 
+def _rotation(axis, deg):
+    th = np.deg2rad(deg)
+    c, s = np.cos(th), np.sin(th)
+    i, j = [(1, 2), (0, 2), (0, 1)][axis]       # rotate in the plane of the two other axes
+    r = np.eye(3)
+    r[i, i], r[i, j], r[j, i], r[j, j] = c, -s, s, c
+    return r
+
+
+def _tilted_matrix(rots, scale=(1.0, 1.0, 1.0), shift=(0.0, 0.0, 0.0), centre=None):
+    """Rotations about (axis, degrees) in sequence, then a diagonal scale; about ``centre`` if given."""
+    lin = np.eye(3)
+    for axis, deg in rots:
+        lin = lin @ _rotation(axis, deg)
+    lin = lin @ np.diag(scale)
+    m = np.eye(4)
+    m[:3, :3] = lin
+    m[:3, 3] = shift
+    if centre is not None:
+        c = np.asarray(centre, dtype=np.float64)
+        m[:3, 3] = c - lin @ c + np.asarray(shift)
+    return m
+
+
+BOX_CASES = [
+    # a tilted registration: light-sheet volume rotated 3 deg about Y (couples z and x), 2 deg in the plane
+    dict(shape=(24, 96, 132), m=_tilted_matrix([(1, 3.0), (0, 2.0)], (1.0, 0.98, 1.02), (1.5, -4.25, 6.75))),
+    # about the volume centre, all three axes, ragged output larger than the input
+    dict(shape=(19, 45, 76), out=(23, 50, 91), m=_tilted_matrix([(0, 4.0), (1, -6.0), (2, 5.0)], centre=(9, 22, 38))),
+    # z depends on (y, x) only through a shear; the plane does not depend on z
+    dict(shape=(16, 40, 64), m=np.array([[1, 0.11, -0.07, 2.0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])),
+    # the plane depends on z; z decoupled
+    dict(shape=(16, 40, 64), m=np.array([[1, 0, 0, 0.5], [0.3, 1, 0, -1.0], [-0.2, 0, 1, 2.0], [0, 0, 0, 1.0]])),
+    # flips on every axis plus a tilt
+    dict(shape=(12, 33, 68), m=_tilted_matrix([(1, 2.0)], (-1.0, -1.0, -1.0), (11.0, 32.0, 67.0))),
+    # downsampling 1.3x with a tilt: a large (but fitting) source box, one workgroup per CU
+    dict(shape=(40, 90, 200), out=(28, 66, 150), m=_tilted_matrix([(1, 1.5), (2, 1.0)], (1.3, 1.3, 1.3))),
+    # upsampling 3x: tiny source boxes, many output blocks per source voxel
+    dict(shape=(6, 10, 24), out=(17, 28, 70), m=_tilted_matrix([(1, 8.0)], (0.33, 0.33, 0.33))),
+    # 30 degrees about X: steep coupling of z and y
+    dict(shape=(30, 30, 64), m=_tilted_matrix([(2, 30.0)], centre=(15, 15, 32))),
+    # pushed far away: every block is blind
+    dict(shape=(8, 24, 64), m=_tilted_matrix([(1, 3.0)], shift=(0.0, 0.0, 5000.0))),
+    # one plane / one row outputs
+    dict(shape=(9, 17, 32), out=(1, 1, 130), m=_tilted_matrix([(1, 3.0), (2, 2.0)], (1.0, 1.0, 0.24), (3.0, 5.0, 0.0))),
+]
+
+
+@pytest.mark.parametrize("case", BOX_CASES)
+@pytest.mark.parametrize("exact", [True, False])
+def test_affine_box_kernel_vs_oracle(device, case, exact):
+    """Maps that couple z with the plane (and any other map whose per-block source box fits in LDS)
+    run affine_box.hip: bit-identical to scipy in exact mode, within 2e-5 of the data range with f32
+    interpolation and with the same in / out-of-range decisions."""
+    from shrimpy_amd import _lib
+    from shrimpy_amd.geometry import as_matrix_3x4
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    m, shape = case["m"], case["shape"]
+    path = _lib.call_value("lsr_affine_path", shape[0], shape[1], shape[2], _lib.matrix12(as_matrix_3x4(m)),
+                           _lib.MODE_CONSTANT)
+    assert path == 2
+    rng = np.random.default_rng(len(str(case)))
+    vol = (rng.random(shape) * 1000 - 100).astype(np.float32)
+    oshape = case.get("out", shape)
+    ref = o.affine_apply_4x4(vol, m, oshape, cval=-3.0, mode="constant")
+    out = apply_affine_transform_zyx(_t(vol, device), m, oshape, cval=-3.0, exact=exact).cpu().numpy()
+    if exact:
+        np.testing.assert_array_equal(out, ref)
+    else:
+        assert np.array_equal(out == -3.0, ref == -3.0)
+        assert np.abs(out - ref).max() <= 2e-5 * 1100
+
+
+def test_affine_path_selection(device):
+    """planar (1) for z-decoupled maps, box (2) for the rest that fit, gather (0) otherwise; every
+    path gives the oracle's bits."""
+    from shrimpy_amd import _lib
+    from shrimpy_amd.geometry import as_matrix_3x4
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    def path(shape, m, mode=_lib.MODE_CONSTANT):
+        return _lib.call_value("lsr_affine_path", shape[0], shape[1], shape[2], _lib.matrix12(as_matrix_3x4(m)), mode)
+
+    tilt = _tilted_matrix([(1, 3.0)])
+    assert path((20, 96, 132), _config3_matrix()) == 1
+    assert path((20, 96, 132), tilt) == 2
+    assert path((20, 96, 130), tilt) == 0                                 # Xi not a multiple of 4
+    assert path((20, 96, 132), tilt, _lib.MODE_GRID_CONSTANT) == 0        # blending border: gather kernel
+    assert path((20, 96, 132), _tilted_matrix([(1, 3.0)], (9.0, 9.0, 9.0))) == 0   # source box beyond LDS
+    rng = np.random.default_rng(77)
+    for shape in ((20, 96, 132), (20, 96, 130)):
+        vol = (rng.random(shape) * 1000).astype(np.float32)
+        out = apply_affine_transform_zyx(_t(vol, device), tilt).cpu().numpy()
+        np.testing.assert_array_equal(out, o.affine_apply_4x4(vol, tilt, shape))
+
+
 @pytest.mark.parametrize("mode", ["constant", "grid-constant"])
 def test_affine_f32_interpolation_mode_is_close_and_keeps_the_border(device, mode):
     """``exact=False``: f32 interpolation; tolerance 2e-5 of the data range, and the

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--skip-dense", action="store_true")
     ap.add_argument("--only-rl", action="store_true", help="skip the affine and deskew sections")
+    ap.add_argument("--only-affine", action="store_true", help="only the affine apply section")
     ap.add_argument("--rl-grid", default="171,2048,2270", help="Z,Y,X of the RL launch section")
     args = ap.parse_args()
 
@@ -54,6 +55,8 @@ def main():
     if not args.only_rl:
         _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_geometry, apply_affine_transform_zyx)
 
+    if args.only_affine:
+        return
     # ---- RL launches on the config-2 grid: separable (tuned) and dense
     oshape = tuple(int(v) for v in args.rl_grid.split(","))
     if not args.only_rl:
@@ -77,23 +80,38 @@ def _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_ge
         print(json.dumps({"kernel": f"affine_kernel ({mode}, {'exact fp64' if exact else 'f32 interp'})", "shape": shape, "ms": ms,
                           "algorithmic_GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / 8000,
                           "voxels_per_s": vol.numel() / (ms * 1e-3)}))
-    # a map that couples z with the plane (tilt about y): the general gather kernel
+    # maps that couple z with the plane: (a) tilt 1.5 deg about y; (b) the config-3 registration with
+    # a 3 deg tilt about y on top (the oblique light-sheet <-> label-free case) -- affine_box.hip;
+    # the same maps in grid-constant mode take the general gather kernel (the old path)
+    from shrimpy_amd import _lib
+    from shrimpy_amd.geometry import as_matrix_3x4
+
     tilt = np.eye(4)
     c, sn = np.cos(np.deg2rad(1.5)), np.sin(np.deg2rad(1.5))
     tilt[0, 0], tilt[0, 2], tilt[2, 0], tilt[2, 2] = c, -sn, sn, c
     tilt[:3, 3] = [2.0, 0.5, -3.25]
-    for exact in (True, False):
-        ms = timed(lambda: apply_affine_transform_zyx(vol, tilt, out=out, exact=exact), args.reps)
-        nbytes = 8.0 * vol.numel()
-        print(json.dumps({"kernel": f"affine_kernel (tilted map, gather, {'exact fp64' if exact else 'f32 interp'})",
-                          "shape": shape, "ms": ms, "algorithmic_GBps": nbytes / ms / 1e6,
-                          "frac_of_8TBps": nbytes / ms / 1e6 / 8000}))
+    c3, s3 = np.cos(np.deg2rad(3.0)), np.sin(np.deg2rad(3.0))
+    ry = np.array([[c3, 0, -s3], [0, 1, 0], [s3, 0, c3]])
+    both = m.copy()
+    both[:3, :3] = ry @ m[:3, :3]
+    for name, mat in (("tilt 1.5deg about y", tilt), ("config3 o tilt 3deg about y", both)):
+        for mode, exact in (("constant", True), ("constant", False), ("grid-constant", True)):
+            path = _lib.call_value("lsr_affine_path", shape[0], shape[1], shape[2],
+                                   _lib.matrix12(as_matrix_3x4(mat)), _lib.MODE_CONSTANT if mode == "constant" else _lib.MODE_GRID_CONSTANT)
+            ms = timed(lambda: apply_affine_transform_zyx(vol, mat, mode=mode, out=out, exact=exact), args.reps)
+            nbytes = 8.0 * vol.numel()
+            print(json.dumps({"kernel": f"affine ({name}, {mode}, {'exact fp64' if exact else 'f32 interp'})",
+                              "path": {0: "gather", 1: "planar", 2: "box"}[path],
+                              "shape": shape, "ms": ms, "algorithmic_GBps": nbytes / ms / 1e6,
+                              "frac_of_8TBps": nbytes / ms / 1e6 / 8000}))
     del vol, out
+    if args.only_affine:
+        return
 
     # ---- flat-field (median over Z + apply / fused deskew), config 2 raw stack of camera counts
     from shrimpy_amd.flatfield import flat_field_pattern
 
-    raw_shape = bench.WORKLOADS["config2"]
+    raw_shape = bench.WORKLOADS["config2"][1]
     raw = torch.randint(80, 600, raw_shape, device=dev, generator=g).to(torch.float32)
     ms = timed(lambda: flat_field_pattern(raw), args.reps)             # camera counts: 2 passes
     print(json.dumps({"kernel": "flat_median_kernel (+ mean), integer counts", "raw": raw_shape, "ms": ms,
@@ -131,7 +149,7 @@ def _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_ge
 
     # ---- deskew alone, config 2 and config 4 mappings
     for name in ("config2", "config4"):
-        raw_shape = bench.WORKLOADS[name]
+        raw_shape = bench.WORKLOADS[name][1]
         raw = torch.rand(raw_shape, device=dev, generator=g)
         geo = deskew_geometry(raw_shape, **bench.DESKEW)
         dst = torch.empty(geo.output_shape, device=dev)

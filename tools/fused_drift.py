@@ -25,7 +25,7 @@ def main():
     from shrimpy_amd.deskew import get_deskewed_data_shape
 
     dev = torch.device("cuda", 0)
-    out_shape, _ = get_deskewed_data_shape(bench.WORKLOADS["config2"], **bench.DESKEW)
+    out_shape, _ = get_deskewed_data_shape(bench.WORKLOADS["config2"][1], **bench.DESKEW)
     plan = RichardsonLucyPlan(out_shape, None, dev, psf_factors=bench.gaussian_factors())
     y = plan.new_padded_input()
     y.view.copy_(torch.rand(out_shape, device=dev) + 0.5)

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--workload", default="config2")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    raw_shape = bench.WORKLOADS[args.workload]
+    raw_shape = bench.WORKLOADS[args.workload][1]
     settings = bench.reconstruct_settings() if hasattr(bench, "reconstruct_settings") else None
     if settings is None:
         from shrimpy_amd.settings import DeconvolveSettings, DeskewSettings, ReconstructSettings

@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--workload", default="config4")
     ap.add_argument("--dir", default=None)
     args = ap.parse_args()
-    raw_shape = bench.WORKLOADS[args.workload]
+    raw_shape = bench.WORKLOADS[args.workload][1]
     root = tempfile.mkdtemp(prefix="lsr_plate_", dir=args.dir)
     try:
         rng = np.random.default_rng(4000)
