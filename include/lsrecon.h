@@ -110,6 +110,23 @@ int lsr_affine_kernel_choice(int64_t Yi, int64_t Xi, const double M[12], int mod
  * 0 = the general gather kernel. Results are identical whichever runs. */
 int lsr_affine_path(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int mode);
 
+/*
+ * Affine registration, estimate half (no reference symbol, docs/data_structure.md:58-62).
+ * Normal equations of one Gauss-Newton step of   min sum_x (gain * moving(M x) + offset - target(x))^2
+ * over the target grid sampled every `stride` voxels (trilinear taps; a sample counts when all eight
+ * lie inside `moving`).  Parameters: the 3x4 matrix row by row in centred, scaled target coordinates
+ * ((x - centre) / scale, 1), then gain, offset (14).  `partial` receives lsr_affine_normal_blocks()
+ * rows of lsr_affine_normal_size() doubles (105 upper-triangle entries of J^T J row by row, 14 of
+ * J^T r, sum r^2, sample count); their sum over rows, in row order, is the result.
+ */
+int lsr_affine_normal_size(void);
+int lsr_affine_normal_blocks(void);
+int lsr_affine_normal_equations_f32(const float* moving, int64_t Zi, int64_t Yi, int64_t Xi,
+                                    const float* target, int64_t Zo, int64_t Yo, int64_t Xo,
+                                    const double M[12], double gain, double offset, int stride,
+                                    const double centre[3], double scale, double* partial,
+                                    lsr_stream_t stream);
+
 /* out[zo] = mean_k in[min(zo*avg_n + k, Zd-1)], k < avg_n, f32, ((d0+d1)+...)/avg_n. */
 int lsr_average_slices_f32(const float* in, int64_t Zd, int64_t Y, int64_t X, float* out,
                            int64_t Zo, int avg_n, lsr_stream_t stream);

@@ -306,6 +306,104 @@ def bead_scene(shape, seed, psf=None, density=2e-5, background=100.0, psf_factor
 
 
 # --------------------------------------------------------------------------------------------
+# Next row f-4, second half: estimating the label-free <-> light-sheet affine.  No reference code
+# exists (docs/data_structure.md:58-62; biahub's estimate-registration is [RECALLED]) -- PARITY
+# UNPINNED; this restates the textbook additive Gauss-Newton / Lucas-Kanade step the product's kernel
+# implements, in numpy, so that the kernel's sums and the recovered transforms can be checked.
+# --------------------------------------------------------------------------------------------
+
+
+def affine_normal_equations(moving, target, matrix_3x4, gain=1.0, offset=0.0, stride=1, centre=None, scale=None):
+    """``(H 14x14, b 14, sse, n)`` of  min sum (gain * M(A x) + offset - T(x))^2  at ``matrix_3x4`` over
+    the target grid sampled every ``stride`` voxels; parameters = the matrix rows in centred, scaled
+    target coordinates ``((x - centre) / scale, 1)``, then gain, offset."""
+    mov = np.asarray(moving, np.float64)
+    tgt = np.asarray(target, np.float64)
+    m = np.asarray(matrix_3x4, np.float64)[:3]
+    shape = tgt.shape
+    c = np.asarray(centre if centre is not None else [(n - 1) / 2 for n in shape], np.float64)
+    s = float(scale if scale is not None else max(shape) / 2)
+    idx = np.stack(np.meshgrid(*[np.arange(0, n, stride, dtype=np.float64) for n in shape], indexing="ij"), -1).reshape(-1, 3)
+    coord = idx @ m[:, :3].T + m[:, 3]
+    lim = np.array(mov.shape) - 1
+    keep = np.all((coord >= 0) & (coord < lim), axis=1)
+    idx, coord = idx[keep], coord[keep]
+    j = np.floor(coord).astype(int)
+    f = coord - j
+    v = {(a, b_, c_): mov[j[:, 0] + a, j[:, 1] + b_, j[:, 2] + c_] for a in (0, 1) for b_ in (0, 1) for c_ in (0, 1)}
+    fz, fy, fx = f[:, 0], f[:, 1], f[:, 2]
+    a00 = v[0, 0, 0] + fx * (v[0, 0, 1] - v[0, 0, 0]); a01 = v[0, 1, 0] + fx * (v[0, 1, 1] - v[0, 1, 0])
+    a10 = v[1, 0, 0] + fx * (v[1, 0, 1] - v[1, 0, 0]); a11 = v[1, 1, 0] + fx * (v[1, 1, 1] - v[1, 1, 0])
+    b0 = a00 + fy * (a01 - a00); b1 = a10 + fy * (a11 - a10)
+    mval = b0 + fz * (b1 - b0)
+    gz = b1 - b0
+    gy = (a01 - a00) + fz * ((a11 - a10) - (a01 - a00))
+    d00, d01 = v[0, 0, 1] - v[0, 0, 0], v[0, 1, 1] - v[0, 1, 0]
+    d10, d11 = v[1, 0, 1] - v[1, 0, 0], v[1, 1, 1] - v[1, 1, 0]
+    e0 = d00 + fy * (d01 - d00); e1 = d10 + fy * (d11 - d10)
+    gx = e0 + fz * (e1 - e0)
+    tv = tgt[idx[:, 0].astype(int), idx[:, 1].astype(int), idx[:, 2].astype(int)]
+    r = gain * mval + offset - tv
+    xt = np.concatenate([(idx - c) / s, np.ones((len(idx), 1))], axis=1)
+    jac = np.concatenate([gain * g[:, None] * xt for g in (gz, gy, gx)] + [mval[:, None], np.ones((len(idx), 1))], axis=1)
+    return jac.T @ jac, jac.T @ r, float(r @ r), int(len(idx))
+
+
+def estimate_affine(moving, target, initial=None, model="affine", intensity=True, levels=((2, 1.0), (1, 0.0)),
+                    max_iterations=40, tol=2e-3):
+    """Gauss-Newton with Levenberg-Marquardt damping on the sums above, coarse to fine; returns
+    ``(4x4 target index -> moving coordinate, gain, offset, rms)``."""
+    shape = np.asarray(target).shape
+    c = np.array([(n - 1) / 2 for n in shape])
+    s = max(shape) / 2
+    m = np.eye(4)[:3].copy() if initial is None else np.asarray(initial, np.float64)[:3].copy()
+    mov, tgt = np.asarray(moving, np.float32), np.asarray(target, np.float32)
+    gain, offset = 1.0, 0.0
+    if intensity and mov.std() > 0 and tgt.std() > 0:
+        gain = float(tgt.std() / mov.std())
+        offset = float(tgt.mean() - gain * mov.mean())
+    free = np.zeros(14, bool)
+    free[[3, 7, 11]] = True
+    if model == "affine":
+        free[:12] = True
+    if intensity:
+        free[12:] = True
+    corners = np.array([[z, y, x, 1.0] for z in (0, shape[0] - 1) for y in (0, shape[1] - 1) for x in (0, shape[2] - 1)])
+    rms = np.nan
+    for stride, sigma in levels:
+        lm = ndimage.gaussian_filter(mov, sigma, mode="reflect", truncate=4.0) if sigma > 0 else mov
+        lt = ndimage.gaussian_filter(tgt, sigma, mode="reflect", truncate=4.0) if sigma > 0 else tgt
+        h, b, sse, n = affine_normal_equations(lm, lt, m, gain, offset, stride, c, s)
+        lam = 1e-3
+        for _ in range(max_iterations):
+            hf, bf = h[np.ix_(free, free)], b[free]
+            accepted = None
+            for _try in range(8):
+                delta = np.linalg.solve(hf + lam * np.diag(np.diag(hf)) + 1e-12 * np.eye(hf.shape[0]), -bf)
+                full = np.zeros(14)
+                full[free] = delta
+                q = np.concatenate([m[:, :3] * s, (m[:, :3] @ c + m[:, 3])[:, None]], axis=1) + full[:12].reshape(3, 4)
+                m_new = np.concatenate([q[:, :3] / s, (q[:, 3] - (q[:, :3] / s) @ c)[:, None]], axis=1)
+                g_new, o_new = gain + full[12], offset + full[13]
+                h2, b2, sse2, n2 = affine_normal_equations(lm, lt, m_new, g_new, o_new, stride, c, s)
+                if n2 >= 0.5 * n and sse2 / max(n2, 1) <= sse / n * (1 + 1e-12):
+                    accepted = (m_new, g_new, o_new, h2, b2, sse2, n2)
+                    lam = max(lam / 3, 1e-9)
+                    break
+                lam *= 10
+            if accepted is None:
+                break
+            moved = float(np.abs(corners @ (accepted[0] - m).T).max())
+            m, gain, offset, h, b, sse, n = accepted
+            if moved < tol:
+                break
+        rms = float(np.sqrt(sse / n))
+    out = np.eye(4)
+    out[:3] = m
+    return out, gain, offset, rms
+
+
+# --------------------------------------------------------------------------------------------
 # Next row f-3: DynaTrack shift estimators on the deskewed volume
 # (shrimpy/dynatrack/tracking.py:386-707, 759-787).  Pinned by tests/golden/ref_dynatrack.npz,
 # which oracle/make_golden.py captured by running the reference's own functions.

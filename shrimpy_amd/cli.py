@@ -9,6 +9,7 @@ CPU path (biahub's; the reference's own CLI has only ``acquire`` and ``gui``,
     python -m shrimpy_amd.cli register    -i in.zarr  -c register.yml    -o registered.zarr
     python -m shrimpy_amd.cli deconvolve  -i in.zarr  -c deconvolve.yml  -o deconvolved.zarr
     python -m shrimpy_amd.cli reconstruct -i raw.zarr -c recon.yml       -o recon.zarr
+    python -m shrimpy_amd.cli estimate-registration -s moving.zarr -t target.zarr -o register.yml
 
 Every (position, timepoint, channel) volume is an independent unit.  Launched under
 ``python -m torch.distributed.run --nproc-per-node N`` each rank takes the units
@@ -420,6 +421,80 @@ def reconstruct(input_path, config, output_path, positions, zarr_version, resume
         raise click.ClickException("the config enables no step")
     click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
                          io_backend=io_backend, compression=compression))
+
+
+@cli.command("estimate-registration")
+@click.option("-s", "--source-position-dirpaths", "source_path", required=True,
+              type=click.Path(exists=True, path_type=Path), help="Store holding the MOVING volume.")
+@click.option("-t", "--target-position-dirpaths", "target_path", required=True,
+              type=click.Path(exists=True, path_type=Path), help="Store holding the TARGET (fixed) volume.")
+@click.option("-o", "--output-filepath", "output_path", required=True, type=click.Path(dir_okay=False, path_type=Path),
+              help="RegisterSettings YAML to write (affine_transform_zyx, source_channel_names).")
+@click.option("--source-channel", default=None, help="Channel name in the source store (default: the first).")
+@click.option("--target-channel", default=None, help="Channel name in the target store (default: the first).")
+@click.option("-p", "--position", default=None, help='Position key ("row/col/fov") in both stores (default: the first).')
+@click.option("--timepoint", type=int, default=0, show_default=True)
+@click.option("--model", type=click.Choice(["affine", "translation"]), default="affine", show_default=True)
+@click.option("--no-intensity", is_flag=True, help="Do not fit the gain / offset between the two volumes.")
+@click.option("--io", "io_backend", type=click.Choice(["auto", "native", "iohub"]), default="auto", show_default=True)
+def estimate_registration(source_path, target_path, output_path, source_channel, target_channel, position, timepoint,
+                          model, no_intensity, io_backend):
+    """Estimate the affine that maps TARGET indices to SOURCE coordinates (what `register` applies)."""
+    click.echo(run_estimate(source_path, target_path, output_path, source_channel, target_channel, position, timepoint,
+                            model, not no_intensity, io_backend))
+
+
+def run_estimate(source_path, target_path, output_path, source_channel=None, target_channel=None, position=None,
+                 timepoint: int = 0, model: str = "affine", intensity: bool = True, io_backend: str = "auto",
+                 estimator=None) -> dict:
+    """Read one volume from each store, estimate, write the ``RegisterSettings`` YAML.
+    ``estimator(moving, target, model=, intensity=)`` defaults to :func:`estimate.estimate_affine_zyx`."""
+    import torch
+    import yaml
+
+    from .io.omezarr import as_volume_array
+
+    _, _, device, created = _distributed()
+    try:
+        def read(path, channel):
+            _, positions = _open_source(path, io_backend)
+            key = position or next(iter(positions))
+            if key not in positions:
+                raise click.ClickException(f"position {key!r} not in {path} (it has {list(positions)})")
+            pos = positions[key]
+            names = list(pos.channel_names)
+            if channel is None:
+                c = 0
+            elif channel in names:
+                c = names.index(channel)
+            else:
+                raise click.ClickException(f"channel {channel!r} not in {path} (it has {names})")
+            arr = as_volume_array(pos["0"])
+            if not 0 <= timepoint < arr.shape[0]:
+                raise click.ClickException(f"timepoint {timepoint} out of range for {path} (T = {arr.shape[0]})")
+            vol = arr.read_volume(timepoint, c)
+            return torch.as_tensor(np.ascontiguousarray(vol, dtype=np.float32), device=device), (names[c] if names else str(c))
+
+        moving, src_name = read(source_path, source_channel)
+        target, tgt_name = read(target_path, target_channel)
+        if estimator is None:
+            from .estimate import estimate_affine_zyx as estimator
+        est = estimator(moving, target, model=model, intensity=intensity)
+        doc = est.to_settings_dict(source_channel_names=[src_name], output_shape_zyx=[int(n) for n in target.shape])
+        if Path(source_path).resolve() == Path(target_path).resolve() and tgt_name != src_name:
+            doc["target_channel_name"] = tgt_name
+        RegisterSettings(**doc)   # what we write must load
+        Path(output_path).parent.mkdir(parents=True, exist_ok=True)
+        with open(output_path, "w") as f:
+            yaml.safe_dump(doc, f, sort_keys=False)
+        return {"output": str(output_path), "rms": est.rms, "gain": est.gain, "offset": est.offset,
+                "iterations": est.iterations, "converged": est.converged,
+                "affine_transform_zyx": doc["affine_transform_zyx"]}
+    finally:
+        if created:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
 
 
 def main():

@@ -151,14 +151,23 @@ __device__ __forceinline__ void gload(float& dst, const float* sbase, int voff) 
 // Stores are non-temporal: x_new is not read again before the next launch, and keeping it out of
 // the way leaves more of L2 / MALL to the x planes that ARE read again nine planes later
 // (measured 2.56 -> 2.50 ms per launch; `nt` on the y loads instead made it slower, 2.66 ms).
+#ifndef LSR_FUSED_STORE_POLICY
+#define LSR_FUSED_STORE_POLICY "nt"   // probes (round 2): "sc1", "nt sc1", "sc0 sc1" -- see DESIGN.md section 4.3
+#endif
+#ifndef LSR_FUSED_GLDS_POLICY
+#define LSR_FUSED_GLDS_POLICY ""      // probe: "nt" on the LDS-DMA of the x window
+#endif
 template <int IMM>
 __device__ __forceinline__ void gstore(float* sbase, int voff, float v) {
-  asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+  asm volatile("global_store_dword %0, %1, %2 offset:%3 " LSR_FUSED_STORE_POLICY
+               :
+               : "v"(voff), "v"(v), "s"(sbase), "n"(IMM)
+               : "memory");
 }
 // LDS-DMA: 16 bytes per lane, LDS address = m0 + 16 * lane.  One wait state between the write of
 // m0 and the load (s_nop).
 __device__ __forceinline__ void glds_x4(const float* sbase, int voff, unsigned lds_byte_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 " LSR_FUSED_GLDS_POLICY
                :
                : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
                : "memory");  // (m0 is a reserved register: hipcc sets it right at each of its own uses)

@@ -1,0 +1,239 @@
+"""Estimating the registration affine (second half): the normal-equations kernel
+against the numpy oracle, known transforms recovered, and the estimate -> apply loop closed.
+
+No reference code exists for this step (``docs/data_structure.md:58-62``): the oracle restates the
+textbook Gauss-Newton step and is itself pinned here by finite differences and by recovering known
+transforms -- parity unpinned, as for deskew / apply / RL."""
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as o
+
+SHAPE = (24, 40, 48)
+
+
+def _scene(seed, shape=SHAPE, n=25):
+    rng = np.random.default_rng(seed)
+    zz, yy, xx = np.meshgrid(*[np.arange(s, dtype=np.float64) for s in shape], indexing="ij")
+    vol = np.zeros(shape)
+    for _ in range(n):
+        c = [rng.uniform(3, s - 3) for s in shape]
+        a, w = rng.uniform(50, 200), rng.uniform(1.5, 3.0)
+        vol += a * np.exp(-0.5 * (((zz - c[0]) / w) ** 2 + ((yy - c[1]) / w) ** 2 + ((xx - c[2]) / w) ** 2))
+    return (vol + 10).astype(np.float32)
+
+
+def _tilted(shape=SHAPE, tilt=3.0, scale=(1.0, 0.97, 1.03), shift=(0.8, -1.5, 2.2)):
+    th = np.deg2rad(tilt)
+    m = np.eye(4)
+    m[:3, :3] = np.array([[np.cos(th), 0, -np.sin(th)], [0, 1, 0], [np.sin(th), 0, np.cos(th)]]) @ np.diag(scale)
+    c = np.array([(n - 1) / 2 for n in shape])
+    m[:3, 3] = c - m[:3, :3] @ c + np.asarray(shift)
+    return m
+
+
+def test_oracle_gradient_is_the_derivative_of_the_residual():
+    """b = J^T r must be the gradient of sse / 2 with respect to the 14 parameters (finite differences
+    on the parameterisation the kernel uses: matrix rows in centred, scaled coordinates, gain, offset)."""
+    mov, tgt = _scene(1), _scene(2)
+    m = _tilted()[:3]
+    c = np.array([(n - 1) / 2 for n in SHAPE])
+    s = max(SHAPE) / 2
+
+    def sse(params):
+        q = params[:12].reshape(3, 4)
+        mm = np.concatenate([q[:, :3] / s, (q[:, 3] - (q[:, :3] / s) @ c)[:, None]], axis=1)
+        return o.affine_normal_equations(mov, tgt, mm, params[12], params[13], 2, c, s)[2]
+
+    q0 = np.concatenate([np.concatenate([m[:, :3] * s, (m[:, :3] @ c + m[:, 3])[:, None]], axis=1).ravel(), [1.3, -2.0]])
+    h, b, _, n = o.affine_normal_equations(mov, tgt, m, 1.3, -2.0, 2, c, s)
+    assert n > 1000 and np.allclose(h, h.T) and np.all(np.linalg.eigvalsh(h) > 0)
+    for k in (0, 3, 5, 7, 10, 11, 12, 13):
+        e = np.zeros(14)
+        e[k] = 1e-4
+        # (the trilinear interpolant is piecewise: a central difference is exact up to cell crossings)
+        num = (sse(q0 + e) - sse(q0 - e)) / 2e-4 / 2
+        assert num == pytest.approx(b[k], rel=2e-3, abs=1e-3 * abs(b).max())
+
+
+@pytest.mark.parametrize("model", ["affine", "translation"])
+def test_oracle_recovers_a_known_transform(model):
+    mov = _scene(3)
+    true = _tilted() if model == "affine" else _tilted(tilt=0.0, scale=(1, 1, 1), shift=(1.25, -0.5, 2.75))
+    tgt = (1.7 * o.affine_apply_4x4(mov, true, SHAPE) + 5).astype(np.float32)
+    est, gain, offset, rms = o.estimate_affine(mov, tgt, model=model)
+    assert np.abs(est - true).max() < 1e-4 and gain == pytest.approx(1.7, rel=1e-4) and offset == pytest.approx(5, abs=1e-2)
+    assert rms < 1e-3
+
+
+def test_host_parameter_maps_are_inverse_and_settings_round_trip(tmp_path):
+    import yaml
+
+    from shrimpy_amd import estimate as e
+    from shrimpy_amd.settings import RegisterSettings
+
+    m = _tilted()[:3]
+    c, s = np.array([11.5, 19.5, 23.5]), 24.0
+    np.testing.assert_allclose(e._from_normalised(e._to_normalised(m, c, s), c, s), m, rtol=0, atol=1e-13)
+    row = np.arange(121, dtype=np.float64)
+    h, b, sse, n = e._unpack(row)
+    assert np.array_equal(h, h.T) and h[0, 13] == 13 and h[1, 1] == 14 and b[0] == 105 and (sse, n) == (119.0, 120)
+    est = e.RegistrationEstimate(_tilted(), 1.0, 0.0, 0.1, 10, 3, True)
+    doc = est.to_settings_dict(source_channel_names=["LS"])
+    (tmp_path / "r.yml").write_text(yaml.safe_dump(doc))
+    back = RegisterSettings.from_yaml(tmp_path / "r.yml")
+    np.testing.assert_allclose(np.array(back.affine_transform_zyx), _tilted())
+    assert e._corner_motion(m, m, SHAPE) == 0.0
+    with pytest.raises(ValueError, match="model"):
+        e.estimate_affine_zyx(None, None, model="rigid")
+
+
+def test_cli_estimate_registration_writes_loadable_settings(tmp_path, monkeypatch):
+    """CLI plumbing with the estimator stubbed: the right volumes are read and the YAML loads."""
+    import torch
+    import yaml
+
+    import shrimpy_amd.cli as cli
+    from shrimpy_amd.estimate import RegistrationEstimate
+    from shrimpy_amd.io.omezarr import open_ome_zarr
+    from shrimpy_amd.settings import RegisterSettings
+
+    monkeypatch.setattr(cli, "_distributed", lambda: (0, 1, torch.device("cpu"), False))
+    rng = np.random.default_rng(0)
+    vols = rng.integers(0, 900, (2, 2, 6, 5, 4)).astype(np.uint16)
+    with open_ome_zarr(tmp_path / "a.zarr", layout="hcs", mode="w", channel_names=["BF", "LS"], prefer_iohub=False) as p:
+        arr = p.create_position("A", "1", "0").create_zeros("0", shape=vols.shape, dtype="uint16")
+        for t in range(2):
+            for c in range(2):
+                arr.write_volume(t, c, vols[t, c])
+    seen = {}
+
+    def fake(moving, target, model, intensity):
+        seen.update(moving=moving.numpy().copy(), target=target.numpy().copy(), model=model, intensity=intensity)
+        return RegistrationEstimate(_tilted(), 1.0, 0.0, 0.5, 100, 7, True)
+
+    res = cli.run_estimate(tmp_path / "a.zarr", tmp_path / "a.zarr", tmp_path / "out" / "reg.yml", "LS", "BF",
+                           "A/1/0", 1, "translation", False, "native", estimator=fake)
+    np.testing.assert_array_equal(seen["moving"], vols[1, 1].astype(np.float32))
+    np.testing.assert_array_equal(seen["target"], vols[1, 0].astype(np.float32))
+    assert (seen["model"], seen["intensity"]) == ("translation", False) and res["iterations"] == 7
+    s = RegisterSettings.from_yaml(tmp_path / "out" / "reg.yml")
+    assert s.source_channel_names == ["LS"] and s.target_channel_name == "BF" and s.output_shape_zyx == (6, 5, 4)
+    doc = yaml.safe_load((tmp_path / "out" / "reg.yml").read_text())
+    np.testing.assert_allclose(np.array(doc["affine_transform_zyx"]), _tilted())
+    import click
+
+    with pytest.raises(click.ClickException, match="channel"):
+        cli.run_estimate(tmp_path / "a.zarr", tmp_path / "a.zarr", tmp_path / "x.yml", "nope", None, estimator=fake)
+    with pytest.raises(click.ClickException, match="position"):
+        cli.run_estimate(tmp_path / "a.zarr", tmp_path / "a.zarr", tmp_path / "x.yml", position="B/9/9", estimator=fake)
+
+
+# ------------------------------------------------------------------ GPU
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stride", [1, 2, 3])
+def test_normal_equations_kernel_matches_the_oracle(device, stride):
+    import torch
+
+    from shrimpy_amd.estimate import normal_equations
+
+    mov, tgt = _scene(5, (20, 37, 51)), _scene(6, (18, 40, 45))     # different shapes on purpose
+    m = _tilted((18, 40, 45), tilt=4.0, shift=(1.5, -2.0, 3.0))
+    c, s = np.array([8.5, 19.5, 22.0]), 22.5
+    want = o.affine_normal_equations(mov, tgt, m[:3], 1.3, -2.0, stride, c, s)
+    got = normal_equations(torch.as_tensor(mov, device=device), torch.as_tensor(tgt, device=device), m, 1.3, -2.0,
+                           stride, c, s)
+    assert got[3] == want[3] and got[3] > 500
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-9, atol=1e-9 * np.abs(want[0]).max())
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-9, atol=1e-9 * np.abs(want[1]).max())
+    assert got[2] == pytest.approx(want[2], rel=1e-10)
+    again = normal_equations(torch.as_tensor(mov, device=device), torch.as_tensor(tgt, device=device), m, 1.3, -2.0,
+                             stride, c, s)
+    assert np.array_equal(again[0], got[0]) and np.array_equal(again[1], got[1])     # fixed summation order
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    dict(model="affine", true=_tilted((32, 64, 72), tilt=3.0)),
+    dict(model="affine", true=_tilted((32, 64, 72), tilt=-2.0, scale=(1.02, 0.98, 1.0), shift=(3.0, -7.0, 11.0))),  # big shift: PCC start
+    dict(model="translation", true=_tilted((32, 64, 72), tilt=0.0, scale=(1, 1, 1), shift=(2.25, -4.5, 6.75))),
+])
+def test_estimate_recovers_known_transforms_and_closes_the_register_loop(device, case):
+    """estimate -> apply: the estimated matrix resamples the moving volume onto the target (which was
+    made by the oracle from the true matrix, with a gain and an offset)."""
+    import torch
+
+    from shrimpy_amd.estimate import estimate_affine_zyx
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    shape = (32, 64, 72)
+    mov = _scene(7, shape, n=60)
+    tgt = (1.7 * o.affine_apply_4x4(mov, case["true"], shape) + 5).astype(np.float32)
+    est = estimate_affine_zyx(torch.as_tensor(mov, device=device), torch.as_tensor(tgt, device=device), model=case["model"])
+    assert est.converged and est.n_samples > 0.5 * np.prod(shape)
+    corners = np.array([[z, y, x, 1.0] for z in (0, shape[0] - 1) for y in (0, shape[1] - 1) for x in (0, shape[2] - 1)])
+    assert np.abs(corners @ (est.affine_transform_zyx - case["true"]).T).max() < 0.02      # voxels, anywhere in the volume
+    assert est.gain == pytest.approx(1.7, rel=1e-3) and est.offset == pytest.approx(5.0, abs=0.1)
+    warped = apply_affine_transform_zyx(torch.as_tensor(mov, device=device), est.affine_transform_zyx, shape)
+    resid = (est.gain * warped + est.offset).cpu().numpy() - tgt
+    inside = o.affine_apply_4x4(np.ones(shape, np.float32), case["true"], shape) > 0.999
+    assert np.sqrt(np.mean(resid[inside] ** 2)) < 0.02 * tgt.std()
+    # the numpy oracle, started from the same PCC-free initial guess where that converges, agrees
+    if case["model"] == "affine" and np.abs(case["true"][:3, 3]).max() < 5:
+        ref, _, _, _ = o.estimate_affine(mov, tgt, levels=((4, 2.0), (2, 1.0), (1, 0.0)))
+        assert np.abs(corners @ (est.affine_transform_zyx - ref).T).max() < 0.02
+
+
+@pytest.mark.gpu
+def test_estimate_errors(device):
+    import torch
+
+    from shrimpy_amd._lib import LsrError
+    from shrimpy_amd.estimate import estimate_affine_zyx, normal_equations
+
+    a = torch.zeros((8, 8, 8), device=device)
+    far = np.eye(4)
+    far[:3, 3] = 100
+    with pytest.raises(LsrError, match="samples"):
+        estimate_affine_zyx(a, a, initial=far)
+    with pytest.raises(LsrError):
+        normal_equations(a.cpu(), a, np.eye(4))
+    with pytest.raises(LsrError):
+        normal_equations(a, a, np.eye(4), stride=0)
+
+
+@pytest.mark.gpu
+def test_cli_estimate_then_register_store_to_store(tmp_path, device):
+    """The two CLI commands chained: ``estimate-registration`` writes the YAML, ``register`` applies it
+    to the source channel only; the registered channel then matches the target channel."""
+    from click.testing import CliRunner
+
+    from shrimpy_amd.cli import cli
+    from shrimpy_amd.io.omezarr import open_ome_zarr
+
+    shape = (32, 64, 72)
+    true = _tilted(shape, tilt=2.0, shift=(1.0, -3.0, 4.0))
+    mov = _scene(11, shape, n=60)
+    tgt = o.affine_apply_4x4(mov, true, shape).astype(np.float32)
+    with open_ome_zarr(tmp_path / "pair.zarr", layout="hcs", mode="w", channel_names=["LF", "LS"],
+                       prefer_iohub=False) as plate:
+        arr = plate.create_position("A", "1", "0").create_zeros("0", shape=(1, 2) + shape, dtype="float32")
+        arr.write_volume(0, 0, tgt)
+        arr.write_volume(0, 1, mov)
+    run = CliRunner()
+    r = run.invoke(cli, ["estimate-registration", "-s", str(tmp_path / "pair.zarr"), "-t", str(tmp_path / "pair.zarr"),
+                         "-o", str(tmp_path / "register.yml"), "--source-channel", "LS", "--target-channel", "LF",
+                         "--no-intensity"])
+    assert r.exit_code == 0, (r.output, r.exception)
+    r = run.invoke(cli, ["register", "-i", str(tmp_path / "pair.zarr"), "-c", str(tmp_path / "register.yml"),
+                         "-o", str(tmp_path / "registered.zarr")])
+    assert r.exit_code == 0, (r.output, r.exception)
+    with open_ome_zarr(tmp_path / "registered.zarr", prefer_iohub=False) as plate:
+        out = plate["A/1/0"]["0"]
+        np.testing.assert_array_equal(out.read_volume(0, 0), tgt)                 # the target channel: untouched
+        reg = out.read_volume(0, 1)
+    inside = o.affine_apply_4x4(np.ones(shape, np.float32), true, shape) > 0.999
+    assert np.sqrt(np.mean((reg - tgt)[inside] ** 2)) < 0.02 * tgt.std()
