@@ -50,11 +50,10 @@ struct BoxArgs {
   float cval;
   int ty, tx, tx_shift;      // block rows / columns (powers of two; TZ is the template parameter)
   int box_z, box_y, box_x;   // staged box (planes, rows, floats per row: a multiple of 4)
-  int n_loads;               // ceil(box chunks / 512)
   float inv_cx, inv_by;      // 1 / (box_x / 4), 1 / box_y  (index -> (plane, row, chunk) without a divide)
   int tz_n, ty_n, tx_n;      // blocks per axis
   int pz_n, py_n, px_n;      // patches per axis
-  int per_xcd;               // workgroups per XCD (padded grid / 8)
+  int per_xcd;               // blocks per XCD (padded grid / 8)
   int probe;                 // diagnostics (-DLSR_BOX_PROBES, env LSR_BOX_PROBE): 1 = no staging, 3 = staging + stores only
 };
 
@@ -101,88 +100,88 @@ __device__ __forceinline__ Tap axis_tap(double c, double last) {
   return t;
 }
 
-// DEP: bit k set = source coordinate k (z, y, x) depends on zo.  A coordinate that does not is
-// worked out once per pixel instead of once per voxel (a tilt about y leaves y_in free of zo, a tilt
-// about x leaves x_in).
-template <bool F32, int TZ, int DEP>
-__global__ __launch_bounds__(kThreads, 4) void affine_box_kernel(BoxArgs p) {
-  constexpr int P = kBlockVoxels / TZ / kThreads;   // output pixels per thread
-  static_assert(P >= 1 && P * TZ * kThreads == kBlockVoxels, "block shape");
-  extern __shared__ f32x4 smem4[];
-  const float* const smem = reinterpret_cast<const float*>(smem4);
-  const unsigned lds_base =
-      static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) char*)smem4));
+// One block of the launch: its output origin, the origin of its source box, and whether it exists
+// (the patch grid is padded) / sees anything of the moving volume.
+struct Blk {
+  int z0, y0, x0;
+  int zlo, ylo, xlo;
+  bool valid, blind;
+};
 
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  // ---- which block: workgroups b, b + 8, ... share an XCD (round-robin dispatch); give every XCD
-  // a contiguous run of the patch-major order, z fastest inside a patch
-  const int b = blockIdx.x;
-  const int g = (b & 7) * p.per_xcd + (b >> 3);
+// Block g of the XCD-ordered list: patch-major, z fastest inside a 4 x 4 x 4 patch.
+template <int TZ>
+__device__ __forceinline__ Blk locate(const BoxArgs& p, int g) {
+  Blk b;
   const int patch = g >> 6, inner = g & 63;
   const int pz = patch % p.pz_n, py = (patch / p.pz_n) % p.py_n, px = patch / (p.pz_n * p.py_n);
   const int bz = pz * kPatch + (inner & 3), by = py * kPatch + ((inner >> 2) & 3), bx = px * kPatch + (inner >> 4);
-  if (bz >= p.tz_n || by >= p.ty_n || bx >= p.tx_n) return;   // padding of the patch grid (wave-uniform)
-  const int z0 = bz * TZ, y0 = by * p.ty, x0 = bx * p.tx;
-
-  // ---- source box of the block -------------------------------------------------------------
-  const int lo[3] = {z0, y0, x0};
-  const int hi[3] = {min(z0 + TZ, p.Zo) - 1, min(y0 + p.ty, p.Yo) - 1, min(x0 + p.tx, p.Xo) - 1};
+  b.valid = bz < p.tz_n && by < p.ty_n && bx < p.tx_n;   // (padding of the patch grid; wave-uniform)
+  b.z0 = bz * TZ; b.y0 = by * p.ty; b.x0 = bx * p.tx;
+  const int lo[3] = {b.z0, b.y0, b.x0};
+  const int hi[3] = {min(b.z0 + TZ, p.Zo) - 1, min(b.y0 + p.ty, p.Yo) - 1, min(b.x0 + p.tx, p.Xo) - 1};
   double zmin, zmax, ymin, ymax, xmin, xmax;
   corner_range(p.m + 0, lo, hi, zmin, zmax);
   corner_range(p.m + 4, lo, hi, ymin, ymax);
   corner_range(p.m + 8, lo, hi, xmin, xmax);
   const double Zl = static_cast<double>(p.Zi - 1), Yl = static_cast<double>(p.Yi - 1), Xl = static_cast<double>(p.Xi - 1);
-  const int zlo = static_cast<int>(fmin(fmax(floor(zmin), 0.0), Zl));
-  const int ylo = static_cast<int>(fmin(fmax(floor(ymin), 0.0), Yl));
-  const int xlo = static_cast<int>(fmin(fmax(floor(xmin), 0.0), Xl)) & ~3;
+  b.zlo = static_cast<int>(fmin(fmax(floor(zmin), 0.0), Zl));
+  b.ylo = static_cast<int>(fmin(fmax(floor(ymin), 0.0), Yl));
+  b.xlo = static_cast<int>(fmin(fmax(floor(xmin), 0.0), Xl)) & ~3;
   // a block that sees nothing of the volume: every voxel is cval, nothing to stage
-  const bool blind = zmax < 0.0 || zmin > Zl || ymax < 0.0 || ymin > Yl || xmax < 0.0 || xmin > Xl;
+  b.blind = zmax < 0.0 || zmin > Zl || ymax < 0.0 || ymin > Yl || xmax < 0.0 || xmin > Xl;
+  return b;
+}
 
+// Issue the LDS-DMA of a block's source box: chunk e = tid + 512 k, LDS image linear in e.
+template <int NT>
+__device__ __forceinline__ void stage(const BoxArgs& p, const Blk& b, unsigned lds_byte_base, int tid, int wave) {
+  const int box_x = p.box_x, box_y = p.box_y, box_z = p.box_z;
+  const int chunks_x = box_x >> 2;
+  const int n_chunks = box_z * box_y * chunks_x;
+  const unsigned plane_i = static_cast<unsigned>(p.Yi) * static_cast<unsigned>(p.Xi);
+  // 32-bit byte offsets are taken from the box's first source plane (host: box_z planes < 4 GiB)
+  const float* const src = p.in + static_cast<int64_t>(b.zlo) * plane_i;
+  const int n_loads = (n_chunks + NT - 1) / NT;
+  for (int k = 0; k < n_loads; ++k) {
+    const int e = min(tid + k * NT, n_chunks - 1);
+    // e -> (plane, row, chunk); the reciprocals are exact enough for e < 2^20 with the fix-up
+    int row = static_cast<int>((static_cast<float>(e) + 0.5f) * p.inv_cx);
+    row -= (row * chunks_x > e);
+    row += ((row + 1) * chunks_x <= e);
+    const int c4 = e - row * chunks_x;
+    int pl = static_cast<int>((static_cast<float>(row) + 0.5f) * p.inv_by);
+    pl -= (pl * box_y > row);
+    pl += ((pl + 1) * box_y <= row);
+    const int r = row - pl * box_y;
+    const unsigned gz = static_cast<unsigned>(min(b.zlo + pl, p.Zi - 1) - b.zlo);   // past the volume: duplicates
+    const unsigned gy = static_cast<unsigned>(min(b.ylo + r, p.Yi - 1));
+    const unsigned gx = static_cast<unsigned>(min(b.xlo + 4 * c4, p.Xi - 4));
+    const unsigned voff = (gz * plane_i + gy * static_cast<unsigned>(p.Xi) + gx) * 4u;
+    if (wave * 64 + k * NT < n_chunks)   // wave-uniform: whole waves of chunks
+      glds_x4(src, voff, __builtin_amdgcn_readfirstlane(lds_byte_base + static_cast<unsigned>((k * NT + wave * 64) * 16)));
+  }
+}
+
+// DEP: bit k set = source coordinate k (z, y, x) depends on zo.  A coordinate that does not is
+// worked out once per pixel instead of once per voxel (a tilt about y leaves y_in free of zo, a tilt
+// about x leaves x_in).
+template <bool F32, int TZ, int DEP, int NT>
+__device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const float* smem, int tid, int probe) {
+  constexpr int P = kBlockVoxels / TZ / NT;   // output pixels per thread
+  static_assert(P >= 1 && P * TZ * NT == kBlockVoxels, "block shape");
+  const int z0 = b.z0, y0 = b.y0, x0 = b.x0, zlo = b.zlo, ylo = b.ylo, xlo = b.xlo;
   const int box_x = p.box_x, box_y = p.box_y, box_z = p.box_z;
   const int plane_floats = box_y * box_x;
+  const double Zl = static_cast<double>(p.Zi - 1), Yl = static_cast<double>(p.Yi - 1), Xl = static_cast<double>(p.Xi - 1);
 
-  // ---- staging: chunk e = tid + 512 k of the box, LDS image linear in e ---------------------
-#ifdef LSR_BOX_PROBES
-  const int probe = p.probe;
-#else
-  constexpr int probe = 0;
-#endif
-  if (!blind && probe != 1) {
-    const int chunks_x = box_x >> 2;
-    const int n_chunks = box_z * box_y * chunks_x;
-    const unsigned plane_i = static_cast<unsigned>(p.Yi) * static_cast<unsigned>(p.Xi);
-    // 32-bit byte offsets are taken from the box's first source plane (host: box_z planes < 4 GiB)
-    const float* const src = p.in + static_cast<int64_t>(zlo) * plane_i;
-    for (int k = 0; k < p.n_loads; ++k) {
-      const int e = min(tid + k * kThreads, n_chunks - 1);
-      // e -> (plane, row, chunk); the reciprocals are exact enough for e < 2^20 with the fix-up
-      int row = static_cast<int>((static_cast<float>(e) + 0.5f) * p.inv_cx);
-      row -= (row * chunks_x > e);
-      row += ((row + 1) * chunks_x <= e);
-      const int c4 = e - row * chunks_x;
-      int pl = static_cast<int>((static_cast<float>(row) + 0.5f) * p.inv_by);
-      pl -= (pl * box_y > row);
-      pl += ((pl + 1) * box_y <= row);
-      const int r = row - pl * box_y;
-      const unsigned gz = static_cast<unsigned>(min(zlo + pl, p.Zi - 1) - zlo);   // past the volume: duplicates
-      const unsigned gy = static_cast<unsigned>(min(ylo + r, p.Yi - 1));
-      const unsigned gx = static_cast<unsigned>(min(xlo + 4 * c4, p.Xi - 4));
-      const unsigned voff = (gz * plane_i + gy * static_cast<unsigned>(p.Xi) + gx) * 4u;
-      if (wave * 64 + k * kThreads < n_chunks)   // wave-uniform: whole waves of chunks
-        glds_x4(src, voff, lds_base + static_cast<unsigned>((k * kThreads + wave * 64) * 16));
-    }
-  }
-
-  // ---- per-pixel constants while the box is in flight ----------------------------------------
+  // ---- per-pixel constants -------------------------------------------------------------------
   // pixel q = tid + 512 j of the block's TY x TX plane: consecutive lanes are consecutive xo
   unsigned pix[P];   // yo * Xo + xo: the output offset inside a plane (host: Yo * Xo < 2^31)
   double tzy[P], tyy[P], txy[P], tzx[P], tyx[P], txx[P];
   bool ok[P];
 #pragma unroll
   for (int j = 0; j < P; ++j) {
-    const int q = tid + j * kThreads;
+    const int q = tid + j * NT;
     const int yo = y0 + (q >> p.tx_shift), xo = x0 + (q & (p.tx - 1));
     ok[j] = yo < p.Yo && xo < p.Xo;
     pix[j] = static_cast<unsigned>(yo) * static_cast<unsigned>(p.Xo) + static_cast<unsigned>(xo);
@@ -204,10 +203,7 @@ __global__ __launch_bounds__(kThreads, 4) void affine_box_kernel(BoxArgs p) {
     }
   }
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const bool live = !blind;
+  const bool live = !b.blind;
   // The upper neighbour of a tap is always read one element / row / plane further on, also when it
   // lies past the volume (coordinate exactly on the last index): its weight is then exactly 0, and
   // what the staging put there is a duplicate of in-volume data, so the product is the same zero the
@@ -307,6 +303,38 @@ __global__ __launch_bounds__(kThreads, 4) void affine_box_kernel(BoxArgs p) {
   }
 }
 
+#ifdef LSR_BOX_PROBES
+#define LSR_BOX_PROBE_VALUE(p) ((p).probe)
+#else
+#define LSR_BOX_PROBE_VALUE(p) 0
+#endif
+
+// One block per workgroup.  Two or three such workgroups share a CU when the box is under 78 / 52 KB:
+// one computes while another's box is in flight.  (A persistent, double-buffered form of the same walk
+// -- one workgroup per CU, the DMA of block n + 1 issued before the arithmetic of block n -- was
+// measured at 512 and at 1024 threads and ran 8-30 % SLOWER: 3.97 / 3.09 ms and 3.83 / 2.86 ms
+// against 3.30 / 2.30 ms (exact / f32, 1.5 deg tilt, config-3 size).  The arithmetic wants more
+// resident waves than one workgroup brings)
+template <bool F32, int TZ, int DEP>
+__global__ __launch_bounds__(kThreads, 4) void affine_box_kernel(BoxArgs p) {
+  extern __shared__ f32x4 smem4[];
+  const float* const smem = reinterpret_cast<const float*>(smem4);
+  const unsigned lds_base =
+      static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) char*)smem4));
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int probe = LSR_BOX_PROBE_VALUE(p);
+  // workgroups b, b + 8, ... share an XCD (round-robin dispatch); every XCD gets a contiguous run of
+  // the patch-major block order
+  const int bid = blockIdx.x;
+  const Blk b = locate<TZ>(p, (bid & 7) * p.per_xcd + (bid >> 3));
+  if (!b.valid) return;
+  if (!b.blind && probe != 1) stage<kThreads>(p, b, lds_base, tid, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  compute<F32, TZ, DEP, kThreads>(p, b, smem, tid, probe);
+}
+
 struct BoxShape {
   int tz, ty, tx;
   int bz, by, bx;
@@ -403,8 +431,6 @@ bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, floa
   p.ty = sh.ty; p.tx = sh.tx;
   p.tx_shift = sh.tx == 32 ? 5 : (sh.tx == 64 ? 6 : 7);
   p.box_z = sh.bz; p.box_y = sh.by; p.box_x = sh.bx;
-  const int chunks = sh.bz * sh.by * (sh.bx / 4);
-  p.n_loads = static_cast<int>(ceil_div(chunks, kThreads));
   p.inv_cx = 1.0f / static_cast<float>(sh.bx / 4);
   p.inv_by = 1.0f / static_cast<float>(sh.by);
   p.tz_n = static_cast<int>(ceil_div(Zo, sh.tz));
