@@ -463,7 +463,8 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
     # ---- store to store: T x P units through cli.run_store (staged path) ----
     store = None
     if not args.no_store_leg:
-        n_t, n_p = (1, max(4, 2 * world)) if args.workload == "config4" else (3, max(2, world))
+        # enough units that the run is its steady state, not the pipeline's fill and drain
+        n_t, n_p = (1, max(12, 3 * world)) if args.workload == "config4" else (4, max(3, world))
         scratch = Path(tempfile.mkdtemp(prefix="lsr_bench_", dir=args.scratch))
         root = [str(scratch)]
         if world > 1:
@@ -491,7 +492,7 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
                 "positions": n_p, "timepoints": n_t, "units": units, "seconds": res["job_seconds"],
                 "s_per_unit": res["job_seconds"] / max(units, 1) * world,
                 "voxels_per_s": units * n_in / res["job_seconds"],
-                "io": (f"native OME-Zarr reader/writer, uncompressed chunks (1,1,32,ny,nx), scratch {root.parent}, "
+                "io": (f"native OME-Zarr reader/writer, uncompressed chunks (input (1,1,32,ny,nx), output ~64 MB), scratch {root.parent}, "
                        "input from the page cache; pinned staging slots + copy streams (cli.run_store)"),
             }
             if world > 1:

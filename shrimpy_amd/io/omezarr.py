@@ -859,7 +859,14 @@ def create_level(position, shape, dtype, scale, chunks=None, name: str = "0", **
     ``scripts/measure_psf.py:273-287``)."""
     shape = tuple(int(n) for n in shape)
     if chunks is None:
-        chunks = (1, 1, min(32, shape[2]), shape[3], shape[4])   # tracking.py:1362
+        # the reference's (1, 1, min(32, nz), ny, nx) (tracking.py:1362), with the z extent cut down
+        # where that would make chunks of hundreds of MB: a deskewed (86, 2048, 2491) float32 volume
+        # in 32-plane chunks is three 650 MB files, and buffered writes to ONE file serialise on its
+        # inode lock (measured: 6 GB/s, 0.29 s per volume against 0.03 s of kernels); ~64 MB chunks
+        # are 29 files that sixteen threads write side by side
+        plane_bytes = shape[3] * shape[4] * np.dtype(dtype).itemsize
+        zc = max(1, min(32, shape[2], (64 << 20) // max(plane_bytes, 1)))
+        chunks = (1, 1, zc, shape[3], shape[4])
     if isinstance(position, Position):
         return position.create_zeros(name, shape=shape, dtype=dtype, chunks=chunks, scale=scale, **kw)
     from iohub.ngff.models import TransformationMeta
