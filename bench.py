@@ -214,7 +214,7 @@ def pmc_traffic(key, workload, kernel_symbol):
     have = kernel_source_sha16()
     if rec.get("source_sha16") != have:
         return None, f"stale: record {rec.get('source_sha16')} != build {have}"
-    if rec.get("kernel") and kernel_symbol and not kernel_symbol.startswith(rec["kernel"].split("(")[0][:24]):
+    if kernel_symbol and kernel_symbol not in (rec.get("kernel") or ""):
         return None, f"record is for kernel {rec.get('kernel')!r}"
     return rec.get("hbm_bytes_per_launch"), f"{rec.get('source')} @ {rec.get('git_head', '?')}"
 
