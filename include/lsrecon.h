@@ -109,6 +109,11 @@ int lsr_affine_kernel_choice(int64_t Yi, int64_t Xi, const double M[12], int mod
  * whose source box of an 8 x 16 x 64 output block fits in 150 KB of LDS, Xi a multiple of 4);
  * 0 = the general gather kernel. Results are identical whichever runs. */
 int lsr_affine_path(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int mode);
+/* Host-side geometry of the box kernel for this matrix: out6 = {block z, y, x extents; staged source
+ * box planes, rows, floats per row}; returns 1, or 0 when the box kernel does not apply.  (What the
+ * CPU tests check the kernel's coverage claim against: every tap of every voxel of a block lies inside
+ * the box spanned from the block's two extreme corners.) */
+int lsr_affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int* out6);
 
 /*
  * Affine registration, estimate half (no reference symbol, docs/data_structure.md:58-62).

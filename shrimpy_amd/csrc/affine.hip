@@ -212,6 +212,7 @@ bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, floa
                        int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32, hipStream_t s);
 bool affine_box_geometry(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int* box_z, int* box_y,
                          int* box_x, int64_t* lds_bytes);
+bool affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int out6[6]);
 }  // namespace lsr
 
 extern "C" int lsr_affine_kernel_choice(int64_t Yi, int64_t Xi, const double M[12], int mode) {
@@ -232,6 +233,11 @@ extern "C" int lsr_affine_path(int64_t Zi, int64_t Yi, int64_t Xi, const double 
   if (lsr::affine_planar_geometry(Yi, Xi, M, &a, &b, &c, &lds)) return 1;
   if (lsr::affine_box_geometry(Zi, Yi, Xi, M, &a, &b, &c, &lds)) return 2;
   return 0;
+}
+
+extern "C" int lsr_affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int* out6) {
+  if (M == nullptr || out6 == nullptr) return 0;
+  return lsr::affine_box_shape(Zi, Yi, Xi, M, out6) ? 1 : 0;
 }
 
 extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out,

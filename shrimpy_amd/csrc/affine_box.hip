@@ -418,6 +418,13 @@ bool affine_box_geometry(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12],
   return true;
 }
 
+bool affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int out6[6]) {
+  BoxShape s;
+  if (!pick_shape(Zi, Yi, Xi, M, &s)) return false;
+  out6[0] = s.tz; out6[1] = s.ty; out6[2] = s.tx; out6[3] = s.bz; out6[4] = s.by; out6[5] = s.bx;
+  return true;
+}
+
 bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
                        int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32, hipStream_t s) {
   BoxShape sh;

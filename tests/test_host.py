@@ -373,3 +373,102 @@ def test_deskew_with_matrix_rejects_an_unknown_border():
 
     with pytest.raises(ValueError, match="border"):
         deskew_with_matrix(torch.zeros(4, 4, 4), np.zeros((3, 4)), (4, 4, 4), border="wrap")
+
+
+# ---------------------------------------------------------------- host-side index math of the kernels
+# (the entry points below run on the host; no GPU is touched)
+
+
+def _box_shape(shape, m):
+    import ctypes
+
+    from shrimpy_amd import _lib
+
+    out = (ctypes.c_int * 6)()
+    ok = _lib.call_value("lsr_affine_box_shape", shape[0], shape[1], shape[2], _lib.matrix12(geometry.as_matrix_3x4(m)), out)
+    return tuple(out) if ok else None
+
+
+def _random_affine(rng, tilt=0.25):
+    th = np.deg2rad(rng.uniform(-20, 20))
+    m = np.eye(4)
+    m[:3, :3] = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]]) @ np.diag(
+        rng.uniform(0.6, 1.4, 3) * rng.choice([1.0, 1.0, -1.0], 3))
+    m[0, 1:3] = rng.uniform(-tilt, tilt, 2)
+    m[1:3, 0] = rng.uniform(-tilt, tilt, 2)
+    m[:3, 3] = rng.uniform(-20, 200, 3)
+    return m
+
+
+def test_affine_box_covers_every_tap_of_every_block():
+    """The box kernel stages, per block of output voxels, the source box spanned from the block's two
+    extreme corners (no slack: the coordinate expression is monotone in each index).  Restated in numpy
+    float64 in scipy's operation order: for random matrices and random block positions, every voxel's
+    lower tap and its upper neighbour lie inside the box the library sizes."""
+    rng = np.random.default_rng(12)
+    shape = (300, 400, 512)
+    checked = 0
+    for _ in range(200):
+        m = _random_affine(rng)
+        got = _box_shape(shape, m)
+        if got is None:
+            continue
+        tz, ty, tx, bz, by, bx = got
+        assert tz * ty * tx == 8192 and bx % 4 == 0
+        z0, y0, x0 = (int(rng.integers(0, 30)) * tz, int(rng.integers(0, 20)) * ty, int(rng.integers(0, 12)) * tx)
+        zo, yo, xo = np.meshgrid(np.arange(z0, z0 + tz, dtype=np.float64), np.arange(y0, y0 + ty, dtype=np.float64),
+                                 np.arange(x0, x0 + tx, dtype=np.float64), indexing="ij")
+        for axis, n_box in enumerate((bz, by, bx)):
+            r = m[axis]
+            c = ((zo * r[0] + yo * r[1]) + xo * r[2]) + r[3]          # scipy's order, every step rounded
+            lo = [z0 if r[0] >= 0 else z0 + tz - 1, y0 if r[1] >= 0 else y0 + ty - 1, x0 if r[2] >= 0 else x0 + tx - 1]
+            hi = [z0 + tz - 1 if r[0] >= 0 else z0, y0 + ty - 1 if r[1] >= 0 else y0, x0 + tx - 1 if r[2] >= 0 else x0]
+            cmin = ((lo[0] * r[0] + lo[1] * r[1]) + lo[2] * r[2]) + r[3]
+            cmax = ((hi[0] * r[0] + hi[1] * r[1]) + hi[2] * r[2]) + r[3]
+            assert cmin == c.min() and cmax == c.max()               # the corners ARE the extremes, exactly
+            origin = np.floor(cmin) - (np.floor(cmin) % 4 if axis == 2 else 0)   # x origin: 16-byte aligned
+            assert np.floor(c).max() + 1 - origin <= n_box - 1
+        checked += 1
+    assert checked > 100
+
+
+def test_affine_path_is_decided_on_the_host():
+    from shrimpy_amd import _lib
+
+    def path(shape, m, mode=_lib.MODE_CONSTANT):
+        return _lib.call_value("lsr_affine_path", shape[0], shape[1], shape[2], _lib.matrix12(geometry.as_matrix_3x4(m)), mode)
+
+    ident = np.eye(4)
+    tilt = np.eye(4)
+    tilt[0, 2], tilt[2, 0] = -0.05, 0.05
+    assert path((64, 256, 256), ident) == 1 and path((64, 256, 256), tilt) == 2
+    assert path((64, 256, 254), tilt) == 0 and path((64, 256, 256), tilt, _lib.MODE_GRID_CONSTANT) == 0
+    big = np.diag([9.0, 9.0, 9.0, 1.0])
+    big[0, 2] = 0.1
+    assert path((64, 256, 256), big) == 0 and _box_shape((64, 256, 256), big) is None
+    # a tilt about y wants a short block along x, a tilt about x a short block along y
+    about_y, about_x = np.eye(4), np.eye(4)
+    about_y[0, 2], about_x[0, 1] = 0.3, 0.3
+    sy, sx = _box_shape((64, 256, 256), about_y), _box_shape((64, 256, 256), about_x)
+    assert sy[2] <= sx[2] and sx[1] <= sy[1]
+
+
+def test_padded_shape_and_fused_support_tables():
+    """``lsr_sep_padded_shape``: logical origin at row 2C / column 32, pitch a multiple of 32 floats,
+    rows a whole number of tiles plus 4C; ``lsr_rl_sep_fused_supported``: odd tap counts up to 15, the
+    spill-prone corner excluded."""
+    import ctypes
+
+    from shrimpy_amd import _lib
+
+    for (y, x, pz, py, px) in [(2048, 2270, 9, 7, 7), (100, 70, 3, 3, 3), (1, 1, 15, 15, 15), (33, 129, 5, 9, 3)]:
+        out = (ctypes.c_int64 * 4)()
+        _lib.call("lsr_sep_padded_shape", y, x, pz, py, px, out)
+        rows, pitch = out[0], out[1]
+        c = max(py, px) // 2
+        assert pitch % 32 == 0 and pitch >= x + 32 + 2 * c and rows >= y + 4 * c
+    assert tuple(_lib.call_value("lsr_sep_padded_shape", 2048, 2270, 9, 7, 7, (ctypes.c_int64 * 4)()) for _ in range(1)) == (0,)
+    ok = {(pz, pyx): _lib.call_value("lsr_rl_sep_fused_supported", pz, pyx, pyx) for pz in range(1, 17) for pyx in range(1, 17)}
+    assert ok[(9, 7)] == 1 and ok[(3, 3)] == 1 and ok[(15, 9)] == 1
+    assert ok[(15, 11)] == 0 and ok[(15, 15)] == 0          # would spill the accumulators
+    assert all(v == 0 for (pz, pyx), v in ok.items() if pz % 2 == 0 or pyx % 2 == 0 or pz > 15 or pyx > 15)
