@@ -234,6 +234,15 @@ def require_device_f32(t, name: str):
     return t
 
 
+def mark_written(t) -> None:
+    """Tell torch that ``t`` was written in place.  The kernels write through raw ``data_ptr()``s, which
+    torch's version counter does not see; anything that keys on ``t._version`` (the DynaTrack reference
+    cache, autograd's saved-tensor checks) would otherwise take a caller-supplied ``out=`` buffer for
+    unchanged.  A zero-length in-place op on a view bumps the shared counter and launches nothing."""
+    if t is not None and hasattr(t, "narrow") and t.dim() > 0:
+        t.narrow(0, 0, 0).zero_()
+
+
 def stream_ptr(device=None) -> int:
     """The current torch HIP stream of ``device`` as an integer ``hipStream_t``."""
     import torch

@@ -543,6 +543,7 @@ class RichardsonLucyPlan:
                 )
             if events:
                 events[1].record()
+        _lib.mark_written(x)
         return x
 
 

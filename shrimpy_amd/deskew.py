@@ -167,6 +167,7 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
             )
             if avg > 1:
                 _average_into(pre, out, avg, stream)
+    _lib.mark_written(out.full if hasattr(out, "logical_ptr") else out)
     return result
 
 

@@ -42,7 +42,7 @@ __all__ = [
     "_gaussian_blur_3d", "_multiotsu_threshold", "_binary_mask", "_center_of_mass", "_percentile",
     "_intensity_center_of_mass", "_intensity_center_of_mass_to_roi_center", "_multiotsu_center_of_mass",
     "_next_fast_len", "_match_shape", "_phase_cross_corr", "_centered_gaussian_blob", "_roi_center_pcc",
-    "_multiotsu_pcc", "set_spectrum_cache_bytes", "ShiftSettings", "SegmentationSettings", "RoiCenterSettings",
+    "_multiotsu_pcc", "set_spectrum_cache_bytes", "invalidate_reference", "ShiftSettings", "SegmentationSettings", "RoiCenterSettings",
     "_limit_shifts_zyx", "compute_shift", "TRACKING_METHODS",
 ]
 
@@ -288,8 +288,13 @@ class _ReferenceCache:
     of ``_multiotsu_center_of_mass``) -- repeats identical work.  Entries are keyed by the tensor
     OBJECT (weak reference; the entries go when the tensor does) plus a tag, and checked against
     the tensor's version counter, storage and shape, so an in-place edit or a different tensor is a
-    miss, never a stale hit.  Byte-bounded LRU over the device tensors it holds;
-    ``set_spectrum_cache_bytes(0)`` turns it off.
+    miss, never a stale hit.  This package's own kernels write through raw pointers, which the version
+    counter does not see: every entry point that takes ``out=`` therefore bumps it
+    (``_lib.mark_written``); a caller that rewrites a reference buffer by other means calls
+    :func:`invalidate_reference`.  Byte-bounded LRU over the device tensors it holds (4 GiB by
+    default: the spectrum of one config-2 reference); ``set_spectrum_cache_bytes(0)`` turns it off --
+    the reference itself keeps nothing and calls ``empty_cache()`` after every correlation
+    (``tracking.py:1097-1102``).
     """
 
     def __init__(self, max_bytes: int):
@@ -345,13 +350,22 @@ class _ReferenceCache:
         self._bytes += nbytes
 
 
-_spectra = _ReferenceCache(8 << 30)
+_spectra = _ReferenceCache(4 << 30)
 
 
 def set_spectrum_cache_bytes(n: int) -> None:
-    """Upper bound on device memory held by cached reference results (default 8 GiB; 0 = off)."""
+    """Upper bound on device memory held by cached reference results (default 4 GiB; 0 = off)."""
     _spectra.max_bytes = int(n)
     _spectra.clear()
+
+
+def invalidate_reference(t=None) -> None:
+    """Forget what was cached for the reference tensor ``t`` (all references when ``None``): call it
+    after refreshing a reference volume in place by a route torch's version counter cannot see."""
+    if t is None:
+        _spectra.clear()
+    else:
+        _spectra._drop_tensor(id(t))
 
 
 def _next_fast_len(n: int) -> int:

@@ -43,6 +43,7 @@ class FlatFieldPattern:
         with torch.cuda.device(vol.device):
             _lib.call("lsr_flatfield_apply_u16" if u16 else "lsr_flatfield_apply_f32", vol.data_ptr(), self.pattern.data_ptr(),
                       self.mean.data_ptr(), out.data_ptr(), z, y, x, _lib.stream_ptr(vol.device))
+        _lib.mark_written(out)
         return out
 
 

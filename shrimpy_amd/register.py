@@ -68,6 +68,7 @@ def apply_affine_transform_zyx(moving, affine_transform_zyx, output_shape_zyx=No
             _MODES[mode] | (0 if exact else _lib.MODE_F32_INTERP),
             _lib.stream_ptr(moving.device),
         )
+    _lib.mark_written(out)
     return out
 
 

@@ -279,3 +279,32 @@ def test_compute_shift_dispatcher_matches_the_reference_updater(device, golden):
         d.compute_shift(a, b, "nope")
     with pytest.raises(Exception):
         d.ShiftSettings(maximum=1.0, typo=1)
+
+
+def test_reference_cache_sees_kernels_that_write_through_out(device):
+    """A reference refreshed IN PLACE by one of this package's kernels (``out=``) must be a cache miss:
+    the kernels write through raw pointers, so the entry points bump torch's version counter."""
+    import torch
+
+    from shrimpy_amd import dynatrack as d
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    rng = np.random.default_rng(21)
+    a = torch.as_tensor(rng.random((8, 32, 32)).astype(np.float32), device=device)
+    ref = a.clone()
+    mov = torch.roll(a, (1, 2, -3), dims=(0, 1, 2))
+    assert d._phase_cross_corr(ref, mov) == (1, 2, -3)
+    hits = d._spectra.hits
+    assert d._phase_cross_corr(ref, mov) == (1, 2, -3) and d._spectra.hits == hits + 1
+    # refresh the reference buffer in place with a shifted volume, through the affine kernel's out=
+    shift = np.eye(4)
+    shift[:3, 3] = [0.0, 0.0, 1.0]
+    v0 = ref._version
+    apply_affine_transform_zyx(mov.clone(), shift, out=ref)
+    assert ref._version > v0
+    want = d._phase_cross_corr(ref.clone(), mov)           # an uncached tensor with the same content
+    misses = d._spectra.misses
+    assert d._phase_cross_corr(ref, mov) == want and d._spectra.misses == misses + 1
+    d.invalidate_reference(ref)
+    misses = d._spectra.misses
+    assert d._phase_cross_corr(ref, mov) == want and d._spectra.misses == misses + 1
