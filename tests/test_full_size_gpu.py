@@ -170,6 +170,54 @@ def test_affine_full_size_matches_the_oracle_on_output_blocks(device):
     torch.cuda.empty_cache()
 
 
+def test_affine_full_size_tilted_map_matches_the_oracle_on_output_blocks(device):
+    """Config 3 with a 3 degree tilt about y on top of its registration -- a map that couples z with
+    the plane, i.e. ``affine_box.hip`` at full size: output blocks against scipy run on the source box
+    they reach (at most one ulp: block-local fp64 coordinates), exact and f32 modes, and the f32 mode
+    keeps the exact mode's in / out-of-range decisions over the WHOLE volume."""
+    import torch
+
+    from shrimpy_amd import _lib
+    from shrimpy_amd.geometry import as_matrix_3x4
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    shape = (256, 2048, 2048)
+    m = _config3_matrix()
+    c3, s3 = np.cos(np.deg2rad(3.0)), np.sin(np.deg2rad(3.0))
+    m[:3, :3] = np.array([[c3, 0, -s3], [0, 1, 0], [s3, 0, c3]]) @ m[:3, :3]
+    assert _lib.call_value("lsr_affine_path", *shape, _lib.matrix12(as_matrix_3x4(m)), _lib.MODE_CONSTANT) == 2
+    g = torch.Generator(device=device).manual_seed(3001)
+    moving = torch.rand(shape, device=device, generator=g) * 1000 - 100
+    out = apply_affine_transform_zyx(moving, m, shape, cval=-3.0)
+    out32 = apply_affine_transform_zyx(moving, m, shape, cval=-3.0, exact=False)
+    assert torch.equal(out == -3.0, out32 == -3.0)
+    assert float((out - out32).abs().max()) <= 2e-5 * 1100
+    blocks = [((100, 1000, 900), (8, 40, 60)), ((60, 700, 1200), (9, 33, 70)), ((200, 1500, 400), (8, 40, 60)),
+              ((0, 0, 0), (8, 40, 60)), ((248, 2000, 1980), (8, 48, 68)), ((120, 8, 2040), (9, 30, 8))]
+    checked = 0
+    for origin, size in blocks:
+        origin, size = np.array(origin), np.array(size)
+        corners = np.array([[origin[i] + (size[i] - 1) * ((c >> i) & 1) for i in range(3)] for c in range(8)])
+        src = corners @ m[:3, :3].T + m[:3, 3]
+        lo = np.maximum(np.floor(src.min(0)).astype(int) - 2, 0)
+        hi = np.minimum(np.ceil(src.max(0)).astype(int) + 3, np.array(shape))
+        sl = tuple(slice(a, a + n) for a, n in zip(origin, size))
+        if np.any(hi - lo < 2):
+            assert bool((out[sl] == -3.0).all())
+            continue
+        if not (np.all((lo == 0) | (src.min(0) - lo >= 1)) and np.all((hi == shape) | (hi - 1 - src.max(0) >= 1))):
+            continue
+        crop = moving[tuple(slice(a, b) for a, b in zip(lo, hi))].contiguous().cpu().numpy()
+        want = o.affine_apply(crop, m[:3, :3], m[:3, :3] @ origin + m[:3, 3] - lo, tuple(size), cval=-3.0)
+        got = out[sl].cpu().numpy()
+        np.testing.assert_array_max_ulp(got, want, maxulp=1)
+        assert np.mean(got == want) > 0.95
+        checked += 1
+    assert checked >= 4
+    del moving, out, out32
+    torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------- the rows either side, full size
 
 
