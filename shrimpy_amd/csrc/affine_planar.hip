@@ -61,7 +61,7 @@ __device__ __forceinline__ double plane_coord(double yo, double xo, double m1, d
 }
 
 template <bool F32>
-__global__ __launch_bounds__(kThreads) void affine_planar_kernel(PlanarArgs p) {
+__global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p) {  // (two workgroups per CU: <= 128 VGPRs)
   extern __shared__ f32x4 smem4[];
   const float* const smem = reinterpret_cast<const float*>(smem4);
   const unsigned lds_base =
@@ -78,25 +78,27 @@ __global__ __launch_bounds__(kThreads) void affine_planar_kernel(PlanarArgs p) {
   const int x0 = tx * kTX, y0 = ty * kTY;
   const int zo_begin = zc * p.z_chunk, zo_end = min(zo_begin + p.z_chunk, p.Zo);
 
-  // ---- source box of the tile: extremes of a linear map sit at the tile's corners ------------
+  // ---- source box of the tile.  The coordinate expression is monotone in each index (every rounded
+  // product and sum is), so its minimum over the tile is the value at the corner that takes the low
+  // index where the coefficient is >= 0 and the high one where it is negative -- evaluated with the
+  // pixels' own expression it IS the smallest coordinate any pixel computes: no slack row or column.
   const int y1 = min(y0 + kTY, p.Yo) - 1, x1 = min(x0 + kTX, p.Xo) - 1;
-  double cy_min = 1e300, cy_max = -1e300, cx_min = 1e300, cx_max = -1e300;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const double yo = static_cast<double>((k & 1) ? y1 : y0), xo = static_cast<double>((k & 2) ? x1 : x0);
-    const double cy = plane_coord(yo, xo, p.b, p.c, p.ty), cx = plane_coord(yo, xo, p.d, p.e, p.tx);
-    cy_min = fmin(cy_min, cy); cy_max = fmax(cy_max, cy);
-    cx_min = fmin(cx_min, cx); cx_max = fmax(cx_max, cx);
-  }
-  // one element of slack each side: the per-pixel coordinates are rounded individually
-  const int ylo = static_cast<int>(fmin(fmax(floor(cy_min) - 1.0, 0.0), static_cast<double>(p.Yi - 1)));
-  const int xlo = static_cast<int>(fmin(fmax(floor(cx_min) - 1.0, 0.0), static_cast<double>(p.Xi - 1))) & ~3;
+  const double cy_min = plane_coord(static_cast<double>(p.b < 0.0 ? y1 : y0), static_cast<double>(p.c < 0.0 ? x1 : x0),
+                                    p.b, p.c, p.ty);
+  const double cx_min = plane_coord(static_cast<double>(p.d < 0.0 ? y1 : y0), static_cast<double>(p.e < 0.0 ? x1 : x0),
+                                    p.d, p.e, p.tx);
+  const int ylo = static_cast<int>(fmin(fmax(floor(cy_min), 0.0), static_cast<double>(p.Yi - 1)));
+  const int xlo = static_cast<int>(fmin(fmax(floor(cx_min), 0.0), static_cast<double>(p.Xi - 1))) & ~3;
   const int box_x = p.box_x, box_y = p.box_y;
   const int slot_floats = (box_y * box_x + 255) & ~255;  // whole waves of 16-byte chunks
 
   // ---- per-pixel in-plane taps, once ------------------------------------------------------
-  int idx00[kPts];        // LDS float index of (iy0, ix0) inside a slot
-  int step[kPts];         // bit 0: ix1 == ix0 + 1, bit 1: iy1 == iy0 + 1, bit 2: pixel inside
+  // The upper neighbour of a tap is always read one element / one row further on, also when it lies
+  // past the volume (coordinate exactly on the last index): its weight is then exactly 0 and what the
+  // staging put there is a duplicate of in-volume data -- the same zero product (finite inputs).  So
+  // the four in-plane taps of a source plane are two ds_read2_b32 at a fixed row stride.
+  int idx00[kPts];        // LDS byte offset of (iy0, ix0) inside a slot
+  bool ok[kPts];          // pixel inside the output and its coordinate inside the moving plane
   double wy0[kPts], wy1[kPts], wx0[kPts], wx1[kPts];
 #pragma unroll
   for (int i = 0; i < kPts; ++i) {
@@ -109,18 +111,18 @@ __global__ __launch_bounds__(kThreads) void affine_planar_kernel(PlanarArgs p) {
     const double ry = cy - fy, rx = cx - fx;
     wy0[i] = 1.0 - ry; wy1[i] = 1.0 - wy0[i];
     wx0[i] = 1.0 - rx; wx1[i] = 1.0 - wx0[i];
-    int iy0 = 0, ix0 = 0, st = 0;
+    int iy0 = 0, ix0 = 0;
     if (inside) {
-      iy0 = static_cast<int>(fy);
-      ix0 = static_cast<int>(fx);
-      st = 4 | (ix0 + 1 <= p.Xi - 1 ? 1 : 0) | (iy0 + 1 <= p.Yi - 1 ? 2 : 0);
       // the box covers every inside pixel's taps by construction (host sizes it from |b|,|c|,|d|,|e|)
-      iy0 = min(max(iy0 - ylo, 0), box_y - 2);
-      ix0 = min(max(ix0 - xlo, 0), box_x - 2);
+      iy0 = min(max(static_cast<int>(fy) - ylo, 0), box_y - 2);
+      ix0 = min(max(static_cast<int>(fx) - xlo, 0), box_x - 2);
     }
-    idx00[i] = iy0 * box_x + ix0;
-    step[i] = st;
+    idx00[i] = (iy0 * box_x + ix0) * 4;
+    ok[i] = inside;
   }
+  const bool tile_full = y0 + kTY <= p.Yo && x0 + kTX <= p.Xo;   // every thread stores all its pixels
+  const bool in_out[kPts / 2] = {y0 + wave < p.Yo, y0 + wave + 8 < p.Yo, y0 + wave + 16 < p.Yo, y0 + wave + 24 < p.Yo};
+  const bool col_out[2] = {x0 + lane < p.Xo, x0 + lane + 64 < p.Xo};
 
   // ---- staging: 16-byte chunks of the box, lane-linear in LDS -------------------------------
   const int chunks_x = box_x >> 2;
@@ -179,12 +181,18 @@ __global__ __launch_bounds__(kThreads) void affine_planar_kernel(PlanarArgs p) {
       request(z1);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no stores behind the prologue's DMAs yet: wait for all)
   for (int zo = zo_begin; zo < zo_end; ++zo) {
     int z0 = 0, z1 = 0;
     double wz0 = 0.0, wz1 = 0.0;
     const bool z_in = z_taps(zo, z0, z1, wz0, wz1);
-    // this plane's sources were requested one iteration ago: wait, publish
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // this plane's sources were requested one iteration ago: wait, publish.  Vector-memory operations
+    // retire in issue order and stores share the counter: behind those DMAs this wave issued only the
+    // previous plane's stores -- exactly kPts of them in a tile that lies wholly inside the output -- so
+    // waiting for "all but kPts" waits for the DMAs and lets the stores drain on their own (waiting
+    // for 0 stalled every plane on its predecessor's HBM writes).
+    if (tile_full) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kPts) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // next plane's sources: their slots differ from this plane's (|a| <= 1.5, ring of 3 or 4)
     {
@@ -196,43 +204,63 @@ __global__ __launch_bounds__(kThreads) void affine_planar_kernel(PlanarArgs p) {
       }
     }
     float* orow = p.out + (static_cast<int64_t>(zo) * p.Yo + y0) * p.Xo + x0;
-    const float* s0 = smem + slot_of(z0) * slot_floats;
-    const float* s1 = smem + slot_of(z1) * slot_floats;
+    const char* s0 = reinterpret_cast<const char*>(smem + slot_of(z0) * slot_floats);
+    const char* s1 = reinterpret_cast<const char*>(smem + slot_of(z1) * slot_floats);
+    typedef float f32x2 __attribute__((ext_vector_type(2), aligned(4)));
+    const int row_b = box_x * 4;
+    // G pixels at a time: all their LDS reads first, then the arithmetic -- nothing in between is
+    // conditional, so the pixels overlap (an `if (inside)` per pixel made hipcc run them one by one,
+    // each waiting for its own reads)
+    constexpr int G = F32 ? 4 : 2;   // (the fp64 corner sums of four pixels at once do not fit 128 VGPRs)
 #pragma unroll
-    for (int i = 0; i < kPts; ++i) {
-      const int yo = wave + 8 * (i >> 1), xo = lane + 64 * (i & 1);
-      if (y0 + yo >= p.Yo || x0 + xo >= p.Xo) continue;
-      float result = p.cval;
-      if (z_in && (step[i] & 4)) {
-        const int dx = step[i] & 1, dy = (step[i] & 2) ? box_x : 0;
-        const int o00 = idx00[i];
-        const float v000 = s0[o00], v001 = s0[o00 + dx], v010 = s0[o00 + dy], v011 = s0[o00 + dy + dx];
-        const float v100 = s1[o00], v101 = s1[o00 + dx], v110 = s1[o00 + dy], v111 = s1[o00 + dy + dx];
+    for (int h = 0; h < kPts; h += G) {
+      f32x2 v[G][4];
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        const int o = idx00[h + k];
+        v[k][0] = *reinterpret_cast<const f32x2*>(s0 + o);
+        v[k][1] = *reinterpret_cast<const f32x2*>(s0 + o + row_b);
+        v[k][2] = *reinterpret_cast<const f32x2*>(s1 + o);
+        v[k][3] = *reinterpret_cast<const f32x2*>(s1 + o + row_b);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      float res[G];
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        const int i = h + k;
+        float result;
         if constexpr (F32) {
           const float fx = static_cast<float>(wx1[i]), fy = static_cast<float>(wy1[i]),
                       fz = static_cast<float>(wz1);
-          const float a0 = fmaf(fx, v001 - v000, v000), a1 = fmaf(fx, v011 - v010, v010);
-          const float b0 = fmaf(fx, v101 - v100, v100), b1 = fmaf(fx, v111 - v110, v110);
+          const float a0 = fmaf(fx, v[k][0].y - v[k][0].x, v[k][0].x), a1 = fmaf(fx, v[k][1].y - v[k][1].x, v[k][1].x);
+          const float b0 = fmaf(fx, v[k][2].y - v[k][2].x, v[k][2].x), b1 = fmaf(fx, v[k][3].y - v[k][3].x, v[k][3].x);
           const float c0 = fmaf(fy, a1 - a0, a0), c1 = fmaf(fy, b1 - b0, b0);
           result = fmaf(fz, c1 - c0, c0);
         } else {
           // scipy's corner order and product order: ((v * wz) * wy) * wx, summed in sequence
           double t = 0.0;
-          auto corner = [&](float v, double wz, double wy, double wx) {
-            t = lsr::dadd(t, lsr::dmul(lsr::dmul(lsr::dmul(static_cast<double>(v), wz), wy), wx));
+          auto corner = [&](float val, double wz, double wy, double wx) {
+            t = lsr::dadd(t, lsr::dmul(lsr::dmul(lsr::dmul(static_cast<double>(val), wz), wy), wx));
           };
-          corner(v000, wz0, wy0[i], wx0[i]);
-          corner(v001, wz0, wy0[i], wx1[i]);
-          corner(v010, wz0, wy1[i], wx0[i]);
-          corner(v011, wz0, wy1[i], wx1[i]);
-          corner(v100, wz1, wy0[i], wx0[i]);
-          corner(v101, wz1, wy0[i], wx1[i]);
-          corner(v110, wz1, wy1[i], wx0[i]);
-          corner(v111, wz1, wy1[i], wx1[i]);
+          corner(v[k][0].x, wz0, wy0[i], wx0[i]);
+          corner(v[k][0].y, wz0, wy0[i], wx1[i]);
+          corner(v[k][1].x, wz0, wy1[i], wx0[i]);
+          corner(v[k][1].y, wz0, wy1[i], wx1[i]);
+          corner(v[k][2].x, wz1, wy0[i], wx0[i]);
+          corner(v[k][2].y, wz1, wy0[i], wx1[i]);
+          corner(v[k][3].x, wz1, wy1[i], wx0[i]);
+          corner(v[k][3].y, wz1, wy1[i], wx1[i]);
           result = static_cast<float>(t);
         }
+        res[k] = (z_in && ok[i]) ? result : p.cval;
+        asm volatile("" : "+v"(res[k]));   // (keeps hipcc from sinking the pixel into its store's condition)
       }
-      orow[static_cast<int64_t>(yo) * p.Xo + xo] = result;
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        const int i = h + k;
+        if (in_out[i >> 1] && col_out[i & 1])
+          orow[static_cast<int64_t>(wave + 8 * (i >> 1)) * p.Xo + lane + 64 * (i & 1)] = res[k];
+      }
     }
     // (no barrier here: the next iteration's DMAs are issued behind its own barrier, which every
     // wave reaches only after these reads)
@@ -252,12 +280,13 @@ bool affine_planar_geometry(int64_t Yi, int64_t Xi, const double M[12], int* box
   const double a = M[0] < 0 ? -M[0] : M[0];
   if (a > 1.5 || Xi % 4 != 0 || Xi < 8 || Yi < 2) return false;
   auto ab = [](double v) { return v < 0 ? -v : v; };
-  // source box of a 32 x 128 tile: extent of the linear map + 2 (floor + upper neighbour) + 2
-  // (slack for per-pixel rounding) [+ 3 for the 16-byte alignment of the first column]
+  // source box of a 32 x 128 tile: span of floor() over the tile (<= floor(extent) + 2; the 1e-6
+  // absorbs the different summation order on the device) + 1 for the upper neighbour [+ 3 + 3: 16-byte
+  // alignment of the first column, rows rounded up to whole chunks]
   const double ey = ab(M[5]) * (kTY - 1) + ab(M[6]) * (kTX - 1), ex = ab(M[9]) * (kTY - 1) + ab(M[10]) * (kTX - 1);
   if (!(ey < 4096.0) || !(ex < 4096.0)) return false;
-  const int box_y = static_cast<int>(ey) + 5;
-  const int box_x = (static_cast<int>(ex) + 5 + 3 + 3) & ~3;
+  const int box_y = static_cast<int>(ey + 1e-6) + 3;
+  const int box_x = (static_cast<int>(ex + 1e-6) + 3 + 3 + 3) & ~3;
   const int slots = a <= 1.0 ? 3 : 4;
   const int64_t lds_bytes = int64_t(slots) * ((int64_t(box_y) * box_x + 255) & ~int64_t(255)) * 4;
   if (lds_bytes > 150 * 1024 || int64_t(box_y) * (box_x / 4) > 8 * kThreads) return false;
