@@ -153,6 +153,8 @@ def test_config4_plate_deskew_rl_through_the_staged_store_path(tmp_path, device,
                                  out[:, y0:y0 + CORE, x0:x0 + CORE], factors)
             del raw16, deskewed
     torch.cuda.empty_cache()
+    shutil.rmtree(tmp_path / "plate.zarr", ignore_errors=True)     # 16 GB: do not leave them for the session
+    shutil.rmtree(tmp_path / "recon.zarr", ignore_errors=True)
 
 
 def _config5_matrix():
@@ -232,3 +234,5 @@ def test_config5_streamed_units_deskew_register_deconvolve(tmp_path, device, mon
         for j in range(i + 1, len(ks)):
             assert not np.array_equal(cores[ks[i]], cores[ks[j]])
     torch.cuda.empty_cache()
+    shutil.rmtree(tmp_path / "lapse.zarr", ignore_errors=True)
+    shutil.rmtree(tmp_path / "recon.zarr", ignore_errors=True)
