@@ -10,7 +10,9 @@ this module implements the first two and borrows the third from whatever the hos
 * blosc 1.x frames      -- ``blosc_decode`` / ``blosc_encode`` follow the published c-blosc 1.x
   layout (16-byte header, ``bstarts`` table, per-block streams with the typesize split rule, byte-
   and bit-shuffle).  When a ``libblosc`` is loadable (``LSR_LIBBLOSC`` or the system one) it does
-  the work instead -- same bytes, C speed, straight into the caller's buffer;
+  the work instead -- same bytes, C speed, straight into the caller's buffer; failing that,
+  ``numcodecs.blosc`` where that package is installed; the pure-Python path (224 MB/s per thread on
+  uint16 camera data against libblosc's 590 MB/s) is the last resort;
 * zstd / lz4 block codecs -- first hit of: ``numcodecs``, ``zstandard`` / ``lz4``, ``pyarrow``, the
   system ``libzstd`` / ``liblz4`` through ctypes.
 
@@ -242,9 +244,30 @@ def _blosc_lib():
     return _libblosc
 
 
+_numcodecs_blosc = None
+_numcodecs_tried = False
+
+
+def _numcodecs():
+    """numcodecs' own blosc binding, when that package is installed (it is wherever iohub / zarr are)."""
+    global _numcodecs_blosc, _numcodecs_tried
+    if not _numcodecs_tried:
+        _numcodecs_tried = True
+        if os.environ.get("LSR_BLOSC", "auto") != "python":
+            try:
+                from numcodecs import blosc as nb
+
+                _numcodecs_blosc = nb
+            except ImportError:
+                _numcodecs_blosc = None
+    return _numcodecs_blosc
+
+
 def blosc_backend() -> str:
-    """``"libblosc"`` when a C library does the work, else ``"python"``."""
-    return "libblosc" if _blosc_lib() is not None else "python"
+    """``"libblosc"`` (ctypes) or ``"numcodecs"`` when a C library does the work, else ``"python"``."""
+    if _blosc_lib() is not None:
+        return "libblosc"
+    return "numcodecs" if _numcodecs() is not None else "python"
 
 
 def blosc_header(frame) -> dict:
@@ -370,6 +393,8 @@ def blosc_decode(frame, out=None, backend: str | None = None) -> np.ndarray:
         got = lib.blosc_decompress_ctx(buf, dest.ctypes.data, dest.size, 1)
         if got != h["nbytes"]:
             raise ValueError(f"blosc_decompress_ctx returned {got}, expected {h['nbytes']}")
+    elif backend is None and _numcodecs() is not None:
+        _numcodecs().decompress(bytes(frame), dest)
     else:
         _py_blosc_decode(frame, dest)
     return dest if out is None else out
