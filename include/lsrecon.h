@@ -118,7 +118,7 @@ int lsr_affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12],
 /*
  * Affine registration, estimate half (no reference symbol, docs/data_structure.md:58-62).
  * Normal equations of one Gauss-Newton step of   min sum_x (gain * moving(M x) + offset - target(x))^2
- * over the target grid sampled every `stride` voxels (trilinear taps; a sample counts when all eight
+ * over the target grid sampled every `stride[axis]` voxels (trilinear taps; a sample counts when all eight
  * lie inside `moving`).  Parameters: the 3x4 matrix row by row in centred, scaled target coordinates
  * ((x - centre) / scale, 1), then gain, offset (14).  `partial` receives lsr_affine_normal_blocks()
  * rows of lsr_affine_normal_size() doubles (105 upper-triangle entries of J^T J row by row, 14 of
@@ -128,7 +128,7 @@ int lsr_affine_normal_size(void);
 int lsr_affine_normal_blocks(void);
 int lsr_affine_normal_equations_f32(const float* moving, int64_t Zi, int64_t Yi, int64_t Xi,
                                     const float* target, int64_t Zo, int64_t Yo, int64_t Xo,
-                                    const double M[12], double gain, double offset, int stride,
+                                    const double M[12], double gain, double offset, const int stride[3],
                                     const double centre[3], double scale, double* partial,
                                     lsr_stream_t stream);
 

@@ -323,7 +323,9 @@ def affine_normal_equations(moving, target, matrix_3x4, gain=1.0, offset=0.0, st
     shape = tgt.shape
     c = np.asarray(centre if centre is not None else [(n - 1) / 2 for n in shape], np.float64)
     s = float(scale if scale is not None else max(shape) / 2)
-    idx = np.stack(np.meshgrid(*[np.arange(0, n, stride, dtype=np.float64) for n in shape], indexing="ij"), -1).reshape(-1, 3)
+    strides = (stride,) * 3 if np.isscalar(stride) else tuple(int(v) for v in stride)
+    idx = np.stack(np.meshgrid(*[np.arange(0, n, st, dtype=np.float64) for n, st in zip(shape, strides)], indexing="ij"),
+                   -1).reshape(-1, 3)
     coord = idx @ m[:, :3].T + m[:, 3]
     lim = np.array(mov.shape) - 1
     keep = np.all((coord >= 0) & (coord < lim), axis=1)

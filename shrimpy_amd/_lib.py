@@ -70,7 +70,8 @@ SIGNATURES: dict[str, list] = {
     "lsr_affine_normal_size": [],
     "lsr_affine_normal_blocks": [],
     "lsr_affine_normal_equations_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _f64p, ctypes.c_double,
-                                        ctypes.c_double, _int, _f64p, ctypes.c_double, ctypes.c_void_p, _stream],
+                                        ctypes.c_double, ctypes.POINTER(ctypes.c_int), _f64p, ctypes.c_double,
+                                        ctypes.c_void_p, _stream],
     "lsr_average_slices_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _int, _stream],
     "lsr_correlate_sep_f32": [
         _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _int, _c_f32p, _int, _c_f32p, _int,

@@ -4,7 +4,7 @@
 // standard additive Lucas-Kanade step with a linear intensity map, on the same conventions as the
 // apply kernels (3x4 matrix, target index -> moving coordinate, trilinear interpolation):
 //
-//     r(x)  = gain * M(A x~) + offset - T(x)                 x over a strided grid of target voxels
+//     r(x)  = gain * M(A x~) + offset - T(x)                 x over a strided grid of target voxels (a stride per axis)
 //     J(x)  = [ gain * dM/dz * x~ , gain * dM/dy * x~ , gain * dM/dx * x~ , M , 1 ]      (14 columns)
 //     H     = sum J J^T  (upper triangle, 105),   b = sum J r  (14),   sse = sum r^2,   n
 //
@@ -35,7 +35,7 @@ struct NormalArgs {
   int Zo, Yo, Xo;
   double m[12];
   double gain, offset;
-  int stride;
+  int sz, sy, sx;        // sampling stride per axis
   int nz, ny, nx;        // sampled grid: indices 0, stride, 2 stride, ... below Zo / Yo / Xo
   double cz, cy, cx, inv_s;
   double* partial;       // [gridDim.x][kOut]
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kThreads, 1) void affine_normal_kernel(NormalArgs p
     const int ix = static_cast<int>(s % p.nx);
     const int64_t t = s / p.nx;
     const int iy = static_cast<int>(t % p.ny), iz = static_cast<int>(t / p.ny);
-    const int zo = iz * p.stride, yo = iy * p.stride, xo = ix * p.stride;
+    const int zo = iz * p.sz, yo = iy * p.sy, xo = ix * p.sx;
     const double zd = zo, yd = yo, xd = xo;
     const double cz = p.m[0] * zd + p.m[1] * yd + p.m[2] * xd + p.m[3];
     const double cy = p.m[4] * zd + p.m[5] * yd + p.m[6] * xd + p.m[7];
@@ -130,8 +130,9 @@ extern "C" int lsr_affine_normal_blocks(void) { return 256; }
 
 extern "C" int lsr_affine_normal_equations_f32(const float* moving, int64_t Zi, int64_t Yi, int64_t Xi,
                                                const float* target, int64_t Zo, int64_t Yo, int64_t Xo,
-                                               const double M[12], double gain, double offset, int stride,
-                                               const double centre[3], double scale, double* partial,
+                                               const double M[12], double gain, double offset,
+                                               const int stride[3], const double centre[3], double scale,
+                                               double* partial,
                                                lsr_stream_t stream) {
   LSR_REQUIRE_PTR(moving);
   LSR_REQUIRE_PTR(target);
@@ -145,7 +146,9 @@ extern "C" int lsr_affine_normal_equations_f32(const float* moving, int64_t Zi, 
   const int64_t lim = int64_t(1) << 30;
   LSR_REQUIRE(Zi < lim && Yi < lim && Xi < lim && Zo < lim && Yo < lim && Xo < lim, LSR_E_UNSUPPORTED,
               "a dimension exceeds 2^30");
-  LSR_REQUIRE(stride >= 1, LSR_E_ARG, "stride must be >= 1, got %d", stride);
+  LSR_REQUIRE_PTR(stride);
+  LSR_REQUIRE(stride[0] >= 1 && stride[1] >= 1 && stride[2] >= 1, LSR_E_ARG, "strides must be >= 1, got (%d,%d,%d)",
+              stride[0], stride[1], stride[2]);
   LSR_REQUIRE(scale > 0.0, LSR_E_ARG, "scale must be positive");
   for (int i = 0; i < 12; ++i) LSR_REQUIRE(M[i] == M[i] && M[i] - M[i] == 0.0, LSR_E_ARG, "M[%d] is not finite", i);
   NormalArgs p;
@@ -154,10 +157,10 @@ extern "C" int lsr_affine_normal_equations_f32(const float* moving, int64_t Zi, 
   p.Zo = static_cast<int>(Zo); p.Yo = static_cast<int>(Yo); p.Xo = static_cast<int>(Xo);
   for (int i = 0; i < 12; ++i) p.m[i] = M[i];
   p.gain = gain; p.offset = offset;
-  p.stride = stride;
-  p.nz = static_cast<int>(lsr::ceil_div(Zo, stride));
-  p.ny = static_cast<int>(lsr::ceil_div(Yo, stride));
-  p.nx = static_cast<int>(lsr::ceil_div(Xo, stride));
+  p.sz = stride[0]; p.sy = stride[1]; p.sx = stride[2];
+  p.nz = static_cast<int>(lsr::ceil_div(Zo, stride[0]));
+  p.ny = static_cast<int>(lsr::ceil_div(Yo, stride[1]));
+  p.nx = static_cast<int>(lsr::ceil_div(Xo, stride[2]));
   p.cz = centre[0]; p.cy = centre[1]; p.cx = centre[2];
   p.inv_s = 1.0 / scale;
   p.partial = partial;

@@ -237,3 +237,32 @@ def test_cli_estimate_then_register_store_to_store(tmp_path, device):
         reg = out.read_volume(0, 1)
     inside = o.affine_apply_4x4(np.ones(shape, np.float32), true, shape) > 0.999
     assert np.sqrt(np.mean((reg - tgt)[inside] ** 2)) < 0.02 * tgt.std()
+
+
+@pytest.mark.gpu
+def test_estimate_on_a_noisy_bead_volume_with_large_corner_displacements(device):
+    """The benchmark's own bead scene (sparse beads, Poisson noise) under the config-3 registration
+    (rotation 2 deg, scale 0.98 / 1.02: 10-20 voxels at the corners of a 512-wide plane) plus a 1 deg
+    tilt: only the coarse levels of ``default_levels`` see that far.  (A fixed (4, 2, 1) pyramid
+    converged to a wrong minimum here -- gain 0.13, 38 voxels off.)"""
+    import torch
+
+    import bench
+    from shrimpy_amd.estimate import default_levels, estimate_affine_zyx
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    shape = (64, 512, 512)
+    assert [lv[0] for lv in default_levels(shape)] == [(8, 32, 32), (8, 16, 16), (8, 8, 8), (4, 4, 4), (2, 2, 2), (1, 1, 1)]
+    mov = bench.synthetic_raw(shape, 3000, device)
+    true = bench.registration_matrix()
+    c1, s1 = np.cos(np.deg2rad(1.0)), np.sin(np.deg2rad(1.0))
+    true[:3, :3] = np.array([[c1, 0, -s1], [0, 1, 0], [s1, 0, c1]]) @ true[:3, :3]
+    c = np.array([(n - 1) / 2 for n in shape])
+    true[:3, 3] = c - true[:3, :3] @ c + np.array([1.5, -4.25, 6.75])
+    tgt = 1.3 * apply_affine_transform_zyx(mov, true, shape) + 20.0
+    est = estimate_affine_zyx(mov, tgt)
+    corners = np.array([[z, y, x, 1.0] for z in (0, shape[0] - 1) for y in (0, shape[1] - 1) for x in (0, shape[2] - 1)])
+    assert np.abs(corners @ (est.affine_transform_zyx - true).T).max() < 0.01
+    assert est.gain == pytest.approx(1.3, rel=1e-3) and est.offset == pytest.approx(20.0, abs=0.1)
+    del mov, tgt
+    torch.cuda.empty_cache()
