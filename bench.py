@@ -141,15 +141,10 @@ def _cpu_worker(args):
 
 
 def host_cores() -> int:
-    """Cores this process may use: the affinity mask, cut down to a cgroup CPU quota if one is set."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
-        if quota != "max":
-            n = min(n, max(1, int(float(quota) / float(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, n)
+    """Cores this process may use (affinity mask cut down to a cgroup CPU quota)."""
+    from shrimpy_amd.io.omezarr import host_cores as cores
+
+    return cores()
 
 
 def cpu_baseline(config_id=2, all_core_shape=(640, 128, 640), single_shape=(512, 128, 512), max_procs=None):

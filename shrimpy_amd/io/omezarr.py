@@ -52,6 +52,42 @@ _V3_DTYPES = {"float32": "<f4", "float64": "<f8", "uint16": "<u2", "uint8": "|u1
               "int32": "<i4", "uint32": "<u4"}
 
 
+def host_cores() -> int:
+    """Cores this process may use: its affinity mask, cut down to the cgroup CPU quota if one is set
+    (a container with a 16-core share of a 256-core host reports 256 from ``os.cpu_count()``; more
+    runnable threads than the share only buys CFS throttling)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+# Threads one volume read / write fans its files out to.  ``None`` = min(16, host_cores()).  A
+# streamed run reads unit k+1 while it writes unit k-1: ``pipeline._run_staged`` splits the cores
+# between the two (``io_thread_budget``) so that together they stay within the share.
+IO_THREADS = {"read": None, "write": None}
+
+
+def io_thread_budget(read: int | None = None, write: int | None = None) -> dict:
+    """Set (or with no arguments reset) the reader / writer thread budgets; returns the previous ones."""
+    prev = dict(IO_THREADS)
+    IO_THREADS["read"], IO_THREADS["write"] = read, write
+    return prev
+
+
+def _io_threads(role: str) -> int:
+    env = os.environ.get("LSR_IO_THREADS")          # "r,w": measurement override
+    if env:
+        r, w = (int(v) for v in env.split(","))
+        return max(1, r if role == "read" else w)
+    n = IO_THREADS.get(role)
+    return max(1, int(n)) if n else min(16, host_cores())
+
+
 class UnsupportedCodec(RuntimeError):
     """The array uses a codec this minimal reader cannot decode (blosc, sharding, ...)."""
 
@@ -374,8 +410,8 @@ class ZarrArray:
     # (e.g. a pinned staging slot) without an intermediate copy.
     _POOL_MIN_BYTES = 8 << 20
 
-    def _map_chunks(self, fn, cidxs, nbytes):
-        workers = min(16, os.cpu_count() or 1, len(cidxs))
+    def _map_chunks(self, fn, cidxs, nbytes, role="read"):
+        workers = min(_io_threads(role), len(cidxs))
         if workers <= 1 or nbytes < self._POOL_MIN_BYTES:
             for c in cidxs:
                 fn(c)
@@ -585,7 +621,7 @@ class ZarrArray:
                 block[tuple(slice(0, s.stop - s.start) for s in sl)] = vol[sl]
             self._write_chunk(lead + cidx, block)
 
-        self._map_chunks(write_one, list(self._grid(lead)), vol.nbytes)
+        self._map_chunks(write_one, list(self._grid(lead)), vol.nbytes, "write")
 
     def __getitem__(self, key):
         """Convenience for tests: ``arr[t, c]`` -> volume; ``arr[:]`` -> everything."""

@@ -231,3 +231,22 @@ def test_unknown_codecs_name_the_fix(tmp_path):
         ZarrArray.create(tmp_path / "bad", "0.5", (1, 1, 8, 4, 4), (1, 1, 3, 4, 4), "uint16", None, (1, 1, 8, 4, 4))
     with pytest.raises(ValueError, match="0.5"):
         ZarrArray.create(tmp_path / "bad2", "0.4", (1, 1, 8, 4, 4), (1, 1, 4, 4, 4), "uint16", None, (1, 1, 8, 4, 4))
+
+
+def test_io_thread_budget_defaults_to_the_core_share_and_can_be_split(monkeypatch):
+    """Volume reads / writes fan out to min(16, cores the process may use); a streamed run may split
+    the share between its reader and its writer, and an explicit budget is honoured."""
+    from shrimpy_amd.io import omezarr
+
+    monkeypatch.delenv("LSR_IO_THREADS", raising=False)
+    cores = omezarr.host_cores()
+    assert 1 <= cores <= (os.cpu_count() or 1)
+    assert omezarr._io_threads("read") == omezarr._io_threads("write") == min(16, cores)
+    prev = omezarr.io_thread_budget(read=3, write=5)
+    try:
+        assert (omezarr._io_threads("read"), omezarr._io_threads("write")) == (3, 5)
+    finally:
+        omezarr.io_thread_budget(**prev)
+    assert omezarr._io_threads("read") == min(16, cores)
+    monkeypatch.setenv("LSR_IO_THREADS", "2,7")
+    assert (omezarr._io_threads("read"), omezarr._io_threads("write")) == (2, 7)
