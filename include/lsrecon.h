@@ -132,6 +132,20 @@ int lsr_affine_normal_equations_f32(const float* moving, int64_t Zi, int64_t Yi,
                                     const double centre[3], double scale, double* partial,
                                     lsr_stream_t stream);
 
+/*
+ * Ingest, host side (no device work): the acquisition writes blosc frames (zstd, byte
+ * shuffle; shrimpy/mantis/mantis_engine.py:474-481) and the reference reads them through iohub -> zarr ->
+ * numcodecs.blosc.decompress.  lsr_blosc_decode_host walks one c-blosc 1.x frame, entropy-decodes every stream
+ * and undoes the byte shuffle into `out` (out_bytes = the frame's nbytes; host memory, e.g. a slab of a pinned
+ * staging slot).  One call per chunk, safe from many threads at once (a Python walk costs ~10 us per stream
+ * under the GIL; c-blosc frames have ~1000 streams per chunk).  *typesize (may be NULL) = the frame's element
+ * size.  zstd / lz4 / zlib come from the system libraries at run time (dlopen).
+ * LSR_E_UNSUPPORTED: bit shuffle, blosclz / snappy, or the decoder library is missing (callers fall back to
+ * another codec); LSR_E_ARG: corrupt frame; LSR_E_SHAPE: out_bytes differs from the frame's nbytes.
+ */
+int lsr_blosc_host_codec(int compressor); /* 1 when the decoder of blosc compressor code 1 (lz4) / 3 (zlib) / 4 (zstd) is loadable */
+int lsr_blosc_decode_host(const uint8_t* frame, int64_t frame_bytes, uint8_t* out, int64_t out_bytes, int* typesize);
+
 /* out[zo] = mean_k in[min(zo*avg_n + k, Zd-1)], k < avg_n, f32, ((d0+d1)+...)/avg_n. */
 int lsr_average_slices_f32(const float* in, int64_t Zd, int64_t Y, int64_t X, float* out,
                            int64_t Zo, int avg_n, lsr_stream_t stream);

@@ -72,6 +72,8 @@ SIGNATURES: dict[str, list] = {
     "lsr_affine_normal_equations_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _f64p, ctypes.c_double,
                                         ctypes.c_double, ctypes.POINTER(ctypes.c_int), _f64p, ctypes.c_double,
                                         ctypes.c_void_p, _stream],
+    "lsr_blosc_host_codec": [_int],
+    "lsr_blosc_decode_host": [ctypes.c_void_p, _i64, ctypes.c_void_p, _i64, ctypes.POINTER(ctypes.c_int)],
     "lsr_average_slices_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _int, _stream],
     "lsr_correlate_sep_f32": [
         _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _int, _c_f32p, _int, _c_f32p, _int,

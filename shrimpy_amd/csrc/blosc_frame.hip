@@ -1,0 +1,176 @@
+// Host side of the blosc ingest (no kernel in this file): walk one c-blosc 1.x frame and run the entropy
+// decoder of every stream straight into the caller's buffer -- typically a slab of a pinned staging
+// slot.  The acquisition writes such frames (blosc, zstd, byte shuffle; shrimpy/mantis/mantis_engine.py:
+// 474-481) with c-blosc's own parameters: 32 KB blocks, one zstd stream each (c-blosc does not split zstd
+// blocks), i.e. ~1000 streams per 32-plane chunk of a camera stack.  Walking them in Python costs ~10 us
+// per stream under the GIL -- 2.5 s per config-4 volume however many threads decode -- so the walk lives
+// here, one call per chunk with the GIL released, and a reader thread pool scales (0.11 s per volume on 16
+// threads, the rate of c-blosc itself).  The byte shuffle is undone here too, block
+// by block while the block is in cache (undoing it on the device behind the upload was built and measured:
+// no gain, zstd is what the time goes to -- DESIGN.md section 5).
+//
+// Frame layout (c-blosc 1.x, blosc.h / blosc.c; restated, not copied): 16-byte header
+//   [0] format version  [1] codec format  [2] flags  [3] typesize  [4:8] nbytes  [8:12] blocksize  [12:16] cbytes
+// flags: 0x1 byte shuffle, 0x2 stored ("memcpyed": the nbytes follow the header), 0x4 bit shuffle,
+// 0x10 blocks are not split, bits 5-7 compressor (0 blosclz, 1 lz4, 2 snappy, 3 zlib, 4 zstd); then
+// int32 bstarts[nblocks]; a block is 1 or `typesize` streams (split when !0x10, typesize <= 16,
+// blocksize / typesize >= 128 and the block is not the short last one), each int32 cbytes + payload,
+// payload stored verbatim when cbytes equals the stream's decoded size.
+// The zstd / lz4 / zlib decoders come from the system libraries at run time (dlopen): no headers needed.
+
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "common.hpp"
+
+namespace {
+
+using zstd_decompress_t = size_t (*)(void*, size_t, const void*, size_t);
+using zstd_is_error_t = unsigned (*)(size_t);
+using lz4_decompress_t = int (*)(const char*, char*, int, int);
+using zlib_uncompress_t = int (*)(unsigned char*, unsigned long*, const unsigned char*, unsigned long);
+
+struct Decoders {
+  zstd_decompress_t zstd = nullptr;
+  zstd_is_error_t zstd_is_error = nullptr;
+  lz4_decompress_t lz4 = nullptr;
+  zlib_uncompress_t zlib = nullptr;
+};
+
+void* open_first(const char* env, const char* a, const char* b) {
+  const char* names[3] = {env ? std::getenv(env) : nullptr, a, b};
+  for (const char* n : names) {
+    if (n == nullptr || *n == 0) continue;
+    if (void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) return h;
+  }
+  return nullptr;
+}
+
+const Decoders& decoders() {
+  static const Decoders d = [] {
+    Decoders r;
+    if (void* h = open_first("LSR_LIBZSTD", "libzstd.so.1", "libzstd.so")) {
+      r.zstd = reinterpret_cast<zstd_decompress_t>(dlsym(h, "ZSTD_decompress"));
+      r.zstd_is_error = reinterpret_cast<zstd_is_error_t>(dlsym(h, "ZSTD_isError"));
+      if (r.zstd == nullptr || r.zstd_is_error == nullptr) r.zstd = nullptr;
+    }
+    if (void* h = open_first("LSR_LIBLZ4", "liblz4.so.1", "liblz4.so"))
+      r.lz4 = reinterpret_cast<lz4_decompress_t>(dlsym(h, "LZ4_decompress_safe"));
+    if (void* h = open_first("LSR_LIBZ", "libz.so.1", "libz.so"))
+      r.zlib = reinterpret_cast<zlib_uncompress_t>(dlsym(h, "uncompress"));
+    return r;
+  }();
+  return d;
+}
+
+inline int32_t le32(const uint8_t* p) {
+  return static_cast<int32_t>(uint32_t(p[0]) | uint32_t(p[1]) << 8 | uint32_t(p[2]) << 16 | uint32_t(p[3]) << 24);
+}
+
+// dst[i * T + k] = src[k * n + i]; trailing nbytes % T bytes verbatim
+void unshuffle_block(const uint8_t* src, uint8_t* dst, int64_t nbytes, int T) {
+  const int64_t n = nbytes / T;
+  if (T == 2) {
+    const uint8_t *lo = src, *hi = src + n;
+    for (int64_t i = 0; i < n; ++i) {
+      dst[2 * i] = lo[i];
+      dst[2 * i + 1] = hi[i];
+    }
+  } else if (T == 4) {
+    const uint8_t *a = src, *b = src + n, *c = src + 2 * n, *d = src + 3 * n;
+    for (int64_t i = 0; i < n; ++i) {
+      dst[4 * i] = a[i];
+      dst[4 * i + 1] = b[i];
+      dst[4 * i + 2] = c[i];
+      dst[4 * i + 3] = d[i];
+    }
+  } else {
+    for (int k = 0; k < T; ++k)
+      for (int64_t i = 0; i < n; ++i) dst[i * T + k] = src[k * n + i];
+  }
+  std::memcpy(dst + n * T, src + n * T, static_cast<size_t>(nbytes - n * T));
+}
+
+}  // namespace
+
+// 1 when the decoder of blosc compressor code `compressor` (1 lz4, 3 zlib, 4 zstd) is loadable here
+extern "C" int lsr_blosc_host_codec(int compressor) {
+  const Decoders& d = decoders();
+  return compressor == 4 ? d.zstd != nullptr : compressor == 1 ? d.lz4 != nullptr : compressor == 3 ? d.zlib != nullptr : 0;
+}
+
+extern "C" int lsr_blosc_decode_host(const uint8_t* frame, int64_t frame_bytes, uint8_t* out, int64_t out_bytes,
+                                     int* typesize_out) {
+  LSR_REQUIRE_PTR(frame);
+  LSR_REQUIRE(frame_bytes >= 16, LSR_E_ARG, "blosc frame shorter than its 16-byte header");
+  const int flags = frame[2];
+  const int T = frame[3] ? frame[3] : 1;
+  const int64_t nbytes = static_cast<uint32_t>(le32(frame + 4));
+  const int64_t blocksize = static_cast<uint32_t>(le32(frame + 8));
+  if (typesize_out) *typesize_out = T;
+  LSR_REQUIRE(nbytes == out_bytes, LSR_E_SHAPE, "blosc frame holds %lld bytes, destination has %lld",
+              (long long)nbytes, (long long)out_bytes);
+  if (nbytes == 0) return LSR_OK;
+  LSR_REQUIRE_PTR(out);
+  if (flags & 0x2) {  // stored
+    LSR_REQUIRE(frame_bytes >= 16 + nbytes, LSR_E_ARG, "corrupt blosc frame: stored payload runs past the end");
+    std::memcpy(out, frame + 16, static_cast<size_t>(nbytes));
+    return LSR_OK;
+  }
+  const bool byte_shuffled = (flags & 0x1) && T > 1;
+  LSR_REQUIRE(byte_shuffled || !(flags & 0x4), LSR_E_UNSUPPORTED, "bit-shuffled blosc frame: decoded by the Python codec");
+  LSR_REQUIRE(blocksize > 0, LSR_E_ARG, "corrupt blosc frame: blocksize 0");
+  const int compressor = flags >> 5;
+  const Decoders& dec = decoders();
+  LSR_REQUIRE(lsr_blosc_host_codec(compressor), LSR_E_UNSUPPORTED,
+              "blosc compressor %d: its decoder library is not loadable here (zstd 4, lz4 1, zlib 3 via dlopen)", compressor);
+  const int64_t nblocks = (nbytes + blocksize - 1) / blocksize;
+  LSR_REQUIRE(16 + 4 * nblocks <= frame_bytes, LSR_E_ARG, "corrupt blosc frame: block table runs past the end");
+  uint8_t* scratch = nullptr;
+  if (byte_shuffled) {
+    scratch = static_cast<uint8_t*>(std::malloc(static_cast<size_t>(blocksize)));
+    LSR_REQUIRE(scratch != nullptr, LSR_E_ARG, "out of memory for a %lld-byte block", (long long)blocksize);
+  }
+  int status = LSR_OK;
+  for (int64_t b = 0; b < nblocks && status == LSR_OK; ++b) {
+    const int64_t bsize = b * blocksize + blocksize <= nbytes ? blocksize : nbytes - b * blocksize;
+    const bool leftover = bsize != blocksize;
+    const bool split = !(flags & 0x10) && T <= 16 && blocksize / T >= 128 && !leftover;
+    const int nsplits = split ? T : 1;
+    const int64_t neblock = bsize / nsplits;
+    uint8_t* dest = out + b * blocksize;
+    uint8_t* target = scratch ? scratch : dest;
+    int64_t pos = le32(frame + 16 + 4 * b);
+    for (int k = 0; k < nsplits; ++k) {
+      if (pos < 0 || pos + 4 > frame_bytes) { status = lsr::fail(LSR_E_ARG, "corrupt blosc frame: stream runs past the end"); break; }
+      const int64_t cb = le32(frame + pos);
+      pos += 4;
+      if (cb < 0 || pos + cb > frame_bytes) { status = lsr::fail(LSR_E_ARG, "corrupt blosc frame: stream runs past the end"); break; }
+      uint8_t* dst = target + k * neblock;
+      if (cb == neblock) {
+        std::memcpy(dst, frame + pos, static_cast<size_t>(cb));
+      } else if (compressor == 4) {
+        const size_t got = dec.zstd(dst, static_cast<size_t>(neblock), frame + pos, static_cast<size_t>(cb));
+        if (dec.zstd_is_error(got) || static_cast<int64_t>(got) != neblock)
+          status = lsr::fail(LSR_E_ARG, "corrupt blosc frame: zstd stream does not decode to the block size");
+      } else if (compressor == 1) {
+        const int got = dec.lz4(reinterpret_cast<const char*>(frame + pos), reinterpret_cast<char*>(dst), static_cast<int>(cb),
+                                static_cast<int>(neblock));
+        if (got != neblock) status = lsr::fail(LSR_E_ARG, "corrupt blosc frame: lz4 stream does not decode to the block size");
+      } else {
+        unsigned long got = static_cast<unsigned long>(neblock);
+        const int rc = dec.zlib(dst, &got, frame + pos, static_cast<unsigned long>(cb));
+        if (rc != 0 || static_cast<int64_t>(got) != neblock)
+          status = lsr::fail(LSR_E_ARG, "corrupt blosc frame: zlib stream does not decode to the block size");
+      }
+      if (status != LSR_OK) break;
+      pos += cb;
+    }
+    if (status != LSR_OK) break;
+    if (byte_shuffled) unshuffle_block(scratch, dest, bsize, T);
+  }
+  std::free(scratch);
+  return status;
+}

@@ -421,6 +421,25 @@ class ZarrArray:
         with ThreadPoolExecutor(workers, "lsr-zarr") as pool:
             list(pool.map(fn, cidxs))  # list(): re-raise the first worker exception
 
+    def _inner_threads(self, n_files: int, nbytes: int, role: str) -> int:
+        """Threads ONE shard may spread its inner chunks over: the budget left by the fan-out over
+        files (a volume stored as a single shard -- the acquisition's layout -- would otherwise be
+        decoded by one thread, chunk after chunk)."""
+        if nbytes < self._POOL_MIN_BYTES:
+            return 1
+        budget = _io_threads(role)
+        return max(1, budget // max(1, min(budget, n_files)))
+
+    @staticmethod
+    def _fan_out(fn, items, threads: int) -> list:
+        items = list(items)
+        if threads <= 1 or len(items) <= 1:
+            return [fn(i) for i in items]
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(min(threads, len(items)), "lsr-shard") as pool:
+            return list(pool.map(fn, items))
+
     def _slab(self, vol: np.ndarray, sl, block_shape) -> np.ndarray | None:
         """``vol[sl]`` when that is a whole block and contiguous in ``vol`` (decode / encode in place)."""
         full = all(s.stop - s.start == c for s, c in zip(sl, block_shape))
@@ -469,7 +488,7 @@ class ZarrArray:
                 continue
             yield head + inner, tuple(slice(a, min(a + c, n)) for a, c, n in zip(lo, vchunks, vshape))
 
-    def _read_shard(self, lead, fidx, out: np.ndarray) -> None:
+    def _read_shard(self, lead, fidx, out: np.ndarray, threads: int = 1) -> None:
         k = len(lead)
         vchunks = self.chunks[k:]
         path = self._file_path(tuple(i // s for i, s in zip(lead, self.shards[:k])) + tuple(fidx))
@@ -480,17 +499,21 @@ class ZarrArray:
                 out[sl] = self.fill_value
             return
         with f:
-            size = os.fstat(f.fileno()).st_size
+            fd = f.fileno()
+            size = os.fstat(fd).st_size
             index = self._read_shard_index(f, size)
-            for inner, sl in self._inner_of(lead, fidx):
+
+            def one(item):
+                inner, sl = item
                 off, nb = (int(v) for v in index[inner])
                 if off == _MISSING and nb == _MISSING:
                     out[sl] = self.fill_value
-                    continue
+                    return
                 if off + nb > size:
                     raise OSError(f"shard {path}: chunk {inner} runs past the end of the file")
-                f.seek(off)
-                raw = f.read(nb)
+                raw = os.pread(fd, nb, off)          # positional: the workers share the descriptor
+                if len(raw) != nb:
+                    raise OSError(f"shard {path}: short read of chunk {inner}")
                 dest = self._slab(out, sl, vchunks)
                 if dest is not None:
                     self._codec.decode(raw, dest.shape, self.dtype, out=dest)
@@ -498,7 +521,9 @@ class ZarrArray:
                     block = self._codec.decode(raw, vchunks, self.dtype)
                     out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
 
-    def _write_shard(self, lead, fidx, vol: np.ndarray) -> None:
+            self._fan_out(one, self._inner_of(lead, fidx), threads)
+
+    def _write_shard(self, lead, fidx, vol: np.ndarray, threads: int = 1) -> None:
         from .codecs import crc32c
 
         k = len(lead)
@@ -516,12 +541,15 @@ class ZarrArray:
                     if off != _MISSING:
                         f.seek(off)
                         blobs[inner] = f.read(nb)
-        for inner, sl in self._inner_of(lead, fidx):
+        def encode(item):
+            inner, sl = item
             block = self._slab(vol, sl, vchunks)
             if block is None:
                 block = np.zeros(vchunks, dtype=self.dtype)
                 block[tuple(slice(0, s.stop - s.start) for s in sl)] = vol[sl]
-            blobs[inner] = self._codec.encode(np.ascontiguousarray(block, dtype=self.dtype))
+            return inner, self._codec.encode(np.ascontiguousarray(block, dtype=self.dtype))
+
+        blobs.update(self._fan_out(encode, self._inner_of(lead, fidx), threads))
         index = np.full(counts + (2,), _MISSING, dtype="<u8")
         ilen = index.nbytes + (4 if self._index_crc else 0)
         pos = ilen if self._index_location == "start" else 0
@@ -555,9 +583,12 @@ class ZarrArray:
         elif tuple(out.shape) != tuple(vshape) or out.dtype != self.dtype:
             raise ValueError(f"out must be {tuple(vshape)} {self.dtype}, got {out.shape} {out.dtype}")
 
+        files = list(self._grid(lead))
+        inner_threads = self._inner_threads(len(files), out.nbytes, "read") if self.shards is not None else 1
+
         def read_one(cidx):
             if self.shards is not None:
-                self._read_shard(lead, cidx, out)
+                self._read_shard(lead, cidx, out, inner_threads)
                 return
             sl = tuple(slice(c * s, min((c + 1) * s, n)) for c, s, n in zip(cidx, vchunks, vshape))
             path = self._file_path(lead + cidx)
@@ -586,7 +617,7 @@ class ZarrArray:
             block = self._codec.decode(raw, vchunks, self.dtype)
             out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
 
-        self._map_chunks(read_one, list(self._grid(lead)), out.nbytes)
+        self._map_chunks(read_one, files, out.nbytes)
         return out
 
     def write_volume(self, *args) -> None:
@@ -601,9 +632,12 @@ class ZarrArray:
         lead = self._check_lead(lead)
         vchunks = self.chunks[k:]
 
+        files = list(self._grid(lead))
+        inner_threads = self._inner_threads(len(files), vol.nbytes, "write") if self.shards is not None else 1
+
         def write_one(cidx):
             if self.shards is not None:
-                self._write_shard(lead, cidx, vol)
+                self._write_shard(lead, cidx, vol, inner_threads)
                 return
             sl = tuple(slice(c * s, min((c + 1) * s, n)) for c, s, n in zip(cidx, vchunks, vol.shape))
             view = self._slab_view(vol, sl)
@@ -621,7 +655,7 @@ class ZarrArray:
                 block[tuple(slice(0, s.stop - s.start) for s in sl)] = vol[sl]
             self._write_chunk(lead + cidx, block)
 
-        self._map_chunks(write_one, list(self._grid(lead)), vol.nbytes, "write")
+        self._map_chunks(write_one, files, vol.nbytes, "write")
 
     def __getitem__(self, key):
         """Convenience for tests: ``arr[t, c]`` -> volume; ``arr[:]`` -> everything."""

@@ -733,3 +733,37 @@ def test_cli_deskew_register_deconvolve_chain_on_gpu(tmp_path, version):
     finally:
         for st in stores.values():
             st.close()
+
+
+@pytest.mark.gpu
+def test_staged_run_over_a_store_in_the_acquisition_format_on_gpu(tmp_path):
+    """deskew + 3 RL iterations store to store with the input as the acquisition writes it -- Zarr v3,
+    one shard per (t, c) volume around blosc-zstd chunks (``shrimpy/mantis/mantis_engine.py:474-481``)
+    -- through the staged path (reader threads decode the frames into the pinned slots); every
+    position against the oracle."""
+    from oracle import cpu_ref as o
+    from shrimpy_amd import cli as lsr_cli
+    from shrimpy_amd.settings import ReconstructSettings
+
+    rng = np.random.default_rng(5)
+    src = tmp_path / "acq.ome.zarr"
+    vols = {}
+    with open_ome_zarr(src, layout="hcs", mode="w", channel_names=["LS"], version="0.5", prefer_iohub=False) as plate:
+        for p in range(4):
+            arr = plate.create_position("A", str(p + 1), "0").create_zeros(
+                "0", shape=(1, 1, 72, 16, 40), dtype="uint16", scale=(1, 1, 0.15, 0.1133, 0.1133),
+                chunks=(1, 1, 32, 16, 40), compress="blosc-zstd", shards="volume")
+            vols[f"A/{p + 1}/0"] = rng.poisson(300, (72, 16, 40)).astype(np.uint16)
+            arr.write_volume(0, 0, vols[f"A/{p + 1}/0"])
+    settings = ReconstructSettings.model_validate(dict(
+        deskew=dict(pixel_size_um=0.1133, ls_angle_deg=30.0, scan_step_um=0.15, keep_overhang=True, average_n_slices=3),
+        deconvolution=dict(iterations=3, gaussian_shape_zyx=[5, 5, 5], gaussian_sigma_zyx=[1.2, 1.0, 1.0])))
+    res = lsr_cli.run_store(src, tmp_path / "out.zarr", settings)
+    assert res["units_total"] == 4
+    psf, _ = o.gaussian_psf((5, 5, 5), (1.2, 1.0, 1.0))
+    with open_ome_zarr(tmp_path / "out.zarr", prefer_iohub=False) as plate:
+        for key, pos in plate.positions():
+            got = pos["0"].read_volume(0, 0).astype(np.float64)
+            ref = o.richardson_lucy(o.deskew(vols[key].astype(np.float32), 30.0, 0.755, True, 3), psf, 3).astype(np.float64)
+            assert got.shape == ref.shape
+            assert np.all(np.abs(got - ref) <= 5e-5 * np.abs(ref) + 2e-5 * np.abs(ref).max())

@@ -10,6 +10,7 @@ The blosc frame codec is checked three ways: against frames a real c-blosc 1.21.
 
 import json
 import os
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -29,16 +30,26 @@ def test_crc32c_known_answers():
 
 def test_blosc_decoder_reads_frames_made_by_c_blosc(golden_dir):
     """Frames from libblosc 1.21.0 (zstd / lz4 / zlib; no-, byte- and bit-shuffle; split and
-    unsplit blocks; a leftover block; the memcpyed form) through the pure-Python decoder."""
+    unsplit blocks; a leftover block; the memcpyed form) through the pure-Python decoder and through
+    the native frame walker in liblsrecon."""
     g = np.load(golden_dir / "blosc_frames.npz")
     names = sorted({k.rsplit(".", 1)[0] for k in g.files})
     assert len(names) >= 12
+    taken = 0
     for name in names:
         frame, want = g[name + ".frame"].tobytes(), g[name + ".data"]
         out = np.empty(want.nbytes, np.uint8)
         codecs._py_blosc_decode(frame, out)
         np.testing.assert_array_equal(out.view(want.dtype), want.reshape(-1), err_msg=name)
         np.testing.assert_array_equal(codecs.blosc_decode(frame).view(want.dtype), want.reshape(-1))
+        if codecs._native_lib() is not None:      # the native walker (lsr_blosc_decode_host) on the same vectors
+            out = np.full(want.nbytes, 0xEE, np.uint8)
+            if codecs._native_decode(frame, out):
+                taken += 1
+                np.testing.assert_array_equal(out.view(want.dtype), want.reshape(-1), err_msg=name + " (native)")
+            else:
+                assert codecs.blosc_header(frame)["flags"] & 0x4, name      # only bit-shuffled frames are declined
+    assert codecs._native_lib() is None or taken >= 8
 
 
 @pytest.mark.parametrize("cname", ["zstd", "zlib"])
@@ -166,12 +177,14 @@ def test_sharded_and_compressed_v3_arrays_round_trip(tmp_path, kw):
         np.testing.assert_array_equal(arr[:], data)
 
 
-def test_engine_layout_through_libblosc_equals_the_python_codec(tmp_path, libblosc):
+def test_engine_layout_through_libblosc_equals_the_python_codec(tmp_path, libblosc, monkeypatch):
     """With a C library doing the frames (the fast path on a real host) the store reads back the same,
     and a store written by either codec is readable by the other."""
     assert codecs.blosc_backend() == "libblosc"
     data = _plate(tmp_path / "c.zarr", "0.5", chunks=(1, 1, 16, 12, 20), **ENGINE)
     codecs._libblosc = None                         # read it back with the pure-Python decoder
+    monkeypatch.setattr(codecs, "_native", None)
+    monkeypatch.setattr(codecs, "_native_tried", True)
     assert codecs.blosc_backend() == "python"
     with open_ome_zarr(tmp_path / "c.zarr", prefer_iohub=False) as plate:
         np.testing.assert_array_equal(plate["A/1/fov0"]["0"][:], data)
@@ -250,3 +263,90 @@ def test_io_thread_budget_defaults_to_the_core_share_and_can_be_split(monkeypatc
     assert omezarr._io_threads("read") == min(16, cores)
     monkeypatch.setenv("LSR_IO_THREADS", "2,7")
     assert (omezarr._io_threads("read"), omezarr._io_threads("write")) == (2, 7)
+
+
+def test_a_single_shard_spreads_its_inner_chunks_over_the_thread_budget(tmp_path, monkeypatch):
+    """The acquisition stores a volume as ONE shard file; its inner chunks are encoded / decoded by
+    the whole thread budget (they used to be handled by one thread, one after another).  The files
+    written are the same bytes whatever the thread count; errors of a worker propagate."""
+    import threading
+
+    from shrimpy_amd.io import omezarr
+
+    monkeypatch.delenv("LSR_IO_THREADS", raising=False)
+    monkeypatch.setattr(omezarr.ZarrArray, "_POOL_MIN_BYTES", 0)
+    seen = set()
+    real = omezarr._BlockCodec.decode
+
+    def spy(self, *a, **k):
+        seen.add(threading.current_thread().name)
+        return real(self, *a, **k)
+
+    monkeypatch.setattr(omezarr._BlockCodec, "decode", spy)
+    prev = omezarr.io_thread_budget(read=4, write=4)
+    try:
+        data = _plate(tmp_path / "par.zarr", "0.5", shape=(1, 2, 70, 12, 20), chunks=(1, 1, 8, 12, 20), **ENGINE)
+        with open_ome_zarr(tmp_path / "par.zarr", prefer_iohub=False) as plate:
+            arr = plate["A/1/fov0"]["0"]
+            assert arr._inner_threads(1, 1 << 20, "read") == 4 and arr._inner_threads(2, 1 << 20, "read") == 2
+            out = np.empty((70, 12, 20), np.uint16)
+            np.testing.assert_array_equal(arr.read_volume(0, 1, out=out), data[0, 1])
+        assert len({n for n in seen if n.startswith("lsr-shard")}) > 1
+        omezarr.io_thread_budget(read=1, write=1)
+        data1 = _plate(tmp_path / "ser.zarr", "0.5", shape=(1, 2, 70, 12, 20), chunks=(1, 1, 8, 12, 20), **ENGINE)
+        np.testing.assert_array_equal(data, data1)
+        for c in range(2):
+            rel = Path("A/1/fov0/0/c/0") / str(c) / "0/0/0"
+            assert (tmp_path / "par.zarr" / rel).read_bytes() == (tmp_path / "ser.zarr" / rel).read_bytes()
+        # a truncated shard: the failing worker's error reaches the caller
+        omezarr.io_thread_budget(read=4, write=4)
+        shard = tmp_path / "par.zarr" / "A/1/fov0/0/c/0/0/0/0/0"
+        raw = shard.read_bytes()
+        ilen = 16 * 9 + 4
+        shard.write_bytes(raw[:40] + raw[-ilen:])
+        with open_ome_zarr(tmp_path / "par.zarr", prefer_iohub=False) as plate:
+            with pytest.raises(OSError, match="runs past the end"):
+                plate["A/1/fov0"]["0"].read_volume(0, 0)
+    finally:
+        omezarr.io_thread_budget(**prev)
+
+
+def test_native_frame_walker_agrees_with_c_blosc_and_with_the_python_codec(libblosc):
+    """``lsr_blosc_decode_host`` (csrc/blosc_frame.hip) on frames made by c-blosc itself -- 32 KB blocks,
+    the acquisition's kind -- and by the Python encoder, for zstd / lz4 / zlib streams, shuffled and not:
+    equal to the data and to the Python walker; what it does not take falls through; corrupt frames are
+    reported."""
+    if codecs._native_lib() is None:
+        pytest.skip("liblsrecon is not built")
+    rng = np.random.default_rng(4)
+    for dtype, n, cname, shuffle in [("uint16", 1 << 20, "zstd", 1), ("uint16", 33333, "zstd", 1),
+                                     ("float32", 300001, "lz4", 1), ("float64", 20000, "zlib", 1),
+                                     ("uint8", 100000, "zstd", 0), ("uint16", 70001, "zstd", 0)]:
+        a = rng.poisson(300, n).astype(dtype)
+        for maker in ("libblosc", "python"):
+            if maker == "python" and cname == "lz4":
+                continue
+            frame = codecs.blosc_encode(a, a.itemsize, cname, 1, shuffle, backend=maker)
+            out = np.zeros(a.nbytes, np.uint8)
+            assert codecs._native_decode(frame, out) is True
+            np.testing.assert_array_equal(out.view(dtype), a)
+            assert codecs.blosc_decode(frame, backend="lsrecon").view(dtype).tolist() == a.tolist()
+            ref = np.zeros(a.nbytes, np.uint8)
+            codecs._py_blosc_decode(frame, ref)                        # the Python statement of the same walk
+            np.testing.assert_array_equal(ref, out)
+    # bit shuffle: not taken (the Python codec decodes it)
+    a = rng.integers(0, 600, 4096).astype(np.uint16)
+    frame = codecs.blosc_encode(a, 2, "zstd", 1, 2, backend="libblosc")
+    assert codecs._native_decode(frame, np.zeros(a.nbytes, np.uint8)) is False
+    np.testing.assert_array_equal(codecs.blosc_decode(frame, backend=None).view(np.uint16), a)
+    # corrupt frames are reported, not dereferenced
+    frame = codecs.blosc_encode(rng.poisson(300, 50000).astype(np.uint16), 2, "zstd", 1, 1, backend="libblosc")
+    out = np.zeros(100000, np.uint8)
+    with pytest.raises(ValueError, match="runs past the end|does not decode"):
+        codecs._native_decode(frame[:len(frame) // 2], out)
+    bad = bytearray(frame)
+    bad[40:60] = bytes(20)
+    with pytest.raises(ValueError, match="corrupt blosc frame"):
+        codecs._native_decode(bytes(bad), out)
+    with pytest.raises(ValueError, match="destination has"):
+        codecs._native_decode(frame, np.zeros(10, np.uint8))

@@ -23,6 +23,11 @@ def main():
     ap.add_argument("--units", type=int, default=12)
     ap.add_argument("--scratch", default=None)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--engine-format", action="store_true",
+                    help="input as the acquisition writes it: Zarr v3, one shard per volume around blosc-zstd chunks "
+                         "(frames made by c-blosc when LSR_LIBBLOSC points at one)")
+    ap.add_argument("--read-backend", default=None, choices=["libblosc", "lsrecon", "python"],
+                    help="who decodes the frames in the timed run (default: the best one loadable)")
     args = ap.parse_args()
     import torch
 
@@ -51,14 +56,23 @@ def main():
         return wrapper
 
     try:
-        with open_ome_zarr(root / "in.zarr", layout="hcs", mode="w", channel_names=["LS"], prefer_iohub=False) as plate:
+        fmt = dict(compress="blosc-zstd", shards="volume") if args.engine_format else {}
+        with open_ome_zarr(root / "in.zarr", layout="hcs", mode="w", channel_names=["LS"], prefer_iohub=False,
+                           version="0.5" if args.engine_format else "0.4") as plate:
             for p in range(args.units):
                 arr = plate.create_position("A", str(p + 1), "0").create_zeros(
-                    "0", shape=(1, 1) + tuple(raw_shape), dtype="uint16", scale=(1, 1, 0.15, 0.1133, 0.1133))
+                    "0", shape=(1, 1) + tuple(raw_shape), dtype="uint16", scale=(1, 1, 0.15, 0.1133, 0.1133), **fmt)
                 v = bench.synthetic_raw(raw_shape, seed=1000 * cid + 7 * p, device=dev)
                 arr.write_volume(0, 0, v.to(torch.uint16).cpu().numpy())
                 del v
         torch.cuda.empty_cache()
+        from shrimpy_amd.io import codecs
+        writer = codecs.blosc_backend()
+        if args.read_backend in ("lsrecon", "python"):
+            codecs._libblosc, codecs._libblosc_tried = None, True
+            codecs._numcodecs_blosc, codecs._numcodecs_tried = None, True
+        if args.read_backend == "python":
+            codecs._native, codecs._native_tried = None, True
         omezarr.ZarrArray.read_volume = timed("read", omezarr.ZarrArray.read_volume)
         omezarr.ZarrArray.write_volume = timed("write", omezarr.ZarrArray.write_volume)
         staging.VolumeStager.host_in = timed("wait_host_in", staging.VolumeStager.host_in)
@@ -75,7 +89,9 @@ def main():
                        "max": round(max(v), 4)} for k, v in busy.items()}
         print(json.dumps({"workload": args.workload, "units": res["units_total"], "job_seconds": res["job_seconds"],
                           "wall_seconds": total, "s_per_unit": res["job_seconds"] / res["units_total"],
-                          "scratch": str(root.parent), "stages": summary}))
+                          "scratch": str(root.parent), "engine_format": args.engine_format, "frames_written_by": writer if args.engine_format else None,
+                          "blosc_backend": __import__("shrimpy_amd.io.codecs", fromlist=["x"]).blosc_backend(),
+                          "stages": summary}))
         if args.verbose:
             for name, th, a, b in sorted(spans, key=lambda s: s[2]):
                 print(f"{a:8.3f} {b:8.3f} {b - a:7.3f}  {name:14s} {th}")
