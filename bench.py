@@ -419,6 +419,12 @@ def plate_settings(workload):
         deconvolution=DeconvolveSettings(iterations=RL_ITERS))
 
 
+def _blosc_backend() -> str:
+    from shrimpy_amd.io.codecs import blosc_backend
+
+    return blosc_backend()
+
+
 def run_plate(args, rank, world, device, shared, backend, cpu):
     """Configs 4 / 5: (a) one unit per GPU with its uint16 stack resident in HBM through the
     production pipeline object (``VolumeReconstructor``); (b) the same kind of units store to store."""
@@ -468,12 +474,13 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
         try:
             keys = [f"A/{p + 1}/0" for p in range(n_p)]
             if rank == 0:
+                fmt = dict(compress="blosc-zstd", shards="volume") if args.engine_format else {}
                 with open_ome_zarr(root / "in.zarr", layout="hcs", mode="w", channel_names=["LS"],
-                                   prefer_iohub=False) as plate:
+                                   prefer_iohub=False, version="0.5" if args.engine_format else "0.4") as plate:
                     for p, key in enumerate(keys):
                         arr = plate.create_position(*key.split("/")).create_zeros(
                             "0", shape=(n_t, 1) + tuple(raw_shape), dtype="uint16",
-                            scale=(1, 1, 0.15, 0.1133, 0.1133))
+                            scale=(1, 1, 0.15, 0.1133, 0.1133), **fmt)
                         for t in range(n_t):
                             v = synthetic_raw(raw_shape, seed=1000 * config_id + 7 * p + t, device=device)
                             arr.write_volume(t, 0, v.to(torch.uint16).cpu().numpy())
@@ -487,8 +494,11 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
                 "positions": n_p, "timepoints": n_t, "units": units, "seconds": res["job_seconds"],
                 "s_per_unit": res["job_seconds"] / max(units, 1) * world,
                 "voxels_per_s": units * n_in / res["job_seconds"],
-                "io": (f"native OME-Zarr reader/writer, uncompressed chunks (input (1,1,32,ny,nx), output ~64 MB), scratch {root.parent}, "
-                       "input from the page cache; pinned staging slots + copy streams (cli.run_store)"),
+                "io": ("native OME-Zarr reader/writer, "
+                       + ("input in the acquisition's format (Zarr v3, one shard per volume, blosc-zstd chunks (1,1,32,ny,nx), "
+                          f"frames decoded by {_blosc_backend()}), output uncompressed ~64 MB chunks, " if args.engine_format
+                          else "uncompressed chunks (input (1,1,32,ny,nx), output ~64 MB), ")
+                       + f"scratch {root.parent}, input from the page cache; pinned staging slots + copy streams (cli.run_store)"),
             }
             if world > 1:
                 dist.barrier()
@@ -555,6 +565,9 @@ def main():
                     help="separable PSF: one launch per RL iteration (default) or the ratio / update pair")
     ap.add_argument("--no-store-leg", action="store_true", help="config4/5: skip the store-to-store leg")
     ap.add_argument("--scratch", default=None, help="config4/5: directory for the temporary plates (default: TMPDIR)")
+    ap.add_argument("--engine-format", action="store_true",
+                    help="config4/5 store leg: input plate as the acquisition writes it (Zarr v3, one shard per "
+                         "volume around blosc-zstd chunks) instead of uncompressed chunks")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
