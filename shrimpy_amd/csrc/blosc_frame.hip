@@ -121,7 +121,8 @@ extern "C" int lsr_blosc_decode_host(const uint8_t* frame, int64_t frame_bytes, 
   }
   const bool byte_shuffled = (flags & 0x1) && T > 1;
   LSR_REQUIRE(byte_shuffled || !(flags & 0x4), LSR_E_UNSUPPORTED, "bit-shuffled blosc frame: decoded by the Python codec");
-  LSR_REQUIRE(blocksize > 0, LSR_E_ARG, "corrupt blosc frame: blocksize 0");
+  LSR_REQUIRE(blocksize > 0 && blocksize <= nbytes, LSR_E_ARG, "corrupt blosc frame: blocksize %lld of %lld bytes",
+              (long long)blocksize, (long long)nbytes);
   const int compressor = flags >> 5;
   const Decoders& dec = decoders();
   LSR_REQUIRE(lsr_blosc_host_codec(compressor), LSR_E_UNSUPPORTED,
