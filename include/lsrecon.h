@@ -92,6 +92,20 @@ int lsr_deskew_u16(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* o
                    const double M[12], int avg_n, lsr_stream_t stream);
 
 /*
+ * The same kernel under an explicit border rule, all input variants behind one entry: in_u16 != 0 reads
+ * uint16 counts, flat_pattern / flat_mean (both or neither NULL) fuse the flat-field correction, and
+ * mode = LSR_MODE_CONSTANT | LSR_MODE_GRID_CONSTANT.  "grid-constant" continues the raw stack with zeros, so
+ * a scan coordinate within one sample of either end blends its inside neighbour with 0 -- what
+ * scipy mode="grid-constant" and torch grid_sample(padding_mode="zeros") do; the deskew geometry is
+ * [RECALLED], this is the switch that covers the other border convention at full
+ * speed.  Bit-identical to lsr_affine_f32(mode) followed by lsr_average_slices_f32.
+ */
+int lsr_deskew_border(const void* in, int in_u16, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo,
+                      int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd,
+                      const double M[12], int avg_n, int mode, const float* flat_pattern,
+                      const float* flat_mean, lsr_stream_t stream);
+
+/*
  * General order-1 (trilinear) affine resample; any 3x4 matrix.
  * mode/cval as scipy.ndimage.affine_transform. fp64 coordinates and weights, same operation
  * order as scipy: bit-identical to the CPU oracle for finite inputs.

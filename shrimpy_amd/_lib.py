@@ -43,6 +43,8 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 SIGNATURES: dict[str, list] = {
     "lsr_version": [],
     "lsr_deskew_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p, _int, _stream],
+    "lsr_deskew_border": [ctypes.c_void_p, _int, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p,
+                          _int, _int, ctypes.c_void_p, ctypes.c_void_p, _stream],
     "lsr_deskew_u16": [ctypes.c_void_p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p, _int, _stream],
     "lsr_deskew_flat_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p, _int,
                             _c_f32p, _c_f32p, _stream],

@@ -41,6 +41,7 @@ struct DeskewArgs {
   int64_t oy, ox;
   int sy, sx;
   int avg_n;
+  int grid;                 // border rule: 0 = scipy "constant", 1 = "grid-constant" (blend towards 0 across the z border)
   int tile_x;               // X' handled per workgroup (<= kTileX, chosen so the slab fits)
   int64_t tiles_x, tiles_y; // workgroup grid, flattened: x fastest, then y, then zo
   const float* flat_pattern;  // FLAT: (Y, X) per-pixel median over Z (flatfield.hip)
@@ -57,6 +58,8 @@ template <bool FLAT, bool U16 = false>
 __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
   using raw_t = std::conditional_t<U16, unsigned short, float>;
   __shared__ float slab[kSlabRows * kPitch];
+  __shared__ float zero_row[kPitch];
+  if (threadIdx.x < kPitch) zero_row[threadIdx.x] = 0.0f;   // visible after the first barrier below
 
   const int tid = threadIdx.x;
   int64_t bid = blockIdx.x;
@@ -139,17 +142,23 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
 
     // sample: scipy order-1 along z only (the y/x weights are exactly 1 and 0)
     const double z_in = lsr::affine_coord(zd_d, 0.0, xo_d, p.a, 0.0, p.b, p.c);
-    const bool ok = row_ok && (li < n_xo) && !(z_in < 0.0) && !(z_in > zmax_d);
+    // "constant": a coordinate outside [0, Z-1] gives 0.  "grid-constant": the volume continues as
+    // zeros, so a coordinate in (-1, 0) or (Z-1, Z) still blends its one inside neighbour with 0
+    // (scipy sums cval * weight for the outside tap: +0 here).  y_in / x_in are integers: a row or
+    // column outside the volume is 0 under both rules.
+    const bool ok = row_ok && (li < n_xo) &&
+                    (p.grid ? (z_in > -1.0 && z_in < zmax_d + 1.0) : (!(z_in < 0.0) && !(z_in > zmax_d)));
     if (ok) {
       const double zf = floor(z_in);
       const double f = z_in - zf;
       const double w0 = 1.0 - f;
       const double w1 = 1.0 - w0;
-      const int64_t z0 = static_cast<int64_t>(zf);
-      const int r0 = static_cast<int>(z0 - z_lo);
+      const int64_t z0 = static_cast<int64_t>(zf);              // -1 .. Z-1
+      const int r0 = static_cast<int>(max(z0, static_cast<int64_t>(0)) - z_lo);
       const int r1 = static_cast<int>(min(z0 + 1, p.Z - 1) - z_lo);
-      const float* s0 = slab + r0 * kPitch;
-      const float* s1 = slab + r1 * kPitch;
+      // a neighbour past the end of the scan ("grid-constant" only) reads the row of zeros
+      const float* s0 = z0 < 0 ? zero_row : slab + r0 * kPitch;
+      const float* s1 = (p.grid && z0 + 1 > p.Z - 1) ? zero_row : slab + r1 * kPitch;
 #pragma unroll
       for (int m = 0; m < kRowsPerThread; ++m) {
         const int j = lj0 + 4 * m;
@@ -201,8 +210,10 @@ namespace {
 int deskew_impl(const char* what, const void* in, bool u16, int64_t Z, int64_t Y, int64_t X, float* out,
                 int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane,
                 int64_t Zd, const double M[12], int avg_n, const float* flat_pattern,
-                const float* flat_mean, lsr_stream_t stream) {
+                const float* flat_mean, lsr_stream_t stream, int mode = LSR_MODE_CONSTANT) {
   LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE(mode == LSR_MODE_CONSTANT || mode == LSR_MODE_GRID_CONSTANT, LSR_E_ARG,
+              "mode %d: LSR_MODE_CONSTANT or LSR_MODE_GRID_CONSTANT", mode);
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE_PTR(M);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "raw shape (%lld,%lld,%lld) must be positive",
@@ -238,6 +249,7 @@ int deskew_impl(const char* what, const void* in, bool u16, int64_t Z, int64_t Y
   p.sy = static_cast<int>(M[4]); p.oy = static_cast<int64_t>(M[7]);
   p.sx = static_cast<int>(M[9]); p.ox = static_cast<int64_t>(M[11]);
   p.avg_n = avg_n;
+  p.grid = mode == LSR_MODE_GRID_CONSTANT ? 1 : 0;
 
   // slab rows needed by a tile of w X' values: floor span of |b|*(w-1) plus the +1 neighbour
   const double ab = p.b < 0 ? -p.b : p.b;
@@ -301,6 +313,16 @@ extern "C" int lsr_deskew_flat_f32(const float* in, int64_t Z, int64_t Y, int64_
   LSR_REQUIRE_PTR(flat_mean);
   return deskew_impl("lsr_deskew_flat_f32", in, false, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd,
                      M, avg_n, flat_pattern, flat_mean, stream);
+}
+
+extern "C" int lsr_deskew_border(const void* in, int in_u16, int64_t Z, int64_t Y, int64_t X, float* out,
+                                 int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane,
+                                 int64_t Zd, const double M[12], int avg_n, int mode, const float* flat_pattern,
+                                 const float* flat_mean, lsr_stream_t stream) {
+  LSR_REQUIRE((flat_pattern == nullptr) == (flat_mean == nullptr), LSR_E_NULL,
+              "flat_pattern and flat_mean come together (both NULL: no flat-field correction)");
+  return deskew_impl("lsr_deskew_border", in, in_u16 != 0, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M,
+                     avg_n, flat_pattern, flat_mean, stream, mode);
 }
 
 extern "C" int lsr_average_slices_f32(const float* in, int64_t Zd, int64_t Y, int64_t X,

@@ -86,7 +86,9 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
     ``border``: ``"constant"`` (default) is scipy's ``mode="constant"`` -- a sample with any
     coordinate outside ``[0, n-1]`` is zero, no blending; ``"grid-constant"`` blends towards zero
     across the border the way ``scipy mode="grid-constant"`` / torch ``grid_sample(zeros)`` do
-    (SURVEY.md section 7).  The blending form runs the general trilinear kernel.
+    (SURVEY.md section 7).  Both rules run the fused transpose kernel (``lsr_deskew_border``) and may
+    write into a padded RL volume; matrices that are not a deskew shear fall back to the general
+    trilinear kernel under either rule.
     """
     import torch
 
@@ -136,11 +138,13 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
             raise ValueError(f"flat_field pattern must be {(y, x)}, got {tuple(flat_field.pattern.shape)}")
         try:
             if border != "constant":
-                if hasattr(out, "logical_ptr"):
-                    raise ValueError("border='grid-constant' cannot write into a padded RL volume")
-                raise _lib.LsrUnsupported("deskew_with_matrix", _lib.E_UNSUPPORTED,
-                                          "blending border: general trilinear kernel")
-            if flat_field is not None:
+                _lib.call(
+                    "lsr_deskew_border", raw.data_ptr(), 1 if u16 else 0, z, y, x, out_ptr, zo, yo, xo, out_pitch,
+                    out_plane, zd, _lib.matrix12(m), avg, _lib.MODE_GRID_CONSTANT,
+                    flat_field.pattern.data_ptr() if flat_field is not None else None,
+                    flat_field.mean.data_ptr() if flat_field is not None else None, stream,
+                )
+            elif flat_field is not None:
                 _lib.call(
                     "lsr_deskew_flat_u16" if u16 else "lsr_deskew_flat_f32", raw.data_ptr(), z, y, x, out_ptr, zo, yo, xo, out_pitch,
                     out_plane, zd, _lib.matrix12(m), avg, flat_field.pattern.data_ptr(),

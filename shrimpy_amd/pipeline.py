@@ -88,7 +88,8 @@ class VolumeReconstructor:
             from .geometry import orient_shape
 
             shape = orient_shape(self._geo.output_shape, d.orientation)
-            self._canonical_deskew = d.orientation in ("identity", "") and d.border == "constant"
+            # un-oriented output: the deskew kernel (either border rule) can write the RL input in place
+            self._canonical_deskew = d.orientation in ("identity", "")
         self._register: RegisterSettings | None = settings.registration
         if self._register is not None and self._register.output_shape_zyx is not None:
             shape = tuple(self._register.output_shape_zyx)

@@ -9,6 +9,8 @@ Bars (stated here, as the north-star requires):
   max|cpu|`` after 20 iterations (5e-5 / 2e-5 after <= 5), separable factorisation included.
 """
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -129,6 +131,54 @@ def test_deskew_orientation_and_border_switches_vs_oracle_bit_exact(device, spec
     parts = [fast_deskew_zyx(raw_data=c.contiguous(), orientation=spec, border=border, **kw)
              for c in torch.chunk(_t(raw, device), 4, dim=-1)]
     assert torch.equal(torch.cat(parts[::-1] if reverse else parts, dim=axis), got)
+
+
+@pytest.mark.parametrize("shape,keep,avg", [((90, 25, 48), True, 3), ((300, 40, 70), False, 3), ((64, 16, 130), True, 1),
+                                            ((257, 33, 65), False, 2)])
+def test_blending_border_runs_the_fused_deskew_kernel(device, shape, keep, avg):
+    """``border="grid-constant"`` (scipy ``mode="grid-constant"`` / ``grid_sample(zeros)``: the scan
+    continues as zeros, a coordinate within one sample of either end blends) goes through the same
+    LDS-transpose kernel as the default rule (``lsr_deskew_border``): equal to the oracle and to the
+    general gather kernel + slice averaging bit for bit, for float32 / uint16 input, with the
+    flat-field division fused, and when the destination is the RL plan's padded volume."""
+    import torch
+
+    from shrimpy_amd import _lib
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+    from shrimpy_amd.deskew import deskew_with_matrix
+    from shrimpy_amd.flatfield import flat_field_pattern
+    from shrimpy_amd.geometry import deskew_geometry
+
+    rng = np.random.default_rng(41)
+    raw = rng.integers(80, 600, shape).astype(np.float32)
+    geo = deskew_geometry(shape, 30.0, 0.755, keep, avg, 0.1133)
+    want = o.deskew(raw, 30.0, 0.755, keep, avg, border="grid-constant")
+    if keep:   # with the overhang kept, output voxels straddle both ends of the scan: the rule matters
+        assert not np.array_equal(want, o.deskew(raw, 30.0, 0.755, keep, avg))
+    t = _t(raw, device)
+    got = deskew_with_matrix(t, geo.matrix_3x4, geo.pre_average_shape, avg, border="grid-constant")
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    # the general kernel + averaging: the pair the fused kernel replaces
+    zd, yo, xo = geo.pre_average_shape
+    pre = torch.empty((zd, yo, xo), dtype=torch.float32, device=device)
+    _lib.call("lsr_affine_f32", t.data_ptr(), *shape, pre.data_ptr(), zd, yo, xo, _lib.matrix12(geo.matrix_3x4),
+              ctypes.c_float(0.0), _lib.MODE_GRID_CONSTANT, _lib.stream_ptr(device))
+    ref = torch.empty_like(got)
+    _lib.call("lsr_average_slices_f32", pre.data_ptr(), zd, yo, xo, ref.data_ptr(), ref.shape[0], avg,
+              _lib.stream_ptr(device))
+    assert torch.equal(got, ref)
+    got16 = deskew_with_matrix(t.to(torch.uint16), geo.matrix_3x4, geo.pre_average_shape, avg, border="grid-constant")
+    assert torch.equal(got16, got)
+    flat = flat_field_pattern(t)
+    fused = deskew_with_matrix(t, geo.matrix_3x4, geo.pre_average_shape, avg, flat_field=flat, border="grid-constant")
+    two_step = deskew_with_matrix(flat.apply(t), geo.matrix_3x4, geo.pre_average_shape, avg, border="grid-constant")
+    assert torch.equal(fused, two_step)
+    psf, _ = o.gaussian_psf((5, 5, 5), (1.2, 1.0, 1.0))
+    pl = RichardsonLucyPlan(tuple(got.shape), psf, device)
+    if pl.path != "generic":
+        padded = pl.new_padded_input()
+        deskew_with_matrix(t, geo.matrix_3x4, geo.pre_average_shape, avg, out=padded, border="grid-constant")
+        assert torch.equal(padded.view, got)
 
 
 def test_pipeline_honours_deskew_switches(device):

@@ -153,11 +153,14 @@ def _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_ge
         raw = torch.rand(raw_shape, device=dev, generator=g)
         geo = deskew_geometry(raw_shape, **bench.DESKEW)
         dst = torch.empty(geo.output_shape, device=dev)
-        ms = timed(lambda: deskew_with_matrix(raw, geo.matrix_3x4, geo.pre_average_shape, 3, out=dst), args.reps)
         nbytes = 4.0 * raw.numel() + 4.0 * dst.numel()
-        print(json.dumps({"kernel": "deskew_kernel", "workload": name, "raw": raw_shape,
-                          "out": geo.output_shape, "ms": ms, "algorithmic_GBps": nbytes / ms / 1e6,
-                          "frac_of_8TBps": nbytes / ms / 1e6 / 8000}))
+        for border in ("constant", "grid-constant"):
+            ms = timed(lambda: deskew_with_matrix(raw, geo.matrix_3x4, geo.pre_average_shape, 3, out=dst, border=border),
+                       args.reps)
+            print(json.dumps({"kernel": "deskew_kernel" + ("" if border == "constant" else " (border grid-constant)"),
+                              "workload": name, "raw": raw_shape,
+                              "out": geo.output_shape, "ms": ms, "algorithmic_GBps": nbytes / ms / 1e6,
+                              "frac_of_8TBps": nbytes / ms / 1e6 / 8000}))
         del raw, dst
 
 
