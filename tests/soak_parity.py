@@ -49,6 +49,7 @@ def main():
         ratio = float(np.round(r.uniform(0.25, 2.0), 3))
         keep, avg = bool(r.integers(0, 2)), int(r.integers(1, 6))
         u16 = bool(r.integers(0, 2))
+        border = "grid-constant" if r.integers(0, 2) else "constant"     # both rules run the fused kernel
         try:
             want_shape = o.deskewed_shape(shape, angle, ratio, keep, avg)[0]
         except Exception:
@@ -56,10 +57,10 @@ def main():
         if min(want_shape) <= 0:
             return None
         raw = r.integers(0, 60000, shape).astype(np.uint16) if u16 else (r.random(shape) * 4000 - 500).astype(np.float32)
-        want = o.deskew(raw.astype(np.float32), angle, ratio, keep, avg)
+        want = o.deskew(raw.astype(np.float32), angle, ratio, keep, avg, border=border)
         got = fast_deskew_zyx(raw_data=t(raw), ls_angle_deg=angle, px_to_scan_ratio=ratio, keep_overhang=keep,
-                              average_n_slices=avg).cpu().numpy()
-        return got.shape == want.shape and np.array_equal(got, want), (shape, angle, ratio, keep, avg, u16)
+                              average_n_slices=avg, border=border).cpu().numpy()
+        return got.shape == want.shape and np.array_equal(got, want), (shape, angle, ratio, keep, avg, u16, border)
 
     def affine_case(r):
         shape = (int(r.integers(1, 40)), int(r.integers(2, 90)), int(r.integers(2, 140)))
