@@ -383,6 +383,9 @@ int lsr_blur_reflect_f32(const float* in, float* out, int64_t Z, int64_t Y, int6
 int lsr_match_shape_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
                         int64_t Yo, int64_t Xo, lsr_stream_t stream);
 int lsr_cross_power_c64(float* a, const float* b, int64_t n, lsr_stream_t stream);
+/* dst[a][c][b] = src[a][b][c] for complex64 (8-byte) elements, out of place: the layout change between
+ * the per-axis transforms of the cross-correlation's 3-D FFT (A = 1: a plain 2-D transpose). */
+int lsr_transpose_last2_c64(const float* src, float* dst, int64_t A, int64_t B, int64_t C, lsr_stream_t stream);
 /* b <- a * conj(b): the same product written over the second operand, so that `a` (the spectrum of
  * a reference volume that is compared against many timepoints) can be kept. */
 int lsr_cross_power_into_c64(const float* a, float* b, int64_t n, lsr_stream_t stream);

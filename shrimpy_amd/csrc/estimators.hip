@@ -550,6 +550,49 @@ __global__ __launch_bounds__(kThreads) void cross_power_kernel(float* __restrict
   }
 }
 
+// dst[a][c][b] = src[a][b][c] for 8-byte elements (complex64): the layout changes between the per-axis
+// transforms of the 3-D FFT (dynatrack._Fft3 runs one contiguous batched 1-D transform per axis; rocFFT's
+// own 3-D plan spends more time in its transposes and in torch's input clone than in the butterflies).
+// 64 x 64 tiles through LDS: 512-byte runs on both sides.  Also the plain 2-D transpose (A = 1).
+constexpr int kTr = 64;
+struct TransposeArgs {
+  const double* src;     // 8-byte payloads, moved as doubles (never interpreted)
+  double* dst;
+  int64_t A, B, C;
+  int64_t tiles_b, tiles_c;
+};
+__global__ __launch_bounds__(kThreads) void transpose_c64_kernel(TransposeArgs p) {
+  __shared__ double tile[kTr][kTr + 1];
+  int64_t t = blockIdx.x;
+  const int64_t tc = t % p.tiles_c;
+  t /= p.tiles_c;
+  const int64_t tb = t % p.tiles_b;
+  const int64_t a = t / p.tiles_b;
+  const int64_t b0 = tb * kTr, c0 = tc * kTr;
+  const int lane = threadIdx.x & 63, row0 = threadIdx.x >> 6;     // 4 rows per pass, 16 passes
+  constexpr int kPer = kTr / (kThreads / 64);
+  // all 16 loads of a thread are issued before the first use: addresses are clamped into the array
+  // (the values of out-of-range positions are never stored), so no load sits under a condition
+  const double* src = p.src + a * p.B * p.C;
+  const int64_t col = min(c0 + lane, p.C - 1);
+  double v[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) v[i] = src[min(b0 + row0 + 4 * i, p.B - 1) * p.C + col];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) tile[row0 + 4 * i][lane] = v[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) v[i] = tile[lane][row0 + 4 * i];
+  double* dst = p.dst + (a * p.C + c0) * p.B + b0 + lane;
+  if (b0 + lane < p.B) {
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int r = row0 + 4 * i;
+      if (c0 + r < p.C) dst[static_cast<int64_t>(r) * p.B] = v[i];
+    }
+  }
+}
+
 // argmax(fftshift(|corr|)) without materialising either: the largest |v|, ties resolved by the
 // smallest flat index in fftshift order (torch.argmax returns the first maximum).
 struct PeakArgs {
@@ -767,6 +810,27 @@ extern "C" int lsr_cross_power_c64(float* a, const float* b, int64_t n, lsr_stre
   hipLaunchKernelGGL(cross_power_kernel<false>, dim3(grid_for(n) * 4), dim3(kThreads), 0, lsr::as_stream(stream), a,
                      const_cast<float*>(b), n);
   return lsr::launch_status("lsr_cross_power_c64");
+}
+
+extern "C" int lsr_transpose_last2_c64(const float* src, float* dst, int64_t A, int64_t B, int64_t C,
+                                       lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(src);
+  LSR_REQUIRE_PTR(dst);
+  LSR_REQUIRE(src != dst, LSR_E_ARG, "the transpose works out of place");
+  LSR_REQUIRE(A > 0 && B > 0 && C > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)A, (long long)B,
+              (long long)C);
+  LSR_REQUIRE((reinterpret_cast<uintptr_t>(src) & 7) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0, LSR_E_ARG,
+              "complex64 arrays must be 8-byte aligned");
+  TransposeArgs p;
+  p.src = reinterpret_cast<const double*>(src);
+  p.dst = reinterpret_cast<double*>(dst);
+  p.A = A; p.B = B; p.C = C;
+  p.tiles_b = lsr::ceil_div(B, kTr);
+  p.tiles_c = lsr::ceil_div(C, kTr);
+  const int64_t blocks = A * p.tiles_b * p.tiles_c;
+  LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large", (long long)blocks);
+  hipLaunchKernelGGL(transpose_c64_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, lsr::as_stream(stream), p);
+  return lsr::launch_status("lsr_transpose_last2_c64");
 }
 
 extern "C" int lsr_cross_power_into_c64(const float* a, float* b, int64_t n, lsr_stream_t stream) {

@@ -397,14 +397,35 @@ def _match_shape(t, shape):
     return out
 
 
+def _spectrum(vol, shape, kind: str):
+    """Forward transform of ``vol`` matched to the FFT ``shape``: ``kind`` "rfft3" = one batched
+    1-D library transform per axis with this package's transposes in between (``fft3.rfft3``,
+    spectrum laid out ``[XC][Y][Z]``), "rfftn" = ``torch.fft.rfftn``."""
+    import torch
+
+    matched = _match_shape(vol, shape)
+    if kind == "rfft3":
+        from . import fft3
+
+        return fft3.rfft3(matched)
+    return torch.fft.rfftn(matched)
+
+
+_axis_fft_ok = [True]      # cleared when hipFFT refuses a plan: the torch.fft route is used from then on
+
+
 def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0) -> tuple[int, ...]:
     """FFT phase cross-correlation, pixel shifts in ZYX order (``tracking.py:309-378``).
 
-    The two forward FFTs and the inverse one are rocFFT library calls (through ``torch.fft``); the
-    steps around them -- shape matching, ``f1 * conj(f2)``, ``argmax(fftshift(|corr|))`` -- are HIP
-    kernels that write nothing but their result.
+    The transforms are rocFFT library calls; the steps around them -- shape matching,
+    ``f1 * conj(f2)``, ``argmax(fftshift(|corr|))`` -- are HIP kernels that write nothing but their
+    result.  The 3-D transforms run axis by axis (``fft3``: contiguous batched 1-D transforms through
+    hipFFT's C API, this package's transposes in between, spectra kept in the transposed layout);
+    ``torch.fft.rfftn`` / ``irfftn`` are the fallback when hipFFT's C API is not loadable.
     """
     import torch
+
+    from . import fft3
 
     ref_t, mov_t = _volume(ref_img, "ref_img"), _volume(mov_img, "mov_img")
     if ref_t.dim() != 3 or mov_t.dim() != 3:
@@ -412,28 +433,46 @@ def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0) -> tuple[int
     shape = tuple(_next_fast_len(int(max(s1, s2) * maximum_shift)) for s1, s2 in zip(ref_t.shape, mov_t.shape))
     logger.debug("phase cross corr: fft shape %s for arrays %s and %s (max_shift=%.2f)", shape,
                  tuple(ref_t.shape), tuple(mov_t.shape), maximum_shift)
-    # the reference's spectrum is reused while the caller keeps comparing against the same tensor
-    cacheable = ref_t is ref_img and _spectra.max_bytes > 0
-    fimg1 = _spectra.get(ref_t, ("rfftn", shape)) if cacheable else None
-    if fimg1 is None:
-        fimg1 = torch.fft.rfftn(_match_shape(ref_t, shape))
-        if cacheable:
-            _spectra.put(ref_t, ("rfftn", shape), fimg1)
-    fimg2 = torch.fft.rfftn(_match_shape(mov_t, shape))
-    with torch.cuda.device(fimg2.device):
-        stream = _lib.stream_ptr(fimg2.device)
-        # f1 * conj(f2), written over f2: f1 may be the cached spectrum
-        _lib.call("lsr_cross_power_into_c64", fimg1.data_ptr(), fimg2.data_ptr(), fimg2.numel(), stream)
-        del fimg1
-        corr = torch.fft.irfftn(fimg2, s=shape).contiguous()
-        del fimg2
+    kind = "rfft3" if (_axis_fft_ok[0] and fft3.available()) else "rfftn"
+    try:
+        corr = _cross_correlation(ref_t, ref_t is ref_img, mov_t, shape, kind)
+    except fft3.AxisFftError as exc:
+        logger.warning("axis-by-axis FFT unavailable (%s): using torch.fft", exc)
+        _axis_fft_ok[0] = False
+        corr = _cross_correlation(ref_t, ref_t is ref_img, mov_t, shape, "rfftn")
+    with torch.cuda.device(corr.device):
         peak_index = torch.empty((1,), dtype=torch.int64, device=corr.device)
         _lib.call("lsr_peak_abs_shifted_f32", corr.data_ptr(), *shape, peak_index.data_ptr(),
-                  _scratch(corr.device).data_ptr(), stream)
+                  _scratch(corr.device).data_ptr(), _lib.stream_ptr(corr.device))
     peak = np.unravel_index(int(peak_index.item()), shape)
     result = tuple(int(s // 2) - int(p) for s, p in zip(shape, peak))
     logger.debug("phase cross corr: peak at %s (device=%s)", result, corr.device)
     return result
+
+
+def _cross_correlation(ref_t, ref_is_callers, mov_t, shape, kind: str):
+    """``irfftn(rfftn(ref) * conj(rfftn(mov)))`` on the FFT grid ``shape`` (any positive scale: only
+    its peak is used), float32 ``(Z, Y, X)``."""
+    import torch
+
+    # the reference's spectrum is reused while the caller keeps comparing against the same tensor
+    cacheable = ref_is_callers and _spectra.max_bytes > 0
+    fimg1 = _spectra.get(ref_t, (kind, shape)) if cacheable else None
+    if fimg1 is None:
+        fimg1 = _spectrum(ref_t, shape, kind)
+        if cacheable:
+            _spectra.put(ref_t, (kind, shape), fimg1)
+    fimg2 = _spectrum(mov_t, shape, kind)
+    with torch.cuda.device(fimg2.device):
+        # f1 * conj(f2), written over f2: f1 may be the cached spectrum (element-wise: any layout)
+        _lib.call("lsr_cross_power_into_c64", fimg1.data_ptr(), fimg2.data_ptr(), fimg2.numel(),
+                  _lib.stream_ptr(fimg2.device))
+        del fimg1
+        if kind == "rfft3":
+            from . import fft3
+
+            return fft3.irfft3(fimg2, shape)
+        return torch.fft.irfftn(fimg2, s=shape).contiguous()
 
 
 def _centered_gaussian_blob(shape, sigma: float, device):

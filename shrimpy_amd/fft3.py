@@ -1,0 +1,172 @@
+"""3-D real FFT for the cross-correlation of ``dynatrack._phase_cross_corr``, axis by axis.
+
+``torch.fft.rfftn`` / ``irfftn`` of the tracker's grid (180 x 2048 x 2304) take 13.6 / 16.9 ms on an
+MI355X, of which the butterfly kernels are 4.4 ms: the rest is rocFFT's own transposes between the
+axes, its real <-> complex pre / post passes, and a device-to-device clone of the input that PyTorch
+makes before every rocFFT call on ROCm plus a separate normalisation kernel on the way back
+(``tools/probes/fft_split.py``, ``fft_calls.py``; ``profiles/r02_secondary_kernel_stats.csv``).  Here
+the same library does only what it is fast at -- one contiguous, batched, in-place 1-D transform per
+axis, called through hipFFT's C API (the copy PyTorch ships and has already loaded: no second FFT
+library enters the process) -- and the layout changes between the axes are this package's transpose
+kernel (``lsr_transpose_last2_c64``).  The spectrum stays in the transposed layout ``[XC][Y][Z]``
+(``XC = X // 2 + 1``): the cross power is element-wise and does not care, and the way back undoes it.
+No normalisation either way: the consumer takes an argmax.
+
+The FFTs remain library calls (rocFFT), as the build's rules ask for plain library transforms.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+from . import _lib
+
+__all__ = ["available", "rfft3", "irfft3", "AxisFftError"]
+
+_HIPFFT_R2C, _HIPFFT_C2R, _HIPFFT_C2C = 0x2A, 0x2C, 0x29
+_FORWARD, _BACKWARD = -1, 1
+
+
+class AxisFftError(RuntimeError):
+    """hipFFT refused a plan or an execution (the caller falls back to ``torch.fft``)."""
+
+
+_hipfft = None
+_hipfft_tried = False
+
+
+def _lib_hipfft():
+    global _hipfft, _hipfft_tried
+    if not _hipfft_tried:
+        _hipfft_tried = True
+        if os.environ.get("LSR_AXIS_FFT", "1") in ("0", "off", "false"):
+            return None
+        try:
+            import torch
+
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "libhipfft.so")
+            lib = ctypes.CDLL(path)
+            lib.hipfftPlanMany.restype = ctypes.c_int
+            lib.hipfftPlanMany.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                           ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int]
+            lib.hipfftSetStream.restype = ctypes.c_int
+            lib.hipfftSetStream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            lib.hipfftExecC2C.restype = ctypes.c_int
+            lib.hipfftExecC2C.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+            lib.hipfftExecR2C.restype = ctypes.c_int
+            lib.hipfftExecR2C.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            lib.hipfftExecC2R.restype = ctypes.c_int
+            lib.hipfftExecC2R.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            lib.hipfftDestroy.restype = ctypes.c_int
+            lib.hipfftDestroy.argtypes = [ctypes.c_void_p]
+            _hipfft = lib
+        except (OSError, AttributeError, ImportError):
+            _hipfft = None
+    return _hipfft
+
+
+def available() -> bool:
+    """hipFFT's C API is loadable from the PyTorch installation (``LSR_AXIS_FFT=0`` switches this path off)."""
+    return _lib_hipfft() is not None
+
+
+# (device index, kind, n, batch) -> plan handle; a handful of plans per grid shape, dropped oldest first
+_plans: dict = {}
+_MAX_PLANS = 24
+
+
+def _plan(device, kind: int, n: int, batch: int):
+    lib = _lib_hipfft()
+    key = (device.index, kind, int(n), int(batch))
+    plan = _plans.get(key)
+    if plan is None:
+        if batch >= 2 ** 31 or n >= 2 ** 31:
+            raise AxisFftError(f"transform of length {n} x batch {batch} exceeds hipFFT's int arguments")
+        while len(_plans) >= _MAX_PLANS:
+            lib.hipfftDestroy(_plans.pop(next(iter(_plans))))
+        handle = ctypes.c_void_p()
+        dims = (ctypes.c_int * 1)(int(n))
+        # NULL embeds: contiguous sequences, distance n (C2C), n -> n // 2 + 1 (R2C), n // 2 + 1 -> n (C2R)
+        rc = lib.hipfftPlanMany(ctypes.byref(handle), 1, dims, None, 1, 0, None, 1, 0, kind, int(batch))
+        if rc != 0:
+            raise AxisFftError(f"hipfftPlanMany(n={n}, batch={batch}, type={kind:#x}) failed with status {rc}")
+        plan = _plans[key] = handle
+    else:
+        _plans[key] = _plans.pop(key)        # most recently used last
+    return plan
+
+
+def _exec(device, kind: int, n: int, batch: int, src_ptr: int, dst_ptr: int, direction: int = _FORWARD) -> None:
+    lib = _lib_hipfft()
+    plan = _plan(device, kind, n, batch)
+    rc = lib.hipfftSetStream(plan, ctypes.c_void_p(_lib.stream_ptr(device)))
+    if rc == 0:
+        if kind == _HIPFFT_C2C:
+            rc = lib.hipfftExecC2C(plan, ctypes.c_void_p(src_ptr), ctypes.c_void_p(dst_ptr), direction)
+        elif kind == _HIPFFT_R2C:
+            rc = lib.hipfftExecR2C(plan, ctypes.c_void_p(src_ptr), ctypes.c_void_p(dst_ptr))
+        else:
+            rc = lib.hipfftExecC2R(plan, ctypes.c_void_p(src_ptr), ctypes.c_void_p(dst_ptr))
+    if rc != 0:
+        raise AxisFftError(f"hipFFT execution (n={n}, batch={batch}, type={kind:#x}) failed with status {rc}")
+
+
+def _transpose(src, dst, a: int, b: int, c: int, device) -> None:
+    _lib.call("lsr_transpose_last2_c64", src.data_ptr(), dst.data_ptr(), a, b, c, _lib.stream_ptr(device))
+
+
+def rfft3(volume):
+    """Unnormalised forward transform of a contiguous float32 ``(Z, Y, X)`` device volume.
+
+    Returns a complex64 tensor of shape ``(X // 2 + 1, Y, Z)``: ``torch.fft.rfftn(volume)`` with its
+    axes reversed (``result[kx, ky, kz] == rfftn(volume)[kz, ky, kx]`` up to rounding).
+    """
+    import torch
+
+    if not available():
+        raise AxisFftError("hipFFT's C API is not loadable")
+    if volume.dim() != 3 or volume.dtype != torch.float32 or not volume.is_contiguous() or volume.device.type != "cuda":
+        raise ValueError("rfft3 takes a contiguous float32 (Z, Y, X) tensor on a HIP device")
+    z, y, x = (int(v) for v in volume.shape)
+    xc = x // 2 + 1
+    dev = volume.device
+    with torch.cuda.device(dev):
+        a = torch.empty((z, y, xc), dtype=torch.complex64, device=dev)
+        _exec(dev, _HIPFFT_R2C, x, z * y, volume.data_ptr(), a.data_ptr())
+        b = torch.empty((z, xc, y), dtype=torch.complex64, device=dev)
+        _transpose(a, b, z, y, xc, dev)                                   # [Z][Y][XC] -> [Z][XC][Y]
+        _exec(dev, _HIPFFT_C2C, y, z * xc, b.data_ptr(), b.data_ptr(), _FORWARD)
+        a = a.view(-1).view(xc, y, z)
+        _transpose(b, a, 1, z, xc * y, dev)                               # [Z][XC Y] -> [XC Y][Z]
+        del b
+        _exec(dev, _HIPFFT_C2C, z, xc * y, a.data_ptr(), a.data_ptr(), _FORWARD)
+    return a
+
+
+def irfft3(spectrum, shape_zyx):
+    """Unnormalised inverse of :func:`rfft3` (``N`` times ``irfftn``): a float32 ``(Z, Y, X)`` volume.
+    ``spectrum`` (``(X // 2 + 1, Y, Z)`` complex64) is used as scratch and holds garbage afterwards."""
+    import torch
+
+    if not available():
+        raise AxisFftError("hipFFT's C API is not loadable")
+    z, y, x = (int(v) for v in shape_zyx)
+    xc = x // 2 + 1
+    if (tuple(spectrum.shape) != (xc, y, z) or spectrum.dtype != torch.complex64 or not spectrum.is_contiguous()
+            or spectrum.device.type != "cuda"):
+        raise ValueError(f"irfft3 takes a contiguous complex64 {(xc, y, z)} tensor on a HIP device")
+    dev = spectrum.device
+    with torch.cuda.device(dev):
+        _exec(dev, _HIPFFT_C2C, z, xc * y, spectrum.data_ptr(), spectrum.data_ptr(), _BACKWARD)
+        b = torch.empty((z, xc, y), dtype=torch.complex64, device=dev)
+        _transpose(spectrum, b, 1, xc * y, z, dev)                        # [XC Y][Z] -> [Z][XC Y]
+        _exec(dev, _HIPFFT_C2C, y, z * xc, b.data_ptr(), b.data_ptr(), _BACKWARD)
+        a = spectrum.view(-1).view(z, y, xc)
+        _transpose(b, a, z, xc, y, dev)                                   # [Z][XC][Y] -> [Z][Y][XC]
+        del b
+        out = torch.empty((z, y, x), dtype=torch.float32, device=dev)
+        _exec(dev, _HIPFFT_C2R, x, z * y, a.data_ptr(), out.data_ptr())
+    return out

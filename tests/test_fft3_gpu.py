@@ -1,0 +1,78 @@
+"""The axis-by-axis 3-D real FFT behind ``dynatrack._phase_cross_corr`` (``shrimpy_amd/fft3.py``):
+``lsr_transpose_last2_c64`` against ``torch.permute``, the transforms against ``torch.fft.rfftn`` /
+``irfftn`` (float32 FFT tolerance, stated below), and the tracker's shifts through both routes."""
+import numpy as np
+import pytest
+import torch
+
+from shrimpy_amd import _lib, fft3
+from shrimpy_amd import dynatrack as d
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 64), (2, 70, 33), (1, 180, 1000), (5, 1, 129), (1, 7, 1), (4, 200, 65)])
+def test_transpose_last2_equals_permute(shape):
+    a, b, c = shape
+    src = torch.randn((a, b, c), dtype=torch.complex64, device=DEV)
+    dst = torch.full((a, c, b), complex(7, 7), dtype=torch.complex64, device=DEV)
+    _lib.call("lsr_transpose_last2_c64", src.data_ptr(), dst.data_ptr(), a, b, c, _lib.stream_ptr(torch.device(DEV)))
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src.permute(0, 2, 1).contiguous())
+    with pytest.raises(_lib.LsrError, match="out of place"):
+        _lib.call("lsr_transpose_last2_c64", src.data_ptr(), src.data_ptr(), a, b, c, _lib.stream_ptr(torch.device(DEV)))
+
+
+@pytest.mark.parametrize("shape", [(12, 32, 48), (9, 20, 15), (180, 64, 50), (6, 125, 36), (1, 8, 8)])
+def test_rfft3_and_irfft3_against_torch_fft(shape):
+    """Same library underneath (rocFFT): agreement to float32 FFT rounding, 2e-6 of the largest
+    coefficient; the input is left untouched; the inverse is N times ``irfftn``."""
+    if not fft3.available():
+        pytest.skip("hipFFT's C API is not loadable from this PyTorch")
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.rand(shape, device=DEV, generator=g) * 900 + 80
+    keep = x.clone()
+    spec = fft3.rfft3(x)
+    assert torch.equal(x, keep)
+    ref = torch.fft.rfftn(x)
+    assert tuple(spec.shape) == tuple(reversed(ref.shape)) and spec.is_contiguous()
+    err = (spec.permute(2, 1, 0) - ref).abs().max() / ref.abs().max()
+    assert float(err) < 2e-6
+    n = float(np.prod(shape))
+    back = fft3.irfft3(spec.clone(), shape)
+    assert tuple(back.shape) == tuple(shape)
+    assert float((back / n - x).abs().max()) < 2e-6 * float(x.abs().max()) * np.log2(n)
+    want = torch.fft.irfftn(ref, s=shape)
+    assert float((back / n - want).abs().max()) < 2e-6 * float(x.abs().max()) * np.log2(n)
+    with pytest.raises(ValueError):
+        fft3.rfft3(x[:, ::2])                      # not contiguous
+    with pytest.raises(ValueError):
+        fft3.irfft3(spec, (shape[0] + 1,) + tuple(shape[1:]))
+
+
+def test_tracker_shifts_are_the_same_through_both_fft_routes():
+    """``_phase_cross_corr`` on rolled volumes (the reference's own test: rolled by (1, 2, -3),
+    ``test_dynatrack.py:102-111``) and on a non-5-smooth grid: the axis-by-axis route and
+    ``torch.fft.rfftn`` / ``irfftn`` find the same peak; spectra of the two routes never mix in the cache."""
+    if not fft3.available():
+        pytest.skip("hipFFT's C API is not loadable from this PyTorch")
+    rng = np.random.default_rng(42)
+    cases = [((8, 32, 32), (1, 2, -3)), ((17, 45, 70), (-2, 5, 4)), ((30, 64, 96), (3, -7, 11))]
+    try:
+        for shape, roll in cases:
+            ref = torch.as_tensor(rng.random(shape).astype(np.float32), device=DEV)
+            mov = torch.roll(ref, shifts=roll, dims=(0, 1, 2))
+            d.set_spectrum_cache_bytes(1 << 30)
+            d._axis_fft_ok[0] = True
+            a = d._phase_cross_corr(ref, mov)
+            a2 = d._phase_cross_corr(ref, mov)             # second call: the cached [XC][Y][Z] spectrum
+            d._axis_fft_ok[0] = False
+            b = d._phase_cross_corr(ref, mov)              # torch.fft route; must not pick up the other layout
+            assert a == a2 == b
+            if shape == (8, 32, 32):
+                assert a == (1, 2, -3)
+    finally:
+        d._axis_fft_ok[0] = True
+        d.set_spectrum_cache_bytes(0)

@@ -184,17 +184,28 @@ def _estimators(args, torch, dev, g, oshape):
     mov = torch.roll(vol, shifts=(2, -5, 7), dims=(0, 1, 2))
     shift = d._phase_cross_corr(vol, mov)
     assert shift in ((2, -5, 7), (-2, 5, -7)), shift
-    d.set_spectrum_cache_bytes(0)
-    ms = timed(lambda: d._phase_cross_corr(vol, mov), max(1, args.reps // 2))
-    print(json.dumps({"kernel": "_phase_cross_corr (2 rfftn + irfftn via rocFFT, 3 kernels)", "grid": oshape, "ms": ms,
-                      "rolled_by": [2, -5, 7], "found": list(shift)}))
-    d.set_spectrum_cache_bytes(8 << 30)
-    ms = timed(lambda: d._phase_cross_corr(vol, mov), max(1, args.reps // 2))
-    print(json.dumps({"kernel": "_phase_cross_corr, reference spectrum cached (rfftn + irfftn, 3 kernels)",
-                      "grid": oshape, "ms": ms}))
+    from shrimpy_amd import fft3
+
+    for route, ok in (("axis by axis: hipFFT 1-D transforms + lsr_transpose_last2_c64", True), ("torch.fft.rfftn / irfftn", False)):
+        if ok and not fft3.available():
+            continue
+        d._axis_fft_ok[0] = ok
+        d.set_spectrum_cache_bytes(0)
+        assert d._phase_cross_corr(vol, mov) == shift
+        ms = timed(lambda: d._phase_cross_corr(vol, mov), max(1, args.reps // 2))
+        print(json.dumps({"kernel": f"_phase_cross_corr (2 forward + 1 inverse 3-D FFT; {route})", "grid": oshape, "ms": ms,
+                          "rolled_by": [2, -5, 7], "found": list(shift)}))
+        d.set_spectrum_cache_bytes(8 << 30)
+        ms = timed(lambda: d._phase_cross_corr(vol, mov), max(1, args.reps // 2))
+        print(json.dumps({"kernel": f"_phase_cross_corr, reference spectrum cached (1 forward + 1 inverse; {route})",
+                          "grid": oshape, "ms": ms}))
+    d._axis_fft_ok[0] = True
     d.set_spectrum_cache_bytes(0)
     ms = timed(lambda: torch.fft.rfftn(vol), max(1, args.reps // 2))
     print(json.dumps({"kernel": "torch.fft.rfftn alone (rocFFT)", "grid": oshape, "ms": ms}))
+    if fft3.available():
+        ms = timed(lambda: fft3.rfft3(vol), max(1, args.reps // 2))
+        print(json.dumps({"kernel": "fft3.rfft3 alone (at the volume's own shape)", "grid": oshape, "ms": ms}))
 
 
 def _rl(args, torch, dev, g, bench, RichardsonLucyPlan, oshape):
