@@ -330,7 +330,10 @@ def test_staged_run_drains_the_stager_when_a_loader_fails():
         depth = 2
 
         def __init__(self):
+            # raw slots and result slots are separate buffers, as in VolumeStager: the loader fills the
+            # raw slot of unit i + 1 while the writer still reads the result slot of unit i - 1
             self.events, self.slots = [], [np.zeros(4, np.float32) for _ in range(2)]
+            self.results = [None, None]
 
         def host_in(self, slot):
             return self.slots[slot]
@@ -346,10 +349,10 @@ def test_staged_run_drains_the_stager_when_a_loader_fails():
             pass
 
         def stage_out(self, slot, result):
-            self.slots[slot] = np.asarray(result)
+            self.results[slot] = np.asarray(result)
 
         def collect(self, slot):
-            return self.slots[slot]
+            return self.results[slot]
 
         def drain(self):
             self.events.append("drain")
