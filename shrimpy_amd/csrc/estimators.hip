@@ -610,14 +610,27 @@ __global__ __launch_bounds__(kThreads) void peak_partial_kernel(PeakArgs p) {
   float best = -1.0f;
   unsigned long long best_i = ~0ull;
   const int64_t rows = static_cast<int64_t>(p.Z) * p.Y;
+  const bool vec = (p.X & 3) == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0;   // rows are 16-byte aligned
   for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
     const int z = static_cast<int>(r / p.Y), y = static_cast<int>(r - static_cast<int64_t>(z) * p.Y);
     const int zs = (z + p.Z / 2) % p.Z, ys = (y + p.Y / 2) % p.Y;   // fftshift: index i -> (i + n/2) % n
     const float* row = p.in + r * p.X;
     const unsigned long long base = (static_cast<unsigned long long>(zs) * p.Y + ys) * p.X;
-    for (int x = threadIdx.x; x < p.X; x += kThreads) {
-      const float v = fabsf(row[x]);
-      peak_merge(best, best_i, v, base + static_cast<unsigned>((x + p.X / 2) % p.X));
+    // the shifted index is only worked out for a value that can replace the running maximum
+    if (vec) {
+      const float4* row4 = reinterpret_cast<const float4*>(row);
+      for (int x4 = threadIdx.x; x4 < p.X / 4; x4 += kThreads) {
+        const float4 f = row4[x4];
+        const float v[4] = {fabsf(f.x), fabsf(f.y), fabsf(f.z), fabsf(f.w)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (v[k] >= best) peak_merge(best, best_i, v[k], base + static_cast<unsigned>((4 * x4 + k + p.X / 2) % p.X));
+      }
+    } else {
+      for (int x = threadIdx.x; x < p.X; x += kThreads) {
+        const float v = fabsf(row[x]);
+        if (v >= best) peak_merge(best, best_i, v, base + static_cast<unsigned>((x + p.X / 2) % p.X));
+      }
     }
   }
   s_v[threadIdx.x] = best;
