@@ -9,10 +9,14 @@ this module implements the first two and borrows the third from whatever the hos
 * ``crc32c``            -- table-driven, pure Python/numpy (the index is a few hundred bytes);
 * blosc 1.x frames      -- ``blosc_decode`` / ``blosc_encode`` follow the published c-blosc 1.x
   layout (16-byte header, ``bstarts`` table, per-block streams with the typesize split rule, byte-
-  and bit-shuffle).  When a ``libblosc`` is loadable (``LSR_LIBBLOSC`` or the system one) it does
-  the work instead -- same bytes, C speed, straight into the caller's buffer; failing that,
-  ``numcodecs.blosc`` where that package is installed; the pure-Python path (224 MB/s per thread on
-  uint16 camera data against libblosc's 590 MB/s) is the last resort;
+  and bit-shuffle).  Who decodes, in order (``blosc_backend()``): a ``libblosc`` when one is
+  loadable (``LSR_LIBBLOSC`` or the system one) -- same bytes, C speed, straight into the caller's
+  buffer; ``numcodecs.blosc`` where that package is installed; this package's own frame walker in
+  liblsrecon (``lsr_blosc_decode_host``, ``csrc/blosc_frame.hip``: host C++, the system zstd /
+  lz4 / zlib by ``dlopen``, one call per chunk with the GIL released -- as fast as libblosc, and what
+  a host without either library uses); the pure-Python walker last (it holds the GIL for ~10 us
+  per stream, 20x slower on the acquisition's 32 KB blocks however many threads decode) and as the
+  cross-check of the native one;
 * zstd / lz4 block codecs -- first hit of: ``numcodecs``, ``zstandard`` / ``lz4``, ``pyarrow``, the
   system ``libzstd`` / ``liblz4`` through ctypes.
 
