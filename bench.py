@@ -467,10 +467,16 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
         # enough units that the run is its steady state, not the pipeline's fill and drain
         n_t, n_p = (1, max(12, 3 * world)) if args.workload == "config4" else (4, max(3, world))
         scratch = Path(tempfile.mkdtemp(prefix="lsr_bench_", dir=args.scratch))
-        root = [str(scratch)]
+        # the temporary plates (uint16 in, float32 out) must fit the scratch file system: fewer positions
+        # (never fewer than one per rank) rather than a run that dies with the disk full
+        per_unit = 2 * n_in + 4 * n_o
+        free = shutil.disk_usage(scratch).free
+        while n_p > world and 1.25 * n_t * n_p * per_unit > free:
+            n_p -= 1
+        root = [str(scratch), n_p]
         if world > 1:
-            dist.broadcast_object_list(root, src=0)
-        root = Path(root[0])
+            dist.broadcast_object_list(root, src=0)     # rank 0's directory and position count
+        root, n_p = Path(root[0]), int(root[1])
         try:
             keys = [f"A/{p + 1}/0" for p in range(n_p)]
             if rank == 0:
