@@ -466,13 +466,15 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
     if not args.no_store_leg:
         # enough units that the run is its steady state, not the pipeline's fill and drain
         n_t, n_p = (1, max(12, 3 * world)) if args.workload == "config4" else (4, max(3, world))
-        scratch = Path(tempfile.mkdtemp(prefix="lsr_bench_", dir=args.scratch))
-        # the temporary plates (uint16 in, float32 out) must fit the scratch file system: fewer positions
-        # (never fewer than one per rank) rather than a run that dies with the disk full
-        per_unit = 2 * n_in + 4 * n_o
-        free = shutil.disk_usage(scratch).free
-        while n_p > world and 1.25 * n_t * n_p * per_unit > free:
-            n_p -= 1
+        scratch = None
+        if rank == 0:
+            scratch = Path(tempfile.mkdtemp(prefix="lsr_bench_", dir=args.scratch))
+            # the temporary plates (uint16 in, float32 out) must fit the scratch file system: fewer
+            # positions (never fewer than one per rank) rather than a run that dies with the disk full
+            per_unit = 2 * n_in + 4 * n_o
+            free = shutil.disk_usage(scratch).free
+            while n_p > world and 1.25 * n_t * n_p * per_unit > free:
+                n_p -= 1
         root = [str(scratch), n_p]
         if world > 1:
             dist.broadcast_object_list(root, src=0)     # rank 0's directory and position count
