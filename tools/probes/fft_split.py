@@ -1,7 +1,7 @@
 """Where do rocFFT's 24 ms for one rfftn of the PCC grid go?  Times the three axes separately, a few
 layouts and shapes (torch.fft = rocFFT)."""
 import json
-import sys
+
 import torch
 
 dev = torch.device("cuda:0")
