@@ -113,6 +113,20 @@ int lsr_deskew_border(const void* in, int in_u16, int64_t Z, int64_t Y, int64_t 
 int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
                    int64_t Yo, int64_t Xo, const double M[12], float cval, int mode,
                    lsr_stream_t stream);
+/*
+ * The same with a source whose rows are padded: in_pitch floats from row to row, in_plane from plane to
+ * plane.  The LDS-staged kernels move 16-byte chunks, so they need rows that start on 16-byte
+ * boundaries: in_pitch and in_plane multiples of 4, in_pitch >= Xi rounded up to 4, `in` 16-byte aligned,
+ * and FINITE values in the padding columns [Xi, in_pitch) (they only ever meet weight 0; zeros are the
+ * natural choice).  A deskewed volume is Xp = ceil(Z / r - Y cos(theta)) wide -- a multiple of 4 one time
+ * in four; lsr_deskew_* writes any out_pitch, so the deskew -> register chain keeps the fast kernels for
+ * every width.  Other strides run the gather kernel, as lsr_affine_f32 does for Xi % 4 != 0.
+ */
+int lsr_affine_pitched_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t in_pitch,
+                           int64_t in_plane, float* out, int64_t Zo, int64_t Yo, int64_t Xo,
+                           const double M[12], float cval, int mode, lsr_stream_t stream);
+int lsr_affine_path_pitched(int64_t Zi, int64_t Yi, int64_t Xi, int64_t in_pitch, int64_t in_plane,
+                            const double M[12], int mode); /* lsr_affine_path for such a source */
 /* Which kernel lsr_affine_f32 runs for this matrix on a (.., Yi, Xi) moving volume: 1 = the
  * LDS-staged z-marching kernel (csrc/affine_planar.hip: constant mode, z decoupled from the plane,
  * |M[0]| <= 1.5, Xi a multiple of 4, source box of a 32 x 128 tile within LDS), 0 = the general

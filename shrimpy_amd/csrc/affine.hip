@@ -31,6 +31,7 @@ struct AffineArgs {
   const float* in;
   float* out;
   int Zi, Yi, Xi;
+  unsigned pitch, plane;   // source strides in floats (dense: Xi, Yi * Xi)
   int Zo, Yo, Xo;
   double m[12];
   float cval;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
   const double ry = lsr::dadd(lsr::dmul(zd, p.m[4]), lsr::dmul(yd, p.m[5]));
   const double rx = lsr::dadd(lsr::dmul(zd, p.m[8]), lsr::dmul(yd, p.m[9]));
   // element indices fit 32 bits unsigned (host check); one 64-bit add per load
-  const unsigned sz = static_cast<unsigned>(p.Yi) * static_cast<unsigned>(p.Xi);
+  const unsigned sz = p.plane;
   const double cv = static_cast<double>(p.cval);
   float* orow = p.out + (static_cast<int64_t>(zo) * p.Yo + yo) * p.Xo;
 
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
 #pragma unroll
               for (int b = 0; b < 2; ++b) {
                 const unsigned o = static_cast<unsigned>(a ? tz.i1 : tz.i0) * sz +
-                                   static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * static_cast<unsigned>(p.Xi);
+                                   static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * p.pitch;
                 load_x_pair(p.in + o, tx_.i0, p.Xi, v[a][b][0], v[a][b][1]);
               }
           } else {
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
 #pragma unroll
               for (int b = 0; b < 2; ++b)
                 v[a][b][0] = v[a][b][1] = p.in[static_cast<unsigned>(a ? tz.i1 : tz.i0) * sz +
-                                               static_cast<unsigned>(b ? ty_.i1 : ty_.i0)];
+                                               static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * p.pitch];
           }
         } else
 #pragma unroll
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
               const unsigned o = static_cast<unsigned>(a ? tz.i1 : tz.i0) * sz +
-                                 static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * static_cast<unsigned>(p.Xi) +
+                                 static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * p.pitch +
                                  static_cast<unsigned>(c ? tx_.i1 : tx_.i0);
               float val = p.in[o];
               if (GRID && ((a ? tz.out1 : tz.out0) || (b ? ty_.out1 : ty_.out0) || (c ? tx_.out1 : tx_.out0)))
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
         const bool bz = a ? tz.out1 : tz.out0;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const unsigned oy = oz + static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * static_cast<unsigned>(p.Xi);
+          const unsigned oy = oz + static_cast<unsigned>(b ? ty_.i1 : ty_.i0) * p.pitch;
           const double wy = b ? ty_.w1 : ty_.w0;
           const bool by = b ? ty_.out1 : ty_.out0;
 #pragma unroll
@@ -201,17 +202,18 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
 
 namespace lsr {
 // affine_planar.hip: z-decoupled maps in constant mode; false = not applicable
-bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
-                          int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32,
+// (pitch / plane: source strides in floats; dense = Xi, Yi * Xi)
+bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane,
+                          float* out, int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32,
                           hipStream_t s);
-bool affine_planar_geometry(int64_t Yi, int64_t Xi, const double M[12], int* box_y, int* box_x,
+bool affine_planar_geometry(int64_t Yi, int64_t Xi, int64_t pitch, const double M[12], int* box_y, int* box_x,
                             int* slots, int64_t* lds_bytes);
 // affine_box.hip: any map whose per-block source box fits in LDS (z-coupled maps included),
 // constant mode; false = not applicable
-bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
-                       int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32, hipStream_t s);
-bool affine_box_geometry(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int* box_z, int* box_y,
-                         int* box_x, int64_t* lds_bytes);
+bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, float* out,
+                       int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32, hipStream_t s);
+bool affine_box_geometry(int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, const double M[12],
+                         int* box_z, int* box_y, int* box_x, int64_t* lds_bytes);
 bool affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int out6[6]);
 }  // namespace lsr
 
@@ -220,7 +222,7 @@ extern "C" int lsr_affine_kernel_choice(int64_t Yi, int64_t Xi, const double M[1
   int by, bx, sl;
   int64_t lds;
   return (mode & ~LSR_MODE_F32_INTERP) == LSR_MODE_CONSTANT &&
-                 lsr::affine_planar_geometry(Yi, Xi, M, &by, &bx, &sl, &lds)
+                 lsr::affine_planar_geometry(Yi, Xi, Xi, M, &by, &bx, &sl, &lds)
              ? 1
              : 0;
 }
@@ -230,8 +232,20 @@ extern "C" int lsr_affine_path(int64_t Zi, int64_t Yi, int64_t Xi, const double 
   if ((mode & ~LSR_MODE_F32_INTERP) != LSR_MODE_CONSTANT) return 0;
   int a, b, c;
   int64_t lds;
-  if (lsr::affine_planar_geometry(Yi, Xi, M, &a, &b, &c, &lds)) return 1;
-  if (lsr::affine_box_geometry(Zi, Yi, Xi, M, &a, &b, &c, &lds)) return 2;
+  if (lsr::affine_planar_geometry(Yi, Xi, Xi, M, &a, &b, &c, &lds)) return 1;
+  if (lsr::affine_box_geometry(Zi, Yi, Xi, Xi, Yi * Xi, M, &a, &b, &c, &lds)) return 2;
+  return 0;
+}
+
+// the same question for a source with padded rows (lsr_affine_pitched_f32)
+extern "C" int lsr_affine_path_pitched(int64_t Zi, int64_t Yi, int64_t Xi, int64_t in_pitch, int64_t in_plane,
+                                       const double M[12], int mode) {
+  if (M == nullptr) return 0;
+  if ((mode & ~LSR_MODE_F32_INTERP) != LSR_MODE_CONSTANT) return 0;
+  int a, b, c;
+  int64_t lds;
+  if (in_plane % 4 == 0 && lsr::affine_planar_geometry(Yi, Xi, in_pitch, M, &a, &b, &c, &lds)) return 1;
+  if (lsr::affine_box_geometry(Zi, Yi, Xi, in_pitch, in_plane, M, &a, &b, &c, &lds)) return 2;
   return 0;
 }
 
@@ -240,9 +254,32 @@ extern "C" int lsr_affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const do
   return lsr::affine_box_shape(Zi, Yi, Xi, M, out6) ? 1 : 0;
 }
 
+namespace {
+int affine_impl(const char* what, const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane,
+                float* out, int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval, int mode,
+                lsr_stream_t stream);
+}
+
 extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out,
                               int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval,
                               int mode, lsr_stream_t stream) {
+  return affine_impl("lsr_affine_f32", in, Zi, Yi, Xi, Xi, Yi * Xi, out, Zo, Yo, Xo, M, cval, mode, stream);
+}
+
+extern "C" int lsr_affine_pitched_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t in_pitch,
+                                      int64_t in_plane, float* out, int64_t Zo, int64_t Yo, int64_t Xo,
+                                      const double M[12], float cval, int mode, lsr_stream_t stream) {
+  LSR_REQUIRE(in_pitch >= Xi && in_plane >= Yi * in_pitch, LSR_E_SHAPE,
+              "source strides (%lld, %lld) are smaller than a (%lld x %lld) plane", (long long)in_pitch,
+              (long long)in_plane, (long long)Yi, (long long)Xi);
+  return affine_impl("lsr_affine_pitched_f32", in, Zi, Yi, Xi, in_pitch, in_plane, out, Zo, Yo, Xo, M, cval, mode,
+                     stream);
+}
+
+namespace {
+int affine_impl(const char* what, const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane,
+                float* out, int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval, int mode,
+                lsr_stream_t stream) {
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE_PTR(M);
@@ -255,8 +292,8 @@ extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t X
   const int64_t lim = int64_t(1) << 30;
   LSR_REQUIRE(Zi < lim && Yi < lim && Xi < lim && Zo < lim && Yo < lim && Xo < lim,
               LSR_E_UNSUPPORTED, "a dimension exceeds 2^30");
-  LSR_REQUIRE(Zi * Yi * Xi <= (int64_t(1) << 32), LSR_E_UNSUPPORTED,
-              "the moving volume has more than 2^32 voxels (32-bit element indices)");
+  LSR_REQUIRE(Zi * plane <= (int64_t(1) << 32) && pitch < lim, LSR_E_UNSUPPORTED,
+              "the moving volume spans more than 2^32 elements (32-bit element indices)");
   const bool f32 = (mode & LSR_MODE_F32_INTERP) != 0;
   mode &= ~LSR_MODE_F32_INTERP;
   LSR_REQUIRE(mode == LSR_MODE_CONSTANT || mode == LSR_MODE_GRID_CONSTANT, LSR_E_ARG,
@@ -265,14 +302,15 @@ extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t X
     LSR_REQUIRE(M[i] == M[i] && M[i] - M[i] == 0.0, LSR_E_ARG, "M[%d] is not finite", i);
 
   if (mode == LSR_MODE_CONSTANT && in != out &&
-      (lsr::launch_affine_planar(in, Zi, Yi, Xi, out, Zo, Yo, Xo, M, cval, f32, lsr::as_stream(stream)) ||
-       lsr::launch_affine_box(in, Zi, Yi, Xi, out, Zo, Yo, Xo, M, cval, f32, lsr::as_stream(stream))))
-    return lsr::launch_status("lsr_affine_f32");
+      (lsr::launch_affine_planar(in, Zi, Yi, Xi, pitch, plane, out, Zo, Yo, Xo, M, cval, f32, lsr::as_stream(stream)) ||
+       lsr::launch_affine_box(in, Zi, Yi, Xi, pitch, plane, out, Zo, Yo, Xo, M, cval, f32, lsr::as_stream(stream))))
+    return lsr::launch_status(what);
 
   AffineArgs p;
   p.in = in;
   p.out = out;
   p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
+  p.pitch = static_cast<unsigned>(pitch); p.plane = static_cast<unsigned>(plane);
   p.Zo = static_cast<int>(Zo); p.Yo = static_cast<int>(Yo); p.Xo = static_cast<int>(Xo);
   for (int i = 0; i < 12; ++i) p.m[i] = M[i];
   p.cval = cval;
@@ -291,5 +329,6 @@ extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t X
     if (f32) hipLaunchKernelGGL((affine_kernel<false, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((affine_kernel<false, false>), grid, block, 0, s, p);
   }
-  return lsr::launch_status("lsr_affine_f32");
+  return lsr::launch_status(what);
 }
+}  // namespace

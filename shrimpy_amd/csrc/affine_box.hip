@@ -45,6 +45,7 @@ struct BoxArgs {
   const float* in;
   float* out;
   int Zi, Yi, Xi;
+  unsigned pitch, plane;   // source strides in floats (multiples of 4; columns [Xi, pitch) finite: they only meet weight 0)
   int Zo, Yo, Xo;
   double m[12];
   float cval;
@@ -138,7 +139,7 @@ __device__ __forceinline__ void stage(const BoxArgs& p, const Blk& b, unsigned l
   const int box_x = p.box_x, box_y = p.box_y, box_z = p.box_z;
   const int chunks_x = box_x >> 2;
   const int n_chunks = box_z * box_y * chunks_x;
-  const unsigned plane_i = static_cast<unsigned>(p.Yi) * static_cast<unsigned>(p.Xi);
+  const unsigned plane_i = p.plane;
   // 32-bit byte offsets are taken from the box's first source plane (host: box_z planes < 4 GiB)
   const float* const src = p.in + static_cast<int64_t>(b.zlo) * plane_i;
   const int n_loads = (n_chunks + NT - 1) / NT;
@@ -155,8 +156,8 @@ __device__ __forceinline__ void stage(const BoxArgs& p, const Blk& b, unsigned l
     const int r = row - pl * box_y;
     const unsigned gz = static_cast<unsigned>(min(b.zlo + pl, p.Zi - 1) - b.zlo);   // past the volume: duplicates
     const unsigned gy = static_cast<unsigned>(min(b.ylo + r, p.Yi - 1));
-    const unsigned gx = static_cast<unsigned>(min(b.xlo + 4 * c4, p.Xi - 4));
-    const unsigned voff = (gz * plane_i + gy * static_cast<unsigned>(p.Xi) + gx) * 4u;
+    const unsigned gx = static_cast<unsigned>(min(b.xlo + 4 * c4, ((p.Xi + 3) & ~3) - 4));
+    const unsigned voff = (gz * plane_i + gy * p.pitch + gx) * 4u;
     if (wave * 64 + k * NT < n_chunks)   // wave-uniform: whole waves of chunks
       glds_x4(src, voff, __builtin_amdgcn_readfirstlane(lds_byte_base + static_cast<unsigned>((k * NT + wave * 64) * 16)));
   }
@@ -362,8 +363,10 @@ bool box_of(const double M[12], int tz, int ty, int tx, BoxShape* s) {
 }
 
 // Block shape and box of the box path for this matrix and moving volume; false = not applicable.
-bool pick_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], BoxShape* best) {
-  if (Xi % 4 != 0 || Xi < 8 || Yi < 2 || Zi < 2) return false;
+bool pick_shape(int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, const double M[12], BoxShape* best) {
+  // rows start on 16-byte boundaries (LDS-DMA moves 16-byte chunks) and hold whole chunks up to the last column
+  if (pitch % 4 != 0 || plane % 4 != 0 || pitch < ((Xi + 3) & ~int64_t(3)) || Xi < 8 || Yi < 2 || Zi < 2) return false;
+  if (plane >= (int64_t(1) << 32)) return false;
   // 8192 voxels, tx >= 32 (stores stay 128-byte runs), tz in {8, 16} (the compiled walks)
   static const int shapes[][3] = {{8, 16, 64}, {16, 16, 32}, {8, 32, 32}, {16, 8, 64}, {8, 8, 128}, {16, 4, 128}};
   bool found = false;
@@ -371,7 +374,7 @@ bool pick_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], BoxShape
     BoxShape s;
     if (!box_of(M, sh[0], sh[1], sh[2], &s)) continue;
     if (s.lds_bytes > 150 * 1024 || lsr::ceil_div(s.lds_bytes / 16, kThreads) > kMaxLoads) continue;
-    if (int64_t(s.bz) * Yi * Xi * 4 >= (int64_t(1) << 32)) continue;   // 32-bit byte offsets inside a box
+    if (int64_t(s.bz) * plane * 4 >= (int64_t(1) << 32)) continue;   // 32-bit byte offsets inside a box
     // two workgroups per CU (box <= 78 KB) beat any single-workgroup shape; then the smaller box
     // (first listed wins a tie: pricing the 160-byte rows of tx = 32 shapes higher than their byte
     // count picked 16x8x64 over 16x16x32 at equal bytes and ran 12 % slower)
@@ -410,28 +413,30 @@ void launch_shape(const BoxArgs& p, unsigned blocks, size_t lds_bytes, hipStream
 
 namespace lsr {
 
-bool affine_box_geometry(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int* box_z, int* box_y,
-                         int* box_x, int64_t* lds_bytes) {
+bool affine_box_geometry(int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, const double M[12],
+                         int* box_z, int* box_y, int* box_x, int64_t* lds_bytes) {
   BoxShape s;
-  if (!pick_shape(Zi, Yi, Xi, M, &s)) return false;
+  if (!pick_shape(Zi, Yi, Xi, pitch, plane, M, &s)) return false;
   *box_z = s.bz; *box_y = s.by; *box_x = s.bx; *lds_bytes = s.lds_bytes;
   return true;
 }
 
 bool affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int out6[6]) {
   BoxShape s;
-  if (!pick_shape(Zi, Yi, Xi, M, &s)) return false;
+  if (!pick_shape(Zi, Yi, Xi, Xi, Yi * Xi, M, &s)) return false;
   out6[0] = s.tz; out6[1] = s.ty; out6[2] = s.tx; out6[3] = s.bz; out6[4] = s.by; out6[5] = s.bx;
   return true;
 }
 
-bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
-                       int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32, hipStream_t s) {
+bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, float* out,
+                       int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32, hipStream_t s) {
   BoxShape sh;
-  if (!pick_shape(Zi, Yi, Xi, M, &sh)) return false;
+  if ((reinterpret_cast<uintptr_t>(in) & 15) != 0) return false;
+  if (!pick_shape(Zi, Yi, Xi, pitch, plane, M, &sh)) return false;
   BoxArgs p;
   p.in = in; p.out = out;
   p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
+  p.pitch = static_cast<unsigned>(pitch); p.plane = static_cast<unsigned>(plane);
   p.Zo = static_cast<int>(Zo); p.Yo = static_cast<int>(Yo); p.Xo = static_cast<int>(Xo);
   for (int i = 0; i < 12; ++i) p.m[i] = M[i];
   p.cval = cval;

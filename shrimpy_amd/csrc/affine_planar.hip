@@ -34,6 +34,9 @@ struct PlanarArgs {
   const float* in;
   float* out;
   int Zi, Yi, Xi;
+  int pitch;             // source row stride in floats (a multiple of 4, >= Xi rounded up to 4; columns
+                         // [Xi, pitch) hold finite values -- they only ever meet weight 0)
+  int64_t plane;         // source plane stride in floats (a multiple of 4)
   int Zo, Yo, Xo;
   double a, tz;          // z_in = zo * a + tz
   double b, c, ty;       // y_in = (yo * b + xo * c) + ty
@@ -134,12 +137,12 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
     const int e = min(tid + k * kThreads, n_chunks - 1);
     const int r = e / chunks_x, c4 = e - r * chunks_x;
     const int gy = min(ylo + r, p.Yi - 1);            // rows / columns past the volume: duplicates
-    const int gx = min(xlo + 4 * c4, p.Xi - 4);
-    s_voff[k] = (gy * p.Xi + gx) * 4;
+    const int gx = min(xlo + 4 * c4, ((p.Xi + 3) & ~3) - 4);
+    s_voff[k] = (gy * p.pitch + gx) * 4;
   }
   const int n_loads = (n_chunks + kThreads - 1) / kThreads;  // scalar
   auto issue_plane = [&](int zs, int slot) {
-    const float* src = p.in + static_cast<int64_t>(zs) * p.Yi * p.Xi;
+    const float* src = p.in + static_cast<int64_t>(zs) * p.plane;
     const unsigned dst = lds_base + (slot * slot_floats + wave * 64 * 4) * 4;
 #pragma unroll
     for (int k = 0; k < kMaxLoads; ++k)
@@ -274,11 +277,12 @@ namespace lsr {
 
 // Returns true if the planar kernel took the launch; false = not applicable, use the general one.
 // Geometry of the planar path for this matrix and moving volume; false = not applicable.
-bool affine_planar_geometry(int64_t Yi, int64_t Xi, const double M[12], int* box_y_out, int* box_x_out,
+bool affine_planar_geometry(int64_t Yi, int64_t Xi, int64_t pitch, const double M[12], int* box_y_out, int* box_x_out,
                             int* slots_out, int64_t* lds_bytes_out) {
   if (M[1] != 0.0 || M[2] != 0.0 || M[4] != 0.0 || M[8] != 0.0) return false;
   const double a = M[0] < 0 ? -M[0] : M[0];
-  if (a > 1.5 || Xi % 4 != 0 || Xi < 8 || Yi < 2) return false;
+  // rows start on 16-byte boundaries (LDS-DMA moves 16-byte chunks) and hold whole chunks up to the last column
+  if (a > 1.5 || pitch % 4 != 0 || pitch < ((Xi + 3) & ~int64_t(3)) || Xi < 8 || Yi < 2) return false;
   auto ab = [](double v) { return v < 0 ? -v : v; };
   // source box of a 32 x 128 tile: span of floor() over the tile (<= floor(extent) + 2; the 1e-6
   // absorbs the different summation order on the device) + 1 for the upper neighbour [+ 3 + 3: 16-byte
@@ -290,21 +294,23 @@ bool affine_planar_geometry(int64_t Yi, int64_t Xi, const double M[12], int* box
   const int slots = a <= 1.0 ? 3 : 4;
   const int64_t lds_bytes = int64_t(slots) * ((int64_t(box_y) * box_x + 255) & ~int64_t(255)) * 4;
   if (lds_bytes > 150 * 1024 || int64_t(box_y) * (box_x / 4) > 8 * kThreads) return false;
-  if (Yi * Xi * 4 >= (int64_t(1) << 31)) return false;  // 32-bit in-plane byte offsets
+  if (Yi * pitch * 4 >= (int64_t(1) << 31)) return false;  // 32-bit in-plane byte offsets
   *box_y_out = box_y; *box_x_out = box_x; *slots_out = slots; *lds_bytes_out = lds_bytes;
   return true;
 }
 
-bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
-                          int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32,
+bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane,
+                          float* out, int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32,
                           hipStream_t s) {
   int box_y, box_x, slots;
   int64_t lds_bytes;
-  if (!affine_planar_geometry(Yi, Xi, M, &box_y, &box_x, &slots, &lds_bytes)) return false;
+  if (plane % 4 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return false;
+  if (!affine_planar_geometry(Yi, Xi, pitch, M, &box_y, &box_x, &slots, &lds_bytes)) return false;
 
   PlanarArgs p;
   p.in = in; p.out = out;
   p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
+  p.pitch = static_cast<int>(pitch); p.plane = plane;
   p.Zo = static_cast<int>(Zo); p.Yo = static_cast<int>(Yo); p.Xo = static_cast<int>(Xo);
   p.a = M[0]; p.tz = M[3];
   p.b = M[5]; p.c = M[6]; p.ty = M[7];

@@ -96,6 +96,7 @@ class VolumeReconstructor:
         self.output_shape = tuple(shape)
         self._plan = None
         self._y_pad = None
+        self._pitched = None      # deskew target with zero-padded rows, when a registration reads it (see __call__)
         dec: DeconvolveSettings | None = settings.deconvolution
         if dec is not None and dec.iterations > 0:
             from .deconvolve import RichardsonLucyPlan
@@ -148,6 +149,15 @@ class VolumeReconstructor:
                 if self._y_pad is None:
                     self._y_pad = self._plan.new_padded_input()
                 target = self._y_pad
+            elif (self._register is not None and self._canonical_deskew and self._register.mode == "constant"
+                    and self._geo.output_shape[2] % 4 != 0 and self._geo.output_shape[2] >= 8):
+                # a registration follows and the deskewed rows would not start on 16-byte boundaries:
+                # deskew into zero-padded rows so that the LDS-staged affine kernels take the map
+                if self._pitched is None:
+                    from .register import PitchedVolume
+
+                    self._pitched = PitchedVolume(self._geo.output_shape, self.device)
+                target = self._pitched
             # (with flat-field on, its division rides along inside the deskew kernel)
             vol = deskew_with_matrix(vol, self._geo.matrix_3x4, self._geo.pre_average_shape,
                                      d.average_n_slices, out=target, flat_field=flat, border=d.border)

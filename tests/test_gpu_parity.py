@@ -377,6 +377,96 @@ def test_affine_box_kernel_vs_oracle(device, case, exact):
         assert np.abs(out - ref).max() <= 2e-5 * 1100
 
 
+PITCHED_CASES = [
+    dict(shape=(24, 96, 130), m="config3", path=1),                       # planar, width 130 = 4 * 32 + 2
+    dict(shape=(20, 70, 133), out=(22, 75, 140), m="config3", path=1),
+    dict(shape=(24, 96, 134), m=_tilted_matrix([(1, 3.0), (0, 2.0)], (1.0, 0.98, 1.02), (1.5, -4.25, 6.75)), path=2),
+    dict(shape=(19, 45, 77), out=(23, 50, 91), m=_tilted_matrix([(0, 4.0), (1, -6.0), (2, 5.0)], centre=(9, 22, 38)), path=2),
+    dict(shape=(12, 33, 67), m=_tilted_matrix([(1, 2.0)], (-1.0, -1.0, -1.0), (11.0, 32.0, 66.0)), path=2),   # flips: taps at both ends of a row
+    dict(shape=(16, 40, 9), m=_tilted_matrix([(1, 2.0)]), path=2),        # narrower than three chunks
+]
+
+
+@pytest.mark.parametrize("case", PITCHED_CASES)
+@pytest.mark.parametrize("exact", [True, False])
+def test_affine_over_padded_rows_keeps_the_lds_kernels(device, case, exact):
+    """A moving volume whose width is not a multiple of 4 (three deskewed volumes in four) goes to the
+    gather kernel through ``lsr_affine_f32``; with its rows padded to a multiple of 4
+    (``register.PitchedVolume``, ``lsr_affine_pitched_f32``) the planar / box kernels take it: same
+    bits as the oracle, whatever finite values sit in the padding."""
+    import torch
+
+    from shrimpy_amd import _lib
+    from shrimpy_amd.geometry import as_matrix_3x4
+    from shrimpy_amd.register import PitchedVolume, apply_affine_transform_zyx
+
+    shape = case["shape"]
+    m = _config3_matrix() if isinstance(case["m"], str) else case["m"]
+    m12 = _lib.matrix12(as_matrix_3x4(m))
+    assert _lib.call_value("lsr_affine_path", *shape, m12, _lib.MODE_CONSTANT) == 0
+    rng = np.random.default_rng(len(str(case)))
+    vol = (rng.random(shape) * 1000 - 100).astype(np.float32)
+    oshape = case.get("out", shape)
+    ref = o.affine_apply_4x4(vol, m, oshape, cval=-3.0, mode="constant")
+    src = PitchedVolume.copy_of(_t(vol, device))
+    assert src.pitch % 4 == 0 and src.pitch - shape[2] in (1, 2, 3) and tuple(src.shape) == shape
+    assert _lib.call_value("lsr_affine_path_pitched", *shape, src.pitch, src.plane, m12, _lib.MODE_CONSTANT) == case["path"]
+
+    def check(out):
+        out = out.cpu().numpy()
+        if exact:
+            np.testing.assert_array_equal(out, ref)
+        else:
+            assert np.array_equal(out == -3.0, ref == -3.0)
+            assert np.abs(out - ref).max() <= 2e-5 * 1100
+
+    check(apply_affine_transform_zyx(src, m, oshape, cval=-3.0, exact=exact))
+    src.full[:, :, shape[2]:] = 4321.0              # the padding only ever meets weight 0
+    check(apply_affine_transform_zyx(src, m, oshape, cval=-3.0, exact=exact))
+    # a dense tensor of that width keeps the gather kernel (a padded copy costs more than it saves): same bits
+    check(apply_affine_transform_zyx(_t(vol, device), m, oshape, cval=-3.0, exact=exact))
+
+
+def test_affine_pitched_argument_errors(device):
+    import torch
+
+    from shrimpy_amd import _lib
+    from shrimpy_amd.geometry import as_matrix_3x4
+
+    a = torch.zeros((4, 8, 12), device=device)
+    b = torch.zeros((4, 8, 10), device=device)
+    m12 = _lib.matrix12(as_matrix_3x4(np.eye(4)))
+    for pitch, plane in ((9, 96), (12, 80)):
+        with pytest.raises(_lib.LsrError, match="source strides"):
+            _lib.call("lsr_affine_pitched_f32", a.data_ptr(), 4, 8, 10, pitch, plane, b.data_ptr(), 4, 8, 10, m12,
+                      ctypes.c_float(0.0), _lib.MODE_CONSTANT, _lib.stream_ptr(device))
+    # strides the LDS kernels cannot take (pitch 11: rows off 16-byte boundaries) still give the right answer
+    c = torch.arange(4 * 8 * 11, dtype=torch.float32, device=device).reshape(4, 8, 11)
+    _lib.call("lsr_affine_pitched_f32", c.data_ptr(), 4, 8, 10, 11, 88, b.data_ptr(), 4, 8, 10, m12,
+              ctypes.c_float(0.0), _lib.MODE_CONSTANT, _lib.stream_ptr(device))
+    assert torch.equal(b, c[:, :, :10])
+
+
+def test_pipeline_deskews_into_padded_rows_when_a_registration_follows(device):
+    """deskew -> register on a stack whose deskewed width is not a multiple of 4: the deskew writes
+    zero-padded rows and the registration reads them through the LDS-staged kernel; result = oracle."""
+    from shrimpy_amd.pipeline import VolumeReconstructor
+    from shrimpy_amd.settings import DeskewSettings, ReconstructSettings, RegisterSettings
+
+    rng = np.random.default_rng(35)
+    raw = rng.integers(80, 600, (98, 24, 40)).astype(np.uint16)        # deskews to (8, 40, 151)
+    d = DeskewSettings(pixel_size_um=0.1133, scan_step_um=0.15, ls_angle_deg=30.0, keep_overhang=True, average_n_slices=3)
+    desk = o.deskew(raw.astype(np.float32), 30.0, 0.755, True, 3)
+    assert desk.shape[2] % 4 != 0
+    m = _tilted_matrix([(1, 2.0), (0, 1.0)], (1.0, 0.99, 1.01), (0.5, -1.25, 2.75))
+    reg = RegisterSettings(affine_transform_zyx=m.tolist())
+    rec = VolumeReconstructor(raw.shape, ReconstructSettings(deskew=d, registration=reg), device)
+    got = rec(raw)
+    assert rec._pitched is not None and rec._pitched.pitch == (desk.shape[2] + 3) // 4 * 4
+    np.testing.assert_array_equal(got.cpu().numpy(), o.affine_apply_4x4(desk, m, desk.shape, cval=0.0, mode="constant"))
+    np.testing.assert_array_equal(rec(raw).cpu().numpy(), got.cpu().numpy())     # the padded target is reused
+
+
 def test_affine_path_selection(device):
     """planar (1) for z-decoupled maps, box (2) for the rest that fit, gather (0) otherwise; every
     path gives the oracle's bits."""
