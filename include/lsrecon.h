@@ -121,10 +121,13 @@ int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* o
  * natural choice).  A deskewed volume is Xp = ceil(Z / r - Y cos(theta)) wide -- a multiple of 4 one time
  * in four; lsr_deskew_* writes any out_pitch, so the deskew -> register chain keeps the fast kernels for
  * every width.  Other strides run the gather kernel, as lsr_affine_f32 does for Xi % 4 != 0.
+ * out_pitch / out_plane (any values >= the dense ones) let the result land inside a larger allocation, e.g.
+ * the padded volume the Richardson-Lucy kernels read, so no copy sits between registration and deconvolution.
  */
 int lsr_affine_pitched_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t in_pitch,
                            int64_t in_plane, float* out, int64_t Zo, int64_t Yo, int64_t Xo,
-                           const double M[12], float cval, int mode, lsr_stream_t stream);
+                           int64_t out_pitch, int64_t out_plane, const double M[12], float cval, int mode,
+                           lsr_stream_t stream);
 int lsr_affine_path_pitched(int64_t Zi, int64_t Yi, int64_t Xi, int64_t in_pitch, int64_t in_plane,
                             const double M[12], int mode); /* lsr_affine_path for such a source */
 /* Which kernel lsr_affine_f32 runs for this matrix on a (.., Yi, Xi) moving volume: 1 = the

@@ -68,8 +68,8 @@ SIGNATURES: dict[str, list] = {
     "lsr_cross_power_into_c64": [_c_f32p, _c_f32p, _i64, _stream],
     "lsr_peak_abs_shifted_f32": [_c_f32p, _i64, _i64, _i64, ctypes.c_void_p, ctypes.c_void_p, _stream],
     "lsr_affine_kernel_choice": [_i64, _i64, _f64p, _int],
-    "lsr_affine_pitched_f32": [_c_f32p, _i64, _i64, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _f64p, _f32, _int,
-                               _stream],
+    "lsr_affine_pitched_f32": [_c_f32p, _i64, _i64, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _f64p, _f32,
+                               _int, _stream],
     "lsr_affine_path_pitched": [_i64, _i64, _i64, _i64, _i64, _f64p, _int],
     "lsr_affine_path": [_i64, _i64, _i64, _f64p, _int],
     "lsr_affine_box_shape": [_i64, _i64, _i64, _f64p, ctypes.POINTER(ctypes.c_int)],

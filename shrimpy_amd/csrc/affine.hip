@@ -32,6 +32,7 @@ struct AffineArgs {
   float* out;
   int Zi, Yi, Xi;
   unsigned pitch, plane;   // source strides in floats (dense: Xi, Yi * Xi)
+  int64_t opitch, oplane;  // output strides in floats (dense: Xo, Yo * Xo)
   int Zo, Yo, Xo;
   double m[12];
   float cval;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
   // element indices fit 32 bits unsigned (host check); one 64-bit add per load
   const unsigned sz = p.plane;
   const double cv = static_cast<double>(p.cval);
-  float* orow = p.out + (static_cast<int64_t>(zo) * p.Yo + yo) * p.Xo;
+  float* orow = p.out + static_cast<int64_t>(zo) * p.oplane + static_cast<int64_t>(yo) * p.opitch;
 
 #pragma unroll
   for (int k = 0; k < kPerThread; ++k) {
@@ -204,14 +205,15 @@ namespace lsr {
 // affine_planar.hip: z-decoupled maps in constant mode; false = not applicable
 // (pitch / plane: source strides in floats; dense = Xi, Yi * Xi)
 bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane,
-                          float* out, int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32,
-                          hipStream_t s);
+                          float* out, int64_t Zo, int64_t Yo, int64_t Xo, int64_t opitch, int64_t oplane,
+                          const double M[12], float cval, bool f32, hipStream_t s);
 bool affine_planar_geometry(int64_t Yi, int64_t Xi, int64_t pitch, const double M[12], int* box_y, int* box_x,
                             int* slots, int64_t* lds_bytes);
 // affine_box.hip: any map whose per-block source box fits in LDS (z-coupled maps included),
 // constant mode; false = not applicable
 bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, float* out,
-                       int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32, hipStream_t s);
+                       int64_t Zo, int64_t Yo, int64_t Xo, int64_t opitch, int64_t oplane, const double M[12], float cval,
+                       bool f32, hipStream_t s);
 bool affine_box_geometry(int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, const double M[12],
                          int* box_z, int* box_y, int* box_x, int64_t* lds_bytes);
 bool affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int out6[6]);
@@ -256,30 +258,34 @@ extern "C" int lsr_affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const do
 
 namespace {
 int affine_impl(const char* what, const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane,
-                float* out, int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval, int mode,
-                lsr_stream_t stream);
+                float* out, int64_t Zo, int64_t Yo, int64_t Xo, int64_t opitch, int64_t oplane, const double M[12],
+                float cval, int mode, lsr_stream_t stream);
 }
 
 extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out,
                               int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval,
                               int mode, lsr_stream_t stream) {
-  return affine_impl("lsr_affine_f32", in, Zi, Yi, Xi, Xi, Yi * Xi, out, Zo, Yo, Xo, M, cval, mode, stream);
+  return affine_impl("lsr_affine_f32", in, Zi, Yi, Xi, Xi, Yi * Xi, out, Zo, Yo, Xo, Xo, Yo * Xo, M, cval, mode, stream);
 }
 
 extern "C" int lsr_affine_pitched_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t in_pitch,
                                       int64_t in_plane, float* out, int64_t Zo, int64_t Yo, int64_t Xo,
-                                      const double M[12], float cval, int mode, lsr_stream_t stream) {
+                                      int64_t out_pitch, int64_t out_plane, const double M[12], float cval, int mode,
+                                      lsr_stream_t stream) {
   LSR_REQUIRE(in_pitch >= Xi && in_plane >= Yi * in_pitch, LSR_E_SHAPE,
               "source strides (%lld, %lld) are smaller than a (%lld x %lld) plane", (long long)in_pitch,
               (long long)in_plane, (long long)Yi, (long long)Xi);
-  return affine_impl("lsr_affine_pitched_f32", in, Zi, Yi, Xi, in_pitch, in_plane, out, Zo, Yo, Xo, M, cval, mode,
-                     stream);
+  LSR_REQUIRE(out_pitch >= Xo && out_plane >= Yo * out_pitch, LSR_E_SHAPE,
+              "output strides (%lld, %lld) are smaller than a (%lld x %lld) plane", (long long)out_pitch,
+              (long long)out_plane, (long long)Yo, (long long)Xo);
+  return affine_impl("lsr_affine_pitched_f32", in, Zi, Yi, Xi, in_pitch, in_plane, out, Zo, Yo, Xo, out_pitch, out_plane,
+                     M, cval, mode, stream);
 }
 
 namespace {
 int affine_impl(const char* what, const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane,
-                float* out, int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval, int mode,
-                lsr_stream_t stream) {
+                float* out, int64_t Zo, int64_t Yo, int64_t Xo, int64_t opitch, int64_t oplane, const double M[12],
+                float cval, int mode, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE_PTR(M);
@@ -302,8 +308,10 @@ int affine_impl(const char* what, const float* in, int64_t Zi, int64_t Yi, int64
     LSR_REQUIRE(M[i] == M[i] && M[i] - M[i] == 0.0, LSR_E_ARG, "M[%d] is not finite", i);
 
   if (mode == LSR_MODE_CONSTANT && in != out &&
-      (lsr::launch_affine_planar(in, Zi, Yi, Xi, pitch, plane, out, Zo, Yo, Xo, M, cval, f32, lsr::as_stream(stream)) ||
-       lsr::launch_affine_box(in, Zi, Yi, Xi, pitch, plane, out, Zo, Yo, Xo, M, cval, f32, lsr::as_stream(stream))))
+      (lsr::launch_affine_planar(in, Zi, Yi, Xi, pitch, plane, out, Zo, Yo, Xo, opitch, oplane, M, cval, f32,
+                                 lsr::as_stream(stream)) ||
+       lsr::launch_affine_box(in, Zi, Yi, Xi, pitch, plane, out, Zo, Yo, Xo, opitch, oplane, M, cval, f32,
+                              lsr::as_stream(stream))))
     return lsr::launch_status(what);
 
   AffineArgs p;
@@ -311,6 +319,7 @@ int affine_impl(const char* what, const float* in, int64_t Zi, int64_t Yi, int64
   p.out = out;
   p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
   p.pitch = static_cast<unsigned>(pitch); p.plane = static_cast<unsigned>(plane);
+  p.opitch = opitch; p.oplane = oplane;
   p.Zo = static_cast<int>(Zo); p.Yo = static_cast<int>(Yo); p.Xo = static_cast<int>(Xo);
   for (int i = 0; i < 12; ++i) p.m[i] = M[i];
   p.cval = cval;

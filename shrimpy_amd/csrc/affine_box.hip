@@ -46,6 +46,8 @@ struct BoxArgs {
   float* out;
   int Zi, Yi, Xi;
   unsigned pitch, plane;   // source strides in floats (multiples of 4; columns [Xi, pitch) finite: they only meet weight 0)
+  unsigned opitch;         // output row stride in floats (host: Yo * opitch < 2^31)
+  int64_t oplane;          // output plane stride in floats
   int Zo, Yo, Xo;
   double m[12];
   float cval;
@@ -177,7 +179,7 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
 
   // ---- per-pixel constants -------------------------------------------------------------------
   // pixel q = tid + 512 j of the block's TY x TX plane: consecutive lanes are consecutive xo
-  unsigned pix[P];   // yo * Xo + xo: the output offset inside a plane (host: Yo * Xo < 2^31)
+  unsigned pix[P];   // yo * opitch + xo: the output offset inside a plane (host: Yo * opitch < 2^31)
   double tzy[P], tyy[P], txy[P], tzx[P], tyx[P], txx[P];
   bool ok[P];
 #pragma unroll
@@ -185,7 +187,7 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
     const int q = tid + j * NT;
     const int yo = y0 + (q >> p.tx_shift), xo = x0 + (q & (p.tx - 1));
     ok[j] = yo < p.Yo && xo < p.Xo;
-    pix[j] = static_cast<unsigned>(yo) * static_cast<unsigned>(p.Xo) + static_cast<unsigned>(xo);
+    pix[j] = static_cast<unsigned>(yo) * p.opitch + static_cast<unsigned>(xo);
     const double yd = static_cast<double>(yo), xd = static_cast<double>(xo);
     tzy[j] = lsr::dmul(yd, p.m[1]); tyy[j] = lsr::dmul(yd, p.m[5]); txy[j] = lsr::dmul(yd, p.m[9]);
     tzx[j] = lsr::dmul(xd, p.m[2]); tyx[j] = lsr::dmul(xd, p.m[6]); txx[j] = lsr::dmul(xd, p.m[10]);
@@ -223,7 +225,7 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
     for (int dz = 0; dz < nz; ++dz)
 #pragma unroll
       for (int j = 0; j < P; ++j)
-        if (ok[j]) p.out[static_cast<int64_t>(z0 + dz) * p.Yo * p.Xo + pix[j]] = smem[tid];
+        if (ok[j]) p.out[static_cast<int64_t>(z0 + dz) * p.oplane + pix[j]] = smem[tid];
     return;
   }
   for (int dz = 0; dz < nz; dz += U) {
@@ -296,7 +298,7 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
     for (int u = 0; u < U; ++u) {
       const int zo = z0 + dz + u;
       if (zo >= p.Zo) break;   // uniform
-      float* const oplane = p.out + static_cast<int64_t>(zo) * p.Yo * p.Xo;   // scalar
+      float* const oplane = p.out + static_cast<int64_t>(zo) * p.oplane;   // scalar
 #pragma unroll
       for (int j = 0; j < P; ++j)
         if (ok[j]) oplane[pix[j]] = res[u * P + j];
@@ -429,14 +431,16 @@ bool affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], in
 }
 
 bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, float* out,
-                       int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32, hipStream_t s) {
+                       int64_t Zo, int64_t Yo, int64_t Xo, int64_t opitch, int64_t oplane, const double M[12], float cval,
+                       bool f32, hipStream_t s) {
   BoxShape sh;
-  if ((reinterpret_cast<uintptr_t>(in) & 15) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || Yo * opitch >= (int64_t(1) << 31)) return false;
   if (!pick_shape(Zi, Yi, Xi, pitch, plane, M, &sh)) return false;
   BoxArgs p;
   p.in = in; p.out = out;
   p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
   p.pitch = static_cast<unsigned>(pitch); p.plane = static_cast<unsigned>(plane);
+  p.opitch = static_cast<unsigned>(opitch); p.oplane = oplane;
   p.Zo = static_cast<int>(Zo); p.Yo = static_cast<int>(Yo); p.Xo = static_cast<int>(Xo);
   for (int i = 0; i < 12; ++i) p.m[i] = M[i];
   p.cval = cval;
@@ -468,7 +472,7 @@ bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int6
 #endif
   const unsigned blocks = static_cast<unsigned>(per_xcd * 8);
   const size_t lds = static_cast<size_t>(sh.lds_bytes);
-  if (Yo * Xo >= (int64_t(1) << 31)) return false;   // 32-bit output offsets inside a plane
+  if (Yo * opitch >= (int64_t(1) << 31)) return false;   // 32-bit output offsets inside a plane
   switch (sh.tz * 2 + (f32 ? 1 : 0)) {
     case 8 * 2 + 1: launch_shape<true, 8>(p, blocks, lds, s); break;
     case 8 * 2 + 0: launch_shape<false, 8>(p, blocks, lds, s); break;

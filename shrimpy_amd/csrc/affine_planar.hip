@@ -37,6 +37,7 @@ struct PlanarArgs {
   int pitch;             // source row stride in floats (a multiple of 4, >= Xi rounded up to 4; columns
                          // [Xi, pitch) hold finite values -- they only ever meet weight 0)
   int64_t plane;         // source plane stride in floats (a multiple of 4)
+  int64_t opitch, oplane;  // output strides in floats (dense: Xo, Yo * Xo)
   int Zo, Yo, Xo;
   double a, tz;          // z_in = zo * a + tz
   double b, c, ty;       // y_in = (yo * b + xo * c) + ty
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
         request(n1);
       }
     }
-    float* orow = p.out + (static_cast<int64_t>(zo) * p.Yo + y0) * p.Xo + x0;
+    float* orow = p.out + static_cast<int64_t>(zo) * p.oplane + static_cast<int64_t>(y0) * p.opitch + x0;
     const char* s0 = reinterpret_cast<const char*>(smem + slot_of(z0) * slot_floats);
     const char* s1 = reinterpret_cast<const char*>(smem + slot_of(z1) * slot_floats);
     typedef float f32x2 __attribute__((ext_vector_type(2), aligned(4)));
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
       for (int k = 0; k < G; ++k) {
         const int i = h + k;
         if (in_out[i >> 1] && col_out[i & 1])
-          orow[static_cast<int64_t>(wave + 8 * (i >> 1)) * p.Xo + lane + 64 * (i & 1)] = res[k];
+          orow[static_cast<int64_t>(wave + 8 * (i >> 1)) * p.opitch + lane + 64 * (i & 1)] = res[k];
       }
     }
     // (no barrier here: the next iteration's DMAs are issued behind its own barrier, which every
@@ -300,8 +301,8 @@ bool affine_planar_geometry(int64_t Yi, int64_t Xi, int64_t pitch, const double 
 }
 
 bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane,
-                          float* out, int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval, bool f32,
-                          hipStream_t s) {
+                          float* out, int64_t Zo, int64_t Yo, int64_t Xo, int64_t opitch, int64_t oplane,
+                          const double M[12], float cval, bool f32, hipStream_t s) {
   int box_y, box_x, slots;
   int64_t lds_bytes;
   if (plane % 4 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return false;
@@ -311,6 +312,7 @@ bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, i
   p.in = in; p.out = out;
   p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
   p.pitch = static_cast<int>(pitch); p.plane = plane;
+  p.opitch = opitch; p.oplane = oplane;
   p.Zo = static_cast<int>(Zo); p.Yo = static_cast<int>(Yo); p.Xo = static_cast<int>(Xo);
   p.a = M[0]; p.tz = M[3];
   p.b = M[5]; p.c = M[6]; p.ty = M[7];

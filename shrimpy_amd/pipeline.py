@@ -167,8 +167,14 @@ class VolumeReconstructor:
                 vol = orient_volume(vol, d.orientation)
         if self._register is not None:
             r = self._register
+            target = None
+            if self._plan is not None and self._plan.path != "generic":
+                # resample straight into the RL kernels' padded, line-aligned input volume
+                if self._y_pad is None:
+                    self._y_pad = self._plan.new_padded_input()
+                target = self._y_pad
             vol = apply_affine_transform_zyx(vol, np.asarray(r.affine_transform_zyx), self.output_shape,
-                                             mode=r.mode, cval=r.cval)
+                                             mode=r.mode, cval=r.cval, out=target)
         if self._plan is not None:
             dec = self.settings.deconvolution
             vol = self._plan(vol, iterations=dec.iterations, eps=dec.eps, events=rl_events)

@@ -67,6 +67,9 @@ def apply_affine_transform_zyx(moving, affine_transform_zyx, output_shape_zyx=No
     output_shape_zyx : target grid shape; defaults to ``moving.shape``.
     mode : ``"constant"`` (scipy default: any coordinate outside ``[0, n-1]`` gives ``cval``) or
         ``"grid-constant"`` (blend towards ``cval`` across the border).
+    moving : a dense tensor, or a :class:`PitchedVolume` (rows padded to 16-byte multiples).
+    out : a dense tensor, or a padded working volume with ``logical_ptr`` / ``pitch`` / ``plane`` / ``view``
+        (``deconvolve.PaddedVolume``): the result then lands where the RL kernels read it.
     exact : ``True`` (default) interpolates in fp64 in scipy's operation order -- bit-identical to
         ``scipy.ndimage.affine_transform``; ``False`` interpolates in float32 (border decisions
         unchanged, ~1e-6 relative difference), which is about 2x faster (HBM-bound).
@@ -93,31 +96,34 @@ def apply_affine_transform_zyx(moving, affine_transform_zyx, output_shape_zyx=No
     shape = tuple(int(v) for v in (output_shape_zyx if output_shape_zyx is not None else moving.shape))
     if len(shape) != 3 or min(shape) <= 0:
         raise ValueError(f"output_shape_zyx must be three positive ints, got {shape}")
+    result = out
     if out is None:
-        out = torch.empty(shape, dtype=torch.float32, device=moving.device)
+        out = result = torch.empty(shape, dtype=torch.float32, device=moving.device)
+        out_ptr, out_pitch, out_plane = out.data_ptr(), shape[2], shape[1] * shape[2]
+    elif hasattr(out, "logical_ptr"):   # a padded working volume (e.g. the RL plan's input): written in place
+        if tuple(out.view.shape) != shape or out.full.device != moving.device:
+            raise ValueError(f"out must hold a {shape} window on {moving.device}")
+        if out.full.data_ptr() == (pitched.full if pitched is not None else moving).data_ptr():
+            raise ValueError("out must not alias moving")
+        out_ptr, out_pitch, out_plane = out.logical_ptr(), out.pitch, out.plane
     else:
         _lib.require_device_f32(out, "out")
         if tuple(out.shape) != shape or out.device != moving.device:
             raise ValueError(f"out must be {shape} on {moving.device}")
         if out.data_ptr() == moving.data_ptr():
             raise ValueError("out must not alias moving")
+        out_ptr, out_pitch, out_plane = out.data_ptr(), shape[2], shape[1] * shape[2]
     zi, yi, xi = (int(v) for v in moving.shape)
+    in_ptr, in_pitch, in_plane = ((pitched.logical_ptr(), pitched.pitch, pitched.plane) if pitched is not None
+                                  else (moving.data_ptr(), xi, yi * xi))
     flags = _MODES[mode] | (0 if exact else _lib.MODE_F32_INTERP)
     with torch.cuda.device(moving.device):
-        if pitched is not None:
-            _lib.call(
-                "lsr_affine_pitched_f32", pitched.logical_ptr(), zi, yi, xi, pitched.pitch, pitched.plane,
-                out.data_ptr(), shape[0], shape[1], shape[2], _lib.matrix12(m), ctypes.c_float(float(cval)),
-                flags, _lib.stream_ptr(moving.device),
-            )
-        else:
-            _lib.call(
-                "lsr_affine_f32", moving.data_ptr(), zi, yi, xi, out.data_ptr(), shape[0], shape[1],
-                shape[2], _lib.matrix12(m), ctypes.c_float(float(cval)), flags,
-                _lib.stream_ptr(moving.device),
-            )
-    _lib.mark_written(out)
-    return out
+        _lib.call(
+            "lsr_affine_pitched_f32", in_ptr, zi, yi, xi, in_pitch, in_plane, out_ptr, shape[0], shape[1], shape[2],
+            out_pitch, out_plane, _lib.matrix12(m), ctypes.c_float(float(cval)), flags, _lib.stream_ptr(moving.device),
+        )
+    _lib.mark_written(out.full if hasattr(out, "logical_ptr") else out)
+    return result
 
 
 def affine_transform(input, matrix, offset=0.0, output_shape=None, order=1, mode="constant",

@@ -438,11 +438,15 @@ def test_affine_pitched_argument_errors(device):
     m12 = _lib.matrix12(as_matrix_3x4(np.eye(4)))
     for pitch, plane in ((9, 96), (12, 80)):
         with pytest.raises(_lib.LsrError, match="source strides"):
-            _lib.call("lsr_affine_pitched_f32", a.data_ptr(), 4, 8, 10, pitch, plane, b.data_ptr(), 4, 8, 10, m12,
+            _lib.call("lsr_affine_pitched_f32", a.data_ptr(), 4, 8, 10, pitch, plane, b.data_ptr(), 4, 8, 10, 10, 80, m12,
+                      ctypes.c_float(0.0), _lib.MODE_CONSTANT, _lib.stream_ptr(device))
+    for pitch, plane in ((9, 80), (10, 79)):
+        with pytest.raises(_lib.LsrError, match="output strides"):
+            _lib.call("lsr_affine_pitched_f32", a.data_ptr(), 4, 8, 10, 12, 96, b.data_ptr(), 4, 8, 10, pitch, plane, m12,
                       ctypes.c_float(0.0), _lib.MODE_CONSTANT, _lib.stream_ptr(device))
     # strides the LDS kernels cannot take (pitch 11: rows off 16-byte boundaries) still give the right answer
     c = torch.arange(4 * 8 * 11, dtype=torch.float32, device=device).reshape(4, 8, 11)
-    _lib.call("lsr_affine_pitched_f32", c.data_ptr(), 4, 8, 10, 11, 88, b.data_ptr(), 4, 8, 10, m12,
+    _lib.call("lsr_affine_pitched_f32", c.data_ptr(), 4, 8, 10, 11, 88, b.data_ptr(), 4, 8, 10, 10, 80, m12,
               ctypes.c_float(0.0), _lib.MODE_CONSTANT, _lib.stream_ptr(device))
     assert torch.equal(b, c[:, :, :10])
 
@@ -1049,3 +1053,39 @@ def test_zxy_entry_rejects_what_it_does_not_cover(device):
         call(_lib.EPI_RATIO, p=(5, 11, 5))      # y taps beyond the dense kernel's nine
     call(_lib.EPI_RATIO)                         # and the valid call goes through
     torch.cuda.synchronize()
+
+
+def test_registration_writes_the_rl_input_in_place(device):
+    """deskew -> register -> RL through ``VolumeReconstructor``: the registration's result lands in the RL
+    plan's padded input (``apply_affine_transform_zyx(out=PaddedVolume)``, strided stores of all three
+    affine kernels) -- same bits as the dense call, and the chain follows the oracle."""
+    import torch
+
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+    from shrimpy_amd.pipeline import VolumeReconstructor
+    from shrimpy_amd.register import apply_affine_transform_zyx
+    from shrimpy_amd.settings import DeconvolveSettings, DeskewSettings, ReconstructSettings, RegisterSettings
+
+    rng = np.random.default_rng(37)
+    psf, _ = o.gaussian_psf((9, 7, 7), (2.0, 1.2, 1.2))
+    for shape, m, mode in [((20, 96, 132), _config3_matrix(), "constant"),                                   # planar
+                           ((24, 96, 132), _tilted_matrix([(1, 3.0), (0, 2.0)], (1.0, 0.98, 1.02), (1.5, -4.25, 6.75)), "constant"),
+                           ((20, 50, 70), _tilted_matrix([(1, 3.0)]), "grid-constant")]:                    # gather
+        vol = (rng.random(shape) * 1000).astype(np.float32)
+        dense = apply_affine_transform_zyx(_t(vol, device), m, shape, mode=mode)
+        plan = RichardsonLucyPlan(shape, psf, device)
+        pad = plan.new_padded_input()
+        got = apply_affine_transform_zyx(_t(vol, device), m, shape, mode=mode, out=pad)
+        assert got is pad and torch.equal(pad.view, dense)
+        halo = pad.full.clone()
+        halo[:, pad.view.storage_offset() % pad.plane // pad.pitch:, :][:, :shape[1], pad.view.storage_offset() % pad.pitch:][:, :, :shape[2]] = 0
+        assert not halo.any()                                  # nothing written outside the window
+    raw = rng.integers(80, 600, (98, 24, 40)).astype(np.uint16)
+    d = DeskewSettings(pixel_size_um=0.1133, scan_step_um=0.15, ls_angle_deg=30.0, keep_overhang=True, average_n_slices=3)
+    m = _tilted_matrix([(1, 2.0), (0, 1.0)], (1.0, 0.99, 1.01), (0.5, -1.25, 2.75))
+    rec = VolumeReconstructor(raw.shape, ReconstructSettings(
+        deskew=d, registration=RegisterSettings(affine_transform_zyx=m.tolist()),
+        deconvolution=DeconvolveSettings(iterations=5)), device)
+    desk = o.deskew(raw.astype(np.float32), 30.0, 0.755, True, 3)
+    reg = o.affine_apply_4x4(desk, m, desk.shape, cval=0.0, mode="constant")
+    _close(rec(raw).cpu().numpy(), o.richardson_lucy(reg, psf, iterations=5), 5e-5, 2e-5)
