@@ -82,14 +82,16 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-def test_run_sharded_world_size_2_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_run_sharded_world_size_2_gloo(tmp_path, world):
+    """Seven units over 2 and over 3 ranks (uneven shares: 4 + 3, 3 + 2 + 2), real processes over gloo."""
     import torch.multiprocessing as mp
 
-    world, port = 2, _free_port()
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     owned = [(tmp_path / f"ok{r}").read_text().split(",") for r in range(world)]
-    assert owned[0] == ["A/0/0", "A/2/0", "A/4/0", "A/6/0"]
-    assert owned[1] == ["A/1/0", "A/3/0", "A/5/0"]
+    for r in range(world):
+        assert owned[r] == [f"A/{i}/0" for i in range(r, 7, world)]
     # rank 0 holds every unit's result, in unit order
     np.testing.assert_array_equal(np.load(tmp_path / "gathered.npy"), [2 * i + 1 for i in range(7)])
 
