@@ -543,7 +543,7 @@ def dt_phase_cross_corr(ref, mov, maximum_shift=1.0):
     shape = tuple(dt_next_fast_len(int(max(a, b) * maximum_shift)) for a, b in zip(ref.shape, mov.shape))
     f1 = np.fft.rfftn(dt_match_shape(ref, shape))
     f2 = np.fft.rfftn(dt_match_shape(mov, shape))
-    corr = np.fft.fftshift(np.abs(np.fft.irfftn(f1 * np.conj(f2), s=shape, axes=(0, 1, 2))))
+    corr = np.fft.fftshift(np.abs(np.fft.irfftn(f1 * np.conj(f2), s=shape, axes=tuple(range(len(shape))))))
     peak = np.unravel_index(int(np.argmax(corr)), corr.shape)
     return tuple(int(s // 2) - int(p) for s, p in zip(corr.shape, peak))
 

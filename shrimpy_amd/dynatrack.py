@@ -427,13 +427,18 @@ def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0) -> tuple[int
 
     from . import fft3
 
+    if (isinstance(ref_img, torch.Tensor) and isinstance(mov_img, torch.Tensor)
+            and ref_img.dim() == 2 and mov_img.dim() == 2):
+        # 2-D images (the reference takes both, ``test_dynatrack.py:85-100``): a one-plane volume; the
+        # length-1 axis transforms to itself and contributes shift 0
+        return _phase_cross_corr(ref_img.unsqueeze(0), mov_img.unsqueeze(0), maximum_shift)[1:]
     ref_t, mov_t = _volume(ref_img, "ref_img"), _volume(mov_img, "mov_img")
     if ref_t.dim() != 3 or mov_t.dim() != 3:
-        raise ValueError("phase cross-correlation is implemented for (Z, Y, X) volumes")
+        raise ValueError("phase cross-correlation takes two (Y, X) images or two (Z, Y, X) volumes")
     shape = tuple(_next_fast_len(int(max(s1, s2) * maximum_shift)) for s1, s2 in zip(ref_t.shape, mov_t.shape))
     logger.debug("phase cross corr: fft shape %s for arrays %s and %s (max_shift=%.2f)", shape,
                  tuple(ref_t.shape), tuple(mov_t.shape), maximum_shift)
-    kind = "rfft3" if (_axis_fft_ok[0] and fft3.available()) else "rfftn"
+    kind = "rfft3" if (_axis_fft_ok[0] and fft3.available() and min(shape) >= 2) else "rfftn"
     try:
         corr = _cross_correlation(ref_t, ref_t is ref_img, mov_t, shape, kind)
     except fft3.AxisFftError as exc:

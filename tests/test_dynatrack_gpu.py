@@ -126,6 +126,26 @@ def test_phase_cross_correlation_matches_the_reference(device, golden):
     assert [d._next_fast_len(n) for n in (1, 7, 11, 49, 171, 2270)] == [o.dt_next_fast_len(n) for n in (1, 7, 11, 49, 171, 2270)]
 
 
+def test_phase_cross_correlation_of_2d_images_as_the_reference_tests_it(device):
+    """The reference's own 2-D known answers (``shrimpy/tests/test_dynatrack.py:85-100``): rng(42) (32, 32)
+    against itself -> (0, 0); rng(42) (64, 64) rolled by (3, -5) -> (3, -5); plus odd sizes vs the oracle."""
+    import torch
+
+    from shrimpy_amd import dynatrack as d
+
+    img = _t(np.random.default_rng(42).random((32, 32)).astype(np.float32), device)
+    assert d._phase_cross_corr(img, img.clone()) == (0, 0)
+    ref = _t(np.random.default_rng(42).random((64, 64)).astype(np.float32), device)
+    assert d._phase_cross_corr(ref, torch.roll(ref, shifts=(3, -5), dims=(0, 1))) == (3, -5)
+    rng = np.random.default_rng(9)
+    a = rng.random((45, 77)).astype(np.float32)
+    b = np.roll(a, (-4, 9), axis=(0, 1))
+    assert d._phase_cross_corr(_t(a, device), _t(b, device)) == o.dt_phase_cross_corr(a, b) == (-4, 9)
+    assert d._phase_cross_corr(_t(a, device), _t(b, device), 0.6) == o.dt_phase_cross_corr(a, b, 0.6)
+    with pytest.raises(ValueError, match="two \\(Y, X\\) images or two"):
+        d._phase_cross_corr(_t(a, device), _t(a[None], device))
+
+
 def test_phase_cross_correlation_on_a_larger_volume(device):
     from oracle.make_golden import dynatrack_scene
     from shrimpy_amd import dynatrack as d

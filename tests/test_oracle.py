@@ -195,6 +195,15 @@ def test_dynatrack_oracle_matches_reference_capture(golden_dir):
     np.testing.assert_allclose(o.dt_multiotsu_center_of_mass(a, b, 2.0, 1), g["motsu_shift_ab_s2_c1"], atol=2e-2)
 
 
+def test_dynatrack_pcc_oracle_on_the_references_2d_known_answers():
+    """``shrimpy/tests/test_dynatrack.py:85-100``: (32, 32) against itself -> (0, 0); (64, 64) rolled by
+    (3, -5) -> (3, -5)."""
+    img = np.random.default_rng(42).random((32, 32)).astype(np.float32)
+    assert o.dt_phase_cross_corr(img, img.copy()) == (0, 0)
+    ref = np.random.default_rng(42).random((64, 64)).astype(np.float32)
+    assert o.dt_phase_cross_corr(ref, np.roll(ref, (3, -5), axis=(0, 1))) == (3, -5)
+
+
 def test_dynatrack_pcc_oracle_matches_reference_capture(golden_dir):
     g = np.load(golden_dir / "ref_dynatrack.npz")
     assert o.dt_phase_cross_corr(g["pcc_ref"], g["pcc_mov"]) == tuple(g["pcc_shift"]) == (1, 2, -3)
