@@ -388,6 +388,10 @@ def _match_shape(t, shape):
 
     vol = _volume(t, "t")
     shape = tuple(int(v) for v in shape)
+    if vol.dim() != len(shape) or vol.dim() not in (2, 3):
+        raise ValueError(f"cannot match a {tuple(vol.shape)} tensor to shape {shape}: two or three axes each")
+    if vol.dim() == 2:      # images (``test_dynatrack.py:62-82``): a one-plane volume
+        return _match_shape(vol.unsqueeze(0), (1,) + shape).squeeze(0)
     if tuple(vol.shape) == shape:
         return vol
     out = torch.empty(shape, dtype=torch.float32, device=vol.device)
