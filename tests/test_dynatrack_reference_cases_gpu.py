@@ -133,3 +133,19 @@ def test_multiotsu_tracker_cases():
     mov[2:6, 18:53, 15:50] = 0.9
     s = d._multiotsu_pcc(_dev(ref), _dev(mov), sigma=1.0, otsu_component=0)
     assert abs(s[1] - 3) <= 1 and abs(s[2]) <= 1
+
+
+def test_compute_shift_cases():
+    """``TestComputeShift`` (:219-298): pixels -> microns, dampening, limits, on rng(42) (8, 64, 64) rolled volumes."""
+    ref = _dev(np.random.default_rng(42).random((8, 64, 64)))
+    mov = torch.roll(ref, shifts=(1, 2, -3), dims=(0, 1, 2))
+    x, y, z = d.compute_shift(ref, mov, "pcc", scale_yx=0.5, scale_z=2.0)
+    assert (x, y, z) == pytest.approx((-3 * 0.5, 2 * 0.5, 1 * 2.0), abs=1e-6)
+    x, y, z = d.compute_shift(ref, mov, "pcc", scale_yx=0.5, scale_z=2.0, shift={"dampening": (0.5, 0.25, 0.1)})
+    assert (x, y, z) == pytest.approx((-3 * 0.5 * 0.1, 2 * 0.5 * 0.25, 1 * 2.0 * 0.5), abs=1e-6)
+    mov = torch.roll(ref, shifts=-3, dims=2)
+    limits = {"z": (0.1, 50.0), "y": (0.1, 50.0), "x": (0.1, 5.0)}
+    x, y, z = d.compute_shift(ref, mov, "pcc", scale_yx=10.0, scale_z=2.0, shift={"limits": limits})
+    assert x == pytest.approx(-5.0, abs=1e-6) and z == pytest.approx(0.0, abs=1e-6)     # -30 um clipped, sign kept
+    with pytest.raises(ValueError, match="Unknown tracking_method"):
+        d.compute_shift(ref, mov, "nope")

@@ -472,3 +472,17 @@ def test_padded_shape_and_fused_support_tables():
     assert ok[(9, 7)] == 1 and ok[(3, 3)] == 1 and ok[(15, 9)] == 1
     assert ok[(15, 11)] == 0 and ok[(15, 15)] == 0          # would spill the accumulators
     assert all(v == 0 for (pz, pyx), v in ok.items() if pz % 2 == 0 or pyx % 2 == 0 or pz > 15 or pyx > 15)
+
+
+def test_limit_shifts_cases_of_the_reference():
+    """``TestLimitShiftsZyx`` (``shrimpy/tests/test_dynatrack.py:119-142``): deadband below the minimum, clip above
+    the maximum with the sign kept, unchanged inside, axes without limits untouched -- host logic, no device."""
+    from shrimpy_amd.dynatrack import _limit_shifts_zyx
+
+    wide = {"z": (0.1, 10.0), "y": (0.1, 10.0), "x": (0.1, 10.0)}
+    cases = [([0.5, 0.3, 0.1], {"z": (1.0, 10.0), "y": (1.0, 10.0), "x": (1.0, 10.0)}, [0.0, 0.0, 0.0]),
+             ([15.0, -12.0, 8.0], wide, [10.0, -10.0, 8.0]),
+             ([5.0, -3.0, 2.0], wide, [5.0, -3.0, 2.0]),
+             ([5.0, 0.01, 2.0], {"z": (0.1, 10.0)}, [5.0, 0.01, 2.0])]
+    for shifts, limits, want in cases:
+        np.testing.assert_array_equal(_limit_shifts_zyx(np.array(shifts), limits), want)
