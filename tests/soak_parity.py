@@ -29,7 +29,8 @@ def main():
     from shrimpy_amd.deconvolve import RichardsonLucyPlan
     from shrimpy_amd.deskew import fast_deskew_zyx
     from shrimpy_amd.flatfield import flat_field_pattern
-    from shrimpy_amd.register import apply_affine_transform_zyx
+    from shrimpy_amd.deconvolve import PaddedVolume
+    from shrimpy_amd.register import PitchedVolume, apply_affine_transform_zyx
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
@@ -79,12 +80,21 @@ def main():
         mode = "constant" if r.integers(0, 3) else "grid-constant"
         vol = (r.random(shape) * 1000 - 100).astype(np.float32)
         want = o.affine_apply_4x4(vol, m, oshape, cval=-3.0, mode=mode)
-        got = apply_affine_transform_zyx(t(vol), m, oshape, mode=mode, cval=-3.0).cpu().numpy()
+        # any width through zero-padded rows (the LDS kernels then take it), any destination strides
+        src = PitchedVolume.copy_of(t(vol)) if r.integers(0, 2) else t(vol)
+        dst = None
+        if r.integers(0, 2):
+            dst = PaddedVolume(oshape, (int(r.choice([3, 5, 9])), int(r.choice([3, 7])), int(r.choice([3, 7]))), dev)
+        got = apply_affine_transform_zyx(src, m, oshape, mode=mode, cval=-3.0, out=dst)
+        got = (got.view if dst is not None else got).cpu().numpy()
         ok = np.array_equal(got, want)
+        if ok and dst is not None:     # nothing outside the window was touched
+            dst.view.zero_()
+            ok = not bool(dst.full.any())
         if ok and mode == "constant":   # f32 interpolation: same border decisions, close values
             g32 = apply_affine_transform_zyx(t(vol), m, oshape, cval=-3.0, exact=False).cpu().numpy()
             ok = np.array_equal(g32 == -3.0, want == -3.0) and float(np.abs(g32 - want).max()) <= 2e-5 * 1100
-        return ok, (shape, oshape, mode, planar, m[:3].round(4).tolist())
+        return ok, (shape, oshape, mode, planar, type(src).__name__, dst is not None, m[:3].round(4).tolist())
 
     odd = np.array([1, 3, 5, 7, 9, 11, 13, 15])
 
