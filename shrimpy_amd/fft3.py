@@ -47,11 +47,17 @@ def _lib_hipfft():
 
             path = os.path.join(os.path.dirname(torch.__file__), "lib", "libhipfft.so")
             lib = ctypes.CDLL(path)
-            lib.hipfftPlanMany.restype = ctypes.c_int
-            lib.hipfftPlanMany.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ctypes.c_int),
-                                           ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
-                                           ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                           ctypes.c_int]
+            lib.hipfftCreate.restype = ctypes.c_int
+            lib.hipfftCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+            lib.hipfftSetAutoAllocation.restype = ctypes.c_int
+            lib.hipfftSetAutoAllocation.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            lib.hipfftMakePlanMany.restype = ctypes.c_int
+            lib.hipfftMakePlanMany.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                               ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
+                                               ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
+            lib.hipfftSetWorkArea.restype = ctypes.c_int
+            lib.hipfftSetWorkArea.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
             lib.hipfftSetStream.restype = ctypes.c_int
             lib.hipfftSetStream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
             lib.hipfftExecC2C.restype = ctypes.c_int
@@ -73,7 +79,10 @@ def available() -> bool:
     return _lib_hipfft() is not None
 
 
-# (device index, kind, n, batch) -> plan handle; a handful of plans per grid shape, dropped oldest first
+# (device index, kind, n, batch) -> (plan handle, work-area bytes); a handful of plans per grid shape,
+# dropped oldest first.  Plans do not own device memory: hipFFT's automatic work-area allocation is off
+# (the real-to-complex plan of the tracker's grid wants 3.4 GB) and every execution borrows the work
+# area from PyTorch's caching allocator for the duration of the call.
 _plans: dict = {}
 _MAX_PLANS = 24
 
@@ -86,23 +95,37 @@ def _plan(device, kind: int, n: int, batch: int):
         if batch >= 2 ** 31 or n >= 2 ** 31:
             raise AxisFftError(f"transform of length {n} x batch {batch} exceeds hipFFT's int arguments")
         while len(_plans) >= _MAX_PLANS:
-            lib.hipfftDestroy(_plans.pop(next(iter(_plans))))
+            lib.hipfftDestroy(_plans.pop(next(iter(_plans)))[0])
         handle = ctypes.c_void_p()
-        dims = (ctypes.c_int * 1)(int(n))
-        # NULL embeds: contiguous sequences, distance n (C2C), n -> n // 2 + 1 (R2C), n // 2 + 1 -> n (C2R)
-        rc = lib.hipfftPlanMany(ctypes.byref(handle), 1, dims, None, 1, 0, None, 1, 0, kind, int(batch))
+        rc = lib.hipfftCreate(ctypes.byref(handle))
+        if rc == 0:
+            rc = lib.hipfftSetAutoAllocation(handle, 0)
+        work = ctypes.c_size_t(0)
+        if rc == 0:
+            dims = (ctypes.c_int * 1)(int(n))
+            # NULL embeds: contiguous sequences, distance n (C2C), n -> n // 2 + 1 (R2C), n // 2 + 1 -> n (C2R)
+            rc = lib.hipfftMakePlanMany(handle, 1, dims, None, 1, 0, None, 1, 0, kind, int(batch), ctypes.byref(work))
         if rc != 0:
-            raise AxisFftError(f"hipfftPlanMany(n={n}, batch={batch}, type={kind:#x}) failed with status {rc}")
-        plan = _plans[key] = handle
+            if handle:
+                lib.hipfftDestroy(handle)
+            raise AxisFftError(f"hipFFT plan (n={n}, batch={batch}, type={kind:#x}) failed with status {rc}")
+        plan = _plans[key] = (handle, int(work.value))
     else:
         _plans[key] = _plans.pop(key)        # most recently used last
     return plan
 
 
 def _exec(device, kind: int, n: int, batch: int, src_ptr: int, dst_ptr: int, direction: int = _FORWARD) -> None:
+    import torch
+
     lib = _lib_hipfft()
-    plan = _plan(device, kind, n, batch)
+    plan, work_bytes = _plan(device, kind, n, batch)
     rc = lib.hipfftSetStream(plan, ctypes.c_void_p(_lib.stream_ptr(device)))
+    work = None
+    if rc == 0 and work_bytes:
+        # freed back to the caching allocator right after the launches are queued: stream order keeps it safe
+        work = torch.empty((work_bytes,), dtype=torch.uint8, device=device)
+        rc = lib.hipfftSetWorkArea(plan, ctypes.c_void_p(work.data_ptr()))
     if rc == 0:
         if kind == _HIPFFT_C2C:
             rc = lib.hipfftExecC2C(plan, ctypes.c_void_p(src_ptr), ctypes.c_void_p(dst_ptr), direction)
@@ -110,6 +133,7 @@ def _exec(device, kind: int, n: int, batch: int, src_ptr: int, dst_ptr: int, dir
             rc = lib.hipfftExecR2C(plan, ctypes.c_void_p(src_ptr), ctypes.c_void_p(dst_ptr))
         else:
             rc = lib.hipfftExecC2R(plan, ctypes.c_void_p(src_ptr), ctypes.c_void_p(dst_ptr))
+    del work
     if rc != 0:
         raise AxisFftError(f"hipFFT execution (n={n}, batch={batch}, type={kind:#x}) failed with status {rc}")
 
