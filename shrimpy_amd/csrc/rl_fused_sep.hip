@@ -219,6 +219,9 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
   // XCD-aware order inside each class: workgroups b, b+8, ... share an XCD (round-robin dispatch),
   // so every XCD gets a contiguous run of tiles.
   auto xcd_contiguous = [](int b, int n) {
+#ifdef LSR_FUSED_PLAIN_ORDER   // probe build: blocks in launch order, one per XCD in turn
+    return b;
+#endif
     const int per = n / 8, rem = n % 8;
     const int xcd = b % 8, idx = b / 8;
     return xcd * per + (xcd < rem ? xcd : rem) + idx;
@@ -240,8 +243,14 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
   const int band = lin / (p.tiles_x * kBand);
   const int lb = lin - band * (p.tiles_x * kBand);
   const int band_h = min(kBand, p.tiles_y - band * kBand);
+#if defined(LSR_FUSED_PLAIN_ORDER) && LSR_FUSED_PLAIN_ORDER == 2   // probe build: row-major tiles
+  const int tx = lin % p.tiles_x;
+  const int ty = lin / p.tiles_x;
+  (void)lb; (void)band_h;
+#else
   const int tx = lb / band_h;
   const int ty = band * kBand + (lb - tx * band_h);
+#endif
   const int x0 = tx * kTX, y0 = ty * TY;
 #ifdef LSR_FUSED_LAG
   if ((tx + ty) & 1) {
