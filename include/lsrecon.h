@@ -403,6 +403,16 @@ int lsr_cross_power_c64(float* a, const float* b, int64_t n, lsr_stream_t stream
 /* dst[a][c][b] = src[a][b][c] for complex64 (8-byte) elements, out of place: the layout change between
  * the per-axis transforms of the cross-correlation's 3-D FFT (A = 1: a plain 2-D transpose). */
 int lsr_transpose_last2_c64(const float* src, float* dst, int64_t A, int64_t B, int64_t C, lsr_stream_t stream);
+/*
+ * The z leg of the cross-correlation in one pass: g <- N * IFFT_z( f1 * conj( FFT_z(g) ) ) along the first axis of
+ * g ([N][XC][Y] complex64: the moving volume's spectrum after its x and y transforms), f1 = the reference's fully
+ * transformed spectrum in [XC][Y][N] (z contiguous), twiddles[k] = exp(-2 pi i k / N) (N complex64, device).  Replaces
+ * transpose + forward z transform + cross power + inverse z transform + transpose (csrc/zcorr.hip).  N: 5-smooth, 2..256
+ * (lsr_cross_correlate_z_supported; LSR_E_UNSUPPORTED otherwise -- callers keep the five-pass route).
+ */
+int lsr_cross_correlate_z_supported(int64_t n);
+int lsr_cross_correlate_z_c64(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC,
+                              lsr_stream_t stream);
 /* b <- a * conj(b): the same product written over the second operand, so that `a` (the spectrum of
  * a reference volume that is compared against many timepoints) can be kept. */
 int lsr_cross_power_into_c64(const float* a, float* b, int64_t n, lsr_stream_t stream);

@@ -471,6 +471,12 @@ def _cross_correlation(ref_t, ref_is_callers, mov_t, shape, kind: str):
         fimg1 = _spectrum(ref_t, shape, kind)
         if cacheable:
             _spectra.put(ref_t, (kind, shape), fimg1)
+    if kind == "rfft3" and _lib.call_value("lsr_cross_correlate_z_supported", shape[0]):
+        # short z axis (a deskewed volume's always is): forward z transform, product and inverse z
+        # transform in one kernel on LDS-resident columns (csrc/zcorr.hip)
+        from . import fft3
+
+        return fft3.correlate_with_spectrum(fimg1, _match_shape(mov_t, shape))
     fimg2 = _spectrum(mov_t, shape, kind)
     with torch.cuda.device(fimg2.device):
         # f1 * conj(f2), written over f2: f1 may be the cached spectrum (element-wise: any layout)

@@ -22,7 +22,7 @@ import os
 
 from . import _lib
 
-__all__ = ["available", "rfft3", "irfft3", "AxisFftError"]
+__all__ = ["available", "rfft3", "irfft3", "correlate_with_spectrum", "AxisFftError"]
 
 _HIPFFT_R2C, _HIPFFT_C2R, _HIPFFT_C2C = 0x2A, 0x2C, 0x29
 _FORWARD, _BACKWARD = -1, 1
@@ -189,6 +189,63 @@ def irfft3(spectrum, shape_zyx):
         _transpose(spectrum, b, 1, xc * y, z, dev)                        # [XC Y][Z] -> [Z][XC Y]
         _exec(dev, _HIPFFT_C2C, y, z * xc, b.data_ptr(), b.data_ptr(), _BACKWARD)
         a = spectrum.view(-1).view(z, y, xc)
+        _transpose(b, a, z, xc, y, dev)                                   # [Z][XC][Y] -> [Z][Y][XC]
+        del b
+        out = torch.empty((z, y, x), dtype=torch.float32, device=dev)
+        _exec(dev, _HIPFFT_C2R, x, z * y, a.data_ptr(), out.data_ptr())
+    return out
+
+
+_twiddles: dict = {}
+
+
+def _twiddle_table(n: int, device):
+    """``exp(-2 pi i k / n)``, k < n, complex64 on ``device`` (worked out in float64)."""
+    import numpy as np
+    import torch
+
+    key = (int(n), device.index)
+    t = _twiddles.get(key)
+    if t is None:
+        if len(_twiddles) >= 16:
+            _twiddles.pop(next(iter(_twiddles)))
+        k = np.arange(n, dtype=np.float64)
+        t = _twiddles[key] = torch.as_tensor(np.exp(-2j * np.pi * k / n).astype(np.complex64), device=device)
+    return t
+
+
+def correlate_with_spectrum(ref_spectrum, volume):
+    """``irfft3(ref_spectrum * conj(rfft3(volume)))`` -- the cross-correlation of the volume behind
+    ``ref_spectrum`` (an :func:`rfft3` result, left intact) with ``volume``, unnormalised, float32
+    ``(Z, Y, X)`` -- without the moving spectrum ever taking the ``[XC][Y][Z]`` layout: after the x
+    and y transforms one kernel (``lsr_cross_correlate_z_c64``) does the forward z transform, the
+    product and the inverse z transform on LDS-resident columns.  Needs a z length that kernel takes
+    (5-smooth, <= 256: ``lsr_cross_correlate_z_supported``); callers fall back to
+    ``rfft3`` / cross power / ``irfft3`` otherwise.
+    """
+    import torch
+
+    if not available():
+        raise AxisFftError("hipFFT's C API is not loadable")
+    if volume.dim() != 3 or volume.dtype != torch.float32 or not volume.is_contiguous() or volume.device.type != "cuda":
+        raise ValueError("correlate_with_spectrum takes a contiguous float32 (Z, Y, X) tensor on a HIP device")
+    z, y, x = (int(v) for v in volume.shape)
+    xc = x // 2 + 1
+    if (tuple(ref_spectrum.shape) != (xc, y, z) or ref_spectrum.dtype != torch.complex64 or not ref_spectrum.is_contiguous()
+            or ref_spectrum.device != volume.device):
+        raise ValueError(f"the reference spectrum must be a contiguous complex64 {(xc, y, z)} tensor on {volume.device}")
+    if not _lib.call_value("lsr_cross_correlate_z_supported", z):
+        raise AxisFftError(f"z length {z} is not handled by lsr_cross_correlate_z_c64")
+    dev = volume.device
+    with torch.cuda.device(dev):
+        a = torch.empty((z, y, xc), dtype=torch.complex64, device=dev)
+        _exec(dev, _HIPFFT_R2C, x, z * y, volume.data_ptr(), a.data_ptr())
+        b = torch.empty((z, xc, y), dtype=torch.complex64, device=dev)
+        _transpose(a, b, z, y, xc, dev)                                   # [Z][Y][XC] -> [Z][XC][Y]
+        _exec(dev, _HIPFFT_C2C, y, z * xc, b.data_ptr(), b.data_ptr(), _FORWARD)
+        _lib.call("lsr_cross_correlate_z_c64", ref_spectrum.data_ptr(), b.data_ptr(), _twiddle_table(z, dev).data_ptr(),
+                  z, y, xc, _lib.stream_ptr(dev))
+        _exec(dev, _HIPFFT_C2C, y, z * xc, b.data_ptr(), b.data_ptr(), _BACKWARD)
         _transpose(b, a, z, xc, y, dev)                                   # [Z][XC][Y] -> [Z][Y][XC]
         del b
         out = torch.empty((z, y, x), dtype=torch.float32, device=dev)

@@ -76,3 +76,35 @@ def test_tracker_shifts_are_the_same_through_both_fft_routes():
     finally:
         d._axis_fft_ok[0] = True
         d.set_spectrum_cache_bytes(0)
+
+
+@pytest.mark.parametrize("shape", [(12, 32, 48), (9, 20, 15), (180, 70, 50), (90, 33, 36), (72, 64, 130), (256, 40, 24),
+                                   (2, 8, 8), (250, 31, 18)])
+def test_z_leg_in_one_kernel_equals_the_five_pass_route(shape):
+    """``correlate_with_spectrum`` (x and y transforms, then ``lsr_cross_correlate_z_c64``: forward z
+    transform, product with the reference spectrum, inverse z transform in LDS) against
+    ``irfft3(ref * conj(rfft3(mov)))`` and against ``torch.fft``: float32 FFT rounding, stated below.
+    z lengths with every radix (4, 2, 3, 5), ragged y tiles, one- and many-tile grids."""
+    if not fft3.available():
+        pytest.skip("hipFFT's C API is not loadable from this PyTorch")
+    assert _lib.call_value("lsr_cross_correlate_z_supported", shape[0]) == 1
+    g = torch.Generator(device=DEV).manual_seed(7)
+    ref = torch.rand(shape, device=DEV, generator=g) * 900 + 80
+    mov = torch.roll(ref, shifts=(1, -2, 3), dims=(0, 1, 2)) + torch.rand(shape, device=DEV, generator=g)
+    spec = fft3.rfft3(ref)
+    keep = spec.clone()
+    got = fft3.correlate_with_spectrum(spec, mov)
+    assert torch.equal(spec, keep)                                          # the cached spectrum is left intact
+    prod = spec * torch.conj(fft3.rfft3(mov))
+    five = fft3.irfft3(prod.contiguous(), shape)
+    n = float(np.prod(shape))
+    want = torch.fft.irfftn(torch.fft.rfftn(ref) * torch.conj(torch.fft.rfftn(mov)), s=shape) * n
+    scale = float(want.abs().max())
+    assert float((got - five).abs().max()) < 4e-6 * scale
+    assert float((got - want).abs().max()) < 4e-6 * scale
+    assert int(torch.argmax(got)) == int(torch.argmax(want))
+
+
+def test_z_lengths_the_one_kernel_route_declines():
+    for n, ok in ((1, 0), (2, 1), (7, 0), (171, 0), (180, 1), (256, 1), (270, 0), (243, 1), (250, 1)):
+        assert _lib.call_value("lsr_cross_correlate_z_supported", n) == ok, n
