@@ -413,6 +413,24 @@ int lsr_transpose_last2_c64(const float* src, float* dst, int64_t A, int64_t B, 
 int lsr_cross_correlate_z_supported(int64_t n);
 int lsr_cross_correlate_z_c64(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC,
                               lsr_stream_t stream);
+/*
+ * The x leg of the same cross-correlation, each way in one kernel (csrc/rfft_rows.hip).  Row lengths X that are
+ * multiples of 4 with X / 2 5-smooth and <= 2048 (lsr_rfft_rows_supported); tw_half[k] = exp(-2 pi i k / (X/2)),
+ * k < X / 4, and tw_x[k] = exp(-2 pi i k / X), k <= X / 2 (complex64, device).
+ * lsr_rfft_rows_t_c64: spec[z][k][y] = sum_n v(z, y, n) exp(-2 pi i k n / X), k <= X / 2, where v is `in`
+ *   ((Zi, Yi, Xi) float32) reflect-padded / centre-cropped to the grid (Z, Y, X) the way _match_shape does
+ *   (tracking.py:266-306: pad left = d // 2, crop start = d // 2) -- the padded volume is never written.
+ *   Replaces _match_shape + the real-to-complex transform along x + the transpose to y-contiguous.
+ * lsr_irfft_rows_peak: the flat index of max |corr| in fftshift order (ties: the smallest), corr = the
+ *   unnormalised complex-to-real inverse along x of spec ([Z][X/2+1][Y]); corr is never written.  `scratch`:
+ *   lsr_rfft_rows_scratch_bytes(Z, Y) bytes.  Replaces the transpose back, irfft along x, fftshift(abs()), argmax.
+ */
+int lsr_rfft_rows_supported(int64_t n);
+int64_t lsr_rfft_rows_scratch_bytes(int64_t Z, int64_t Y);
+int lsr_rfft_rows_t_c64(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* spec, int64_t Z, int64_t Y,
+                        int64_t X, const float* tw_half, const float* tw_x, lsr_stream_t stream);
+int lsr_irfft_rows_peak(const float* spec, int64_t Z, int64_t Y, int64_t X, const float* tw_half, const float* tw_x,
+                        long long* out_index, void* scratch, lsr_stream_t stream);
 /* b <- a * conj(b): the same product written over the second operand, so that `a` (the spectrum of
  * a reference volume that is compared against many timepoints) can be kept. */
 int lsr_cross_power_into_c64(const float* a, float* b, int64_t n, lsr_stream_t stream);

@@ -1,0 +1,304 @@
+// The x leg of the tracker's cross-correlation, both ways, as one kernel each (reference
+// shrimpy/dynatrack/tracking.py:266-378).  With rocFFT the forward x leg was four passes over the volume --
+// reflect-pad / crop to the FFT grid (_match_shape), the half-length complex transform, the real-to-complex
+// post pass, the transpose to y-contiguous -- and the way back four more: transpose, complex-to-real pre
+// pass, transform, peak search.  A row of the grid (2304 reals = 1152 complex) fits in LDS eight times
+// over, so here a workgroup takes eight neighbouring rows (fixed z, eight y) and
+//
+//   lsr_rfft_rows_t_c64:   gathers them from the un-padded source with the reflect / crop index map, packs
+//                          (even, odd) samples as complex, transforms in LDS (fft_lds.hpp), applies the
+//                          real-to-complex post step and stores X[k] TRANSPOSED, out[z][k][y]: 64-byte runs;
+//   lsr_irfft_rows_peak:   loads such a tile, applies the complex-to-real pre step, transforms back, and
+//                          reduces |corr| with its fftshift-ed flat index to one candidate per workgroup --
+//                          the correlation volume is never written.
+//
+// Unnormalised, like hipFFT: forward X[k] = sum_n x[n] exp(-2 pi i k n / X); the inverse carries a factor
+// 2 X / 2 = X (irrelevant to an argmax, and the same for every voxel).
+// Lengths: X a multiple of 4 with X / 2 5-smooth and <= 2048 (lsr_rfft_rows_supported); others keep rocFFT.
+
+#include "fft_lds.hpp"
+
+namespace {
+
+using namespace lsr_fft;
+
+constexpr int kThreads = 512;
+constexpr int kRows = 8;                      // y rows per workgroup: 64-byte runs in the transposed layout
+constexpr int kPerRow = kThreads / kRows;     // 64 threads share a row's butterflies
+constexpr int kMaxM = 2048;                   // longest half-length: 8 * 2049 * 8 B + 8 KB of twiddles = 139 KB of LDS
+
+struct RowsArgs {
+  const float* in;        // forward: un-padded source [Zi][Yi][Xi]
+  int Zi, Yi, Xi;
+  float2* spec;           // [Z][XC][Y] (forward: written; inverse: read)
+  int Z, Y, X, M, XC;     // FFT grid, M = X / 2, XC = M + 1
+  const float2* tw_half;  // [M / 2]  exp(-2 pi i k / M)
+  const float2* tw_x;     // [M + 1]  exp(-2 pi i k / X)
+  Factors f;
+  float* pval;            // inverse: one candidate per workgroup
+  unsigned long long* pidx;
+};
+
+__device__ __forceinline__ int reflect_index(int i, int n) {
+  if (n == 1) return 0;
+  const int period = 2 * (n - 1);
+  i = i % period;
+  if (i < 0) i += period;
+  return i < n ? i : period - i;
+}
+// _match_shape (tracking.py:266-306): reflect-pad (left = d // 2) or centre-crop (start = d // 2), per axis
+__device__ __forceinline__ int match_index(int o, int ni, int no) {
+  if (no > ni) return reflect_index(o - (no - ni) / 2, ni);
+  return o + (ni - no) / 2;
+}
+
+struct Tile {
+  float2* buf;       // [kRows][pitch]
+  float2* tw;        // [M / 2]
+  int pitch;
+};
+
+__device__ __forceinline__ Tile carve(float2* smem, int M) {
+  Tile t;
+  t.pitch = M + 1;
+  t.buf = smem;
+  t.tw = smem + kRows * t.pitch;
+  return t;
+}
+
+// exp(-2 pi i k / M) from the half table: w^(k + M/2) = -w^k
+__device__ __forceinline__ float2 tw_m(const float2* tw, int half, int i) {
+  const bool hi = i >= half;
+  const float2 v = tw[hi ? i - half : i];
+  return hi ? float2{-v.x, -v.y} : v;
+}
+
+__global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
+  extern __shared__ float2 smem[];
+  const int M = p.M, half = M / 2;
+  const Tile t = carve(smem, M);
+  const int tid = threadIdx.x;
+  const int tiles_y = (p.Y + kRows - 1) / kRows;
+  const int z = blockIdx.x / tiles_y, y0 = (blockIdx.x - z * tiles_y) * kRows;
+  const int nrows = min(kRows, p.Y - y0);
+
+  for (int k = tid; k < half; k += kThreads) t.tw[k] = p.tw_half[k];
+  {  // gather: row r of the tile <- source row (match(z), match(y0 + r)), columns through match(x); (even, odd) packed
+    const int r = tid / kPerRow, lane = tid & (kPerRow - 1);
+    float2* row = t.buf + r * t.pitch;
+    if (r < nrows) {
+      const float* src = p.in + (static_cast<int64_t>(match_index(z, p.Zi, p.Z)) * p.Yi + match_index(y0 + r, p.Yi, p.Y)) * p.Xi;
+      const int shift = p.X > p.Xi ? -((p.X - p.Xi) / 2) : (p.Xi - p.X) / 2;   // source column of grid column 0 (before reflection)
+      for (int m = lane; m < M; m += kPerRow) {
+        const int x0 = 2 * m + shift, x1 = x0 + 1;
+        const bool inside = x0 >= 0 && x1 < p.Xi;
+        row[m] = float2{src[inside ? x0 : reflect_index(x0, p.Xi)], src[inside ? x1 : reflect_index(x1, p.Xi)]};
+      }
+    } else {
+      for (int m = lane; m < M; m += kPerRow) row[m] = float2{0.0f, 0.0f};
+    }
+  }
+  __syncthreads();
+
+  const float2* twl = t.tw;
+  transform<kMaxM, kPerRow>(t.buf + (tid / kPerRow) * t.pitch, M, p.f, [twl, half](int i) { return tw_m(twl, half, i); },
+                            tid & (kPerRow - 1));
+
+  // real-to-complex post step, stored transposed: X[k] = E[k] + w_X^k O[k],
+  //   E = (Z[k] + conj(Z[M - k])) / 2,  O = -i (Z[k] - conj(Z[M - k])) / 2,  Z[M] = Z[0]
+  const int r = tid & (kRows - 1), k0 = tid / kRows;
+  if (r < nrows) {
+    const float2* row = t.buf + r * t.pitch;
+    float2* out = p.spec + static_cast<int64_t>(z) * p.XC * p.Y + y0 + r;
+    for (int k = k0; k <= M; k += kThreads / kRows) {
+      const float2 a = row[k == M ? 0 : k], b = cconj(row[k == 0 ? 0 : M - k]);
+      const float2 e = float2{0.5f * (a.x + b.x), 0.5f * (a.y + b.y)};
+      const float2 o = mul_mi(float2{0.5f * (a.x - b.x), 0.5f * (a.y - b.y)});
+      out[static_cast<int64_t>(k) * p.Y] = cadd(e, cmul(p.tw_x[k], o));
+    }
+  }
+}
+
+__device__ __forceinline__ void peak_merge(float& v, unsigned long long& i, float v2, unsigned long long i2) {
+  if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+}
+
+__global__ __launch_bounds__(kThreads) void irfft_rows_peak_kernel(RowsArgs p) {
+  extern __shared__ float2 smem[];
+  const int M = p.M, half = M / 2;
+  const Tile t = carve(smem, M);
+  // the reduction at the end reuses the tile's memory (6 KB of static LDS would cost the second workgroup per CU)
+  unsigned long long* const s_i = reinterpret_cast<unsigned long long*>(smem);
+  float* const s_v = reinterpret_cast<float*>(smem + kThreads);
+  const int tid = threadIdx.x;
+  const int tiles_y = (p.Y + kRows - 1) / kRows;
+  const int z = blockIdx.x / tiles_y, y0 = (blockIdx.x - z * tiles_y) * kRows;
+  const int nrows = min(kRows, p.Y - y0);
+
+  for (int k = tid; k < half; k += kThreads) t.tw[k] = p.tw_half[k];
+  {  // tile of the spectrum: X[k], k = 0 .. M, for eight neighbouring y (64-byte runs)
+    const int r = tid & (kRows - 1), k0 = tid / kRows;
+    float2* row = t.buf + r * t.pitch;
+    const float2* in = p.spec + static_cast<int64_t>(z) * p.XC * p.Y + y0 + r;
+    for (int k = k0; k <= M; k += kThreads / kRows)
+      row[k] = r < nrows ? in[static_cast<int64_t>(k) * p.Y] : float2{0.0f, 0.0f};
+  }
+  __syncthreads();
+  {  // complex-to-real pre step, pairs (m, M - m) by one thread; conjugated on the way for the conj-FFT-conj inverse:
+     //   Zt[m] = (X[m] + conj(X[M - m])) + i conj(w_X^m) (X[m] - conj(X[M - m]))        (= 2 x the packed signal's spectrum)
+    const int r = tid / kPerRow, lane = tid & (kPerRow - 1);
+    float2* row = t.buf + r * t.pitch;
+    for (int m = lane; m <= half; m += kPerRow) {
+      const int mm = M - m;                       // partner; m == 0 pairs with X[M], m == M / 2 with itself
+      const float2 xa = row[m], xb = row[mm];
+      const float2 wa = cconj(p.tw_x[m]), wb = cconj(p.tw_x[mm]);
+      const float2 za = cadd(cadd(xa, cconj(xb)), mul_i(cmul(wa, csub(xa, cconj(xb)))));
+      const float2 zb = cadd(cadd(xb, cconj(xa)), mul_i(cmul(wb, csub(xb, cconj(xa)))));
+      row[m] = cconj(za);
+      if (m != 0 && mm != m) row[mm] = cconj(zb);
+    }
+  }
+  __syncthreads();
+
+  const float2* twl = t.tw;
+  transform<kMaxM, kPerRow>(t.buf + (tid / kPerRow) * t.pitch, M, p.f, [twl, half](int i) { return tw_m(twl, half, i); },
+                            tid & (kPerRow - 1));
+
+  // conj(FFT(conj(Zt)))[m] = x[2m] + i x[2m + 1]; the candidate of every value is its fftshift-ed flat index
+  float best = -1.0f;
+  unsigned long long best_i = ~0ull;
+  {
+    const int r = tid / kPerRow, lane = tid & (kPerRow - 1);
+    if (r < nrows) {
+      const float2* row = t.buf + r * t.pitch;
+      const int y = y0 + r;
+      const int zs = (z + p.Z / 2) % p.Z, ys = (y + p.Y / 2) % p.Y;
+      const unsigned long long base = (static_cast<unsigned long long>(zs) * p.Y + ys) * p.X;
+      for (int m = lane; m < M; m += kPerRow) {
+        const float2 v = row[m];
+        const float a = fabsf(v.x), b = fabsf(v.y);      // conj does not change the moduli
+        if (a >= best) peak_merge(best, best_i, a, base + static_cast<unsigned>((2 * m + p.X / 2) % p.X));
+        if (b >= best) peak_merge(best, best_i, b, base + static_cast<unsigned>((2 * m + 1 + p.X / 2) % p.X));
+      }
+    }
+  }
+  __syncthreads();            // every row has been scanned: the tile's memory is free
+  s_v[tid] = best;
+  s_i[tid] = best_i;
+  __syncthreads();
+  for (int w = kThreads / 2; w > 0; w >>= 1) {
+    if (tid < w) peak_merge(s_v[tid], s_i[tid], s_v[tid + w], s_i[tid + w]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    p.pval[blockIdx.x] = s_v[0];
+    p.pidx[blockIdx.x] = s_i[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_peak_final_kernel(const float* __restrict__ pval,
+                                                             const unsigned long long* __restrict__ pidx, int64_t nb,
+                                                             long long* __restrict__ out) {
+  __shared__ float s_v[256];
+  __shared__ unsigned long long s_i[256];
+  float best = -1.0f;
+  unsigned long long best_i = ~0ull;
+  for (int64_t i = threadIdx.x; i < nb; i += 256) peak_merge(best, best_i, pval[i], pidx[i]);
+  s_v[threadIdx.x] = best;
+  s_i[threadIdx.x] = best_i;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w) peak_merge(s_v[threadIdx.x], s_i[threadIdx.x], s_v[threadIdx.x + w], s_i[threadIdx.x + w]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = static_cast<long long>(s_i[0]);
+}
+
+int fill(RowsArgs& p, int64_t Z, int64_t Y, int64_t X, const float* tw_half, const float* tw_x) {
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "grid (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
+              (long long)X);
+  LSR_REQUIRE(lsr_rfft_rows_supported(X), LSR_E_UNSUPPORTED,
+              "row length %lld: a multiple of 4 whose half is 5-smooth and at most %d", (long long)X, kMaxM);
+  LSR_REQUIRE_PTR(tw_half);
+  LSR_REQUIRE_PTR(tw_x);
+  const int64_t lim = int64_t(1) << 30;
+  LSR_REQUIRE(Z < lim && Y < lim, LSR_E_UNSUPPORTED, "a dimension exceeds 2^30");
+  p.Z = static_cast<int>(Z); p.Y = static_cast<int>(Y); p.X = static_cast<int>(X);
+  p.M = p.X / 2; p.XC = p.M + 1;
+  p.tw_half = reinterpret_cast<const float2*>(tw_half);
+  p.tw_x = reinterpret_cast<const float2*>(tw_x);
+  LSR_REQUIRE(factorize(p.M, &p.f), LSR_E_UNSUPPORTED, "row length %lld has too many factors", (long long)X);
+  LSR_REQUIRE(Z * lsr::ceil_div(Y, kRows) < (int64_t(1) << 31), LSR_E_SHAPE, "grid of workgroups is too large");
+  return LSR_OK;
+}
+
+// the tile and the half twiddle table; at least the 6 KB the final reduction of the inverse kernel lays over it
+size_t lds_bytes(int M) {
+  const size_t tile = (static_cast<size_t>(kRows) * (M + 1) + M / 2) * sizeof(float2);
+  const size_t reduction = static_cast<size_t>(kThreads) * (sizeof(unsigned long long) + sizeof(float));
+  return tile > reduction ? tile : reduction;
+}
+
+template <typename K>
+void allow_lds(K kernel) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds_bytes(kMaxM)));
+}
+
+}  // namespace
+
+// 1 when the row kernels take a transform of length n along x (n % 4 == 0, n / 2 5-smooth and <= 2048)
+extern "C" int lsr_rfft_rows_supported(int64_t n) {
+  if (n < 8 || n % 4 != 0 || n / 2 > kMaxM) return 0;
+  int64_t m = n / 2;
+  for (int f : {2, 3, 5})
+    while (m % f == 0) m /= f;
+  return m == 1;
+}
+
+extern "C" int64_t lsr_rfft_rows_scratch_bytes(int64_t Z, int64_t Y) {
+  return Z * lsr::ceil_div(Y, kRows) * 16;   // one (value, index) candidate per workgroup of lsr_irfft_rows_peak
+}
+
+extern "C" int lsr_rfft_rows_t_c64(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* spec, int64_t Z, int64_t Y,
+                                   int64_t X, const float* tw_half, const float* tw_x, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(spec);
+  LSR_REQUIRE(Zi > 0 && Yi > 0 && Xi > 0, LSR_E_SHAPE, "source shape (%lld,%lld,%lld) must be positive", (long long)Zi,
+              (long long)Yi, (long long)Xi);
+  const int64_t lim = int64_t(1) << 30;
+  LSR_REQUIRE(Zi < lim && Yi < lim && Xi < lim, LSR_E_UNSUPPORTED, "a dimension exceeds 2^30");
+  // F.pad "reflect" needs pad < size on every padded axis (torch raises otherwise)
+  LSR_REQUIRE((Z <= Zi || Z - Zi < 2 * Zi - 1) && (Y <= Yi || Y - Yi < 2 * Yi - 1) && (X <= Xi || X - Xi < 2 * Xi - 1),
+              LSR_E_ARG, "reflect padding from (%lld,%lld,%lld) to (%lld,%lld,%lld) exceeds the source size", (long long)Zi,
+              (long long)Yi, (long long)Xi, (long long)Z, (long long)Y, (long long)X);
+  RowsArgs p{};
+  if (int rc = fill(p, Z, Y, X, tw_half, tw_x)) return rc;
+  p.in = in;
+  p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
+  p.spec = reinterpret_cast<float2*>(spec);
+  static bool once = false;
+  if (!once) { allow_lds(rfft_rows_kernel); once = true; }
+  const unsigned blocks = static_cast<unsigned>(Z * lsr::ceil_div(Y, kRows));
+  hipLaunchKernelGGL(rfft_rows_kernel, dim3(blocks), dim3(kThreads), lds_bytes(p.M), lsr::as_stream(stream), p);
+  return lsr::launch_status("lsr_rfft_rows_t_c64");
+}
+
+extern "C" int lsr_irfft_rows_peak(const float* spec, int64_t Z, int64_t Y, int64_t X, const float* tw_half,
+                                   const float* tw_x, long long* out_index, void* scratch, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(spec);
+  LSR_REQUIRE_PTR(out_index);
+  LSR_REQUIRE_PTR(scratch);
+  RowsArgs p{};
+  if (int rc = fill(p, Z, Y, X, tw_half, tw_x)) return rc;
+  p.spec = const_cast<float2*>(reinterpret_cast<const float2*>(spec));
+  const int64_t nb = Z * lsr::ceil_div(Y, kRows);
+  p.pidx = static_cast<unsigned long long*>(scratch);
+  p.pval = reinterpret_cast<float*>(static_cast<char*>(scratch) + 8 * nb);
+  static bool once = false;
+  if (!once) { allow_lds(irfft_rows_peak_kernel); once = true; }
+  hipStream_t s = lsr::as_stream(stream);
+  hipLaunchKernelGGL(irfft_rows_peak_kernel, dim3(static_cast<unsigned>(nb)), dim3(kThreads), lds_bytes(p.M), s, p);
+  hipLaunchKernelGGL(rows_peak_final_kernel, dim3(1), dim3(256), 0, s, p.pval, p.pidx, nb, out_index);
+  return lsr::launch_status("lsr_irfft_rows_peak");
+}

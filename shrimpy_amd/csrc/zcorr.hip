@@ -15,126 +15,27 @@
 // out = Z * IFFT_z( F1 * conj( FFT_z(g) ) ), unnormalised like the rest of fft3 (the consumer takes an
 // argmax).  The inverse is done with the forward machinery: IFFT(v) = conj(FFT(conj(v))) / Z.
 
-#include "common.hpp"
+#include "fft_lds.hpp"
 
 #include <cstdlib>
 
 namespace {
 
+using namespace lsr_fft;
+
 constexpr int kThreads = 256;
 constexpr int kCols = 16;          // y columns per workgroup: 128-byte runs of complex64 (32 columns x 512 threads: 3.50 against 3.32 ms)
 constexpr int kPerCol = kThreads / kCols;   // threads that share a column's butterflies
 constexpr int kMaxN = 256;         // longest z transform: kCols * (kMaxN + 1) * 8 bytes = 33 KB of LDS
-constexpr int kMaxFactors = 8;
 
 struct ZcorrArgs {
   const float2* f1;      // [XC][Y][N]  reference spectrum, fully transformed
   float2* g;             // [N][XC][Y]  moving spectrum after the x and y transforms; overwritten
   const float2* tw;      // [N] exp(-2 pi i k / N)
   int N, Y, XC;
-  int n_factors;
-  int factors[kMaxFactors];
-  float inv_stride[kMaxFactors];   // 1 / s of each pass (s = product of the radices before it)
+  Factors f;
   float inv_n;                     // 1 / N
 };
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return float2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return float2{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return float2{a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ float2 cconj(float2 a) { return float2{a.x, -a.y}; }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return float2{a.y, -a.x}; }   // a * (-i)
-
-// DFT of R points, forward sign
-template <int R>
-__device__ __forceinline__ void dft(float2 (&a)[R]) {
-  if constexpr (R == 2) {
-    const float2 t = a[0];
-    a[0] = cadd(t, a[1]);
-    a[1] = csub(t, a[1]);
-  } else if constexpr (R == 3) {
-    constexpr float c = -0.5f, s = -0.86602540378443864676f;   // exp(-2 pi i / 3) = c + i s
-    const float2 t1 = cadd(a[1], a[2]), t2 = csub(a[1], a[2]);
-    const float2 m = float2{a[0].x + c * t1.x, a[0].y + c * t1.y};
-    const float2 r = float2{-s * t2.y, s * t2.x};               // i s t2
-    a[0] = cadd(a[0], t1);
-    a[1] = cadd(m, r);
-    a[2] = csub(m, r);
-  } else if constexpr (R == 4) {
-    const float2 s0 = cadd(a[0], a[2]), d0 = csub(a[0], a[2]);
-    const float2 s1 = cadd(a[1], a[3]), d1 = mul_mi(csub(a[1], a[3]));
-    a[0] = cadd(s0, s1);
-    a[1] = cadd(d0, d1);
-    a[2] = csub(s0, s1);
-    a[3] = csub(d0, d1);
-  } else {
-    static_assert(R == 5, "radix");
-    constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;    // cos(2 pi k / 5)
-    constexpr float s1 = -0.95105651629515357212f, s2 = -0.58778525229247312917f;   // -sin(2 pi k / 5)
-    const float2 t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]);
-    const float2 t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
-    const float2 m1 = float2{a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y};
-    const float2 m2 = float2{a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y};
-    // i * (s1 t3 + s2 t4), i * (s2 t3 - s1 t4)
-    const float2 u1 = float2{-(s1 * t3.y + s2 * t4.y), s1 * t3.x + s2 * t4.x};
-    const float2 u2 = float2{-(s2 * t3.y - s1 * t4.y), s2 * t3.x - s1 * t4.x};
-    a[0] = cadd(a[0], cadd(t1, t2));
-    a[1] = cadd(m1, u1);
-    a[4] = csub(m1, u1);
-    a[2] = cadd(m2, u2);
-    a[3] = csub(m2, u2);
-  }
-}
-
-// One Stockham pass (decimation in frequency) over every column of the tile, in place: all inputs of a
-// thread's butterflies are read into registers before the barrier, all outputs written after it.
-//   x[q + s (p + m k)]  ->  y[q + s (R p + j)] = (sum_k x_k w_R^{jk}) * w_n^{p j},   n = R m, 0 <= p < m, 0 <= q < s
-// Sixteen threads share a column: thread t of it takes butterflies t, t + 16, ...
-template <int R>
-__device__ __forceinline__ void stockham_pass(float2* col, int N, int n, int s, float inv_s, const float2* tw, int t) {
-  const int m = n / R;
-  const int per_col = N / R;                       // butterflies per column (m * s)
-  constexpr int kMaxBf = (kMaxN / R + kPerCol - 1) / kPerCol;
-  float2 a[kMaxBf][R];
-#pragma unroll
-  for (int i = 0; i < kMaxBf; ++i) {
-    const int r = t + i * kPerCol;
-    if (r < per_col) {
-      const int p = static_cast<int>((static_cast<float>(r) + 0.5f) * inv_s), q = r - p * s;   // r / s, r % s (r < 128)
-      const float2* x = col + q + s * p;
-#pragma unroll
-      for (int k = 0; k < R; ++k) a[i][k] = x[s * m * k];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < kMaxBf; ++i) {
-    const int r = t + i * kPerCol;
-    if (r < per_col) {
-      const int p = static_cast<int>((static_cast<float>(r) + 0.5f) * inv_s), q = r - p * s;
-      dft<R>(a[i]);
-      float2* y = col + q + s * R * p;
-      y[0] = a[i][0];
-      const int step = p * s;                       // w_n^p = w_N^(p s); step * j < N
-#pragma unroll
-      for (int j = 1; j < R; ++j) y[s * j] = cmul(a[i][j], tw[step * j]);
-    }
-  }
-  __syncthreads();
-}
-
-__device__ __forceinline__ void transform(float2* col, const ZcorrArgs& p, const float2* tw, int t) {
-  int n = p.N, s = 1;
-  for (int f = 0; f < p.n_factors; ++f) {
-    const int r = p.factors[f];
-    const float inv_s = p.inv_stride[f];
-    if (r == 4) stockham_pass<4>(col, p.N, n, s, inv_s, tw, t);
-    else if (r == 2) stockham_pass<2>(col, p.N, n, s, inv_s, tw, t);
-    else if (r == 3) stockham_pass<3>(col, p.N, n, s, inv_s, tw, t);
-    else stockham_pass<5>(col, p.N, n, s, inv_s, tw, t);
-    n /= r;
-    s *= r;
-  }
-}
 
 __global__ __launch_bounds__(kThreads) void zcorr_kernel(ZcorrArgs p) {
   extern __shared__ float2 smem[];
@@ -162,7 +63,7 @@ __global__ __launch_bounds__(kThreads) void zcorr_kernel(ZcorrArgs p) {
   // (requesting the reference's values before the first transform and holding them in registers was tried:
   // 153 VGPRs, one workgroup per CU, 6.4 ms instead of 3.5)
   for (int round = 0; round < 2; ++round) {
-    transform(my_col, p, tw, t);
+    transform<kMaxN, kPerCol>(my_col, N, p.f, [tw](int i) { return tw[i]; }, t);
     if (round == 0) {
       for (int i = tid; i < ncols * N; i += kThreads) {
         const int col = static_cast<int>((static_cast<float>(i) + 0.5f) * p.inv_n), k = i - col * N;
@@ -204,12 +105,7 @@ extern "C" int lsr_cross_correlate_z_c64(const float* f1, float* g, const float*
   p.g = reinterpret_cast<float2*>(g);
   p.tw = reinterpret_cast<const float2*>(twiddles);
   p.N = static_cast<int>(N); p.Y = static_cast<int>(Y); p.XC = static_cast<int>(XC);
-  // radix-4 passes first, then what is left of the twos, threes and fives
-  int n = p.N, nf = 0;
-  while (n % 4 == 0 && nf < kMaxFactors) { p.factors[nf++] = 4; n /= 4; }
-  for (int f : {2, 3, 5})
-    while (n % f == 0 && nf < kMaxFactors) { p.factors[nf++] = f; n /= f; }
-  LSR_REQUIRE(n == 1, LSR_E_UNSUPPORTED, "z length %lld has more than %d factors", (long long)N, kMaxFactors);
+  LSR_REQUIRE(factorize(N, &p.f), LSR_E_UNSUPPORTED, "z length %lld has more than %d factors", (long long)N, kMaxFactors);
   if (const char* e = std::getenv("LSR_ZCORR_ORDER")) {   // measurement override: the radices in another order, e.g. "5,3,3,4"
     int f[kMaxFactors], k = 0;
     long long prod = 1;
@@ -222,14 +118,13 @@ extern "C" int lsr_cross_correlate_z_c64(const float* f1, float* g, const float*
       if (*c == ',') ++c;
     }
     if (k > 0 && prod == N) {
-      nf = k;
-      for (int i = 0; i < k; ++i) p.factors[i] = f[i];
+      p.f.n = k;
+      for (int i = 0, stride = 1; i < k; ++i) {
+        p.f.radix[i] = f[i];
+        p.f.inv_stride[i] = 1.0f / static_cast<float>(stride);
+        stride *= f[i];
+      }
     }
-  }
-  p.n_factors = nf;
-  for (int f = 0, stride = 1; f < nf; ++f) {
-    p.inv_stride[f] = 1.0f / static_cast<float>(stride);
-    stride *= p.factors[f];
   }
   p.inv_n = 1.0f / static_cast<float>(p.N);
   const int64_t blocks = XC * lsr::ceil_div(Y, kCols);

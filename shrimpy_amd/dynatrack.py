@@ -443,20 +443,40 @@ def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0) -> tuple[int
     logger.debug("phase cross corr: fft shape %s for arrays %s and %s (max_shift=%.2f)", shape,
                  tuple(ref_t.shape), tuple(mov_t.shape), maximum_shift)
     kind = "rfft3" if (_axis_fft_ok[0] and fft3.available() and min(shape) >= 2) else "rfftn"
+    peak_index = None
     try:
-        corr = _cross_correlation(ref_t, ref_t is ref_img, mov_t, shape, kind)
+        if kind == "rfft3" and fft3.rows_supported(shape):
+            peak_index = _correlation_peak_rows(ref_t, ref_t is ref_img, mov_t, shape)
+        else:
+            corr = _cross_correlation(ref_t, ref_t is ref_img, mov_t, shape, kind)
     except fft3.AxisFftError as exc:
         logger.warning("axis-by-axis FFT unavailable (%s): using torch.fft", exc)
         _axis_fft_ok[0] = False
+        peak_index = None
         corr = _cross_correlation(ref_t, ref_t is ref_img, mov_t, shape, "rfftn")
-    with torch.cuda.device(corr.device):
-        peak_index = torch.empty((1,), dtype=torch.int64, device=corr.device)
-        _lib.call("lsr_peak_abs_shifted_f32", corr.data_ptr(), *shape, peak_index.data_ptr(),
-                  _scratch(corr.device).data_ptr(), _lib.stream_ptr(corr.device))
+    if peak_index is None:
+        with torch.cuda.device(corr.device):
+            peak_index = torch.empty((1,), dtype=torch.int64, device=corr.device)
+            _lib.call("lsr_peak_abs_shifted_f32", corr.data_ptr(), *shape, peak_index.data_ptr(),
+                      _scratch(corr.device).data_ptr(), _lib.stream_ptr(corr.device))
     peak = np.unravel_index(int(peak_index.item()), shape)
     result = tuple(int(s // 2) - int(p) for s, p in zip(shape, peak))
-    logger.debug("phase cross corr: peak at %s (device=%s)", result, corr.device)
+    logger.debug("phase cross corr: peak at %s (device=%s)", result, ref_t.device)
     return result
+
+
+def _correlation_peak_rows(ref_t, ref_is_callers, mov_t, shape):
+    """The whole correlation with this package's kernels along x and z (``fft3.correlation_peak``): the flat
+    index of the peak; the reference's spectrum is cached under the same key as the other axis-by-axis route."""
+    from . import fft3
+
+    cacheable = ref_is_callers and _spectra.max_bytes > 0
+    fimg1 = _spectra.get(ref_t, ("rfft3", shape)) if cacheable else None
+    if fimg1 is None:
+        fimg1 = fft3.spectrum_of(ref_t, shape)
+        if cacheable:
+            _spectra.put(ref_t, ("rfft3", shape), fimg1)
+    return fft3.correlation_peak(fimg1, mov_t, shape)
 
 
 def _cross_correlation(ref_t, ref_is_callers, mov_t, shape, kind: str):

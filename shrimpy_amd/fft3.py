@@ -12,7 +12,10 @@ kernel (``lsr_transpose_last2_c64``).  The spectrum stays in the transposed layo
 (``XC = X // 2 + 1``): the cross power is element-wise and does not care, and the way back undoes it.
 No normalisation either way: the consumer takes an argmax.
 
-The FFTs remain library calls (rocFFT), as the build's rules ask for plain library transforms.
+The long y axis stays a library call (rocFFT).  The short z leg (``lsr_cross_correlate_z_c64``) and the
+x leg each way (``lsr_rfft_rows_t_c64``, ``lsr_irfft_rows_peak``) are this package's own LDS-resident
+transforms, fused with the steps around them -- see :func:`correlation_peak`; :func:`rfft3` /
+:func:`irfft3` / :func:`correlate_with_spectrum` are the routes for grids those kernels do not take.
 """
 
 from __future__ import annotations
@@ -22,7 +25,8 @@ import os
 
 from . import _lib
 
-__all__ = ["available", "rfft3", "irfft3", "correlate_with_spectrum", "AxisFftError"]
+__all__ = ["available", "rfft3", "irfft3", "correlate_with_spectrum", "rows_supported", "spectrum_of", "correlation_peak",
+           "AxisFftError"]
 
 _HIPFFT_R2C, _HIPFFT_C2R, _HIPFFT_C2C = 0x2A, 0x2C, 0x29
 _FORWARD, _BACKWARD = -1, 1
@@ -251,3 +255,108 @@ def correlate_with_spectrum(ref_spectrum, volume):
         out = torch.empty((z, y, x), dtype=torch.float32, device=dev)
         _exec(dev, _HIPFFT_C2R, x, z * y, a.data_ptr(), out.data_ptr())
     return out
+
+
+# ---- the x leg in this package's own kernels (csrc/rfft_rows.hip) ------------------------------------------
+
+_row_tables: dict = {}
+
+
+def _row_twiddles(x: int, device):
+    """``(exp(-2 pi i k / (x/2)), k < x/4)`` and ``(exp(-2 pi i k / x), k <= x/2)``, complex64 on ``device``."""
+    import numpy as np
+    import torch
+
+    key = (int(x), device.index)
+    t = _row_tables.get(key)
+    if t is None:
+        if len(_row_tables) >= 16:
+            _row_tables.pop(next(iter(_row_tables)))
+        m = x // 2
+        half = np.exp(-2j * np.pi * np.arange(m // 2, dtype=np.float64) / m).astype(np.complex64)
+        full = np.exp(-2j * np.pi * np.arange(m + 1, dtype=np.float64) / x).astype(np.complex64)
+        t = _row_tables[key] = (torch.as_tensor(half, device=device), torch.as_tensor(full, device=device))
+    return t
+
+
+def rows_supported(shape_zyx) -> bool:
+    """The row kernels take this FFT grid (x a multiple of 4, x / 2 5-smooth and <= 2048) and the z-leg
+    kernel its z length: the whole correlation then runs without rocFFT along x and z."""
+    z, _, x = (int(v) for v in shape_zyx)
+    return (available() and bool(_lib.call_value("lsr_rfft_rows_supported", x))
+            and bool(_lib.call_value("lsr_cross_correlate_z_supported", z)))
+
+
+def _rows_forward(source, shape_zyx):
+    """``[Z][XC][Y]`` complex64: ``source`` matched to the grid (reflect pad / centre crop, never written),
+    transformed along x and along y."""
+    import torch
+
+    z, y, x = (int(v) for v in shape_zyx)
+    xc = x // 2 + 1
+    dev = source.device
+    half, full = _row_twiddles(x, dev)
+    b = torch.empty((z, xc, y), dtype=torch.complex64, device=dev)
+    zi, yi, xi = (int(v) for v in source.shape)
+    _lib.call("lsr_rfft_rows_t_c64", source.data_ptr(), zi, yi, xi, b.data_ptr(), z, y, x, half.data_ptr(), full.data_ptr(),
+              _lib.stream_ptr(dev))
+    _exec(dev, _HIPFFT_C2C, y, z * xc, b.data_ptr(), b.data_ptr(), _FORWARD)
+    return b
+
+
+def _check_source(source):
+    import torch
+
+    if source.dim() != 3 or source.dtype != torch.float32 or not source.is_contiguous() or source.device.type != "cuda":
+        raise ValueError("a contiguous float32 (Z, Y, X) tensor on a HIP device is required")
+
+
+def spectrum_of(source, shape_zyx):
+    """:func:`rfft3` of ``source`` reflect-padded / centre-cropped to ``shape_zyx`` (``_match_shape``), with the
+    padding, the x transform and the first transpose in one kernel: ``(X // 2 + 1, Y, Z)`` complex64."""
+    import torch
+
+    _check_source(source)
+    if not rows_supported(shape_zyx):
+        raise AxisFftError(f"FFT grid {tuple(shape_zyx)} is not handled by the row kernels")
+    z, y, x = (int(v) for v in shape_zyx)
+    xc = x // 2 + 1
+    dev = source.device
+    with torch.cuda.device(dev):
+        b = _rows_forward(source, shape_zyx)
+        a = torch.empty((xc, y, z), dtype=torch.complex64, device=dev)
+        _transpose(b, a, 1, z, xc * y, dev)                               # [Z][XC Y] -> [XC Y][Z]
+        del b
+        _exec(dev, _HIPFFT_C2C, z, xc * y, a.data_ptr(), a.data_ptr(), _FORWARD)
+    return a
+
+
+def correlation_peak(ref_spectrum, source, shape_zyx):
+    """Flat index (a one-element int64 device tensor) of ``argmax(fftshift(|corr|))``, ``corr`` = the
+    cross-correlation on the FFT grid ``shape_zyx`` of the volume behind ``ref_spectrum`` (a
+    :func:`spectrum_of` / :func:`rfft3` result, left intact) with ``source`` matched to the grid.  Six
+    launches: rows forward (pad + x transform + transpose), y transform (rocFFT), z leg (transform, cross
+    power, inverse), y inverse (rocFFT), rows inverse + peak search; neither the padded volume, nor the
+    moving spectrum in z-contiguous layout, nor the correlation volume is ever written."""
+    import torch
+
+    _check_source(source)
+    if not rows_supported(shape_zyx):
+        raise AxisFftError(f"FFT grid {tuple(shape_zyx)} is not handled by the row kernels")
+    z, y, x = (int(v) for v in shape_zyx)
+    xc = x // 2 + 1
+    if (tuple(ref_spectrum.shape) != (xc, y, z) or ref_spectrum.dtype != torch.complex64 or not ref_spectrum.is_contiguous()
+            or ref_spectrum.device != source.device):
+        raise ValueError(f"the reference spectrum must be a contiguous complex64 {(xc, y, z)} tensor on {source.device}")
+    dev = source.device
+    half, full = _row_twiddles(x, dev)
+    with torch.cuda.device(dev):
+        b = _rows_forward(source, shape_zyx)
+        _lib.call("lsr_cross_correlate_z_c64", ref_spectrum.data_ptr(), b.data_ptr(), _twiddle_table(z, dev).data_ptr(),
+                  z, y, xc, _lib.stream_ptr(dev))
+        _exec(dev, _HIPFFT_C2C, y, z * xc, b.data_ptr(), b.data_ptr(), _BACKWARD)
+        scratch = torch.empty((z * (-(-y // 8)) * 16,), dtype=torch.uint8, device=dev)
+        peak = torch.empty((1,), dtype=torch.int64, device=dev)
+        _lib.call("lsr_irfft_rows_peak", b.data_ptr(), z, y, x, half.data_ptr(), full.data_ptr(), peak.data_ptr(),
+                  scratch.data_ptr(), _lib.stream_ptr(dev))
+    return peak

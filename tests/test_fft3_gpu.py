@@ -108,3 +108,44 @@ def test_z_leg_in_one_kernel_equals_the_five_pass_route(shape):
 def test_z_lengths_the_one_kernel_route_declines():
     for n, ok in ((1, 0), (2, 1), (7, 0), (171, 0), (180, 1), (256, 1), (270, 0), (243, 1), (250, 1)):
         assert _lib.call_value("lsr_cross_correlate_z_supported", n) == ok, n
+
+
+ROW_CASES = [((12, 32, 48), (12, 32, 48)), ((9, 20, 16), (10, 24, 20)), ((171, 60, 50), (180, 64, 60)),
+             ((8, 33, 130), (8, 36, 128)), ((30, 17, 2270), (30, 18, 2304)), ((5, 9, 8), (6, 10, 8)),
+             ((20, 70, 4000), (20, 72, 4096))]
+
+
+@pytest.mark.parametrize("src_shape,grid", ROW_CASES)
+def test_row_kernels_against_torch_fft(src_shape, grid):
+    """``spectrum_of`` (reflect pad / crop + x transform + transposes in this package's kernels) against
+    ``torch.fft.rfftn`` of the ``_match_shape``-d volume, and ``correlation_peak`` against the argmax of the
+    five-pass correlation: float32 FFT rounding (2e-6 of the largest coefficient), identical peak."""
+    if not fft3.rows_supported(grid):
+        pytest.skip("hipFFT's C API is not loadable from this PyTorch")
+    g = torch.Generator(device=DEV).manual_seed(3)
+    ref = torch.rand(src_shape, device=DEV, generator=g) * 900 + 80
+    matched = d._match_shape(ref, grid)
+    spec = fft3.spectrum_of(ref, grid)
+    want = torch.fft.rfftn(matched)
+    assert tuple(spec.shape) == tuple(reversed(want.shape))
+    assert float((spec.permute(2, 1, 0) - want).abs().max() / want.abs().max()) < 2e-6
+    mov = torch.roll(ref, shifts=(1, -2, 3), dims=(0, 1, 2)) + torch.rand(src_shape, device=DEV, generator=g)
+    idx = int(fft3.correlation_peak(spec, mov, grid).item())
+    corr = torch.fft.irfftn(want * torch.conj(torch.fft.rfftn(d._match_shape(mov, grid))), s=grid)
+    shifted = torch.fft.fftshift(corr.abs())
+    assert idx == int(torch.argmax(shifted))
+    # and through the tracker: same shift as the torch.fft route
+    try:
+        a = d._phase_cross_corr(ref, mov)
+        d._axis_fft_ok[0] = False
+        assert d._phase_cross_corr(ref, mov) == a
+    finally:
+        d._axis_fft_ok[0] = True
+
+
+def test_row_kernels_decline_what_they_do_not_take():
+    assert _lib.call_value("lsr_rfft_rows_supported", 2304) == 1 and _lib.call_value("lsr_rfft_rows_supported", 4096) == 1
+    for n in (6, 90, 2270, 4100, 8192, 2):          # not a multiple of 4 / half not 5-smooth / too long
+        assert _lib.call_value("lsr_rfft_rows_supported", n) == 0, n
+    assert fft3.rows_supported((180, 2048, 2304)) == fft3.available()
+    assert not fft3.rows_supported((171, 2048, 2304))            # z length 171 is not 5-smooth: five-pass z leg
