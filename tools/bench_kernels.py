@@ -186,7 +186,8 @@ def _estimators(args, torch, dev, g, oshape):
     assert shift in ((2, -5, 7), (-2, 5, -7)), shift
     from shrimpy_amd import fft3
 
-    for route, ok in (("axis by axis: hipFFT 1-D transforms + lsr_transpose_last2_c64", True), ("torch.fft.rfftn / irfftn", False)):
+    for route, ok in (("x and z legs in this package's kernels, rocFFT along y (fft3.correlation_peak)", True),
+                      ("torch.fft.rfftn / irfftn", False)):
         if ok and not fft3.available():
             continue
         d._axis_fft_ok[0] = ok
