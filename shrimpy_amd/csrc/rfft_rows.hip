@@ -104,6 +104,7 @@ __global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
   transform<kMaxM, kPerRow>(t.buf + (tid / kPerRow) * t.pitch, M, p.f, [twl, half](int i) { return tw_m(twl, half, i); },
                             tid & (kPerRow - 1));
 
+  __syncthreads();            // the post step below reads rows across wavefronts
   // real-to-complex post step, stored transposed: X[k] = E[k] + w_X^k O[k],
   //   E = (Z[k] + conj(Z[M - k])) / 2,  O = -i (Z[k] - conj(Z[M - k])) / 2,  Z[M] = Z[0]
   const int r = tid & (kRows - 1), k0 = tid / kRows;

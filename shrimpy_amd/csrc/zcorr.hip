@@ -62,17 +62,20 @@ __global__ __launch_bounds__(kThreads) void zcorr_kernel(ZcorrArgs p) {
   // round 0: G = FFT_z(g), then v = conj(F1 * conj(G)) = conj(F1) * G;  round 1: FFT(v) = conj(N * IFFT(F1 conj(G)))
   // (requesting the reference's values before the first transform and holding them in registers was tried:
   // 153 VGPRs, one workgroup per CU, 6.4 ms instead of 3.5)
+  // Every column belongs to the sixteen threads that transform it (one quarter of a wavefront): the product
+  // with the reference is done by those threads too, so nothing between the load and the store needs a barrier.
+  const int my = tid / kPerCol;
   for (int round = 0; round < 2; ++round) {
     transform<kMaxN, kPerCol>(my_col, N, p.f, [tw](int i) { return tw[i]; }, t);
     if (round == 0) {
-      for (int i = tid; i < ncols * N; i += kThreads) {
-        const int col = static_cast<int>((static_cast<float>(i) + 0.5f) * p.inv_n), k = i - col * N;
-        float2* e = buf + col * pitch + k;
-        *e = cmul(cconj(f1[i]), *e);
+      if (my < ncols) {
+        const float2* ref = f1 + static_cast<int64_t>(my) * N;
+        for (int k = t; k < N; k += kPerCol) my_col[k] = cmul(cconj(ref[k]), my_col[k]);
       }
-      __syncthreads();
+      sequence_sync();
     }
   }
+  __syncthreads();            // the store below takes columns across wavefronts
 
   float2* out = p.g + static_cast<int64_t>(xc) * p.Y + y0 + c;
   if (c < ncols)
