@@ -239,6 +239,24 @@ def dist_setup(args):
     return rank, world, device, shared, backend
 
 
+def self_launch(n: int) -> int:
+    """``python bench.py --gpus N`` from a bare shell: start ``torch.distributed.run`` with N ranks as a
+    CHILD process (nothing here has touched the GPU yet, and a GPU-initialised process must never be
+    replaced by exec on this pool), pass its output through and return its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def timed_steps(step, args, world, shared, device):
     """W untimed warm-ups, then exactly K steps between barrier + synchronize, max over ranks."""
     import torch
@@ -578,6 +596,8 @@ def main():
                          "volume around blosc-zstd chunks) instead of uncompressed chunks")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     # CPU baseline first (rank 0, N = 1 only), in spawned processes that never touch the GPU.
     cpu = None

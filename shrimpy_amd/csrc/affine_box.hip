@@ -390,26 +390,25 @@ bool pick_shape(int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane
   return found;
 }
 
+// false: the device refuses the LDS budget (message in lsr_last_error()); the caller runs the gather kernel
 template <bool F32, int TZ, int DEP>
-void launch_one(const BoxArgs& p, unsigned blocks, size_t lds_bytes, hipStream_t s) {
-  static bool attr_set = false;
+bool launch_one(const BoxArgs& p, unsigned blocks, size_t lds_bytes, hipStream_t s) {
+  static std::atomic<uint64_t> lds_allowed{0};
   auto kernel = affine_box_kernel<F32, TZ, DEP>;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              150 * 1024);
-    attr_set = true;
-  }
+  if (lsr::allow_dynamic_lds(reinterpret_cast<const void*>(kernel), 150 * 1024, lds_allowed, "affine_box_kernel") != LSR_OK)
+    return false;
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds_bytes, s, p);
+  return true;
 }
 
 template <bool F32, int TZ>
-void launch_shape(const BoxArgs& p, unsigned blocks, size_t lds_bytes, hipStream_t s) {
+bool launch_shape(const BoxArgs& p, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   // the compiled walks: everything depends on zo / y_in does not (tilt about y) / x_in does not
   // (tilt about x); other patterns run the general walk (their zo * 0 terms are exact zeros)
   const bool dz = p.m[0] != 0.0, dy = p.m[4] != 0.0, dx = p.m[8] != 0.0;
-  if (dz && !dy && dx) launch_one<F32, TZ, 5>(p, blocks, lds_bytes, s);
-  else if (dz && dy && !dx) launch_one<F32, TZ, 3>(p, blocks, lds_bytes, s);
-  else launch_one<F32, TZ, 7>(p, blocks, lds_bytes, s);
+  if (dz && !dy && dx) return launch_one<F32, TZ, 5>(p, blocks, lds_bytes, s);
+  if (dz && dy && !dx) return launch_one<F32, TZ, 3>(p, blocks, lds_bytes, s);
+  return launch_one<F32, TZ, 7>(p, blocks, lds_bytes, s);
 }
 
 }  // namespace
@@ -480,12 +479,11 @@ bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int6
   const size_t lds = static_cast<size_t>(sh.lds_bytes);
   if (Yo * opitch >= (int64_t(1) << 31)) return false;   // 32-bit output offsets inside a plane
   switch (sh.tz * 2 + (f32 ? 1 : 0)) {
-    case 8 * 2 + 1: launch_shape<true, 8>(p, blocks, lds, s); break;
-    case 8 * 2 + 0: launch_shape<false, 8>(p, blocks, lds, s); break;
-    case 16 * 2 + 1: launch_shape<true, 16>(p, blocks, lds, s); break;
-    default: launch_shape<false, 16>(p, blocks, lds, s); break;
+    case 8 * 2 + 1: return launch_shape<true, 8>(p, blocks, lds, s);
+    case 8 * 2 + 0: return launch_shape<false, 8>(p, blocks, lds, s);
+    case 16 * 2 + 1: return launch_shape<true, 16>(p, blocks, lds, s);
+    default: return launch_shape<false, 16>(p, blocks, lds, s);
   }
-  return true;
 }
 
 }  // namespace lsr

@@ -371,13 +371,10 @@ bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, i
   if (padded >= (int64_t(1) << 30)) return false;
   p.per_xcd = static_cast<int>(ceil_div(padded, 8));
   const int64_t blocks = f32 ? tiles * ceil_div(Zo, chunk) : int64_t(p.per_xcd) * 8;
-  static bool attr_set[2] = {false, false};
+  static std::atomic<uint64_t> lds_allowed[2] = {{0}, {0}};
   auto kernel = f32 ? affine_planar_kernel<true> : affine_planar_kernel<false>;
-  if (!attr_set[f32]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              150 * 1024);
-    attr_set[f32] = true;
-  }
+  if (lsr::allow_dynamic_lds(reinterpret_cast<const void*>(kernel), 150 * 1024, lds_allowed[f32], "affine_planar_kernel") != LSR_OK)
+    return false;   // the caller runs the gather kernel
   hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
                      static_cast<size_t>(lds_bytes), s, p);
   return true;

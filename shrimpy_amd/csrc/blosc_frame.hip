@@ -123,6 +123,9 @@ extern "C" int lsr_blosc_decode_host(const uint8_t* frame, int64_t frame_bytes, 
   LSR_REQUIRE(byte_shuffled || !(flags & 0x4), LSR_E_UNSUPPORTED, "bit-shuffled blosc frame: decoded by the Python codec");
   LSR_REQUIRE(blocksize > 0 && blocksize <= nbytes, LSR_E_ARG, "corrupt blosc frame: blocksize %lld of %lld bytes",
               (long long)blocksize, (long long)nbytes);
+  // a split block is T streams of blocksize / T bytes each: a remainder would leave the tail of the scratch undecoded
+  LSR_REQUIRE((flags & 0x10) || T > 16 || blocksize / T < 128 || blocksize % T == 0, LSR_E_ARG,
+              "corrupt blosc frame: split blocks of %lld bytes are not a multiple of typesize %d", (long long)blocksize, T);
   const int compressor = flags >> 5;
   const Decoders& dec = decoders();
   LSR_REQUIRE(lsr_blosc_host_codec(compressor), LSR_E_UNSUPPORTED,
@@ -131,7 +134,7 @@ extern "C" int lsr_blosc_decode_host(const uint8_t* frame, int64_t frame_bytes, 
   LSR_REQUIRE(16 + 4 * nblocks <= frame_bytes, LSR_E_ARG, "corrupt blosc frame: block table runs past the end");
   uint8_t* scratch = nullptr;
   if (byte_shuffled) {
-    scratch = static_cast<uint8_t*>(std::malloc(static_cast<size_t>(blocksize)));
+    scratch = static_cast<uint8_t*>(std::calloc(static_cast<size_t>(blocksize), 1));
     LSR_REQUIRE(scratch != nullptr, LSR_E_ARG, "out of memory for a %lld-byte block", (long long)blocksize);
   }
   int status = LSR_OK;

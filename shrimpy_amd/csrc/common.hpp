@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -22,6 +23,24 @@ inline int launch_status(const char* what) {
 }
 
 inline hipStream_t as_stream(lsr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Raise a kernel's dynamic-LDS ceiling above the 64 KB default.  The attribute belongs to the kernel's
+// code object on ONE device, so it is set once per (kernel, device): `done` is that kernel's bit mask of
+// devices already served (one static per call site; devices >= 64 are simply set every time).
+// Returns LSR_OK or the HIP error (message in lsr_last_error()).
+inline int allow_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done, const char* what) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail(static_cast<int>(e), "%s: hipGetDevice: %s", what, hipGetErrorString(e));
+  const uint64_t bit = dev < 64 ? uint64_t(1) << dev : 0;
+  if (bit && (done.load(std::memory_order_acquire) & bit)) return LSR_OK;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess)
+    return fail(static_cast<int>(e), "%s: device %d refuses %d bytes of dynamic LDS: %s", what, dev, bytes,
+                hipGetErrorString(e));
+  if (bit) done.fetch_or(bit, std::memory_order_release);
+  return LSR_OK;
+}
 
 constexpr int kWave = 64;  // CDNA4 wavefront
 

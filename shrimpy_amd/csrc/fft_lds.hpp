@@ -88,7 +88,19 @@ __device__ __forceinline__ void dft(float2 (&a)[R]) {
 // wave's own outstanding ones) replaces the workgroup barrier -- sixteen to twenty-four barriers per
 // transform pair were what these kernels spent most of their cycles in (SQ counters: waves issuing 20-30 %
 // of the time, 60 % idle).
-__device__ __forceinline__ void sequence_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+//
+// The fence is sequentially consistent: pass k's stores followed by pass k + 1's loads BY OTHER LANES is a
+// store -> load ordering, which acquire/release alone does not promise; and the wave barrier keeps the
+// compiler from scheduling any lane's code across the point (it emits no instruction on a wave64 target).
+// Both rest on the 64-lane wavefront: a wave32 build would split a sequence over two waves.
+// (ROCm 7 dropped the __AMDGCN_WAVEFRONT_SIZE macro; gfx950 has no wave32 mode, so the target is the check.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the LDS transforms assume 64-lane wavefronts: build for gfx950 only"
+#endif
+__device__ __forceinline__ void sequence_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
 // One Stockham pass (decimation in frequency) over the sequence `seq` of length N, shared by PERCOL
 // threads of one wavefront (thread t takes butterflies t, t + PERCOL, ...).

@@ -241,9 +241,8 @@ size_t lds_bytes(int M) {
 }
 
 template <typename K>
-void allow_lds(K kernel) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(lds_bytes(kMaxM)));
+int allow_lds(K kernel, std::atomic<uint64_t>& done, const char* what) {
+  return lsr::allow_dynamic_lds(reinterpret_cast<const void*>(kernel), static_cast<int>(lds_bytes(kMaxM)), done, what);
 }
 
 }  // namespace
@@ -278,8 +277,8 @@ extern "C" int lsr_rfft_rows_t_c64(const float* in, int64_t Zi, int64_t Yi, int6
   p.in = in;
   p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
   p.spec = reinterpret_cast<float2*>(spec);
-  static bool once = false;
-  if (!once) { allow_lds(rfft_rows_kernel); once = true; }
+  static std::atomic<uint64_t> lds_allowed{0};
+  if (int rc = allow_lds(rfft_rows_kernel, lds_allowed, "lsr_rfft_rows_t_c64")) return rc;
   const unsigned blocks = static_cast<unsigned>(Z * lsr::ceil_div(Y, kRows));
   hipLaunchKernelGGL(rfft_rows_kernel, dim3(blocks), dim3(kThreads), lds_bytes(p.M), lsr::as_stream(stream), p);
   return lsr::launch_status("lsr_rfft_rows_t_c64");
@@ -296,8 +295,8 @@ extern "C" int lsr_irfft_rows_peak(const float* spec, int64_t Z, int64_t Y, int6
   const int64_t nb = Z * lsr::ceil_div(Y, kRows);
   p.pidx = static_cast<unsigned long long*>(scratch);
   p.pval = reinterpret_cast<float*>(static_cast<char*>(scratch) + 8 * nb);
-  static bool once = false;
-  if (!once) { allow_lds(irfft_rows_peak_kernel); once = true; }
+  static std::atomic<uint64_t> lds_allowed{0};
+  if (int rc = allow_lds(irfft_rows_peak_kernel, lds_allowed, "lsr_irfft_rows_peak")) return rc;
   hipStream_t s = lsr::as_stream(stream);
   hipLaunchKernelGGL(irfft_rows_peak_kernel, dim3(static_cast<unsigned>(nb)), dim3(kThreads), lds_bytes(p.M), s, p);
   hipLaunchKernelGGL(rows_peak_final_kernel, dim3(1), dim3(256), 0, s, p.pval, p.pidx, nb, out_index);

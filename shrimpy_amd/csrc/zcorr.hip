@@ -133,12 +133,11 @@ extern "C" int lsr_cross_correlate_z_c64(const float* f1, float* g, const float*
   const int64_t blocks = XC * lsr::ceil_div(Y, kCols);
   LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large", (long long)blocks);
   const size_t lds = (static_cast<size_t>(kCols) * (p.N + 1) + p.N) * sizeof(float2);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(zcorr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (kCols * (kMaxN + 1) + kMaxN) * sizeof(float2));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_allowed{0};
+  if (int rc = lsr::allow_dynamic_lds(reinterpret_cast<const void*>(zcorr_kernel),
+                                      static_cast<int>((kCols * (kMaxN + 1) + kMaxN) * sizeof(float2)), lds_allowed,
+                                      "lsr_cross_correlate_z_c64"))
+    return rc;
   hipLaunchKernelGGL(zcorr_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), lds, lsr::as_stream(stream), p);
   return lsr::launch_status("lsr_cross_correlate_z_c64");
 }

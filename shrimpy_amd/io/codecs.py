@@ -465,6 +465,11 @@ def _py_blosc_decode(frame, out: np.ndarray) -> None:
         return
     byte_shuffled = bool(flags & _F_SHUFFLE) and typesize > 1
     bit_shuffled = not byte_shuffled and bool(flags & _F_BITSHUFFLE)
+    if not 0 < blocksize <= nbytes:
+        raise ValueError(f"corrupt blosc frame: blocksize {blocksize} of {nbytes} bytes")
+    if (not (flags & _F_DONTSPLIT) and typesize <= _MAX_SPLITS and blocksize // typesize >= _MIN_BUFFERSIZE
+            and blocksize % typesize):
+        raise ValueError(f"corrupt blosc frame: split blocks of {blocksize} bytes are not a multiple of typesize {typesize}")
     nblocks = -(-nbytes // blocksize)
     if _BLOSC_HEADER + 4 * nblocks > src.size:
         raise ValueError("corrupt blosc frame: block table runs past the end")

@@ -350,3 +350,25 @@ def test_native_frame_walker_agrees_with_c_blosc_and_with_the_python_codec(libbl
         codecs._native_decode(bytes(bad), out)
     with pytest.raises(ValueError, match="destination has"):
         codecs._native_decode(frame, np.zeros(10, np.uint8))
+
+
+def test_frames_with_impossible_block_sizes_are_refused_by_both_walkers():
+    """A hostile or damaged header: blocksize 0, blocksize > nbytes, and split blocks whose size is not a
+    multiple of the typesize (the T streams would not cover the block: the rest of the scratch would be
+    copied out undecoded).  ``ValueError`` from the Python walker and from ``lsr_blosc_decode_host``."""
+    import struct
+
+    def header(typesize, nbytes, blocksize, flags):
+        return struct.pack("<BBBBIII", 2, 1, flags, typesize, nbytes, blocksize, 16 + 4 + 4 + nbytes)
+
+    zstd_split = 4 << 5                      # zstd, blocks may be split (0x10 clear), no shuffle flag
+    cases = [header(2, 4096, 0, zstd_split | 1), header(2, 4096, 8192, zstd_split | 1),
+             header(3, 3001, 1000, zstd_split | 1)]
+    for head in cases:
+        nbytes = struct.unpack_from("<I", head, 4)[0]
+        frame = head + struct.pack("<i", 20) + bytes(nbytes + 64)
+        with pytest.raises(ValueError, match="corrupt blosc frame"):
+            codecs._py_blosc_decode(frame, np.zeros(nbytes, np.uint8))
+        if codecs._native_lib() is not None:
+            with pytest.raises(ValueError, match="corrupt blosc frame"):
+                codecs._native_decode(frame, np.zeros(nbytes, np.uint8))
