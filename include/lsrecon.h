@@ -437,6 +437,35 @@ int lsr_cross_power_into_c64(const float* a, float* b, int64_t n, lsr_stream_t s
 int lsr_peak_abs_shifted_f32(const float* in, int64_t Z, int64_t Y, int64_t X, long long* out_index,
                              void* scratch, lsr_stream_t stream);
 
+/*
+ * Host twins (csrc/host_twins.hip): the same signatures with HOST pointers, the same argument checks and the
+ * same arithmetic in the same order, so the results equal the device entry points' bit for bit.  They serve
+ * the boxes where the reference itself resolves to the CPU (shrimpy/preprocessing.py:78-82 -- its CI has no
+ * GPU, shrimpy/tests/conftest.py:11-17) and BASELINE config 1; they are product code and never touch oracle/.
+ * `stream` is ignored.  Work is split over at most lsr_set_host_threads(n) plain threads (default 1, no OpenMP).
+ * lsr_affine_f32_cpu takes LSR_MODE_CONSTANT / LSR_MODE_GRID_CONSTANT only (its arithmetic is always fp64).
+ */
+int lsr_set_host_threads(int n);
+int lsr_get_host_threads(void);
+int lsr_deskew_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo,
+                       int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd,
+                       const double M[12], int avg_n, lsr_stream_t stream);
+int lsr_deskew_u16_cpu(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo,
+                       int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd,
+                       const double M[12], int avg_n, lsr_stream_t stream);
+int lsr_affine_f32_cpu(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
+                       int64_t Yo, int64_t Xo, const double M[12], float cval, int mode,
+                       lsr_stream_t stream);
+int lsr_average_slices_f32_cpu(const float* in, int64_t Zd, int64_t Y, int64_t X, float* out,
+                               int64_t Zo, int avg_n, lsr_stream_t stream);
+int lsr_correlate_sep_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y,
+                              int64_t X, const float* wz, int pz, const float* wy, int py,
+                              const float* wx, int px, int epilogue, float eps, const float* nz,
+                              const float* ny, const float* nx, lsr_stream_t stream);
+int lsr_correlate_dense_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y,
+                                int64_t X, const float* w, int pz, int py, int px, int epilogue,
+                                float eps, const double* norm_table, lsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,7 +130,13 @@ SIGNATURES: dict[str, list] = {
         _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _int, _int,
         ctypes.c_void_p, _int, _f32, _stream,
     ],
+    "lsr_set_host_threads": [_int],
+    "lsr_get_host_threads": [],
 }
+# host twins (csrc/host_twins.hip): the device entry point's signature, host pointers
+for _name in ("lsr_deskew_f32", "lsr_deskew_u16", "lsr_affine_f32", "lsr_average_slices_f32", "lsr_correlate_sep_f32",
+              "lsr_correlate_dense_f32"):
+    SIGNATURES[_name + "_cpu"] = SIGNATURES[_name]
 
 
 def kernel_source_sha16() -> str:

@@ -1,0 +1,367 @@
+// Host twins of the hot-path entry points (no kernel in this file): the same signatures with HOST pointers,
+// the same argument checks, the same arithmetic in the same order -- so the results equal the device
+// kernels' bit for bit -- for the boxes where the reference itself falls back to the CPU
+// (`torch.device("cuda" if torch.cuda.is_available() else "cpu")`, shrimpy/preprocessing.py:78-82; its CI has
+// no GPU, shrimpy/tests/conftest.py:11-17) and for BASELINE config 1 ("deskew-only via the CPU path").
+// This is product code: it does not call, link or read anything under oracle/.
+//
+//   lsr_deskew_f32_cpu / lsr_deskew_u16_cpu   <->  lsr_deskew_f32 / lsr_deskew_u16     (deskew.hip)
+//   lsr_affine_f32_cpu                        <->  lsr_affine_f32                      (affine.hip)
+//   lsr_average_slices_f32_cpu                <->  lsr_average_slices_f32              (deskew.hip)
+//   lsr_correlate_sep_f32_cpu                 <->  lsr_correlate_sep_f32               (correlate.hip)
+//   lsr_correlate_dense_f32_cpu               <->  lsr_correlate_dense_f32             (correlate.hip)
+//
+// Arithmetic (what "the same" means):
+//   resamplers -- coordinates ((zo*m0 + yo*m1) + xo*m2) + shift, weights w0 = 1 - f, w1 = 1 - w0 and the
+//     8-corner sum ((v*wz)*wy)*wx accumulated z-major in fp64, every operation rounded on its own (the TU is
+//     built with -ffp-contract=off), the result rounded to f32 once: scipy.ndimage.affine_transform(order=1);
+//   averaging  -- ((d0 + d1) + ...) / n in f32, the last group edge-padded;
+//   stencils   -- f32 FMA chains in tap order (separable: x, then y, then z; dense: z-major), zeros outside the
+//     volume, the Richardson-Lucy epilogues of correlate.hip.
+// The `stream` argument is ignored (kept so the signatures are identical).  Threads: plain std::thread over
+// output planes, at most lsr_set_host_threads(n) of them (default 1) -- no OpenMP runtime enters the process
+// (the reference's warning about torch plus a second OpenMP, shrimpy/tests/conftest.py:11-17).
+
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+std::atomic<int> g_threads{1};
+constexpr int kMaxAvg = 16;    // as deskew.hip
+constexpr int kMaxTaps = 15;   // as correlate.hip
+
+// fn(first, last) over [0, n) split into contiguous ranges, one per worker
+template <typename F>
+void parallel_ranges(int64_t n, F&& fn) {
+  int workers = g_threads.load(std::memory_order_relaxed);
+  if (workers > n) workers = static_cast<int>(n);
+  if (workers <= 1) {
+    fn(int64_t(0), n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve(static_cast<size_t>(workers));
+  const int64_t per = (n + workers - 1) / workers;
+  for (int w = 0; w < workers; ++w) {
+    const int64_t a = w * per, b = a + per < n ? a + per : n;
+    if (a >= b) break;
+    pool.emplace_back([&fn, a, b] { fn(a, b); });
+  }
+  for (std::thread& t : pool) t.join();
+}
+
+struct AxisTap {
+  int64_t i0, i1;
+  double w0, w1;
+  bool out0, out1;
+};
+
+template <bool GRID>
+inline bool axis_tap(double c, int64_t n, AxisTap& t) {
+  if (!GRID && (c < 0.0 || c > static_cast<double>(n - 1))) return false;
+  const double fl = std::floor(c);
+  const double f = c - fl;
+  t.w0 = 1.0 - f;
+  t.w1 = 1.0 - t.w0;
+  if (!GRID) {
+    t.i0 = static_cast<int64_t>(fl);
+    t.i1 = t.i0 + 1 < n ? t.i0 + 1 : n - 1;
+    t.out0 = t.out1 = false;
+  } else {
+    const double lo = fl < -2.0 ? -2.0 : fl;
+    const int64_t start = static_cast<int64_t>(lo > static_cast<double>(n) + 1.0 ? static_cast<double>(n) + 1.0 : lo);
+    t.out0 = start < 0 || start >= n;
+    t.out1 = start + 1 < 0 || start + 1 >= n;
+    t.i0 = start < 0 ? 0 : (start > n - 1 ? n - 1 : start);
+    t.i1 = start + 1 < 0 ? 0 : (start + 1 > n - 1 ? n - 1 : start + 1);
+  }
+  return true;
+}
+
+inline double coord(double zo, double yo, double xo, const double* row) {
+  double c = zo * row[0];
+  c = c + yo * row[1];
+  c = c + xo * row[2];
+  return c + row[3];
+}
+
+template <typename T, bool GRID>
+inline float sample(const T* in, int64_t Z, int64_t Y, int64_t X, const double M[12], double zo, double yo, double xo,
+                    float cval) {
+  AxisTap tz, ty, tx;
+  if (!axis_tap<GRID>(coord(zo, yo, xo, M), Z, tz) || !axis_tap<GRID>(coord(zo, yo, xo, M + 4), Y, ty) ||
+      !axis_tap<GRID>(coord(zo, yo, xo, M + 8), X, tx))
+    return cval;
+  const double cv = static_cast<double>(cval);
+  double t = 0.0;
+  for (int a = 0; a < 2; ++a) {
+    const int64_t oz = (a ? tz.i1 : tz.i0) * Y * X;
+    const double wz = a ? tz.w1 : tz.w0;
+    const bool bz = a ? tz.out1 : tz.out0;
+    for (int b = 0; b < 2; ++b) {
+      const int64_t oy = oz + (b ? ty.i1 : ty.i0) * X;
+      const double wy = b ? ty.w1 : ty.w0;
+      const bool by = b ? ty.out1 : ty.out0;
+      for (int c = 0; c < 2; ++c) {
+        double v = static_cast<double>(in[oy + (c ? tx.i1 : tx.i0)]);
+        if (GRID && (bz || by || (c ? tx.out1 : tx.out0))) v = cv;
+        v = v * wz;
+        v = v * wy;
+        v = v * (c ? tx.w1 : tx.w0);
+        t = t + v;
+      }
+    }
+  }
+  return static_cast<float>(t);
+}
+
+bool is_integer(double v) { return v == static_cast<double>(static_cast<int64_t>(v)); }
+
+int check_matrix(const double M[12]) {
+  LSR_REQUIRE_PTR(M);
+  for (int i = 0; i < 12; ++i) LSR_REQUIRE(M[i] == M[i] && M[i] - M[i] == 0.0, LSR_E_ARG, "M[%d] is not finite", i);
+  return LSR_OK;
+}
+
+template <typename T>
+int deskew_cpu(const T* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo, int64_t Yo, int64_t Xo,
+               int64_t out_pitch, int64_t out_plane, int64_t Zd, const double M[12], int avg_n) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(out);
+  if (int rc = check_matrix(M)) return rc;
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "raw shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
+              (long long)X);
+  LSR_REQUIRE(Zo > 0 && Yo > 0 && Xo > 0 && Zd > 0, LSR_E_SHAPE, "output shape (%lld,%lld,%lld) / Zd %lld must be positive",
+              (long long)Zo, (long long)Yo, (long long)Xo, (long long)Zd);
+  LSR_REQUIRE(avg_n >= 1 && avg_n <= kMaxAvg, LSR_E_ARG, "avg_n %d outside [1,%d]", avg_n, kMaxAvg);
+  LSR_REQUIRE(Zo == lsr::ceil_div(Zd, avg_n), LSR_E_SHAPE, "Zo %lld != ceil(Zd %lld / avg_n %d)", (long long)Zo,
+              (long long)Zd, avg_n);
+  LSR_REQUIRE(out_pitch >= Xo && out_plane >= Yo * out_pitch, LSR_E_SHAPE,
+              "output strides (%lld, %lld) are smaller than the output plane (%lld x %lld)", (long long)out_pitch,
+              (long long)out_plane, (long long)Yo, (long long)Xo);
+  const bool structured = M[1] == 0.0 && (M[4] == 1.0 || M[4] == -1.0) && M[5] == 0.0 && M[6] == 0.0 && is_integer(M[7]) &&
+                          M[8] == 0.0 && (M[9] == 1.0 || M[9] == -1.0) && M[10] == 0.0 && is_integer(M[11]);
+  LSR_REQUIRE(structured, LSR_E_UNSUPPORTED,
+              "matrix is not a deskew shear (rows 1,2 must be signed unit axes with integer offsets, M[0][1] == 0): use "
+              "lsr_affine_f32_cpu + lsr_average_slices_f32_cpu");
+  parallel_ranges(Zo, [&](int64_t z_first, int64_t z_last) {
+    for (int64_t zo = z_first; zo < z_last; ++zo)
+      for (int64_t yo = 0; yo < Yo; ++yo) {
+        float* row = out + zo * out_plane + yo * out_pitch;
+        for (int64_t xo = 0; xo < Xo; ++xo) {
+          float acc = 0.0f;
+          for (int k = 0; k < avg_n; ++k) {
+            const int64_t zd = zo * avg_n + k < Zd - 1 ? zo * avg_n + k : Zd - 1;
+            const float d = sample<T, false>(in, Z, Y, X, M, static_cast<double>(zd), static_cast<double>(yo),
+                                             static_cast<double>(xo), 0.0f);
+            acc = k == 0 ? d : acc + d;
+          }
+          row[xo] = avg_n > 1 ? acc / static_cast<float>(avg_n) : acc;
+        }
+      }
+  });
+  return LSR_OK;
+}
+
+int check_corr(const float* in, float* out, const float* aux, int64_t Z, int64_t Y, int64_t X, int pz, int py, int px,
+               int epilogue) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(out);
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
+              (long long)X);
+  LSR_REQUIRE(pz >= 1 && py >= 1 && px >= 1 && (pz & 1) && (py & 1) && (px & 1) && pz <= kMaxTaps && py <= kMaxTaps &&
+                  px <= kMaxTaps,
+              LSR_E_UNSUPPORTED, "PSF taps (%d,%d,%d) must be odd and <= %d per axis", pz, py, px, kMaxTaps);
+  LSR_REQUIRE(epilogue == LSR_EPI_NONE || epilogue == LSR_EPI_RATIO || epilogue == LSR_EPI_UPDATE, LSR_E_ARG,
+              "unknown epilogue %d", epilogue);
+  if (epilogue != LSR_EPI_NONE) LSR_REQUIRE_PTR(aux);
+  LSR_REQUIRE(in != out, LSR_E_ARG, "out must not alias in");
+  return LSR_OK;
+}
+
+// H^T 1 of the dense form, as correlate.hip evaluates it from the prefix-sum table
+double dense_norm(const double* P, int pz, int py, int px, int64_t Z, int64_t Y, int64_t X, int64_t z, int64_t y, int64_t x) {
+  const int cz = pz / 2, cy = py / 2, cx = px / 2;
+  auto lo = [](int64_t v) { return static_cast<int>(v > 0 ? v : 0); };
+  auto hi = [](int64_t n, int64_t v) { return static_cast<int>(v < n ? v : n); };
+  const int a0 = lo(cz - z), a1 = hi(pz, Z - z + cz), b0 = lo(cy - y), b1 = hi(py, Y - y + cy), c0 = lo(cx - x),
+            c1 = hi(px, X - x + cx);
+  const int sb = px + 1, sa = (py + 1) * sb;
+  if (a0 == 0 && a1 == pz && b0 == 0 && b1 == py && c0 == 0 && c1 == px) return P[pz * sa + py * sb + px];
+  return ((P[a1 * sa + b1 * sb + c1] - P[a0 * sa + b1 * sb + c1]) - (P[a1 * sa + b0 * sb + c1] - P[a0 * sa + b0 * sb + c1])) -
+         ((P[a1 * sa + b1 * sb + c0] - P[a0 * sa + b1 * sb + c0]) - (P[a1 * sa + b0 * sb + c0] - P[a0 * sa + b0 * sb + c0]));
+}
+
+}  // namespace
+
+extern "C" int lsr_set_host_threads(int n) {
+  LSR_REQUIRE(n >= 1 && n <= 1024, LSR_E_ARG, "host threads %d outside [1, 1024]", n);
+  g_threads.store(n, std::memory_order_relaxed);
+  return LSR_OK;
+}
+
+extern "C" int lsr_get_host_threads(void) { return g_threads.load(std::memory_order_relaxed); }
+
+extern "C" int lsr_deskew_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo, int64_t Yo,
+                                  int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd, const double M[12],
+                                  int avg_n, lsr_stream_t) {
+  return deskew_cpu(in, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M, avg_n);
+}
+
+extern "C" int lsr_deskew_u16_cpu(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo, int64_t Yo,
+                                  int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd, const double M[12],
+                                  int avg_n, lsr_stream_t) {
+  return deskew_cpu(in, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M, avg_n);
+}
+
+extern "C" int lsr_affine_f32_cpu(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo, int64_t Yo,
+                                  int64_t Xo, const double M[12], float cval, int mode, lsr_stream_t) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(out);
+  if (int rc = check_matrix(M)) return rc;
+  LSR_REQUIRE(Zi > 0 && Yi > 0 && Xi > 0 && Zo > 0 && Yo > 0 && Xo > 0, LSR_E_SHAPE, "shapes must be positive");
+  LSR_REQUIRE(mode == LSR_MODE_CONSTANT || mode == LSR_MODE_GRID_CONSTANT, LSR_E_ARG,
+              "mode %d: LSR_MODE_CONSTANT or LSR_MODE_GRID_CONSTANT (the f32-interpolation flag has no host twin: "
+              "the host arithmetic is always scipy's fp64)", mode);
+  const bool grid = mode == LSR_MODE_GRID_CONSTANT;
+  parallel_ranges(Zo, [&](int64_t z_first, int64_t z_last) {
+    for (int64_t zo = z_first; zo < z_last; ++zo)
+      for (int64_t yo = 0; yo < Yo; ++yo) {
+        float* row = out + (zo * Yo + yo) * Xo;
+        for (int64_t xo = 0; xo < Xo; ++xo)
+          row[xo] = grid ? sample<float, true>(in, Zi, Yi, Xi, M, double(zo), double(yo), double(xo), cval)
+                         : sample<float, false>(in, Zi, Yi, Xi, M, double(zo), double(yo), double(xo), cval);
+      }
+  });
+  return LSR_OK;
+}
+
+extern "C" int lsr_average_slices_f32_cpu(const float* in, int64_t Zd, int64_t Y, int64_t X, float* out, int64_t Zo, int avg_n,
+                                          lsr_stream_t) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(out);
+  LSR_REQUIRE(Zd > 0 && Y > 0 && X > 0 && Zo > 0, LSR_E_SHAPE, "shape must be positive");
+  LSR_REQUIRE(avg_n >= 1 && avg_n <= kMaxAvg, LSR_E_ARG, "avg_n %d outside [1,%d]", avg_n, kMaxAvg);
+  LSR_REQUIRE(Zo == lsr::ceil_div(Zd, avg_n), LSR_E_SHAPE, "Zo %lld != ceil(Zd %lld / avg_n %d)", (long long)Zo,
+              (long long)Zd, avg_n);
+  const int64_t plane = Y * X;
+  parallel_ranges(Zo, [&](int64_t z_first, int64_t z_last) {
+    for (int64_t zo = z_first; zo < z_last; ++zo)
+      for (int64_t r = 0; r < plane; ++r) {
+        float acc = 0.0f;
+        for (int k = 0; k < avg_n; ++k) {
+          const int64_t zd = zo * avg_n + k < Zd - 1 ? zo * avg_n + k : Zd - 1;
+          const float d = in[zd * plane + r];
+          acc = k == 0 ? d : acc + d;
+        }
+        out[zo * plane + r] = avg_n > 1 ? acc / static_cast<float>(avg_n) : acc;
+      }
+  });
+  return LSR_OK;
+}
+
+extern "C" int lsr_correlate_sep_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y, int64_t X,
+                                         const float* wz, int pz, const float* wy, int py, const float* wx, int px,
+                                         int epilogue, float eps, const float* nz, const float* ny, const float* nx,
+                                         lsr_stream_t) {
+  if (int rc = check_corr(in, out, aux, Z, Y, X, pz, py, px, epilogue)) return rc;
+  LSR_REQUIRE_PTR(wz);
+  LSR_REQUIRE_PTR(wy);
+  LSR_REQUIRE_PTR(wx);
+  if (epilogue == LSR_EPI_UPDATE) {
+    LSR_REQUIRE_PTR(nz);
+    LSR_REQUIRE_PTR(ny);
+    LSR_REQUIRE_PTR(nx);
+  }
+  const int64_t plane = Y * X;
+  const int cz = pz / 2, cy = py / 2, cx = px / 2;
+  // in-plane passes of every plane first (x then y, f32 FMA chains from 0), then the z chain + epilogue
+  std::vector<float> filtered(static_cast<size_t>(Z * plane));
+  parallel_ranges(Z, [&](int64_t z_first, int64_t z_last) {
+    std::vector<float> rows(static_cast<size_t>(plane));
+    for (int64_t z = z_first; z < z_last; ++z) {
+      const float* src = in + z * plane;
+      for (int64_t y = 0; y < Y; ++y)
+        for (int64_t x = 0; x < X; ++x) {
+          float s = 0.0f;
+          for (int c = 0; c < px; ++c) {
+            const int64_t gx = x + c - cx;
+            s = std::fmaf(wx[c], gx >= 0 && gx < X ? src[y * X + gx] : 0.0f, s);
+          }
+          rows[static_cast<size_t>(y * X + x)] = s;
+        }
+      float* dst = filtered.data() + z * plane;
+      for (int64_t y = 0; y < Y; ++y)
+        for (int64_t x = 0; x < X; ++x) {
+          float s = 0.0f;
+          for (int b = 0; b < py; ++b) {
+            const int64_t gy = y + b - cy;
+            s = std::fmaf(wy[b], gy >= 0 && gy < Y ? rows[static_cast<size_t>(gy * X + x)] : 0.0f, s);
+          }
+          dst[y * X + x] = s;
+        }
+    }
+  });
+  parallel_ranges(Z, [&](int64_t z_first, int64_t z_last) {
+    for (int64_t z = z_first; z < z_last; ++z)
+      for (int64_t y = 0; y < Y; ++y)
+        for (int64_t x = 0; x < X; ++x) {
+          const int64_t r = y * X + x;
+          // the march of correlate.hip: the first plane's term is a plain product, the others FMAs onto it
+          auto pl = [&](int a) {
+            const int64_t zi = z + a - cz;
+            return zi >= 0 && zi < Z ? filtered[static_cast<size_t>(zi * plane + r)] : 0.0f;
+          };
+          float c = wz[0] * pl(0);
+          for (int a = 1; a < pz; ++a) c = std::fmaf(wz[a], pl(a), c);
+          const int64_t o = z * plane + r;
+          float v = c;
+          if (epilogue == LSR_EPI_RATIO) v = aux[o] / (c + eps);
+          else if (epilogue == LSR_EPI_UPDATE) v = aux[o] * c / (nz[z] * ny[y] * nx[x]);
+          out[o] = v;
+        }
+  });
+  return LSR_OK;
+}
+
+extern "C" int lsr_correlate_dense_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y, int64_t X,
+                                           const float* w, int pz, int py, int px, int epilogue, float eps,
+                                           const double* norm_table, lsr_stream_t) {
+  if (int rc = check_corr(in, out, aux, Z, Y, X, pz, py, px, epilogue)) return rc;
+  LSR_REQUIRE_PTR(w);
+  if (epilogue == LSR_EPI_UPDATE) LSR_REQUIRE_PTR(norm_table);
+  const int64_t plane = Y * X;
+  const int cz = pz / 2, cy = py / 2, cx = px / 2;
+  parallel_ranges(Z, [&](int64_t z_first, int64_t z_last) {
+    for (int64_t z = z_first; z < z_last; ++z)
+      for (int64_t y = 0; y < Y; ++y)
+        for (int64_t x = 0; x < X; ++x) {
+          float c = 0.0f;   // planes in z order, within a plane y-major: the order the march accumulates in
+          for (int a = 0; a < pz; ++a) {
+            const int64_t zi = z + a - cz;
+            if (zi < 0 || zi >= Z) continue;      // (a whole plane of zeros leaves the chain unchanged)
+            for (int b = 0; b < py; ++b) {
+              const int64_t gy = y + b - cy;
+              for (int k = 0; k < px; ++k) {
+                const int64_t gx = x + k - cx;
+                const float v = gy >= 0 && gy < Y && gx >= 0 && gx < X ? in[zi * plane + gy * X + gx] : 0.0f;
+                c = std::fmaf(w[(a * py + b) * px + k], v, c);
+              }
+            }
+          }
+          const int64_t o = z * plane + y * X + x;
+          float v = c;
+          if (epilogue == LSR_EPI_RATIO) v = aux[o] / (c + eps);
+          else if (epilogue == LSR_EPI_UPDATE)
+            v = aux[o] * c / static_cast<float>(dense_norm(norm_table, pz, py, px, Z, Y, X, z, y, x));
+          out[o] = v;
+        }
+  });
+  return LSR_OK;
+}

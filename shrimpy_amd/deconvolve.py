@@ -564,6 +564,11 @@ def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=Non
     if y.dtype != torch.float32:
         y = y.to(torch.float32)
     y = y.contiguous()
+    if y.device.type == "cpu":     # no HIP device in play: the host twins of the two launches per iteration
+        from . import host
+
+        return host.richardson_lucy(y, psf, iterations, eps, x0, separable=separable, separable_rtol=separable_rtol,
+                                    psf_factors=psf_factors)
     plan = RichardsonLucyPlan(tuple(y.shape), psf, y.device, separable=separable,
                               separable_rtol=separable_rtol, psf_factors=psf_factors)
     return plan(y, iterations=iterations, eps=eps, x0=x0)
@@ -578,6 +583,10 @@ def correlate3d(volume, weights=None, *, weight_factors=None, tuned: bool = True
     """
     import torch
 
+    if isinstance(volume, torch.Tensor) and volume.device.type == "cpu":
+        from . import host
+
+        return host.correlate3d(volume, weights, weight_factors)
     vol = _lib.require_device_f32(volume, "volume")
     if vol.dim() != 3:
         raise ValueError("volume must be (Z, Y, X)")

@@ -11,7 +11,9 @@ The reference filters kwargs by ``inspect.signature`` (``shrimpy/preprocessing.p
 parameter NAMES below are the API.  The arithmetic runs in the HIP kernel ``lsr_deskew_f32``
 (``csrc/deskew.hip``): fused slice averaging, results bit-identical to
 ``scipy.ndimage.affine_transform(order=1, mode="constant", cval=0)`` + edge-padded float32 mean.
-There is no CPU fallback: a CPU tensor raises.
+A CPU tensor -- what the reference hands over on a box without a GPU (``shrimpy/preprocessing.py:78-82``) --
+runs the native host twin of the same entry point (``shrimpy_amd.host`` / ``csrc/host_twins.hip``: same
+arithmetic, same bits); nothing routes through the test oracle, and a missing library raises.
 """
 
 from __future__ import annotations
@@ -20,7 +22,7 @@ import ctypes
 
 import numpy as np
 
-from . import _lib
+from . import _lib, host
 from .geometry import as_matrix_3x4, deskew_geometry, orient_axes, orient_shape, orient_voxel
 
 __all__ = [
@@ -94,6 +96,18 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
 
     if border not in BORDERS:
         raise ValueError(f"border must be one of {BORDERS}, got {border!r}")
+    if host.is_host(raw_data):     # no HIP device in play: the native host twin (same arithmetic, same bits)
+        if raw_data.dim() != 3:
+            raise ValueError(f"raw_data must be (Z, Y, X), got shape {tuple(raw_data.shape)}")
+        avg = int(average_n_slices)
+        if avg < 1:
+            raise ValueError(f"average_n_slices must be >= 1, got {avg}")
+        if min(int(v) for v in pre_average_shape) <= 0:
+            raise ValueError(
+                f"deskewed shape {tuple(int(v) for v in pre_average_shape)} is empty: the scan is too short for this "
+                "tilt (use keep_overhang=True or a longer scan)")
+        return host.deskew_with_matrix(raw_data, as_matrix_3x4(matrix_3x4), pre_average_shape, avg, out=out,
+                                       flat_field=flat_field, border=border)
 
     # uint16 camera counts are deskewed as they are (converted to float32 inside the kernel, exact):
     # half the HBM read and, upstream, half the PCIe upload of a float32 stack
@@ -187,6 +201,8 @@ def average_n_slices(data, average_window_width: int = 1):
     avg = int(average_window_width)
     if avg < 1:
         raise ValueError(f"average_window_width must be >= 1, got {avg}")
+    if host.is_host(data):
+        return host.average_n_slices(data, avg)
     data = _lib.require_device_f32(data, "data")
     if avg == 1:
         return data
@@ -242,12 +258,10 @@ def deskew_data(
     orientation: str = "identity",
     border: str = "constant",
 ):
-    """Older biahub entry point: numpy in, numpy out, compute on ``device`` (must be a GPU)."""
+    """Older biahub entry point: numpy in, numpy out, compute on ``device`` (``"cpu"`` runs the host twin)."""
     import torch
 
     dev = torch.device(device)
-    if dev.type != "cuda":
-        raise _lib.LsrError("deskew_data", -1, f"device {dev} is not a GPU; there is no CPU fallback")
     vol = torch.as_tensor(np.ascontiguousarray(raw_data, dtype=np.float32), device=dev)
     out = fast_deskew_zyx(vol, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices,
                           orientation=orientation, border=border)

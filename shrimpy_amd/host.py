@@ -1,0 +1,219 @@
+"""The hot path on HOST tensors: what runs when no HIP device is visible.
+
+The reference resolves its device as ``cuda`` if available, else ``cpu`` (``shrimpy/preprocessing.py:78-82``)
+and its CI has no GPU (``shrimpy/tests/conftest.py:11-17``), so a drop-in has to accept CPU tensors too --
+BASELINE config 1 ("deskew-only via the CPU path, plumbing, no GPU") is exactly that.  The public functions
+(``deskew.fast_deskew_zyx``, ``register.apply_affine_transform_zyx``, ``deconvolve.richardson_lucy`` /
+``correlate3d``) hand CPU tensors to the functions below, which call the native host twins of
+``csrc/host_twins.hip`` (``lsr_*_cpu``: the device entry points' signatures, host pointers, the same
+arithmetic in the same order -- results equal the kernels' bit for bit).  Nothing here imports, calls or
+reads anything under ``oracle/``; the library must be built (``_lib.load`` raises otherwise).
+
+Threads: ``lsr_set_host_threads`` is set from ``torch.get_num_threads()`` at each call -- the knob the
+reference's CPU path is governed by -- and the twins use plain ``std::thread`` (no second OpenMP runtime).
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["is_host", "deskew_with_matrix", "average_n_slices", "apply_affine", "correlate3d", "richardson_lucy"]
+
+_MODES = {"constant": _lib.MODE_CONSTANT, "grid-constant": _lib.MODE_GRID_CONSTANT}
+
+
+def is_host(t) -> bool:
+    import torch
+
+    return isinstance(t, torch.Tensor) and t.device.type == "cpu"
+
+
+def _threads() -> None:
+    import torch
+
+    _lib.call("lsr_set_host_threads", max(1, min(1024, int(torch.get_num_threads()))))
+
+
+def _f32(t, name: str):
+    import torch
+
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
+    if t.device.type != "cpu":
+        raise ValueError(f"{name} is on {t.device}; the host path takes CPU tensors")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def average_n_slices(data, avg: int):
+    import torch
+
+    data = _f32(data, "data")
+    if avg == 1:
+        return data
+    zd, y, x = (int(v) for v in data.shape)
+    out = torch.empty((-(-zd // avg), y, x), dtype=torch.float32)
+    _threads()
+    _lib.call("lsr_average_slices_f32_cpu", data.data_ptr(), zd, y, x, out.data_ptr(), int(out.shape[0]), avg, None)
+    return out
+
+
+def deskew_with_matrix(raw, m, pre_average_shape, avg: int, out=None, flat_field=None, border: str = "constant"):
+    """``deskew.deskew_with_matrix`` for a CPU tensor (float32 or uint16 counts), dense ``out`` only."""
+    import torch
+
+    if flat_field is not None:
+        raise _lib.LsrError("deskew_with_matrix", -1, "the fused flat-field correction exists only in the HIP kernel; "
+                            "on a CPU tensor correct first, then deskew")
+    u16 = raw.dtype == torch.uint16
+    if not u16:
+        raw = _f32(raw, "raw_data")
+    elif not raw.is_contiguous():
+        raise ValueError("raw_data must be contiguous")
+    zd, yo, xo = (int(v) for v in pre_average_shape)
+    zo = -(-zd // avg)
+    if out is None:
+        out = torch.empty((zo, yo, xo), dtype=torch.float32)
+    else:
+        if hasattr(out, "logical_ptr"):
+            raise ValueError("a padded device volume cannot receive a host deskew")
+        _f32(out, "out")
+        if tuple(out.shape) != (zo, yo, xo):
+            raise ValueError(f"out must be {(zo, yo, xo)} on cpu")
+    z, y, x = (int(v) for v in raw.shape)
+    _threads()
+    try:
+        if border != "constant":
+            raise _lib.LsrUnsupported("lsr_deskew_f32_cpu", _lib.E_UNSUPPORTED, "grid-constant border")
+        _lib.call("lsr_deskew_u16_cpu" if u16 else "lsr_deskew_f32_cpu", raw.data_ptr(), z, y, x, out.data_ptr(),
+                  zo, yo, xo, xo, yo * xo, zd, _lib.matrix12(m), avg, None)
+    except _lib.LsrUnsupported:
+        # a general matrix, or the blending border rule: trilinear resample, then average
+        src = raw.to(torch.float32) if u16 else raw
+        pre = out if avg == 1 else torch.empty((zd, yo, xo), dtype=torch.float32)
+        _lib.call("lsr_affine_f32_cpu", src.data_ptr(), z, y, x, pre.data_ptr(), zd, yo, xo, _lib.matrix12(m),
+                  ctypes.c_float(0.0), _MODES[border], None)
+        if avg > 1:
+            _lib.call("lsr_average_slices_f32_cpu", pre.data_ptr(), zd, yo, xo, out.data_ptr(), zo, avg, None)
+    _lib.mark_written(out)
+    return out
+
+
+def apply_affine(moving, m, shape, mode: str, cval: float, out=None):
+    """``register.apply_affine_transform_zyx`` for a CPU tensor: scipy's fp64 arithmetic (``exact``)."""
+    import torch
+
+    moving = _f32(moving, "moving")
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32)
+    else:
+        if hasattr(out, "logical_ptr"):
+            raise ValueError("a padded device volume cannot receive a host resample")
+        _f32(out, "out")
+        if tuple(out.shape) != tuple(shape):
+            raise ValueError(f"out must be {tuple(shape)} on cpu")
+        if out.data_ptr() == moving.data_ptr():
+            raise ValueError("out must not alias moving")
+    zi, yi, xi = (int(v) for v in moving.shape)
+    _threads()
+    _lib.call("lsr_affine_f32_cpu", moving.data_ptr(), zi, yi, xi, out.data_ptr(), int(shape[0]), int(shape[1]),
+              int(shape[2]), _lib.matrix12(m), ctypes.c_float(float(cval)), _MODES[mode], None)
+    _lib.mark_written(out)
+    return out
+
+
+def _taps(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def correlate3d(volume, weights=None, weight_factors=None):
+    """``scipy.ndimage.correlate(volume, weights, mode="constant", cval=0)`` on a CPU tensor."""
+    import torch
+
+    from .deconvolve import prepare_psf
+
+    vol = _f32(volume, "volume")
+    if vol.dim() != 3:
+        raise ValueError("volume must be (Z, Y, X)")
+    out = torch.empty_like(vol)
+    z, y, x = (int(v) for v in vol.shape)
+    _threads()
+    if weight_factors is not None:
+        wz, wy, wx = (_taps(np.asarray(k).ravel()) for k in weight_factors)
+        _lib.call("lsr_correlate_sep_f32_cpu", vol.data_ptr(), out.data_ptr(), None, z, y, x, wz.ctypes.data, len(wz),
+                  wy.ctypes.data, len(wy), wx.ctypes.data, len(wx), _lib.EPI_NONE, ctypes.c_float(0.0), None, None, None,
+                  None)
+    else:
+        w = prepare_psf(weights)
+        _lib.call("lsr_correlate_dense_f32_cpu", vol.data_ptr(), out.data_ptr(), None, z, y, x, w.ctypes.data, w.shape[0],
+                  w.shape[1], w.shape[2], _lib.EPI_NONE, ctypes.c_float(0.0), None, None)
+    return out
+
+
+def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=None, *, separable: str = "auto",
+                    separable_rtol: float = 1e-6, psf_factors=None):
+    """``deconvolve.richardson_lucy`` for a CPU tensor: ``x <- x * H^T(y / (H x + eps)) / H^T 1`` with the two
+    correlations and their epilogues as the host twins of the device launches (rank-1 PSFs run the
+    separable form, others the dense one)."""
+    import torch
+
+    from .deconvolve import MAX_TAPS, _axis_norm, _prefix_table, factor_psf, prepare_psf
+
+    y = _f32(y, "y")
+    if separable not in ("auto", "force", "never"):
+        raise ValueError("separable must be 'auto', 'force' or 'never'")
+    iterations = int(iterations)
+    if iterations < 0:
+        raise ValueError("iterations must be >= 0")
+    if not eps > 0:
+        raise ValueError("eps must be > 0")
+    factors = None
+    if psf_factors is not None:
+        factors = tuple(_taps(np.asarray(k).ravel()) for k in psf_factors)
+        if len(factors) != 3 or any(len(k) % 2 == 0 or len(k) > MAX_TAPS for k in factors):
+            raise ValueError("psf_factors must be three odd-length 1-D kernels (<= 15 taps)")
+    else:
+        w = prepare_psf(psf)
+        if separable != "never":
+            factors = factor_psf(w, separable_rtol)
+            if factors is None and separable == "force":
+                raise ValueError("psf is not rank-1 within separable_rtol")
+    init = y if x0 is None else _f32(x0, "x0")
+    if tuple(init.shape) != tuple(y.shape):
+        raise ValueError(f"x0 must be {tuple(y.shape)}")
+    x = init.clone()
+    if iterations == 0:
+        return x
+    z, yy, xx = (int(v) for v in y.shape)
+    ratio, nxt = torch.empty_like(y), torch.empty_like(y)
+    e = ctypes.c_float(eps)
+    _threads()
+    if factors is not None:
+        k = [_taps(f) for f in factors]
+        kf = [_taps(f[::-1]) for f in factors]
+        norm = [_axis_norm(f, n) for f, n in zip(factors, (z, yy, xx))]
+        sizes = [len(f) for f in k]
+
+        def corr(src, dst, aux, taps, epi):
+            _lib.call("lsr_correlate_sep_f32_cpu", src.data_ptr(), dst.data_ptr(), aux.data_ptr(), z, yy, xx,
+                      taps[0].ctypes.data, sizes[0], taps[1].ctypes.data, sizes[1], taps[2].ctypes.data, sizes[2], epi, e,
+                      norm[0].ctypes.data, norm[1].ctypes.data, norm[2].ctypes.data, None)
+    else:
+        k, kf = _taps(w), _taps(w[::-1, ::-1, ::-1])
+        table = np.ascontiguousarray(_prefix_table(w).ravel(), dtype=np.float64)
+
+        def corr(src, dst, aux, taps, epi):
+            _lib.call("lsr_correlate_dense_f32_cpu", src.data_ptr(), dst.data_ptr(), aux.data_ptr(), z, yy, xx,
+                      taps.ctypes.data, w.shape[0], w.shape[1], w.shape[2], epi, e, table.ctypes.data, None)
+    for _ in range(iterations):
+        corr(x, ratio, y, kf, _lib.EPI_RATIO)       # ratio = y / (H x + eps): H = correlation with the flipped taps
+        corr(ratio, nxt, x, k, _lib.EPI_UPDATE)     # x <- x * H^T ratio / H^T 1
+        x, nxt = nxt, x
+    return x

@@ -51,7 +51,8 @@ _settings_kwargs = accepted_kwargs   # the reference's name for the same helper
 
 
 def _resolve_device():
-    """``cuda`` (HIP under ROCm) when a device is visible, else ``cpu`` -- which ``warm_up`` rejects."""
+    """``cuda`` (HIP under ROCm) when a device is visible, else ``cpu`` -- the reference's rule
+    (``shrimpy/preprocessing.py:78-82``); on ``cpu`` the deskew runs its native host twin."""
     import torch
 
     return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
@@ -105,11 +106,10 @@ class HotPathPreprocessor:
         """Pick the device (it must be a GPU as soon as a kernel stage is on) and switch the working
         shape to the deskewed one, which is what downstream consumers size themselves from."""
         self._device = _resolve_device()
-        needs_kernels = self._apply_flatfield or self._deskew_settings is not None
-        if self._device.type != "cuda" and (needs_kernels or self._require_gpu):
+        if self._device.type != "cuda" and (self._apply_flatfield or self._require_gpu):
             raise RuntimeError(
-                "no HIP device visible: flat-field and deskew exist only as gfx950 kernels and there "
-                "is no CPU fallback (device resolved to %s)" % self._device)
+                "no HIP device visible (device resolved to %s): the flat-field correction exists only as a "
+                "gfx950 kernel, and require_gpu asks for one; the deskew alone runs its host twin" % self._device)
         if self._deskew_settings is not None:
             from .deskew import get_deskewed_data_shape
 

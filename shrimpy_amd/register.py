@@ -85,6 +85,15 @@ def apply_affine_transform_zyx(moving, affine_transform_zyx, output_shape_zyx=No
         raise TypeError(f"moving must be a torch.Tensor, got {type(moving).__name__}")
     if moving.dim() != 3:
         raise ValueError(f"moving must be (Z, Y, X), got shape {tuple(moving.shape)}")
+    if pitched is None and moving.device.type == "cpu":
+        # no HIP device in play: the native host twin (always scipy's fp64 arithmetic, whatever `exact` says)
+        from . import host
+
+        src = moving.to(torch.float32).contiguous()
+        shape = tuple(int(v) for v in (output_shape_zyx if output_shape_zyx is not None else src.shape))
+        if len(shape) != 3 or min(shape) <= 0:
+            raise ValueError(f"output_shape_zyx must be three positive ints, got {shape}")
+        return host.apply_affine(src, as_matrix_3x4(affine_transform_zyx), shape, mode, cval, out=out)
     if pitched is None:
         if moving.dtype != torch.float32:
             moving = moving.to(torch.float32)

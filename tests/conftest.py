@@ -21,9 +21,16 @@ import pytest  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if _TRACE:   # Python stacks of every thread at a fatal signal, beside the trace (never in the log's tail)
+        import faulthandler
+
+        global _FAULT_FILE
+        _FAULT_FILE = open(_TRACE + ".fault", "w")
+        faulthandler.enable(file=_FAULT_FILE, all_threads=True)
 
 
 _T0 = time.monotonic()
+_FAULT_FILE = None
 _TRACE = os.environ.get("LSR_TEST_TRACE")  # optional file that receives the same lines
 
 

@@ -193,24 +193,21 @@ def test_library_loads_and_reports_version_and_arg_errors():
         _lib.call("lsr_deskew_f32", p, 4, 4, 4, p, 2, 4, 4, 4, 16, 4, m, 3, None)
 
 
-def test_product_path_fails_loudly_on_cpu_tensors():
-    """No CPU fallback: the reference's ``cpu`` device branch (``shrimpy/preprocessing.py:80``) gets
-    an exception, which ``_step`` logs and re-raises (``:377-381``)."""
+def test_gpu_only_objects_fail_loudly_on_cpu():
+    """CPU tensors run the native host twins (tests/test_host_twins.py); what exists only on a HIP device --
+    the staged store path, the RL plan with its padded device volumes, the fused flat-field -- says so."""
     import torch
 
-    from shrimpy_amd.deconvolve import richardson_lucy
-    from shrimpy_amd.deskew import deskew_data, fast_deskew_zyx
-    from shrimpy_amd.register import apply_affine_transform_zyx
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+    from shrimpy_amd.flatfield import flat_field_pattern
+    from shrimpy_amd.staging import VolumeStager
 
-    v = torch.zeros((8, 4, 4))
     with pytest.raises(_lib.LsrError, match="no CPU fallback"):
-        fast_deskew_zyx(raw_data=v, ls_angle_deg=30, px_to_scan_ratio=0.755, keep_overhang=True)
+        RichardsonLucyPlan((8, 8, 8), np.ones((3, 3, 3), np.float32) / 27, "cpu")
     with pytest.raises(_lib.LsrError, match="no CPU fallback"):
-        apply_affine_transform_zyx(v, np.eye(4))
+        VolumeStager((8, 8, 8), "uint16", (4, 8, 8), "cpu")
     with pytest.raises(_lib.LsrError, match="no CPU fallback"):
-        richardson_lucy(v, np.ones((3, 3, 3), np.float32) / 27)
-    with pytest.raises(_lib.LsrError, match="no CPU fallback"):
-        deskew_data(np.zeros((8, 4, 4), np.float32), 30, 0.755, True, device="cpu")
+        flat_field_pattern(torch.zeros((8, 4, 4)))
 
 
 def test_product_never_imports_the_oracle():

@@ -1,0 +1,183 @@
+"""The native host twins (``csrc/host_twins.hip`` behind ``shrimpy_amd.host``): the product's path for CPU
+tensors, i.e. for boxes where the reference itself resolves to ``cpu`` (``shrimpy/preprocessing.py:78-82``)
+and for BASELINE config 1.  Checked against the oracle and the golden vectors here (no GPU needed), and
+against the device kernels bit for bit in the ``gpu`` tests at the bottom.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as o
+from shrimpy_amd import _lib
+
+RL_TOL = dict(rel=2e-4, floor=1e-4)      # the RL bar of tests/test_gpu_parity.py
+
+
+def _t(a):
+    import torch
+
+    return torch.as_tensor(np.ascontiguousarray(a))
+
+
+def _rl_close(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    tol = RL_TOL["rel"] * np.abs(want) + RL_TOL["floor"] * np.abs(want).max()
+    assert np.all(np.abs(got - want) <= tol), float(np.max(np.abs(got - want) / tol))
+
+
+@pytest.mark.parametrize("name", ["deskew_nooverhang_avg3", "deskew_overhang_avg1", "deskew_nooverhang_avg5_r0p4"])
+def test_deskew_on_a_cpu_tensor_equals_the_golden_vectors(golden_dir, name):
+    from shrimpy_amd.deskew import fast_deskew_zyx
+
+    g = np.load(golden_dir / f"{name}.npz")
+    kw = dict(ls_angle_deg=float(g["ls_angle_deg"]), px_to_scan_ratio=float(g["px_to_scan_ratio"]),
+              keep_overhang=bool(g["keep_overhang"]), average_n_slices=int(g["average_n_slices"]))
+    out = fast_deskew_zyx(raw_data=_t(g["raw"]), **kw)
+    assert out.device.type == "cpu"
+    np.testing.assert_array_equal(out.numpy(), g["out"])
+
+
+def test_config1_deskew_through_the_product_path_equals_the_oracle():
+    """BASELINE configs[0]: a single 256x256x64 oblique stack (raw (256, 64, 256)), deskew only, no GPU."""
+    from shrimpy_amd.deskew import deskew_data, fast_deskew_zyx, get_deskewed_data_shape
+
+    psf_factors = o.gaussian_psf((9, 7, 7), (2.0, 1.2, 1.2))[1]
+    raw = o.bead_scene((256, 64, 256), seed=1000, psf_factors=psf_factors)
+    kw = dict(ls_angle_deg=30.0, px_to_scan_ratio=0.755, keep_overhang=False, average_n_slices=3)
+    want = o.deskew(raw, 30.0, 0.755, False, 3)
+    out = fast_deskew_zyx(raw_data=_t(raw), **kw)
+    assert tuple(out.shape) == get_deskewed_data_shape(raw.shape, **kw)[0]
+    np.testing.assert_array_equal(out.numpy(), want)
+    # camera counts go in unconverted, the older numpy entry point and a thread pool give the same bits
+    np.testing.assert_array_equal(fast_deskew_zyx(raw_data=_t(raw.astype(np.uint16)), **kw).numpy(),
+                                  o.deskew(raw.astype(np.uint16).astype(np.float32), 30.0, 0.755, False, 3))
+    import torch
+
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(4)
+        np.testing.assert_array_equal(deskew_data(raw, device="cpu", **kw), want)
+        assert _lib.call_value("lsr_get_host_threads") == 4
+    finally:
+        torch.set_num_threads(before)
+
+
+@pytest.mark.parametrize("border", ["constant", "grid-constant"])
+@pytest.mark.parametrize("keep_overhang,avg", [(True, 1), (False, 3), (True, 4)])
+def test_deskew_borders_and_the_general_matrix_route(border, keep_overhang, avg):
+    from shrimpy_amd.deskew import deskew_with_matrix, fast_deskew_zyx
+    from shrimpy_amd.geometry import deskew_geometry
+
+    raw = np.random.default_rng(3).poisson(300, (70, 12, 18)).astype(np.float32)
+    out = fast_deskew_zyx(raw_data=_t(raw), ls_angle_deg=30.0, px_to_scan_ratio=0.755, keep_overhang=keep_overhang,
+                          average_n_slices=avg, border=border)
+    np.testing.assert_array_equal(out.numpy(), o.deskew(raw, 30.0, 0.755, keep_overhang, avg, border=border))
+    # a matrix that is not a deskew shear: trilinear resample, then the average
+    geo = deskew_geometry(raw.shape, 30.0, 0.755, keep_overhang, avg)
+    m = np.array(geo.matrix_3x4, dtype=np.float64)
+    m[1, 2], m[2, 0] = 0.03, -0.02
+    got = deskew_with_matrix(_t(raw), m, geo.pre_average_shape, avg, border=border)
+    pre = o.affine_apply(raw, m[:, :3], m[:, 3], geo.pre_average_shape, mode=border)
+    np.testing.assert_array_equal(got.numpy(), o.average_slices(pre, avg))
+
+
+@pytest.mark.parametrize("mode", ["constant", "grid-constant"])
+def test_affine_apply_on_a_cpu_tensor_is_scipy_bit_for_bit(golden_dir, mode):
+    from shrimpy_amd.register import affine_transform, apply_affine_transform_zyx
+
+    g = np.load(golden_dir / "affine_rot2deg.npz")
+    if mode == "constant":
+        got = apply_affine_transform_zyx(_t(g["vol"]), g["matrix"])
+        np.testing.assert_array_equal(got.numpy(), g["out_constant"])
+    else:
+        got = apply_affine_transform_zyx(_t(g["vol"]), g["matrix"], tuple(int(v) for v in g["grid_shape"]), mode=mode,
+                                         cval=float(g["grid_cval"]))
+        np.testing.assert_array_equal(got.numpy(), g["out_grid"])
+    rng = np.random.default_rng(11)
+    vol = rng.random((9, 21, 30)).astype(np.float32)
+    m = np.eye(4)
+    m[:3, :3] += rng.normal(0, 0.05, (3, 3))
+    m[:3, 3] = [0.7, -2.2, 3.1]
+    got = apply_affine_transform_zyx(_t(vol), m, (11, 19, 33), mode=mode, cval=-2.5, exact=False)   # host: always exact
+    np.testing.assert_array_equal(got.numpy(), o.affine_apply_4x4(vol, m, (11, 19, 33), cval=-2.5, mode=mode))
+    got = affine_transform(_t(vol), m[:3, :3], offset=m[:3, 3], mode=mode)
+    np.testing.assert_array_equal(got.numpy(), o.affine_apply_4x4(vol, m, vol.shape, mode=mode))
+
+
+def test_richardson_lucy_on_a_cpu_tensor_meets_the_rl_bar(golden_dir):
+    from shrimpy_amd.deconvolve import correlate3d, richardson_lucy
+
+    g = np.load(golden_dir / "rl_5iter.npz")
+    got = richardson_lucy(_t(g["y"]), g["psf_sep"], iterations=5)
+    assert got.device.type == "cpu"
+    _rl_close(got.numpy(), g["x_sep_5"])
+    _rl_close(richardson_lucy(_t(g["y"]), psf_factors=(g["kz"], g["ky"], g["kx"]), iterations=5).numpy(), g["x_sep_5"])
+    _rl_close(richardson_lucy(_t(g["y"]), g["psf_rot"], iterations=5).numpy(), g["x_rot_5"])
+    _rl_close(richardson_lucy(_t(g["y"]), g["psf_rot"], iterations=1).numpy(), g["x_rot_1"])
+    # a rotated (non-separable) PSF takes the dense twin; zero input stays zero (autofocus-failed stacks)
+    psf, factors = o.gaussian_psf((5, 5, 7), (1.1, 0.9, 1.4))
+    rot = psf.copy()
+    rot[0, 0, 0] += 0.01
+    rot /= rot.sum()
+    y = o.bead_scene((12, 20, 26), seed=2, psf=psf, density=2e-3)
+    _rl_close(richardson_lucy(_t(y), rot, iterations=4).numpy(), o.richardson_lucy(y, rot, iterations=4))
+    _rl_close(richardson_lucy(_t(y), psf_factors=factors, iterations=4).numpy(),
+              o.richardson_lucy_separable(y, factors, iterations=4))
+    assert not richardson_lucy(_t(np.zeros((6, 8, 8), np.float32)), psf, iterations=3).numpy().any()
+    # the building block is scipy's correlate(mode="constant")
+    from scipy import ndimage
+
+    np.testing.assert_allclose(correlate3d(_t(y), rot).numpy(), ndimage.correlate(y, rot, mode="constant"), rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(correlate3d(_t(y), weight_factors=factors).numpy(), ndimage.correlate(y, psf, mode="constant"),
+                               rtol=2e-5, atol=1e-3)
+
+
+def test_host_twins_check_their_arguments_like_the_device_entries():
+    buf = np.zeros(64, np.float32)
+    p, m = buf.ctypes.data, _lib.matrix12(np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0.0]]))
+    lib = _lib.load()
+    assert lib.lsr_deskew_f32_cpu(None, 4, 4, 4, p, 2, 4, 4, 4, 16, 4, m, 3, None) == -1          # LSR_E_NULL
+    assert lib.lsr_deskew_f32_cpu(p, 4, 4, 4, p, 3, 4, 4, 4, 16, 4, m, 3, None) == -2             # Zo != ceil(Zd / avg)
+    with pytest.raises(_lib.LsrUnsupported, match="not a deskew shear"):
+        _lib.call("lsr_deskew_f32_cpu", p, 4, 4, 4, p, 2, 4, 4, 4, 16, 4, m, 3, None)
+    assert lib.lsr_affine_f32_cpu(p, 2, 2, 2, p, 2, 2, 2, m, 0.0, 7, None) == -4                   # unknown mode
+    assert lib.lsr_correlate_sep_f32_cpu(p, p, None, 2, 2, 2, p, 3, p, 3, p, 3, 0, 0.0, None, None, None, None) == -4   # out aliases in
+    assert lib.lsr_set_host_threads(0) == -4 and lib.lsr_set_host_threads(1) == 0
+
+
+# ------------------------------------------------------------------------------------------------ vs the kernels
+
+
+@pytest.mark.gpu
+def test_host_twins_equal_the_device_kernels_bit_for_bit(device):
+    import torch
+
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan, correlate3d, richardson_lucy
+    from shrimpy_amd.deskew import fast_deskew_zyx
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    rng = np.random.default_rng(8)
+    raw = rng.poisson(300, (200, 40, 70)).astype(np.float32)
+    for keep, avg, border in [(False, 3, "constant"), (True, 2, "grid-constant"), (False, 1, "constant")]:
+        kw = dict(ls_angle_deg=30.0, px_to_scan_ratio=0.755, keep_overhang=keep, average_n_slices=avg, border=border)
+        assert torch.equal(fast_deskew_zyx(raw_data=_t(raw), **kw), fast_deskew_zyx(raw_data=_t(raw).to(device), **kw).cpu())
+        r16 = _t(raw.astype(np.uint16))
+        assert torch.equal(fast_deskew_zyx(raw_data=r16, **kw), fast_deskew_zyx(raw_data=r16.to(device), **kw).cpu())
+    vol = _t(rng.random((24, 48, 64)).astype(np.float32))
+    m = np.eye(4)
+    m[:3, :3] += rng.normal(0, 0.03, (3, 3))
+    m[:3, 3] = [0.7, -2.2, 3.1]
+    for mode in ("constant", "grid-constant"):
+        assert torch.equal(apply_affine_transform_zyx(vol, m, mode=mode, cval=1.0),
+                           apply_affine_transform_zyx(vol.to(device), m, mode=mode, cval=1.0).cpu())
+    # stencils: the generic device kernels share the twins' operation order exactly
+    psf, factors = o.gaussian_psf((9, 7, 7), (2.0, 1.2, 1.2))
+    rot = psf.copy()
+    rot[1, 2, 3] += 0.002
+    y = _t(o.bead_scene((20, 50, 70), seed=4, psf=psf, density=1e-3))
+    assert torch.equal(correlate3d(y, rot), correlate3d(y.to(device), rot, tuned=False).cpu())
+    got = richardson_lucy(y, psf_factors=factors, iterations=6)
+    for fused in ("auto", "never"):
+        dev = RichardsonLucyPlan(tuple(y.shape), None, device, psf_factors=factors, fused=fused)(y.to(device), iterations=6)
+        _rl_close(got.numpy(), dev.cpu().numpy())
+    _rl_close(richardson_lucy(y, rot, iterations=3).numpy(), richardson_lucy(y.to(device), rot, iterations=3).cpu().numpy())

@@ -120,14 +120,26 @@ def test_flatfield_matches_reference_capture(golden_dir):
         np.testing.assert_allclose(out.cpu().numpy(), g["flatfield_out" + k], rtol=1e-6)
 
 
-def test_warm_up_without_gpu_raises_instead_of_falling_back(monkeypatch):
+def test_without_a_gpu_the_deskew_runs_its_host_twin_and_the_rest_says_no(monkeypatch):
+    """The reference's device rule (``shrimpy/preprocessing.py:78-82``): ``cpu`` when no GPU is visible.  The
+    deskew then runs the native host twin (bit-equal to the oracle); flat-field and ``require_gpu`` raise."""
     import torch
 
+    from oracle import cpu_ref as o
+
     monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        build_preprocessor(ZYX, ["deskew"], deskew=DESKEW)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
+    shape = (96, 16, 24)      # scan long enough for the no-overhang window
+    pre = build_preprocessor(shape, ["deskew"], deskew=DESKEW, output_channel="BF")
+    raw = np.random.default_rng(5).integers(80, 600, shape).astype(np.uint16)
+    out = pre(raw, return_intermediates=True)
+    assert set(out) == {"BF", "deskew"} and out["BF"].device.type == "cpu" and out["BF"].dtype == torch.float32
+    want = o.deskew(raw.astype(np.float32), DESKEW["ls_angle_deg"], round(DESKEW["pixel_size_um"] / DESKEW["scan_step_um"], 3),
+                    DESKEW["keep_overhang"], DESKEW["average_n_slices"])
+    np.testing.assert_array_equal(out["BF"].numpy(), want)
+    with pytest.raises(RuntimeError, match="no HIP device visible"):
         build_preprocessor(ZYX, ["flatfield"])
+    with pytest.raises(RuntimeError, match="no HIP device visible"):
+        build_preprocessor(ZYX, ["deskew"], deskew=DESKEW, require_gpu=True)
 
 
 def test_warm_up_resolves_deskewed_shape(monkeypatch):
