@@ -62,6 +62,10 @@ typedef void* lsr_stream_t; /* a hipStream_t; NULL = the default stream */
 
 int lsr_version(void);
 const char* lsr_last_error(void);
+/* Page-locked host memory of exactly `bytes` bytes from the HIP runtime (hipHostMalloc, portable across
+ * devices): the staging slots of the store-to-store path.  Returns 0 or the hipError_t (then *out = NULL). */
+int lsr_pinned_alloc(int64_t bytes, void** out);
+int lsr_pinned_free(void* ptr);
 
 /*
  * Oblique-plane deskew with the slice averaging fused in.

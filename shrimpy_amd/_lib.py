@@ -130,6 +130,8 @@ SIGNATURES: dict[str, list] = {
         _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _int, _int,
         ctypes.c_void_p, _int, _f32, _stream,
     ],
+    "lsr_pinned_alloc": [_i64, ctypes.POINTER(ctypes.c_void_p)],
+    "lsr_pinned_free": [ctypes.c_void_p],
     "lsr_set_host_threads": [_int],
     "lsr_get_host_threads": [],
 }

@@ -25,6 +25,26 @@ from . import _lib
 __all__ = ["VolumeStager"]
 
 
+def _pinned_tensor(shape, dtype):
+    """A CPU tensor over ``lsr_pinned_alloc`` memory of exactly the tensor's size.  The allocation belongs
+    to the buffer object every view (tensor, numpy array) keeps alive, and is freed with it."""
+    import ctypes
+    import weakref
+
+    import torch
+
+    nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+    ptr = ctypes.c_void_p()
+    _lib.call("lsr_pinned_alloc", nbytes, ctypes.byref(ptr))
+    buf = (ctypes.c_char * nbytes).from_address(ptr.value)
+    weakref.finalize(buf, _lib.load().lsr_pinned_free, ptr.value)
+    t = torch.frombuffer(buf, dtype=dtype).view(shape)
+    if not t.is_pinned():      # torch does not recognise the range: treat it like any failed pin
+        del t, buf
+        raise _lib.LsrError("lsr_pinned_alloc", -1, "torch does not see the allocation as page-locked")
+    return t
+
+
 class VolumeStager:
     """``depth`` pinned host slots + device slots for raw stacks, ``depth`` pinned slots for results.
 
@@ -36,11 +56,17 @@ class VolumeStager:
     def __init__(self, raw_shape, raw_dtype, out_shape, device, depth: int = 2, pin: str = "exact"):
         """``depth`` slots each way (default 2; more only helps when load times vary a lot).
 
-        ``pin``: ``"exact"`` page-locks plain allocations of exactly the slot size with
-        ``hipHostRegister`` -- torch's caching host allocator rounds every pinned block up to a power
-        of two (a 4.3 GB raw slot becomes 8 GB, a 3.2 GB result slot 4 GB: ~24 GB per rank instead of
-        ~15 GB at config 2); ``"torch"`` uses ``pin_memory=True``; ``"none"`` keeps the slots
-        pageable (copies are then synchronous: correct, slower)."""
+        ``pin``: ``"exact"`` takes page-locked allocations of exactly the slot size from the HIP runtime
+        (``lsr_pinned_alloc`` = ``hipHostMalloc``) -- torch's caching host allocator rounds every pinned
+        block up to a power of two (a 4.3 GB raw slot becomes 8 GB, a 3.2 GB result slot 4 GB: ~24 GB per
+        rank instead of ~15 GB at config 2); ``"torch"`` uses ``pin_memory=True``; ``"none"`` keeps the
+        slots pageable (copies are then synchronous: correct, slower).
+
+        (Round 2 pinned ordinary torch allocations in place with ``hipHostRegister``.  That is the
+        kernel's user-pointer path: the pages stay the process's own, and when their CPU mapping changes
+        under a registered range -- huge-page collapse, NUMA balancing, compaction -- the driver evicts and
+        restores the process's GPU queues with copies in flight.  The store-to-store tests that use these
+        slots were the ones that aborted intermittently; driver-owned pinned memory has no such path.)"""
         import torch
 
         self.device = torch.device(device)
@@ -57,47 +83,34 @@ class VolumeStager:
             raise TypeError(f"raw dtype {raw_dtype}: uint16 (camera counts) or float32")
         if pin not in ("exact", "torch", "none"):
             raise ValueError("pin must be 'exact', 'torch' or 'none'")
-        self._registered: list = []
-        self._host_in = [self._host_slot(self.raw_shape, dt, pin) for _ in range(depth)]
+        with torch.cuda.device(self.device):
+            self._host_in = [self._host_slot(self.raw_shape, dt, pin) for _ in range(depth)]
+            self._host_out = [self._host_slot(self.out_shape, torch.float32, pin) for _ in range(depth)]
         self._dev_in = [torch.empty(self.raw_shape, dtype=dt, device=self.device) for _ in range(depth)]
-        self._host_out = [self._host_slot(self.out_shape, torch.float32, pin) for _ in range(depth)]
         self._up = torch.cuda.Stream(self.device)
         self._down = torch.cuda.Stream(self.device)
         self._uploaded = [None] * depth      # recorded on `up` after the H2D copy of the slot
         self._consumed = [None] * depth      # recorded on the compute stream when the raw slot is dead
         self._downloaded = [None] * depth    # recorded on `down` after the D2H copy of the slot
 
-    def _host_slot(self, shape, dtype, pin: str):
+    @staticmethod
+    def _host_slot(shape, dtype, pin: str):
         import torch
 
         if pin == "torch":
             return torch.empty(shape, dtype=dtype, pin_memory=True)
-        t = torch.empty(shape, dtype=dtype)
-        if pin == "exact" and t.numel():
-            rt = torch.cuda.cudart()
-            err = rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)
-            if int(err) != 0 or not t.is_pinned():
-                if int(err) == 0:
-                    rt.cudaHostUnregister(t.data_ptr())
-                return torch.empty(shape, dtype=dtype, pin_memory=True)   # fall back to torch's allocator
-            self._registered.append(t)
-        return t
+        if pin == "none" or not all(shape):
+            return torch.empty(shape, dtype=dtype)
+        try:
+            return _pinned_tensor(shape, dtype)
+        except _lib.LsrError:
+            return torch.empty(shape, dtype=dtype, pin_memory=True)   # fall back to torch's allocator
 
     def close(self) -> None:
-        """Drain the copy streams and give the page-locked slots back."""
-        import torch
-
+        """Drain the copy streams and let go of the slots.  A pinned slot goes back to the driver when its
+        last view dies -- a numpy view a caller still holds (``host_in`` / ``collect``) keeps it valid."""
         self.drain()
-        rt = torch.cuda.cudart()
-        while self._registered:
-            rt.cudaHostUnregister(self._registered.pop().data_ptr())
-
-    def __del__(self):
-        try:
-            if getattr(self, "_registered", None):
-                self.close()
-        except Exception:  # noqa: BLE001 -- interpreter shutdown
-            pass
+        self._host_in, self._host_out, self._dev_in = [], [], []
 
     # ---- host -> device --------------------------------------------------------------------
     def host_in(self, slot: int) -> np.ndarray:

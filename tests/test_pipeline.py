@@ -252,3 +252,35 @@ def test_stager_refuses_cpu_devices():
 
     with pytest.raises(LsrError, match="no CPU fallback"):
         VolumeStager((4, 4, 4), np.uint16, (4, 4, 4), "cpu")
+
+
+@pytest.mark.gpu
+def test_staging_slots_are_driver_owned_pinned_memory_of_the_exact_size(device):
+    """``lsr_pinned_alloc`` (hipHostMalloc) behind a torch tensor: page-locked as torch sees it, exactly the
+    slot's size, asynchronous copies both ways, and valid for as long as any view of it lives."""
+    import gc
+
+    import torch
+
+    from shrimpy_amd.staging import VolumeStager, _pinned_tensor
+
+    t = _pinned_tensor((3, 5, 7), torch.uint16)
+    assert t.is_pinned() and t.is_contiguous() and t.numel() * t.element_size() == 3 * 5 * 7 * 2
+    t.numpy()[...] = np.arange(105, dtype=np.uint16).reshape(3, 5, 7)
+    d = torch.empty((3, 5, 7), dtype=torch.uint16, device=device)
+    d.copy_(t, non_blocking=True)
+    back = _pinned_tensor((3, 5, 7), torch.uint16)
+    back.copy_(d, non_blocking=True)
+    torch.cuda.synchronize()
+    assert torch.equal(back, t)
+    view = back.numpy()
+    del back
+    gc.collect()
+    assert view.sum() == np.arange(105).sum()          # the view keeps the allocation alive
+
+    st = VolumeStager((16, 8, 12), np.uint16, (4, 12, 20), device)
+    assert all(s.is_pinned() for s in st._host_in + st._host_out)
+    held = st.host_in(0)
+    held[...] = 7
+    st.close()
+    assert int(held.sum()) == 7 * 16 * 8 * 12          # closed, but a caller's view stays readable
