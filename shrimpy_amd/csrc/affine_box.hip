@@ -67,7 +67,8 @@ __device__ __forceinline__ void glds_x4(const float* sbase, unsigned voff, unsig
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                :
                : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
-               : "memory");
+               : "memory");  // (m0 is a RESERVED register to hipcc: naming it as a clobber is refused with a
+                             // warning; the compiler re-loads m0 right before each of its own uses instead)
 }
 
 // extremes of one coordinate over the block.  The coordinate expression is monotone in each index

@@ -65,7 +65,14 @@ __device__ __forceinline__ void glds_x4(const float* sbase, int voff, unsigned l
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                :
                : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
-               : "memory");
+               : "memory");  // (m0 is a RESERVED register to hipcc: naming it as a clobber is refused with a
+                             // warning; the compiler re-loads m0 right before each of its own uses instead)
+}
+// One output value = exactly ONE vector-memory operation, whatever the optimiser thinks of its neighbours:
+// the counted wait of the plane loop (`s_waitcnt vmcnt(kPts)`) is only right while every plane issues at
+// least kPts stores behind its DMAs.
+__device__ __forceinline__ void store_one(float* addr, float v) {
+  asm volatile("global_store_dword %0, %1, off" : : "v"(addr), "v"(v) : "memory");
 }
 
 // scipy's coordinate ((zo*m0 + yo*m1) + xo*m2) + shift with zo*m0 == 0 (exact: adding +-0 is the
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
       for (int k = 0; k < G; ++k) {
         const int i = h + k;
         if (in_out[i >> 1] && col_out[i & 1])
-          orow[static_cast<int64_t>(wave + 8 * (i >> 1)) * p.opitch + lane + 64 * (i & 1)] = res[k];
+          store_one(orow + static_cast<int64_t>(wave + 8 * (i >> 1)) * p.opitch + lane + 64 * (i & 1), res[k]);
       }
     }
     // (no barrier here: the next iteration's DMAs are issued behind its own barrier, which every

@@ -42,6 +42,18 @@ inline int allow_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t
   return LSR_OK;
 }
 
+// Does a workgroup of the current device get `bytes` of LDS?  (gfx950: 160 KB per CU.)  Without a device to
+// ask -- the build container -- the answer is yes: the *_supported functions then speak for the lengths only.
+inline bool lds_fits(size_t bytes) {
+  int dev = 0, cap = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return true; }
+  if (hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;
+  }
+  return static_cast<size_t>(cap) >= bytes;
+}
+
 constexpr int kWave = 64;  // CDNA4 wavefront
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -253,7 +253,7 @@ extern "C" int lsr_rfft_rows_supported(int64_t n) {
   int64_t m = n / 2;
   for (int f : {2, 3, 5})
     while (m % f == 0) m /= f;
-  return m == 1;
+  return m == 1 && lsr::lds_fits(lds_bytes(static_cast<int>(n / 2)));
 }
 
 extern "C" int64_t lsr_rfft_rows_scratch_bytes(int64_t Z, int64_t Y) {

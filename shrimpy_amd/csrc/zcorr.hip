@@ -87,9 +87,10 @@ __global__ __launch_bounds__(kThreads) void zcorr_kernel(ZcorrArgs p) {
 // 1 when lsr_cross_correlate_z_c64 handles a z transform of length n (5-smooth, <= 256)
 extern "C" int lsr_cross_correlate_z_supported(int64_t n) {
   if (n < 2 || n > kMaxN) return 0;
+  const size_t lds = (static_cast<size_t>(kCols) * (n + 1) + n) * sizeof(float2);
   for (int f : {2, 3, 5})
     while (n % f == 0) n /= f;
-  return n == 1;
+  return n == 1 && lsr::lds_fits(lds);
 }
 
 extern "C" int lsr_cross_correlate_z_c64(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC,

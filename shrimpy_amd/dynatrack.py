@@ -416,6 +416,7 @@ def _spectrum(vol, shape, kind: str):
 
 
 _axis_fft_ok = [True]      # cleared when hipFFT refuses a plan: the torch.fft route is used from then on
+_rows_ok = [True]       # the LDS row / z transforms launched (cleared on the first refusal)
 
 
 def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0) -> tuple[int, ...]:
@@ -445,8 +446,15 @@ def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0) -> tuple[int
     kind = "rfft3" if (_axis_fft_ok[0] and fft3.available() and min(shape) >= 2) else "rfftn"
     peak_index = None
     try:
-        if kind == "rfft3" and fft3.rows_supported(shape):
-            peak_index = _correlation_peak_rows(ref_t, ref_t is ref_img, mov_t, shape)
+        if kind == "rfft3" and _rows_ok[0] and fft3.rows_supported(shape):
+            try:
+                peak_index = _correlation_peak_rows(ref_t, ref_t is ref_img, mov_t, shape)
+            except _lib.LsrError as exc:
+                # the LDS transforms were refused at launch (their 78-139 KB of dynamic LDS only fit a
+                # gfx950 CU): keep tracking through the library transforms instead of failing the volume
+                logger.warning("LDS row / z transforms unavailable (%s): using the hipFFT route", exc)
+                _rows_ok[0] = False
+                corr = _cross_correlation(ref_t, ref_t is ref_img, mov_t, shape, kind)
         else:
             corr = _cross_correlation(ref_t, ref_t is ref_img, mov_t, shape, kind)
     except fft3.AxisFftError as exc:

@@ -27,10 +27,12 @@ package is importable; ``as_volume_array`` gives either kind the whole-volume in
 
 from __future__ import annotations
 
+import contextlib
 import gzip
 import itertools
 import json
 import os
+import threading
 import zlib
 
 from pathlib import Path
@@ -66,9 +68,21 @@ def host_cores() -> int:
     return max(1, n)
 
 
-# Threads one volume read / write fans its files out to.  ``None`` = min(16, host_cores()).  A
-# streamed run reads unit k+1 while it writes unit k-1: ``pipeline._run_staged`` splits the cores
-# between the two (``io_thread_budget``) so that together they stay within the share.
+def rank_cores() -> int:
+    """This rank's share of ``host_cores()``: the ranks ``torch.distributed.run`` started on this host
+    (``LOCAL_WORLD_SIZE``) read and write their own positions side by side, so each sizes its pools from an
+    equal part of the box -- 8 ranks x (16 + 16) threads on one host was the first thing to break a node-wide
+    store-to-store run."""
+    try:
+        local = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    except ValueError:
+        local = 1
+    return max(1, host_cores() // max(1, local))
+
+
+# Threads one volume read / write fans its files out to.  ``None`` = min(16, rank_cores()).  (A streamed
+# run reads unit k+1 while it writes unit k-1; the two pools block on the page cache and on zstd in turn,
+# and measured best with the full share each -- profiles/r02_io_threads.jsonl.)
 IO_THREADS = {"read": None, "write": None}
 
 
@@ -85,7 +99,7 @@ def _io_threads(role: str) -> int:
         r, w = (int(v) for v in env.split(","))
         return max(1, r if role == "read" else w)
     n = IO_THREADS.get(role)
-    return max(1, int(n)) if n else min(16, host_cores())
+    return max(1, int(n)) if n else min(16, rank_cores())
 
 
 class UnsupportedCodec(RuntimeError):
@@ -227,7 +241,13 @@ class _BlockCodec:
 
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         if self.params.get("crc32c"):
-            raw = memoryview(raw)[:-4]
+            raw = memoryview(raw)
+            if len(raw) < 4:
+                raise ValueError("corrupt chunk: shorter than its CRC-32C suffix")
+            want = int.from_bytes(raw[-4:], "little")
+            raw = raw[:-4]
+            if int(codecs.crc32c(raw)) != want:
+                raise ValueError("corrupt chunk: CRC-32C mismatch")
         if self.kind == "blosc":
             if out is not None and out.flags.c_contiguous and out.dtype == dtype and out.nbytes == nbytes:
                 codecs.blosc_decode(raw, out=out)
@@ -269,6 +289,30 @@ class _BlockCodec:
 
 
 _MISSING = 0xFFFFFFFFFFFFFFFF   # (offset, nbytes) of an absent inner chunk in a shard index
+
+_shard_locks_guard = threading.Lock()
+_shard_locks: dict[str, threading.Lock] = {}
+
+
+@contextlib.contextmanager
+def _shard_lock(path: Path):
+    """Exclusive access to one shard file for a read-modify-write: a lock per path for the threads of
+    this process, ``flock`` on ``<shard>.lock`` for other processes (ranks) on the same host."""
+    import fcntl
+
+    key = str(path)
+    with _shard_locks_guard:
+        lock = _shard_locks.setdefault(key, threading.Lock())
+    with lock:
+        fd = os.open(str(path) + ".lock", os.O_CREAT | os.O_RDWR, 0o644)
+        try:
+            fcntl.flock(fd, fcntl.LOCK_EX)
+            yield
+        finally:
+            try:
+                fcntl.flock(fd, fcntl.LOCK_UN)
+            finally:
+                os.close(fd)
 
 
 class ZarrArray:
@@ -530,8 +574,23 @@ class ZarrArray:
         vchunks = self.chunks[k:]
         counts = self._shard_counts()
         path = self._file_path(tuple(i // s for i, s in zip(lead, self.shards[:k])) + tuple(fidx))
+        if any(s > 1 for s in self.shards[:k]):
+            # the shard also holds other (t, c) volumes: a read-modify-write, one writer at a time --
+            # writer threads of a streamed run, or ranks, may hold different volumes of this shard
+            path.parent.mkdir(parents=True, exist_ok=True)
+            with _shard_lock(path):
+                self._write_shard_locked(path, lead, fidx, vol, threads, merge=True)
+        else:
+            self._write_shard_locked(path, lead, fidx, vol, threads, merge=False)
+
+    def _write_shard_locked(self, path, lead, fidx, vol, threads, merge: bool) -> None:
+        from .codecs import crc32c
+
+        k = len(lead)
+        vchunks = self.chunks[k:]
+        counts = self._shard_counts()
         blobs: dict[tuple, bytes] = {}
-        if path.exists() and any(s > 1 for s in self.shards[:k]):
+        if merge and path.exists():
             # the shard also holds other (t, c) volumes: keep their encoded chunks as they are
             with open(path, "rb", buffering=0) as f:
                 size = os.fstat(f.fileno()).st_size
@@ -561,7 +620,7 @@ class ZarrArray:
         if self._index_crc:
             ibytes += int(crc32c(ibytes)).to_bytes(4, "little")
         path.parent.mkdir(parents=True, exist_ok=True)
-        tmp = path.with_name(path.name + ".partial")
+        tmp = path.with_name(f"{path.name}.{os.getpid()}.{threading.get_ident()}.partial")   # never shared
         with open(tmp, "wb") as f:
             if self._index_location == "start":
                 f.write(ibytes)

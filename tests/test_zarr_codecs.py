@@ -252,9 +252,19 @@ def test_io_thread_budget_defaults_to_the_core_share_and_can_be_split(monkeypatc
     from shrimpy_amd.io import omezarr
 
     monkeypatch.delenv("LSR_IO_THREADS", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     cores = omezarr.host_cores()
     assert 1 <= cores <= (os.cpu_count() or 1)
     assert omezarr._io_threads("read") == omezarr._io_threads("write") == min(16, cores)
+    # the local ranks of one launch divide the box between them
+    monkeypatch.setattr(omezarr, "host_cores", lambda: 128)
+    for local, share in ((1, 16), (8, 16), (16, 8), (64, 2), (512, 1)):
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", str(local))
+        assert omezarr.rank_cores() == max(1, 128 // local)
+        assert omezarr._io_threads("read") == omezarr._io_threads("write") == share
+    monkeypatch.undo()
+    monkeypatch.delenv("LSR_IO_THREADS", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     prev = omezarr.io_thread_budget(read=3, write=5)
     try:
         assert (omezarr._io_threads("read"), omezarr._io_threads("write")) == (3, 5)
@@ -372,3 +382,39 @@ def test_frames_with_impossible_block_sizes_are_refused_by_both_walkers():
         if codecs._native_lib() is not None:
             with pytest.raises(ValueError, match="corrupt blosc frame"):
                 codecs._native_decode(frame, np.zeros(nbytes, np.uint8))
+
+
+def test_concurrent_writers_of_one_shared_shard_keep_each_others_volumes(tmp_path):
+    """A shard that holds several (t, c) volumes is rewritten by read-modify-write: writer threads (and
+    ranks) holding different volumes of it take turns, and none loses the other's chunks."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    shape = (4, 2, 24, 8, 20)
+    rng = np.random.default_rng(9)
+    data = rng.integers(80, 600, shape).astype("uint16")
+    with open_ome_zarr(tmp_path / "p.zarr", layout="hcs", mode="w", channel_names=["BF", "GFP"], version="0.5",
+                       prefer_iohub=False) as plate:
+        arr = plate.create_position("A", "1", "fov0").create_zeros(
+            "0", shape=shape, dtype="uint16", chunks=(1, 1, 8, 8, 20), compress="blosc-zstd", shards=(4, 2, 24, 8, 20))
+        for _ in range(3):                         # every (t, c) at once, three times over
+            with ThreadPoolExecutor(8) as pool:
+                list(pool.map(lambda tc: arr.write_volume(tc[0], tc[1], data[tc]),
+                              [(t, c) for t in range(4) for c in range(2)]))
+    with open_ome_zarr(tmp_path / "p.zarr", prefer_iohub=False) as plate:
+        np.testing.assert_array_equal(plate["A/1/fov0"]["0"][:], data)
+    assert not list((tmp_path / "p.zarr").rglob("*.partial"))
+
+
+def test_a_chunk_whose_crc32c_suffix_does_not_match_is_refused(tmp_path):
+    from shrimpy_amd.io.omezarr import _BlockCodec
+
+    codec = _BlockCodec("zstd", level=1)
+    codec.params["crc32c"] = True
+    block = np.arange(240, dtype="uint16").reshape(3, 8, 10)
+    raw = bytearray(codec.encode(block))
+    np.testing.assert_array_equal(codec.decode(bytes(raw), block.shape, block.dtype), block)
+    raw[5] ^= 0x40
+    with pytest.raises(ValueError, match="CRC-32C"):
+        codec.decode(bytes(raw), block.shape, block.dtype)
+    with pytest.raises(ValueError, match="shorter"):
+        codec.decode(b"ab", block.shape, block.dtype)
