@@ -214,6 +214,70 @@ def pmc_traffic(key, workload, kernel_symbol):
     return rec.get("hbm_bytes_per_launch"), f"{rec.get('source')} @ {rec.get('git_head', '?')}"
 
 
+def device_state(device) -> dict:
+    """Clocks and power of the card under ``device``, read from sysfs (no process is started): the
+    box-to-box spread of the launch time is only attributable with these next to it.  Every field is
+    optional -- a box that hides sysfs gives {}."""
+    import torch
+
+    out = {}
+    try:
+        prop = torch.cuda.get_device_properties(device)
+        out["name"] = prop.name
+        out["compute_units"] = int(prop.multi_processor_count)
+        bdf = None
+        if all(hasattr(prop, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            bdf = f"{prop.pci_domain_id:04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}.0"
+        cards = sorted(Path("/sys/class/drm").glob("card[0-9]*/device"))
+        card = None
+        for c in cards:
+            try:
+                if bdf and c.resolve().name.lower() == bdf:
+                    card = c
+                    break
+            except OSError:
+                continue
+        if card is None and len(cards) == 1:
+            card = cards[0]
+        if card is None:
+            return out
+        out["pci"] = card.resolve().name
+
+        def current(name):   # the starred level of a pp_dpm_* table, MHz
+            try:
+                for line in (card / name).read_text().splitlines():
+                    if line.rstrip().endswith("*"):
+                        return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+            except (OSError, ValueError, IndexError):
+                pass
+            return None
+
+        def top(name):
+            try:
+                vals = [int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+                        for ln in (card / name).read_text().splitlines() if ":" in ln]
+                return max(vals) if vals else None
+            except (OSError, ValueError, IndexError):
+                return None
+
+        out["sclk_mhz"], out["sclk_max_mhz"] = current("pp_dpm_sclk"), top("pp_dpm_sclk")
+        out["mclk_mhz"], out["mclk_max_mhz"] = current("pp_dpm_mclk"), top("pp_dpm_mclk")
+        for hw in sorted(card.glob("hwmon/hwmon*")):
+            for key, fname, scale in (("power_cap_w", "power1_cap", 1e-6), ("power_avg_w", "power1_average", 1e-6),
+                                      ("power_input_w", "power1_input", 1e-6), ("temp_c", "temp1_input", 1e-3)):
+                try:
+                    out[key] = round(int((hw / fname).read_text()) * scale, 1)
+                except (OSError, ValueError):
+                    pass
+        try:
+            out["perf_level"] = (card / "power_dpm_force_performance_level").read_text().strip()
+        except OSError:
+            pass
+    except Exception as exc:  # noqa: BLE001 -- never let bookkeeping fail a bench
+        out["error"] = f"{type(exc).__name__}: {exc}"
+    return {k: v for k, v in out.items() if v is not None}
+
+
 def dist_setup(args):
     import torch
     import torch.distributed as dist
@@ -309,7 +373,7 @@ def run_resident(args, rank, world, device, shared, backend, cpu):
         plan = RichardsonLucyPlan(out_shape, None, device, psf_factors=gaussian_factors(),
                                   fused="auto" if args.rl == "fused" else "never")
     elif args.psf == "rotated":
-        plan = RichardsonLucyPlan(out_shape, rotated_psf(), device)
+        plan = RichardsonLucyPlan(out_shape, rotated_psf(), device, fused="auto" if args.rl == "fused" else "never")
     else:
         plan = RichardsonLucyPlan(out_shape, rotated_psf(), device, separable="never")
     # the deskew kernel writes straight into the RL kernels' padded, line-aligned input volume
@@ -334,6 +398,7 @@ def run_resident(args, rank, world, device, shared, backend, cpu):
         assert torch.equal(fast_deskew_zyx(raw_data=raw, **DESKEW), padded.view)
 
     elapsed, events = timed_steps(step, args, world, shared, device)
+    state_after = device_state(device) if rank == 0 else None   # right behind the timed steps: clocks under load
     deskew_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
     rl_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps          # incl. x0 = y copy
     rl_kernels_ms = sum(e[3].elapsed_time(e[4]) for e in events) / args.steps  # the 2*iters launches
@@ -341,7 +406,7 @@ def run_resident(args, rank, world, device, shared, backend, cpu):
     if rank != 0:
         return None
 
-    fused = bool(getattr(plan, "fused", False))
+    fused = bool(getattr(plan, "fused", False)) or bool(getattr(plan, "fused_ysep", False))
     ysep = plan.path.startswith("y-separable")
     launches = RL_ITERS if fused else (4 * RL_ITERS if plan.path.endswith("(4 launches)") else 2 * RL_ITERS)
     launch_s = rl_kernels_ms * 1e-3 / launches  # HIP events right around the launches, / count
@@ -358,11 +423,13 @@ def run_resident(args, rank, world, device, shared, backend, cpu):
         kernel = ("rl_fused_sep_kernel<9,7> (one RL iteration per launch)" if fused
                   else "correlate_sep_kernel<9,7,7> (RL ratio / update launch)")
         symbol = "rl_fused_sep_kernel" if fused else "correlate_sep_kernel"
+    elif ysep and fused:
+        kernel, symbol = "rl_fused_ysep_kernel<9,7> (ky (x) kzx, one RL iteration per launch)", "rl_fused_ysep_kernel"
     elif ysep:
         kernel, symbol = "correlate_dense_kernel<9,7,*,2> (ky (x) kzx, RL ratio / update launch)", "correlate_dense_kernel"
     else:
         kernel, symbol = "correlate_dense_kernel<9,7> (dense RL ratio / update launch)", "correlate_dense_kernel"
-    key = "fused" if fused else ("two-launch" if args.psf == "separable" else args.psf)
+    key = ("fused" if fused else "two-launch") if args.psf == "separable" else args.psf
     traffic, traffic_note = pmc_traffic(key, args.workload, symbol)
     if args.psf == "separable" or ysep:
         roofline = {
@@ -415,6 +482,7 @@ def run_resident(args, rank, world, device, shared, backend, cpu):
                 "frac_if_those_bytes_moved": survey_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "parallelism": parallelism_note(world, shared),
             "collective_backend": backend,
+            "device_after_timed_steps": state_after,
         },
         "roofline": roofline,
     }

@@ -323,6 +323,25 @@ int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_plane, int i
                          const float* ny, const float* nx, int iters, float eps,
                          lsr_stream_t stream);
 
+/*
+ * The same one-launch iteration for PSFs that separate along y only, psf[a][b][c] = ky[b] * kzx[a][c]
+ * (rl_fused_ysep.hip) -- the PSF of an oblique light sheet, tilted in (z, x) and Gaussian along y; SURVEY.md
+ * section 8(d)'s secondary PSF.  Volumes as lsr_rl_sep_fused_f32 (y padded with a zero halo, x_a / x_b padded
+ * working volumes, x_out dense or NULL).  `taps`: a DEVICE array of lsr_rl_ysep_fused_taps_count() floats whose
+ * HOST image lsr_rl_ysep_fused_prepare_taps fills from ky (py taps) and kzx (pz x px, C order);
+ * norm_table / norm_full: the full PSF's, as for lsr_correlate_dense_f32.  Compiled for pz <= 11 and
+ * py, px <= 9 (lsr_rl_ysep_fused_supported; otherwise LSR_E_UNSUPPORTED: use lsr_correlate_zxy_padded_f32 twice
+ * per iteration).  Results are bit-identical to that two-launch form.
+ */
+int lsr_rl_ysep_fused_supported(int pz, int py, int px);
+int lsr_rl_ysep_fused_taps_count(void);
+int lsr_rl_ysep_fused_prepare_taps(const float* ky_host, int py, const float* kzx_host, int pz, int px,
+                                   float* taps_host);
+int lsr_rl_ysep_fused_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y, float* x_a,
+                          float* x_b, float* x_out, int64_t Z, int64_t Y, int64_t X, const float* taps,
+                          int pz, int py, int px, const double* norm_table, float norm_full, int iters,
+                          float eps, lsr_stream_t stream);
+
 int lsr_rl_dense_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X,
                      const float* psf, const float* psf_flipped, int pz, int py, int px,
                      const double* norm_table, int iters, float eps, lsr_stream_t stream);

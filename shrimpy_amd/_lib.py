@@ -112,6 +112,13 @@ SIGNATURES: dict[str, list] = {
         _c_f32p, _i64, _i64, _int, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _int, _int, _int,
         _c_f32p, _c_f32p, _c_f32p, _int, _f32, _stream,
     ],
+    "lsr_rl_ysep_fused_supported": [_int, _int, _int],
+    "lsr_rl_ysep_fused_taps_count": [],
+    "lsr_rl_ysep_fused_prepare_taps": [ctypes.c_void_p, _int, ctypes.c_void_p, _int, _int, ctypes.c_void_p],
+    "lsr_rl_ysep_fused_f32": [
+        _c_f32p, _i64, _i64, _int, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _int, _int, _int,
+        ctypes.c_void_p, _f32, _int, _f32, _stream,
+    ],
     "lsr_dense_taps_count": [_int, _int, _int],
     "lsr_dense_prepare_taps": [ctypes.c_void_p, _int, _int, _int, _int, ctypes.c_void_p],
     "lsr_correlate_zxy_padded_f32": [

@@ -624,6 +624,115 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
   return LSR_OK;
 }
 
+// ---- fused iteration for psf = ky (x) kzx (rl_fused_ysep.hip) --------------------------------------------
+
+extern "C" int lsr_rl_ysep_fused_supported(int pz, int py, int px) {
+  if (pz < 1 || py < 1 || px < 1 || !(pz & 1) || !(py & 1) || !(px & 1)) return 0;
+  const int PZ = lsr::sep_round_taps(pz), PYX = lsr::sep_round_taps(py > px ? py : px);
+  return PZ <= lsr::kYsepMaxPZ && PYX <= lsr::kYsepMaxPYX ? 1 : 0;
+}
+
+extern "C" int lsr_rl_ysep_fused_taps_count(void) { return 256; }
+
+extern "C" int lsr_rl_ysep_fused_prepare_taps(const float* ky_host, int py, const float* kzx_host, int pz, int px,
+                                              float* taps_host) {
+  LSR_REQUIRE_PTR(ky_host);
+  LSR_REQUIRE_PTR(kzx_host);
+  LSR_REQUIRE_PTR(taps_host);
+  if (int rc = check_taps(pz, py, px)) return rc;
+  LSR_REQUIRE(lsr_rl_ysep_fused_supported(pz, py, px), LSR_E_UNSUPPORTED,
+              "no fused ky (x) kzx specialisation for taps (%d,%d,%d) (up to %d z taps, %d in-plane): use "
+              "lsr_correlate_zxy_padded_f32", pz, py, px, lsr::kYsepMaxPZ, lsr::kYsepMaxPYX);
+  const int PZ = lsr::sep_round_taps(pz), PYX = lsr::sep_round_taps(py > px ? py : px);
+  const int oz = (PZ - pz) / 2, oy = (PYX - py) / 2, ox = (PYX - px) / 2;
+  for (int i = 0; i < 256; ++i) taps_host[i] = 0.0f;
+  // two stages of 128 floats: stage 1 (H = correlation with the reversed PSF), stage 2 (H^T, the PSF itself);
+  // (z, x) taps at [c * PZ + j], j = PZ - 1 - a (the order a staged plane feeds the pending planes in), the y
+  // taps at 112 + b; each centred in its compiled extent, zeros elsewhere
+  for (int stage = 0; stage < 2; ++stage) {
+    float* t = taps_host + 128 * stage;
+    for (int a = 0; a < pz; ++a)
+      for (int c = 0; c < px; ++c) {
+        const float v = stage == 0 ? kzx_host[(pz - 1 - a) * px + (px - 1 - c)] : kzx_host[a * px + c];
+        t[(c + ox) * PZ + (PZ - 1 - (a + oz))] = v;
+      }
+    for (int b = 0; b < py; ++b) t[112 + b + oy] = stage == 0 ? ky_host[py - 1 - b] : ky_host[b];
+  }
+  return LSR_OK;
+}
+
+extern "C" int lsr_rl_ysep_fused_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y, float* x_a,
+                                     float* x_b, float* x_out, int64_t Z, int64_t Y, int64_t X, const float* taps,
+                                     int pz, int py, int px, const double* norm_table, float norm_full, int iters,
+                                     float eps, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(y);
+  LSR_REQUIRE_PTR(x_a);
+  LSR_REQUIRE_PTR(x_b);
+  LSR_REQUIRE_PTR(taps);
+  LSR_REQUIRE_PTR(norm_table);
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
+              (long long)X);
+  LSR_REQUIRE(iters >= 1, LSR_E_ARG, "iters %d must be >= 1", iters);
+  LSR_REQUIRE(x_a != x_b, LSR_E_ARG, "x_a and x_b must be distinct");
+  if (int rc = check_taps(pz, py, px)) return rc;
+  LSR_REQUIRE(lsr_rl_ysep_fused_supported(pz, py, px), LSR_E_UNSUPPORTED,
+              "no fused ky (x) kzx specialisation for taps (%d,%d,%d) (up to %d z taps, %d in-plane): use "
+              "lsr_correlate_zxy_padded_f32", pz, py, px, lsr::kYsepMaxPZ, lsr::kYsepMaxPYX);
+  const int PZ = lsr::sep_round_taps(pz), PYX = lsr::sep_round_taps(py > px ? py : px);
+  int64_t ps[4];
+  if (int rc = lsr_sep_padded_shape(Y, X, pz, py, px, ps)) return rc;
+  const int64_t pitch = ps[1], plane = ps[0] * ps[1];
+  const int64_t origin = ps[2] * pitch + ps[3];
+  LSR_REQUIRE(y_pitch >= pitch && y_plane >= ps[0] * y_pitch, LSR_E_SHAPE,
+              "y strides (%lld,%lld) are smaller than the padded shape (%lld rows x %lld) that lsr_sep_padded_shape asks "
+              "for: y must be a zero-haloed padded volume", (long long)y_pitch, (long long)y_plane, (long long)ps[0],
+              (long long)pitch);
+  LSR_REQUIRE(y_pitch % 4 == 0 && y_plane % 4 == 0, LSR_E_ARG,
+              "pitch and plane stride of the padded y must be multiples of 4 floats");
+  const int64_t lim = int64_t(1) << 29;
+  LSR_REQUIRE(plane < lim && y_plane < lim && Y * X < lim && Z < lim, LSR_E_UNSUPPORTED,
+              "plane strides exceed the kernel's 32-bit in-plane offsets");
+
+  lsr::YsepArgs p{};
+  p.y = y; p.y_pitch = static_cast<int>(y_pitch); p.y_plane = y_plane;
+  p.Z = static_cast<int>(Z); p.Y = static_cast<int>(Y); p.X = static_cast<int>(X);
+  p.taps = taps; p.eps = eps;
+  p.pz = pz; p.py = py; p.px = px;
+  p.norm_table = norm_table; p.norm_full = norm_full;
+  p.tiles_x = static_cast<int>(lsr::ceil_div(X, lsr::kSepWideTileX));
+  p.tiles_y = static_cast<int>(lsr::ceil_div(Y, 8 * lsr::ysep_run(PZ)));
+  const int64_t tiles_xy = int64_t(p.tiles_x) * p.tiles_y;
+  plan_fused_split(tiles_xy, Z, PZ, &p.n_full, &p.pieces, &p.z_chunk);
+  const int64_t blocks64 = p.n_full + (tiles_xy - p.n_full) * p.pieces;
+  LSR_REQUIRE(blocks64 < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large", (long long)blocks64);
+  const unsigned blocks = static_cast<unsigned>(blocks64);
+  hipStream_t s = lsr::as_stream(stream);
+
+  float* bufs[2] = {x_a + origin, x_b + origin};  // logical (0,0,0) of the two working volumes
+  for (int it = 0; it < iters; ++it) {
+    const bool from_y = init_from_y && it == 0;
+    const bool last = it + 1 == iters && x_out != nullptr;
+    p.x = from_y ? y : bufs[it & 1];
+    p.pitch = static_cast<int>(from_y ? y_pitch : pitch);
+    p.plane = from_y ? y_plane : plane;
+    p.out = last ? x_out : bufs[(it + 1) & 1];
+    p.out_pitch = static_cast<int>(last ? X : pitch);
+    p.out_plane = last ? Y * X : plane;
+    bool ok = false;
+    switch (PZ) {
+      case 3: ok = lsr::launch_ysep_pz3(PYX, p, blocks, s); break;
+      case 5: ok = lsr::launch_ysep_pz5(PYX, p, blocks, s); break;
+      case 7: ok = lsr::launch_ysep_pz7(PYX, p, blocks, s); break;
+      case 9: ok = lsr::launch_ysep_pz9(PYX, p, blocks, s); break;
+      case 11: ok = lsr::launch_ysep_pz11(PYX, p, blocks, s); break;
+      default: break;
+    }
+    LSR_REQUIRE(ok, LSR_E_UNSUPPORTED, "no fused ky (x) kzx specialisation for taps (%d,%d,%d)", pz, py, px);
+    if (int rc = lsr::launch_status("lsr_rl_ysep_fused_f32")) return rc;
+  }
+  return LSR_OK;
+}
+
 extern "C" int lsr_rl_dense_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y,
                                 int64_t X, const float* psf, const float* psf_flipped, int pz,
                                 int py, int px, const double* norm_table, int iters, float eps,

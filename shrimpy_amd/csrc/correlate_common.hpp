@@ -134,6 +134,27 @@ constexpr bool fused_compiled(int PZ, int PYX) {
   return PZ <= kFusedMaxPZ && PYX <= kFusedMaxPYX && !(PZ >= 15 && PYX >= 11);
 }
 
+// Fused Richardson-Lucy iteration for psf = ky (x) kzx (rl_fused_ysep.hip): volumes as FusedArgs; the taps are a
+// 256-float device block from lsr_rl_ysep_fused_prepare_taps, the normalisation that of the dense kernels.
+struct YsepArgs {
+  const float* x;
+  const float* y;
+  float* out;
+  int64_t plane, y_plane, out_plane;  // z strides (floats)
+  int pitch, y_pitch, out_pitch;      // y strides (floats)
+  int Z, Y, X;
+  const float* taps;
+  float eps;
+  int pz, py, px;                     // the caller's PSF extents (geometry of the norm table)
+  const double* norm_table;           // (pz+1)(py+1)(px+1) prefix sums of the full PSF
+  float norm_full;                    // sum of all taps (interior voxels)
+  int tiles_x, tiles_y;
+  int n_full, pieces, z_chunk;        // work split, as FusedArgs
+};
+// tile rows / 8: the accumulators of both stencils (PZ planes each) must fit 256 VGPRs per thread
+constexpr int ysep_run(int PZ) { return PZ <= 9 ? 4 : 3; }
+constexpr int kYsepMaxPZ = 11, kYsepMaxPYX = 9;
+
 inline int sep_wide_stage_cols(int PX) { return kSepWideTileX - 4 + 4 * ((4 + PX - 1 + 3) / 4); }
 
 // correlate_sep.hip, compiled once per PZ (-DLSR_SEP_PZ=n).  `pyx` is the (square) in-plane tap
@@ -160,6 +181,16 @@ LSR_DECL_FUSED(11)
 LSR_DECL_FUSED(13)
 LSR_DECL_FUSED(15)
 #undef LSR_DECL_FUSED
+
+// rl_fused_ysep.hip, compiled once per PZ (-DLSR_YSEP_PZ=n); pyx in {3,5,7,9}.
+#define LSR_DECL_YSEP(n) \
+  bool launch_ysep_pz##n(int pyx, const YsepArgs& p, unsigned blocks, hipStream_t s);
+LSR_DECL_YSEP(3)
+LSR_DECL_YSEP(5)
+LSR_DECL_YSEP(7)
+LSR_DECL_YSEP(9)
+LSR_DECL_YSEP(11)
+#undef LSR_DECL_YSEP
 
 // correlate_dense.hip, compiled once per PZ (-DLSR_DENSE_PZ=n); pyx in {3,5,7,9}, PZ*pyx*pyx <= 900.
 #define LSR_DECL_DENSE(n) \

@@ -1,0 +1,571 @@
+// One Richardson-Lucy iteration in ONE launch for PSFs that separate along y only, psf = ky (x) kzx:
+//
+//     x_new = x * H^T( y / (H x + eps) ) / (H^T 1)
+//
+// The PSF of an oblique light sheet is tilted in the (z, x) plane and Gaussian along y -- SURVEY.md 8(d)'s
+// secondary PSF, "rotated 30 deg about Y" -- so it has no rank-1 form, but it factors into a y kernel and a
+// dense (z, x) stencil.  The two-launch form (correlate_dense.hip, MODE 2: RATIO, then UPDATE) moves 24
+// bytes per voxel and iteration through HBM; this kernel moves 12 algorithmic bytes (x, y -> x_new): the
+// ratio volume never leaves the CU.  It is rl_fused_sep.hip with the passes of this PSF family:
+//
+//   stage 1  t1 = ky~ * x  (y pass, LDS -> LDS) on the staged plane, then c = kzx~ * t1 on the tile grown by
+//            the in-plane radius C: every staged plane feeds the PZ pending ratio planes at once, PZ * PYX
+//            FMAs per point from a window of 2C+1 neighbouring columns;  ratio = y * rcp(c + eps), zero
+//            outside the volume                                                    -> LDS only
+//   stage 2  t2 = ky * ratio, u = kzx * t2 on the tile;  x_new = x * u * rcp(H^T 1)     -> HBM
+//
+// (~ = reversed taps.)  H^T 1 at border voxels comes from the full PSF's prefix-sum table (staged in LDS),
+// interior voxels use the tap sum -- exactly what the two-launch UPDATE does.  The arithmetic of every
+// voxel (y chain first: product, then FMAs in tap order; (z, x) chain plane by plane in z, tap by tap in x;
+// rcp with one Newton step) is the two-launch kernels', so both forms return bit-identical volumes.
+//
+// Volumes, work split, the LDS ring of staged x planes (global_load_lds_dwordx4), the hand-counted
+// s_waitcnt vmcnt scheme and the per-iteration schedule (two workgroup barriers) are rl_fused_sep.hip's;
+// see its header.  Roofline: 2 * (PZ * PYX + PYX) FMAs per voxel and iteration on ~1.2x the points for
+// stage 1 -- fp32-VALU and HBM time are of the same order, neither hides the other
+// completely.  Algorithmic HBM bytes: 12 per voxel and iteration.
+
+#include "common.hpp"
+#include "correlate_common.hpp"
+
+#ifndef LSR_YSEP_PZ
+#error "compile with -DLSR_YSEP_PZ=<odd tap count along z>"
+#endif
+
+namespace {
+
+using lsr::YsepArgs;
+
+constexpr int kTX = lsr::kSepWideTileX;  // 128
+constexpr int kWaves = 8;
+constexpr int kThreads = 64 * kWaves;
+constexpr int kBand = 8;
+constexpr int kRing = 3;
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <int PZ, int PYX, int RUN>
+struct Geo {
+  static constexpr int C = PYX / 2, CZ = PZ / 2;
+  static constexpr int TY = 8 * RUN;
+  static constexpr int WL = lsr::fused_window_halo(PYX);  // staged columns left/right of the tile
+  static constexpr int AR = TY + 4 * C;                   // staged rows
+  static constexpr int PA = kTX + 2 * WL;                 // staged columns = pitch of A and of B1
+  static constexpr int CH = PA / 4;                       // 16-byte chunks per staged row
+  static constexpr int NCH = AR * CH;
+  static constexpr int SL = cdiv(NCH, kThreads);          // glds per thread and plane
+  static constexpr int ASZ = cdiv(NCH, 64) * 64 * 4;      // floats per ring slot (whole waves of chunks)
+  static constexpr int R1 = TY + 2 * C;                   // stage-1 (ratio) rows
+  static constexpr int RUN1 = cdiv(R1, 8);                // ratio rows per thread
+  static constexpr int NIT1 = R1 * CH;                    // y1 items: one 16-byte chunk of t1 each
+  static constexpr int XIT1 = cdiv(NIT1, kThreads);
+  static constexpr int B1SZ = 8 * RUN1 * PA;              // (rows >= R1: padding the last wave reads, never uses)
+  static constexpr int SH1 = WL - 2 * C;                  // B1 column of ratio column 0's first x tap
+  static constexpr int E = 2 * C;                         // ratio columns beyond the two 64-lane groups
+  static constexpr int NE = R1 * E;
+  static constexpr int EP = cdiv(NE, kThreads);           // edge points per thread
+  static constexpr int PR = kTX + 8;                      // pitch of R and B2 (ratio columns 0 .. 128 + 2C - 1)
+  static constexpr int CH2 = PR / 4;
+  static constexpr int RSZ = 8 * RUN1 * PR;
+  static constexpr int NIT2 = TY * CH2;                   // y2 items
+  static constexpr int XIT2 = cdiv(NIT2, kThreads);
+  static constexpr int B2SZ = TY * PR;
+  static constexpr int NORM = (PZ + 1) * (PYX + 1) * (PYX + 1);   // doubles: prefix sums of the caller's PSF
+  // LDS map (floats): ring | B1 | R | B2 | dump | norm table (doubles)
+  static constexpr int OFF_B1 = kRing * ASZ;
+  static constexpr int OFF_R = OFF_B1 + B1SZ;
+  static constexpr int OFF_B2 = OFF_R + RSZ;
+  static constexpr int OFF_DUMP = OFF_B2 + B2SZ;          // 1 KB: where glds of waves past the window land
+  static constexpr int OFF_NORM = OFF_DUMP + 256;
+  static constexpr int TOTAL = OFF_NORM + 2 * NORM;
+  static constexpr int NY = 2 * RUN1 + EP;                // y loads per thread and iteration
+  static constexpr int NXC = 2 * RUN;                     // x (centre) loads
+  static constexpr int NTAP = PYX * PZ;                   // (z, x) taps of one stage
+  static_assert(TOTAL * 4 <= 160 * 1024, "LDS per workgroup");
+  static_assert(2 * C <= WL && WL <= lsr::kSepOriginCol && 2 * C <= 8, "halo columns");
+  static_assert(SL + 2 * (NY + NXC) <= 63, "vmcnt is a 6-bit counter");
+  static_assert(OFF_B1 % 4 == 0 && OFF_R % 4 == 0 && OFF_B2 % 4 == 0 && OFF_NORM % 2 == 0, "aligned buffers");
+  static_assert(NTAP + PYX <= 128, "a stage's taps fill two registers' lanes");
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float fast_rcp(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ f32x2 splat(float a) { return f32x2{a, a}; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 fast_rcp2(f32x2 d) {
+  const f32x2 r = f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  return pk_fma(pk_fma(-d, r, splat(1.0f)), r, r);
+}
+
+// ---- hand-managed memory operations (as rl_fused_sep.hip) ----------------------------------------
+template <int IMM>
+__device__ __forceinline__ void gload(float& dst, const float* sbase, int voff) {
+  asm volatile("global_load_dword %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void gstore(float* sbase, int voff, float v) {
+  asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void glds_x4(const float* sbase, int voff, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+               : "memory");  // (m0 is a reserved register: hipcc sets it right at each of its own uses)
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+template <int K>
+__device__ __forceinline__ void tie(float (&a)[K]) {
+#pragma unroll
+  for (int i = 0; i < K; ++i) asm volatile("" : "+v"(a[i]));
+}
+// The FMAs of a tap group have no side effect, and their results are next used a whole plane later: left
+// alone, the optimiser sinks them to the end of the loop body -- away from the taps, which were fetched in
+// place (volatile) and would all have to stay live until then.  Passing an accumulator through an empty
+// volatile asm pins its computation where it is written.
+__device__ __forceinline__ void pin(f32x2& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pin(float& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// H^T 1 at (z, y, x) from the prefix-sum table of the caller's pz x py x px PSF (as correlate_dense.hip)
+__device__ float dense_norm(const YsepArgs& p, const double* P, int z, int y, int x) {
+  const int cz = p.pz / 2, cy = p.py / 2, cx = p.px / 2;
+  const int a0 = max(0, cz - z), a1 = min(p.pz, p.Z - z + cz);
+  const int b0 = max(0, cy - y), b1 = min(p.py, p.Y - y + cy);
+  const int c0 = max(0, cx - x), c1 = min(p.px, p.X - x + cx);
+  const int sb = p.px + 1, sa = (p.py + 1) * sb;
+  return static_cast<float>(((P[a1 * sa + b1 * sb + c1] - P[a0 * sa + b1 * sb + c1]) -
+                             (P[a1 * sa + b0 * sb + c1] - P[a0 * sa + b0 * sb + c1])) -
+                            ((P[a1 * sa + b1 * sb + c0] - P[a0 * sa + b1 * sb + c0]) -
+                             (P[a1 * sa + b0 * sb + c0] - P[a0 * sa + b0 * sb + c0])));
+}
+
+template <int PZ, int PYX, int RUN>
+__global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
+  using T = Geo<PZ, PYX, RUN>;
+  constexpr int C = T::C, CZ = T::CZ, TY = T::TY, RUN1 = T::RUN1, EP = T::EP;
+  constexpr int NY = T::NY, NXC = T::NXC, SL = T::SL;
+  __shared__ f32x4 smem4[T::TOTAL / 4 + 1];
+  float* const smem = reinterpret_cast<float*>(smem4);
+  f32x4* const B1_4 = smem4 + T::OFF_B1 / 4;
+  const float* const B1 = smem + T::OFF_B1;
+  float* const Rw = smem + T::OFF_R;
+  const f32x4* const R_4 = smem4 + T::OFF_R / 4;
+  f32x4* const B2_4 = smem4 + T::OFF_B2 / 4;
+  const float* const B2 = smem + T::OFF_B2;
+  double* const s_norm = reinterpret_cast<double*>(smem + T::OFF_NORM);
+  const unsigned lds_base =
+      static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) char*)smem4));
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  {  // border normalisation table (read by the epilogue only; the prologue's barrier publishes it)
+    const int n = (p.pz + 1) * (p.py + 1) * (p.px + 1);
+    for (int i = tid; i < n; i += kThreads) s_norm[i] = p.norm_table[i];
+  }
+
+  // work items, longest first, XCD-contiguous, tiles in bands of 8 rows (rl_fused_sep.hip)
+  auto xcd_contiguous = [](int b, int n) {
+    const int per = n / 8, rem = n % 8;
+    const int xcd = b % 8, idx = b / 8;
+    return xcd * per + (xcd < rem ? xcd : rem) + idx;
+  };
+  const int Z = p.Z, Y = p.Y, X = p.X;
+  int lin, zb, ze;
+  if (static_cast<int>(blockIdx.x) < p.n_full) {
+    lin = xcd_contiguous(blockIdx.x, p.n_full);
+    zb = 0;
+    ze = Z;
+  } else {
+    const int t = xcd_contiguous(blockIdx.x - p.n_full, gridDim.x - p.n_full);
+    const int col = t / p.pieces;
+    lin = p.n_full + col;
+    zb = (t - col * p.pieces) * p.z_chunk;
+    ze = min(zb + p.z_chunk, Z);
+  }
+  const int band = lin / (p.tiles_x * kBand);
+  const int lb = lin - band * (p.tiles_x * kBand);
+  const int band_h = min(kBand, p.tiles_y - band * kBand);
+  const int tx = lb / band_h;
+  const int ty = band * kBand + (lb - tx * band_h);
+  const int x0 = tx * kTX, y0 = ty * TY;
+
+  // taps: two stages of 128 floats (stage 1 = reversed taps, stage 2 = the PSF's): (z, x) taps [c][j],
+  // j = PZ - 1 - a, at 0 .. PYX * PZ - 1, the y taps at 112 .. 112 + PYX - 1.  They live across the lanes of
+  // four VGPRs; a pass pulls each tap into an SGPR with v_readlane right where it is used.
+  float tv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tv[i] = p.taps[64 * i + lane];
+  // (volatile asm, not the builtin: a readlane has no ordering of its own, and instruction selection floats
+  // all PZ * PYX of a pass to the top of the block -- past the scheduling fences -- where they spill)
+#define LSR_TAP(dst, stage, f)                                                                          \
+  asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(dst) : "v"(tv[((stage) * 128 + (f)) >> 6]), "n"(((stage) * 128 + (f)) & 63))
+
+  // ---- staging (glds): chunk e = tid + 512 k of the (AR x PA) window whose first element is (y0 - 2C, x0 - WL)
+  const float* const x_tile = p.x + (static_cast<int64_t>(y0 - 2 * C) * p.pitch + (x0 - T::WL));
+  // (its byte offset inside the plane is recomputed per plane from the thread index -- a few integer operations
+  // against SL registers held across the loop)
+  int tid_v = tid;
+  auto s_voff = [&](int k) {
+    const int e = min(tid_v + k * kThreads, T::NCH - 1);
+    const int r = e / T::CH, c = e - r * T::CH;
+    return (r * p.pitch + 4 * c) * 4;
+  };
+  // ---- stage-1 points.  Main: ratio columns rho = lane + 64 cg, ratio rows wave * RUN1 + m.
+  // Ratio row r <-> tile row r - C; ratio column rho <-> tile column rho - C <-> window column rho - C + WL.
+  const int r1_row0 = wave * RUN1;                                  // scalar
+  const int t1_col = r1_row0 * T::PA + lane + T::SH1;               // B1 float index of the first x tap of (row0, lane)
+  const int r_col = r1_row0 * T::PR + lane;                         // R float index of the same point
+  const bool interior = x0 - C >= 0 && x0 + kTX + C <= X && y0 - C >= 0 && y0 + TY + C <= Y;
+  // edge points: t = tid + 512 e -> (row t / E, ratio column 128 + t % E), kept as ONE packed register per point;
+  // the three offsets derived from it are recomputed where they are used (registers are what this kernel
+  // is short of: two more live values spill, and a spill reload drains the whole load pipeline)
+  int e_rc[EP];              // (row << 16) | column of the edge point in the ratio region
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    const int t = min(tid + e * kThreads, T::NE - 1);
+    const int er = t / T::E, ec = t - er * T::E;
+    e_rc[e] = (er << 16) | (kTX + ec);
+  }
+  auto e_t1 = [&](int e) { return (e_rc[e] >> 16) * T::PA + (e_rc[e] & 0xffff) + T::SH1; };   // B1 index of its first x tap
+  auto e_r = [&](int e) { return (e_rc[e] >> 16) * T::PR + (e_rc[e] & 0xffff); };               // R index
+  auto e_voff = [&](int e) { return ((e_rc[e] >> 16) * p.y_pitch + (e_rc[e] & 0xffff)) * 4; };  // from the y window's first element
+  // ---- stage-2 points: tile columns lane + 64 cg, tile rows wave * RUN + m
+  const int t2_col = (wave * RUN) * T::PR + lane;
+  // rows of a wave differ by a wave-uniform stride: one lane offset register per stream, the row term goes
+  // into the scalar base of each load / store
+  const int lane_off = lane * 4;
+  // in-plane interior test of the epilogue's normalisation (the caller's PSF extents)
+  const int ry = p.py / 2, rx = p.px / 2, rz = p.pz / 2;
+  // every point of the tile has all its in-plane taps inside the volume (wave-uniform: the fast path of the norm)
+  const bool tile_norm_interior = x0 >= rx && x0 + kTX <= X - rx && y0 >= ry && y0 + TY <= Y - ry;
+  const bool ok0 = x0 + lane < X, ok1 = x0 + lane + 64 < X;
+
+  f32x2 acc1[PZ][RUN1], acc2[PZ][RUN];
+  float acc1e[PZ][EP];
+#pragma unroll
+  for (int j = 0; j < PZ; ++j) {
+#pragma unroll
+    for (int i = 0; i < RUN1; ++i) acc1[j][i] = splat(0.0f);
+#pragma unroll
+    for (int i = 0; i < EP; ++i) acc1e[j][i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < RUN; ++i) acc2[j][i] = splat(0.0f);
+  }
+  float yv[2 * RUN1], ye[EP], xc[2 * RUN];
+#pragma unroll
+  for (int i = 0; i < 2 * RUN1; ++i) yv[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < EP; ++i) ye[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 2 * RUN; ++i) xc[i] = 0.0f;
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto clampz = [&](int z) { return min(max(z, 0), Z - 1); };
+  auto issue_glds = [&](int plane, int slot) {  // SL loads
+    const float* src = x_tile + static_cast<int64_t>(clampz(plane)) * p.plane;
+    const unsigned dst = lds_base + (slot * T::ASZ + wave * 64 * 4) * 4;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+      const bool live = wave * 64 + k * kThreads < T::NCH;  // wave-uniform
+      glds_x4(src, s_voff(k), live ? dst + k * kThreads * 16 : lds_base + T::OFF_DUMP * 4);
+    }
+  };
+  const float* const xc_tile = p.x + (static_cast<int64_t>(y0) * p.pitch + x0);
+  const float* const y_tile = p.y + (static_cast<int64_t>(y0 - C) * p.y_pitch + (x0 - C));
+  float* const o_tile = p.out + (static_cast<int64_t>(y0) * p.out_pitch + x0);
+  auto issue_xc = [&](int o) {  // NXC loads: x at the output points of plane o
+    const float* base = xc_tile + (static_cast<int64_t>(clampz(o)) * p.plane + static_cast<int64_t>(wave * RUN) * p.pitch);
+#pragma unroll
+    for (int m = 0; m < RUN; ++m) {
+      gload<0>(xc[m], base + m * p.pitch, lane_off);
+      gload<256>(xc[RUN + m], base + m * p.pitch, lane_off);
+    }
+  };
+  auto issue_y = [&](int q) {  // NY loads: y at the ratio points of plane q
+    const float* base = y_tile + static_cast<int64_t>(clampz(q)) * p.y_plane;
+#pragma unroll
+    for (int m = 0; m < RUN1; ++m) {
+      const float* row = base + min(r1_row0 + m, T::R1 - 1) * p.y_pitch;   // (scalar)
+      gload<0>(yv[m], row, lane_off);
+      gload<256>(yv[RUN1 + m], row, lane_off);
+    }
+#pragma unroll
+    for (int e = 0; e < EP; ++e) gload<0>(ye[e], base, e_voff(e));
+  };
+
+  const int q_lo = max(zb - CZ, 0), q_hi = min(ze - 1 + CZ, Z - 1);  // ratio planes that matter
+  const int p_lo = max(q_lo - CZ, 0);
+  const int p_hi = ze + 2 * CZ;  // inclusive: the iteration that completes output plane ze - 1
+
+  int slot = 0;
+  issue_glds(p_lo, 0);
+  issue_xc(p_lo - 1 - 2 * CZ);
+  issue_y(p_lo - CZ);
+  issue_glds(p_lo + 1, 1);
+  issue_xc(p_lo - 1 - 2 * CZ);
+  issue_y(p_lo - CZ);
+  wait_vm<SL + 2 * (NXC + NY)>();  // this wave's part of plane p_lo has landed
+  lds_barrier();
+
+  for (int pz = p_lo; pz <= p_hi; ++pz) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(tv[i]));  // loop-variant for the optimiser: no hoisting of the taps
+#pragma unroll
+    for (int e = 0; e < EP; ++e) asm volatile("" : "+v"(e_rc[e]));   // ... nor of the offsets derived from e_rc
+    asm volatile("" : "+v"(tid_v));                                  // ... and from the thread index
+    const int qr = pz - 1 - CZ;      // ratio plane in R (written by the previous iteration)
+    const int o = qr - CZ;           // output plane completed by this iteration
+    const int q = pz - CZ;           // ratio plane completed by this iteration
+    const bool x_live = pz < Z && pz <= q_hi + CZ;
+    const bool r_live = qr >= q_lo && qr <= q_hi;
+    const int slot2 = slot >= 1 ? slot - 1 : 2;           // (slot + 2) % 3
+
+    // ---------------- phase A: stage the plane after next; the two y passes ----------------
+    issue_glds(pz + 2, slot2);
+    if (x_live) {
+      float w1y[PYX];
+#pragma unroll
+      for (int b = 0; b < PYX; ++b) LSR_TAP(w1y[b], 0, 112 + b);
+      const f32x4* A_4 = smem4 + slot * (T::ASZ / 4);
+#pragma unroll
+      for (int k = 0; k < T::XIT1; ++k) {
+        const int i = tid + k * kThreads;
+        if (k + 1 < T::XIT1 || i < T::NIT1) {
+          const f32x4 a0 = A_4[i];
+          f32x2 lo = splat(w1y[0]) * f32x2{a0.x, a0.y}, hi = splat(w1y[0]) * f32x2{a0.z, a0.w};
+#pragma unroll
+          for (int b = 1; b < PYX; ++b) {
+            const f32x4 a = A_4[i + b * T::CH];
+            lo = pk_fma(splat(w1y[b]), f32x2{a.x, a.y}, lo);
+            hi = pk_fma(splat(w1y[b]), f32x2{a.z, a.w}, hi);
+          }
+          B1_4[i] = f32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+      }
+    } else {  // a plane outside the volume: zeros
+#pragma unroll
+      for (int k = 0; k < T::XIT1; ++k)
+        if (k + 1 < T::XIT1 || tid + k * kThreads < T::NIT1) B1_4[tid + k * kThreads] = f32x4{0, 0, 0, 0};
+    }
+    if (r_live) {
+      float w2y[PYX];
+#pragma unroll
+      for (int b = 0; b < PYX; ++b) LSR_TAP(w2y[b], 1, 112 + b);
+#pragma unroll
+      for (int k = 0; k < T::XIT2; ++k) {
+        const int i = tid + k * kThreads;
+        if (k + 1 < T::XIT2 || i < T::NIT2) {
+          const f32x4 a0 = R_4[i];
+          f32x2 lo = splat(w2y[0]) * f32x2{a0.x, a0.y}, hi = splat(w2y[0]) * f32x2{a0.z, a0.w};
+#pragma unroll
+          for (int b = 1; b < PYX; ++b) {
+            const f32x4 a = R_4[i + b * T::CH2];
+            lo = pk_fma(splat(w2y[b]), f32x2{a.x, a.y}, lo);
+            hi = pk_fma(splat(w2y[b]), f32x2{a.z, a.w}, hi);
+          }
+          B2_4[i] = f32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < T::XIT2; ++k)
+        if (k + 1 < T::XIT2 || tid + k * kThreads < T::NIT2) B2_4[tid + k * kThreads] = f32x4{0, 0, 0, 0};
+    }
+    lds_barrier();
+
+    // ---------------- phase B ----------------
+    // stage 2: absorb t2 of ratio plane qr into the pending output planes, finish output plane o
+    {
+      // column c of the thread's RUN rows (both column groups) one group ahead of its FMAs; a scheduling
+      // fence per group keeps the PZ taps of ONE group in SGPRs (all PZ * PYX at once spill)
+      const float* base = B2 + t2_col;
+      f32x2 v[RUN], vn[RUN];
+#pragma unroll
+      for (int m = 0; m < RUN; ++m) vn[m] = f32x2{base[m * T::PR], base[m * T::PR + 64]};
+#pragma unroll
+      for (int c = 0; c < PYX; ++c) {
+#pragma unroll
+        for (int m = 0; m < RUN; ++m) v[m] = vn[m];
+        if (c + 1 < PYX) {
+#pragma unroll
+          for (int m = 0; m < RUN; ++m) vn[m] = f32x2{base[m * T::PR + c + 1], base[m * T::PR + c + 1 + 64]};
+        }
+#pragma unroll
+        for (int j = 0; j < PZ; ++j) {
+          float ws;
+          LSR_TAP(ws, 1, c * PZ + j);
+          const f32x2 w = splat(ws);
+#pragma unroll
+          for (int m = 0; m < RUN; ++m) {
+            if (c == 0) acc2[j][m] = j + 1 < PZ ? pk_fma(w, v[m], acc2[j + 1][m]) : w * v[m];
+            else acc2[j][m] = pk_fma(w, v[m], acc2[j][m]);
+            pin(acc2[j][m]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // x(o): requested by the previous iteration; issued since: its y loads, this iteration's glds
+      wait_vm<NY + SL>();
+      tie(xc);
+      if (o >= zb && o < ze) {
+        float* obase = o_tile + (static_cast<int64_t>(o) * p.out_plane + static_cast<int64_t>(wave * RUN) * p.out_pitch);
+        // 1 / (H^T 1) of the thread's 2 * RUN points ([m] = column group 0, [RUN + m] = group 1).  Almost every
+        // point of almost every plane is interior (all taps land inside the volume: the tap sum); the rest
+        // take the prefix-sum table -- one rolled loop, so that its eight LDS reads and their branch exist
+        // once in the code, not once per point.
+        float rn[2 * RUN];
+        const float rfull = fast_rcp(p.norm_full);
+#pragma unroll
+        for (int i = 0; i < 2 * RUN; ++i) rn[i] = rfull;
+        if (!(tile_norm_interior && o >= rz && o < Z - rz)) {   // wave-uniform
+#pragma unroll 1
+          for (int i = 0; i < 2 * RUN; ++i) {
+            const int m = i < RUN ? i : i - RUN;
+            const int gy = min(y0 + wave * RUN + m, Y - 1), gx = min(x0 + lane + (i < RUN ? 0 : 64), X - 1);
+            const bool inside = o >= rz && o < Z - rz && gy >= ry && gy < Y - ry && gx >= rx && gx < X - rx;
+            const float r = fast_rcp(inside ? p.norm_full : dense_norm(p, s_norm, o, gy, gx));
+#pragma unroll
+            for (int k = 0; k < 2 * RUN; ++k) rn[k] = i == k ? r : rn[k];
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < RUN; ++m) {
+          if (y0 + wave * RUN + m < Y) {  // wave-uniform
+            // (x * u) * rcp(H^T 1): the two-launch UPDATE's order
+            if (ok0) gstore<0>(obase + m * p.out_pitch, lane_off, xc[m] * acc2[0][m].x * rn[m]);
+            if (ok1) gstore<256>(obase + m * p.out_pitch, lane_off, xc[RUN + m] * acc2[0][m].y * rn[RUN + m]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the refill reuses xc
+      issue_xc(o + 1);
+    }
+    // stage 1: absorb t1 of x plane pz into the pending ratio planes, finish ratio plane q
+    {
+      const float* base = B1 + t1_col;
+      f32x2 v[RUN1], vn[RUN1];
+      float ve[EP], ven[EP];
+#pragma unroll
+      for (int m = 0; m < RUN1; ++m) vn[m] = f32x2{base[m * T::PA], base[m * T::PA + 64]};
+#pragma unroll
+      for (int e = 0; e < EP; ++e) ven[e] = B1[e_t1(e)];
+#pragma unroll
+      for (int c = 0; c < PYX; ++c) {
+#pragma unroll
+        for (int m = 0; m < RUN1; ++m) v[m] = vn[m];
+#pragma unroll
+        for (int e = 0; e < EP; ++e) ve[e] = ven[e];
+        if (c + 1 < PYX) {
+#pragma unroll
+          for (int m = 0; m < RUN1; ++m) vn[m] = f32x2{base[m * T::PA + c + 1], base[m * T::PA + c + 1 + 64]};
+#pragma unroll
+          for (int e = 0; e < EP; ++e) ven[e] = B1[e_t1(e) + c + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < PZ; ++j) {
+          float ws;
+          LSR_TAP(ws, 0, c * PZ + j);
+          const f32x2 w = splat(ws);
+#pragma unroll
+          for (int m = 0; m < RUN1; ++m) {
+            if (c == 0) acc1[j][m] = j + 1 < PZ ? pk_fma(w, v[m], acc1[j + 1][m]) : w * v[m];
+            else acc1[j][m] = pk_fma(w, v[m], acc1[j][m]);
+            pin(acc1[j][m]);
+          }
+#pragma unroll
+          for (int e = 0; e < EP; ++e) {
+            if (c == 0) acc1e[j][e] = j + 1 < PZ ? fmaf(ws, ve[e], acc1e[j + 1][e]) : ws * ve[e];
+            else acc1e[j][e] = fmaf(ws, ve[e], acc1e[j][e]);
+            pin(acc1e[j][e]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // y(q): requested by the previous iteration; issued since: this iteration's glds and x loads
+      wait_vm<SL + NXC>();
+      tie(yv);
+      tie(ye);
+      const bool q_in = q >= q_lo && q <= q_hi;  // wave-uniform; planes outside are zero
+      if (q_in && interior) {
+#pragma unroll
+        for (int m = 0; m < RUN1; ++m) {
+          const f32x2 r = f32x2{yv[m], yv[RUN1 + m]} * fast_rcp2(acc1[0][m] + splat(p.eps));
+          Rw[r_col + m * T::PR] = r.x;
+          Rw[r_col + m * T::PR + 64] = r.y;
+        }
+#pragma unroll
+        for (int e = 0; e < EP; ++e)
+          if (e + 1 < EP || tid + e * kThreads < T::NE) Rw[e_r(e)] = ye[e] * fast_rcp(acc1e[0][e] + p.eps);
+      } else {
+        // border tiles and planes outside the volume: ratio is zero wherever its point is outside
+        const int gx0 = x0 + lane - C;
+        const bool in0 = q_in && gx0 >= 0 && gx0 < X, in1 = q_in && gx0 + 64 >= 0 && gx0 + 64 < X;
+#pragma unroll
+        for (int m = 0; m < RUN1; ++m) {
+          const int gy = y0 + r1_row0 + m - C;
+          const bool row_in = gy >= 0 && gy < Y && r1_row0 + m < T::R1;  // wave-uniform
+          const f32x2 r = f32x2{yv[m], yv[RUN1 + m]} * fast_rcp2(acc1[0][m] + splat(p.eps));
+          Rw[r_col + m * T::PR] = (row_in && in0) ? r.x : 0.0f;
+          Rw[r_col + m * T::PR + 64] = (row_in && in1) ? r.y : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+          if (e + 1 < EP || tid + e * kThreads < T::NE) {
+            const int gy = y0 + (e_rc[e] >> 16) - C, gx = x0 + (e_rc[e] & 0xffff) - C;
+            const float r = ye[e] * fast_rcp(acc1e[0][e] + p.eps);
+            Rw[e_r(e)] = (q_in && gy >= 0 && gy < Y && gx >= 0 && gx < X) ? r : 0.0f;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the refill reuses yv / ye
+      issue_y(q + 1);
+    }
+    // plane pz+1 (requested one iteration ago); issued since: x, y loads of the previous iteration, this
+    // iteration's glds, x and y loads
+    wait_vm<SL + 2 * (NXC + NY)>();
+    lds_barrier();
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land after the wave has ended
+}
+
+template <int PZ, int PYX>
+bool launch_one(const YsepArgs& p, dim3 grid, hipStream_t s) {
+  constexpr int RUN = lsr::ysep_run(PZ);
+  hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, RUN>), grid, dim3(kThreads), 0, s, p);
+  return true;
+}
+
+}  // namespace
+
+namespace lsr {
+
+#define LSR_CAT2(a, b) a##b
+#define LSR_CAT(a, b) LSR_CAT2(a, b)
+bool LSR_CAT(launch_ysep_pz, LSR_YSEP_PZ)(int pyx, const YsepArgs& p, unsigned blocks, hipStream_t s) {
+  constexpr int PZ = LSR_YSEP_PZ;
+  const dim3 grid(blocks);
+  switch (pyx) {
+    case 3: return launch_one<PZ, 3>(p, grid, s);
+    case 5: return launch_one<PZ, 5>(p, grid, s);
+    case 7: return launch_one<PZ, 7>(p, grid, s);
+    case 9: return launch_one<PZ, 9>(p, grid, s);
+    default: return false;
+  }
+}
+
+}  // namespace lsr

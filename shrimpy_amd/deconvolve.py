@@ -287,6 +287,18 @@ class RichardsonLucyPlan:
             self._norm = None
         if factors is not None:
             self._ysep = None
+        # ky (x) kzx with both factors inside the dense kernel's range: one launch per ITERATION
+        # (rl_fused_ysep.hip) where the extents have a specialisation, else one per correlation
+        self.fused_ysep = False
+        if (self._ysep is not None and self._ysep["fused"] is not None and self._fused_mode == "auto"
+                and _lib.call_value("lsr_rl_ysep_fused_supported", *self._psf.shape)):
+            ky, kzx = ysep
+            ky_c, kzx_c = np.ascontiguousarray(ky, dtype=np.float32), np.ascontiguousarray(kzx, dtype=np.float32)
+            block = np.zeros(_lib.call_value("lsr_rl_ysep_fused_taps_count"), np.float32)
+            _lib.call("lsr_rl_ysep_fused_prepare_taps", ky_c.ctypes.data, len(ky_c), kzx_c.ctypes.data,
+                      kzx_c.shape[0], kzx_c.shape[1], block.ctypes.data)
+            self._ysep["iter_taps"] = dev(block)
+            self.fused_ysep = True
         self._t_pad = None   # y-separable path: the intermediate between the (z, x) and the y pass
         self._ratio = None   # dense path: ratio scratch
         self._x_pad = None   # separable path: zero-haloed working volumes
@@ -313,6 +325,8 @@ class RichardsonLucyPlan:
         if self._psf.separable:
             return "fused" if self.fused else "separable"
         if self._ysep is not None:
+            if self.fused_ysep:
+                return "y-separable (fused)"
             return "y-separable" if self._ysep["fused"] is not None else "y-separable (4 launches)"
         return "dense" if self._psf.taps is not None else "generic"
 
@@ -515,6 +529,27 @@ class RichardsonLucyPlan:
                     ky.data_ptr(), fy.data_ptr(), ps.shape[1], kx.data_ptr(), fx.data_ptr(),
                     ps.shape[2], nz.data_ptr(), ny.data_ptr(), nx.data_ptr(), iterations,
                     ctypes.c_float(eps), stream,
+                )
+            elif self._ysep is not None and self.fused_ysep:
+                # one launch per iteration; y must be a zero-haloed padded volume, as for the separable fused kernel
+                x_pad, ratio_pad = self._scratch()
+                if y_padded is None:
+                    if self._y_pad is None:
+                        self._y_pad = PaddedVolume(self.shape, ps.shape, self.device)
+                    self._y_pad.view.copy_(y)
+                    y_padded = self._y_pad
+                    y_ptr, y_pitch, y_plane = y_padded.logical_ptr(), y_padded.pitch, y_padded.plane
+                    from_y = x0 is None
+                if not from_y:
+                    x_pad.view.copy_(init)
+                f = self._ysep["fused"]
+                if events:
+                    events[0].record()
+                _lib.call(
+                    "lsr_rl_ysep_fused_f32", y_ptr, y_pitch, y_plane, int(from_y), x_pad.full.data_ptr(),
+                    ratio_pad.full.data_ptr(), x.data_ptr(), z, yy, xx, self._ysep["iter_taps"].data_ptr(),
+                    ps.shape[0], ps.shape[1], ps.shape[2], f["norm_table"].data_ptr(), ctypes.c_float(f["norm_full"]),
+                    iterations, ctypes.c_float(eps), stream,
                 )
             elif self._ysep is not None:
                 self._iterate_ysep(y_ptr, y_pitch, y_plane, init, x, iterations, eps, stream, events)

@@ -983,12 +983,17 @@ def test_rl_y_separable_psf_takes_the_stencil_plus_y_pass_and_matches_dense(devi
     rng = np.random.default_rng(44)
     y = (rng.poisson(100 + 3000 * (rng.random(shape) > 0.999)).astype(np.float32))
     auto = RichardsonLucyPlan(shape, psf, device)
+    two = RichardsonLucyPlan(shape, psf, device, fused="never")
     dense = RichardsonLucyPlan(shape, psf, device, separable="never")
-    assert (auto.path, dense.path) == ("y-separable", "dense")
+    assert (auto.path, two.path, dense.path) == ("y-separable (fused)", "y-separable", "dense")
     a, b = auto(_t(y, device), iterations=8), dense(_t(y, device), iterations=8)
     ref = o.richardson_lucy(y, psf, 8)
     for got in (a, b):
         _close(got.cpu().numpy(), ref, 2e-4, 1e-4)
+    # one launch per iteration == one launch per correlation, bit for bit (odd and even iteration counts:
+    # the result sits in either working volume)
+    for n in (1, 2, 8):
+        assert torch.equal(auto(_t(y, device), iterations=n), two(_t(y, device), iterations=n)), n
     # x0, a padded y written by a producer, zero iterations, one-plane and thin volumes
     x0 = _t(np.full(shape, 50.0, np.float32), device)
     _close(auto(_t(y, device), iterations=3, x0=x0).cpu().numpy(), o.richardson_lucy(y, psf, 3, x0=x0.cpu().numpy()),
@@ -999,11 +1004,15 @@ def test_rl_y_separable_psf_takes_the_stencil_plus_y_pass_and_matches_dense(devi
     for thin in ((1, 9, 40), (3, 2, 5), (12, 33, 65)):
         yt = (rng.random(thin) * 50 + 1).astype(np.float32)
         p = RichardsonLucyPlan(thin, psf, device)
-        assert p.path == "y-separable"
-        _close(p(_t(yt, device), iterations=2).cpu().numpy(), o.richardson_lucy(yt, psf, 2), 2e-4, 1e-4)
+        assert p.path == "y-separable (fused)"
+        got = p(_t(yt, device), iterations=2)
+        _close(got.cpu().numpy(), o.richardson_lucy(yt, psf, 2), 2e-4, 1e-4)
+        assert torch.equal(got, RichardsonLucyPlan(thin, psf, device, fused="never")(_t(yt, device), iterations=2))
 
 
 def test_rl_y_separable_random_psf_shapes(device):
+    import torch
+
     from shrimpy_amd.deconvolve import RichardsonLucyPlan
 
     rng = np.random.default_rng(45)
@@ -1016,9 +1025,14 @@ def test_rl_y_separable_random_psf_shapes(device):
         shape = (int(rng.integers(1, 30)), int(rng.integers(1, 80)), int(rng.integers(1, 200)))
         y = (rng.random(shape) * 80 + 1).astype(np.float32)
         plan = RichardsonLucyPlan(shape, psf, device)
-        assert plan.path == ("y-separable" if py <= 9 else "y-separable (4 launches)"), (case, psf.shape)
+        assert plan.path == ("y-separable (fused)" if py <= 9 else "y-separable (4 launches)"), (case, psf.shape)
         iters = int(rng.integers(1, 4))
-        _close(plan(_t(y, device), iterations=iters).cpu().numpy(), o.richardson_lucy(y, psf, iters), 2e-4, 1e-4)
+        got = plan(_t(y, device), iterations=iters)
+        _close(got.cpu().numpy(), o.richardson_lucy(y, psf, iters), 2e-4, 1e-4)
+        if py <= 9:   # every compiled extent: the fused iteration is the two-launch form, bit for bit
+            two = RichardsonLucyPlan(shape, psf, device, fused="never")
+            assert two.path == "y-separable"
+            assert torch.equal(got, two(_t(y, device), iterations=iters)), (case, psf.shape, shape)
 
 
 def test_zxy_entry_rejects_what_it_does_not_cover(device):

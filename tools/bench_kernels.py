@@ -223,10 +223,10 @@ def _rl(args, torch, dev, g, bench, RichardsonLucyPlan, oshape):
         torch.cuda.synchronize()
         plan(y, iterations=iters, events=ev)
         torch.cuda.synchronize()
-        launches = {"fused": 1, "y-separable (4 launches)": 4}.get(plan.path, 2) * iters
+        launches = {"fused": 1, "y-separable (fused)": 1, "y-separable (4 launches)": 4}.get(plan.path, 2) * iters
         ms = ev[0].elapsed_time(ev[1]) / launches
         nbytes = 12.0 * y.numel()
-        taps = {"fused": 46, "separable": 23, "y-separable": 70}.get(plan.path, 441)
+        taps = {"fused": 46, "separable": 23, "y-separable": 70, "y-separable (fused)": 140}.get(plan.path, 441)
         plan.release()
         print(json.dumps({"kernel": f"RL launch, {name}", "path": plan.path, "grid": oshape, "ms_per_launch": ms,
                           "algorithmic_GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / 8000,
