@@ -202,11 +202,11 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(AffineArgs p) {
 }  // namespace
 
 namespace lsr {
-// affine_planar.hip: z-decoupled maps in constant mode; false = not applicable
+// affine_planar.hip: z-decoupled maps, either border rule; false = not applicable
 // (pitch / plane: source strides in floats; dense = Xi, Yi * Xi)
 bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane,
                           float* out, int64_t Zo, int64_t Yo, int64_t Xo, int64_t opitch, int64_t oplane,
-                          const double M[12], float cval, bool f32, hipStream_t s);
+                          const double M[12], float cval, bool f32, bool grid, hipStream_t s);
 bool affine_planar_geometry(int64_t Yi, int64_t Xi, int64_t pitch, const double M[12], int* box_y, int* box_x,
                             int* slots, int64_t* lds_bytes);
 // affine_box.hip: any map whose per-block source box fits in LDS (z-coupled maps included),
@@ -223,7 +223,8 @@ extern "C" int lsr_affine_kernel_choice(int64_t Yi, int64_t Xi, const double M[1
   if (M == nullptr) return 0;
   int by, bx, sl;
   int64_t lds;
-  return (mode & ~LSR_MODE_F32_INTERP) == LSR_MODE_CONSTANT &&
+  const int border = mode & ~LSR_MODE_F32_INTERP;
+  return (border == LSR_MODE_CONSTANT || border == LSR_MODE_GRID_CONSTANT) &&
                  lsr::affine_planar_geometry(Yi, Xi, Xi, M, &by, &bx, &sl, &lds)
              ? 1
              : 0;
@@ -231,11 +232,12 @@ extern "C" int lsr_affine_kernel_choice(int64_t Yi, int64_t Xi, const double M[1
 
 extern "C" int lsr_affine_path(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int mode) {
   if (M == nullptr) return 0;
-  if ((mode & ~LSR_MODE_F32_INTERP) != LSR_MODE_CONSTANT) return 0;
+  const int border = mode & ~LSR_MODE_F32_INTERP;
+  if (border != LSR_MODE_CONSTANT && border != LSR_MODE_GRID_CONSTANT) return 0;
   int a, b, c;
   int64_t lds;
   if (lsr::affine_planar_geometry(Yi, Xi, Xi, M, &a, &b, &c, &lds)) return 1;
-  if (lsr::affine_box_geometry(Zi, Yi, Xi, Xi, Yi * Xi, M, &a, &b, &c, &lds)) return 2;
+  if (border == LSR_MODE_CONSTANT && lsr::affine_box_geometry(Zi, Yi, Xi, Xi, Yi * Xi, M, &a, &b, &c, &lds)) return 2;
   return 0;
 }
 
@@ -243,11 +245,12 @@ extern "C" int lsr_affine_path(int64_t Zi, int64_t Yi, int64_t Xi, const double 
 extern "C" int lsr_affine_path_pitched(int64_t Zi, int64_t Yi, int64_t Xi, int64_t in_pitch, int64_t in_plane,
                                        const double M[12], int mode) {
   if (M == nullptr) return 0;
-  if ((mode & ~LSR_MODE_F32_INTERP) != LSR_MODE_CONSTANT) return 0;
+  const int border = mode & ~LSR_MODE_F32_INTERP;
+  if (border != LSR_MODE_CONSTANT && border != LSR_MODE_GRID_CONSTANT) return 0;
   int a, b, c;
   int64_t lds;
   if (in_plane % 4 == 0 && lsr::affine_planar_geometry(Yi, Xi, in_pitch, M, &a, &b, &c, &lds)) return 1;
-  if (lsr::affine_box_geometry(Zi, Yi, Xi, in_pitch, in_plane, M, &a, &b, &c, &lds)) return 2;
+  if (border == LSR_MODE_CONSTANT && lsr::affine_box_geometry(Zi, Yi, Xi, in_pitch, in_plane, M, &a, &b, &c, &lds)) return 2;
   return 0;
 }
 
@@ -307,11 +310,13 @@ int affine_impl(const char* what, const float* in, int64_t Zi, int64_t Yi, int64
   for (int i = 0; i < 12; ++i)
     LSR_REQUIRE(M[i] == M[i] && M[i] - M[i] == 0.0, LSR_E_ARG, "M[%d] is not finite", i);
 
-  if (mode == LSR_MODE_CONSTANT && in != out &&
+  // the LDS-staged kernels: z-decoupled maps under either border rule, z-coupled ones under "constant"
+  if (in != out &&
       (lsr::launch_affine_planar(in, Zi, Yi, Xi, pitch, plane, out, Zo, Yo, Xo, opitch, oplane, M, cval, f32,
-                                 lsr::as_stream(stream)) ||
-       lsr::launch_affine_box(in, Zi, Yi, Xi, pitch, plane, out, Zo, Yo, Xo, opitch, oplane, M, cval, f32,
-                              lsr::as_stream(stream))))
+                                 mode == LSR_MODE_GRID_CONSTANT, lsr::as_stream(stream)) ||
+       (mode == LSR_MODE_CONSTANT &&
+        lsr::launch_affine_box(in, Zi, Yi, Xi, pitch, plane, out, Zo, Yo, Xo, opitch, oplane, M, cval, f32,
+                               lsr::as_stream(stream)))))
     return lsr::launch_status(what);
 
   AffineArgs p;

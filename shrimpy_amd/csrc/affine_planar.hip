@@ -6,8 +6,8 @@
 //   M =  | 0  b  c  ty |        (y_in, x_in) depend on (yo, xo) only.
 //        | 0  d  e  tx |
 //
-// Replaces the same scipy.ndimage.affine_transform(order=1, mode="constant") call as affine.hip
-// (which keeps every other matrix and the grid-constant mode), bit for bit.
+// Replaces the same scipy.ndimage.affine_transform(order=1, mode="constant" | "grid-constant") call as
+// affine.hip (which keeps the matrices neither this kernel nor affine_box.hip takes), bit for bit.
 //
 // Why a second kernel: the general one spends ~170 instructions per voxel, half of them fp64
 // coordinate / weight arithmetic, and gathers its 8 taps through the texture-address path
@@ -81,7 +81,11 @@ __device__ __forceinline__ double plane_coord(double yo, double xo, double m1, d
   return lsr::dadd(lsr::dadd(lsr::dmul(yo, m1), lsr::dmul(xo, m2)), shift);
 }
 
-template <bool F32>
+// GRID: scipy's mode="grid-constant" -- the volume is continued with cval, so a tap outside it contributes
+// cval times its weight and samples up to one voxel outside still blend (mode="constant" drops the whole
+// sample).  The box then starts at source index -1 at the earliest: row / column 0 of the box may stand for
+// index -1 (a duplicate of index 0 in LDS, replaced by cval through the tap's flag).
+template <bool F32, bool GRID>
 __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p) {  // (two workgroups per CU: <= 128 VGPRs)
   extern __shared__ f32x4 smem4[];
   const float* const smem = reinterpret_cast<const float*>(smem4);
@@ -128,8 +132,9 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
                                     p.b, p.c, p.ty);
   const double cx_min = plane_coord(static_cast<double>(p.d < 0.0 ? y1 : y0), static_cast<double>(p.e < 0.0 ? x1 : x0),
                                     p.d, p.e, p.tx);
-  const int ylo = static_cast<int>(fmin(fmax(floor(cy_min), 0.0), static_cast<double>(p.Yi - 1)));
-  const int xlo = static_cast<int>(fmin(fmax(floor(cx_min), 0.0), static_cast<double>(p.Xi - 1))) & ~3;
+  constexpr double kLow = GRID ? -1.0 : 0.0;     // first source index a tap may carry
+  const int ylo = static_cast<int>(fmin(fmax(floor(cy_min), kLow), static_cast<double>(p.Yi - 1)));
+  const int xlo = static_cast<int>(fmin(fmax(floor(cx_min), kLow), static_cast<double>(p.Xi - 1))) & ~3;   // (-1 -> -4)
   const int box_x = p.box_x, box_y = p.box_y;
   const int slot_floats = (box_y * box_x + 255) & ~255;  // whole waves of 16-byte chunks
 
@@ -139,27 +144,39 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
   // staging put there is a duplicate of in-volume data -- the same zero product (finite inputs).  So
   // the four in-plane taps of a source plane are two ds_read2_b32 at a fixed row stride.
   int idx00[kPts];        // LDS byte offset of (iy0, ix0) inside a slot
-  bool ok[kPts];          // pixel inside the output and its coordinate inside the moving plane
+  bool ok[kPts];          // pixel inside the output and (mode constant) its coordinate inside the moving plane
+  unsigned outside[kPts]; // GRID: taps that lie outside the plane -- bit 0: row iy0, 1: row iy0 + 1, 2: column ix0, 3: ix0 + 1
   double wy0[kPts], wy1[kPts], wx0[kPts], wx1[kPts];
 #pragma unroll
   for (int i = 0; i < kPts; ++i) {
     const int yo = y0 + wave + 8 * (i >> 1), xo = x0 + lane + 64 * (i & 1);
     const double cy = plane_coord(static_cast<double>(yo), static_cast<double>(xo), p.b, p.c, p.ty);
     const double cx = plane_coord(static_cast<double>(yo), static_cast<double>(xo), p.d, p.e, p.tx);
-    const bool inside = yo < p.Yo && xo < p.Xo && !(cy < 0.0) && !(cy > static_cast<double>(p.Yi - 1)) &&
+    const bool in_output = yo < p.Yo && xo < p.Xo;
+    const bool inside = in_output && !(cy < 0.0) && !(cy > static_cast<double>(p.Yi - 1)) &&
                         !(cx < 0.0) && !(cx > static_cast<double>(p.Xi - 1));
     const double fy = floor(cy), fx = floor(cx);
     const double ry = cy - fy, rx = cx - fx;
     wy0[i] = 1.0 - ry; wy1[i] = 1.0 - wy0[i];
     wx0[i] = 1.0 - rx; wx1[i] = 1.0 - wx0[i];
     int iy0 = 0, ix0 = 0;
-    if (inside) {
+    outside[i] = 0;
+    if constexpr (GRID) {
+      // lower neighbours clamped to [-2, n + 1] (beyond that nothing of the sample is inside and the
+      // indices do not matter); the box covers the taps of every sample that touches the plane
+      const int sy = static_cast<int>(fmin(fmax(fy, -2.0), static_cast<double>(p.Yi) + 1.0));
+      const int sx = static_cast<int>(fmin(fmax(fx, -2.0), static_cast<double>(p.Xi) + 1.0));
+      outside[i] = (sy < 0 || sy >= p.Yi ? 1u : 0u) | (sy + 1 < 0 || sy + 1 >= p.Yi ? 2u : 0u) |
+                   (sx < 0 || sx >= p.Xi ? 4u : 0u) | (sx + 1 < 0 || sx + 1 >= p.Xi ? 8u : 0u);
+      iy0 = min(max(sy - ylo, 0), box_y - 2);
+      ix0 = min(max(sx - xlo, 0), box_x - 2);
+    } else if (inside) {
       // the box covers every inside pixel's taps by construction (host sizes it from |b|,|c|,|d|,|e|)
       iy0 = min(max(static_cast<int>(fy) - ylo, 0), box_y - 2);
       ix0 = min(max(static_cast<int>(fx) - xlo, 0), box_x - 2);
     }
     idx00[i] = (iy0 * box_x + ix0) * 4;
-    ok[i] = inside;
+    ok[i] = GRID ? in_output : inside;
   }
   const bool tile_full = y0 + kTY <= p.Yo && x0 + kTX <= p.Xo;   // every thread stores all its pixels
   const bool in_out[kPts / 2] = {y0 + wave < p.Yo, y0 + wave + 8 < p.Yo, y0 + wave + 16 < p.Yo, y0 + wave + 24 < p.Yo};
@@ -174,8 +191,8 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
   for (int k = 0; k < kMaxLoads; ++k) {
     const int e = min(tid + k * kThreads, n_chunks - 1);
     const int r = e / chunks_x, c4 = e - r * chunks_x;
-    const int gy = min(ylo + r, p.Yi - 1);            // rows / columns past the volume: duplicates
-    const int gx = min(xlo + 4 * c4, ((p.Xi + 3) & ~3) - 4);
+    const int gy = min(max(ylo + r, 0), p.Yi - 1);    // rows / columns past the volume: duplicates
+    const int gx = min(max(xlo + 4 * c4, 0), ((p.Xi + 3) & ~3) - 4);
     s_voff[k] = (gy * p.pitch + gx) * 4;
   }
   const int n_loads = (n_chunks + kThreads - 1) / kThreads;  // scalar
@@ -191,14 +208,25 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
   int resident[4] = {-1, -1, -1, -1};
   const int slots = p.slots;
   auto slot_of = [&](int zs) { return zs % slots; };
-  auto z_taps = [&](int zo, int& z0, int& z1, double& wz0, double& wz1) {
+  // source planes and weights of output plane zo; false (mode constant only): the plane is cval.  GRID:
+  // `zout` bit 0 / 1 = the lower / upper source plane lies outside the volume (z0 / z1 are then clamped
+  // stand-ins whose values are replaced by cval)
+  auto z_taps = [&](int zo, int& z0, int& z1, double& wz0, double& wz1, unsigned& zout) {
+    zout = 0;
     const double cz = lsr::dadd(lsr::dmul(static_cast<double>(zo), p.a), p.tz);
-    if (cz < 0.0 || cz > static_cast<double>(p.Zi - 1)) return false;
+    if (!GRID && (cz < 0.0 || cz > static_cast<double>(p.Zi - 1))) return false;
     const double fz = floor(cz), rz = cz - fz;
     wz0 = 1.0 - rz;
     wz1 = 1.0 - wz0;
-    z0 = static_cast<int>(fz);
-    z1 = min(z0 + 1, p.Zi - 1);
+    if constexpr (GRID) {
+      const int sz = static_cast<int>(fmin(fmax(fz, -2.0), static_cast<double>(p.Zi) + 1.0));
+      zout = (sz < 0 || sz >= p.Zi ? 1u : 0u) | (sz + 1 < 0 || sz + 1 >= p.Zi ? 2u : 0u);
+      z0 = min(max(sz, 0), p.Zi - 1);
+      z1 = min(max(sz + 1, 0), p.Zi - 1);
+    } else {
+      z0 = static_cast<int>(fz);
+      z1 = min(z0 + 1, p.Zi - 1);
+    }
     return true;
   };
   auto request = [&](int zs) {  // make plane zs resident (issue its DMA if it is not)
@@ -217,7 +245,8 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
   {  // prologue: the first output plane's sources
     int z0, z1;
     double w0, w1;
-    if (zo_begin < zo_end && z_taps(zo_begin, z0, z1, w0, w1)) {
+    unsigned zf;
+    if (zo_begin < zo_end && z_taps(zo_begin, z0, z1, w0, w1, zf)) {
       request(z0);
       request(z1);
     }
@@ -226,7 +255,8 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
   for (int zo = zo_begin; zo < zo_end; ++zo) {
     int z0 = 0, z1 = 0;
     double wz0 = 0.0, wz1 = 0.0;
-    const bool z_in = z_taps(zo, z0, z1, wz0, wz1);
+    unsigned zout = 0;
+    const bool z_in = z_taps(zo, z0, z1, wz0, wz1, zout);
     // this plane's sources were requested one iteration ago: wait, publish.  Vector-memory operations
     // retire in issue order and stores share the counter: behind those DMAs this wave issued only the
     // previous plane's stores -- exactly kPts of them in a tile that lies wholly inside the output -- so
@@ -239,7 +269,8 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
     {
       int n0, n1;
       double u0, u1;
-      if (zo + 1 < zo_end && z_taps(zo + 1, n0, n1, u0, u1)) {
+      unsigned nf;
+      if (zo + 1 < zo_end && z_taps(zo + 1, n0, n1, u0, u1, nf)) {
         request(n0);
         request(n1);
       }
@@ -265,6 +296,21 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
         v[k][3] = *reinterpret_cast<const f32x2*>(s1 + o + row_b);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (GRID) {   // taps outside the volume carry cval (flags: in-plane per pixel, z per plane)
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+          const unsigned f = outside[h + k];
+          const bool r0 = f & 1u, r1 = f & 2u, c0 = f & 4u, c1 = f & 8u, p0 = zout & 1u, p1 = zout & 2u;
+          v[k][0].x = (p0 || r0 || c0) ? p.cval : v[k][0].x;
+          v[k][0].y = (p0 || r0 || c1) ? p.cval : v[k][0].y;
+          v[k][1].x = (p0 || r1 || c0) ? p.cval : v[k][1].x;
+          v[k][1].y = (p0 || r1 || c1) ? p.cval : v[k][1].y;
+          v[k][2].x = (p1 || r0 || c0) ? p.cval : v[k][2].x;
+          v[k][2].y = (p1 || r0 || c1) ? p.cval : v[k][2].y;
+          v[k][3].x = (p1 || r1 || c0) ? p.cval : v[k][3].x;
+          v[k][3].y = (p1 || r1 || c1) ? p.cval : v[k][3].y;
+        }
+      }
       float res[G];
 #pragma unroll
       for (int k = 0; k < G; ++k) {
@@ -339,7 +385,7 @@ bool affine_planar_geometry(int64_t Yi, int64_t Xi, int64_t pitch, const double 
 
 bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane,
                           float* out, int64_t Zo, int64_t Yo, int64_t Xo, int64_t opitch, int64_t oplane,
-                          const double M[12], float cval, bool f32, hipStream_t s) {
+                          const double M[12], float cval, bool f32, bool grid, hipStream_t s) {
   int box_y, box_x, slots;
   int64_t lds_bytes;
   if (plane % 4 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return false;
@@ -378,9 +424,11 @@ bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, i
   if (padded >= (int64_t(1) << 30)) return false;
   p.per_xcd = static_cast<int>(ceil_div(padded, 8));
   const int64_t blocks = f32 ? tiles * ceil_div(Zo, chunk) : int64_t(p.per_xcd) * 8;
-  static std::atomic<uint64_t> lds_allowed[2] = {{0}, {0}};
-  auto kernel = f32 ? affine_planar_kernel<true> : affine_planar_kernel<false>;
-  if (lsr::allow_dynamic_lds(reinterpret_cast<const void*>(kernel), 150 * 1024, lds_allowed[f32], "affine_planar_kernel") != LSR_OK)
+  static std::atomic<uint64_t> lds_allowed[4] = {{0}, {0}, {0}, {0}};
+  auto kernel = f32 ? (grid ? affine_planar_kernel<true, true> : affine_planar_kernel<true, false>)
+                    : (grid ? affine_planar_kernel<false, true> : affine_planar_kernel<false, false>);
+  if (lsr::allow_dynamic_lds(reinterpret_cast<const void*>(kernel), 150 * 1024, lds_allowed[2 * grid + f32],
+                             "affine_planar_kernel") != LSR_OK)
     return false;   // the caller runs the gather kernel
   hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
                      static_cast<size_t>(lds_bytes), s, p);

@@ -70,6 +70,9 @@ struct Geo {
   static constexpr int NIT2 = TY * CH2;                   // y2 items
   static constexpr int XIT2 = cdiv(NIT2, kThreads);
   static constexpr int B2SZ = TY * PR;
+  static constexpr int RY = 3;                            // output rows per y-pass item
+  static constexpr int NG1 = cdiv(R1, RY) * CH;           // y1 items
+  static constexpr int NG2 = cdiv(TY, RY) * CH2;          // y2 items
   static constexpr int NORM = (PZ + 1) * (PYX + 1) * (PYX + 1);   // doubles: prefix sums of the caller's PSF
   // LDS map (floats): ring | B1 | R | B2 | dump | norm table (doubles)
   static constexpr int OFF_B1 = kRing * ASZ;
@@ -149,6 +152,32 @@ __device__ float dense_norm(const YsepArgs& p, const double* P, int z, int y, in
                              (P[a1 * sa + b0 * sb + c1] - P[a0 * sa + b0 * sb + c1])) -
                             ((P[a1 * sa + b1 * sb + c0] - P[a0 * sa + b1 * sb + c0]) -
                              (P[a1 * sa + b0 * sb + c0] - P[a0 * sa + b0 * sb + c0])));
+}
+
+// dst[r][g] = sum_b w[b] * src[r + b][g] for rows r < rows and 16-byte chunks g < chunks (both arrays `chunks`
+// wide); item i -> (row group i / chunks, chunk i % chunks), `items` = ceil(rows / RY) * chunks of them.
+// Per output the chain is w[0] * v, then FMAs in tap order.
+template <int RY, int PYX>
+__device__ __forceinline__ void ypass(const f32x4* src, f32x4* dst, int chunks, int rows, int items, const float (&w)[PYX],
+                                      int tid) {
+  for (int i = tid; i < items; i += kThreads) {   // (one round, or two for the widest windows)
+    const int rg = i / chunks, g = i - rg * chunks;
+    const int r0 = rg * RY;
+    const f32x4* in = src + r0 * chunks + g;
+    f32x4 a[RY + PYX - 1];
+#pragma unroll
+    for (int k = 0; k < RY + PYX - 1; ++k) a[k] = in[k * chunks];   // (rows past the last one: stale LDS, results dropped)
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      f32x2 lo = splat(w[0]) * f32x2{a[r].x, a[r].y}, hi = splat(w[0]) * f32x2{a[r].z, a[r].w};
+#pragma unroll
+      for (int b = 1; b < PYX; ++b) {
+        lo = pk_fma(splat(w[b]), f32x2{a[r + b].x, a[r + b].y}, lo);
+        hi = pk_fma(splat(w[b]), f32x2{a[r + b].z, a[r + b].w}, hi);
+      }
+      if (r0 + r < rows) dst[(r0 + r) * chunks + g] = f32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+  }
 }
 
 template <int PZ, int PYX, int RUN>
@@ -336,26 +365,13 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
 
     // ---------------- phase A: stage the plane after next; the two y passes ----------------
     issue_glds(pz + 2, slot2);
+    // y passes, LDS -> LDS: an item is one 16-byte column chunk of RY consecutive output rows -- RY + 2C input
+    // chunks instead of RY * (2C + 1) (these passes are what the LDS pipe spends the phase on)
     if (x_live) {
       float w1y[PYX];
 #pragma unroll
       for (int b = 0; b < PYX; ++b) LSR_TAP(w1y[b], 0, 112 + b);
-      const f32x4* A_4 = smem4 + slot * (T::ASZ / 4);
-#pragma unroll
-      for (int k = 0; k < T::XIT1; ++k) {
-        const int i = tid + k * kThreads;
-        if (k + 1 < T::XIT1 || i < T::NIT1) {
-          const f32x4 a0 = A_4[i];
-          f32x2 lo = splat(w1y[0]) * f32x2{a0.x, a0.y}, hi = splat(w1y[0]) * f32x2{a0.z, a0.w};
-#pragma unroll
-          for (int b = 1; b < PYX; ++b) {
-            const f32x4 a = A_4[i + b * T::CH];
-            lo = pk_fma(splat(w1y[b]), f32x2{a.x, a.y}, lo);
-            hi = pk_fma(splat(w1y[b]), f32x2{a.z, a.w}, hi);
-          }
-          B1_4[i] = f32x4{lo.x, lo.y, hi.x, hi.y};
-        }
-      }
+      ypass<T::RY, PYX>(smem4 + slot * (T::ASZ / 4), B1_4, T::CH, T::R1, T::NG1, w1y, tid);
     } else {  // a plane outside the volume: zeros
 #pragma unroll
       for (int k = 0; k < T::XIT1; ++k)
@@ -365,21 +381,7 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
       float w2y[PYX];
 #pragma unroll
       for (int b = 0; b < PYX; ++b) LSR_TAP(w2y[b], 1, 112 + b);
-#pragma unroll
-      for (int k = 0; k < T::XIT2; ++k) {
-        const int i = tid + k * kThreads;
-        if (k + 1 < T::XIT2 || i < T::NIT2) {
-          const f32x4 a0 = R_4[i];
-          f32x2 lo = splat(w2y[0]) * f32x2{a0.x, a0.y}, hi = splat(w2y[0]) * f32x2{a0.z, a0.w};
-#pragma unroll
-          for (int b = 1; b < PYX; ++b) {
-            const f32x4 a = R_4[i + b * T::CH2];
-            lo = pk_fma(splat(w2y[b]), f32x2{a.x, a.y}, lo);
-            hi = pk_fma(splat(w2y[b]), f32x2{a.z, a.w}, hi);
-          }
-          B2_4[i] = f32x4{lo.x, lo.y, hi.x, hi.y};
-        }
-      }
+      ypass<T::RY, PYX>(R_4, B2_4, T::CH2, TY, T::NG2, w2y, tid);
     } else {
 #pragma unroll
       for (int k = 0; k < T::XIT2; ++k)
@@ -393,21 +395,24 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
       // column c of the thread's RUN rows (both column groups) one group ahead of its FMAs; a scheduling
       // fence per group keeps the PZ taps of ONE group in SGPRs (all PZ * PYX at once spill)
       const float* base = B2 + t2_col;
-      f32x2 v[RUN], vn[RUN];
+      f32x2 vb[2][RUN];   // two register sets, indexed by the (compile-time) parity of c: no copies
 #pragma unroll
-      for (int m = 0; m < RUN; ++m) vn[m] = f32x2{base[m * T::PR], base[m * T::PR + 64]};
+      for (int m = 0; m < RUN; ++m) vb[0][m] = f32x2{base[m * T::PR], base[m * T::PR + 64]};
 #pragma unroll
       for (int c = 0; c < PYX; ++c) {
-#pragma unroll
-        for (int m = 0; m < RUN; ++m) v[m] = vn[m];
+        f32x2 (&v)[RUN] = vb[c & 1];
         if (c + 1 < PYX) {
 #pragma unroll
-          for (int m = 0; m < RUN; ++m) vn[m] = f32x2{base[m * T::PR + c + 1], base[m * T::PR + c + 1 + 64]};
+          for (int m = 0; m < RUN; ++m) vb[(c + 1) & 1][m] = f32x2{base[m * T::PR + c + 1], base[m * T::PR + c + 1 + 64]};
         }
+        // (the tap of plane j + 1 is fetched ahead of the FMAs of plane j: a VALU-written SGPR needs a wait
+        // state before a VALU reads it, which the FMAs in between provide)
+        float wnext;
+        LSR_TAP(wnext, 1, c * PZ);
 #pragma unroll
         for (int j = 0; j < PZ; ++j) {
-          float ws;
-          LSR_TAP(ws, 1, c * PZ + j);
+          const float ws = wnext;
+          if (j + 1 < PZ) LSR_TAP(wnext, 1, c * PZ + j + 1);
           const f32x2 w = splat(ws);
 #pragma unroll
           for (int m = 0; m < RUN; ++m) {
@@ -457,28 +462,28 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
     // stage 1: absorb t1 of x plane pz into the pending ratio planes, finish ratio plane q
     {
       const float* base = B1 + t1_col;
-      f32x2 v[RUN1], vn[RUN1];
-      float ve[EP], ven[EP];
+      f32x2 vb[2][RUN1];
+      float veb[2][EP];
 #pragma unroll
-      for (int m = 0; m < RUN1; ++m) vn[m] = f32x2{base[m * T::PA], base[m * T::PA + 64]};
+      for (int m = 0; m < RUN1; ++m) vb[0][m] = f32x2{base[m * T::PA], base[m * T::PA + 64]};
 #pragma unroll
-      for (int e = 0; e < EP; ++e) ven[e] = B1[e_t1(e)];
+      for (int e = 0; e < EP; ++e) veb[0][e] = B1[e_t1(e)];
 #pragma unroll
       for (int c = 0; c < PYX; ++c) {
-#pragma unroll
-        for (int m = 0; m < RUN1; ++m) v[m] = vn[m];
-#pragma unroll
-        for (int e = 0; e < EP; ++e) ve[e] = ven[e];
+        f32x2 (&v)[RUN1] = vb[c & 1];
+        float (&ve)[EP] = veb[c & 1];
         if (c + 1 < PYX) {
 #pragma unroll
-          for (int m = 0; m < RUN1; ++m) vn[m] = f32x2{base[m * T::PA + c + 1], base[m * T::PA + c + 1 + 64]};
+          for (int m = 0; m < RUN1; ++m) vb[(c + 1) & 1][m] = f32x2{base[m * T::PA + c + 1], base[m * T::PA + c + 1 + 64]};
 #pragma unroll
-          for (int e = 0; e < EP; ++e) ven[e] = B1[e_t1(e) + c + 1];
+          for (int e = 0; e < EP; ++e) veb[(c + 1) & 1][e] = B1[e_t1(e) + c + 1];
         }
+        float wnext;
+        LSR_TAP(wnext, 0, c * PZ);
 #pragma unroll
         for (int j = 0; j < PZ; ++j) {
-          float ws;
-          LSR_TAP(ws, 0, c * PZ + j);
+          const float ws = wnext;
+          if (j + 1 < PZ) LSR_TAP(wnext, 0, c * PZ + j + 1);
           const f32x2 w = splat(ws);
 #pragma unroll
           for (int m = 0; m < RUN1; ++m) {

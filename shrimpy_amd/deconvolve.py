@@ -201,8 +201,8 @@ class RichardsonLucyPlan:
         border normalisation along y is then the taller volume's (``shrimpy_amd.slab``)."""
         import torch
 
-        if fused not in ("auto", "never"):
-            raise ValueError("fused must be 'auto' or 'never'")
+        if fused not in ("auto", "never", "always"):
+            raise ValueError("fused must be 'auto', 'never' or 'always'")
         self._fused_mode = fused
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -287,10 +287,12 @@ class RichardsonLucyPlan:
             self._norm = None
         if factors is not None:
             self._ysep = None
-        # ky (x) kzx with both factors inside the dense kernel's range: one launch per ITERATION
-        # (rl_fused_ysep.hip) where the extents have a specialisation, else one per correlation
+        # ky (x) kzx with both factors inside the dense kernel's range: one launch per correlation by default.
+        # The one-launch-per-ITERATION kernel (rl_fused_ysep.hip, bit-identical results) is opt-in
+        # (fused="always"): it halves the HBM traffic, but with 140 FMAs per voxel its single workgroup per
+        # CU is VALU- and barrier-bound -- measured 5.8 ms per iteration against 2 x 2.28 ms
         self.fused_ysep = False
-        if (self._ysep is not None and self._ysep["fused"] is not None and self._fused_mode == "auto"
+        if (self._ysep is not None and self._ysep["fused"] is not None and self._fused_mode == "always"
                 and _lib.call_value("lsr_rl_ysep_fused_supported", *self._psf.shape)):
             ky, kzx = ysep
             ky_c, kzx_c = np.ascontiguousarray(ky, dtype=np.float32), np.ascontiguousarray(kzx, dtype=np.float32)
@@ -305,7 +307,7 @@ class RichardsonLucyPlan:
         self._ratio_pad = None
         self._y_pad = None   # fused path: padded copy of a dense y
         # one launch per iteration (rl_fused_sep.hip) where the PSF fits its specialisations
-        self.fused = bool(self._psf.separable and self._fused_mode == "auto"
+        self.fused = bool(self._psf.separable and self._fused_mode in ("auto", "always")
                           and _lib.call_value("lsr_rl_sep_fused_supported", *self._psf.shape))
         if self.fused:
             kz, ky, kx = (np.ascontiguousarray(k, dtype=np.float32) for k in factors)

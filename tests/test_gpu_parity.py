@@ -279,27 +279,31 @@ def _planar_matrix(theta_deg, scale_zyx, shift_zyx, shear=0.0):
     dict(shape=(8, 48, 96), theta=12.0, scale=(1.0, 1.0, 1.0), shift=(0.0, 500.0, 0.0)),          # everything outside
 ])
 @pytest.mark.parametrize("exact", [True, False])
-def test_affine_planar_kernel_vs_oracle(device, case, exact):
-    """z-decoupled maps in constant mode run affine_planar.hip (LDS-staged source boxes, z march):
+@pytest.mark.parametrize("mode", ["constant", "grid-constant"])
+def test_affine_planar_kernel_vs_oracle(device, case, exact, mode):
+    """z-decoupled maps run affine_planar.hip (LDS-staged source boxes, z march) under either border rule:
     bit-identical to scipy in exact mode, ~1e-6 with f32 interpolation, same border decisions."""
     from shrimpy_amd import _lib
     from shrimpy_amd.geometry import as_matrix_3x4
     from shrimpy_amd.register import apply_affine_transform_zyx
 
+    code = _lib.MODE_CONSTANT if mode == "constant" else _lib.MODE_GRID_CONSTANT
     planar = _lib.call_value("lsr_affine_kernel_choice", case["shape"][1], case["shape"][2],
                              _lib.matrix12(as_matrix_3x4(_planar_matrix(case["theta"], case["scale"], case["shift"],
-                                                                        case.get("shear", 0.0)))), _lib.MODE_CONSTANT)
+                                                                        case.get("shear", 0.0)))), code)
     assert planar == (0 if case["scale"][2] > 10 else 1)   # 14x decimation: the source box exceeds LDS
     rng = np.random.default_rng(hash(str(case)) % 2**32)
     vol = (rng.random(case["shape"]) * 1000 - 100).astype(np.float32)
     m = _planar_matrix(case["theta"], case["scale"], case["shift"], case.get("shear", 0.0))
     oshape = case.get("out", case["shape"])
-    ref = o.affine_apply_4x4(vol, m, oshape, cval=-3.0, mode="constant")
-    out = apply_affine_transform_zyx(_t(vol, device), m, oshape, cval=-3.0, exact=exact).cpu().numpy()
+    ref = o.affine_apply_4x4(vol, m, oshape, cval=-3.0, mode=mode)
+    out = apply_affine_transform_zyx(_t(vol, device), m, oshape, cval=-3.0, exact=exact, mode=mode).cpu().numpy()
     if exact:
         np.testing.assert_array_equal(out, ref)
-    else:
+    elif mode == "constant":
         assert np.array_equal(out == -3.0, ref == -3.0)
+        np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-3)
+    else:   # blended borders: no exact cval pattern to compare, the values carry the decision
         np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-3)
 
 
@@ -982,8 +986,8 @@ def test_rl_y_separable_psf_takes_the_stencil_plus_y_pass_and_matches_dense(devi
     shape = (21, 70, 150)
     rng = np.random.default_rng(44)
     y = (rng.poisson(100 + 3000 * (rng.random(shape) > 0.999)).astype(np.float32))
-    auto = RichardsonLucyPlan(shape, psf, device)
-    two = RichardsonLucyPlan(shape, psf, device, fused="never")
+    auto = RichardsonLucyPlan(shape, psf, device, fused="always")
+    two = RichardsonLucyPlan(shape, psf, device)
     dense = RichardsonLucyPlan(shape, psf, device, separable="never")
     assert (auto.path, two.path, dense.path) == ("y-separable (fused)", "y-separable", "dense")
     a, b = auto(_t(y, device), iterations=8), dense(_t(y, device), iterations=8)
@@ -1003,11 +1007,11 @@ def test_rl_y_separable_psf_takes_the_stencil_plus_y_pass_and_matches_dense(devi
     assert torch.equal(auto(ypad, iterations=8), a)
     for thin in ((1, 9, 40), (3, 2, 5), (12, 33, 65)):
         yt = (rng.random(thin) * 50 + 1).astype(np.float32)
-        p = RichardsonLucyPlan(thin, psf, device)
+        p = RichardsonLucyPlan(thin, psf, device, fused="always")
         assert p.path == "y-separable (fused)"
         got = p(_t(yt, device), iterations=2)
         _close(got.cpu().numpy(), o.richardson_lucy(yt, psf, 2), 2e-4, 1e-4)
-        assert torch.equal(got, RichardsonLucyPlan(thin, psf, device, fused="never")(_t(yt, device), iterations=2))
+        assert torch.equal(got, RichardsonLucyPlan(thin, psf, device)(_t(yt, device), iterations=2))
 
 
 def test_rl_y_separable_random_psf_shapes(device):
@@ -1024,13 +1028,13 @@ def test_rl_y_separable_random_psf_shapes(device):
         psf /= psf.sum()
         shape = (int(rng.integers(1, 30)), int(rng.integers(1, 80)), int(rng.integers(1, 200)))
         y = (rng.random(shape) * 80 + 1).astype(np.float32)
-        plan = RichardsonLucyPlan(shape, psf, device)
+        plan = RichardsonLucyPlan(shape, psf, device, fused="always")
         assert plan.path == ("y-separable (fused)" if py <= 9 else "y-separable (4 launches)"), (case, psf.shape)
         iters = int(rng.integers(1, 4))
         got = plan(_t(y, device), iterations=iters)
         _close(got.cpu().numpy(), o.richardson_lucy(y, psf, iters), 2e-4, 1e-4)
         if py <= 9:   # every compiled extent: the fused iteration is the two-launch form, bit for bit
-            two = RichardsonLucyPlan(shape, psf, device, fused="never")
+            two = RichardsonLucyPlan(shape, psf, device)
             assert two.path == "y-separable"
             assert torch.equal(got, two(_t(y, device), iterations=iters)), (case, psf.shape, shape)
 
