@@ -210,10 +210,10 @@ bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, i
 bool affine_planar_geometry(int64_t Yi, int64_t Xi, int64_t pitch, const double M[12], int* box_y, int* box_x,
                             int* slots, int64_t* lds_bytes);
 // affine_box.hip: any map whose per-block source box fits in LDS (z-coupled maps included),
-// constant mode; false = not applicable
+// either border rule; false = not applicable
 bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, float* out,
                        int64_t Zo, int64_t Yo, int64_t Xo, int64_t opitch, int64_t oplane, const double M[12], float cval,
-                       bool f32, hipStream_t s);
+                       bool f32, bool grid, hipStream_t s);
 bool affine_box_geometry(int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, const double M[12],
                          int* box_z, int* box_y, int* box_x, int64_t* lds_bytes);
 bool affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int out6[6]);
@@ -237,7 +237,7 @@ extern "C" int lsr_affine_path(int64_t Zi, int64_t Yi, int64_t Xi, const double 
   int a, b, c;
   int64_t lds;
   if (lsr::affine_planar_geometry(Yi, Xi, Xi, M, &a, &b, &c, &lds)) return 1;
-  if (border == LSR_MODE_CONSTANT && lsr::affine_box_geometry(Zi, Yi, Xi, Xi, Yi * Xi, M, &a, &b, &c, &lds)) return 2;
+  if (lsr::affine_box_geometry(Zi, Yi, Xi, Xi, Yi * Xi, M, &a, &b, &c, &lds)) return 2;
   return 0;
 }
 
@@ -250,7 +250,7 @@ extern "C" int lsr_affine_path_pitched(int64_t Zi, int64_t Yi, int64_t Xi, int64
   int a, b, c;
   int64_t lds;
   if (in_plane % 4 == 0 && lsr::affine_planar_geometry(Yi, Xi, in_pitch, M, &a, &b, &c, &lds)) return 1;
-  if (border == LSR_MODE_CONSTANT && lsr::affine_box_geometry(Zi, Yi, Xi, in_pitch, in_plane, M, &a, &b, &c, &lds)) return 2;
+  if (lsr::affine_box_geometry(Zi, Yi, Xi, in_pitch, in_plane, M, &a, &b, &c, &lds)) return 2;
   return 0;
 }
 
@@ -310,13 +310,12 @@ int affine_impl(const char* what, const float* in, int64_t Zi, int64_t Yi, int64
   for (int i = 0; i < 12; ++i)
     LSR_REQUIRE(M[i] == M[i] && M[i] - M[i] == 0.0, LSR_E_ARG, "M[%d] is not finite", i);
 
-  // the LDS-staged kernels: z-decoupled maps under either border rule, z-coupled ones under "constant"
+  // the LDS-staged kernels (either border rule): z-decoupled maps, then any map whose source box fits LDS
   if (in != out &&
       (lsr::launch_affine_planar(in, Zi, Yi, Xi, pitch, plane, out, Zo, Yo, Xo, opitch, oplane, M, cval, f32,
                                  mode == LSR_MODE_GRID_CONSTANT, lsr::as_stream(stream)) ||
-       (mode == LSR_MODE_CONSTANT &&
-        lsr::launch_affine_box(in, Zi, Yi, Xi, pitch, plane, out, Zo, Yo, Xo, opitch, oplane, M, cval, f32,
-                               lsr::as_stream(stream)))))
+       lsr::launch_affine_box(in, Zi, Yi, Xi, pitch, plane, out, Zo, Yo, Xo, opitch, oplane, M, cval, f32,
+                              mode == LSR_MODE_GRID_CONSTANT, lsr::as_stream(stream))))
     return lsr::launch_status(what);
 
   AffineArgs p;

@@ -89,19 +89,32 @@ __device__ __forceinline__ void corner_range(const double* m, const int lo[3], c
 }
 
 // One axis of one voxel: is the coordinate inside [0, n - 1] (scipy's test, on the fp64 value), its
-// lower tap and its fraction.
+// lower tap and its fraction.  GRID (mode "grid-constant": the volume continued with cval): the lower tap
+// clamped to [-2, n + 1] and which of the two taps lie outside the volume (bit 0: lower, bit 1: upper).
 struct Tap {
   int i;        // floor(c) for an inside coordinate (trunc(c) = floor(c) for c >= 0)
   double f;     // c - floor(c), exact (v_fract_f64)
   bool inside;
+  unsigned out; // GRID only
 };
+template <bool GRID>
 __device__ __forceinline__ Tap axis_tap(double c, double last) {
   Tap t;
   t.f = __builtin_amdgcn_fract(c);
-  t.i = static_cast<int>(c);   // v_cvt_i32_f64: towards zero, saturating
-  // (bitwise on purpose: short-circuit evaluation would turn every voxel into its own exec-masked
-  // region and keep the independent voxels of a thread from overlapping)
-  t.inside = static_cast<bool>(static_cast<int>(!(c < 0.0)) & static_cast<int>(!(c > last)));
+  if constexpr (GRID) {
+    const int i = static_cast<int>(fmin(fmax(floor(c), -2.0), last + 2.0));
+    const int n = static_cast<int>(last) + 1;
+    t.i = i;
+    t.out = (static_cast<unsigned>(i < 0) | static_cast<unsigned>(i >= n)) |
+            ((static_cast<unsigned>(i + 1 < 0) | static_cast<unsigned>(i + 1 >= n)) << 1);
+    t.inside = true;
+  } else {
+    t.i = static_cast<int>(c);   // v_cvt_i32_f64: towards zero, saturating
+    // (bitwise on purpose: short-circuit evaluation would turn every voxel into its own exec-masked
+    // region and keep the independent voxels of a thread from overlapping)
+    t.inside = static_cast<bool>(static_cast<int>(!(c < 0.0)) & static_cast<int>(!(c > last)));
+    t.out = 0;
+  }
   return t;
 }
 
@@ -114,7 +127,7 @@ struct Blk {
 };
 
 // Block g of the XCD-ordered list: patch-major, z fastest inside a 4 x 4 x 4 patch.
-template <int TZ>
+template <int TZ, bool GRID>
 __device__ __forceinline__ Blk locate(const BoxArgs& p, int g) {
   Blk b;
   const int patch = g >> 6, inner = g & 63;
@@ -129,11 +142,17 @@ __device__ __forceinline__ Blk locate(const BoxArgs& p, int g) {
   corner_range(p.m + 4, lo, hi, ymin, ymax);
   corner_range(p.m + 8, lo, hi, xmin, xmax);
   const double Zl = static_cast<double>(p.Zi - 1), Yl = static_cast<double>(p.Yi - 1), Xl = static_cast<double>(p.Xi - 1);
-  b.zlo = static_cast<int>(fmin(fmax(floor(zmin), 0.0), Zl));
-  b.ylo = static_cast<int>(fmin(fmax(floor(ymin), 0.0), Yl));
-  b.xlo = static_cast<int>(fmin(fmax(floor(xmin), 0.0), Xl)) & ~3;
-  // a block that sees nothing of the volume: every voxel is cval, nothing to stage
-  b.blind = zmax < 0.0 || zmin > Zl || ymax < 0.0 || ymin > Yl || xmax < 0.0 || xmin > Xl;
+  // GRID: a tap may carry source index -1 (the box's first plane / row / column then stands for it: a
+  // duplicate of index 0 in LDS, replaced by cval through the tap's flag), and a coordinate up to one
+  // voxel outside still touches the volume
+  constexpr double kLow = GRID ? -1.0 : 0.0;
+  b.zlo = static_cast<int>(fmin(fmax(floor(zmin), kLow), Zl));
+  b.ylo = static_cast<int>(fmin(fmax(floor(ymin), kLow), Yl));
+  b.xlo = static_cast<int>(fmin(fmax(floor(xmin), kLow), Xl)) & ~3;   // (-1 -> -4)
+  // a block that sees nothing of the volume: every voxel is cval (GRID: a weighted sum of cvals), nothing to stage
+  b.blind = GRID ? (!(zmax > -1.0) || !(zmin < Zl + 1.0) || !(ymax > -1.0) || !(ymin < Yl + 1.0) || !(xmax > -1.0) ||
+                    !(xmin < Xl + 1.0))
+                 : (zmax < 0.0 || zmin > Zl || ymax < 0.0 || ymin > Yl || xmax < 0.0 || xmin > Xl);
   return b;
 }
 
@@ -145,7 +164,7 @@ __device__ __forceinline__ void stage(const BoxArgs& p, const Blk& b, unsigned l
   const int n_chunks = box_z * box_y * chunks_x;
   const unsigned plane_i = p.plane;
   // 32-bit byte offsets are taken from the box's first source plane (host: box_z planes < 4 GiB)
-  const float* const src = p.in + static_cast<int64_t>(b.zlo) * plane_i;
+  const float* const src = p.in + static_cast<int64_t>(max(b.zlo, 0)) * plane_i;
   const int n_loads = (n_chunks + NT - 1) / NT;
   for (int k = 0; k < n_loads; ++k) {
     const int e = min(tid + k * NT, n_chunks - 1);
@@ -158,9 +177,11 @@ __device__ __forceinline__ void stage(const BoxArgs& p, const Blk& b, unsigned l
     pl -= (pl * box_y > row);
     pl += ((pl + 1) * box_y <= row);
     const int r = row - pl * box_y;
-    const unsigned gz = static_cast<unsigned>(min(b.zlo + pl, p.Zi - 1) - b.zlo);   // past the volume: duplicates
-    const unsigned gy = static_cast<unsigned>(min(b.ylo + r, p.Yi - 1));
-    const unsigned gx = static_cast<unsigned>(min(b.xlo + 4 * c4, ((p.Xi + 3) & ~3) - 4));
+    // planes / rows / columns past the volume (or, GRID, before it): duplicates of the nearest inside one
+    const int zfirst = max(b.zlo, 0);
+    const unsigned gz = static_cast<unsigned>(min(max(b.zlo + pl, 0), p.Zi - 1) - zfirst);
+    const unsigned gy = static_cast<unsigned>(min(max(b.ylo + r, 0), p.Yi - 1));
+    const unsigned gx = static_cast<unsigned>(min(max(b.xlo + 4 * c4, 0), ((p.Xi + 3) & ~3) - 4));
     const unsigned voff = (gz * plane_i + gy * p.pitch + gx) * 4u;
     if (wave * 64 + k * NT < n_chunks)   // wave-uniform: whole waves of chunks
       glds_x4(src, voff, __builtin_amdgcn_readfirstlane(lds_byte_base + static_cast<unsigned>((k * NT + wave * 64) * 16)));
@@ -170,7 +191,7 @@ __device__ __forceinline__ void stage(const BoxArgs& p, const Blk& b, unsigned l
 // DEP: bit k set = source coordinate k (z, y, x) depends on zo.  A coordinate that does not is
 // worked out once per pixel instead of once per voxel (a tilt about y leaves y_in free of zo, a tilt
 // about x leaves x_in).
-template <bool F32, int TZ, int DEP, int NT>
+template <bool F32, int TZ, int DEP, int NT, bool GRID>
 __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const float* smem, int tid, int probe) {
   constexpr int P = kBlockVoxels / TZ / NT;   // output pixels per thread
   static_assert(P >= 1 && P * TZ * NT == kBlockVoxels, "block shape");
@@ -202,9 +223,9 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
     const double zd = static_cast<double>(z0);
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-      hz[j] = axis_tap(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[0]), tzy[j]), tzx[j]), p.m[3]), Zl);
-      hy[j] = axis_tap(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[4]), tyy[j]), tyx[j]), p.m[7]), Yl);
-      hx[j] = axis_tap(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[8]), txy[j]), txx[j]), p.m[11]), Xl);
+      hz[j] = axis_tap<GRID>(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[0]), tzy[j]), tzx[j]), p.m[3]), Zl);
+      hy[j] = axis_tap<GRID>(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[4]), tyy[j]), tyx[j]), p.m[7]), Yl);
+      hx[j] = axis_tap<GRID>(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[8]), txy[j]), txx[j]), p.m[11]), Xl);
     }
   }
 
@@ -243,14 +264,15 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
       for (int j = 0; j < P; ++j) {
         const int g = u * P + j;
         // scipy's order: ((zo*m0 + yo*m1) + xo*m2) + shift
-        if constexpr (DEP & 1) az[g] = axis_tap(lsr::dadd(lsr::dadd(lsr::dadd(tzz, tzy[j]), tzx[j]), p.m[3]), Zl);
+        if constexpr (DEP & 1) az[g] = axis_tap<GRID>(lsr::dadd(lsr::dadd(lsr::dadd(tzz, tzy[j]), tzx[j]), p.m[3]), Zl);
         else az[g] = hz[j];
-        if constexpr (DEP & 2) ay[g] = axis_tap(lsr::dadd(lsr::dadd(lsr::dadd(tyz, tyy[j]), tyx[j]), p.m[7]), Yl);
+        if constexpr (DEP & 2) ay[g] = axis_tap<GRID>(lsr::dadd(lsr::dadd(lsr::dadd(tyz, tyy[j]), tyx[j]), p.m[7]), Yl);
         else ay[g] = hy[j];
-        if constexpr (DEP & 4) ax[g] = axis_tap(lsr::dadd(lsr::dadd(lsr::dadd(txz, txy[j]), txx[j]), p.m[11]), Xl);
+        if constexpr (DEP & 4) ax[g] = axis_tap<GRID>(lsr::dadd(lsr::dadd(lsr::dadd(txz, txy[j]), txx[j]), p.m[11]), Xl);
         else ax[g] = hx[j];
-        inside[g] = static_cast<bool>(static_cast<int>(live) & static_cast<int>(az[g].inside) &
-                                      static_cast<int>(ay[g].inside) & static_cast<int>(ax[g].inside));
+        inside[g] = GRID ? true
+                         : static_cast<bool>(static_cast<int>(live) & static_cast<int>(az[g].inside) &
+                                             static_cast<int>(ay[g].inside) & static_cast<int>(ax[g].inside));
         // the box covers every inside voxel's taps by construction; the clamp keeps an out-of-range
         // voxel (whose result is dropped) inside the LDS image
         int o = (__mul24(az[g].i - zlo, plane_floats) + __mul24(ay[g].i - ylo, box_x) + (ax[g].i - xlo)) * 4;
@@ -263,6 +285,21 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
     }
     // every LDS read of the group is issued before the first interpolation waits for one
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (GRID) {   // taps outside the volume carry cval (a blind block: all of them, whatever LDS holds)
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const unsigned zf = live ? az[g].out : 3u, yf = ay[g].out, xf = ax[g].out;
+        const bool p0 = zf & 1u, p1 = zf & 2u, r0 = yf & 1u, r1 = yf & 2u, c0 = xf & 1u, c1 = xf & 2u;
+        v[g][0].x = (p0 || r0 || c0) ? p.cval : v[g][0].x;
+        v[g][0].y = (p0 || r0 || c1) ? p.cval : v[g][0].y;
+        v[g][1].x = (p0 || r1 || c0) ? p.cval : v[g][1].x;
+        v[g][1].y = (p0 || r1 || c1) ? p.cval : v[g][1].y;
+        v[g][2].x = (p1 || r0 || c0) ? p.cval : v[g][2].x;
+        v[g][2].y = (p1 || r0 || c1) ? p.cval : v[g][2].y;
+        v[g][3].x = (p1 || r1 || c0) ? p.cval : v[g][3].x;
+        v[g][3].y = (p1 || r1 || c1) ? p.cval : v[g][3].y;
+      }
+    }
     float res[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -320,7 +357,7 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
 // measured at 512 and at 1024 threads and ran 8-30 % SLOWER: 3.97 / 3.09 ms and 3.83 / 2.86 ms
 // against 3.30 / 2.30 ms (exact / f32, 1.5 deg tilt, config-3 size).  The arithmetic wants more
 // resident waves than one workgroup brings)
-template <bool F32, int TZ, int DEP>
+template <bool F32, int TZ, int DEP, bool GRID>
 __global__ __launch_bounds__(kThreads, 4) void affine_box_kernel(BoxArgs p) {
   extern __shared__ f32x4 smem4[];
   const float* const smem = reinterpret_cast<const float*>(smem4);
@@ -332,12 +369,12 @@ __global__ __launch_bounds__(kThreads, 4) void affine_box_kernel(BoxArgs p) {
   // workgroups b, b + 8, ... share an XCD (round-robin dispatch); every XCD gets a contiguous run of
   // the patch-major block order
   const int bid = blockIdx.x;
-  const Blk b = locate<TZ>(p, p.linear ? bid : (bid & 7) * p.per_xcd + (bid >> 3));
+  const Blk b = locate<TZ, GRID>(p, p.linear ? bid : (bid & 7) * p.per_xcd + (bid >> 3));
   if (!b.valid) return;
   if (!b.blind && probe != 1) stage<kThreads>(p, b, lds_base, tid, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  compute<F32, TZ, DEP, kThreads>(p, b, smem, tid, probe);
+  compute<F32, TZ, DEP, kThreads, GRID>(p, b, smem, tid, probe);
 }
 
 struct BoxShape {
@@ -392,10 +429,10 @@ bool pick_shape(int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane
 }
 
 // false: the device refuses the LDS budget (message in lsr_last_error()); the caller runs the gather kernel
-template <bool F32, int TZ, int DEP>
+template <bool F32, int TZ, int DEP, bool GRID = false>
 bool launch_one(const BoxArgs& p, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   static std::atomic<uint64_t> lds_allowed{0};
-  auto kernel = affine_box_kernel<F32, TZ, DEP>;
+  auto kernel = affine_box_kernel<F32, TZ, DEP, GRID>;
   if (lsr::allow_dynamic_lds(reinterpret_cast<const void*>(kernel), 150 * 1024, lds_allowed, "affine_box_kernel") != LSR_OK)
     return false;
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds_bytes, s, p);
@@ -403,9 +440,11 @@ bool launch_one(const BoxArgs& p, unsigned blocks, size_t lds_bytes, hipStream_t
 }
 
 template <bool F32, int TZ>
-bool launch_shape(const BoxArgs& p, unsigned blocks, size_t lds_bytes, hipStream_t s) {
+bool launch_shape(const BoxArgs& p, unsigned blocks, size_t lds_bytes, bool grid, hipStream_t s) {
   // the compiled walks: everything depends on zo / y_in does not (tilt about y) / x_in does not
-  // (tilt about x); other patterns run the general walk (their zo * 0 terms are exact zeros)
+  // (tilt about x); other patterns run the general walk (their zo * 0 terms are exact zeros).
+  // The blending border rule is compiled for the general walk only.
+  if (grid) return launch_one<F32, TZ, 7, true>(p, blocks, lds_bytes, s);
   const bool dz = p.m[0] != 0.0, dy = p.m[4] != 0.0, dx = p.m[8] != 0.0;
   if (dz && !dy && dx) return launch_one<F32, TZ, 5>(p, blocks, lds_bytes, s);
   if (dz && dy && !dx) return launch_one<F32, TZ, 3>(p, blocks, lds_bytes, s);
@@ -433,7 +472,7 @@ bool affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], in
 
 bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, float* out,
                        int64_t Zo, int64_t Yo, int64_t Xo, int64_t opitch, int64_t oplane, const double M[12], float cval,
-                       bool f32, hipStream_t s) {
+                       bool f32, bool grid, hipStream_t s) {
   BoxShape sh;
   if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || Yo * opitch >= (int64_t(1) << 31)) return false;
   if (!pick_shape(Zi, Yi, Xi, pitch, plane, M, &sh)) return false;
@@ -480,10 +519,10 @@ bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int6
   const size_t lds = static_cast<size_t>(sh.lds_bytes);
   if (Yo * opitch >= (int64_t(1) << 31)) return false;   // 32-bit output offsets inside a plane
   switch (sh.tz * 2 + (f32 ? 1 : 0)) {
-    case 8 * 2 + 1: return launch_shape<true, 8>(p, blocks, lds, s);
-    case 8 * 2 + 0: return launch_shape<false, 8>(p, blocks, lds, s);
-    case 16 * 2 + 1: return launch_shape<true, 16>(p, blocks, lds, s);
-    default: return launch_shape<false, 16>(p, blocks, lds, s);
+    case 8 * 2 + 1: return launch_shape<true, 8>(p, blocks, lds, grid, s);
+    case 8 * 2 + 0: return launch_shape<false, 8>(p, blocks, lds, grid, s);
+    case 16 * 2 + 1: return launch_shape<true, 16>(p, blocks, lds, grid, s);
+    default: return launch_shape<false, 16>(p, blocks, lds, grid, s);
   }
 }
 

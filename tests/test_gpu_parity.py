@@ -357,27 +357,29 @@ BOX_CASES = [
 
 @pytest.mark.parametrize("case", BOX_CASES)
 @pytest.mark.parametrize("exact", [True, False])
-def test_affine_box_kernel_vs_oracle(device, case, exact):
+@pytest.mark.parametrize("mode", ["constant", "grid-constant"])
+def test_affine_box_kernel_vs_oracle(device, case, exact, mode):
     """Maps that couple z with the plane (and any other map whose per-block source box fits in LDS)
-    run affine_box.hip: bit-identical to scipy in exact mode, within 2e-5 of the data range with f32
-    interpolation and with the same in / out-of-range decisions."""
+    run affine_box.hip under either border rule: bit-identical to scipy in exact mode, within 2e-5 of the
+    data range with f32 interpolation and with the same in / out-of-range decisions."""
     from shrimpy_amd import _lib
     from shrimpy_amd.geometry import as_matrix_3x4
     from shrimpy_amd.register import apply_affine_transform_zyx
 
     m, shape = case["m"], case["shape"]
     path = _lib.call_value("lsr_affine_path", shape[0], shape[1], shape[2], _lib.matrix12(as_matrix_3x4(m)),
-                           _lib.MODE_CONSTANT)
+                           _lib.MODE_CONSTANT if mode == "constant" else _lib.MODE_GRID_CONSTANT)
     assert path == 2
     rng = np.random.default_rng(len(str(case)))
     vol = (rng.random(shape) * 1000 - 100).astype(np.float32)
     oshape = case.get("out", shape)
-    ref = o.affine_apply_4x4(vol, m, oshape, cval=-3.0, mode="constant")
-    out = apply_affine_transform_zyx(_t(vol, device), m, oshape, cval=-3.0, exact=exact).cpu().numpy()
+    ref = o.affine_apply_4x4(vol, m, oshape, cval=-3.0, mode=mode)
+    out = apply_affine_transform_zyx(_t(vol, device), m, oshape, cval=-3.0, exact=exact, mode=mode).cpu().numpy()
     if exact:
         np.testing.assert_array_equal(out, ref)
     else:
-        assert np.array_equal(out == -3.0, ref == -3.0)
+        if mode == "constant":
+            assert np.array_equal(out == -3.0, ref == -3.0)
         assert np.abs(out - ref).max() <= 2e-5 * 1100
 
 
@@ -489,7 +491,7 @@ def test_affine_path_selection(device):
     assert path((20, 96, 132), _config3_matrix()) == 1
     assert path((20, 96, 132), tilt) == 2
     assert path((20, 96, 130), tilt) == 0                                 # Xi not a multiple of 4
-    assert path((20, 96, 132), tilt, _lib.MODE_GRID_CONSTANT) == 0        # blending border: gather kernel
+    assert path((20, 96, 132), tilt, _lib.MODE_GRID_CONSTANT) == 2        # the blending border rule too
     assert path((20, 96, 132), _tilted_matrix([(1, 3.0)], (9.0, 9.0, 9.0))) == 0   # source box beyond LDS
     rng = np.random.default_rng(77)
     for shape in ((20, 96, 132), (20, 96, 130)):
@@ -1088,7 +1090,7 @@ def test_registration_writes_the_rl_input_in_place(device):
     psf, _ = o.gaussian_psf((9, 7, 7), (2.0, 1.2, 1.2))
     for shape, m, mode in [((20, 96, 132), _config3_matrix(), "constant"),                                   # planar
                            ((24, 96, 132), _tilted_matrix([(1, 3.0), (0, 2.0)], (1.0, 0.98, 1.02), (1.5, -4.25, 6.75)), "constant"),
-                           ((20, 50, 70), _tilted_matrix([(1, 3.0)]), "grid-constant")]:                    # gather
+                           ((20, 50, 70), _tilted_matrix([(1, 3.0)]), "grid-constant")]:                    # gather (Xi % 4)
         vol = (rng.random(shape) * 1000).astype(np.float32)
         dense = apply_affine_transform_zyx(_t(vol, device), m, shape, mode=mode)
         plan = RichardsonLucyPlan(shape, psf, device)

@@ -439,8 +439,8 @@ def test_affine_path_is_decided_on_the_host():
     tilt = np.eye(4)
     tilt[0, 2], tilt[2, 0] = -0.05, 0.05
     assert path((64, 256, 256), ident) == 1 and path((64, 256, 256), tilt) == 2
-    assert path((64, 256, 254), tilt) == 0 and path((64, 256, 256), tilt, _lib.MODE_GRID_CONSTANT) == 0
-    assert path((64, 256, 256), ident, _lib.MODE_GRID_CONSTANT) == 1      # z-decoupled maps: either border rule
+    assert path((64, 256, 254), tilt) == 0 and path((64, 256, 256), tilt, _lib.MODE_GRID_CONSTANT) == 2
+    assert path((64, 256, 256), ident, _lib.MODE_GRID_CONSTANT) == 1      # both LDS-staged kernels: either border rule
     big = np.diag([9.0, 9.0, 9.0, 1.0])
     big[0, 2] = 0.1
     assert path((64, 256, 256), big) == 0 and _box_shape((64, 256, 256), big) is None
