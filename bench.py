@@ -318,7 +318,12 @@ def self_launch(n: int) -> int:
     env = dict(os.environ)
     env.pop("RANK", None)
     env.pop("LOCAL_RANK", None)
-    return subprocess.run(cmd, env=env).returncode
+    # the contract is ONE JSON line on stdout: whatever else the ranks print there (gloo announces its
+    # connections on stdout) goes to stderr
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in (proc.stdout or "").splitlines():
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    return proc.returncode
 
 
 def timed_steps(step, args, world, shared, device):

@@ -20,7 +20,7 @@ def _bare_env():
     return env
 
 
-def test_gpus_n_without_a_launcher_starts_torch_distributed_run_as_a_child(monkeypatch):
+def test_gpus_n_without_a_launcher_starts_torch_distributed_run_as_a_child(monkeypatch, capsys):
     import bench
 
     seen = {}
@@ -30,6 +30,7 @@ def test_gpus_n_without_a_launcher_starts_torch_distributed_run_as_a_child(monke
 
         class R:
             returncode = 7
+            stdout = "[Gloo] Rank 0 is connected to 1 peer ranks.\n{\"metric\": \"m\"}\n"
         return R()
 
     monkeypatch.setattr(subprocess, "run", fake_run)
@@ -39,6 +40,8 @@ def test_gpus_n_without_a_launcher_starts_torch_distributed_run_as_a_child(monke
     with pytest.raises(SystemExit) as exc:
         bench.main()
     assert exc.value.code == 7               # the child's exit code is the bench's
+    out = capsys.readouterr()
+    assert out.out == '{"metric": "m"}\n' and "[Gloo]" in out.err     # stdout carries the JSON line only
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
