@@ -72,7 +72,16 @@ def _distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        raise click.ClickException("no HIP device: this path runs only on a GPU (MI355X); there is no CPU fallback")
+        # the reference's own rule (shrimpy/preprocessing.py:78-82): no GPU visible -> cpu.  The volumes then
+        # run the native host twins (shrimpy_amd/host.py); ranks, if any, meet over gloo.
+        created = False
+        if world > 1:
+            import torch.distributed as dist
+
+            if not dist.is_initialized():
+                dist.init_process_group(os.environ.get("LSR_DIST_BACKEND") or "gloo")
+                created = True
+        return rank, world, torch.device("cpu"), created
     n_dev = torch.cuda.device_count()
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     torch.cuda.set_device(local % n_dev)
@@ -360,8 +369,9 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
             logger.warning("staging slots unavailable (%s): volumes are handed over synchronously", exc)
             stager = None
     try:
-        report = run_sharded(todo, load, process, store, synchronize=torch.cuda.synchronize, stager=stager,
-                             process_takes_unit=True)
+        on_gpu = torch.device(device).type == "cuda"
+        report = run_sharded(todo, load, process, store, synchronize=torch.cuda.synchronize if on_gpu else None,
+                             stager=stager, process_takes_unit=True)
     finally:
         if stager is not None:
             stager.close()

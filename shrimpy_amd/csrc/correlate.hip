@@ -16,6 +16,8 @@
 // Separable PSFs (rank-1: wz x wy x wx) take pz+py+px FMAs per voxel: HBM-bound.
 // Dense PSFs take pz*py*px FMAs per voxel: fp32-VALU-bound beyond ~120 taps.  No MFMA.
 
+#include <cstdlib>
+
 #include "common.hpp"
 #include "correlate_common.hpp"
 
@@ -482,8 +484,8 @@ int device_cu_count() {
 // Work split of the fused kernel (one workgroup per CU; a piece of a tile column costs
 // 2 * (PZ - 1) halo planes): whole columns for as many full dispatch rounds as the tiles give,
 // the remaining tiles cut along z so that they fill one more round.
-void plan_fused_split(int64_t tiles_xy, int64_t Z, int PZ, int* n_full, int* pieces, int* z_chunk) {
-  const int64_t cus = device_cu_count();
+void plan_fused_split(int64_t tiles_xy, int64_t Z, int PZ, int* n_full, int* pieces, int* z_chunk, int per_cu = 1) {
+  const int64_t cus = device_cu_count() * per_cu;   // workgroups resident at once
   const int64_t min_chunk = 2 * (PZ - 1) > 8 ? 2 * (PZ - 1) : 8;  // halo no more than the payload
   int64_t full = tiles_xy / cus * cus;
   int64_t rest = tiles_xy - full;
@@ -699,10 +701,14 @@ extern "C" int lsr_rl_ysep_fused_f32(const float* y, int64_t y_pitch, int64_t y_
   p.taps = taps; p.eps = eps;
   p.pz = pz; p.py = py; p.px = px;
   p.norm_table = norm_table; p.norm_full = norm_full;
-  p.tiles_x = static_cast<int>(lsr::ceil_div(X, lsr::kSepWideTileX));
-  p.tiles_y = static_cast<int>(lsr::ceil_div(Y, 8 * lsr::ysep_run(PZ)));
+  // two shapes: 256-thread workgroups on 32 x 64 tiles, two per CU (default), or 512 threads on 32 x 128, one per
+  // CU (LSR_YSEP_SHAPE=wide: measurement override)
+  const char* shape_env = std::getenv("LSR_YSEP_SHAPE");
+  p.narrow = !(shape_env != nullptr && shape_env[0] == 'w') ? 1 : 0;
+  p.tiles_x = static_cast<int>(lsr::ceil_div(X, p.narrow ? 64 : lsr::kSepWideTileX));
+  p.tiles_y = static_cast<int>(lsr::ceil_div(Y, lsr::ysep_tile_rows(PZ)));
   const int64_t tiles_xy = int64_t(p.tiles_x) * p.tiles_y;
-  plan_fused_split(tiles_xy, Z, PZ, &p.n_full, &p.pieces, &p.z_chunk);
+  plan_fused_split(tiles_xy, Z, PZ, &p.n_full, &p.pieces, &p.z_chunk, p.narrow ? 2 : 1);
   const int64_t blocks64 = p.n_full + (tiles_xy - p.n_full) * p.pieces;
   LSR_REQUIRE(blocks64 < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large", (long long)blocks64);
   const unsigned blocks = static_cast<unsigned>(blocks64);

@@ -150,9 +150,10 @@ struct YsepArgs {
   float norm_full;                    // sum of all taps (interior voxels)
   int tiles_x, tiles_y;
   int n_full, pieces, z_chunk;        // work split, as FusedArgs
+  int narrow;                         // 1: 256-thread workgroups on 32 x 64 tiles (two per CU); 0: 512 threads, 32 x 128
 };
-// tile rows / 8: the accumulators of both stencils (PZ planes each) must fit 256 VGPRs per thread
-constexpr int ysep_run(int PZ) { return PZ <= 9 ? 4 : 3; }
+// tile rows: the accumulators of both stencils (PZ planes each) must fit 256 VGPRs per thread
+constexpr int ysep_tile_rows(int PZ) { return PZ <= 9 ? 32 : 24; }
 constexpr int kYsepMaxPZ = 11, kYsepMaxPYX = 9;
 
 inline int sep_wide_stage_cols(int PX) { return kSepWideTileX - 4 + 4 * ((4 + PX - 1 + 3) / 4); }

@@ -19,6 +19,11 @@
 // voxel (y chain first: product, then FMAs in tap order; (z, x) chain plane by plane in z, tap by tap in x;
 // rcp with one Newton step) is the two-launch kernels', so both forms return bit-identical volumes.
 //
+// Two shapes of the same kernel (template <NW, NCG>): 8 waves owning a 32 x 128 tile (a thread: 4 rows of two
+// 64-column groups, packed pairs = the two groups of a row; one workgroup per CU), and 4 waves owning a
+// 32 x 64 tile (a thread: 8 rows of one column, packed pairs = two neighbouring rows; ~78 KB of LDS, so TWO
+// workgroups share a CU and one's LDS-bound y passes and barriers overlap the other's FMAs).
+//
 // Volumes, work split, the LDS ring of staged x planes (global_load_lds_dwordx4), the hand-counted
 // s_waitcnt vmcnt scheme and the per-iteration schedule (two workgroup barriers) are rl_fused_sep.hip's;
 // see its header.  Roofline: 2 * (PZ * PYX + PYX) FMAs per voxel and iteration on ~1.2x the points for
@@ -36,58 +41,60 @@ namespace {
 
 using lsr::YsepArgs;
 
-constexpr int kTX = lsr::kSepWideTileX;  // 128
-constexpr int kWaves = 8;
-constexpr int kThreads = 64 * kWaves;
 constexpr int kBand = 8;
 constexpr int kRing = 3;
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-template <int PZ, int PYX, int RUN>
+// NW waves per workgroup, NCG column groups (of 64) per thread; RPW = tile rows per wave.
+template <int PZ, int PYX, int NW, int NCG>
 struct Geo {
+  static constexpr int NT = 64 * NW;                      // threads
+  static constexpr int TXW = 64 * NCG;                    // tile width
   static constexpr int C = PYX / 2, CZ = PZ / 2;
-  static constexpr int TY = 8 * RUN;
+  static constexpr int TY = lsr::ysep_tile_rows(PZ);      // tile rows
+  static constexpr int RPW = TY / NW;                     // stage-2 rows per wave
+  static constexpr int NP2 = RPW * NCG / 2;               // stage-2 packed pairs per thread
   static constexpr int WL = lsr::fused_window_halo(PYX);  // staged columns left/right of the tile
   static constexpr int AR = TY + 4 * C;                   // staged rows
-  static constexpr int PA = kTX + 2 * WL;                 // staged columns = pitch of A and of B1
+  static constexpr int PA = TXW + 2 * WL;                 // staged columns = pitch of A and of B1
   static constexpr int CH = PA / 4;                       // 16-byte chunks per staged row
   static constexpr int NCH = AR * CH;
-  static constexpr int SL = cdiv(NCH, kThreads);          // glds per thread and plane
+  static constexpr int SL = cdiv(NCH, NT);                // glds per thread and plane
   static constexpr int ASZ = cdiv(NCH, 64) * 64 * 4;      // floats per ring slot (whole waves of chunks)
   static constexpr int R1 = TY + 2 * C;                   // stage-1 (ratio) rows
-  static constexpr int RUN1 = cdiv(R1, 8);                // ratio rows per thread
-  static constexpr int NIT1 = R1 * CH;                    // y1 items: one 16-byte chunk of t1 each
-  static constexpr int XIT1 = cdiv(NIT1, kThreads);
-  static constexpr int B1SZ = 8 * RUN1 * PA;              // (rows >= R1: padding the last wave reads, never uses)
+  static constexpr int RPW1 = NCG == 2 ? cdiv(R1, NW) : 2 * cdiv(R1, 2 * NW);   // ratio rows per wave (even for row pairs)
+  static constexpr int NP1 = RPW1 * NCG / 2;              // stage-1 packed pairs per thread
+  static constexpr int NIT1 = R1 * CH;                    // chunks of t1 (zero fill)
+  static constexpr int XIT1 = cdiv(NIT1, NT);
+  static constexpr int B1SZ = NW * RPW1 * PA;             // (rows >= R1: padding the last wave reads, never uses)
   static constexpr int SH1 = WL - 2 * C;                  // B1 column of ratio column 0's first x tap
-  static constexpr int E = 2 * C;                         // ratio columns beyond the two 64-lane groups
+  static constexpr int E = 2 * C;                         // ratio columns beyond the 64-lane groups
   static constexpr int NE = R1 * E;
-  static constexpr int EP = cdiv(NE, kThreads);           // edge points per thread
-  static constexpr int PR = kTX + 8;                      // pitch of R and B2 (ratio columns 0 .. 128 + 2C - 1)
+  static constexpr int EP = cdiv(NE, NT);                 // edge points per thread
+  static constexpr int PR = TXW + 8;                      // pitch of R and B2 (ratio columns 0 .. TXW + 2C - 1)
   static constexpr int CH2 = PR / 4;
-  static constexpr int RSZ = 8 * RUN1 * PR;
-  static constexpr int NIT2 = TY * CH2;                   // y2 items
-  static constexpr int XIT2 = cdiv(NIT2, kThreads);
+  static constexpr int RSZ = NW * RPW1 * PR;
+  static constexpr int NIT2 = TY * CH2;
+  static constexpr int XIT2 = cdiv(NIT2, NT);
   static constexpr int B2SZ = TY * PR;
   static constexpr int RY = 3;                            // output rows per y-pass item
   static constexpr int NG1 = cdiv(R1, RY) * CH;           // y1 items
   static constexpr int NG2 = cdiv(TY, RY) * CH2;          // y2 items
-  static constexpr int NORM = (PZ + 1) * (PYX + 1) * (PYX + 1);   // doubles: prefix sums of the caller's PSF
-  // LDS map (floats): ring | B1 | R | B2 | dump | norm table (doubles)
+  // LDS map (floats): ring | B1 | R | B2 | dump
   static constexpr int OFF_B1 = kRing * ASZ;
   static constexpr int OFF_R = OFF_B1 + B1SZ;
   static constexpr int OFF_B2 = OFF_R + RSZ;
   static constexpr int OFF_DUMP = OFF_B2 + B2SZ;          // 1 KB: where glds of waves past the window land
-  static constexpr int OFF_NORM = OFF_DUMP + 256;
-  static constexpr int TOTAL = OFF_NORM + 2 * NORM;
-  static constexpr int NY = 2 * RUN1 + EP;                // y loads per thread and iteration
-  static constexpr int NXC = 2 * RUN;                     // x (centre) loads
+  static constexpr int TOTAL = OFF_DUMP + 256;
+  static constexpr int NY = 2 * NP1 + EP;                 // y loads per thread and iteration
+  static constexpr int NXC = 2 * NP2;                     // x (centre) loads
   static constexpr int NTAP = PYX * PZ;                   // (z, x) taps of one stage
+  static_assert(TY % NW == 0 && (NCG == 2 || RPW % 2 == 0), "rows per wave");
   static_assert(TOTAL * 4 <= 160 * 1024, "LDS per workgroup");
   static_assert(2 * C <= WL && WL <= lsr::kSepOriginCol && 2 * C <= 8, "halo columns");
   static_assert(SL + 2 * (NY + NXC) <= 63, "vmcnt is a 6-bit counter");
-  static_assert(OFF_B1 % 4 == 0 && OFF_R % 4 == 0 && OFF_B2 % 4 == 0 && OFF_NORM % 2 == 0, "aligned buffers");
+  static_assert(OFF_B1 % 4 == 0 && OFF_R % 4 == 0 && OFF_B2 % 4 == 0, "aligned buffers");
   static_assert(NTAP + PYX <= 128, "a stage's taps fill two registers' lanes");
 };
 
@@ -157,10 +164,10 @@ __device__ float dense_norm(const YsepArgs& p, const double* P, int z, int y, in
 // dst[r][g] = sum_b w[b] * src[r + b][g] for rows r < rows and 16-byte chunks g < chunks (both arrays `chunks`
 // wide); item i -> (row group i / chunks, chunk i % chunks), `items` = ceil(rows / RY) * chunks of them.
 // Per output the chain is w[0] * v, then FMAs in tap order.
-template <int RY, int PYX>
+template <int RY, int PYX, int NT>
 __device__ __forceinline__ void ypass(const f32x4* src, f32x4* dst, int chunks, int rows, int items, const float (&w)[PYX],
                                       int tid) {
-  for (int i = tid; i < items; i += kThreads) {   // (one round, or two for the widest windows)
+  for (int i = tid; i < items; i += NT) {   // (one round, or two for the widest windows)
     const int rg = i / chunks, g = i - rg * chunks;
     const int r0 = rg * RY;
     const f32x4* in = src + r0 * chunks + g;
@@ -180,10 +187,18 @@ __device__ __forceinline__ void ypass(const f32x4* src, f32x4* dst, int chunks, 
   }
 }
 
-template <int PZ, int PYX, int RUN>
-__global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
-  using T = Geo<PZ, PYX, RUN>;
-  constexpr int C = T::C, CZ = T::CZ, TY = T::TY, RUN1 = T::RUN1, EP = T::EP;
+// Where the two halves of a thread's packed pair i sit: NCG == 2: row i, column groups 0 and 1; NCG == 1: rows
+// 2 i and 2 i + 1 of the one column group.  (row of half h, its column offset in floats)
+template <int NCG>
+__device__ __forceinline__ constexpr int pair_row(int i, int h) { return NCG == 2 ? i : 2 * i + h; }
+template <int NCG>
+__device__ __forceinline__ constexpr int pair_col(int h) { return NCG == 2 ? 64 * h : 0; }
+
+template <int PZ, int PYX, int NW, int NCG>
+__global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {   // (2 waves per SIMD: <= 256 VGPRs)
+  using T = Geo<PZ, PYX, NW, NCG>;
+  constexpr int C = T::C, CZ = T::CZ, TY = T::TY, EP = T::EP, NT = T::NT, TXW = T::TXW;
+  constexpr int NP1 = T::NP1, NP2 = T::NP2, RPW = T::RPW, RPW1 = T::RPW1;
   constexpr int NY = T::NY, NXC = T::NXC, SL = T::SL;
   __shared__ f32x4 smem4[T::TOTAL / 4 + 1];
   float* const smem = reinterpret_cast<float*>(smem4);
@@ -193,18 +208,12 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
   const f32x4* const R_4 = smem4 + T::OFF_R / 4;
   f32x4* const B2_4 = smem4 + T::OFF_B2 / 4;
   const float* const B2 = smem + T::OFF_B2;
-  double* const s_norm = reinterpret_cast<double*>(smem + T::OFF_NORM);
   const unsigned lds_base =
       static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) char*)smem4));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  {  // border normalisation table (read by the epilogue only; the prologue's barrier publishes it)
-    const int n = (p.pz + 1) * (p.py + 1) * (p.px + 1);
-    for (int i = tid; i < n; i += kThreads) s_norm[i] = p.norm_table[i];
-  }
 
   // work items, longest first, XCD-contiguous, tiles in bands of 8 rows (rl_fused_sep.hip)
   auto xcd_contiguous = [](int b, int n) {
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
   const int band_h = min(kBand, p.tiles_y - band * kBand);
   const int tx = lb / band_h;
   const int ty = band * kBand + (lb - tx * band_h);
-  const int x0 = tx * kTX, y0 = ty * TY;
+  const int x0 = tx * TXW, y0 = ty * TY;
 
   // taps: two stages of 128 floats (stage 1 = reversed taps, stage 2 = the PSF's): (z, x) taps [c][j],
   // j = PZ - 1 - a, at 0 .. PYX * PZ - 1, the y taps at 112 .. 112 + PYX - 1.  They live across the lanes of
@@ -243,64 +252,64 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
 #define LSR_TAP(dst, stage, f)                                                                          \
   asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(dst) : "v"(tv[((stage) * 128 + (f)) >> 6]), "n"(((stage) * 128 + (f)) & 63))
 
-  // ---- staging (glds): chunk e = tid + 512 k of the (AR x PA) window whose first element is (y0 - 2C, x0 - WL)
+  // ---- staging (glds): chunk e = tid + NT k of the (AR x PA) window whose first element is (y0 - 2C, x0 - WL)
   const float* const x_tile = p.x + (static_cast<int64_t>(y0 - 2 * C) * p.pitch + (x0 - T::WL));
   // (its byte offset inside the plane is recomputed per plane from the thread index -- a few integer operations
   // against SL registers held across the loop)
   int tid_v = tid;
   auto s_voff = [&](int k) {
-    const int e = min(tid_v + k * kThreads, T::NCH - 1);
+    const int e = min(tid_v + k * NT, T::NCH - 1);
     const int r = e / T::CH, c = e - r * T::CH;
     return (r * p.pitch + 4 * c) * 4;
   };
-  // ---- stage-1 points.  Main: ratio columns rho = lane + 64 cg, ratio rows wave * RUN1 + m.
+  // ---- stage-1 points.  Main: the wave's ratio rows r1_row0 .. r1_row0 + RPW1 - 1, ratio columns lane (+ 64).
   // Ratio row r <-> tile row r - C; ratio column rho <-> tile column rho - C <-> window column rho - C + WL.
-  const int r1_row0 = wave * RUN1;                                  // scalar
+  const int r1_row0 = wave * RPW1;                                  // scalar
   const int t1_col = r1_row0 * T::PA + lane + T::SH1;               // B1 float index of the first x tap of (row0, lane)
   const int r_col = r1_row0 * T::PR + lane;                         // R float index of the same point
-  const bool interior = x0 - C >= 0 && x0 + kTX + C <= X && y0 - C >= 0 && y0 + TY + C <= Y;
-  // edge points: t = tid + 512 e -> (row t / E, ratio column 128 + t % E), kept as ONE packed register per point;
+  const bool interior = x0 - C >= 0 && x0 + TXW + C <= X && y0 - C >= 0 && y0 + TY + C <= Y;
+  // edge points: t = tid + NT e -> (row t / E, ratio column TXW + t % E), kept as ONE packed register per point;
   // the three offsets derived from it are recomputed where they are used (registers are what this kernel
   // is short of: two more live values spill, and a spill reload drains the whole load pipeline)
   int e_rc[EP];              // (row << 16) | column of the edge point in the ratio region
 #pragma unroll
   for (int e = 0; e < EP; ++e) {
-    const int t = min(tid + e * kThreads, T::NE - 1);
+    const int t = min(tid + e * NT, T::NE - 1);
     const int er = t / T::E, ec = t - er * T::E;
-    e_rc[e] = (er << 16) | (kTX + ec);
+    e_rc[e] = (er << 16) | (TXW + ec);
   }
   auto e_t1 = [&](int e) { return (e_rc[e] >> 16) * T::PA + (e_rc[e] & 0xffff) + T::SH1; };   // B1 index of its first x tap
   auto e_r = [&](int e) { return (e_rc[e] >> 16) * T::PR + (e_rc[e] & 0xffff); };               // R index
   auto e_voff = [&](int e) { return ((e_rc[e] >> 16) * p.y_pitch + (e_rc[e] & 0xffff)) * 4; };  // from the y window's first element
-  // ---- stage-2 points: tile columns lane + 64 cg, tile rows wave * RUN + m
-  const int t2_col = (wave * RUN) * T::PR + lane;
+  // ---- stage-2 points: the wave's tile rows wave * RPW .. + RPW - 1, tile columns lane (+ 64)
+  const int t2_col = (wave * RPW) * T::PR + lane;
   // rows of a wave differ by a wave-uniform stride: one lane offset register per stream, the row term goes
   // into the scalar base of each load / store
   const int lane_off = lane * 4;
   // in-plane interior test of the epilogue's normalisation (the caller's PSF extents)
   const int ry = p.py / 2, rx = p.px / 2, rz = p.pz / 2;
   // every point of the tile has all its in-plane taps inside the volume (wave-uniform: the fast path of the norm)
-  const bool tile_norm_interior = x0 >= rx && x0 + kTX <= X - rx && y0 >= ry && y0 + TY <= Y - ry;
-  const bool ok0 = x0 + lane < X, ok1 = x0 + lane + 64 < X;
+  const bool tile_norm_interior = x0 >= rx && x0 + TXW <= X - rx && y0 >= ry && y0 + TY <= Y - ry;
+  const bool okc[2] = {x0 + lane < X, x0 + lane + pair_col<NCG>(1) < X};
 
-  f32x2 acc1[PZ][RUN1], acc2[PZ][RUN];
+  f32x2 acc1[PZ][NP1], acc2[PZ][NP2];
   float acc1e[PZ][EP];
 #pragma unroll
   for (int j = 0; j < PZ; ++j) {
 #pragma unroll
-    for (int i = 0; i < RUN1; ++i) acc1[j][i] = splat(0.0f);
+    for (int i = 0; i < NP1; ++i) acc1[j][i] = splat(0.0f);
 #pragma unroll
     for (int i = 0; i < EP; ++i) acc1e[j][i] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < RUN; ++i) acc2[j][i] = splat(0.0f);
+    for (int i = 0; i < NP2; ++i) acc2[j][i] = splat(0.0f);
   }
-  float yv[2 * RUN1], ye[EP], xc[2 * RUN];
+  float yv[2 * NP1], ye[EP], xc[2 * NP2];   // [2 i + h] = half h of pair i
 #pragma unroll
-  for (int i = 0; i < 2 * RUN1; ++i) yv[i] = 0.0f;
+  for (int i = 0; i < 2 * NP1; ++i) yv[i] = 0.0f;
 #pragma unroll
   for (int i = 0; i < EP; ++i) ye[i] = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 2 * RUN; ++i) xc[i] = 0.0f;
+  for (int i = 0; i < 2 * NP2; ++i) xc[i] = 0.0f;
   __builtin_amdgcn_sched_barrier(0);
 
   auto clampz = [&](int z) { return min(max(z, 0), Z - 1); };
@@ -309,28 +318,27 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
     const unsigned dst = lds_base + (slot * T::ASZ + wave * 64 * 4) * 4;
 #pragma unroll
     for (int k = 0; k < SL; ++k) {
-      const bool live = wave * 64 + k * kThreads < T::NCH;  // wave-uniform
-      glds_x4(src, s_voff(k), live ? dst + k * kThreads * 16 : lds_base + T::OFF_DUMP * 4);
+      const bool live = wave * 64 + k * NT < T::NCH;  // wave-uniform
+      glds_x4(src, s_voff(k), live ? dst + k * NT * 16 : lds_base + T::OFF_DUMP * 4);
     }
   };
   const float* const xc_tile = p.x + (static_cast<int64_t>(y0) * p.pitch + x0);
   const float* const y_tile = p.y + (static_cast<int64_t>(y0 - C) * p.y_pitch + (x0 - C));
   float* const o_tile = p.out + (static_cast<int64_t>(y0) * p.out_pitch + x0);
   auto issue_xc = [&](int o) {  // NXC loads: x at the output points of plane o
-    const float* base = xc_tile + (static_cast<int64_t>(clampz(o)) * p.plane + static_cast<int64_t>(wave * RUN) * p.pitch);
+    const float* base = xc_tile + (static_cast<int64_t>(clampz(o)) * p.plane + static_cast<int64_t>(wave * RPW) * p.pitch);
 #pragma unroll
-    for (int m = 0; m < RUN; ++m) {
-      gload<0>(xc[m], base + m * p.pitch, lane_off);
-      gload<256>(xc[RUN + m], base + m * p.pitch, lane_off);
+    for (int i = 0; i < NP2; ++i) {
+      gload<0>(xc[2 * i], base + pair_row<NCG>(i, 0) * p.pitch, lane_off);
+      gload<4 * pair_col<NCG>(1)>(xc[2 * i + 1], base + pair_row<NCG>(i, 1) * p.pitch, lane_off);
     }
   };
   auto issue_y = [&](int q) {  // NY loads: y at the ratio points of plane q
     const float* base = y_tile + static_cast<int64_t>(clampz(q)) * p.y_plane;
 #pragma unroll
-    for (int m = 0; m < RUN1; ++m) {
-      const float* row = base + min(r1_row0 + m, T::R1 - 1) * p.y_pitch;   // (scalar)
-      gload<0>(yv[m], row, lane_off);
-      gload<256>(yv[RUN1 + m], row, lane_off);
+    for (int i = 0; i < NP1; ++i) {
+      gload<0>(yv[2 * i], base + min(r1_row0 + pair_row<NCG>(i, 0), T::R1 - 1) * p.y_pitch, lane_off);   // (scalar rows)
+      gload<4 * pair_col<NCG>(1)>(yv[2 * i + 1], base + min(r1_row0 + pair_row<NCG>(i, 1), T::R1 - 1) * p.y_pitch, lane_off);
     }
 #pragma unroll
     for (int e = 0; e < EP; ++e) gload<0>(ye[e], base, e_voff(e));
@@ -371,39 +379,42 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
       float w1y[PYX];
 #pragma unroll
       for (int b = 0; b < PYX; ++b) LSR_TAP(w1y[b], 0, 112 + b);
-      ypass<T::RY, PYX>(smem4 + slot * (T::ASZ / 4), B1_4, T::CH, T::R1, T::NG1, w1y, tid);
+      ypass<T::RY, PYX, NT>(smem4 + slot * (T::ASZ / 4), B1_4, T::CH, T::R1, T::NG1, w1y, tid);
     } else {  // a plane outside the volume: zeros
 #pragma unroll
       for (int k = 0; k < T::XIT1; ++k)
-        if (k + 1 < T::XIT1 || tid + k * kThreads < T::NIT1) B1_4[tid + k * kThreads] = f32x4{0, 0, 0, 0};
+        if (k + 1 < T::XIT1 || tid + k * NT < T::NIT1) B1_4[tid + k * NT] = f32x4{0, 0, 0, 0};
     }
     if (r_live) {
       float w2y[PYX];
 #pragma unroll
       for (int b = 0; b < PYX; ++b) LSR_TAP(w2y[b], 1, 112 + b);
-      ypass<T::RY, PYX>(R_4, B2_4, T::CH2, TY, T::NG2, w2y, tid);
+      ypass<T::RY, PYX, NT>(R_4, B2_4, T::CH2, TY, T::NG2, w2y, tid);
     } else {
 #pragma unroll
       for (int k = 0; k < T::XIT2; ++k)
-        if (k + 1 < T::XIT2 || tid + k * kThreads < T::NIT2) B2_4[tid + k * kThreads] = f32x4{0, 0, 0, 0};
+        if (k + 1 < T::XIT2 || tid + k * NT < T::NIT2) B2_4[tid + k * NT] = f32x4{0, 0, 0, 0};
     }
     lds_barrier();
 
     // ---------------- phase B ----------------
     // stage 2: absorb t2 of ratio plane qr into the pending output planes, finish output plane o
     {
-      // column c of the thread's RUN rows (both column groups) one group ahead of its FMAs; a scheduling
-      // fence per group keeps the PZ taps of ONE group in SGPRs (all PZ * PYX at once spill)
+      // column c of the thread's pairs one tap group ahead of its FMAs; a scheduling fence per group keeps
+      // the PZ taps of ONE group in SGPRs (all PZ * PYX at once spill)
       const float* base = B2 + t2_col;
-      f32x2 vb[2][RUN];   // two register sets, indexed by the (compile-time) parity of c: no copies
+      auto ld = [&](int i, int c) {
+        return f32x2{base[pair_row<NCG>(i, 0) * T::PR + c], base[pair_row<NCG>(i, 1) * T::PR + pair_col<NCG>(1) + c]};
+      };
+      f32x2 vb[2][NP2];   // two register sets, indexed by the (compile-time) parity of c: no copies
 #pragma unroll
-      for (int m = 0; m < RUN; ++m) vb[0][m] = f32x2{base[m * T::PR], base[m * T::PR + 64]};
+      for (int i = 0; i < NP2; ++i) vb[0][i] = ld(i, 0);
 #pragma unroll
       for (int c = 0; c < PYX; ++c) {
-        f32x2 (&v)[RUN] = vb[c & 1];
+        f32x2 (&v)[NP2] = vb[c & 1];
         if (c + 1 < PYX) {
 #pragma unroll
-          for (int m = 0; m < RUN; ++m) vb[(c + 1) & 1][m] = f32x2{base[m * T::PR + c + 1], base[m * T::PR + c + 1 + 64]};
+          for (int i = 0; i < NP2; ++i) vb[(c + 1) & 1][i] = ld(i, c + 1);
         }
         // (the tap of plane j + 1 is fetched ahead of the FMAs of plane j: a VALU-written SGPR needs a wait
         // state before a VALU reads it, which the FMAs in between provide)
@@ -415,10 +426,10 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
           if (j + 1 < PZ) LSR_TAP(wnext, 1, c * PZ + j + 1);
           const f32x2 w = splat(ws);
 #pragma unroll
-          for (int m = 0; m < RUN; ++m) {
-            if (c == 0) acc2[j][m] = j + 1 < PZ ? pk_fma(w, v[m], acc2[j + 1][m]) : w * v[m];
-            else acc2[j][m] = pk_fma(w, v[m], acc2[j][m]);
-            pin(acc2[j][m]);
+          for (int i = 0; i < NP2; ++i) {
+            if (c == 0) acc2[j][i] = j + 1 < PZ ? pk_fma(w, v[i], acc2[j + 1][i]) : w * v[i];
+            else acc2[j][i] = pk_fma(w, v[i], acc2[j][i]);
+            pin(acc2[j][i]);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -427,33 +438,35 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
       wait_vm<NY + SL>();
       tie(xc);
       if (o >= zb && o < ze) {
-        float* obase = o_tile + (static_cast<int64_t>(o) * p.out_plane + static_cast<int64_t>(wave * RUN) * p.out_pitch);
-        // 1 / (H^T 1) of the thread's 2 * RUN points ([m] = column group 0, [RUN + m] = group 1).  Almost every
-        // point of almost every plane is interior (all taps land inside the volume: the tap sum); the rest
-        // take the prefix-sum table -- one rolled loop, so that its eight LDS reads and their branch exist
+        float* obase = o_tile + (static_cast<int64_t>(o) * p.out_plane + static_cast<int64_t>(wave * RPW) * p.out_pitch);
+        // 1 / (H^T 1) of the thread's 2 * NP2 points.  Almost every point of almost every plane is interior (all
+        // taps land inside the volume: the tap sum); the rest take the prefix-sum table (global memory, a few
+        // hundred bytes that stay in cache) -- one rolled loop, so that its eight reads and their branch exist
         // once in the code, not once per point.
-        float rn[2 * RUN];
+        float rn[2 * NP2];
         const float rfull = fast_rcp(p.norm_full);
 #pragma unroll
-        for (int i = 0; i < 2 * RUN; ++i) rn[i] = rfull;
+        for (int i = 0; i < 2 * NP2; ++i) rn[i] = rfull;
         if (!(tile_norm_interior && o >= rz && o < Z - rz)) {   // wave-uniform
 #pragma unroll 1
-          for (int i = 0; i < 2 * RUN; ++i) {
-            const int m = i < RUN ? i : i - RUN;
-            const int gy = min(y0 + wave * RUN + m, Y - 1), gx = min(x0 + lane + (i < RUN ? 0 : 64), X - 1);
+          for (int k = 0; k < 2 * NP2; ++k) {
+            const int i = k >> 1, h = k & 1;
+            const int row = NCG == 2 ? i : 2 * i + h, col = NCG == 2 ? 64 * h : 0;
+            const int gy = min(y0 + wave * RPW + row, Y - 1), gx = min(x0 + lane + col, X - 1);
             const bool inside = o >= rz && o < Z - rz && gy >= ry && gy < Y - ry && gx >= rx && gx < X - rx;
-            const float r = fast_rcp(inside ? p.norm_full : dense_norm(p, s_norm, o, gy, gx));
+            const float r = fast_rcp(inside ? p.norm_full : dense_norm(p, p.norm_table, o, gy, gx));
 #pragma unroll
-            for (int k = 0; k < 2 * RUN; ++k) rn[k] = i == k ? r : rn[k];
+            for (int t = 0; t < 2 * NP2; ++t) rn[t] = k == t ? r : rn[t];
           }
         }
 #pragma unroll
-        for (int m = 0; m < RUN; ++m) {
-          if (y0 + wave * RUN + m < Y) {  // wave-uniform
-            // (x * u) * rcp(H^T 1): the two-launch UPDATE's order
-            if (ok0) gstore<0>(obase + m * p.out_pitch, lane_off, xc[m] * acc2[0][m].x * rn[m]);
-            if (ok1) gstore<256>(obase + m * p.out_pitch, lane_off, xc[RUN + m] * acc2[0][m].y * rn[RUN + m]);
-          }
+        for (int i = 0; i < NP2; ++i) {
+          // (x * u) * rcp(H^T 1): the two-launch UPDATE's order
+          if (y0 + wave * RPW + pair_row<NCG>(i, 0) < Y && okc[0])   // (row test wave-uniform)
+            gstore<0>(obase + pair_row<NCG>(i, 0) * p.out_pitch, lane_off, xc[2 * i] * acc2[0][i].x * rn[2 * i]);
+          if (y0 + wave * RPW + pair_row<NCG>(i, 1) < Y && okc[NCG == 2 ? 1 : 0])
+            gstore<4 * pair_col<NCG>(1)>(obase + pair_row<NCG>(i, 1) * p.out_pitch, lane_off,
+                                         xc[2 * i + 1] * acc2[0][i].y * rn[2 * i + 1]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);  // the refill reuses xc
@@ -462,19 +475,22 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
     // stage 1: absorb t1 of x plane pz into the pending ratio planes, finish ratio plane q
     {
       const float* base = B1 + t1_col;
-      f32x2 vb[2][RUN1];
+      auto ld = [&](int i, int c) {
+        return f32x2{base[pair_row<NCG>(i, 0) * T::PA + c], base[pair_row<NCG>(i, 1) * T::PA + pair_col<NCG>(1) + c]};
+      };
+      f32x2 vb[2][NP1];
       float veb[2][EP];
 #pragma unroll
-      for (int m = 0; m < RUN1; ++m) vb[0][m] = f32x2{base[m * T::PA], base[m * T::PA + 64]};
+      for (int i = 0; i < NP1; ++i) vb[0][i] = ld(i, 0);
 #pragma unroll
       for (int e = 0; e < EP; ++e) veb[0][e] = B1[e_t1(e)];
 #pragma unroll
       for (int c = 0; c < PYX; ++c) {
-        f32x2 (&v)[RUN1] = vb[c & 1];
+        f32x2 (&v)[NP1] = vb[c & 1];
         float (&ve)[EP] = veb[c & 1];
         if (c + 1 < PYX) {
 #pragma unroll
-          for (int m = 0; m < RUN1; ++m) vb[(c + 1) & 1][m] = f32x2{base[m * T::PA + c + 1], base[m * T::PA + c + 1 + 64]};
+          for (int i = 0; i < NP1; ++i) vb[(c + 1) & 1][i] = ld(i, c + 1);
 #pragma unroll
           for (int e = 0; e < EP; ++e) veb[(c + 1) & 1][e] = B1[e_t1(e) + c + 1];
         }
@@ -486,10 +502,10 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
           if (j + 1 < PZ) LSR_TAP(wnext, 0, c * PZ + j + 1);
           const f32x2 w = splat(ws);
 #pragma unroll
-          for (int m = 0; m < RUN1; ++m) {
-            if (c == 0) acc1[j][m] = j + 1 < PZ ? pk_fma(w, v[m], acc1[j + 1][m]) : w * v[m];
-            else acc1[j][m] = pk_fma(w, v[m], acc1[j][m]);
-            pin(acc1[j][m]);
+          for (int i = 0; i < NP1; ++i) {
+            if (c == 0) acc1[j][i] = j + 1 < PZ ? pk_fma(w, v[i], acc1[j + 1][i]) : w * v[i];
+            else acc1[j][i] = pk_fma(w, v[i], acc1[j][i]);
+            pin(acc1[j][i]);
           }
 #pragma unroll
           for (int e = 0; e < EP; ++e) {
@@ -507,29 +523,33 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
       const bool q_in = q >= q_lo && q <= q_hi;  // wave-uniform; planes outside are zero
       if (q_in && interior) {
 #pragma unroll
-        for (int m = 0; m < RUN1; ++m) {
-          const f32x2 r = f32x2{yv[m], yv[RUN1 + m]} * fast_rcp2(acc1[0][m] + splat(p.eps));
-          Rw[r_col + m * T::PR] = r.x;
-          Rw[r_col + m * T::PR + 64] = r.y;
+        for (int i = 0; i < NP1; ++i) {
+          const f32x2 r = f32x2{yv[2 * i], yv[2 * i + 1]} * fast_rcp2(acc1[0][i] + splat(p.eps));
+          Rw[r_col + pair_row<NCG>(i, 0) * T::PR] = r.x;
+          Rw[r_col + pair_row<NCG>(i, 1) * T::PR + pair_col<NCG>(1)] = r.y;
         }
 #pragma unroll
         for (int e = 0; e < EP; ++e)
-          if (e + 1 < EP || tid + e * kThreads < T::NE) Rw[e_r(e)] = ye[e] * fast_rcp(acc1e[0][e] + p.eps);
+          if (e + 1 < EP || tid + e * NT < T::NE) Rw[e_r(e)] = ye[e] * fast_rcp(acc1e[0][e] + p.eps);
       } else {
         // border tiles and planes outside the volume: ratio is zero wherever its point is outside
         const int gx0 = x0 + lane - C;
-        const bool in0 = q_in && gx0 >= 0 && gx0 < X, in1 = q_in && gx0 + 64 >= 0 && gx0 + 64 < X;
+        const bool inc[2] = {q_in && gx0 >= 0 && gx0 < X, q_in && gx0 + pair_col<NCG>(1) >= 0 && gx0 + pair_col<NCG>(1) < X};
 #pragma unroll
-        for (int m = 0; m < RUN1; ++m) {
-          const int gy = y0 + r1_row0 + m - C;
-          const bool row_in = gy >= 0 && gy < Y && r1_row0 + m < T::R1;  // wave-uniform
-          const f32x2 r = f32x2{yv[m], yv[RUN1 + m]} * fast_rcp2(acc1[0][m] + splat(p.eps));
-          Rw[r_col + m * T::PR] = (row_in && in0) ? r.x : 0.0f;
-          Rw[r_col + m * T::PR + 64] = (row_in && in1) ? r.y : 0.0f;
+        for (int i = 0; i < NP1; ++i) {
+          const f32x2 r = f32x2{yv[2 * i], yv[2 * i + 1]} * fast_rcp2(acc1[0][i] + splat(p.eps));
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int row = r1_row0 + pair_row<NCG>(i, h);
+            const int gy = y0 + row - C;
+            const bool row_in = gy >= 0 && gy < Y && row < T::R1;  // wave-uniform
+            Rw[r_col + pair_row<NCG>(i, h) * T::PR + (h ? pair_col<NCG>(1) : 0)] =
+                (row_in && inc[NCG == 2 ? h : 0]) ? (h ? r.y : r.x) : 0.0f;
+          }
         }
 #pragma unroll
         for (int e = 0; e < EP; ++e) {
-          if (e + 1 < EP || tid + e * kThreads < T::NE) {
+          if (e + 1 < EP || tid + e * NT < T::NE) {
             const int gy = y0 + (e_rc[e] >> 16) - C, gx = x0 + (e_rc[e] & 0xffff) - C;
             const float r = ye[e] * fast_rcp(acc1e[0][e] + p.eps);
             Rw[e_r(e)] = (q_in && gy >= 0 && gy < Y && gx >= 0 && gx < X) ? r : 0.0f;
@@ -550,8 +570,8 @@ __global__ __launch_bounds__(kThreads) void rl_fused_ysep_kernel(YsepArgs p) {
 
 template <int PZ, int PYX>
 bool launch_one(const YsepArgs& p, dim3 grid, hipStream_t s) {
-  constexpr int RUN = lsr::ysep_run(PZ);
-  hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, RUN>), grid, dim3(kThreads), 0, s, p);
+  if (p.narrow) hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 4, 1>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 8, 2>), grid, dim3(512), 0, s, p);
   return true;
 }
 

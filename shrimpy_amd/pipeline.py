@@ -63,6 +63,12 @@ def gaussian_psf_factors(shape_zyx=(9, 7, 7), sigma_zyx=(2.0, 1.2, 1.2)):
     return tuple(ks)
 
 
+def _lib_error(message: str):
+    from ._lib import LsrError
+
+    return LsrError("VolumeReconstructor", -1, message)
+
+
 class VolumeReconstructor:
     """(Flat-field) -> deskew -> (affine register) -> (Richardson-Lucy) for volumes of one raw shape
     on one device.
@@ -98,7 +104,24 @@ class VolumeReconstructor:
         self._y_pad = None
         self._pitched = None      # deskew target with zero-padded rows, when a registration reads it (see __call__)
         dec: DeconvolveSettings | None = settings.deconvolution
-        if dec is not None and dec.iterations > 0:
+        self._host_rl = None      # device cpu: the arguments of host.richardson_lucy instead of a plan
+        if self.device.type == "cpu":
+            # no HIP device in play (the reference's cpu branch, shrimpy/preprocessing.py:78-82): every stage
+            # runs its native host twin through the same public functions (shrimpy_amd/host.py)
+            if getattr(settings, "flatfield", False):
+                raise _lib_error("the flat-field correction exists only as a gfx950 kernel; there is no CPU fallback for it")
+            if dec is not None and dec.iterations > 0:
+                if dec.psf_path:
+                    self._host_rl = dict(psf=np.load(dec.psf_path).astype(np.float32), separable=dec.separable,
+                                         separable_rtol=dec.separable_rtol)
+                else:
+                    factors = gaussian_psf_factors(dec.gaussian_shape_zyx, dec.gaussian_sigma_zyx)
+                    if dec.separable == "never":
+                        self._host_rl = dict(psf=factors[0][:, None, None] * factors[1][None, :, None] * factors[2][None, None, :],
+                                             separable="never")
+                    else:
+                        self._host_rl = dict(psf=None, psf_factors=factors)
+        elif dec is not None and dec.iterations > 0:
             from .deconvolve import RichardsonLucyPlan
 
             if dec.psf_path:
@@ -149,7 +172,8 @@ class VolumeReconstructor:
                 if self._y_pad is None:
                     self._y_pad = self._plan.new_padded_input()
                 target = self._y_pad
-            elif (self._register is not None and self._canonical_deskew and self._register.mode == "constant"
+            elif (self.device.type == "cuda" and self._register is not None and self._canonical_deskew
+                    and self._register.mode == "constant"
                     and self._geo.output_shape[2] % 4 != 0 and self._geo.output_shape[2] >= 8):
                 # a registration follows and the deskewed rows would not start on 16-byte boundaries:
                 # deskew into zero-padded rows so that the LDS-staged affine kernels take the map
@@ -178,6 +202,11 @@ class VolumeReconstructor:
         if self._plan is not None:
             dec = self.settings.deconvolution
             vol = self._plan(vol, iterations=dec.iterations, eps=dec.eps, events=rl_events)
+        elif self._host_rl is not None:
+            from .deconvolve import richardson_lucy
+
+            dec = self.settings.deconvolution
+            vol = richardson_lucy(vol, iterations=dec.iterations, eps=dec.eps, **self._host_rl)
         return vol
 
 

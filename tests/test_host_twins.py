@@ -181,3 +181,61 @@ def test_host_twins_equal_the_device_kernels_bit_for_bit(device):
         dev = RichardsonLucyPlan(tuple(y.shape), None, device, psf_factors=factors, fused=fused)(y.to(device), iterations=6)
         _rl_close(got.numpy(), dev.cpu().numpy())
     _rl_close(richardson_lucy(y, rot, iterations=3).numpy(), richardson_lucy(y.to(device), rot, iterations=3).cpu().numpy())
+
+
+def test_the_cli_chain_runs_end_to_end_without_a_gpu(tmp_path, monkeypatch):
+    """BASELINE configs[0] with everything around it: OME-Zarr in, YAML settings, the `reconstruct` command
+    (deskew -> register -> deconvolve) and OME-Zarr out on a box with no HIP device -- the reference's cpu
+    branch (`shrimpy/preprocessing.py:78-82`).  Every stage runs its native host twin; the stored volumes equal
+    the oracle chain (deskew and registration bit for bit, RL within its bar)."""
+    import torch
+    import yaml
+
+    from click.testing import CliRunner
+
+    from shrimpy_amd import cli
+    from shrimpy_amd.io.omezarr import open_ome_zarr
+
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    rng = np.random.default_rng(12)
+    raw = {}
+    with open_ome_zarr(tmp_path / "raw.zarr", layout="hcs", mode="w", channel_names=["LS"], prefer_iohub=False) as plate:
+        for i in range(2):
+            arr = plate.create_position("A", str(i + 1), "0").create_zeros(
+                "0", shape=(2, 1, 96, 16, 40), dtype="uint16", scale=(1, 1, 0.15, 0.1133, 0.1133))
+            for t in range(2):
+                raw[(i, t)] = rng.integers(90, 900, (96, 16, 40)).astype(np.uint16)
+                arr.write_volume(t, 0, raw[(i, t)])
+    m = np.eye(4)
+    m[:3, 3] = [0.5, -1.25, 2.0]
+    m[1, 2] = 0.02
+    (tmp_path / "recon.yml").write_text(yaml.safe_dump(dict(
+        deskew=dict(pixel_size_um=0.1133, ls_angle_deg=30.0, scan_step_um=0.15, keep_overhang=False, average_n_slices=3),
+        registration=dict(affine_transform_zyx=m.tolist()),
+        deconvolution=dict(iterations=4, gaussian_shape_zyx=[5, 5, 5], gaussian_sigma_zyx=[1.2, 1.0, 1.0]))))
+    res = CliRunner().invoke(cli.cli, ["reconstruct", "-i", str(tmp_path / "raw.zarr"), "-c", str(tmp_path / "recon.yml"),
+                                       "-o", str(tmp_path / "out.zarr")])
+    assert res.exit_code == 0, res.output
+    _, factors = o.gaussian_psf((5, 5, 5), (1.2, 1.0, 1.0))
+    with open_ome_zarr(tmp_path / "out.zarr", prefer_iohub=False) as out:
+        positions = dict(out.positions())
+        assert list(positions) == ["A/1/0", "A/2/0"]
+        for i, key in enumerate(positions):
+            for t in range(2):
+                d = o.deskew(raw[(i, t)].astype(np.float32), 30.0, 0.755, False, 3)
+                reg = o.affine_apply_4x4(d, m, d.shape)
+                want = o.richardson_lucy_separable(reg, factors, iterations=4)
+                got = positions[key]["0"].read_volume(t, 0)
+                assert got.shape == want.shape and got.dtype == np.float32
+                _rl_close(got, want)
+    # deskew alone: the stored volume IS the oracle's
+    (tmp_path / "deskew.yml").write_text(yaml.safe_dump(dict(
+        pixel_size_um=0.1133, ls_angle_deg=30.0, scan_step_um=0.15, keep_overhang=False, average_n_slices=3)))
+    res = CliRunner().invoke(cli.cli, ["deskew", "-i", str(tmp_path / "raw.zarr"), "-c", str(tmp_path / "deskew.yml"),
+                                       "-o", str(tmp_path / "deskewed.zarr"), "-p", "A/2/0"])
+    assert res.exit_code == 0, res.output
+    with open_ome_zarr(tmp_path / "deskewed.zarr", prefer_iohub=False) as out:
+        np.testing.assert_array_equal(dict(out.positions())["A/2/0"]["0"].read_volume(1, 0),
+                                      o.deskew(raw[(1, 1)].astype(np.float32), 30.0, 0.755, False, 3))
