@@ -25,6 +25,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -51,7 +52,11 @@ void parallel_ranges(int64_t n, F&& fn) {
   for (int w = 0; w < workers; ++w) {
     const int64_t a = w * per, b = a + per < n ? a + per : n;
     if (a >= b) break;
-    pool.emplace_back([&fn, a, b] { fn(a, b); });
+    try {
+      pool.emplace_back([&fn, a, b] { fn(a, b); });
+    } catch (const std::system_error&) {   // the box refuses another thread: this range runs here
+      fn(a, b);
+    }
   }
   for (std::thread& t : pool) t.join();
 }

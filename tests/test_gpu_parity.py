@@ -1016,10 +1016,15 @@ def test_rl_y_separable_psf_takes_the_stencil_plus_y_pass_and_matches_dense(devi
         assert torch.equal(got, RichardsonLucyPlan(thin, psf, device)(_t(yt, device), iterations=2))
 
 
-def test_rl_y_separable_random_psf_shapes(device):
+@pytest.mark.parametrize("fused_shape", ["narrow", "wide"])
+def test_rl_y_separable_random_psf_shapes(device, fused_shape, monkeypatch):
+    """Both shapes of the fused ky (x) kzx kernel (256 threads on 32 x 64 tiles / 512 threads on 32 x 128,
+    ``LSR_YSEP_SHAPE``) against the oracle and, bit for bit, against the two-launch form."""
     import torch
 
     from shrimpy_amd.deconvolve import RichardsonLucyPlan
+
+    monkeypatch.setenv("LSR_YSEP_SHAPE", fused_shape)
 
     rng = np.random.default_rng(45)
     for case in range(10):
