@@ -239,3 +239,51 @@ def test_the_cli_chain_runs_end_to_end_without_a_gpu(tmp_path, monkeypatch):
     with open_ome_zarr(tmp_path / "deskewed.zarr", prefer_iohub=False) as out:
         np.testing.assert_array_equal(dict(out.positions())["A/2/0"]["0"].read_volume(1, 0),
                                       o.deskew(raw[(1, 1)].astype(np.float32), 30.0, 0.755, False, 3))
+
+
+def test_two_ranks_of_the_cli_on_a_box_without_a_gpu_write_the_single_rank_store(tmp_path):
+    """The sharded `reconstruct` command under `torch.distributed.run` with two ranks and no HIP device: units
+    split round-robin, the ranks meet over gloo (barrier + agreement on rank 0's set-up only, no data-path
+    collective), every rank writes its own positions -- and the store equals the one a single rank writes."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    import yaml
+
+    from pathlib import Path
+
+    from shrimpy_amd.io.omezarr import open_ome_zarr
+
+    root = Path(__file__).resolve().parent.parent
+    rng = np.random.default_rng(2)
+    with open_ome_zarr(tmp_path / "raw.zarr", layout="hcs", mode="w", channel_names=["LS"], prefer_iohub=False) as plate:
+        for i in range(3):
+            arr = plate.create_position("A", str(i + 1), "0").create_zeros(
+                "0", shape=(1, 1, 80, 12, 24), dtype="uint16", scale=(1, 1, 0.15, 0.1133, 0.1133))
+            arr.write_volume(0, 0, rng.integers(90, 900, (80, 12, 24)).astype(np.uint16))
+    (tmp_path / "recon.yml").write_text(yaml.safe_dump(dict(
+        deskew=dict(pixel_size_um=0.1133, ls_angle_deg=30.0, scan_step_um=0.15, keep_overhang=False, average_n_slices=3),
+        deconvolution=dict(iterations=3, gaussian_shape_zyx=[3, 3, 3], gaussian_sigma_zyx=[1.0, 1.0, 1.0]))))
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = ["-m", "shrimpy_amd", "reconstruct", "-i", str(tmp_path / "raw.zarr"), "-c", str(tmp_path / "recon.yml")]
+    one = subprocess.run([sys.executable, *args, "-o", str(tmp_path / "one.zarr")], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), *args, "-o", str(tmp_path / "two.zarr")],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    assert "'world_size': 2" in two.stdout
+    with open_ome_zarr(tmp_path / "one.zarr", prefer_iohub=False) as a, open_ome_zarr(tmp_path / "two.zarr", prefer_iohub=False) as b:
+        for (ka, pa), (kb, pb) in zip(a.positions(), b.positions()):
+            assert ka == kb
+            va = pa["0"].read_volume(0, 0)
+            assert float(va.max()) > 0
+            np.testing.assert_array_equal(va, pb["0"].read_volume(0, 0))
