@@ -156,7 +156,9 @@ def cpu_baseline(config_id=2, all_core_shape=(640, 128, 640), single_shape=(512,
     import statistics
 
     cores = host_cores()
-    procs = cores if max_procs is None else max(1, min(cores, int(max_procs)))
+    # every host core, as BASELINE.md section 4 says -- up to 64 workers (about 1 GB each while the scene is
+    # generated: a whole 8-GPU node's cores at once would be a three-digit GB sample, not a bounded one)
+    procs = min(cores, 64) if max_procs is None else max(1, min(cores, int(max_procs)))
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with ctx.Pool(procs) as pool:
