@@ -488,6 +488,14 @@ int lsr_correlate_sep_f32_cpu(const float* in, float* out, const float* aux, int
 int lsr_correlate_dense_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y,
                                 int64_t X, const float* w, int pz, int py, int px, int epilogue,
                                 float eps, const double* norm_table, lsr_stream_t stream);
+int lsr_flatfield_pattern_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t X, float* pattern,
+                                  float* mean_out, void* scratch /* unused */, lsr_stream_t stream);
+int lsr_flatfield_pattern_u16_cpu(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* pattern,
+                                  float* mean_out, void* scratch /* unused */, lsr_stream_t stream);
+int lsr_flatfield_apply_f32_cpu(const float* in, const float* pattern, const float* mean_dev,
+                                float* out, int64_t Z, int64_t Y, int64_t X, lsr_stream_t stream);
+int lsr_flatfield_apply_u16_cpu(const uint16_t* in, const float* pattern, const float* mean_dev,
+                                float* out, int64_t Z, int64_t Y, int64_t X, lsr_stream_t stream);
 
 #ifdef __cplusplus
 }

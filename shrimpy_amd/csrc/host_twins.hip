@@ -10,6 +10,8 @@
 //   lsr_average_slices_f32_cpu                <->  lsr_average_slices_f32              (deskew.hip)
 //   lsr_correlate_sep_f32_cpu                 <->  lsr_correlate_sep_f32               (correlate.hip)
 //   lsr_correlate_dense_f32_cpu               <->  lsr_correlate_dense_f32             (correlate.hip)
+//   lsr_flatfield_pattern_f32_cpu / _u16_cpu  <->  lsr_flatfield_pattern_f32 / _u16    (flatfield.hip)
+//   lsr_flatfield_apply_f32_cpu / _u16_cpu    <->  lsr_flatfield_apply_f32 / _u16      (flatfield.hip)
 //
 // Arithmetic (what "the same" means):
 //   resamplers -- coordinates ((zo*m0 + yo*m1) + xo*m2) + shift, weights w0 = 1 - f, w1 = 1 - w0 and the
@@ -22,6 +24,7 @@
 // output planes, at most lsr_set_host_threads(n) of them (default 1) -- no OpenMP runtime enters the process
 // (the reference's warning about torch plus a second OpenMP, shrimpy/tests/conftest.py:11-17).
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -369,4 +372,85 @@ extern "C" int lsr_correlate_dense_f32_cpu(const float* in, float* out, const fl
         }
   });
   return LSR_OK;
+}
+
+// ---- bright-field flat-field (shrimpy/preprocessing.py:385-404): pattern = volume.quantile(0.5, dim=0), its
+// mean, out = in / pattern * mean.  The median as flatfield.hip forms it: the two middle order statistics a <= b,
+// torch's lerp b - (b - a) * 0.5 for an even count, a for an odd one, NaN if the column holds one; the mean in f64.
+
+namespace {
+
+template <typename T>
+int flat_pattern_cpu(const T* in, int64_t Z, int64_t Y, int64_t X, float* pattern, float* mean_out) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(pattern);
+  LSR_REQUIRE_PTR(mean_out);
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
+              (long long)X);
+  LSR_REQUIRE(Z < 65536, LSR_E_UNSUPPORTED, "Z = %lld: the median kernel counts in 16 bits", (long long)Z);
+  const int64_t plane = Y * X;
+  parallel_ranges(plane, [&](int64_t first, int64_t last) {
+    std::vector<float> col(static_cast<size_t>(Z));
+    for (int64_t i = first; i < last; ++i) {
+      bool nan = false;
+      for (int64_t z = 0; z < Z; ++z) {
+        const float v = static_cast<float>(in[z * plane + i]);
+        col[static_cast<size_t>(z)] = v;
+        nan |= v != v;
+      }
+      if (nan) {
+        pattern[i] = std::nanf("");
+        continue;
+      }
+      const int64_t hi = Z / 2;
+      std::nth_element(col.begin(), col.begin() + hi, col.end());
+      const float b = col[static_cast<size_t>(hi)];
+      if (Z & 1) {
+        pattern[i] = b;
+      } else {
+        const float a = *std::max_element(col.begin(), col.begin() + hi);
+        pattern[i] = b - (b - a) * 0.5f;
+      }
+    }
+  });
+  double sum = 0.0;
+  for (int64_t i = 0; i < plane; ++i) sum += static_cast<double>(pattern[i]);
+  mean_out[0] = static_cast<float>(sum / static_cast<double>(plane));
+  return LSR_OK;
+}
+
+template <typename T>
+int flat_apply_cpu(const T* in, const float* pattern, const float* mean, float* out, int64_t Z, int64_t Y, int64_t X) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(pattern);
+  LSR_REQUIRE_PTR(mean);
+  LSR_REQUIRE_PTR(out);
+  LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
+              (long long)X);
+  const int64_t plane = Y * X;
+  const float m = mean[0];
+  parallel_ranges(Z, [&](int64_t z_first, int64_t z_last) {
+    for (int64_t z = z_first; z < z_last; ++z)
+      for (int64_t i = 0; i < plane; ++i) out[z * plane + i] = static_cast<float>(in[z * plane + i]) / pattern[i] * m;
+  });
+  return LSR_OK;
+}
+
+}  // namespace
+
+extern "C" int lsr_flatfield_pattern_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t X, float* pattern, float* mean_out,
+                                             void*, lsr_stream_t) {
+  return flat_pattern_cpu(in, Z, Y, X, pattern, mean_out);
+}
+extern "C" int lsr_flatfield_pattern_u16_cpu(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* pattern,
+                                             float* mean_out, void*, lsr_stream_t) {
+  return flat_pattern_cpu(in, Z, Y, X, pattern, mean_out);
+}
+extern "C" int lsr_flatfield_apply_f32_cpu(const float* in, const float* pattern, const float* mean_dev, float* out, int64_t Z,
+                                           int64_t Y, int64_t X, lsr_stream_t) {
+  return flat_apply_cpu(in, pattern, mean_dev, out, Z, Y, X);
+}
+extern "C" int lsr_flatfield_apply_u16_cpu(const uint16_t* in, const float* pattern, const float* mean_dev, float* out,
+                                           int64_t Z, int64_t Y, int64_t X, lsr_stream_t) {
+  return flat_apply_cpu(in, pattern, mean_dev, out, Z, Y, X);
 }

@@ -5,7 +5,7 @@ Mirrors ``_LabelfreePreprocessor._flat_field_BF`` (reference ``shrimpy/preproces
 The median runs as a streaming radix select (``csrc/flatfield.hip``: at most four reads of the
 volume); the division is either its own launch or fused into the deskew kernel's staging pass
 (``deskew_with_matrix(..., flat_field=pattern)``).  Bright field only -- see the reference's note.
-No CPU fallback.
+CPU tensors run the native host twins (``lsr_flatfield_*_cpu``, same median rule, f64 mean).
 """
 
 from __future__ import annotations
@@ -29,17 +29,28 @@ class FlatFieldPattern:
         import torch
 
         u16 = isinstance(volume, torch.Tensor) and volume.dtype == torch.uint16
-        vol = _require_raw(volume, "volume") if u16 else _lib.require_device_f32(volume, "volume")
+        host = isinstance(volume, torch.Tensor) and volume.device.type == "cpu"
+        if host:
+            vol = volume.contiguous() if u16 else volume.to(torch.float32).contiguous()
+        else:
+            vol = _require_raw(volume, "volume") if u16 else _lib.require_device_f32(volume, "volume")
         if vol.dim() != 3 or tuple(vol.shape[1:]) != tuple(self.pattern.shape):
             raise ValueError(f"volume must be (Z, {self.pattern.shape[0]}, {self.pattern.shape[1]}), "
                              f"got {tuple(vol.shape)}")
         if out is None:
             out = torch.empty(tuple(vol.shape), dtype=torch.float32, device=vol.device)
         else:
-            _lib.require_device_f32(out, "out")
-            if tuple(out.shape) != tuple(vol.shape) or out.device != vol.device:
+            if not host:
+                _lib.require_device_f32(out, "out")
+            if (tuple(out.shape) != tuple(vol.shape) or out.device != vol.device or out.dtype != torch.float32
+                    or not out.is_contiguous()):
                 raise ValueError("out must match volume")
         z, y, x = (int(v) for v in vol.shape)
+        if host:     # no HIP device in play: the native host twin (csrc/host_twins.hip)
+            _lib.call("lsr_flatfield_apply_u16_cpu" if u16 else "lsr_flatfield_apply_f32_cpu", vol.data_ptr(),
+                      self.pattern.data_ptr(), self.mean.data_ptr(), out.data_ptr(), z, y, x, None)
+            _lib.mark_written(out)
+            return out
         with torch.cuda.device(vol.device):
             _lib.call("lsr_flatfield_apply_u16" if u16 else "lsr_flatfield_apply_f32", vol.data_ptr(), self.pattern.data_ptr(),
                       self.mean.data_ptr(), out.data_ptr(), z, y, x, _lib.stream_ptr(vol.device))
@@ -66,6 +77,16 @@ def flat_field_pattern(volume) -> FlatFieldPattern:
     if volume.dim() != 3:
         raise ValueError(f"volume must be (Z, Y, X), got shape {tuple(volume.shape)}")
     u16 = volume.dtype == torch.uint16
+    if volume.device.type == "cpu":     # no HIP device in play: the native host twin
+        vol = volume.contiguous() if u16 else volume.to(torch.float32).contiguous()
+        z, y, x = (int(v) for v in vol.shape)
+        pattern, mean = torch.empty((y, x), dtype=torch.float32), torch.empty((1,), dtype=torch.float32)
+        from . import host
+
+        host._threads()
+        _lib.call("lsr_flatfield_pattern_u16_cpu" if u16 else "lsr_flatfield_pattern_f32_cpu", vol.data_ptr(), z, y, x,
+                  pattern.data_ptr(), mean.data_ptr(), None, None)
+        return FlatFieldPattern(pattern, mean)
     if u16:
         vol = _require_raw(volume, "volume")
     else:

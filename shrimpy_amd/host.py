@@ -69,9 +69,8 @@ def deskew_with_matrix(raw, m, pre_average_shape, avg: int, out=None, flat_field
     """``deskew.deskew_with_matrix`` for a CPU tensor (float32 or uint16 counts), dense ``out`` only."""
     import torch
 
-    if flat_field is not None:
-        raise _lib.LsrError("deskew_with_matrix", -1, "the fused flat-field correction exists only in the HIP kernel; "
-                            "on a CPU tensor correct first, then deskew")
+    if flat_field is not None:     # (the fusion is a kernel matter; the values are those of correcting first)
+        raw = flat_field.apply(raw)
     u16 = raw.dtype == torch.uint16
     if not u16:
         raw = _f32(raw, "raw_data")

@@ -108,8 +108,6 @@ class VolumeReconstructor:
         if self.device.type == "cpu":
             # no HIP device in play (the reference's cpu branch, shrimpy/preprocessing.py:78-82): every stage
             # runs its native host twin through the same public functions (shrimpy_amd/host.py)
-            if getattr(settings, "flatfield", False):
-                raise _lib_error("the flat-field correction exists only as a gfx950 kernel; there is no CPU fallback for it")
             if dec is not None and dec.iterations > 0:
                 if dec.psf_path:
                     self._host_rl = dict(psf=np.load(dec.psf_path).astype(np.float32), separable=dec.separable,

@@ -106,10 +106,9 @@ class HotPathPreprocessor:
         """Pick the device (it must be a GPU as soon as a kernel stage is on) and switch the working
         shape to the deskewed one, which is what downstream consumers size themselves from."""
         self._device = _resolve_device()
-        if self._device.type != "cuda" and (self._apply_flatfield or self._require_gpu):
-            raise RuntimeError(
-                "no HIP device visible (device resolved to %s): the flat-field correction exists only as a "
-                "gfx950 kernel, and require_gpu asks for one; the deskew alone runs its host twin" % self._device)
+        if self._device.type != "cuda" and self._require_gpu:
+            raise RuntimeError("no HIP device visible (device resolved to %s) and require_gpu is set; without it the "
+                               "stages run their native host twins" % self._device)
         if self._deskew_settings is not None:
             from .deskew import get_deskewed_data_shape
 

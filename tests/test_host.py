@@ -195,19 +195,14 @@ def test_library_loads_and_reports_version_and_arg_errors():
 
 def test_gpu_only_objects_fail_loudly_on_cpu():
     """CPU tensors run the native host twins (tests/test_host_twins.py); what exists only on a HIP device --
-    the staged store path, the RL plan with its padded device volumes, the fused flat-field -- says so."""
-    import torch
-
+    the staged store path, the RL plan with its padded device volumes -- says so."""
     from shrimpy_amd.deconvolve import RichardsonLucyPlan
-    from shrimpy_amd.flatfield import flat_field_pattern
     from shrimpy_amd.staging import VolumeStager
 
     with pytest.raises(_lib.LsrError, match="no CPU fallback"):
         RichardsonLucyPlan((8, 8, 8), np.ones((3, 3, 3), np.float32) / 27, "cpu")
     with pytest.raises(_lib.LsrError, match="no CPU fallback"):
         VolumeStager((8, 8, 8), "uint16", (4, 8, 8), "cpu")
-    with pytest.raises(_lib.LsrError, match="no CPU fallback"):
-        flat_field_pattern(torch.zeros((8, 4, 4)))
 
 
 def test_product_never_imports_the_oracle():

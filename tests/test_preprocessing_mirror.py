@@ -97,15 +97,26 @@ def test_step_logs_and_reraises(caplog):
     assert "[p0] deskew FAILED: bad stack" in caplog.text
 
 
-def test_flatfield_on_a_cpu_tensor_fails_loudly(golden_dir):
-    """The flat-field step is a HIP kernel: a CPU tensor raises instead of running torch's CPU path."""
+def test_flat_field_on_a_cpu_tensor_equals_the_reference_fixture(golden_dir):
+    """`_flat_field_BF` of the reference itself (imported in the build container, `oracle/make_golden.py`) on its
+    own test input (`shrimpy/tests/test_preprocessing.py:155-160`) and on an odd-Z volume: the host twin's output."""
     import torch
 
-    from shrimpy_amd._lib import LsrError
+    from shrimpy_amd.flatfield import flat_field_bf, flat_field_pattern
 
     g = np.load(golden_dir / "ref_preprocessing.npz")
-    with pytest.raises(LsrError, match="no CPU fallback"):
-        _bare()._flat_field_BF(torch.as_tensor(g["flatfield_in"]))
+    for k in ("", "_odd"):
+        vol = g["flatfield_in" + k]
+        out = _bare()._flat_field_BF(torch.as_tensor(vol))
+        assert out.device.type == "cpu" and out.dtype == torch.float32
+        np.testing.assert_allclose(out.numpy(), g["flatfield_out" + k], rtol=1e-6)
+        if np.issubdtype(vol.dtype, np.integer) and vol.min() >= 0 and vol.max() < 65536:   # camera counts go in unconverted
+            np.testing.assert_allclose(flat_field_bf(torch.as_tensor(vol.astype(np.uint16))).numpy(), g["flatfield_out" + k],
+                                       rtol=1e-6)
+    nan = np.ones((4, 2, 3), np.float32)
+    nan[2, 1, 1] = np.nan
+    pat = flat_field_pattern(torch.as_tensor(nan)).pattern.numpy()
+    assert np.isnan(pat[1, 1]) and np.isfinite(np.delete(pat.ravel(), 4)).all()     # quantile propagates NaN
 
 
 @pytest.mark.gpu
@@ -120,9 +131,9 @@ def test_flatfield_matches_reference_capture(golden_dir):
         np.testing.assert_allclose(out.cpu().numpy(), g["flatfield_out" + k], rtol=1e-6)
 
 
-def test_without_a_gpu_the_deskew_runs_its_host_twin_and_the_rest_says_no(monkeypatch):
+def test_without_a_gpu_the_stages_run_their_host_twins(monkeypatch):
     """The reference's device rule (``shrimpy/preprocessing.py:78-82``): ``cpu`` when no GPU is visible.  The
-    deskew then runs the native host twin (bit-equal to the oracle); flat-field and ``require_gpu`` raise."""
+    stages then run their native host twins (the deskew bit-equal to the oracle); ``require_gpu`` raises."""
     import torch
 
     from oracle import cpu_ref as o
@@ -137,9 +148,13 @@ def test_without_a_gpu_the_deskew_runs_its_host_twin_and_the_rest_says_no(monkey
                     DESKEW["keep_overhang"], DESKEW["average_n_slices"])
     np.testing.assert_array_equal(out["BF"].numpy(), want)
     with pytest.raises(RuntimeError, match="no HIP device visible"):
-        build_preprocessor(ZYX, ["flatfield"])
-    with pytest.raises(RuntimeError, match="no HIP device visible"):
-        build_preprocessor(ZYX, ["deskew"], deskew=DESKEW, require_gpu=True)
+        build_preprocessor(shape, ["deskew"], deskew=DESKEW, require_gpu=True)
+    # flat-field then deskew, the reference's step order (`shrimpy/preprocessing.py:320-327`), on the host twins
+    both = build_preprocessor(shape, ["flatfield", "deskew"], deskew=DESKEW, output_channel="BF")(raw)["BF"]
+    corrected = o.flat_field_bf(raw.astype(np.float32))
+    want = o.deskew(corrected, DESKEW["ls_angle_deg"], round(DESKEW["pixel_size_um"] / DESKEW["scan_step_um"], 3),
+                    DESKEW["keep_overhang"], DESKEW["average_n_slices"])
+    np.testing.assert_allclose(both.numpy(), want, rtol=2e-6)
 
 
 def test_warm_up_resolves_deskewed_shape(monkeypatch):
