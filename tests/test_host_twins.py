@@ -163,6 +163,12 @@ def test_host_twins_equal_the_device_kernels_bit_for_bit(device):
         assert torch.equal(fast_deskew_zyx(raw_data=_t(raw), **kw), fast_deskew_zyx(raw_data=_t(raw).to(device), **kw).cpu())
         r16 = _t(raw.astype(np.uint16))
         assert torch.equal(fast_deskew_zyx(raw_data=r16, **kw), fast_deskew_zyx(raw_data=r16.to(device), **kw).cpu())
+    from shrimpy_amd.flatfield import flat_field_bf, flat_field_pattern
+
+    for stack in (_t(raw), _t(raw.astype(np.uint16)), _t(raw[:199])):          # float, camera counts, odd Z
+        host, dev = flat_field_pattern(stack), flat_field_pattern(stack.to(device))
+        assert torch.equal(host.pattern, dev.pattern.cpu())
+        np.testing.assert_allclose(flat_field_bf(stack).numpy(), flat_field_bf(stack.to(device)).cpu().numpy(), rtol=1e-6)
     vol = _t(rng.random((24, 48, 64)).astype(np.float32))
     m = np.eye(4)
     m[:3, :3] += rng.normal(0, 0.03, (3, 3))
