@@ -170,6 +170,61 @@ def test_affine_full_size_matches_the_oracle_on_output_blocks(device):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("tilted", [False, True])
+def test_affine_full_size_grid_constant_matches_the_oracle_on_output_blocks(device, tilted):
+    """The blending border rule at config-3 size through the LDS-staged kernels (planar for the config-3 map,
+    box for the map with a 3 degree tilt about y on top): wherever the plain rule keeps a sample the two rules
+    give the same bits; blocks at the volume's faces and inside it against scipy's ``mode="grid-constant"`` on
+    the source box they reach (one ulp: block-local fp64 coordinates)."""
+    import torch
+
+    from shrimpy_amd import _lib
+    from shrimpy_amd.geometry import as_matrix_3x4
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    shape = (256, 2048, 2048)
+    m = _config3_matrix()
+    if tilted:
+        c3, s3 = np.cos(np.deg2rad(3.0)), np.sin(np.deg2rad(3.0))
+        m[:3, :3] = np.array([[c3, 0, -s3], [0, 1, 0], [s3, 0, c3]]) @ m[:3, :3]
+    assert _lib.call_value("lsr_affine_path", *shape, _lib.matrix12(as_matrix_3x4(m)),
+                           _lib.MODE_GRID_CONSTANT) == (2 if tilted else 1)
+    g = torch.Generator(device=device).manual_seed(3002)
+    moving = torch.rand(shape, device=device, generator=g) * 1000 - 100
+    out = apply_affine_transform_zyx(moving, m, shape, cval=-3.0, mode="grid-constant")
+    plain = apply_affine_transform_zyx(moving, m, shape, cval=-3.0)
+    kept = plain != -3.0
+    assert torch.equal(out[kept], plain[kept])
+    assert int((out != plain).sum()) > 0          # ... and the blended shell exists
+    del plain, kept
+    blocks = [((100, 1000, 900), (8, 40, 60)), ((0, 0, 0), (8, 40, 60)), ((250, 2000, 1980), (6, 48, 68)),
+              ((0, 1000, 0), (6, 40, 64)), ((120, 8, 2040), (9, 30, 8))]
+    checked = 0
+    for origin, size in blocks:
+        origin, size = np.array(origin), np.array(size)
+        corners = np.array([[origin[i] + (size[i] - 1) * ((c >> i) & 1) for i in range(3)] for c in range(8)])
+        src = corners @ m[:3, :3].T + m[:3, 3]
+        lo = np.maximum(np.floor(src.min(0)).astype(int) - 3, 0)
+        hi = np.minimum(np.ceil(src.max(0)).astype(int) + 4, np.array(shape))
+        sl = tuple(slice(a, a + n) for a, n in zip(origin, size))
+        if np.any(hi - lo < 2):
+            continue
+        # cut faces of the crop that are not faces of the volume must be out of the block's reach (two voxels:
+        # the blending rule looks one voxel past a face)
+        if not (np.all((lo == 0) | (src.min(0) - lo >= 2)) and np.all((hi == shape) | (hi - 1 - src.max(0) >= 2))):
+            continue
+        crop = moving[tuple(slice(a, b) for a, b in zip(lo, hi))].contiguous().cpu().numpy()
+        want = o.affine_apply(crop, m[:3, :3], m[:3, :3] @ origin + m[:3, 3] - lo, tuple(size), cval=-3.0,
+                              mode="grid-constant")
+        got = out[sl].cpu().numpy()
+        np.testing.assert_array_max_ulp(got, want, maxulp=1)
+        assert np.mean(got == want) > 0.95
+        checked += 1
+    assert checked >= 3
+    del moving, out
+    torch.cuda.empty_cache()
+
+
 def test_affine_full_size_tilted_map_matches_the_oracle_on_output_blocks(device):
     """Config 3 with a 3 degree tilt about y on top of its registration -- a map that couples z with
     the plane, i.e. ``affine_box.hip`` at full size: output blocks against scipy run on the source box
