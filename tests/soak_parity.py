@@ -172,10 +172,41 @@ def main():
         if not plan.path.startswith("y-separable"):
             return False, (psf.shape, shape, plan.path)
         iters = int(r.integers(1, 4))
-        got = plan(t(y), iterations=iters).cpu().numpy().astype(np.float64)
+        dev_out = plan(t(y), iterations=iters)
+        got = dev_out.cpu().numpy().astype(np.float64)
         want = o.richardson_lucy(y, psf, iters).astype(np.float64)
         ok = bool(np.all(np.abs(got - want) <= 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max()))
+        if ok and py <= 9:     # the one-launch-per-iteration kernel, both shapes: the two-launch form's bits
+            for shape_name in ("narrow", "wide"):
+                os.environ["LSR_YSEP_SHAPE"] = shape_name
+                fused = RichardsonLucyPlan(shape, psf, dev, fused="always")
+                ok = ok and fused.path == "y-separable (fused)" and bool(torch.equal(fused(t(y), iterations=iters), dev_out))
+            os.environ.pop("LSR_YSEP_SHAPE", None)
         return ok, (psf.shape, shape, iters, plan.path)
+
+    def host_twin_case(r):
+        """CPU tensors through the public functions (csrc/host_twins.hip) against the device kernels: same bits."""
+        from shrimpy_amd.flatfield import flat_field_pattern as ffp
+
+        shape = (int(r.integers(2, 120)), int(r.integers(1, 24)), int(r.integers(1, 60)))
+        angle, ratio = float(r.uniform(10.0, 45.0)), float(np.round(r.uniform(0.3, 1.8), 3))
+        keep, avg = bool(r.integers(0, 2)), int(r.integers(1, 5))
+        border = "grid-constant" if r.integers(0, 2) else "constant"
+        if min(o.deskewed_shape(shape, angle, ratio, keep, avg)[0]) <= 0:
+            return None
+        raw = r.integers(0, 60000, shape).astype(np.uint16) if r.integers(0, 2) else (r.random(shape) * 4000 - 500).astype(np.float32)
+        kw = dict(ls_angle_deg=angle, px_to_scan_ratio=ratio, keep_overhang=keep, average_n_slices=avg, border=border)
+        host_raw = torch.as_tensor(raw)
+        a, b = fast_deskew_zyx(raw_data=host_raw, **kw), fast_deskew_zyx(raw_data=t(raw), **kw)
+        ok = a.device.type == "cpu" and bool(torch.equal(a, b.cpu()))
+        m = np.eye(4)
+        m[:3, :3] += r.normal(0, 0.05, (3, 3))
+        m[:3, 3] = r.uniform(-4, 4, 3)
+        mode = "grid-constant" if r.integers(0, 2) else "constant"
+        ok = ok and bool(torch.equal(apply_affine_transform_zyx(a, m, mode=mode, cval=1.5),
+                                     apply_affine_transform_zyx(b, m, mode=mode, cval=1.5).cpu()))
+        ok = ok and bool(torch.equal(ffp(host_raw).pattern, ffp(t(raw)).pattern.cpu()))
+        return ok, (shape, angle, ratio, keep, avg, border, mode)
 
     def rl_large_case(r):
         """More tiles than CUs: the whole-column / z-piece work split of the fused kernel."""
@@ -211,7 +242,7 @@ def main():
         return ok, (shape, angle, ratio, keep, avg, x0)
 
     families = {"deskew": deskew_case, "affine": affine_case, "rl": rl_case, "flatfield": flat_case,
-                "blur": blur_case, "estimators": estimator_case, "rl_ysep": rl_ysep_case}
+                "blur": blur_case, "estimators": estimator_case, "rl_ysep": rl_ysep_case, "host_twins": host_twin_case}
     if args.only:
         families = {k: v for k, v in families.items() if k in args.only.split(",")}
     if args.large:
