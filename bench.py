@@ -649,6 +649,45 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
     return line
 
 
+def run_config1_cpu(args):
+    """BASELINE configs[0]: a single 256x256x64 oblique stack (raw (256, 64, 256)), deskew only, no GPU --
+    through the PRODUCT path on a CPU tensor (`fast_deskew_zyx` -> `lsr_deskew_f32_cpu`, csrc/host_twins.hip),
+    with the oracle (scipy.ndimage) timed beside it on the same stack and the outputs compared bit for bit."""
+    import numpy as np
+    import torch
+
+    from oracle import cpu_ref as o
+    from shrimpy_amd.deskew import fast_deskew_zyx
+
+    config_id, raw_shape = WORKLOADS["config1"]
+    _, factors = o.gaussian_psf(PSF_SHAPE, PSF_SIGMA)
+    raw = o.bead_scene(raw_shape, 1000 * config_id, psf_factors=factors)
+    vol = torch.as_tensor(raw)
+    threads = torch.get_num_threads()
+    for _ in range(args.warmup):
+        fast_deskew_zyx(raw_data=vol, **DESKEW)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = fast_deskew_zyx(raw_data=vol, **DESKEW)
+    elapsed = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    want = o.deskew(raw, DESKEW["ls_angle_deg"], DESKEW["px_to_scan_ratio"], DESKEW["keep_overhang"], DESKEW["average_n_slices"])
+    oracle_s = time.perf_counter() - t1
+    n_in = raw_shape[0] * raw_shape[1] * raw_shape[2]
+    return {
+        "metric": METRIC, "value": args.steps * n_in / elapsed, "unit": "voxels/s", "n_gpus": 0, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (f"config1: raw (Z_scan,Y_tilt,X)={raw_shape} f32 -> deskew 30deg r=0.755 no-overhang avg3 -> "
+                                f"{tuple(out.shape)}, deskew only, no GPU: the product's host twin on a CPU tensor"),
+                   "raw_shape": list(raw_shape), "deskewed_shape": list(out.shape), "host_threads": threads,
+                   "equals_oracle_bit_for_bit": bool(np.array_equal(out.numpy(), want))},
+        "roofline": None,
+        "cpu_baseline": {"value": n_in / oracle_s, "unit": "voxels/s", "cores": 1, "kind": "port",
+                         "sample": f"the same stack through oracle/cpu_ref.py (scipy.ndimage.affine_transform + slice mean), once: {oracle_s:.2f}s"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -670,8 +709,15 @@ def main():
     ap.add_argument("--engine-format", action="store_true",
                     help="config4/5 store leg: input plate as the acquisition writes it (Zarr v3, one shard per "
                          "volume around blosc-zstd chunks) instead of uncompressed chunks")
+    ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"],
+                    help="cpu: BASELINE configs[0] (config1, deskew only) through the product's host twins, no GPU touched")
     args = ap.parse_args()
 
+    if args.device == "cpu":
+        if args.workload != "config1" or args.gpus != 1:
+            raise SystemExit("--device cpu runs --workload config1 (BASELINE configs[0]: deskew only, no GPU)")
+        print(json.dumps(run_config1_cpu(args)))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
     world_env = int(os.environ.get("WORLD_SIZE", "1"))

@@ -72,3 +72,15 @@ def test_bench_gpus_2_from_a_bare_shell_on_one_card():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert "cpu_baseline" not in line
+
+
+def test_config1_runs_on_the_cpu_through_the_product_path():
+    """BASELINE configs[0] as a bench line: deskew only, no GPU, the host twin on a CPU tensor, equal to the
+    oracle bit for bit (the oracle is the timed baseline beside it, never the thing measured)."""
+    r = subprocess.run([sys.executable, "bench.py", "--device", "cpu", "--workload", "config1", "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=_bare_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 0 and line["dtype"] == "f32" and line["value"] > 0
+    assert line["config"]["equals_oracle_bit_for_bit"] is True and line["config"]["raw_shape"] == [256, 64, 256]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
