@@ -80,6 +80,29 @@ def test_deskew_chunks_along_raw_x_concatenate_reversed():
     np.testing.assert_array_equal(np.concatenate(chunks[::-1], axis=-2), whole)
 
 
+def test_a_deskewed_plane_is_one_tilt_row_across_the_scan_stack():
+    """The reference's viewer builds a deskewed plane from "a single tilt row across the whole scan stack"
+    (``shrimpy/viewer/ring_buffer.py:98-105``, ``shrimpy/viewer/_napari_process.py:202-217``): before the slice
+    averaging, output plane Z' depends on tilt row Y - 1 - Z' of the raw stack and on nothing else -- in the oracle
+    and, on a CPU tensor, in the product's host twin."""
+    import torch
+
+    from shrimpy_amd.deskew import fast_deskew_zyx
+
+    rng = np.random.default_rng(17)
+    raw = rng.poisson(300, (90, 7, 20)).astype(np.float32)
+    kw = dict(ls_angle_deg=30.0, px_to_scan_ratio=0.755, keep_overhang=True, average_n_slices=1)
+    base = o.deskew(raw, 30.0, 0.755, True, 1)
+    assert base.shape[0] == raw.shape[1]
+    for row in (0, 3, 6):
+        bumped = raw.copy()
+        bumped[:, row, :] += 1000.0
+        out = o.deskew(bumped, 30.0, 0.755, True, 1)
+        changed = [z for z in range(base.shape[0]) if not np.array_equal(out[z], base[z])]
+        assert changed == [raw.shape[1] - 1 - row]
+        np.testing.assert_array_equal(fast_deskew_zyx(raw_data=torch.as_tensor(bumped), **kw).numpy(), out)
+
+
 def test_average_slices_edge_padding():
     d = np.arange(5 * 2 * 2, dtype=np.float32).reshape(5, 2, 2)
     a = o.average_slices(d, 3)
