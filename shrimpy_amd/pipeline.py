@@ -110,7 +110,7 @@ class VolumeReconstructor:
             # runs its native host twin through the same public functions (shrimpy_amd/host.py)
             if dec is not None and dec.iterations > 0:
                 if dec.psf_path:
-                    self._host_rl = dict(psf=np.load(dec.psf_path).astype(np.float32), separable=dec.separable,
+                    self._host_rl = dict(psf=dec.load_psf(), separable=dec.separable,
                                          separable_rtol=dec.separable_rtol)
                 else:
                     factors = gaussian_psf_factors(dec.gaussian_shape_zyx, dec.gaussian_sigma_zyx)
@@ -123,7 +123,7 @@ class VolumeReconstructor:
             from .deconvolve import RichardsonLucyPlan
 
             if dec.psf_path:
-                psf = np.load(dec.psf_path).astype(np.float32)
+                psf = dec.load_psf()
                 self._plan = RichardsonLucyPlan(
                     self.output_shape, psf, self.device,
                     separable={"auto": "auto", "force": "force", "never": "never"}[dec.separable],

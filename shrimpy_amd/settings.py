@@ -147,8 +147,12 @@ class RegisterSettings(_StrictModel):
 class DeconvolveSettings(_StrictModel):
     """Richardson-Lucy deconvolution.
 
-    The PSF comes from ``psf_path`` (``.npy`` ZYX array) or, when absent, is the separable
-    anisotropic Gaussian ``gaussian_sigma_zyx`` truncated to ``gaussian_shape_zyx``.
+    The PSF comes from ``psf_path`` -- a ``.npy`` ZYX array, or an OME-Zarr store (an averaged bead
+    volume as the PSF-characterisation tools around the reference write them with iohub,
+    ``scripts/measure_psf.py:273-287``: HCS layout, first position, array ``"0"``, T = C = 0) -- or, when
+    absent, is the separable anisotropic Gaussian ``gaussian_sigma_zyx`` truncated to
+    ``gaussian_shape_zyx``.  A measured PSF larger than the kernels' 15 taps per axis is cut to
+    ``psf_shape_zyx`` (odd, <= 15) around its brightest voxel and renormalised to sum 1 (``load_psf``).
 
     ``separable="auto"`` picks the cheapest exact form of the PSF: three 1-D kernels (one fused launch
     per iteration), else ``ky (x) kzx`` -- a y kernel times a dense (z, x) stencil, the shape of a
@@ -161,17 +165,60 @@ class DeconvolveSettings(_StrictModel):
     iterations: NonNegativeInt = 20
     eps: PositiveFloat = 1e-6
     psf_path: Optional[str] = None
+    psf_shape_zyx: Optional[tuple[PositiveInt, PositiveInt, PositiveInt]] = None
     gaussian_sigma_zyx: tuple[PositiveFloat, PositiveFloat, PositiveFloat] = (2.0, 1.2, 1.2)
     gaussian_shape_zyx: tuple[PositiveInt, PositiveInt, PositiveInt] = (9, 7, 7)
     separable: Literal["auto", "force", "never"] = "auto"
     separable_rtol: PositiveFloat = 1e-6
 
-    @field_validator("gaussian_shape_zyx")
+    @field_validator("gaussian_shape_zyx", "psf_shape_zyx")
     @classmethod
     def _odd_taps(cls, v):
-        if any(n % 2 == 0 or n > 15 for n in v):
-            raise ValueError("gaussian_shape_zyx entries must be odd and <= 15")
+        if v is not None and any(n % 2 == 0 or n > 15 for n in v):
+            raise ValueError("PSF extents must be odd and <= 15 per axis")
         return v
+
+    def load_psf(self):
+        """The PSF array this block names (``None`` for the Gaussian): float32 ZYX, cut to ``psf_shape_zyx``
+        around its peak when that is given (then non-negative and summing to 1)."""
+        import numpy as np
+
+        if not self.psf_path:
+            return None
+        path = str(self.psf_path)
+        if path.endswith(".npy"):
+            psf = np.load(path)
+        else:
+            from pathlib import Path
+
+            from .io.omezarr import as_volume_array, open_ome_zarr
+
+            if not Path(path).is_dir():
+                raise FileNotFoundError(f"psf_path {path}: neither a .npy file nor an OME-Zarr store")
+            with open_ome_zarr(path, prefer_iohub=False) as store:
+                _, pos = next(iter(store.positions()))
+                psf = as_volume_array(pos["0"]).read_volume(0, 0)
+        psf = np.asarray(psf, dtype=np.float32)
+        while psf.ndim > 3 and psf.shape[0] == 1:
+            psf = psf[0]
+        if psf.ndim != 3:
+            raise ValueError(f"psf_path {path}: expected a (Z, Y, X) volume, got shape {psf.shape}")
+        if self.psf_shape_zyx is not None:
+            want = tuple(int(n) for n in self.psf_shape_zyx)
+            peak = np.unravel_index(int(np.argmax(psf)), psf.shape)
+            lo = [c - n // 2 for c, n in zip(peak, want)]
+            if any(a < 0 or a + n > s for a, n, s in zip(lo, want, psf.shape)):
+                raise ValueError(f"psf_path {path}: a {want} window around the peak at {tuple(int(c) for c in peak)} "
+                                 f"does not fit the {psf.shape} volume")
+            psf = np.clip(psf[tuple(slice(a, a + n) for a, n in zip(lo, want))], 0.0, None)
+            total = float(psf.sum(dtype=np.float64))
+            if not total > 0:
+                raise ValueError(f"psf_path {path}: the cut PSF is empty")
+            psf = (psf / total).astype(np.float32)
+        elif max(psf.shape) > 15:
+            raise ValueError(f"psf_path {path}: shape {psf.shape} exceeds 15 taps per axis; give psf_shape_zyx "
+                             "(odd, <= 15) to cut it around its peak")
+        return np.ascontiguousarray(psf, dtype=np.float32)
 
 
 class ReconstructSettings(_StrictModel):

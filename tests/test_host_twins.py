@@ -293,3 +293,40 @@ def test_two_ranks_of_the_cli_on_a_box_without_a_gpu_write_the_single_rank_store
             va = pa["0"].read_volume(0, 0)
             assert float(va.max()) > 0
             np.testing.assert_array_equal(va, pb["0"].read_volume(0, 0))
+
+
+def test_a_measured_psf_comes_from_npy_or_from_an_ome_zarr_store(tmp_path):
+    """``DeconvolveSettings.psf_path``: a ``.npy`` array as it is, or a bead volume in an OME-Zarr store (HCS,
+    position 0/0/0, array "0": what the PSF tools around the reference write, ``scripts/measure_psf.py:273-287``),
+    cut to ``psf_shape_zyx`` around its peak and renormalised; the deconvolution then uses exactly that array."""
+    import torch
+
+    from shrimpy_amd.io.omezarr import open_ome_zarr
+    from shrimpy_amd.pipeline import VolumeReconstructor
+    from shrimpy_amd.settings import DeconvolveSettings, ReconstructSettings
+
+    psf, _ = o.gaussian_psf((5, 5, 7), (1.1, 0.9, 1.4))
+    np.save(tmp_path / "psf.npy", psf)
+    np.testing.assert_array_equal(DeconvolveSettings(psf_path=str(tmp_path / "psf.npy")).load_psf(), psf)
+    big = np.zeros((21, 31, 33), np.float32)          # a measured bead volume, peak off-centre
+    big[8:13, 15:20, 10:17] = psf * 1000.0 + 0.0
+    with open_ome_zarr(tmp_path / "psf.zarr", layout="hcs", mode="w", channel_names=["beads"], prefer_iohub=False) as store:
+        arr = store.create_position("0", "0", "0").create_zeros("0", shape=(1, 1) + big.shape, dtype="float32",
+                                                                  scale=(1, 1, 0.17, 0.1133, 0.1133))
+        arr.write_volume(0, 0, big)
+    dec = DeconvolveSettings(psf_path=str(tmp_path / "psf.zarr"), psf_shape_zyx=(5, 5, 7), iterations=3)
+    cut = dec.load_psf()
+    assert cut.shape == (5, 5, 7) and abs(float(cut.sum()) - 1.0) < 1e-6
+    np.testing.assert_allclose(cut, psf / psf.sum(), rtol=1e-6)
+    with pytest.raises(ValueError, match="psf_shape_zyx"):
+        DeconvolveSettings(psf_path=str(tmp_path / "psf.zarr")).load_psf()
+    edge = np.zeros((9, 9, 9), np.float32)
+    edge[1, 4, 4] = 1.0                                # peak one plane from the face: a 5-plane window does not fit
+    np.save(tmp_path / "edge.npy", edge)
+    with pytest.raises(ValueError, match="does not fit"):
+        DeconvolveSettings(psf_path=str(tmp_path / "edge.npy"), psf_shape_zyx=(5, 5, 5)).load_psf()
+    with pytest.raises(ValueError):
+        DeconvolveSettings(psf_shape_zyx=(4, 5, 5))
+    y = o.bead_scene((10, 18, 24), seed=3, psf=psf, density=2e-3)
+    rec = VolumeReconstructor(y.shape, ReconstructSettings(deconvolution=dec), torch.device("cpu"))
+    _rl_close(rec(y).numpy(), o.richardson_lucy(y, cut, iterations=3))
