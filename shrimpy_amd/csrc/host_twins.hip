@@ -28,6 +28,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <new>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -40,9 +41,19 @@ std::atomic<int> g_threads{1};
 constexpr int kMaxAvg = 16;    // as deskew.hip
 constexpr int kMaxTaps = 15;   // as correlate.hip
 
-// fn(first, last) over [0, n) split into contiguous ranges, one per worker
+// fn(first, last) over [0, n) split into contiguous ranges, one per worker.  Nothing may escape a worker (an
+// exception leaving a std::thread ends the process): a range that cannot get its scratch memory reports through
+// `failed` and the entry point returns an error.
+std::atomic<bool> g_dummy_failed{false};
 template <typename F>
-void parallel_ranges(int64_t n, F&& fn) {
+void parallel_ranges(int64_t n, F&& fn_raw, std::atomic<bool>& failed = g_dummy_failed) {
+  auto fn = [&fn_raw, &failed](int64_t a, int64_t b) {
+    try {
+      fn_raw(a, b);
+    } catch (const std::bad_alloc&) {
+      failed.store(true, std::memory_order_relaxed);
+    }
+  };
   int workers = g_threads.load(std::memory_order_relaxed);
   if (workers > n) workers = static_cast<int>(n);
   if (workers <= 1) {
@@ -290,7 +301,13 @@ extern "C" int lsr_correlate_sep_f32_cpu(const float* in, float* out, const floa
   const int64_t plane = Y * X;
   const int cz = pz / 2, cy = py / 2, cx = px / 2;
   // in-plane passes of every plane first (x then y, f32 FMA chains from 0), then the z chain + epilogue
-  std::vector<float> filtered(static_cast<size_t>(Z * plane));
+  std::atomic<bool> failed{false};
+  std::vector<float> filtered;
+  try {
+    filtered.resize(static_cast<size_t>(Z * plane));
+  } catch (const std::bad_alloc&) {
+    return lsr::fail(LSR_E_ARG, "out of host memory for a %lld-voxel intermediate", (long long)(Z * plane));
+  }
   parallel_ranges(Z, [&](int64_t z_first, int64_t z_last) {
     std::vector<float> rows(static_cast<size_t>(plane));
     for (int64_t z = z_first; z < z_last; ++z) {
@@ -315,7 +332,8 @@ extern "C" int lsr_correlate_sep_f32_cpu(const float* in, float* out, const floa
           dst[y * X + x] = s;
         }
     }
-  });
+  }, failed);
+  if (failed.load()) return lsr::fail(LSR_E_ARG, "out of host memory for the per-thread row buffers");
   parallel_ranges(Z, [&](int64_t z_first, int64_t z_last) {
     for (int64_t z = z_first; z < z_last; ++z)
       for (int64_t y = 0; y < Y; ++y)
@@ -389,6 +407,7 @@ int flat_pattern_cpu(const T* in, int64_t Z, int64_t Y, int64_t X, float* patter
               (long long)X);
   LSR_REQUIRE(Z < 65536, LSR_E_UNSUPPORTED, "Z = %lld: the median kernel counts in 16 bits", (long long)Z);
   const int64_t plane = Y * X;
+  std::atomic<bool> failed{false};
   parallel_ranges(plane, [&](int64_t first, int64_t last) {
     std::vector<float> col(static_cast<size_t>(Z));
     for (int64_t i = first; i < last; ++i) {
@@ -412,7 +431,8 @@ int flat_pattern_cpu(const T* in, int64_t Z, int64_t Y, int64_t X, float* patter
         pattern[i] = b - (b - a) * 0.5f;
       }
     }
-  });
+  }, failed);
+  if (failed.load()) return lsr::fail(LSR_E_ARG, "out of host memory for the per-thread column buffers");
   double sum = 0.0;
   for (int64_t i = 0; i < plane; ++i) sum += static_cast<double>(pattern[i]);
   mean_out[0] = static_cast<float>(sum / static_cast<double>(plane));
