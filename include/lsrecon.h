@@ -488,6 +488,9 @@ int lsr_correlate_sep_f32_cpu(const float* in, float* out, const float* aux, int
 int lsr_correlate_dense_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y,
                                 int64_t X, const float* w, int pz, int py, int px, int epilogue,
                                 float eps, const double* norm_table, lsr_stream_t stream);
+int lsr_rl_dense_f32_cpu(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X,
+                         const float* psf, const float* psf_flipped, int pz, int py, int px,
+                         const double* norm_table, int iters, float eps, lsr_stream_t stream);
 int lsr_flatfield_pattern_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t X, float* pattern,
                                   float* mean_out, void* scratch /* unused */, lsr_stream_t stream);
 int lsr_flatfield_pattern_u16_cpu(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* pattern,

@@ -144,7 +144,7 @@ SIGNATURES: dict[str, list] = {
 }
 # host twins (csrc/host_twins.hip): the device entry point's signature, host pointers
 for _name in ("lsr_deskew_f32", "lsr_deskew_u16", "lsr_affine_f32", "lsr_average_slices_f32", "lsr_correlate_sep_f32",
-              "lsr_correlate_dense_f32", "lsr_flatfield_pattern_f32", "lsr_flatfield_pattern_u16",
+              "lsr_correlate_dense_f32", "lsr_rl_dense_f32", "lsr_flatfield_pattern_f32", "lsr_flatfield_pattern_u16",
               "lsr_flatfield_apply_f32", "lsr_flatfield_apply_u16"):
     SIGNATURES[_name + "_cpu"] = SIGNATURES[_name]
 

@@ -10,6 +10,7 @@
 //   lsr_average_slices_f32_cpu                <->  lsr_average_slices_f32              (deskew.hip)
 //   lsr_correlate_sep_f32_cpu                 <->  lsr_correlate_sep_f32               (correlate.hip)
 //   lsr_correlate_dense_f32_cpu               <->  lsr_correlate_dense_f32             (correlate.hip)
+//   lsr_rl_dense_f32_cpu                      <->  lsr_rl_dense_f32                    (correlate.hip)
 //   lsr_flatfield_pattern_f32_cpu / _u16_cpu  <->  lsr_flatfield_pattern_f32 / _u16    (flatfield.hip)
 //   lsr_flatfield_apply_f32_cpu / _u16_cpu    <->  lsr_flatfield_apply_f32 / _u16      (flatfield.hip)
 //
@@ -389,6 +390,25 @@ extern "C" int lsr_correlate_dense_f32_cpu(const float* in, float* out, const fl
           out[o] = v;
         }
   });
+  return LSR_OK;
+}
+
+// The whole loop of lsr_rl_dense_f32 on host memory: `iters` x { ratio = y / (H x + eps); x <- x * H^T ratio / H^T 1 },
+// x updated in place, `ratio` scratch.
+extern "C" int lsr_rl_dense_f32_cpu(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X, const float* psf,
+                                    const float* psf_flipped, int pz, int py, int px, const double* norm_table, int iters,
+                                    float eps, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(y);
+  LSR_REQUIRE_PTR(x);
+  LSR_REQUIRE_PTR(ratio);
+  LSR_REQUIRE(iters >= 0, LSR_E_ARG, "iters %d must be >= 0", iters);
+  LSR_REQUIRE(ratio != x && ratio != y && x != y, LSR_E_ARG, "y, x and ratio must be distinct");
+  for (int it = 0; it < iters; ++it) {
+    int rc = lsr_correlate_dense_f32_cpu(x, ratio, y, Z, Y, X, psf_flipped, pz, py, px, LSR_EPI_RATIO, eps, nullptr, stream);
+    if (rc) return rc;
+    rc = lsr_correlate_dense_f32_cpu(ratio, x, x, Z, Y, X, psf, pz, py, px, LSR_EPI_UPDATE, eps, norm_table, stream);
+    if (rc) return rc;
+  }
   return LSR_OK;
 }
 

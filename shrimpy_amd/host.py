@@ -204,13 +204,12 @@ def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=Non
             _lib.call("lsr_correlate_sep_f32_cpu", src.data_ptr(), dst.data_ptr(), aux.data_ptr(), z, yy, xx,
                       taps[0].ctypes.data, sizes[0], taps[1].ctypes.data, sizes[1], taps[2].ctypes.data, sizes[2], epi, e,
                       norm[0].ctypes.data, norm[1].ctypes.data, norm[2].ctypes.data, None)
-    else:
+    else:    # the dense loop is one native call (the twin of lsr_rl_dense_f32: x updated in place)
         k, kf = _taps(w), _taps(w[::-1, ::-1, ::-1])
         table = np.ascontiguousarray(_prefix_table(w).ravel(), dtype=np.float64)
-
-        def corr(src, dst, aux, taps, epi):
-            _lib.call("lsr_correlate_dense_f32_cpu", src.data_ptr(), dst.data_ptr(), aux.data_ptr(), z, yy, xx,
-                      taps.ctypes.data, w.shape[0], w.shape[1], w.shape[2], epi, e, table.ctypes.data, None)
+        _lib.call("lsr_rl_dense_f32_cpu", y.data_ptr(), x.data_ptr(), ratio.data_ptr(), z, yy, xx, k.ctypes.data,
+                  kf.ctypes.data, w.shape[0], w.shape[1], w.shape[2], table.ctypes.data, iterations, e, None)
+        return x
     for _ in range(iterations):
         corr(x, ratio, y, kf, _lib.EPI_RATIO)       # ratio = y / (H x + eps): H = correlation with the flipped taps
         corr(ratio, nxt, x, k, _lib.EPI_UPDATE)     # x <- x * H^T ratio / H^T 1
