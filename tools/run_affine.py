@@ -1,6 +1,6 @@
 """Run one config-3-size affine apply a few times (profiling target).
 
-    python tools/run_affine.py [planar|tilt|both] [exact|f32]
+    python tools/run_affine.py [planar|tilt|both] [exact|f32|all] [constant|grid-constant]
 
 planar = the config-3 registration (affine_planar.hip); tilt = 1.5 deg about y; both = config 3 with a
 3 deg tilt about y on top (affine_box.hip)."""
@@ -15,7 +15,8 @@ import torch
 from shrimpy_amd.register import apply_affine_transform_zyx
 
 which = sys.argv[1] if len(sys.argv) > 1 else "planar"
-modes = (sys.argv[2] == "exact",) if len(sys.argv) > 2 else (True, False)
+modes = (sys.argv[2] == "exact",) if len(sys.argv) > 2 and sys.argv[2] != "all" else (True, False)
+border = sys.argv[3] if len(sys.argv) > 3 else "constant"
 th = np.deg2rad(2.0)
 m = np.eye(4)
 m[:3, :3] = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]]) @ np.diag([1.0, 0.98, 1.02])
@@ -33,5 +34,5 @@ vol = torch.rand((256, 2048, 2048), device="cuda", generator=g)
 out = torch.empty_like(vol)
 for exact in modes:
     for _ in range(3):
-        apply_affine_transform_zyx(vol, m, out=out, exact=exact)
+        apply_affine_transform_zyx(vol, m, out=out, exact=exact, mode=border)
 torch.cuda.synchronize()
