@@ -330,3 +330,39 @@ def test_a_measured_psf_comes_from_npy_or_from_an_ome_zarr_store(tmp_path):
     y = o.bead_scene((10, 18, 24), seed=3, psf=psf, density=2e-3)
     rec = VolumeReconstructor(y.shape, ReconstructSettings(deconvolution=dec), torch.device("cpu"))
     _rl_close(rec(y).numpy(), o.richardson_lucy(y, cut, iterations=3))
+
+
+def test_host_path_argument_errors_read_like_the_device_paths():
+    import torch
+
+    from shrimpy_amd.deconvolve import correlate3d, richardson_lucy
+    from shrimpy_amd.deskew import average_n_slices, deskew_with_matrix, fast_deskew_zyx
+    from shrimpy_amd.register import apply_affine_transform_zyx
+
+    v = torch.zeros((8, 4, 6))
+    with pytest.raises(ValueError, match="is empty"):                          # scan too short for the tilt
+        fast_deskew_zyx(raw_data=torch.zeros((4, 64, 8)), ls_angle_deg=30, px_to_scan_ratio=0.755, keep_overhang=False)
+    with pytest.raises(ValueError, match="border"):
+        fast_deskew_zyx(raw_data=v, ls_angle_deg=30, px_to_scan_ratio=0.755, keep_overhang=True, border="wrap")
+    with pytest.raises(ValueError, match="average_n_slices"):
+        deskew_with_matrix(v, np.eye(4)[:3], (8, 4, 6), 0)
+    with pytest.raises(ValueError, match="out must be"):
+        deskew_with_matrix(v, np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0.0]]), (8, 4, 6), 1, out=torch.zeros((3, 4, 6)))
+    with pytest.raises(ValueError, match="alias"):
+        apply_affine_transform_zyx(v, np.eye(4), out=v)
+    with pytest.raises(ValueError, match="mode"):
+        apply_affine_transform_zyx(v, np.eye(4), mode="wrap")
+    with pytest.raises(ValueError, match="iterations"):
+        richardson_lucy(v, np.ones((3, 3, 3), np.float32) / 27, iterations=-1)
+    with pytest.raises(ValueError, match="x0 must be"):
+        richardson_lucy(v, np.ones((3, 3, 3), np.float32) / 27, x0=torch.zeros((2, 2, 2)))
+    with pytest.raises(ValueError, match="exceeds"):
+        richardson_lucy(v, np.ones((17, 3, 3), np.float32))
+    with pytest.raises(ValueError, match="Z, Y, X"):
+        correlate3d(torch.zeros((4, 4)), np.ones((3, 3, 3), np.float32))
+    assert average_n_slices(v, 1) is v and tuple(average_n_slices(v, 3).shape) == (3, 4, 6)
+    # zero iterations hand back the start, a non-contiguous input is made contiguous, float64 is converted
+    assert torch.equal(richardson_lucy(v + 2, np.ones((3, 3, 3), np.float32) / 27, iterations=0), v + 2)
+    t = torch.arange(8 * 4 * 6, dtype=torch.float64).reshape(6, 4, 8).permute(2, 1, 0)
+    np.testing.assert_array_equal(fast_deskew_zyx(raw_data=t, ls_angle_deg=30, px_to_scan_ratio=0.755, keep_overhang=True).numpy(),
+                                  o.deskew(t.numpy().astype(np.float32), 30.0, 0.755, True, 1))
