@@ -32,9 +32,21 @@ def is_host(t) -> bool:
     return isinstance(t, torch.Tensor) and t.device.type == "cpu"
 
 
+_warned = [False]
+
+
 def _threads() -> None:
+    """Worker count of the twins = torch's CPU thread count; and, once per process, a warning when a HIP device
+    is visible: the kernels are the product's path there, and a CPU tensor reaching this module on such a box
+    should be a decision, not an accident (nothing falls back silently)."""
     import torch
 
+    if not _warned[0] and torch.cuda.is_available():
+        import warnings
+
+        _warned[0] = True
+        warnings.warn("shrimpy_amd: a CPU tensor is being processed by the native host twins although a HIP device is "
+                      "visible; move the tensor to the device to run the gfx950 kernels", RuntimeWarning, stacklevel=3)
     _lib.call("lsr_set_host_threads", max(1, min(1024, int(torch.get_num_threads()))))
 
 
