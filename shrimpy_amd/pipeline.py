@@ -171,7 +171,6 @@ class VolumeReconstructor:
                     self._y_pad = self._plan.new_padded_input()
                 target = self._y_pad
             elif (self.device.type == "cuda" and self._register is not None and self._canonical_deskew
-                    and self._register.mode == "constant"
                     and self._geo.output_shape[2] % 4 != 0 and self._geo.output_shape[2] >= 8):
                 # a registration follows and the deskewed rows would not start on 16-byte boundaries:
                 # deskew into zero-padded rows so that the LDS-staged affine kernels take the map

@@ -457,9 +457,11 @@ def test_affine_pitched_argument_errors(device):
     assert torch.equal(b, c[:, :, :10])
 
 
-def test_pipeline_deskews_into_padded_rows_when_a_registration_follows(device):
+@pytest.mark.parametrize("mode,cval", [("constant", 0.0), ("grid-constant", 0.0), ("grid-constant", 7.5)])
+def test_pipeline_deskews_into_padded_rows_when_a_registration_follows(device, mode, cval):
     """deskew -> register on a stack whose deskewed width is not a multiple of 4: the deskew writes
-    zero-padded rows and the registration reads them through the LDS-staged kernel; result = oracle."""
+    zero-padded rows and the registration reads them through the LDS-staged kernel (either border rule:
+    padding columns are never a tap's value); result = oracle."""
     from shrimpy_amd.pipeline import VolumeReconstructor
     from shrimpy_amd.settings import DeskewSettings, ReconstructSettings, RegisterSettings
 
@@ -469,11 +471,11 @@ def test_pipeline_deskews_into_padded_rows_when_a_registration_follows(device):
     desk = o.deskew(raw.astype(np.float32), 30.0, 0.755, True, 3)
     assert desk.shape[2] % 4 != 0
     m = _tilted_matrix([(1, 2.0), (0, 1.0)], (1.0, 0.99, 1.01), (0.5, -1.25, 2.75))
-    reg = RegisterSettings(affine_transform_zyx=m.tolist())
+    reg = RegisterSettings(affine_transform_zyx=m.tolist(), mode=mode, cval=cval)
     rec = VolumeReconstructor(raw.shape, ReconstructSettings(deskew=d, registration=reg), device)
     got = rec(raw)
     assert rec._pitched is not None and rec._pitched.pitch == (desk.shape[2] + 3) // 4 * 4
-    np.testing.assert_array_equal(got.cpu().numpy(), o.affine_apply_4x4(desk, m, desk.shape, cval=0.0, mode="constant"))
+    np.testing.assert_array_equal(got.cpu().numpy(), o.affine_apply_4x4(desk, m, desk.shape, cval=cval, mode=mode))
     np.testing.assert_array_equal(rec(raw).cpu().numpy(), got.cpu().numpy())     # the padded target is reused
 
 
