@@ -595,6 +595,9 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
                 "positions": n_p, "timepoints": n_t, "units": units, "seconds": res["job_seconds"],
                 "s_per_unit": res["job_seconds"] / max(units, 1) * world,
                 "voxels_per_s": units * n_in / res["job_seconds"],
+                # rank 0's stage clocks, seconds per unit (loader thread: wait_slot, load, stage_in; caller: wait_load,
+                # process, wait_store, stage_out; writer thread: collect, write)
+                "stage_s_per_unit": {k: round(v / max(res["units"], 1), 4) for k, v in res.get("stage_seconds", {}).items()},
                 "io": ("native OME-Zarr reader/writer, "
                        + ("input in the acquisition's format (Zarr v3, one shard per volume, blosc-zstd chunks (1,1,32,ny,nx), "
                           f"frames decoded by {_blosc_backend()}), output uncompressed ~64 MB chunks, " if args.engine_format

@@ -384,6 +384,7 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
                 nvox / max(report.seconds, 1e-9), report.max_seconds)
     return {"rank": rank, "world_size": world, "units": len(report.units), "units_total": len(units),
             "units_skipped": skipped, "seconds": report.seconds, "job_seconds": report.max_seconds,
+            "stage_seconds": {k: round(v, 4) for k, v in report.stage_seconds.items()},
             "output_shape": (oz, oy, ox)}
 
 

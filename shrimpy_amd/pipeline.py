@@ -215,6 +215,9 @@ class ShardReport:
     seconds: float = 0.0         # this rank's wall time
     max_seconds: float = 0.0     # max over ranks (what the job took)
     n_units_total: int = 0
+    # seconds each stage of the staged pipeline was busy, summed over this rank's units (``_run_staged``):
+    # wait_slot / load / write / collect on the two host threads, wait_load / process / wait_store on the caller
+    stage_seconds: dict = field(default_factory=dict)
 
 
 def _dist():
@@ -272,8 +275,9 @@ def run_sharded(
         dist.barrier()
     sync()
     t0 = time.perf_counter()
+    stage_seconds: dict = {}
     if stager is not None and mine:
-        _run_staged(mine, load, run, store, stager)
+        _run_staged(mine, load, run, store, stager, stage_seconds)
     elif overlap_io and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor
 
@@ -306,12 +310,13 @@ def run_sharded(
         dist.barrier()
     logger.info("rank %d/%d: %d of %d units in %.3fs (job %.3fs)", rank, world, len(mine), len(units),
                 seconds, max_seconds)
-    return ShardReport(rank, world, mine, seconds, max_seconds, len(units))
+    return ShardReport(rank, world, mine, seconds, max_seconds, len(units), stage_seconds)
 
 
-def _run_staged(mine, load, process, store, stager) -> None:
+def _run_staged(mine, load, process, store, stager, times: dict | None = None) -> None:
     """The ``stager`` branch of ``run_sharded``: loader thread -> up stream -> kernels -> down
-    stream -> writer thread, slot ``i % depth`` for the i-th unit.  ``process(data, unit)``."""
+    stream -> writer thread, slot ``i % depth`` for the i-th unit.  ``process(data, unit)``.
+    ``times`` collects how long each stage was busy (each key is touched by one thread only)."""
     import inspect
 
     from concurrent.futures import ThreadPoolExecutor
@@ -321,12 +326,24 @@ def _run_staged(mine, load, process, store, stager) -> None:
     except (TypeError, ValueError):
         takes_out = False
     depth = stager.depth
+    times = {} if times is None else times
+    clock = time.perf_counter
+
+    def spent(key, since):
+        now = clock()
+        times[key] = times.get(key, 0.0) + (now - since)
+        return now
 
     def stage(i):
         slot = i % depth
+        t = clock()
         view = stager.host_in(slot)            # waits until the slot's previous upload is done
+        t = spent("wait_slot", t)
         data = load(mine[i], out=view) if takes_out else load(mine[i])
-        return stager.stage_in(slot, data)
+        t = spent("load", t)
+        slot = stager.stage_in(slot, data)
+        spent("stage_in", t)
+        return slot
 
     failed = []
 
@@ -334,7 +351,11 @@ def _run_staged(mine, load, process, store, stager) -> None:
         if failed:                 # an earlier unit's write failed: nothing after it is written
             return
         try:
-            store(mine[i], stager.collect(i % depth))
+            t = clock()
+            host = stager.collect(i % depth)    # waits for the download of unit i
+            t = spent("collect", t)
+            store(mine[i], host)
+            spent("write", t)
         except BaseException:
             failed.append(i)
             raise
@@ -345,20 +366,27 @@ def _run_staged(mine, load, process, store, stager) -> None:
     try:
         nxt = loader.submit(stage, 0)
         for i in range(len(mine)):
+            t = clock()
             slot = nxt.result()
+            t = spent("wait_load", t)
             nxt = loader.submit(stage, i + 1) if i + 1 < len(mine) else None
             result = process(stager.acquire(slot), mine[i])
             stager.release(slot)
+            t = spent("process", t)
             # the result slot of unit i was last used by unit i - depth: its write must be over before
             # the download of unit i lands there.  The write of unit i - 1 may still be running -- it
             # overlaps the kernels and the download of unit i (waiting for it here instead cost a
             # third of the streamed rate: 0.11 s per config-4 unit against 0.05 s of the slowest stage)
             if i - depth >= 0:
                 stores[i - depth].result()
+            t = spent("wait_store", t)
             stager.stage_out(slot, result)
+            spent("stage_out", t)
             stores.append(storer.submit(write, i))
+        t = clock()
         for fut in stores:
             fut.result()            # the last writes; raises the first writer error, if any
+        spent("wait_store", t)
         stores = []
     finally:
         # whatever happened: no thread is left filling a slot, no copy is left in flight on the
