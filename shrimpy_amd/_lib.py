@@ -181,6 +181,10 @@ _lock = threading.Lock()
 _lib: ctypes.CDLL | None = None
 
 
+# what the last ``build()`` of this process did: translation units hipcc compiled, whether the library was linked
+LAST_BUILD: dict = {}
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile ``liblsrecon.so`` in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
     cmd = ["make", "-C", str(CSRC_DIR), "-j", str(min(8, os.cpu_count() or 1))]
@@ -191,6 +195,9 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         raise RuntimeError(f"building liblsrecon.so failed:\n{proc.stdout}\n{proc.stderr}")
     if verbose:
         print(proc.stdout)
+    lines = [ln for ln in proc.stdout.splitlines() if "hipcc" in ln]
+    LAST_BUILD.update(compiled=sum(" -c " in ln for ln in lines), linked=any(" -shared " in ln for ln in lines),
+                      forced=bool(force))
     return LIB_PATH
 
 
