@@ -395,6 +395,7 @@ int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane, in
  *
  *   lsr_minmax_f32            out2 = {min, max} of n floats                         (:533-535, :583)
  *   lsr_histogram_f32         torch.histc(in, nbins, vmin, vmax) as uint32 counts   (:465, :586)
+ *                             (n < 2^32 per call, LSR_E_UNSUPPORTED otherwise: add up pieces)
  *   lsr_weighted_centroid_f32 out4 = {sum w, sum w z, sum w y, sum w x}, w = max(v - background, 0)
  *                             (_intensity_center_of_mass, :596-649)
  *   lsr_mask_centroid_f32     the same with w = (v > threshold)  (_center_of_mass of a mask, :545-569)

@@ -301,8 +301,7 @@ int affine_impl(const char* what, const float* in, int64_t Zi, int64_t Yi, int64
   const int64_t lim = int64_t(1) << 30;
   LSR_REQUIRE(Zi < lim && Yi < lim && Xi < lim && Zo < lim && Yo < lim && Xo < lim,
               LSR_E_UNSUPPORTED, "a dimension exceeds 2^30");
-  LSR_REQUIRE(Zi * plane <= (int64_t(1) << 32) && pitch < lim, LSR_E_UNSUPPORTED,
-              "the moving volume spans more than 2^32 elements (32-bit element indices)");
+  LSR_REQUIRE(pitch < lim, LSR_E_UNSUPPORTED, "a source row of %lld floats exceeds 2^30", (long long)pitch);
   const bool f32 = (mode & LSR_MODE_F32_INTERP) != 0;
   mode &= ~LSR_MODE_F32_INTERP;
   LSR_REQUIRE(mode == LSR_MODE_CONSTANT || mode == LSR_MODE_GRID_CONSTANT, LSR_E_ARG,
@@ -318,6 +317,10 @@ int affine_impl(const char* what, const float* in, int64_t Zi, int64_t Yi, int64
                               mode == LSR_MODE_GRID_CONSTANT, lsr::as_stream(stream))))
     return lsr::launch_status(what);
 
+  // (the LDS-staged kernels address a volume plane by plane with 64-bit bases; the gather kernel below does not)
+  LSR_REQUIRE(Zi * plane <= (int64_t(1) << 32), LSR_E_UNSUPPORTED,
+              "the moving volume spans more than 2^32 elements and this map does not fit the LDS-staged kernels "
+              "(the gather kernel indexes elements in 32 bits): resample it in z slabs");
   AffineArgs p;
   p.in = in;
   p.out = out;

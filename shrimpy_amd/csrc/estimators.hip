@@ -699,6 +699,9 @@ extern "C" int lsr_histogram_f32(const float* in, int64_t n, float vmin, float v
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(counts);
   LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  // (one bin may take every sample: 2^32 of them would wrap its counter -- callers add up pieces)
+  LSR_REQUIRE(n < (int64_t(1) << 32), LSR_E_UNSUPPORTED, "n = %lld: the bins count in 32 bits, histogram the volume in pieces",
+              (long long)n);
   LSR_REQUIRE(nbins >= 1 && nbins <= kMaxBins, LSR_E_ARG, "nbins %d outside [1, %d]", nbins, kMaxBins);
   LSR_REQUIRE(vmax > vmin, LSR_E_ARG, "histogram range [%g, %g] is empty", vmin, vmax);
   hipStream_t s = lsr::as_stream(stream);

@@ -76,15 +76,24 @@ def _minmax(img) -> tuple[float, float]:
     return lo, hi
 
 
+_HIST_PIECE = 1 << 31     # voxels per lsr_histogram_f32 call (< 2**32: the bins count in 32 bits)
+
+
 def _histc(img, nbins: int, vmin: float, vmax: float) -> np.ndarray:
     """``torch.histc(img, bins=nbins, min=vmin, max=vmax)`` as a host float32 array."""
     import torch
 
+    # the bins are uint32 counters: a volume of 2**32 voxels or more is histogrammed in pieces (counts add up)
+    flat = img.reshape(-1)
+    total = np.zeros((nbins,), dtype=np.int64)
     counts = torch.empty((nbins,), dtype=torch.int32, device=img.device)
     with torch.cuda.device(img.device):
-        _lib.call("lsr_histogram_f32", img.data_ptr(), img.numel(), ctypes.c_float(vmin), ctypes.c_float(vmax),
-                  int(nbins), counts.data_ptr(), _lib.stream_ptr(img.device))
-    return counts.cpu().numpy().astype(np.float32)
+        for a in range(0, flat.numel(), _HIST_PIECE):
+            piece = flat[a:a + _HIST_PIECE]
+            _lib.call("lsr_histogram_f32", piece.data_ptr(), piece.numel(), ctypes.c_float(vmin), ctypes.c_float(vmax),
+                      int(nbins), counts.data_ptr(), _lib.stream_ptr(img.device))
+            total += counts.cpu().numpy().view(np.uint32)
+    return total.astype(np.float32)
 
 
 def _gaussian_blur_3d(img, sigma: float, _rescale: tuple[float, float] | None = None):

@@ -55,6 +55,27 @@ def test_percentile_and_histogram_match_the_reference(device, golden):
     assert d._percentile(_t(np.full((3, 4, 5), 7.0, np.float32), device), 50.0) == 7.0
 
 
+def test_histogram_in_pieces_adds_up_and_the_entry_refuses_what_its_counters_cannot_hold(device, monkeypatch):
+    """The bins are uint32 counters: ``_histc`` histograms a volume of 2**32 voxels or more piece by piece (forced
+    here with a small piece), and ``lsr_histogram_f32`` itself refuses such an ``n`` instead of wrapping."""
+    import ctypes
+
+    import torch
+
+    from shrimpy_amd import _lib
+    from shrimpy_amd import dynatrack as d
+
+    vol = np.random.default_rng(5).integers(80, 600, (7, 33, 70)).astype(np.float32)
+    whole = d._histc(_t(vol, device), 64, 80.0, 599.0)
+    monkeypatch.setattr(d, "_HIST_PIECE", 1001)
+    np.testing.assert_array_equal(d._histc(_t(vol, device), 64, 80.0, 599.0), whole)
+    np.testing.assert_array_equal(whole, o.dt_histc(vol, 64, 80.0, 599.0))
+    counts = torch.zeros(64, dtype=torch.int32, device=device)
+    with pytest.raises(_lib.LsrUnsupported, match="32 bits"):
+        _lib.call("lsr_histogram_f32", _t(vol, device).data_ptr(), 1 << 32, ctypes.c_float(0.0), ctypes.c_float(1.0), 64,
+                  counts.data_ptr(), None)
+
+
 def test_intensity_center_of_mass_matches_the_reference(device, golden):
     import torch
 
