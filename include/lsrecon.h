@@ -500,6 +500,28 @@ int lsr_flatfield_apply_f32_cpu(const float* in, const float* pattern, const flo
                                 float* out, int64_t Z, int64_t Y, int64_t X, lsr_stream_t stream);
 int lsr_flatfield_apply_u16_cpu(const uint16_t* in, const float* pattern, const float* mean_dev,
                                 float* out, int64_t Z, int64_t Y, int64_t X, lsr_stream_t stream);
+/*
+ * ... and of the DynaTrack estimators (csrc/estimators_host.hip), for a tracker that runs where the reference's own
+ * does without a GPU (shrimpy/dynatrack/tracking.py:1054).  Identical values for min / max, the histogram, the shape
+ * map, the cross power, the peak and the blur (the kernels' FMA chain); the centroid sums are fp64 like the kernels'
+ * but added in row order (equal to the last bits of a double).  `scratch` is unused.  The FFTs between the
+ * cross-correlation's steps stay library calls (torch.fft on the CPU).
+ */
+int lsr_minmax_f32_cpu(const float* in, int64_t n, float* out2, void* scratch, lsr_stream_t stream);
+int lsr_histogram_f32_cpu(const float* in, int64_t n, float vmin, float vmax, int nbins, unsigned* counts,
+                          lsr_stream_t stream);
+int lsr_weighted_centroid_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t X, float background,
+                                  double* out4, void* scratch, lsr_stream_t stream);
+int lsr_mask_centroid_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t X, float threshold,
+                              double* out4, void* scratch, lsr_stream_t stream);
+int lsr_blur_reflect_f32_cpu(const float* in, float* out, int64_t Z, int64_t Y, int64_t X, int axis,
+                             const float* taps, int radius, float sub, float div, lsr_stream_t stream);
+int lsr_match_shape_f32_cpu(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
+                            int64_t Yo, int64_t Xo, lsr_stream_t stream);
+int lsr_cross_power_c64_cpu(float* a, const float* b, int64_t n, lsr_stream_t stream);
+int lsr_cross_power_into_c64_cpu(const float* a, float* b, int64_t n, lsr_stream_t stream);
+int lsr_peak_abs_shifted_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t X, long long* out_index,
+                                 void* scratch, lsr_stream_t stream);
 
 #ifdef __cplusplus
 }

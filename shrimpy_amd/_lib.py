@@ -145,7 +145,11 @@ SIGNATURES: dict[str, list] = {
 # host twins (csrc/host_twins.hip): the device entry point's signature, host pointers
 for _name in ("lsr_deskew_f32", "lsr_deskew_u16", "lsr_affine_f32", "lsr_average_slices_f32", "lsr_correlate_sep_f32",
               "lsr_correlate_dense_f32", "lsr_rl_dense_f32", "lsr_flatfield_pattern_f32", "lsr_flatfield_pattern_u16",
-              "lsr_flatfield_apply_f32", "lsr_flatfield_apply_u16"):
+              "lsr_flatfield_apply_f32", "lsr_flatfield_apply_u16",
+              # ... and of the DynaTrack estimators (csrc/estimators_host.hip)
+              "lsr_minmax_f32", "lsr_histogram_f32", "lsr_weighted_centroid_f32", "lsr_mask_centroid_f32",
+              "lsr_blur_reflect_f32", "lsr_match_shape_f32", "lsr_cross_power_c64", "lsr_cross_power_into_c64",
+              "lsr_peak_abs_shifted_f32"):
     SIGNATURES[_name + "_cpu"] = SIGNATURES[_name]
 
 

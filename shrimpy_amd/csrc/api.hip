@@ -1,5 +1,6 @@
 // Version and error reporting of liblsrecon (see include/lsrecon.h).
 #include "common.hpp"
+#include "host_parallel.hpp"
 
 namespace lsr {
 
@@ -14,6 +15,13 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(error_buffer(), 512, fmt, ap);
   va_end(ap);
   return code;
+}
+
+// Does this CPU have the FMA3 instructions the host twins' translation units are compiled for?  (Asked from here:
+// this file is built for the baseline x86-64.)
+bool host_fma_ok() {
+  static const bool ok = __builtin_cpu_supports("fma") != 0;
+  return ok;
 }
 
 }  // namespace lsr

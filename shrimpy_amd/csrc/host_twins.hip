@@ -35,46 +35,14 @@
 #include <vector>
 
 #include "common.hpp"
+#include "host_parallel.hpp"
 
 namespace {
 
-std::atomic<int> g_threads{1};
+using lsr::parallel_ranges;
+std::atomic<int>& g_threads = lsr::g_host_threads;
 constexpr int kMaxAvg = 16;    // as deskew.hip
 constexpr int kMaxTaps = 15;   // as correlate.hip
-
-// fn(first, last) over [0, n) split into contiguous ranges, one per worker.  Nothing may escape a worker (an
-// exception leaving a std::thread ends the process): a range that cannot get its scratch memory reports through
-// `failed` and the entry point returns an error.
-std::atomic<bool> g_dummy_failed{false};
-template <typename F>
-void parallel_ranges(int64_t n, F&& fn_raw, std::atomic<bool>& failed = g_dummy_failed) {
-  auto fn = [&fn_raw, &failed](int64_t a, int64_t b) {
-    try {
-      fn_raw(a, b);
-    } catch (const std::bad_alloc&) {
-      failed.store(true, std::memory_order_relaxed);
-    }
-  };
-  int workers = g_threads.load(std::memory_order_relaxed);
-  if (workers > n) workers = static_cast<int>(n);
-  if (workers <= 1) {
-    fn(int64_t(0), n);
-    return;
-  }
-  std::vector<std::thread> pool;
-  pool.reserve(static_cast<size_t>(workers));
-  const int64_t per = (n + workers - 1) / workers;
-  for (int w = 0; w < workers; ++w) {
-    const int64_t a = w * per, b = a + per < n ? a + per : n;
-    if (a >= b) break;
-    try {
-      pool.emplace_back([&fn, a, b] { fn(a, b); });
-    } catch (const std::system_error&) {   // the box refuses another thread: this range runs here
-      fn(a, b);
-    }
-  }
-  for (std::thread& t : pool) t.join();
-}
 
 struct AxisTap {
   int64_t i0, i1;
@@ -231,17 +199,20 @@ extern "C" int lsr_get_host_threads(void) { return g_threads.load(std::memory_or
 extern "C" int lsr_deskew_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo, int64_t Yo,
                                   int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd, const double M[12],
                                   int avg_n, lsr_stream_t) {
+  LSR_REQUIRE_HOST_FMA();
   return deskew_cpu(in, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M, avg_n);
 }
 
 extern "C" int lsr_deskew_u16_cpu(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo, int64_t Yo,
                                   int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd, const double M[12],
                                   int avg_n, lsr_stream_t) {
+  LSR_REQUIRE_HOST_FMA();
   return deskew_cpu(in, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M, avg_n);
 }
 
 extern "C" int lsr_affine_f32_cpu(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo, int64_t Yo,
                                   int64_t Xo, const double M[12], float cval, int mode, lsr_stream_t) {
+  LSR_REQUIRE_HOST_FMA();
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(out);
   if (int rc = check_matrix(M)) return rc;
@@ -264,6 +235,7 @@ extern "C" int lsr_affine_f32_cpu(const float* in, int64_t Zi, int64_t Yi, int64
 
 extern "C" int lsr_average_slices_f32_cpu(const float* in, int64_t Zd, int64_t Y, int64_t X, float* out, int64_t Zo, int avg_n,
                                           lsr_stream_t) {
+  LSR_REQUIRE_HOST_FMA();
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE(Zd > 0 && Y > 0 && X > 0 && Zo > 0, LSR_E_SHAPE, "shape must be positive");
@@ -290,6 +262,7 @@ extern "C" int lsr_correlate_sep_f32_cpu(const float* in, float* out, const floa
                                          const float* wz, int pz, const float* wy, int py, const float* wx, int px,
                                          int epilogue, float eps, const float* nz, const float* ny, const float* nx,
                                          lsr_stream_t) {
+  LSR_REQUIRE_HOST_FMA();
   if (int rc = check_corr(in, out, aux, Z, Y, X, pz, py, px, epilogue)) return rc;
   LSR_REQUIRE_PTR(wz);
   LSR_REQUIRE_PTR(wy);
@@ -360,6 +333,7 @@ extern "C" int lsr_correlate_sep_f32_cpu(const float* in, float* out, const floa
 extern "C" int lsr_correlate_dense_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y, int64_t X,
                                            const float* w, int pz, int py, int px, int epilogue, float eps,
                                            const double* norm_table, lsr_stream_t) {
+  LSR_REQUIRE_HOST_FMA();
   if (int rc = check_corr(in, out, aux, Z, Y, X, pz, py, px, epilogue)) return rc;
   LSR_REQUIRE_PTR(w);
   if (epilogue == LSR_EPI_UPDATE) LSR_REQUIRE_PTR(norm_table);
@@ -398,6 +372,7 @@ extern "C" int lsr_correlate_dense_f32_cpu(const float* in, float* out, const fl
 extern "C" int lsr_rl_dense_f32_cpu(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X, const float* psf,
                                     const float* psf_flipped, int pz, int py, int px, const double* norm_table, int iters,
                                     float eps, lsr_stream_t stream) {
+  LSR_REQUIRE_HOST_FMA();
   LSR_REQUIRE_PTR(y);
   LSR_REQUIRE_PTR(x);
   LSR_REQUIRE_PTR(ratio);
@@ -480,17 +455,21 @@ int flat_apply_cpu(const T* in, const float* pattern, const float* mean, float* 
 
 extern "C" int lsr_flatfield_pattern_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t X, float* pattern, float* mean_out,
                                              void*, lsr_stream_t) {
+  LSR_REQUIRE_HOST_FMA();
   return flat_pattern_cpu(in, Z, Y, X, pattern, mean_out);
 }
 extern "C" int lsr_flatfield_pattern_u16_cpu(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* pattern,
                                              float* mean_out, void*, lsr_stream_t) {
+  LSR_REQUIRE_HOST_FMA();
   return flat_pattern_cpu(in, Z, Y, X, pattern, mean_out);
 }
 extern "C" int lsr_flatfield_apply_f32_cpu(const float* in, const float* pattern, const float* mean_dev, float* out, int64_t Z,
                                            int64_t Y, int64_t X, lsr_stream_t) {
+  LSR_REQUIRE_HOST_FMA();
   return flat_apply_cpu(in, pattern, mean_dev, out, Z, Y, X);
 }
 extern "C" int lsr_flatfield_apply_u16_cpu(const uint16_t* in, const float* pattern, const float* mean_dev, float* out,
                                            int64_t Z, int64_t Y, int64_t X, lsr_stream_t) {
+  LSR_REQUIRE_HOST_FMA();
   return flat_apply_cpu(in, pattern, mean_dev, out, Z, Y, X);
 }

@@ -24,7 +24,12 @@ reference (``tracking.py``)                here                                 
 =========================================  =====================================  ==========
 
 ``_binary_mask`` / ``_center_of_mass`` never materialise the boolean mask unless asked to: the
-centroid kernel thresholds on the fly.  No CPU fallback: tensors must live on the GPU.
+centroid kernel thresholds on the fly.
+
+CPU tensors -- the reference's tracker runs on ``cuda`` if available, else ``cpu`` (``tracking.py:1054``), and its CI
+has no GPU -- take the same functions through the native host twins of those kernels (``csrc/estimators_host.hip``,
+``lsr_*_cpu``: same signatures, same arithmetic) and ``torch.fft`` on the CPU for the transforms; nothing here reads
+``oracle/``.  A volume is processed where it lives; nothing is moved between devices behind the caller's back.
 """
 
 from __future__ import annotations
@@ -54,6 +59,8 @@ def _volume(img, name="img"):
         raise TypeError(f"{name} must be a torch.Tensor, got {type(img).__name__}")
     if img.dtype != torch.float32:
         img = img.to(dtype=torch.float32)
+    if img.device.type == "cpu":
+        return img.contiguous()
     return _lib.require_device_f32(img.contiguous(), name)
 
 
@@ -63,15 +70,28 @@ def _scratch(device):
     return torch.empty((_lib.call_value("lsr_reduce_scratch_bytes"),), dtype=torch.uint8, device=device)
 
 
+def _run(device, entry: str, *args) -> None:
+    """Call ``entry`` for operands on ``device``: the kernel on its current stream, or -- CPU tensors -- the
+    entry's host twin (``entry + "_cpu"``, same arguments; worker threads = ``torch.get_num_threads()``)."""
+    import torch
+
+    if device.type == "cpu":
+        from . import host
+
+        host._threads()
+        _lib.call(entry + "_cpu", *args, None)
+        return
+    with torch.cuda.device(device):
+        _lib.call(entry, *args, _lib.stream_ptr(device))
+
+
 def _minmax(img) -> tuple[float, float]:
     """``(float(img.min()), float(img.max()))`` -- one pass, one host round trip (the reference's
     ``float(vmin)`` / ``float(vmax)`` synchronise too)."""
     import torch
 
     out = torch.empty((2,), dtype=torch.float32, device=img.device)
-    with torch.cuda.device(img.device):
-        _lib.call("lsr_minmax_f32", img.data_ptr(), img.numel(), out.data_ptr(), _scratch(img.device).data_ptr(),
-                  _lib.stream_ptr(img.device))
+    _run(img.device, "lsr_minmax_f32", img.data_ptr(), img.numel(), out.data_ptr(), _scratch(img.device).data_ptr())
     lo, hi = out.cpu().tolist()
     return lo, hi
 
@@ -87,12 +107,11 @@ def _histc(img, nbins: int, vmin: float, vmax: float) -> np.ndarray:
     flat = img.reshape(-1)
     total = np.zeros((nbins,), dtype=np.int64)
     counts = torch.empty((nbins,), dtype=torch.int32, device=img.device)
-    with torch.cuda.device(img.device):
-        for a in range(0, flat.numel(), _HIST_PIECE):
-            piece = flat[a:a + _HIST_PIECE]
-            _lib.call("lsr_histogram_f32", piece.data_ptr(), piece.numel(), ctypes.c_float(vmin), ctypes.c_float(vmax),
-                      int(nbins), counts.data_ptr(), _lib.stream_ptr(img.device))
-            total += counts.cpu().numpy().view(np.uint32)
+    for a in range(0, flat.numel(), _HIST_PIECE):
+        piece = flat[a:a + _HIST_PIECE]
+        _run(img.device, "lsr_histogram_f32", piece.data_ptr(), piece.numel(), ctypes.c_float(vmin), ctypes.c_float(vmax),
+             int(nbins), counts.data_ptr())
+        total += counts.cpu().numpy().view(np.uint32)
     return total.astype(np.float32)
 
 
@@ -115,17 +134,15 @@ def _gaussian_blur_3d(img, sigma: float, _rescale: tuple[float, float] | None = 
     z, y, x = (int(v) for v in vol.shape)
     src = vol
     sub, div = (0.0, 0.0) if _rescale is None else (float(_rescale[0]), float(np.float32(_rescale[1]) - np.float32(_rescale[0])))
-    with torch.cuda.device(vol.device):
-        stream = _lib.stream_ptr(vol.device)
-        for axis, n in enumerate((z, y, x)):
-            r = min(max_radius, n - 1)   # reflect padding requires pad < dim (reference :403-404)
-            xs = torch.arange(-r, r + 1, device=vol.device, dtype=torch.float32)
-            k1d = torch.exp(-0.5 * (xs / sigma) ** 2)
-            k1d = (k1d / k1d.sum()).contiguous()
-            dst = torch.empty_like(vol)
-            _lib.call("lsr_blur_reflect_f32", src.data_ptr(), dst.data_ptr(), z, y, x, axis, k1d.data_ptr(), r,
-                      ctypes.c_float(sub), ctypes.c_float(div), stream)
-            src, sub, div = dst, 0.0, 0.0
+    for axis, n in enumerate((z, y, x)):
+        r = min(max_radius, n - 1)   # reflect padding requires pad < dim (reference :403-404)
+        xs = torch.arange(-r, r + 1, device=vol.device, dtype=torch.float32)
+        k1d = torch.exp(-0.5 * (xs / sigma) ** 2)
+        k1d = (k1d / k1d.sum()).contiguous()
+        dst = torch.empty_like(vol)
+        _run(vol.device, "lsr_blur_reflect_f32", src.data_ptr(), dst.data_ptr(), z, y, x, axis, k1d.data_ptr(), r,
+             ctypes.c_float(sub), ctypes.c_float(div))
+        src, sub, div = dst, 0.0, 0.0
     return src
 
 
@@ -194,9 +211,8 @@ def _centroid(kernel: str, vol, param: float):
 
     z, y, x = (int(v) for v in vol.shape)
     out = torch.empty((4,), dtype=torch.float64, device=vol.device)
-    with torch.cuda.device(vol.device):
-        _lib.call(kernel, vol.data_ptr(), z, y, x, ctypes.c_float(param), out.data_ptr(),
-                  _scratch(vol.device).data_ptr(), _lib.stream_ptr(vol.device))
+    _run(vol.device, kernel, vol.data_ptr(), z, y, x, ctypes.c_float(param), out.data_ptr(),
+         _scratch(vol.device).data_ptr())
     return out.cpu().numpy()
 
 
@@ -404,9 +420,7 @@ def _match_shape(t, shape):
     if tuple(vol.shape) == shape:
         return vol
     out = torch.empty(shape, dtype=torch.float32, device=vol.device)
-    with torch.cuda.device(vol.device):
-        _lib.call("lsr_match_shape_f32", vol.data_ptr(), *(int(v) for v in vol.shape), out.data_ptr(), *shape,
-                  _lib.stream_ptr(vol.device))
+    _run(vol.device, "lsr_match_shape_f32", vol.data_ptr(), *(int(v) for v in vol.shape), out.data_ptr(), *shape)
     return out
 
 
@@ -452,7 +466,10 @@ def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0) -> tuple[int
     shape = tuple(_next_fast_len(int(max(s1, s2) * maximum_shift)) for s1, s2 in zip(ref_t.shape, mov_t.shape))
     logger.debug("phase cross corr: fft shape %s for arrays %s and %s (max_shift=%.2f)", shape,
                  tuple(ref_t.shape), tuple(mov_t.shape), maximum_shift)
-    kind = "rfft3" if (_axis_fft_ok[0] and fft3.available() and min(shape) >= 2) else "rfftn"
+    if ref_t.device != mov_t.device:
+        raise ValueError(f"ref_img is on {ref_t.device}, mov_img on {mov_t.device}")
+    on_gpu = ref_t.device.type == "cuda"      # (CPU tensors: torch.fft between the host twins of the other steps)
+    kind = "rfft3" if (on_gpu and _axis_fft_ok[0] and fft3.available() and min(shape) >= 2) else "rfftn"
     peak_index = None
     try:
         if kind == "rfft3" and _rows_ok[0] and fft3.rows_supported(shape):
@@ -472,10 +489,9 @@ def _phase_cross_corr(ref_img, mov_img, maximum_shift: float = 1.0) -> tuple[int
         peak_index = None
         corr = _cross_correlation(ref_t, ref_t is ref_img, mov_t, shape, "rfftn")
     if peak_index is None:
-        with torch.cuda.device(corr.device):
-            peak_index = torch.empty((1,), dtype=torch.int64, device=corr.device)
-            _lib.call("lsr_peak_abs_shifted_f32", corr.data_ptr(), *shape, peak_index.data_ptr(),
-                      _scratch(corr.device).data_ptr(), _lib.stream_ptr(corr.device))
+        peak_index = torch.empty((1,), dtype=torch.int64, device=corr.device)
+        _run(corr.device, "lsr_peak_abs_shifted_f32", corr.data_ptr(), *shape, peak_index.data_ptr(),
+             _scratch(corr.device).data_ptr())
     peak = np.unravel_index(int(peak_index.item()), shape)
     result = tuple(int(s // 2) - int(p) for s, p in zip(shape, peak))
     logger.debug("phase cross corr: peak at %s (device=%s)", result, ref_t.device)
@@ -494,6 +510,20 @@ def _correlation_peak_rows(ref_t, ref_is_callers, mov_t, shape):
         if cacheable:
             _spectra.put(ref_t, ("rfft3", shape), fimg1)
     return fft3.correlation_peak(fimg1, mov_t, shape)
+
+
+def _same_dense_layout(a, b) -> bool:
+    """Same shape and strides, and those strides a permutation of a contiguous tensor's (no gaps, no overlap)."""
+    if a.shape != b.shape or a.stride() != b.stride() or a.dtype != b.dtype:
+        return False
+    expect = 1
+    for size, stride in sorted(zip(a.shape, a.stride()), key=lambda p: p[1]):
+        if size == 1:
+            continue
+        if stride != expect:
+            return False
+        expect *= size
+    return True
 
 
 def _cross_correlation(ref_t, ref_is_callers, mov_t, shape, kind: str):
@@ -515,16 +545,18 @@ def _cross_correlation(ref_t, ref_is_callers, mov_t, shape, kind: str):
 
         return fft3.correlate_with_spectrum(fimg1, _match_shape(mov_t, shape))
     fimg2 = _spectrum(mov_t, shape, kind)
-    with torch.cuda.device(fimg2.device):
-        # f1 * conj(f2), written over f2: f1 may be the cached spectrum (element-wise: any layout)
-        _lib.call("lsr_cross_power_into_c64", fimg1.data_ptr(), fimg2.data_ptr(), fimg2.numel(),
-                  _lib.stream_ptr(fimg2.device))
-        del fimg1
-        if kind == "rfft3":
-            from . import fft3
+    # f1 * conj(f2), written over f2: f1 may be the cached spectrum.  Element-wise over the raw storage, so the two
+    # must share one dense layout -- they do (the same transform of the same shape: rocFFT's rfftn hands back a
+    # permuted, dense spectrum, and both come back that way); anything else is brought to the standard layout first
+    if not _same_dense_layout(fimg1, fimg2):
+        fimg1, fimg2 = fimg1.contiguous(), fimg2.contiguous()
+    _run(fimg2.device, "lsr_cross_power_into_c64", fimg1.data_ptr(), fimg2.data_ptr(), fimg2.numel())
+    del fimg1
+    if kind == "rfft3":
+        from . import fft3
 
-            return fft3.irfft3(fimg2, shape)
-        return torch.fft.irfftn(fimg2, s=shape).contiguous()
+        return fft3.irfft3(fimg2, shape)
+    return torch.fft.irfftn(fimg2, s=shape).contiguous()
 
 
 def _centered_gaussian_blob(shape, sigma: float, device):

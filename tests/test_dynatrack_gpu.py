@@ -196,14 +196,23 @@ def test_estimators_vs_oracle_on_larger_volumes(device, shape, sigma):
                                o.dt_multiotsu_center_of_mass(vol, other, sigma), atol=5e-2)
 
 
-def test_cpu_tensors_fail_loudly(device):
+def test_cpu_tensors_are_never_moved_to_the_device_silently(device):
+    """A CPU tensor is processed where it lives (host twins), with one RuntimeWarning per process on a box that has a
+    HIP device; the result stays on the CPU.  (Twins == kernels: tests/test_dynatrack_host.py.)"""
+    import warnings
+
     import torch
 
     from shrimpy_amd import dynatrack as d
-    from shrimpy_amd._lib import LsrError
+    from shrimpy_amd import host
 
-    with pytest.raises(LsrError, match="no CPU fallback"):
-        d._percentile(torch.zeros(2, 3, 4), 50.0)
+    vol = torch.arange(24, dtype=torch.float32).reshape(2, 3, 4)
+    host._warned[0] = False
+    with pytest.warns(RuntimeWarning, match="CPU tensor"):
+        assert d._percentile(vol, 50.0) == d._percentile(vol.to(device), 50.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # ... once per process
+        assert d._gaussian_blur_3d(vol, 1.0).device.type == "cpu"
 
 
 def test_phase_cross_corr_reuses_the_reference_spectrum_safely(device):
@@ -284,7 +293,7 @@ def test_blur_axis_kernels_match_a_mirror_correlate(device, shape, axis, r):
     import torch
     from scipy import ndimage
 
-    from shrimpy_amd import _lib
+    from shrimpy_amd import dynatrack as d
 
     rng = np.random.default_rng(sum(shape) + 7 * axis + r)
     vol = (rng.random(shape) * 900 + 100).astype(np.float32)
@@ -295,8 +304,8 @@ def test_blur_axis_kernels_match_a_mirror_correlate(device, shape, axis, r):
                                axis=axis, mode="mirror")
     src, out = _t(vol, device), torch.empty(shape, dtype=torch.float32, device=device)
     dt = _t(taps, device)
-    _lib.call("lsr_blur_reflect_f32", src.data_ptr(), out.data_ptr(), *shape, axis, dt.data_ptr(), r,
-              ctypes.c_float(sub), ctypes.c_float(div), _lib.stream_ptr(device))
+    d._run(device, "lsr_blur_reflect_f32", src.data_ptr(), out.data_ptr(), *shape, axis, dt.data_ptr(), r,
+           ctypes.c_float(sub), ctypes.c_float(div))
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-6, atol=2e-6)
 
 

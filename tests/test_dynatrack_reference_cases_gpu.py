@@ -52,7 +52,7 @@ def test_binary_mask_cases():
     vol = rng.random((8, 32, 32)) * 0.2
     vol[3:6, 12:20, 12:20] = 0.9
     mask = d._binary_mask(_dev(vol), sigma=1.0, otsu_component=0)
-    assert mask.dtype == torch.bool and mask.device.type == "cuda" and int(mask.sum()) > 0
+    assert mask.dtype == torch.bool and mask.device.type == torch.device(DEV).type and int(mask.sum()) > 0
     rng = np.random.default_rng(42)
     vol = rng.random((8, 32, 32)) * 0.3
     vol[2:6, 8:24, 8:24] = 0.6
