@@ -187,6 +187,16 @@ class _DevicePsf:
     norm_full: float = 1.0
 
 
+def fused_pays(pz: int, py: int, px: int) -> bool:
+    """Whether the one-launch iteration beats the ratio / update pair for a separable PSF of this extent.
+
+    Its tile shrinks from 32 x 128 to 16 x 128 as the in-plane extent grows (the window's halo takes the LDS), and
+    with 13 or 15 in-plane taps and a short z extent the pair is ~10 % faster; everywhere else the fused launch wins
+    by 20-40 % (config-2 grid, ``tools/bench_kernels.py --psf-sweep --psf-sweep-wide``,
+    ``profiles/r03_rl_psf_sweep.jsonl``: e.g. 5x13x13 4.79 vs 4.28 ms, 11x13x13 5.14 vs 5.34, 9x7x7 2.50 vs 4.31)."""
+    return max(py, px) <= 11 or pz >= 11
+
+
 class RichardsonLucyPlan:
     """PSF taps, border normalisation and scratch for one (volume shape, PSF, device).
 
@@ -308,7 +318,8 @@ class RichardsonLucyPlan:
         self._y_pad = None   # fused path: padded copy of a dense y
         # one launch per iteration (rl_fused_sep.hip) where the PSF fits its specialisations
         self.fused = bool(self._psf.separable and self._fused_mode in ("auto", "always")
-                          and _lib.call_value("lsr_rl_sep_fused_supported", *self._psf.shape))
+                          and _lib.call_value("lsr_rl_sep_fused_supported", *self._psf.shape)
+                          and (self._fused_mode == "always" or fused_pays(*self._psf.shape)))
         if self.fused:
             kz, ky, kx = (np.ascontiguousarray(k, dtype=np.float32) for k in factors)
             block = np.zeros(_lib.call_value("lsr_rl_sep_fused_taps_count"), np.float32)

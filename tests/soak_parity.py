@@ -107,7 +107,7 @@ def main():
         factors = [f / f.sum() for f in factors]
         y = t((r.random(vshape) * 80 + 1).astype(np.float32))
         iters = int(r.integers(1, 4))
-        a = RichardsonLucyPlan(vshape, None, dev, psf_factors=factors)(y, iterations=iters)
+        a = RichardsonLucyPlan(vshape, None, dev, psf_factors=factors, fused="always")(y, iterations=iters)
         b = RichardsonLucyPlan(vshape, None, dev, psf_factors=factors, fused="never")(y, iterations=iters)
         ok = bool(torch.equal(a, b))
         if ok and np.prod(vshape) < 200000 and max(pshape) <= 9:   # and against the oracle, where it is quick
@@ -217,7 +217,7 @@ def main():
         g = torch.Generator(device=dev).manual_seed(int(r.integers(0, 2**31)))
         y = torch.rand(vshape, device=dev, generator=g) * 80 + 1
         iters = int(r.integers(1, 3))
-        pa = RichardsonLucyPlan(vshape, None, dev, psf_factors=factors)
+        pa = RichardsonLucyPlan(vshape, None, dev, psf_factors=factors, fused="always")
         pb = RichardsonLucyPlan(vshape, None, dev, psf_factors=factors, fused="never")
         ok = bool(torch.equal(pa(y, iterations=iters), pb(y, iterations=iters)))
         pa.release(), pb.release()

@@ -645,7 +645,8 @@ def test_rl_fused_equals_two_launch_bit_exact(device, pshape, vshape):
     factors = [f / f.sum() for f in factors]           # asymmetric taps: flipped != unflipped
     y = _t((rng.random(vshape) * 80 + 1).astype(np.float32), device)
     x0 = _t((rng.random(vshape) * 40 + 1).astype(np.float32), device)
-    fused = RichardsonLucyPlan(vshape, None, device, psf_factors=factors)
+    # ("always": the default leaves wide in-plane extents with a short z extent to the pair, deconvolve.fused_pays)
+    fused = RichardsonLucyPlan(vshape, None, device, psf_factors=factors, fused="always")
     plain = RichardsonLucyPlan(vshape, None, device, psf_factors=factors, fused="never")
     assert fused.fused and not plain.fused
     for iters in (1, 2, 5):
@@ -676,7 +677,7 @@ def test_rl_fused_equals_two_launch_on_random_shapes(device):
         factors = [f / f.sum() for f in factors]
         y = _t((rng.random(vshape) * 80 + 1).astype(np.float32), device)
         iters = int(rng.integers(1, 4))
-        a = RichardsonLucyPlan(vshape, None, device, psf_factors=factors)(y, iterations=iters)
+        a = RichardsonLucyPlan(vshape, None, device, psf_factors=factors, fused="always")(y, iterations=iters)
         b = RichardsonLucyPlan(vshape, None, device, psf_factors=factors, fused="never")(y, iterations=iters)
         assert torch.equal(a, b), (case, pshape, vshape, iters)
 
@@ -692,6 +693,13 @@ def test_rl_fused_covers_every_separable_psf(device):
     assert _lib.call_value("lsr_rl_sep_fused_supported", 15, 15, 15) == 0   # would spill: two-launch path
     assert _lib.call_value("lsr_rl_sep_fused_supported", 17, 3, 3) == 0
     assert _lib.call_value("lsr_rl_sep_fused_supported", 4, 3, 3) == 0
+    from shrimpy_amd.deconvolve import fused_pays
+
+    # the default takes the one-launch form where it is the faster one (measured: profiles/r03_rl_psf_sweep.jsonl)
+    assert fused_pays(9, 7, 7) and fused_pays(13, 15, 15) and fused_pays(3, 11, 11)
+    assert not fused_pays(5, 13, 13) and not fused_pays(9, 15, 3)
+    wide = RichardsonLucyPlan((16, 30, 50), None, device, psf_factors=o.gaussian_psf((5, 13, 13), (1.0, 2.5, 2.5))[1])
+    assert wide.separable and not wide.fused and wide.path == "separable"
     psf, factors = o.gaussian_psf((11, 7, 13), (2.0, 1.2, 2.5))
     plan = RichardsonLucyPlan((16, 30, 50), None, device, psf_factors=factors)
     assert plan.separable and plan.fused

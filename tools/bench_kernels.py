@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--only-rl", action="store_true", help="skip the affine and deskew sections")
     ap.add_argument("--only-affine", action="store_true", help="only the affine apply section")
     ap.add_argument("--rl-grid", default="171,2048,2270", help="Z,Y,X of the RL launch section")
+    ap.add_argument("--psf-sweep", action="store_true", help="only: ms per RL iteration over separable PSF sizes")
+    ap.add_argument("--psf-sweep-wide", action="store_true", help="with --psf-sweep: every pz for in-plane extents 9-15")
     args = ap.parse_args()
 
     import torch
@@ -52,6 +54,9 @@ def main():
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(3)
 
+    if args.psf_sweep:
+        _psf_sweep(args, torch, dev, g, RichardsonLucyPlan, tuple(int(v) for v in args.rl_grid.split(",")))
+        return
     if not args.only_rl:
         _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_geometry, apply_affine_transform_zyx)
 
@@ -231,6 +236,40 @@ def _rl(args, torch, dev, g, bench, RichardsonLucyPlan, oshape):
         print(json.dumps({"kernel": f"RL launch, {name}", "path": plan.path, "grid": oshape, "ms_per_launch": ms,
                           "algorithmic_GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / 8000,
                           "fma_TFLOPs": 2.0 * taps * y.numel() / ms / 1e9}))
+
+
+def _psf_sweep(args, torch, dev, g, RichardsonLucyPlan, oshape):
+    """ms per RL iteration over separable Gaussian PSFs from 3x3x3 to 15x15x15: which path each takes and where
+    the rate leaves the 9x7x7 headline's (12 algorithmic bytes per voxel and iteration in every case)."""
+    y = torch.poisson(torch.full(oshape, 100.0, device=dev), generator=g)
+    sizes = [(3, 3, 3), (5, 5, 5), (7, 7, 7), (9, 7, 7), (9, 9, 9), (11, 9, 9), (13, 11, 11), (15, 9, 9), (15, 11, 11),
+             (15, 15, 15), (5, 15, 15), (15, 3, 3)]
+    if args.psf_sweep_wide:     # the in-plane extents where the fused tile shrinks: which form wins per (pz, pyx)
+        sizes = [(pz, pyx, pyx) for pyx in (9, 11, 13, 15) for pz in (3, 5, 7, 9, 11, 13, 15)]
+    for size in sizes:
+        factors = []
+        for n in size:
+            x = np.arange(n) - n // 2
+            k = np.exp(-0.5 * (x / (n / 4.5)) ** 2)
+            factors.append((k / k.sum()).astype(np.float32))
+        for fused in ("auto", "never"):
+            plan = RichardsonLucyPlan(oshape, None, dev, psf_factors=tuple(factors), fused=fused)
+            if fused == "never" and plan.path == "fused":
+                plan.release()
+                continue
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            plan(y, iterations=1)
+            torch.cuda.synchronize()
+            plan(y, iterations=4, events=ev)
+            torch.cuda.synchronize()
+            ms = ev[0].elapsed_time(ev[1]) / 4
+            path = plan.path
+            plan.release()
+            print(json.dumps({"kernel": "RL iteration, separable PSF", "psf": list(size), "requested": fused, "path": path,
+                              "grid": oshape, "ms_per_iteration": ms, "algorithmic_GBps": 12.0 * y.numel() / ms / 1e6,
+                              "frac_of_8TBps": 12.0 * y.numel() / ms / 1e6 / 8000}), flush=True)
+            if fused == "auto" and path != "fused":
+                break      # (the two-launch form was what ran)
 
 
 if __name__ == "__main__":
