@@ -422,18 +422,21 @@ def gather_to_rank0(local: Iterable, n_total: int):
     if dist is None:
         return local
     rank, world = dist.get_rank(), dist.get_world_size()
+    # gloo moves host memory only: device tensors are staged through the host (ranks sharing one card in a
+    # rehearsal, or a CPU-only box); RCCL sends them GPU to GPU
+    via_host = dist.get_backend() == "gloo" and bool(local) and local[0].is_cuda
     if rank != 0:
         for t in local:
-            dist.send(t.contiguous(), dst=0)
+            dist.send(t.contiguous().cpu() if via_host else t.contiguous(), dst=0)
         return None
     out: list = [None] * n_total
     for i, t in enumerate(local):
         out[i * world] = t
     for src in range(1, world):
         for k, idx in enumerate(range(src, n_total, world)):
-            buf = torch.empty_like(local[0]) if local else None
-            if buf is None:
+            if not local:
                 raise RuntimeError("rank 0 owns no unit: cannot infer the result shape")
+            buf = torch.empty_like(local[0], device="cpu" if via_host else local[0].device)
             dist.recv(buf, src=src)
-            out[idx] = buf
+            out[idx] = buf.to(local[0].device) if via_host else buf
     return out

@@ -104,3 +104,57 @@ def test_deskew_slab_writes_the_same_rows_as_the_whole_deskew():
         s = SlabRichardsonLucy(tuple(whole.shape), factors, dev, rank, 2)
         deskew_slab(raw[:, :, x - s.slab.ext1:x - s.slab.ext0].contiguous(), s, **kw)
         assert torch.equal(s.y_pad.view, whole[:, s.slab.ext0:s.slab.ext1, :])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_slab_run_with_ranks_sharing_the_card_equals_the_unsplit_run(world):
+    """The REAL distributed path -- ``torch.distributed.run`` ranks, ``SlabRichardsonLucy.run`` with
+    ``exchange_halos`` as batched point-to-point sends after every iteration -- on the one GPU of the test box: the
+    ranks share the card and meet over gloo (halo rows staged through the host; RCCL refuses duplicate devices).
+    Same kernels, same protocol as the RCCL run of ``tests/test_multi_gpu.py``, which needs one GPU per rank."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from tests.test_multi_gpu import ROOT, _free_port
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "tools/slab_check.py",
+           "--backend", "gloo", "--shape", "24,96,200", "--iters", "6"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"{r.stdout[-2000:]}\n{r.stderr[-3000:]}"
+    assert f"over {world} ranks (gloo): equal to the unsplit run: True" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sharded_units_and_gather_with_ranks_sharing_the_card_equal_the_single_rank_results():
+    """``run_sharded`` + ``gather_to_rank0`` under ``torch.distributed.run`` with three ranks on the one GPU (gloo,
+    results staged through the host): rank 0 recomputes every unit and compares bit for bit."""
+    import json
+    import subprocess
+    import sys
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from tests.test_multi_gpu import ROOT, _free_port
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "tools/sharded_gather_check.py",
+           "--backend", "gloo", "--units", "7"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"{r.stdout[-2000:]}\n{r.stderr[-3000:]}"
+    rec = next(json.loads(ln) for ln in reversed(r.stdout.splitlines()) if ln.startswith("{") and "sharded_gather" in ln)
+    assert rec["backend"] == "gloo" and rec["world_size"] == 3 and rec["equal_to_single_rank"]
+    assert rec["units_per_rank"] == [3, 2, 2]

@@ -4,7 +4,7 @@ single-rank run of the same units.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port 29513 tools/sharded_gather_check.py [--units 7] [--shape 96,24,70]
 
-One rank per GPU (``nccl`` = RCCL).  Every rank reconstructs its round-robin share (deskew + RL,
+One rank per GPU (``nccl`` = RCCL; ``--backend gloo``: a rehearsal with the ranks sharing one card).  Every rank reconstructs its round-robin share (deskew + RL,
 real kernels) with ``pipeline.run_sharded``; ``gather_to_rank0`` then sends the device tensors to
 rank 0, which recomputes every unit itself and compares bit for bit.  Prints one JSON line.
 """
@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--units", type=int, default=7)
     ap.add_argument("--shape", default="96,24,70")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: the ranks may share one GPU (results staged through the host)")
     args = ap.parse_args()
 
     import numpy as np
@@ -39,11 +41,11 @@ def main():
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if torch.cuda.device_count() < world:
+    if args.backend == "nccl" and torch.cuda.device_count() < world:
         raise SystemExit(f"{world} ranks need {world} GPUs, {torch.cuda.device_count()} visible")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", device_id=dev)
+    dist.init_process_group(args.backend, device_id=dev if args.backend == "nccl" else None)
 
     shape = tuple(int(v) for v in args.shape.split(","))
     settings = ReconstructSettings(
