@@ -44,6 +44,20 @@ std::atomic<int>& g_threads = lsr::g_host_threads;
 constexpr int kMaxAvg = 16;    // as deskew.hip
 constexpr int kMaxTaps = 15;   // as correlate.hip
 
+// acc[x] = fma(w, v(x + shift), acc[x]) over a whole row, v = row[...] inside [0, X) and 0 outside it (row == nullptr:
+// a row of zeros) -- the FMA with 0 is executed, as the kernels execute it; the middle part is a plain packed loop.
+inline void row_fma(float* __restrict__ acc, float w, const float* __restrict__ row, int64_t shift, int64_t X) {
+  int64_t lo = 0, hi = 0;
+  if (row != nullptr) {
+    lo = shift < 0 ? (-shift < X ? -shift : X) : 0;
+    hi = shift > 0 ? (X - shift > lo ? X - shift : lo) : X;
+    if (hi < lo) hi = lo;
+  }
+  for (int64_t x = 0; x < lo; ++x) acc[x] = std::fmaf(w, 0.0f, acc[x]);
+  for (int64_t x = lo; x < hi; ++x) acc[x] = std::fmaf(w, row[x + shift], acc[x]);
+  for (int64_t x = hi; x < X; ++x) acc[x] = std::fmaf(w, 0.0f, acc[x]);
+}
+
 struct AxisTap {
   int64_t i0, i1;
   double w0, w1;
@@ -138,22 +152,76 @@ int deskew_cpu(const T* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t
   LSR_REQUIRE(structured, LSR_E_UNSUPPORTED,
               "matrix is not a deskew shear (rows 1,2 must be signed unit axes with integer offsets, M[0][1] == 0): use "
               "lsr_affine_f32_cpu + lsr_average_slices_f32_cpu");
+  // The shear's structure (deskew.hip uses the same): z_in depends on (zd, xo) only, y_in on zd only, x_in on yo only,
+  // and y_in, x_in are whole numbers -- so of scipy's eight corners two carry weight (the z neighbours at (y_in, x_in))
+  // and the other six add zeros.  Per deskewed plane the z taps are tabulated once along xo and reused for every yo;
+  // a voxel is  float( (0.0 + double(v0) * w0) + double(v1) * w1 ), the generic resampler's own sum without its
+  // zero terms (finite inputs: a zero-weight corner holding inf / NaN would poison scipy's sum and the generic twin's,
+  // not the kernel's and not this one).  Then the average of avg_n planes in f32, as the kernel accumulates it.
+  std::vector<int64_t> xin_v(static_cast<size_t>(Yo));
+  for (int64_t yo = 0; yo < Yo; ++yo) {     // x_in(yo), or -1 where it leaves the stack
+    const double c = coord(0.0, static_cast<double>(yo), 0.0, M + 8);
+    xin_v[static_cast<size_t>(yo)] = (c < 0.0 || c > static_cast<double>(X - 1)) ? -1 : static_cast<int64_t>(std::floor(c));
+  }
+  const int64_t* const xin = xin_v.data();
+  const int64_t plane = Y * X;
+  std::atomic<bool> failed{false};
   parallel_ranges(Zo, [&](int64_t z_first, int64_t z_last) {
-    for (int64_t zo = z_first; zo < z_last; ++zo)
-      for (int64_t yo = 0; yo < Yo; ++yo) {
-        float* row = out + zo * out_plane + yo * out_pitch;
-        for (int64_t xo = 0; xo < Xo; ++xo) {
-          float acc = 0.0f;
-          for (int k = 0; k < avg_n; ++k) {
-            const int64_t zd = zo * avg_n + k < Zd - 1 ? zo * avg_n + k : Zd - 1;
-            const float d = sample<T, false>(in, Z, Y, X, M, static_cast<double>(zd), static_cast<double>(yo),
-                                             static_cast<double>(xo), 0.0f);
-            acc = k == 0 ? d : acc + d;
+    std::vector<int64_t> o0_v(static_cast<size_t>(Xo)), o1_v(static_cast<size_t>(Xo));
+    std::vector<double> w0_v(static_cast<size_t>(Xo)), w1_v(static_cast<size_t>(Xo));
+    std::vector<float> d_v(static_cast<size_t>(Xo));
+    int64_t* const o0 = o0_v.data();
+    int64_t* const o1 = o1_v.data();
+    double* const w0 = w0_v.data();
+    double* const w1 = w1_v.data();
+    float* const d = d_v.data();
+    for (int64_t zo = z_first; zo < z_last; ++zo) {
+      for (int k = 0; k < avg_n; ++k) {
+        const int64_t zd = zo * avg_n + k < Zd - 1 ? zo * avg_n + k : Zd - 1;
+        const double cy = coord(static_cast<double>(zd), 0.0, 0.0, M + 4);
+        const bool y_ok = !(cy < 0.0 || cy > static_cast<double>(Y - 1));
+        const int64_t y_in = y_ok ? static_cast<int64_t>(std::floor(cy)) : 0;
+        for (int64_t xo = 0; xo < Xo; ++xo) {      // the z taps of this deskewed plane (o0 < 0: outside the stack)
+          AxisTap tz;
+          if (y_ok && axis_tap<false>(coord(static_cast<double>(zd), 0.0, static_cast<double>(xo), M), Z, tz)) {
+            o0[xo] = tz.i0 * plane + y_in * X;
+            o1[xo] = tz.i1 * plane + y_in * X;
+            w0[xo] = tz.w0;
+            w1[xo] = tz.w1;
+          } else {
+            o0[xo] = -1;
           }
-          row[xo] = avg_n > 1 ? acc / static_cast<float>(avg_n) : acc;
+        }
+        for (int64_t yo = 0; yo < Yo; ++yo) {
+          float* const row = out + zo * out_plane + yo * out_pitch;
+          const int64_t xi = xin[yo];
+          if (xi < 0) {
+            for (int64_t xo = 0; xo < Xo; ++xo) d[xo] = 0.0f;
+          } else {
+            const T* const col = in + xi;
+            for (int64_t xo = 0; xo < Xo; ++xo) {
+              if (o0[xo] < 0) {
+                d[xo] = 0.0f;
+                continue;
+              }
+              double t = 0.0 + static_cast<double>(col[o0[xo]]) * w0[xo];
+              t = t + static_cast<double>(col[o1[xo]]) * w1[xo];
+              d[xo] = static_cast<float>(t);
+            }
+          }
+          if (k == 0) {             // (avg_n == 1: the sample itself, no division)
+            for (int64_t xo = 0; xo < Xo; ++xo) row[xo] = d[xo];
+          } else if (k + 1 < avg_n) {
+            for (int64_t xo = 0; xo < Xo; ++xo) row[xo] = row[xo] + d[xo];
+          } else {
+            const float n = static_cast<float>(avg_n);
+            for (int64_t xo = 0; xo < Xo; ++xo) row[xo] = (row[xo] + d[xo]) / n;
+          }
         }
       }
-  });
+    }
+  }, failed);
+  if (failed.load()) return lsr::fail(LSR_E_ARG, "out of host memory for the per-thread tap tables");
   return LSR_OK;
 }
 
@@ -274,7 +342,11 @@ extern "C" int lsr_correlate_sep_f32_cpu(const float* in, float* out, const floa
   }
   const int64_t plane = Y * X;
   const int cz = pz / 2, cy = py / 2, cx = px / 2;
-  // in-plane passes of every plane first (x then y, f32 FMA chains from 0), then the z chain + epilogue
+  // in-plane passes of every plane first (x then y, f32 FMA chains from 0), then the z chain + epilogue.
+  // Every voxel sees exactly the kernels' operations in the kernels' order -- a tap that falls outside the volume is
+  // an FMA with 0, not a skipped step -- but the loops run taps outermost and x innermost over whole rows, so that
+  // the compiler turns each into packed FMAs (the per-voxel tap loop was a serial dependency chain: 4x slower than
+  // scipy's correlate1d on one core; this form is faster than it).
   std::atomic<bool> failed{false};
   std::vector<float> filtered;
   try {
@@ -283,50 +355,69 @@ extern "C" int lsr_correlate_sep_f32_cpu(const float* in, float* out, const floa
     return lsr::fail(LSR_E_ARG, "out of host memory for a %lld-voxel intermediate", (long long)(Z * plane));
   }
   parallel_ranges(Z, [&](int64_t z_first, int64_t z_last) {
-    std::vector<float> rows(static_cast<size_t>(plane));
+    std::vector<float> rows_v(static_cast<size_t>(plane));
+    float* const rows = rows_v.data();
     for (int64_t z = z_first; z < z_last; ++z) {
-      const float* src = in + z * plane;
-      for (int64_t y = 0; y < Y; ++y)
-        for (int64_t x = 0; x < X; ++x) {
-          float s = 0.0f;
-          for (int c = 0; c < px; ++c) {
-            const int64_t gx = x + c - cx;
-            s = std::fmaf(wx[c], gx >= 0 && gx < X ? src[y * X + gx] : 0.0f, s);
+      const float* const src = in + z * plane;
+      for (int64_t y = 0; y < Y; ++y) {
+        const float* __restrict__ srow = src + y * X;
+        float* __restrict__ acc = rows + y * X;
+        for (int64_t x = 0; x < X; ++x) acc[x] = 0.0f;
+        for (int c = 0; c < px; ++c) row_fma(acc, wx[c], srow, c - cx, X);
+      }
+      float* const dst = filtered.data() + z * plane;
+      for (int64_t y = 0; y < Y; ++y) {
+        float* __restrict__ acc = dst + y * X;
+        for (int64_t x = 0; x < X; ++x) acc[x] = 0.0f;
+        for (int b = 0; b < py; ++b) {
+          const float w = wy[b];
+          const int64_t gy = y + b - cy;
+          if (gy >= 0 && gy < Y) {
+            const float* __restrict__ r = rows + gy * X;
+            for (int64_t x = 0; x < X; ++x) acc[x] = std::fmaf(w, r[x], acc[x]);
+          } else {
+            for (int64_t x = 0; x < X; ++x) acc[x] = std::fmaf(w, 0.0f, acc[x]);
           }
-          rows[static_cast<size_t>(y * X + x)] = s;
         }
-      float* dst = filtered.data() + z * plane;
-      for (int64_t y = 0; y < Y; ++y)
-        for (int64_t x = 0; x < X; ++x) {
-          float s = 0.0f;
-          for (int b = 0; b < py; ++b) {
-            const int64_t gy = y + b - cy;
-            s = std::fmaf(wy[b], gy >= 0 && gy < Y ? rows[static_cast<size_t>(gy * X + x)] : 0.0f, s);
-          }
-          dst[y * X + x] = s;
-        }
+      }
     }
   }, failed);
   if (failed.load()) return lsr::fail(LSR_E_ARG, "out of host memory for the per-thread row buffers");
-  parallel_ranges(Z, [&](int64_t z_first, int64_t z_last) {
-    for (int64_t z = z_first; z < z_last; ++z)
-      for (int64_t y = 0; y < Y; ++y)
-        for (int64_t x = 0; x < X; ++x) {
-          const int64_t r = y * X + x;
-          // the march of correlate.hip: the first plane's term is a plain product, the others FMAs onto it
-          auto pl = [&](int a) {
-            const int64_t zi = z + a - cz;
-            return zi >= 0 && zi < Z ? filtered[static_cast<size_t>(zi * plane + r)] : 0.0f;
-          };
-          float c = wz[0] * pl(0);
-          for (int a = 1; a < pz; ++a) c = std::fmaf(wz[a], pl(a), c);
-          const int64_t o = z * plane + r;
-          float v = c;
-          if (epilogue == LSR_EPI_RATIO) v = aux[o] / (c + eps);
-          else if (epilogue == LSR_EPI_UPDATE) v = aux[o] * c / (nz[z] * ny[y] * nx[x]);
-          out[o] = v;
+  parallel_ranges(Z * Y, [&](int64_t r_first, int64_t r_last) {
+    std::vector<float> c_v(static_cast<size_t>(X));
+    float* __restrict__ c = c_v.data();
+    for (int64_t zy = r_first; zy < r_last; ++zy) {
+      const int64_t z = zy / Y, y = zy - z * Y;
+      // the march of correlate.hip: the first plane's term is a plain product, the others FMAs onto it
+      for (int a = 0; a < pz; ++a) {
+        const int64_t zi = z + a - cz;
+        const float w = wz[a];
+        const bool inside = zi >= 0 && zi < Z;
+        const float* __restrict__ p = filtered.data() + (inside ? zi : 0) * plane + y * X;
+        if (a == 0) {
+          if (inside) for (int64_t x = 0; x < X; ++x) c[x] = w * p[x];
+          else for (int64_t x = 0; x < X; ++x) c[x] = w * 0.0f;
+        } else if (inside) {
+          for (int64_t x = 0; x < X; ++x) c[x] = std::fmaf(w, p[x], c[x]);
+        } else {
+          for (int64_t x = 0; x < X; ++x) c[x] = std::fmaf(w, 0.0f, c[x]);
         }
-  });
+      }
+      const int64_t o = zy * X;
+      float* __restrict__ dst = out + o;
+      if (epilogue == LSR_EPI_RATIO) {
+        const float* __restrict__ ax = aux + o;
+        for (int64_t x = 0; x < X; ++x) dst[x] = ax[x] / (c[x] + eps);
+      } else if (epilogue == LSR_EPI_UPDATE) {
+        const float* __restrict__ ax = aux + o;
+        const float nzy = nz[z] * ny[y];
+        for (int64_t x = 0; x < X; ++x) dst[x] = ax[x] * c[x] / (nzy * nx[x]);
+      } else {
+        for (int64_t x = 0; x < X; ++x) dst[x] = c[x];
+      }
+    }
+  }, failed);
+  if (failed.load()) return lsr::fail(LSR_E_ARG, "out of host memory for the per-thread row buffers");
   return LSR_OK;
 }
 
@@ -339,31 +430,37 @@ extern "C" int lsr_correlate_dense_f32_cpu(const float* in, float* out, const fl
   if (epilogue == LSR_EPI_UPDATE) LSR_REQUIRE_PTR(norm_table);
   const int64_t plane = Y * X;
   const int cz = pz / 2, cy = py / 2, cx = px / 2;
-  parallel_ranges(Z, [&](int64_t z_first, int64_t z_last) {
-    for (int64_t z = z_first; z < z_last; ++z)
-      for (int64_t y = 0; y < Y; ++y)
-        for (int64_t x = 0; x < X; ++x) {
-          float c = 0.0f;   // planes in z order, within a plane y-major: the order the march accumulates in
-          for (int a = 0; a < pz; ++a) {
-            const int64_t zi = z + a - cz;
-            if (zi < 0 || zi >= Z) continue;      // (a whole plane of zeros leaves the chain unchanged)
-            for (int b = 0; b < py; ++b) {
-              const int64_t gy = y + b - cy;
-              for (int k = 0; k < px; ++k) {
-                const int64_t gx = x + k - cx;
-                const float v = gy >= 0 && gy < Y && gx >= 0 && gx < X ? in[zi * plane + gy * X + gx] : 0.0f;
-                c = std::fmaf(w[(a * py + b) * px + k], v, c);
-              }
-            }
-          }
-          const int64_t o = z * plane + y * X + x;
-          float v = c;
-          if (epilogue == LSR_EPI_RATIO) v = aux[o] / (c + eps);
-          else if (epilogue == LSR_EPI_UPDATE)
-            v = aux[o] * c / static_cast<float>(dense_norm(norm_table, pz, py, px, Z, Y, X, z, y, x));
-          out[o] = v;
+  // per output row: taps outermost (planes in z order, within a plane y-major, then x: the order the march accumulates
+  // in), x innermost -- every voxel's chain is the same sequence of FMAs, a row at a time (packed FMAs on the host)
+  std::atomic<bool> failed{false};
+  parallel_ranges(Z * Y, [&](int64_t r_first, int64_t r_last) {
+    std::vector<float> c_v(static_cast<size_t>(X));
+    float* __restrict__ c = c_v.data();
+    for (int64_t zy = r_first; zy < r_last; ++zy) {
+      const int64_t z = zy / Y, y = zy - z * Y;
+      for (int64_t x = 0; x < X; ++x) c[x] = 0.0f;
+      for (int a = 0; a < pz; ++a) {
+        const int64_t zi = z + a - cz;
+        if (zi < 0 || zi >= Z) continue;      // (a whole plane of zeros leaves the chain unchanged)
+        for (int b = 0; b < py; ++b) {
+          const int64_t gy = y + b - cy;
+          const float* row = gy >= 0 && gy < Y ? in + zi * plane + gy * X : nullptr;
+          for (int k = 0; k < px; ++k) row_fma(c, w[(a * py + b) * px + k], row, k - cx, X);
         }
-  });
+      }
+      const int64_t o = zy * X;
+      float* __restrict__ dst = out + o;
+      if (epilogue == LSR_EPI_RATIO) {
+        for (int64_t x = 0; x < X; ++x) dst[x] = aux[o + x] / (c[x] + eps);
+      } else if (epilogue == LSR_EPI_UPDATE) {
+        for (int64_t x = 0; x < X; ++x)
+          dst[x] = aux[o + x] * c[x] / static_cast<float>(dense_norm(norm_table, pz, py, px, Z, Y, X, z, y, x));
+      } else {
+        for (int64_t x = 0; x < X; ++x) dst[x] = c[x];
+      }
+    }
+  }, failed);
+  if (failed.load()) return lsr::fail(LSR_E_ARG, "out of host memory for the per-thread row buffers");
   return LSR_OK;
 }
 
