@@ -296,15 +296,18 @@ _shard_locks: dict[str, threading.Lock] = {}
 
 @contextlib.contextmanager
 def _shard_lock(path: Path):
-    """Exclusive access to one shard file for a read-modify-write: a lock per path for the threads of
-    this process, ``flock`` on ``<shard>.lock`` for other processes (ranks) on the same host."""
+    """Exclusive access to one shard file for a read-modify-write: a lock per directory for the threads of this
+    process, ``flock`` on the shard's DIRECTORY for other processes (ranks) on the same host.  The directory, not a
+    ``<shard>.lock`` beside the chunk (a store keeps nothing but what Zarr defines), and not the shard itself (it is
+    replaced by rename: a lock on the old inode would not hold anyone who opens the new one)."""
     import fcntl
 
-    key = str(path)
+    folder = path.parent
+    key = str(folder)
     with _shard_locks_guard:
         lock = _shard_locks.setdefault(key, threading.Lock())
     with lock:
-        fd = os.open(str(path) + ".lock", os.O_CREAT | os.O_RDWR, 0o644)
+        fd = os.open(str(folder), os.O_RDONLY)
         try:
             fcntl.flock(fd, fcntl.LOCK_EX)
             yield

@@ -403,6 +403,40 @@ def test_concurrent_writers_of_one_shared_shard_keep_each_others_volumes(tmp_pat
     with open_ome_zarr(tmp_path / "p.zarr", prefer_iohub=False) as plate:
         np.testing.assert_array_equal(plate["A/1/fov0"]["0"][:], data)
     assert not list((tmp_path / "p.zarr").rglob("*.partial"))
+    assert not list((tmp_path / "p.zarr").rglob("*.lock"))       # the store holds nothing but what Zarr defines
+
+
+def _shared_shard_writer(path, t, seed, rounds):
+    data = np.random.default_rng(seed).integers(80, 600, (2, 24, 8, 20)).astype("uint16")
+    with open_ome_zarr(path, layout="hcs", mode="a", prefer_iohub=False) as plate:
+        arr = plate["A/1/fov0"]["0"]
+        for _ in range(rounds):
+            for c in range(2):
+                arr.write_volume(t, c, data[c])
+
+
+def test_processes_writing_one_shared_shard_keep_each_others_volumes(tmp_path):
+    """The same between PROCESSES (ranks of one host): four of them, one timepoint each, all in one shard file."""
+    import multiprocessing as mp
+
+    shape = (4, 2, 24, 8, 20)
+    with open_ome_zarr(tmp_path / "p.zarr", layout="hcs", mode="w", channel_names=["BF", "GFP"], version="0.5",
+                       prefer_iohub=False) as plate:
+        plate.create_position("A", "1", "fov0").create_zeros(
+            "0", shape=shape, dtype="uint16", chunks=(1, 1, 8, 8, 20), compress="blosc-zstd", shards=shape)
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_shared_shard_writer, args=(str(tmp_path / "p.zarr"), t, 100 + t, 3)) for t in range(4)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(120)
+        assert pr.exitcode == 0
+    with open_ome_zarr(tmp_path / "p.zarr", prefer_iohub=False) as plate:
+        got = plate["A/1/fov0"]["0"][:]
+    for t in range(4):
+        np.testing.assert_array_equal(got[t], np.random.default_rng(100 + t).integers(80, 600, (2, 24, 8, 20)).astype("uint16"))
+    leftovers = [f.name for f in (tmp_path / "p.zarr").rglob("*") if f.suffix in (".partial", ".lock")]
+    assert not leftovers, leftovers
 
 
 def test_a_chunk_whose_crc32c_suffix_does_not_match_is_refused(tmp_path):
