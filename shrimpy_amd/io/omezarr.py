@@ -298,7 +298,7 @@ _shard_locks: dict[str, threading.Lock] = {}
 def _shard_lock(path: Path):
     """Exclusive access to one shard file for a read-modify-write: a lock per directory for the threads of this
     process, ``flock`` on the shard's DIRECTORY for other processes (ranks) on the same host.  The directory, not a
-    ``<shard>.lock`` beside the chunk (a store keeps nothing but what Zarr defines), and not the shard itself (it is
+    ``<shard>.lock`` beside the chunk (nothing but chunk files lives in an array's key space), and not the shard itself (it is
     replaced by rename: a lock on the old inode would not hold anyone who opens the new one)."""
     import fcntl
 

@@ -403,7 +403,7 @@ def test_concurrent_writers_of_one_shared_shard_keep_each_others_volumes(tmp_pat
     with open_ome_zarr(tmp_path / "p.zarr", prefer_iohub=False) as plate:
         np.testing.assert_array_equal(plate["A/1/fov0"]["0"][:], data)
     assert not list((tmp_path / "p.zarr").rglob("*.partial"))
-    assert not list((tmp_path / "p.zarr").rglob("*.lock"))       # the store holds nothing but what Zarr defines
+    assert not list((tmp_path / "p.zarr").rglob("*.lock"))       # nothing but chunk files among the chunks
 
 
 def _shared_shard_writer(path, t, seed, rounds):
