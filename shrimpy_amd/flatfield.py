@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 from . import _lib
 
-__all__ = ["FlatFieldPattern", "flat_field_pattern", "flat_field_bf"]
+__all__ = ["FlatFieldPattern", "flat_field_pattern", "flat_field_bf", "flat_field_correction"]
 
 
 @dataclass
@@ -111,3 +111,20 @@ def flat_field_bf(volume):
     if isinstance(volume, torch.Tensor) and volume.dtype not in (torch.float32, torch.uint16):
         volume = volume.to(torch.float32)
     return flat_field_pattern(volume).apply(volume.contiguous())
+
+
+def flat_field_correction(data, axis: int = 0):
+    """``biahub.flat_field_correction.flat_field_correction(data, axis)`` -- the numpy-level entry the reference's
+    own test compares its ``_flat_field_BF`` with (``shrimpy/tests/test_preprocessing.py:145-162``): divide a stack
+    by its per-pixel median along ``axis`` and keep the pattern's mean.  A numpy array comes back as a numpy array
+    (computed where a tensor of it lives: the host twins without a GPU tensor), a tensor as a tensor."""
+    import numpy as np
+    import torch
+
+    is_tensor = isinstance(data, torch.Tensor)
+    t = data if is_tensor else torch.as_tensor(np.ascontiguousarray(data))
+    if t.dim() != 3:
+        raise ValueError(f"expected a 3-D stack, got shape {tuple(t.shape)}")
+    moved = t.movedim(int(axis), 0).contiguous()
+    out = flat_field_bf(moved).movedim(0, int(axis))
+    return out if is_tensor else out.contiguous().cpu().numpy()

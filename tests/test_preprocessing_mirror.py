@@ -176,8 +176,8 @@ REFERENCE = Path("/root/reference")
 def test_dropin_through_the_reference_preprocessor(monkeypatch):
     """The reference's ``build_preprocessor`` / ``_LabelfreePreprocessor`` run unmodified with this
     package bound as ``biahub``: settings validation, kwargs filtering by signature, warm-up shape
-    call and the deskew call all go through our modules.  (No GPU here: the C-ABI launch itself is
-    replaced by the oracle for this one check of the *interface*.)"""
+    call and the deskew call all go through our modules -- and, since round 3, the arithmetic too: the CPU
+    tensor the reference hands over runs the native host twin (a spy records the call and passes it on)."""
     import torch
 
     import shrimpy_amd.deskew as our_deskew
@@ -197,14 +197,16 @@ def test_dropin_through_the_reference_preprocessor(monkeypatch):
 
     calls = {}
 
-    def fake_launch(raw, matrix, pre_shape, avg=1, out=None, border="constant"):
+    real_launch = our_deskew.deskew_with_matrix
+
+    def spy(raw, matrix, pre_shape, avg=1, out=None, border="constant", **kw):
         calls["args"] = (tuple(raw.shape), pre_shape, avg)
         calls["border"] = border
-        m = np.asarray(matrix)
-        res = o.average_slices(o.affine_apply(raw.numpy(), m[:, :3], m[:, 3], pre_shape, mode=border), avg)
-        return torch.as_tensor(res)
+        res = real_launch(raw, matrix, pre_shape, avg, out=out, border=border, **kw)
+        assert isinstance(res, torch.Tensor) and res.device.type == "cpu"
+        return res
 
-    monkeypatch.setattr(our_deskew, "deskew_with_matrix", fake_launch)
+    monkeypatch.setattr(our_deskew, "deskew_with_matrix", spy)
     raw_shape = (48, 12, 20)
     pre = ref_pp.build_preprocessor(raw_shape, ["deskew"], deskew=dict(DESKEW), output_channel="BF")
     expect_shape, _ = our_deskew.get_deskewed_data_shape(raw_shape, 30.0, 0.755, False, 3)
