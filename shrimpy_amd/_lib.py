@@ -19,7 +19,9 @@ import threading
 from pathlib import Path
 
 CSRC_DIR = Path(__file__).resolve().parent / "csrc"
-LIB_PATH = CSRC_DIR / "liblsrecon.so"
+# LSR_LIBRARY: another build of the same library (a sanitizer build of the host code, a probe build) -- measurement
+# and debugging only; the product loads the in-tree one
+LIB_PATH = Path(os.environ["LSR_LIBRARY"]) if os.environ.get("LSR_LIBRARY") else CSRC_DIR / "liblsrecon.so"
 HEADER_PATH = Path(__file__).resolve().parent.parent / "include" / "lsrecon.h"
 
 # include/lsrecon.h constants
