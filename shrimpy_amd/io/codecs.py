@@ -436,16 +436,23 @@ def _decode_stream(comp: str, data, nbytes: int) -> bytes:
 
 
 def _stream_into(comp: str, src: np.ndarray, dst: np.ndarray) -> None:
-    """One blosc stream (``src``: its cbytes) into ``dst`` (its decoded bytes)."""
+    """One blosc stream (``src``: its cbytes) into ``dst`` (its decoded bytes).  Whatever a decoder raises on a
+    damaged stream (``zlib.error``, a provider's own exception type) leaves here as ``ValueError``."""
     if src.size == dst.size:                        # stored
         dst[:] = src
-    elif comp == "zstd":
-        zstd_decompress_into(src, dst)
-    else:
+        return
+    try:
+        if comp == "zstd":
+            zstd_decompress_into(src, dst)
+            return
         raw = _decode_stream(comp, memoryview(src), dst.size)
-        if len(raw) != dst.size:
-            raise ValueError("corrupt blosc frame: block size mismatch")
-        dst[:] = np.frombuffer(raw, dtype=np.uint8)
+    except (ValueError, CodecUnavailable, MemoryError):
+        raise
+    except Exception as exc:  # noqa: BLE001 -- decoder-specific error types of four possible providers
+        raise ValueError(f"corrupt blosc frame: the {comp} stream does not decode ({type(exc).__name__}: {exc})") from exc
+    if len(raw) != dst.size:
+        raise ValueError("corrupt blosc frame: block size mismatch")
+    dst[:] = np.frombuffer(raw, dtype=np.uint8)
 
 
 def _py_blosc_decode(frame, out: np.ndarray) -> None:

@@ -452,3 +452,23 @@ def test_a_chunk_whose_crc32c_suffix_does_not_match_is_refused(tmp_path):
         codec.decode(bytes(raw), block.shape, block.dtype)
     with pytest.raises(ValueError, match="shorter"):
         codec.decode(b"ab", block.shape, block.dtype)
+
+
+def test_a_damaged_stream_is_a_value_error_whichever_decoder_meets_it():
+    """A flipped byte inside a zlib / zstd stream: the decoders' own exception types (``zlib.error``, a provider's)
+    leave the frame walkers as ``ValueError`` (found by ``tools/fuzz_blosc.py``)."""
+    from shrimpy_amd.io import codecs
+
+    data = np.random.default_rng(2).integers(0, 4, 30000, dtype=np.uint8)
+    for cname in ("zlib", "zstd"):
+        frame = bytearray(codecs.blosc_encode(data, 2, cname=cname, clevel=3, shuffle=1, blocksize=4096, backend="python"))
+        np.testing.assert_array_equal(codecs.blosc_decode(bytes(frame), backend="python"), data)
+        refused = 0
+        for pos in range(len(frame) - 40, len(frame) - 4, 3):        # inside the last block's stream
+            bad = bytearray(frame)
+            bad[pos] ^= 0x5A
+            try:
+                codecs.blosc_decode(bytes(bad), backend="python")
+            except ValueError:
+                refused += 1
+        assert refused > 0
