@@ -236,6 +236,7 @@ extern "C" int lsr_affine_path(int64_t Zi, int64_t Yi, int64_t Xi, const double 
   if (border != LSR_MODE_CONSTANT && border != LSR_MODE_GRID_CONSTANT) return 0;
   int a, b, c;
   int64_t lds;
+  if (!lsr::volume_in_range(Zi, Yi, Xi)) return 0;
   if (lsr::affine_planar_geometry(Yi, Xi, Xi, M, &a, &b, &c, &lds)) return 1;
   if (lsr::affine_box_geometry(Zi, Yi, Xi, Xi, Yi * Xi, M, &a, &b, &c, &lds)) return 2;
   return 0;
@@ -249,6 +250,7 @@ extern "C" int lsr_affine_path_pitched(int64_t Zi, int64_t Yi, int64_t Xi, int64
   if (border != LSR_MODE_CONSTANT && border != LSR_MODE_GRID_CONSTANT) return 0;
   int a, b, c;
   int64_t lds;
+  if (!lsr::volume_in_range(Zi, Yi, Xi) || !lsr::strides_in_range(in_pitch, in_plane)) return 0;
   if (in_plane % 4 == 0 && lsr::affine_planar_geometry(Yi, Xi, in_pitch, M, &a, &b, &c, &lds)) return 1;
   if (lsr::affine_box_geometry(Zi, Yi, Xi, in_pitch, in_plane, M, &a, &b, &c, &lds)) return 2;
   return 0;
@@ -268,6 +270,11 @@ int affine_impl(const char* what, const float* in, int64_t Zi, int64_t Yi, int64
 extern "C" int lsr_affine_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out,
                               int64_t Zo, int64_t Yo, int64_t Xo, const double M[12], float cval,
                               int mode, lsr_stream_t stream) {
+  LSR_REQUIRE(Zi > 0 && Yi > 0 && Xi > 0 && Zo > 0 && Yo > 0 && Xo > 0, LSR_E_SHAPE,
+              "shapes (%lld,%lld,%lld) -> (%lld,%lld,%lld) must be positive", (long long)Zi, (long long)Yi, (long long)Xi,
+              (long long)Zo, (long long)Yo, (long long)Xo);
+  LSR_REQUIRE_VOLUME(Zi, Yi, Xi);
+  LSR_REQUIRE_VOLUME(Zo, Yo, Xo);
   return affine_impl("lsr_affine_f32", in, Zi, Yi, Xi, Xi, Yi * Xi, out, Zo, Yo, Xo, Xo, Yo * Xo, M, cval, mode, stream);
 }
 
@@ -275,6 +282,10 @@ extern "C" int lsr_affine_pitched_f32(const float* in, int64_t Zi, int64_t Yi, i
                                       int64_t in_plane, float* out, int64_t Zo, int64_t Yo, int64_t Xo,
                                       int64_t out_pitch, int64_t out_plane, const double M[12], float cval, int mode,
                                       lsr_stream_t stream) {
+  LSR_REQUIRE_VOLUME(Zi, Yi, Xi);
+  LSR_REQUIRE_VOLUME(Zo, Yo, Xo);
+  LSR_REQUIRE_STRIDES(in_pitch, in_plane);
+  LSR_REQUIRE_STRIDES(out_pitch, out_plane);
   LSR_REQUIRE(in_pitch >= Xi && in_plane >= Yi * in_pitch, LSR_E_SHAPE,
               "source strides (%lld, %lld) are smaller than a (%lld x %lld) plane", (long long)in_pitch,
               (long long)in_plane, (long long)Yi, (long long)Xi);
@@ -295,9 +306,11 @@ int affine_impl(const char* what, const float* in, int64_t Zi, int64_t Yi, int64
   LSR_REQUIRE(Zi > 0 && Yi > 0 && Xi > 0, LSR_E_SHAPE,
               "input shape (%lld,%lld,%lld) must be positive", (long long)Zi, (long long)Yi,
               (long long)Xi);
+  LSR_REQUIRE_VOLUME(Zi, Yi, Xi);
   LSR_REQUIRE(Zo > 0 && Yo > 0 && Xo > 0, LSR_E_SHAPE,
               "output shape (%lld,%lld,%lld) must be positive", (long long)Zo, (long long)Yo,
               (long long)Xo);
+  LSR_REQUIRE_VOLUME(Zo, Yo, Xo);
   const int64_t lim = int64_t(1) << 30;
   LSR_REQUIRE(Zi < lim && Yi < lim && Xi < lim && Zo < lim && Yo < lim && Xo < lim,
               LSR_E_UNSUPPORTED, "a dimension exceeds 2^30");

@@ -416,6 +416,7 @@ bool box_of(const double M[12], int tz, int ty, int tx, BoxShape* s) {
 
 // Block shape and box of the box path for this matrix and moving volume; false = not applicable.
 bool pick_shape(int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, const double M[12], BoxShape* best) {
+  if (!lsr::volume_in_range(Zi, Yi, Xi) || !lsr::strides_in_range(pitch, plane)) return false;
   // rows start on 16-byte boundaries (LDS-DMA moves 16-byte chunks) and hold whole chunks up to the last column
   if (pitch % 4 != 0 || plane % 4 != 0 || pitch < ((Xi + 3) & ~int64_t(3)) || Xi < 8 || Yi < 2 || Zi < 2) return false;
   if (plane >= (int64_t(1) << 32)) return false;
@@ -479,6 +480,7 @@ bool affine_box_geometry(int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int6
 
 bool affine_box_shape(int64_t Zi, int64_t Yi, int64_t Xi, const double M[12], int out6[6]) {
   BoxShape s;
+  if (!volume_in_range(Zi, Yi, Xi)) return false;
   if (!pick_shape(Zi, Yi, Xi, Xi, Yi * Xi, M, &s)) return false;
   out6[0] = s.tz; out6[1] = s.ty; out6[2] = s.tx; out6[3] = s.bz; out6[4] = s.by; out6[5] = s.bx;
   return true;

@@ -363,6 +363,7 @@ namespace lsr {
 // Geometry of the planar path for this matrix and moving volume; false = not applicable.
 bool affine_planar_geometry(int64_t Yi, int64_t Xi, int64_t pitch, const double M[12], int* box_y_out, int* box_x_out,
                             int* slots_out, int64_t* lds_bytes_out) {
+  if (!volume_in_range(1, Yi, Xi) || !strides_in_range(pitch, 0)) return false;
   if (M[1] != 0.0 || M[2] != 0.0 || M[4] != 0.0 || M[8] != 0.0) return false;
   const double a = M[0] < 0 ? -M[0] : M[0];
   // rows start on 16-byte boundaries (LDS-DMA moves 16-byte chunks) and hold whole chunks up to the last column

@@ -58,6 +58,20 @@ constexpr int kWave = 64;  // CDNA4 wavefront
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// What this library talks about: extents in [1, 2^30) and fewer than 2^48 voxels per volume, element counts below 2^48,
+// row strides below 2^31 and plane strides below 2^32 elements -- so that every product of extents, strides and small
+// factors in the host-side planning (tile counts, byte sizes, workgroup grids) stays far inside int64.  An entry point
+// checks its arguments against these before it computes anything with them (tools/fuzz_device_args.py under UBSan).
+constexpr int64_t kMaxExtent = int64_t(1) << 30;
+constexpr int64_t kMaxVoxels = int64_t(1) << 48;
+inline bool volume_in_range(int64_t Z, int64_t Y, int64_t X) {
+  if (Z <= 0 || Y <= 0 || X <= 0 || Z >= kMaxExtent || Y >= kMaxExtent || X >= kMaxExtent) return false;
+  return Z * Y <= kMaxVoxels / X;
+}
+inline bool strides_in_range(int64_t pitch, int64_t plane) {
+  return pitch >= 0 && pitch < (int64_t(1) << 31) && plane >= 0 && plane < (int64_t(1) << 32);
+}
+
 }  // namespace lsr
 
 #define LSR_REQUIRE_PTR(p)                                                  \
@@ -69,6 +83,17 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
   do {                                                     \
     if (!(cond)) return lsr::fail((code), __VA_ARGS__);    \
   } while (0)
+
+#define LSR_REQUIRE_VOLUME(Z, Y, X)                                                                                   \
+  LSR_REQUIRE(lsr::volume_in_range((Z), (Y), (X)), LSR_E_UNSUPPORTED,                                                 \
+              "shape (%lld,%lld,%lld): every extent must be below 2^30 and the volume below 2^48 voxels", (long long)(Z), \
+              (long long)(Y), (long long)(X))
+#define LSR_REQUIRE_COUNT(n) \
+  LSR_REQUIRE((n) < lsr::kMaxVoxels, LSR_E_UNSUPPORTED, "%lld elements: the limit is 2^48", (long long)(n))
+#define LSR_REQUIRE_STRIDES(pitch, plane)                                                                      \
+  LSR_REQUIRE(lsr::strides_in_range((pitch), (plane)), LSR_E_UNSUPPORTED,                                      \
+              "strides (%lld, %lld): a row stride must be in [0, 2^31), a plane stride in [0, 2^32) elements", \
+              (long long)(pitch), (long long)(plane))
 
 // ---- device-side exact fp64 helpers (no FMA contraction: results must match scipy's C) ----
 #if defined(__HIPCC__)

@@ -235,6 +235,7 @@ int check_common(const float* in, float* out, const float* aux, int64_t Z, int64
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
               (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   LSR_REQUIRE(pz >= 1 && py >= 1 && px >= 1 && (pz & 1) && (py & 1) && (px & 1) &&
                   pz <= kMaxTaps && py <= kMaxTaps && px <= kMaxTaps,
               LSR_E_UNSUPPORTED, "PSF taps (%d,%d,%d) must be odd and <= %d per axis", pz, py, px,
@@ -312,6 +313,7 @@ extern "C" int lsr_sep_padded_shape(int64_t Y, int64_t X, int pz, int py, int px
   LSR_REQUIRE_PTR(shape);
   LSR_REQUIRE(Y > 0 && X > 0, LSR_E_SHAPE, "plane (%lld,%lld) must be positive", (long long)Y,
               (long long)X);
+  LSR_REQUIRE_VOLUME(1, Y, X);
   if (int rc = check_taps(pz, py, px)) return rc;
   int PZ, PYX;
   sep_compiled_taps(pz, py, px, &PZ, &PYX);
@@ -347,6 +349,7 @@ extern "C" int lsr_correlate_sep_strided_f32(
   LSR_REQUIRE_PTR(wx);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
               (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   if (int rc = check_taps(pz, py, px)) return rc;
   LSR_REQUIRE(epilogue == LSR_EPI_NONE || epilogue == LSR_EPI_RATIO || epilogue == LSR_EPI_UPDATE,
               LSR_E_ARG, "unknown epilogue %d", epilogue);
@@ -361,6 +364,7 @@ extern "C" int lsr_correlate_sep_strided_f32(
   sep_compiled_taps(pz, py, px, &PZ, &PYX);
   int64_t need[4];
   lsr_sep_padded_shape(Y, X, pz, py, px, need);
+  LSR_REQUIRE_STRIDES(in_pitch, in_plane);
   LSR_REQUIRE(in_pitch >= need[1] && in_plane >= need[0] * in_pitch, LSR_E_SHAPE,
               "in strides (%lld,%lld) are smaller than the padded shape (%lld rows x %lld) that "
               "lsr_sep_padded_shape asks for",
@@ -557,6 +561,7 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
   LSR_REQUIRE_PTR(nz); LSR_REQUIRE_PTR(ny); LSR_REQUIRE_PTR(nx);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
               (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   LSR_REQUIRE(iters >= 1, LSR_E_ARG, "iters %d must be >= 1", iters);
   LSR_REQUIRE(x_a != x_b, LSR_E_ARG, "x_a and x_b must be distinct");
   if (int rc = check_taps(pz, py, px)) return rc;
@@ -570,6 +575,7 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
   if (int rc = lsr_sep_padded_shape(Y, X, pz, py, px, ps)) return rc;
   const int64_t pitch = ps[1], plane = ps[0] * ps[1];
   const int64_t origin = ps[2] * pitch + ps[3];
+  LSR_REQUIRE_STRIDES(y_pitch, y_plane);
   LSR_REQUIRE(y_pitch >= pitch && y_plane >= ps[0] * y_pitch, LSR_E_SHAPE,
               "y strides (%lld,%lld) are smaller than the padded shape (%lld rows x %lld) that "
               "lsr_sep_padded_shape asks for: y must be a zero-haloed padded volume",
@@ -674,6 +680,7 @@ extern "C" int lsr_rl_ysep_fused_f32(const float* y, int64_t y_pitch, int64_t y_
   LSR_REQUIRE_PTR(norm_table);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
               (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   LSR_REQUIRE(iters >= 1, LSR_E_ARG, "iters %d must be >= 1", iters);
   LSR_REQUIRE(x_a != x_b, LSR_E_ARG, "x_a and x_b must be distinct");
   if (int rc = check_taps(pz, py, px)) return rc;
@@ -685,6 +692,7 @@ extern "C" int lsr_rl_ysep_fused_f32(const float* y, int64_t y_pitch, int64_t y_
   if (int rc = lsr_sep_padded_shape(Y, X, pz, py, px, ps)) return rc;
   const int64_t pitch = ps[1], plane = ps[0] * ps[1];
   const int64_t origin = ps[2] * pitch + ps[3];
+  LSR_REQUIRE_STRIDES(y_pitch, y_plane);
   LSR_REQUIRE(y_pitch >= pitch && y_plane >= ps[0] * y_pitch, LSR_E_SHAPE,
               "y strides (%lld,%lld) are smaller than the padded shape (%lld rows x %lld) that lsr_sep_padded_shape asks "
               "for: y must be a zero-haloed padded volume", (long long)y_pitch, (long long)y_plane, (long long)ps[0],
@@ -822,6 +830,7 @@ int dense_padded_launch(const char* what, int mode, const float* ky,
   LSR_REQUIRE_PTR(taps);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
               (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   if (int rc = check_taps(pz, py, px)) return rc;
   int PZ, PYX;
   LSR_REQUIRE(dense_compiled_taps(pz, py, px, &PZ, &PYX), LSR_E_UNSUPPORTED,
@@ -835,6 +844,7 @@ int dense_padded_launch(const char* what, int mode, const float* ky,
   LSR_REQUIRE(in != out, LSR_E_ARG, "out must not alias in");
   int64_t need[4];
   lsr_sep_padded_shape(Y, X, pz, py, px, need);
+  LSR_REQUIRE_STRIDES(in_pitch, in_plane);
   LSR_REQUIRE(in_pitch >= need[1] && in_plane >= need[0] * in_pitch, LSR_E_SHAPE,
               "in strides (%lld,%lld) are smaller than the padded shape (%lld rows x %lld)",
               (long long)in_pitch, (long long)in_plane, (long long)need[0], (long long)need[1]);

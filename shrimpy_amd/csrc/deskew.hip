@@ -218,13 +218,17 @@ int deskew_impl(const char* what, const void* in, bool u16, int64_t Z, int64_t Y
   LSR_REQUIRE_PTR(M);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "raw shape (%lld,%lld,%lld) must be positive",
               (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   LSR_REQUIRE(Zo > 0 && Yo > 0 && Xo > 0 && Zd > 0, LSR_E_SHAPE,
               "output shape (%lld,%lld,%lld) / Zd %lld must be positive", (long long)Zo,
               (long long)Yo, (long long)Xo, (long long)Zd);
+  LSR_REQUIRE_VOLUME(Zo, Yo, Xo);
+  LSR_REQUIRE_VOLUME(Zd, Yo, Xo);
   LSR_REQUIRE(avg_n >= 1 && avg_n <= kMaxAvg, LSR_E_ARG, "avg_n %d outside [1,%d]", avg_n,
               kMaxAvg);
   LSR_REQUIRE(Zo == lsr::ceil_div(Zd, avg_n), LSR_E_SHAPE,
               "Zo %lld != ceil(Zd %lld / avg_n %d)", (long long)Zo, (long long)Zd, avg_n);
+  LSR_REQUIRE_STRIDES(out_pitch, out_plane);
   LSR_REQUIRE(out_pitch >= Xo && out_plane >= Yo * out_pitch, LSR_E_SHAPE,
               "output strides (%lld, %lld) are smaller than the output plane (%lld x %lld)",
               (long long)out_pitch, (long long)out_plane, (long long)Yo, (long long)Xo);
@@ -330,6 +334,8 @@ extern "C" int lsr_average_slices_f32(const float* in, int64_t Zd, int64_t Y, in
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE(Zd > 0 && Y > 0 && X > 0 && Zo > 0, LSR_E_SHAPE, "shape must be positive");
+  LSR_REQUIRE_VOLUME(Zd, Y, X);
+  LSR_REQUIRE_VOLUME(Zo, Y, X);
   LSR_REQUIRE(avg_n >= 1 && avg_n <= kMaxAvg, LSR_E_ARG, "avg_n %d outside [1,%d]", avg_n,
               kMaxAvg);
   LSR_REQUIRE(Zo == lsr::ceil_div(Zd, avg_n), LSR_E_SHAPE, "Zo %lld != ceil(Zd %lld / avg_n %d)",

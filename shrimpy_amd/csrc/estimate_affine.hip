@@ -143,6 +143,7 @@ extern "C" int lsr_affine_normal_equations_f32(const float* moving, int64_t Zi, 
               (long long)Zi, (long long)Yi, (long long)Xi);
   LSR_REQUIRE(Zo > 0 && Yo > 0 && Xo > 0, LSR_E_SHAPE, "target shape (%lld,%lld,%lld) must be positive", (long long)Zo,
               (long long)Yo, (long long)Xo);
+  LSR_REQUIRE_VOLUME(Zo, Yo, Xo);
   const int64_t lim = int64_t(1) << 30;
   LSR_REQUIRE(Zi < lim && Yi < lim && Xi < lim && Zo < lim && Yo < lim && Xo < lim, LSR_E_UNSUPPORTED,
               "a dimension exceeds 2^30");

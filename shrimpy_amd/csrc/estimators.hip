@@ -667,6 +667,7 @@ int check_volume(const float* in, int64_t Z, int64_t Y, int64_t X) {
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
               (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   LSR_REQUIRE(Z < (int64_t(1) << 30) && Y < (int64_t(1) << 30) && X < (int64_t(1) << 30), LSR_E_UNSUPPORTED,
               "a dimension exceeds 2^30");
   return LSR_OK;
@@ -686,6 +687,7 @@ extern "C" int lsr_minmax_f32(const float* in, int64_t n, float* out2, void* scr
   LSR_REQUIRE_PTR(out2);
   LSR_REQUIRE_PTR(scratch);
   LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  LSR_REQUIRE_COUNT(n);
   const int nb = grid_for(n);
   hipStream_t s = lsr::as_stream(stream);
   float* partial = static_cast<float*>(scratch);
@@ -699,6 +701,7 @@ extern "C" int lsr_histogram_f32(const float* in, int64_t n, float vmin, float v
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(counts);
   LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  LSR_REQUIRE_COUNT(n);
   // (one bin may take every sample: 2^32 of them would wrap its counter -- callers add up pieces)
   LSR_REQUIRE(n < (int64_t(1) << 32), LSR_E_UNSUPPORTED, "n = %lld: the bins count in 32 bits, histogram the volume in pieces",
               (long long)n);
@@ -821,6 +824,7 @@ extern "C" int lsr_cross_power_c64(float* a, const float* b, int64_t n, lsr_stre
   LSR_REQUIRE_PTR(a);
   LSR_REQUIRE_PTR(b);
   LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  LSR_REQUIRE_COUNT(n);
   LSR_REQUIRE((reinterpret_cast<uintptr_t>(a) & 7) == 0 && (reinterpret_cast<uintptr_t>(b) & 7) == 0, LSR_E_ARG,
               "complex64 arrays must be 8-byte aligned");
   hipLaunchKernelGGL(cross_power_kernel<false>, dim3(grid_for(n) * 4), dim3(kThreads), 0, lsr::as_stream(stream), a,
@@ -835,6 +839,7 @@ extern "C" int lsr_transpose_last2_c64(const float* src, float* dst, int64_t A, 
   LSR_REQUIRE(src != dst, LSR_E_ARG, "the transpose works out of place");
   LSR_REQUIRE(A > 0 && B > 0 && C > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)A, (long long)B,
               (long long)C);
+  LSR_REQUIRE_VOLUME(A, B, C);
   LSR_REQUIRE((reinterpret_cast<uintptr_t>(src) & 7) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0, LSR_E_ARG,
               "complex64 arrays must be 8-byte aligned");
   TransposeArgs p;
@@ -853,6 +858,7 @@ extern "C" int lsr_cross_power_into_c64(const float* a, float* b, int64_t n, lsr
   LSR_REQUIRE_PTR(a);
   LSR_REQUIRE_PTR(b);
   LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  LSR_REQUIRE_COUNT(n);
   LSR_REQUIRE((reinterpret_cast<uintptr_t>(a) & 7) == 0 && (reinterpret_cast<uintptr_t>(b) & 7) == 0, LSR_E_ARG,
               "complex64 arrays must be 8-byte aligned");
   hipLaunchKernelGGL(cross_power_kernel<true>, dim3(grid_for(n) * 4), dim3(kThreads), 0, lsr::as_stream(stream),

@@ -38,6 +38,7 @@ int check_volume(const float* in, int64_t Z, int64_t Y, int64_t X) {
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
               (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   LSR_REQUIRE(Z < (int64_t(1) << 30) && Y < (int64_t(1) << 30) && X < (int64_t(1) << 30), LSR_E_UNSUPPORTED,
               "a dimension exceeds 2^30");
   return LSR_OK;
@@ -97,6 +98,7 @@ extern "C" int lsr_minmax_f32_cpu(const float* in, int64_t n, float* out2, void*
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(out2);
   LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  LSR_REQUIRE_COUNT(n);
   float part[2 * kMaxWorkers];
   const int used = parallel_ranges_indexed(n, [&](int k, int64_t first, int64_t last) {
     float lo = INFINITY, hi = -INFINITY;
@@ -123,6 +125,7 @@ extern "C" int lsr_histogram_f32_cpu(const float* in, int64_t n, float vmin, flo
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(counts);
   LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  LSR_REQUIRE_COUNT(n);
   LSR_REQUIRE(n < (int64_t(1) << 32), LSR_E_UNSUPPORTED, "n = %lld: the bins count in 32 bits, histogram the volume in pieces",
               (long long)n);
   LSR_REQUIRE(nbins >= 1 && nbins <= kMaxBins, LSR_E_ARG, "nbins %d outside [1, %d]", nbins, kMaxBins);
@@ -233,6 +236,7 @@ int cross_power_cpu(float* a, float* b, int64_t n) {
   LSR_REQUIRE_PTR(a);
   LSR_REQUIRE_PTR(b);
   LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  LSR_REQUIRE_COUNT(n);
   parallel_ranges(n, [&](int64_t first, int64_t last) {
     for (int64_t i = first; i < last; ++i) {
       const float ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];

@@ -291,6 +291,7 @@ int flatfield_pattern(const char* what, const void* in, bool u16, int64_t Z, int
   LSR_REQUIRE_PTR(scratch);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
               (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   LSR_REQUIRE(Z < 65536, LSR_E_UNSUPPORTED, "Z = %lld: the per-pixel histograms count in 16 bits",
               (long long)Z);
   const int64_t plane = Y * X;
@@ -329,6 +330,7 @@ extern "C" int lsr_flatfield_apply_u16(const uint16_t* in, const float* pattern,
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
               (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   const int64_t plane = Y * X, total = Z * plane;
   int64_t blocks = lsr::ceil_div(total, static_cast<int64_t>(256));
   if (blocks > 256 * 64) blocks = 256 * 64;
@@ -346,6 +348,7 @@ extern "C" int lsr_flatfield_apply_f32(const float* in, const float* pattern, co
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive",
               (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   const int64_t plane = Y * X, total = Z * plane;
   int64_t blocks = lsr::ceil_div(total, static_cast<int64_t>(256 * 4));
   if (blocks > 256 * 64) blocks = 256 * 64;

@@ -139,8 +139,11 @@ int deskew_cpu(const T* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t
   if (int rc = check_matrix(M)) return rc;
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "raw shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
               (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   LSR_REQUIRE(Zo > 0 && Yo > 0 && Xo > 0 && Zd > 0, LSR_E_SHAPE, "output shape (%lld,%lld,%lld) / Zd %lld must be positive",
               (long long)Zo, (long long)Yo, (long long)Xo, (long long)Zd);
+  LSR_REQUIRE_VOLUME(Zo, Yo, Xo);
+  LSR_REQUIRE_VOLUME(Zd, Yo, Xo);
   LSR_REQUIRE(avg_n >= 1 && avg_n <= kMaxAvg, LSR_E_ARG, "avg_n %d outside [1,%d]", avg_n, kMaxAvg);
   LSR_REQUIRE(Zo == lsr::ceil_div(Zd, avg_n), LSR_E_SHAPE, "Zo %lld != ceil(Zd %lld / avg_n %d)", (long long)Zo,
               (long long)Zd, avg_n);
@@ -231,6 +234,7 @@ int check_corr(const float* in, float* out, const float* aux, int64_t Z, int64_t
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
               (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   LSR_REQUIRE(pz >= 1 && py >= 1 && px >= 1 && (pz & 1) && (py & 1) && (px & 1) && pz <= kMaxTaps && py <= kMaxTaps &&
                   px <= kMaxTaps,
               LSR_E_UNSUPPORTED, "PSF taps (%d,%d,%d) must be odd and <= %d per axis", pz, py, px, kMaxTaps);
@@ -285,6 +289,8 @@ extern "C" int lsr_affine_f32_cpu(const float* in, int64_t Zi, int64_t Yi, int64
   LSR_REQUIRE_PTR(out);
   if (int rc = check_matrix(M)) return rc;
   LSR_REQUIRE(Zi > 0 && Yi > 0 && Xi > 0 && Zo > 0 && Yo > 0 && Xo > 0, LSR_E_SHAPE, "shapes must be positive");
+  LSR_REQUIRE_VOLUME(Zi, Yi, Xi);
+  LSR_REQUIRE_VOLUME(Zo, Yo, Xo);
   LSR_REQUIRE(mode == LSR_MODE_CONSTANT || mode == LSR_MODE_GRID_CONSTANT, LSR_E_ARG,
               "mode %d: LSR_MODE_CONSTANT or LSR_MODE_GRID_CONSTANT (the f32-interpolation flag has no host twin: "
               "the host arithmetic is always scipy's fp64)", mode);
@@ -307,6 +313,8 @@ extern "C" int lsr_average_slices_f32_cpu(const float* in, int64_t Zd, int64_t Y
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE(Zd > 0 && Y > 0 && X > 0 && Zo > 0, LSR_E_SHAPE, "shape must be positive");
+  LSR_REQUIRE_VOLUME(Zd, Y, X);
+  LSR_REQUIRE_VOLUME(Zo, Y, X);
   LSR_REQUIRE(avg_n >= 1 && avg_n <= kMaxAvg, LSR_E_ARG, "avg_n %d outside [1,%d]", avg_n, kMaxAvg);
   LSR_REQUIRE(Zo == lsr::ceil_div(Zd, avg_n), LSR_E_SHAPE, "Zo %lld != ceil(Zd %lld / avg_n %d)", (long long)Zo,
               (long long)Zd, avg_n);
@@ -497,6 +505,7 @@ int flat_pattern_cpu(const T* in, int64_t Z, int64_t Y, int64_t X, float* patter
   LSR_REQUIRE_PTR(mean_out);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
               (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   LSR_REQUIRE(Z < 65536, LSR_E_UNSUPPORTED, "Z = %lld: the median kernel counts in 16 bits", (long long)Z);
   const int64_t plane = Y * X;
   std::atomic<bool> failed{false};
@@ -539,6 +548,7 @@ int flat_apply_cpu(const T* in, const float* pattern, const float* mean, float* 
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
               (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   const int64_t plane = Y * X;
   const float m = mean[0];
   parallel_ranges(Z, [&](int64_t z_first, int64_t z_last) {

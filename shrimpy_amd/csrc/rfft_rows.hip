@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void rows_peak_final_kernel(const float* __res
 int fill(RowsArgs& p, int64_t Z, int64_t Y, int64_t X, const float* tw_half, const float* tw_x) {
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "grid (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
               (long long)X);
+  LSR_REQUIRE_VOLUME(Z, Y, X);
   LSR_REQUIRE(lsr_rfft_rows_supported(X), LSR_E_UNSUPPORTED,
               "row length %lld: a multiple of 4 whose half is 5-smooth and at most %d", (long long)X, kMaxM);
   LSR_REQUIRE_PTR(tw_half);
@@ -257,6 +258,7 @@ extern "C" int lsr_rfft_rows_supported(int64_t n) {
 }
 
 extern "C" int64_t lsr_rfft_rows_scratch_bytes(int64_t Z, int64_t Y) {
+  if (!lsr::volume_in_range(Z, Y, 1)) return -1;
   return Z * lsr::ceil_div(Y, kRows) * 16;   // one (value, index) candidate per workgroup of lsr_irfft_rows_peak
 }
 
@@ -266,6 +268,7 @@ extern "C" int lsr_rfft_rows_t_c64(const float* in, int64_t Zi, int64_t Yi, int6
   LSR_REQUIRE_PTR(spec);
   LSR_REQUIRE(Zi > 0 && Yi > 0 && Xi > 0, LSR_E_SHAPE, "source shape (%lld,%lld,%lld) must be positive", (long long)Zi,
               (long long)Yi, (long long)Xi);
+  LSR_REQUIRE_VOLUME(Zi, Yi, Xi);
   const int64_t lim = int64_t(1) << 30;
   LSR_REQUIRE(Zi < lim && Yi < lim && Xi < lim, LSR_E_UNSUPPORTED, "a dimension exceeds 2^30");
   // F.pad "reflect" needs pad < size on every padded axis (torch raises otherwise)

@@ -100,6 +100,7 @@ extern "C" int lsr_cross_correlate_z_c64(const float* f1, float* g, const float*
   LSR_REQUIRE_PTR(twiddles);
   LSR_REQUIRE(N > 0 && Y > 0 && XC > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)N, (long long)Y,
               (long long)XC);
+  LSR_REQUIRE_VOLUME(N, Y, XC);
   LSR_REQUIRE(lsr_cross_correlate_z_supported(N), LSR_E_UNSUPPORTED,
               "z length %lld: this kernel transforms 5-smooth lengths from 2 to %d", (long long)N, kMaxN);
   LSR_REQUIRE((reinterpret_cast<uintptr_t>(f1) & 7) == 0 && (reinterpret_cast<uintptr_t>(g) & 7) == 0 &&

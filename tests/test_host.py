@@ -479,3 +479,38 @@ def test_limit_shifts_cases_of_the_reference():
              ([5.0, 0.01, 2.0], {"z": (0.1, 10.0)}, [5.0, 0.01, 2.0])]
     for shifts, limits, want in cases:
         np.testing.assert_array_equal(_limit_shifts_zyx(np.array(shifts), limits), want)
+
+
+def test_absurd_sizes_are_refused_before_anything_is_computed_with_them():
+    """Extents of 2**30 and more, volumes of 2**48 voxels and more, strides past 2**31 / 2**32: LSR_E_UNSUPPORTED from
+    every entry, device or host -- the planning arithmetic behind the checks never sees them (found by
+    ``tools/fuzz_device_args.py`` under UBSan: signed overflows and a division by zero in tile planning)."""
+    import ctypes
+
+    from shrimpy_amd import _lib
+
+    lib = _lib.load()
+    buf = np.zeros(4096, np.float32)
+    p, f = buf.ctypes.data, ctypes.c_float
+    m = _lib.matrix12(np.eye(3, 4))
+    big, huge = 1 << 30, 1 << 62
+    cases = [
+        ("lsr_flatfield_apply_f32", (p, p, p, p, huge, 4, 4, None)),
+        ("lsr_flatfield_pattern_f32", (p, 8, big, big, p, p, p, None)),
+        ("lsr_deskew_f32", (p, 1 << 20, 1 << 20, 1 << 20, p, 4, 4, 4, 4, 16, 4, m, 1, None)),
+        ("lsr_deskew_f32", (p, 8, 8, 8, p, 4, 4, 4, 1 << 40, 1 << 50, 4, m, 1, None)),
+        ("lsr_affine_f32", (p, big, 4, 4, p, 4, 4, 4, m, f(0.0), 0, None)),
+        ("lsr_affine_pitched_f32", (p, 8, 8, 8, 1 << 31, 1 << 40, p, 8, 8, 8, 8, 64, m, f(0.0), 0, None)),
+        ("lsr_correlate_sep_f32", (p, p + 64, None, huge, huge, 4, p, 3, p, 3, p, 3, 0, f(1e-6), None, None, None, None)),
+        ("lsr_minmax_f32", (p, 1 << 50, p, p, None)),
+        ("lsr_match_shape_f32", (p, 4, 4, 4, p + 64, big, 4, 4, None)),
+        ("lsr_deskew_f32_cpu", (p, 1 << 20, 1 << 20, 1 << 20, p, 4, 4, 4, 4, 16, 4, m, 1, None)),
+        ("lsr_correlate_sep_f32_cpu", (p, p + 64, None, huge, 4, 4, p, 3, p, 3, p, 3, 0, f(1e-6), None, None, None, None)),
+        ("lsr_blur_reflect_f32_cpu", (p, p + 64, big, 4, 4, 0, p, 1, f(0.0), f(0.0), None)),
+    ]
+    for name, args in cases:
+        rc = getattr(lib, name)(*args)
+        assert rc == _lib.E_UNSUPPORTED, (name, rc, lib.lsr_last_error())
+    assert lib.lsr_affine_path(huge, huge, huge, m, 0) == 0
+    lib.lsr_rfft_rows_scratch_bytes.restype = ctypes.c_int64
+    assert lib.lsr_rfft_rows_scratch_bytes(ctypes.c_int64(huge), ctypes.c_int64(huge)) == -1
