@@ -26,6 +26,10 @@
  * Return value: 0 = ok; < 0 = argument error (LSR_E_*), nothing was launched;
  * > 0 = a hipError_t from the launch. lsr_last_error() returns a thread-local message.
  * Nothing here synchronises the stream or the device.
+ *
+ * Sizes: every extent in [1, 2^30), fewer than 2^48 voxels per volume, row strides below 2^31 and plane strides
+ * below 2^32 elements -- anything else is LSR_E_UNSUPPORTED before the entry computes with it.  Inside those bounds
+ * volumes of more than 2^32 voxels are ordinary (64-bit bases per plane / row); narrower limits are stated at the entries.
  */
 #ifndef LSRECON_H
 #define LSRECON_H
