@@ -96,6 +96,9 @@ def _distributed():
             # and the timing reduction instead -- the data path has no collective either way.
             backend = os.environ.get("LSR_DIST_BACKEND") or ("nccl" if local_world <= n_dev else "gloo")
             if backend == "nccl":
+                # (the pool's host driver supports dmabuf IPC only: without this RCCL's buffer exchange between the
+                # ranks of a node fails with hipIpcGetMemHandle: invalid argument)
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
                 dist.init_process_group("nccl", device_id=device)
             else:
                 dist.init_process_group(backend)
