@@ -34,6 +34,10 @@ from .settings import (
 )
 
 logger = logging.getLogger("shrimpy_amd")
+# RCCL between the ranks of a node needs dmabuf IPC on hosts whose driver supports nothing else (otherwise
+# hipIpcGetMemHandle: invalid argument).  The HSA runtime reads this when the first HIP call initialises it, i.e. before
+# anything below can run -- so it is set when the CLI module is imported, and only if the caller has not decided.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 CONTEXT = {"help_option_names": ["-h", "--help"]}
 
 
@@ -96,9 +100,6 @@ def _distributed():
             # and the timing reduction instead -- the data path has no collective either way.
             backend = os.environ.get("LSR_DIST_BACKEND") or ("nccl" if local_world <= n_dev else "gloo")
             if backend == "nccl":
-                # (the pool's host driver supports dmabuf IPC only: without this RCCL's buffer exchange between the
-                # ranks of a node fails with hipIpcGetMemHandle: invalid argument)
-                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
                 dist.init_process_group("nccl", device_id=device)
             else:
                 dist.init_process_group(backend)
