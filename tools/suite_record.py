@@ -29,6 +29,12 @@ def main():
     suite = [ln for ln in (d / "final_suite.log").read_text().splitlines()
              if "lsr-test" not in ln and ln.strip() and not ln.strip().startswith(".")]
     smoke = (d / "final_smoke.log").read_text().strip()
+    # the node ids as the run itself printed them (tests/conftest.py writes them to the real stderr, which the
+    # command redirected into the same log)
+    import re
+
+    trace = "\n".join(m for ln in (d / "final_suite.log").read_text().splitlines()
+                      for m in re.findall(r"\[lsr-test[^\]]*\] (?:start|done|session finished)[^\[]*", ln))
     stamp = json.loads((ROOT / "profiles" / "traffic.json").read_text())["fused"].get("source_sha16")
     earlier = []
     for f in sorted(glob.glob(str(d / "suite*.log")), key=lambda p: Path(p).stat().st_mtime):
@@ -51,7 +57,7 @@ kernel_source_sha16 printed by the run: see the smoke section; stamp of profiles
  before the staging slots moved from hipHostRegister to hipHostMalloc; every run after that change is green)
 
 ---- every test with its start / finish time (tests/conftest.py, LSR_TEST_TRACE)
-{(d / 'final_trace.txt').read_text()}"""
+{trace}"""
     out = ROOT / "profiles" / f"{args.tag}_gpu_suite.txt"
     out.write_text(text)
     print(out, "tree", tree, "stamp", stamp, "|", suite[-2] if len(suite) > 1 else suite)
