@@ -176,9 +176,13 @@ def cpu_baseline(config_id=2, all_core_shape=(640, 128, 640), single_shape=(512,
         "value": voxels / busy,
         "unit": "voxels/s",
         "cores": procs,
+        "host_cores": cores,
+        # fewer workers than cores (the 64-worker memory cap, or --cpu-procs): the aggregate is then a LOWER bound of
+        # what the whole host would do, and any GPU/CPU ratio taken from it an upper bound
+        "capped": procs < cores,
         "kind": "port",
         "sample": (f"{procs} independent raw {shp} f32 bead-scene positions (seeds 1000*{config_id}+7*p), one per "
-                   f"process on every host core (scipy.ndimage affine_transform deskew avg3 + {RL_ITERS}-iter RL "
+                   f"process on {procs} of {cores} host cores (scipy.ndimage affine_transform deskew avg3 + {RL_ITERS}-iter RL "
                    f"as separable correlate1d passes), slowest worker {busy:.1f}s, pool wall {wall:.1f}s"),
         "single_core": {
             "value": n_single / s_med,
@@ -214,6 +218,15 @@ def pmc_traffic(key, workload, kernel_symbol):
     if kernel_symbol and kernel_symbol not in (rec.get("kernel") or ""):
         return None, f"record is for kernel {rec.get('kernel')!r}"
     return rec.get("hbm_bytes_per_launch"), f"{rec.get('source')} @ {rec.get('git_head', '?')}"
+
+
+def library_stamp() -> dict:
+    """Which binary produced the numbers: the stamp compiled into the loaded liblsrecon.so (``lsr_source_sha16``) and
+    the fingerprint of the sources beside it -- equal, or ``_lib.load()`` would have refused the library."""
+    from shrimpy_amd import _lib
+
+    return {"path": str(_lib.LIB_PATH.relative_to(ROOT)) if _lib.LIB_PATH.is_relative_to(ROOT) else str(_lib.LIB_PATH),
+            "source_sha16": _lib.library_source_sha16(), "checkout_sha16": _lib.kernel_source_sha16()}
 
 
 def device_state(device) -> dict:
@@ -490,6 +503,7 @@ def run_resident(args, rank, world, device, shared, backend, cpu):
             "parallelism": parallelism_note(world, shared),
             "collective_backend": backend,
             "device_after_timed_steps": state_after,
+            "library": library_stamp(),
         },
         "roofline": roofline,
     }
@@ -639,6 +653,7 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
             "store_to_store": store,
             "parallelism": parallelism_note(world, shared),
             "collective_backend": backend,
+            "library": library_stamp(),
         },
         "roofline": {
             "kernel": "rl_fused_sep_kernel<9,7> (one RL iteration per launch)", "bound": "hbm",
@@ -684,7 +699,7 @@ def run_config1_cpu(args):
         "config": {"workload": (f"config1: raw (Z_scan,Y_tilt,X)={raw_shape} f32 -> deskew 30deg r=0.755 no-overhang avg3 -> "
                                 f"{tuple(out.shape)}, deskew only, no GPU: the product's host twin on a CPU tensor"),
                    "raw_shape": list(raw_shape), "deskewed_shape": list(out.shape), "host_threads": threads,
-                   "equals_oracle_bit_for_bit": bool(np.array_equal(out.numpy(), want))},
+                   "equals_oracle_bit_for_bit": bool(np.array_equal(out.numpy(), want)), "library": library_stamp()},
         "roofline": None,
         "cpu_baseline": {"value": n_in / oracle_s, "unit": "voxels/s", "cores": 1, "kind": "port",
                          "sample": f"the same stack through oracle/cpu_ref.py (scipy.ndimage.affine_transform + slice mean), once: {oracle_s:.2f}s"},

@@ -66,6 +66,11 @@ typedef void* lsr_stream_t; /* a hipStream_t; NULL = the default stream */
 
 int lsr_version(void);
 const char* lsr_last_error(void);
+/* Fingerprint of the sources this BINARY was compiled from: the first 16 hex digits of the sha256 over (name, bytes) of
+ * include/lsrecon.h, csrc/Makefile and every csrc/*.hip / *.hpp (csrc/Makefile computes it, api.o is rebuilt whenever
+ * one of them changes).  The library is git-ignored and travels to the GPU box as a file: the Python host compares this
+ * with the same hash of the checkout beside it (shrimpy_amd/_lib.py::kernel_source_sha16) and refuses a stale build. */
+const char* lsr_source_sha16(void);
 /* Page-locked host memory of exactly `bytes` bytes from the HIP runtime (hipHostMalloc, portable across
  * devices): the staging slots of the store-to-store path.  Returns 0 or the hipError_t (then *out = NULL). */
 int lsr_pinned_alloc(int64_t bytes, void** out);
@@ -184,6 +189,11 @@ int lsr_affine_normal_equations_f32(const float* moving, int64_t Zi, int64_t Yi,
  */
 int lsr_blosc_host_codec(int compressor); /* 1 when the decoder of blosc compressor code 1 (lz4) / 3 (zlib) / 4 (zstd) is loadable */
 int lsr_blosc_decode_host(const uint8_t* frame, int64_t frame_bytes, uint8_t* out, int64_t out_bytes, int* typesize);
+/* CRC-32C (Castagnoli, the Zarr v3 `crc32c` codec: shard index, optionally every chunk) of n host bytes; seed = 0, or
+ * the value of the bytes before `data` when a buffer is checked in pieces.  SSE4.2 crc32 instruction where the CPU has
+ * it, slice-by-8 tables otherwise (lsr_crc32c_host_portable: always the tables -- the cross-check). */
+int lsr_crc32c_host(const uint8_t* data, int64_t n, uint32_t seed, uint32_t* out);
+int lsr_crc32c_host_portable(const uint8_t* data, int64_t n, uint32_t seed, uint32_t* out);
 
 /* out[zo] = mean_k in[min(zo*avg_n + k, Zd-1)], k < avg_n, f32, ((d0+d1)+...)/avg_n. */
 int lsr_average_slices_f32(const float* in, int64_t Zd, int64_t Y, int64_t X, float* out,

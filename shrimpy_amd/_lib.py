@@ -88,6 +88,8 @@ SIGNATURES: dict[str, list] = {
                                         ctypes.c_void_p, _stream],
     "lsr_blosc_host_codec": [_int],
     "lsr_blosc_decode_host": [ctypes.c_void_p, _i64, ctypes.c_void_p, _i64, ctypes.POINTER(ctypes.c_int)],
+    "lsr_crc32c_host": [ctypes.c_void_p, _i64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)],
+    "lsr_crc32c_host_portable": [ctypes.c_void_p, _i64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)],
     "lsr_average_slices_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _int, _stream],
     "lsr_correlate_sep_f32": [
         _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _int, _c_f32p, _int, _c_f32p, _int,
@@ -163,7 +165,9 @@ def kernel_source_sha16() -> str:
     import hashlib
 
     h = hashlib.sha256()
-    files = sorted(list(CSRC_DIR.glob("*.hip")) + list(CSRC_DIR.glob("*.hpp")) + [CSRC_DIR / "Makefile", HEADER_PATH])
+    # (the order csrc/Makefile's STAMP_FILES uses: header, Makefile, then the sources by the bytes of their names)
+    files = [HEADER_PATH, CSRC_DIR / "Makefile"] + sorted(list(CSRC_DIR.glob("*.hip")) + list(CSRC_DIR.glob("*.hpp")),
+                                                          key=lambda f: f.name.encode())
     for f in files:
         h.update(f.name.encode())
         h.update(f.read_bytes())
@@ -232,8 +236,41 @@ def load() -> ctypes.CDLL:
             fn.restype = ctypes.c_int
         lib.lsr_last_error.argtypes = []
         lib.lsr_last_error.restype = ctypes.c_char_p
+        _check_stamp(lib)
         _lib = lib
     return _lib
+
+
+def library_source_sha16(lib: ctypes.CDLL | None = None) -> str:
+    """The stamp compiled into the loaded binary (``lsr_source_sha16``, csrc/Makefile ``SHA16``)."""
+    lib = lib if lib is not None else load()
+    fn = lib.lsr_source_sha16
+    fn.argtypes = []
+    fn.restype = ctypes.c_char_p
+    return fn().decode("ascii", "replace")
+
+
+def _check_stamp(lib: ctypes.CDLL) -> None:
+    """Refuse a binary that was not built from the sources beside it.  ``liblsrecon.so`` is git-ignored and reaches the
+    GPU box as a file, so nothing else ties it to the checkout: an edit without a rebuild, or a probe build left in
+    place, would otherwise be measured and tested under the committed tree's name.  ``LSR_ALLOW_STALE_LIBRARY=1``
+    turns the refusal into a warning (bisecting an old binary against new host code)."""
+    try:
+        have = library_source_sha16(lib)
+    except AttributeError:
+        have = "unstamped"
+    want = kernel_source_sha16()
+    if have == want:
+        return
+    msg = (f"{LIB_PATH} was built from sources {have}, this checkout's are {want} (csrc/*.hip, *.hpp, Makefile, "
+           f"include/lsrecon.h): rebuild it with `make -C {CSRC_DIR}` or "
+           "`python -c 'import __graft_entry__ as g; g.build()'`")
+    if os.environ.get("LSR_ALLOW_STALE_LIBRARY") == "1":
+        import warnings
+
+        warnings.warn("stale liblsrecon.so in use: " + msg, RuntimeWarning, stacklevel=3)
+        return
+    raise LsrError("load", -1, msg)
 
 
 def call(name: str, *args) -> None:

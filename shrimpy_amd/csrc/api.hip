@@ -30,6 +30,12 @@ extern "C" int lsr_version(void) { return LSR_VERSION; }
 
 extern "C" const char* lsr_last_error(void) { return lsr::error_buffer(); }
 
+// The stamp of the sources this binary was built from (csrc/Makefile: SHA16).  A build outside the Makefile has none.
+#ifndef LSR_SOURCE_SHA16
+#define LSR_SOURCE_SHA16 "unstamped"
+#endif
+extern "C" const char* lsr_source_sha16(void) { return LSR_SOURCE_SHA16; }
+
 // Page-locked host memory of exactly `bytes` bytes, allocated by the HIP runtime (hipHostMalloc: memory the
 // driver owns and maps for every device), for the staging slots of shrimpy_amd/staging.py.  Not
 // hipHostRegister on an ordinary allocation: that pins the pages through the kernel's user-pointer path,

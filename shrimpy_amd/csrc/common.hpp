@@ -35,9 +35,11 @@ inline int allow_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t
   const uint64_t bit = dev < 64 ? uint64_t(1) << dev : 0;
   if (bit && (done.load(std::memory_order_acquire) & bit)) return LSR_OK;
   e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess)
+  if (e != hipSuccess) {
+    (void)hipGetLastError();   // not a sticky state: callers fall back to another kernel and then ask launch_status()
     return fail(static_cast<int>(e), "%s: device %d refuses %d bytes of dynamic LDS: %s", what, dev, bytes,
                 hipGetErrorString(e));
+  }
   if (bit) done.fetch_or(bit, std::memory_order_release);
   return LSR_OK;
 }

@@ -299,23 +299,49 @@ def _shard_lock(path: Path):
     """Exclusive access to one shard file for a read-modify-write: a lock per directory for the threads of this
     process, ``flock`` on the shard's DIRECTORY for other processes (ranks) on the same host.  The directory, not a
     ``<shard>.lock`` beside the chunk (nothing but chunk files lives in an array's key space), and not the shard itself (it is
-    replaced by rename: a lock on the old inode would not hold anyone who opens the new one)."""
+    replaced by rename: a lock on the old inode would not hold anyone who opens the new one).
+
+    Scope: one host.  ``flock`` does not reach ranks on other nodes, and some network file systems refuse it on a
+    read-only directory descriptor (EBADF / ENOLCK where flock is emulated by byte-range locks): the in-process lock then
+    still holds, with one warning -- a multi-node run must give every shard that spans several (t, c) volumes to ONE rank
+    (``pipeline.run_sharded`` deals whole volumes; keep ``shards[:2] == (1, 1)``, what the acquisition writes, or shard
+    the units by shard)."""
     import fcntl
 
     folder = path.parent
     key = str(folder)
     with _shard_locks_guard:
+        if len(_shard_locks) > 4096:       # a long plate run visits every array directory once: do not keep them all
+            for k in [k for k, v in _shard_locks.items() if not v.locked()]:
+                del _shard_locks[k]
         lock = _shard_locks.setdefault(key, threading.Lock())
     with lock:
-        fd = os.open(str(folder), os.O_RDONLY)
+        fd = None
         try:
+            fd = os.open(str(folder), os.O_RDONLY)
             fcntl.flock(fd, fcntl.LOCK_EX)
+        except OSError as exc:
+            if fd is not None:
+                os.close(fd)
+                fd = None
+            global _flock_warned
+            if not _flock_warned:
+                _flock_warned = True
+                import warnings
+
+                warnings.warn(f"flock on {folder} failed ({exc}); shards that span several volumes are protected against "
+                              "this process's threads only", RuntimeWarning, stacklevel=3)
+        try:
             yield
         finally:
-            try:
-                fcntl.flock(fd, fcntl.LOCK_UN)
-            finally:
-                os.close(fd)
+            if fd is not None:
+                try:
+                    fcntl.flock(fd, fcntl.LOCK_UN)
+                finally:
+                    os.close(fd)
+
+
+_flock_warned = False
 
 
 class ZarrArray:
@@ -571,11 +597,7 @@ class ZarrArray:
             self._fan_out(one, self._inner_of(lead, fidx), threads)
 
     def _write_shard(self, lead, fidx, vol: np.ndarray, threads: int = 1) -> None:
-        from .codecs import crc32c
-
         k = len(lead)
-        vchunks = self.chunks[k:]
-        counts = self._shard_counts()
         path = self._file_path(tuple(i // s for i, s in zip(lead, self.shards[:k])) + tuple(fidx))
         if any(s > 1 for s in self.shards[:k]):
             # the shard also holds other (t, c) volumes: a read-modify-write, one writer at a time --

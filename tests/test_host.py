@@ -169,7 +169,39 @@ def test_library_exports_every_symbol_the_header_declares():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/lsrecon.h but not exported"
     # and the ctypes table binds exactly the declared compute entry points
-    assert sorted(set(_lib.SIGNATURES) | {"lsr_last_error"}) == declared
+    assert sorted(set(_lib.SIGNATURES) | {"lsr_last_error", "lsr_source_sha16"}) == declared
+
+
+def test_the_binary_carries_the_stamp_of_the_sources_beside_it():
+    assert _lib.library_source_sha16() == _lib.kernel_source_sha16()
+    assert re.fullmatch(r"[0-9a-f]{16}", _lib.library_source_sha16())
+
+
+def test_a_stale_library_is_refused_at_load_time(tmp_path):
+    """the .so travels as a file; a build of OTHER sources must not load silently.  The stale
+    build here is the real library with the stamp bytes of its read-only data changed."""
+    import os
+    import subprocess
+    import sys
+
+    blob = _lib.LIB_PATH.read_bytes()
+    stamp = _lib.kernel_source_sha16().encode()
+    assert blob.count(stamp) == 1, "the stamp string appears once in the binary"
+    stale = tmp_path / "liblsrecon.so"
+    stale.write_bytes(blob.replace(stamp, b"0123456789abcdef"))
+    code = ("from shrimpy_amd import _lib\n"
+            "try:\n    _lib.load()\n    print('LOADED')\n"
+            "except _lib.LsrError as e:\n    print('REFUSED', e)\n")
+    env = dict(os.environ, LSR_LIBRARY=str(stale))
+    env.pop("LSR_ALLOW_STALE_LIBRARY", None)
+    root = str(_lib.HEADER_PATH.parent.parent)
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.stdout.startswith("REFUSED"), out.stdout + out.stderr
+    assert "0123456789abcdef" in out.stdout and stamp.decode() in out.stdout and "rebuild" in out.stdout
+    # the override loads it, loudly
+    out = subprocess.run([sys.executable, "-W", "always", "-c", code], env=dict(env, LSR_ALLOW_STALE_LIBRARY="1"), cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.stdout.startswith("LOADED") and "stale liblsrecon.so" in out.stderr, out.stdout + out.stderr
 
 
 def test_library_loads_and_reports_version_and_arg_errors():

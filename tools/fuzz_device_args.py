@@ -1,6 +1,6 @@
 """Random arguments through every DEVICE entry point of the C ABI on a machine WITHOUT a GPU: whatever the host side does
 with them before a launch -- shape arithmetic, table sizes, tile plans, LDS budgets -- must end in a status code, not in a
-crash or (against a library whose host code is built with ASan + UBSan, see tools/host_sanitize.sh --all) a report:
+crash or (against a library whose host code is built with ASan + UBSan, see tools/host_sanitize.sh [scratch-dir] [fuzz-seconds]) a report:
 no signed overflow, no division by zero, no read past a host table.  Nothing can launch (there is no device; a call that
 passes validation fails in the HIP runtime with a status), so the pointers are host buffers nobody dereferences except
 the documented host-pointer arguments (taps, matrices, shape outputs), which are sized for the documented maxima.
