@@ -67,7 +67,7 @@ typedef void* lsr_stream_t; /* a hipStream_t; NULL = the default stream */
 int lsr_version(void);
 const char* lsr_last_error(void);
 /* Fingerprint of the sources this BINARY was compiled from: the first 16 hex digits of the sha256 over (name, bytes) of
- * include/lsrecon.h, csrc/Makefile and every csrc/*.hip / *.hpp (csrc/Makefile computes it, api.o is rebuilt whenever
+ * include/lsrecon.h, csrc/Makefile and every .hip / .hpp file in csrc (csrc/Makefile computes it, api.o is rebuilt whenever
  * one of them changes).  The library is git-ignored and travels to the GPU box as a file: the Python host compares this
  * with the same hash of the checkout beside it (shrimpy_amd/_lib.py::kernel_source_sha16) and refuses a stale build. */
 const char* lsr_source_sha16(void);
@@ -403,6 +403,75 @@ int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane, in
                             lsr_stream_t stream);
 
 /*
+ * Richardson-Lucy reduction scalars (the north-star's "wavefront reductions for the ratio / normalisation").
+ * Every entry that finishes an RL iteration has a `_stats` form with one more argument, `double* stats` (DEVICE memory;
+ * host memory for the *_cpu twins); NULL = the plain entry, the same kernels, no cost.  Per iteration i three sums over
+ * the voxels of the volume, formed in the epilogue that writes x_{i+1} (no extra pass, no extra HBM byte):
+ *
+ *   stats[3 i + 0]  flux    sum x_i * H^T(ratio_i)  ==  sum x_{i+1} * H^T 1   -- what the multiplicative update
+ *                           conserves: equals sum_v y_v (H x_i)_v / ((H x_i)_v + eps), i.e. sum y as eps -> 0
+ *   stats[3 i + 1]  change  sum |x_{i+1} - x_i|                                -- the update norm
+ *   stats[3 i + 2]  total   sum x_{i+1}
+ *
+ * change / total is the relative change a caller can stop on (the Python host: richardson_lucy(..., tol=)).  Per thread
+ * the sums run in f32 over the voxels it owns, then wavefront reduction (DPP) -> LDS -> one f64 atomic add per workgroup
+ * and sum; the only run-to-run freedom is the order of those f64 adds (~1e-16 relative).
+ *   lsr_rl_*_stats_f32:        stats = 3 * iters doubles, zeroed by the entry on `stream` before the first launch;
+ *   lsr_correlate_*_stats_f32: stats = 3 doubles the launch ADDS to (LSR_EPI_UPDATE only; ignored for other epilogues):
+ *                              the caller zeroes them -- these are the per-launch building blocks of the loops above.
+ * Otherwise arguments, limits and results are exactly those of the entry without `_stats`.
+ */
+int lsr_rl_sep_fused_stats_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
+                               float* x_a, float* x_b, float* x_out, int64_t Z, int64_t Y, int64_t X,
+                               const float* taps, int pz, int py, int px, const float* nz,
+                               const float* ny, const float* nx, int iters, float eps, double* stats,
+                               lsr_stream_t stream);
+int lsr_rl_sep_stats_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
+                         float* x_pad, float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X,
+                         const float* kz, const float* kz_flipped, int pz,
+                         const float* ky, const float* ky_flipped, int py, const float* kx,
+                         const float* kx_flipped, int px, const float* nz, const float* ny,
+                         const float* nx, int iters, float eps, double* stats, lsr_stream_t stream);
+int lsr_rl_ysep_fused_stats_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y, float* x_a,
+                                float* x_b, float* x_out, int64_t Z, int64_t Y, int64_t X, const float* taps,
+                                int pz, int py, int px, const double* norm_table, float norm_full, int iters,
+                                float eps, double* stats, lsr_stream_t stream);
+int lsr_rl_dense_padded_stats_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
+                                  float* x_pad, float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X,
+                                  const float* taps, const float* taps_flipped, int pz, int py, int px,
+                                  const double* norm_table, float norm_full, int iters, float eps, double* stats,
+                                  lsr_stream_t stream);
+int lsr_rl_dense_stats_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X,
+                           const float* psf, const float* psf_flipped, int pz, int py, int px,
+                           const double* norm_table, int iters, float eps, double* stats, lsr_stream_t stream);
+int lsr_correlate_sep_stats_f32(const float* in, float* out, const float* aux, int64_t Z, int64_t Y,
+                                int64_t X, const float* wz, int pz, const float* wy, int py,
+                                const float* wx, int px, int epilogue, float eps, const float* nz,
+                                const float* ny, const float* nx, double* stats, lsr_stream_t stream);
+int lsr_correlate_dense_stats_f32(const float* in, float* out, const float* aux, int64_t Z, int64_t Y,
+                                  int64_t X, const float* w, int pz, int py, int px, int epilogue,
+                                  float eps, const double* norm_table, double* stats, lsr_stream_t stream);
+int lsr_correlate_sep_strided_stats_f32(const float* in, int64_t in_pitch, int64_t in_plane,
+                                        const float* aux, int64_t aux_pitch, int64_t aux_plane,
+                                        float* out, int64_t out_pitch, int64_t out_plane, int64_t Z,
+                                        int64_t Y, int64_t X, const float* wz, int pz, const float* wy,
+                                        int py, const float* wx, int px, int epilogue, float eps,
+                                        const float* nz, const float* ny, const float* nx, double* stats,
+                                        lsr_stream_t stream);
+int lsr_correlate_dense_padded_stats_f32(const float* in, int64_t in_pitch, int64_t in_plane,
+                                         const float* aux, int64_t aux_pitch, int64_t aux_plane,
+                                         float* out, int64_t out_pitch, int64_t out_plane, int64_t Z,
+                                         int64_t Y, int64_t X, const float* taps, int pz, int py, int px,
+                                         int epilogue, float eps, const double* norm_table,
+                                         float norm_full, double* stats, lsr_stream_t stream);
+int lsr_correlate_zxy_padded_stats_f32(const float* in, int64_t in_pitch, int64_t in_plane,
+                                       const float* aux, int64_t aux_pitch, int64_t aux_plane, float* out,
+                                       int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y, int64_t X,
+                                       const float* taps_zx, const float* ky, int pz, int py, int px,
+                                       int epilogue, float eps, const double* norm_table, float norm_full,
+                                       double* stats, lsr_stream_t stream);
+
+/*
  * Reductions and filters behind the DynaTrack shift estimators that run on the deskewed volume
  * (shrimpy/dynatrack/tracking.py). `scratch` = lsr_reduce_scratch_bytes() bytes of
  * device memory; outputs are device arrays; sums are fp64, reduced in a fixed order.
@@ -506,6 +575,18 @@ int lsr_correlate_dense_f32_cpu(const float* in, float* out, const float* aux, i
 int lsr_rl_dense_f32_cpu(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X,
                          const float* psf, const float* psf_flipped, int pz, int py, int px,
                          const double* norm_table, int iters, float eps, lsr_stream_t stream);
+/* ... with the reduction scalars (see lsr_rl_*_stats_f32; `stats` is HOST memory, sums in f64 per row range) */
+int lsr_correlate_sep_stats_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y,
+                                    int64_t X, const float* wz, int pz, const float* wy, int py,
+                                    const float* wx, int px, int epilogue, float eps, const float* nz,
+                                    const float* ny, const float* nx, double* stats, lsr_stream_t stream);
+int lsr_correlate_dense_stats_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y,
+                                      int64_t X, const float* w, int pz, int py, int px, int epilogue,
+                                      float eps, const double* norm_table, double* stats, lsr_stream_t stream);
+int lsr_rl_dense_stats_f32_cpu(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X,
+                               const float* psf, const float* psf_flipped, int pz, int py, int px,
+                               const double* norm_table, int iters, float eps, double* stats,
+                               lsr_stream_t stream);
 int lsr_flatfield_pattern_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t X, float* pattern,
                                   float* mean_out, void* scratch /* unused */, lsr_stream_t stream);
 int lsr_flatfield_pattern_u16_cpu(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* pattern,

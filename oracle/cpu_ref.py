@@ -207,6 +207,26 @@ def richardson_lucy(y, psf, iterations=20, eps=1e-6, x0=None, use_fft=False):
     return x
 
 
+def rl_iteration_scalars(y, psf, iterations=20, eps=1e-6, x0=None):
+    """Per-iteration reduction scalars of :func:`richardson_lucy`, summed in float64 over the float32 estimates:
+    ``flux[i] = sum x_{i+1} * H^T 1`` (conserved by the multiplicative update: ``-> sum y`` as ``eps -> 0``),
+    ``change[i] = sum |x_{i+1} - x_i|``, ``total[i] = sum x_{i+1}``.  The product's kernels sum the same three in their
+    update epilogues (``include/lsrecon.h``: ``lsr_rl_*_stats_f32``; no reference code: the north-star names
+    "wavefront reductions for the ratio / normalisation", ``/root/reference/docs/data_structure.md:58-62``)."""
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    psf = _as_odd_psf(psf)
+    norm = rl_norm(y.shape, psf).astype(np.float64)
+    x = y.copy() if x0 is None else np.ascontiguousarray(x0, dtype=np.float32).copy()
+    out = {k: np.zeros(int(iterations)) for k in ("flux", "change", "total")}
+    for i in range(int(iterations)):
+        x_new = richardson_lucy(y, psf, iterations=1, eps=eps, x0=x)
+        out["flux"][i] = float((x_new.astype(np.float64) * norm).sum())
+        out["change"][i] = float(np.abs(x_new.astype(np.float64) - x.astype(np.float64)).sum())
+        out["total"][i] = float(x_new.astype(np.float64).sum())
+        x = x_new
+    return out
+
+
 def richardson_lucy_separable(y, factors, iterations=20, eps=1e-6, x0=None):
     """The same RL loop for a rank-1 PSF ``kz x ky x kx`` as three ``ndimage.correlate1d``
     passes per correlation -- the fastest scipy.ndimage formulation, used as the CPU baseline

@@ -146,9 +146,15 @@ SIGNATURES: dict[str, list] = {
     "lsr_set_host_threads": [_int],
     "lsr_get_host_threads": [],
 }
+# the `_stats` forms of the Richardson-Lucy entries: one more argument (double* stats) in front of the stream
+for _name in ("lsr_rl_sep_fused_f32", "lsr_rl_sep_f32", "lsr_rl_ysep_fused_f32", "lsr_rl_dense_padded_f32", "lsr_rl_dense_f32",
+              "lsr_correlate_sep_f32", "lsr_correlate_dense_f32", "lsr_correlate_sep_strided_f32",
+              "lsr_correlate_dense_padded_f32", "lsr_correlate_zxy_padded_f32"):
+    SIGNATURES[_name.replace("_f32", "_stats_f32")] = SIGNATURES[_name][:-1] + [ctypes.c_void_p, _stream]
 # host twins (csrc/host_twins.hip): the device entry point's signature, host pointers
 for _name in ("lsr_deskew_f32", "lsr_deskew_u16", "lsr_affine_f32", "lsr_average_slices_f32", "lsr_correlate_sep_f32",
-              "lsr_correlate_dense_f32", "lsr_rl_dense_f32", "lsr_flatfield_pattern_f32", "lsr_flatfield_pattern_u16",
+              "lsr_correlate_dense_f32", "lsr_rl_dense_f32", "lsr_correlate_sep_stats_f32", "lsr_correlate_dense_stats_f32",
+              "lsr_rl_dense_stats_f32", "lsr_flatfield_pattern_f32", "lsr_flatfield_pattern_u16",
               "lsr_flatfield_apply_f32", "lsr_flatfield_apply_u16",
               # ... and of the DynaTrack estimators (csrc/estimators_host.hip)
               "lsr_minmax_f32", "lsr_histogram_f32", "lsr_weighted_centroid_f32", "lsr_mask_centroid_f32",

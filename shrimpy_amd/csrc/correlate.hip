@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kThreads) void correlate_march_kernel(CorrArgs p) {
     for (int a = 0; a < PZ; ++a) wzr[a] = p.wz[a];
   }
 
+  lsr::RlStats st;   // LSR_EPI_UPDATE with p.stats: the launch's reduction scalars (correlate_common.hpp)
   const int64_t zi_begin = max(zb - cz, int64_t(0));
   const int64_t zi_end = ze + cz;  // exclusive
   for (int64_t zi = zi_begin; zi < zi_end; ++zi) {
@@ -190,7 +191,9 @@ __global__ __launch_bounds__(kThreads) void correlate_march_kernel(CorrArgs p) {
               } else {
                 nrm = static_cast<float>(dense_norm(p, z_out, gy, gx));
               }
-              r = p.aux[o] * c / nrm;
+              const float a = p.aux[o], ac = a * c;
+              r = ac / nrm;
+              if (p.stats) st.add(a, ac, r);
             } else {
               r = c;
             }
@@ -199,6 +202,10 @@ __global__ __launch_bounds__(kThreads) void correlate_march_kernel(CorrArgs p) {
         }
       }
     }
+  }
+  if (p.stats) {   // (kernel-uniform)
+    __syncthreads();
+    lsr::rl_stats_flush<kThreads / 64>(st, bufA, p.stats);
   }
 }
 
@@ -261,11 +268,7 @@ int64_t pick_z_chunk(int64_t Z, int64_t tiles_xy, int pz) {
 
 }  // namespace
 
-extern "C" int lsr_correlate_sep_f32(const float* in, float* out, const float* aux, int64_t Z,
-                                     int64_t Y, int64_t X, const float* wz, int pz,
-                                     const float* wy, int py, const float* wx, int px,
-                                     int epilogue, float eps, const float* nz, const float* ny,
-                                     const float* nx, lsr_stream_t stream) {
+extern "C" int lsr_correlate_sep_stats_f32(const float* in, float* out, const float* aux, int64_t Z, int64_t Y, int64_t X, const float* wz, int pz, const float* wy, int py, const float* wx, int px, int epilogue, float eps, const float* nz, const float* ny, const float* nx, double* stats, lsr_stream_t stream) {
   // Dense volumes without a halo: the generic bounds-checked kernel (correct, not tuned).
   if (int rc = check_common(in, out, aux, Z, Y, X, pz, py, px, epilogue)) return rc;
   LSR_REQUIRE_PTR(wz);
@@ -283,10 +286,15 @@ extern "C" int lsr_correlate_sep_f32(const float* in, float* out, const float* a
   p.pz = pz; p.py = py; p.px = px;
   p.epilogue = epilogue; p.eps = eps;
   p.nz = nz; p.ny = ny; p.nx = nx;
+  p.stats = epilogue == LSR_EPI_UPDATE ? stats : nullptr;
   p.tiles_x = lsr::ceil_div(X, kTileX);
   p.tiles_y = lsr::ceil_div(Y, kTileY);
   p.z_chunk = pick_z_chunk(Z, p.tiles_x * p.tiles_y, pz);
   return launch_correlate<true>(p, lsr::as_stream(stream));
+}
+
+extern "C" int lsr_correlate_sep_f32(const float* in, float* out, const float* aux, int64_t Z, int64_t Y, int64_t X, const float* wz, int pz, const float* wy, int py, const float* wx, int px, int epilogue, float eps, const float* nz, const float* ny, const float* nx, lsr_stream_t stream) {
+  return lsr_correlate_sep_stats_f32(in, out, aux, Z, Y, X, wz, pz, wy, py, wx, px, epilogue, eps, nz, ny, nx, nullptr, stream);
 }
 
 namespace {
@@ -296,6 +304,14 @@ namespace {
 void sep_compiled_taps(int pz, int py, int px, int* PZ, int* PYX) {
   *PZ = lsr::sep_round_taps(pz);
   *PYX = lsr::sep_round_taps(py > px ? py : px);
+}
+
+// The RL loops own their scalars: stats[3 * iters] is zeroed on the stream before the first launch adds to it.
+int zero_stats(double* stats, int iters, lsr_stream_t stream) {
+  if (stats == nullptr || iters <= 0) return LSR_OK;
+  const hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * lsr::kRlStats * static_cast<size_t>(iters), lsr::as_stream(stream));
+  if (e != hipSuccess) return lsr::fail(static_cast<int>(e), "hipMemsetAsync(stats): %s", hipGetErrorString(e));
+  return LSR_OK;
 }
 
 int check_taps(int pz, int py, int px) {
@@ -336,12 +352,7 @@ extern "C" int lsr_sep_padded_shape(int64_t Y, int64_t X, int pz, int py, int px
   return LSR_OK;
 }
 
-extern "C" int lsr_correlate_sep_strided_f32(
-    const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch,
-    int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y,
-    int64_t X, const float* wz, int pz, const float* wy, int py, const float* wx, int px,
-    int epilogue, float eps, const float* nz, const float* ny, const float* nx,
-    lsr_stream_t stream) {
+extern "C" int lsr_correlate_sep_strided_stats_f32(const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch, int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y, int64_t X, const float* wz, int pz, const float* wy, int py, const float* wx, int px, int epilogue, float eps, const float* nz, const float* ny, const float* nx, double* stats, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE_PTR(wz);
@@ -388,6 +399,7 @@ extern "C" int lsr_correlate_sep_strided_f32(
   p.pz = pz; p.py = py; p.px = px;
   p.epilogue = epilogue; p.eps = eps;
   p.nz = nz; p.ny = ny; p.nx = nx;
+  p.stats = epilogue == LSR_EPI_UPDATE ? stats : nullptr;
   p.tiles_x = static_cast<int>(lsr::ceil_div(X, lsr::kSepWideTileX));
   p.tiles_y = static_cast<int>(lsr::ceil_div(Y, lsr::sep_wide_tile_y(PZ)));
   p.z_chunk = static_cast<int>(pick_z_chunk(Z, int64_t(p.tiles_x) * p.tiles_y, PZ));
@@ -411,10 +423,11 @@ extern "C" int lsr_correlate_sep_strided_f32(
   return lsr::launch_status("lsr_correlate_sep_strided_f32");
 }
 
-extern "C" int lsr_correlate_dense_f32(const float* in, float* out, const float* aux, int64_t Z,
-                                       int64_t Y, int64_t X, const float* w, int pz, int py,
-                                       int px, int epilogue, float eps, const double* norm_table,
-                                       lsr_stream_t stream) {
+extern "C" int lsr_correlate_sep_strided_f32(const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch, int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y, int64_t X, const float* wz, int pz, const float* wy, int py, const float* wx, int px, int epilogue, float eps, const float* nz, const float* ny, const float* nx, lsr_stream_t stream) {
+  return lsr_correlate_sep_strided_stats_f32(in, in_pitch, in_plane, aux, aux_pitch, aux_plane, out, out_pitch, out_plane, Z, Y, X, wz, pz, wy, py, wx, px, epilogue, eps, nz, ny, nx, nullptr, stream);
+}
+
+extern "C" int lsr_correlate_dense_stats_f32(const float* in, float* out, const float* aux, int64_t Z, int64_t Y, int64_t X, const float* w, int pz, int py, int px, int epilogue, float eps, const double* norm_table, double* stats, lsr_stream_t stream) {
   if (int rc = check_common(in, out, aux, Z, Y, X, pz, py, px, epilogue)) return rc;
   LSR_REQUIRE_PTR(w);
   if (epilogue == LSR_EPI_UPDATE) LSR_REQUIRE_PTR(norm_table);
@@ -425,19 +438,18 @@ extern "C" int lsr_correlate_dense_f32(const float* in, float* out, const float*
   p.pz = pz; p.py = py; p.px = px;
   p.epilogue = epilogue; p.eps = eps;
   p.norm_table = norm_table;
+  p.stats = epilogue == LSR_EPI_UPDATE ? stats : nullptr;
   p.tiles_x = lsr::ceil_div(X, kTileX);
   p.tiles_y = lsr::ceil_div(Y, kTileY);
   p.z_chunk = pick_z_chunk(Z, p.tiles_x * p.tiles_y, pz);
   return launch_correlate<false>(p, lsr::as_stream(stream));
 }
 
-extern "C" int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
-                              float* x_pad, float* ratio_pad, float* x_out, int64_t Z, int64_t Y,
-                              int64_t X, const float* kz,
-                              const float* kz_flipped, int pz, const float* ky,
-                              const float* ky_flipped, int py, const float* kx,
-                              const float* kx_flipped, int px, const float* nz, const float* ny,
-                              const float* nx, int iters, float eps, lsr_stream_t stream) {
+extern "C" int lsr_correlate_dense_f32(const float* in, float* out, const float* aux, int64_t Z, int64_t Y, int64_t X, const float* w, int pz, int py, int px, int epilogue, float eps, const double* norm_table, lsr_stream_t stream) {
+  return lsr_correlate_dense_stats_f32(in, out, aux, Z, Y, X, w, pz, py, px, epilogue, eps, norm_table, nullptr, stream);
+}
+
+extern "C" int lsr_rl_sep_stats_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y, float* x_pad, float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X, const float* kz, const float* kz_flipped, int pz, const float* ky, const float* ky_flipped, int py, const float* kx, const float* kx_flipped, int px, const float* nz, const float* ny, const float* nx, int iters, float eps, double* stats, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(y);
   LSR_REQUIRE_PTR(x_pad);
   LSR_REQUIRE_PTR(ratio_pad);
@@ -449,6 +461,7 @@ extern "C" int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, 
   const int64_t origin = ps[2] * pitch + ps[3];
   float* xl = x_pad + origin;        // logical (0,0,0) inside the padded volumes
   float* rl = ratio_pad + origin;
+  if (int rc = zero_stats(stats, iters, stream)) return rc;
   for (int it = 0; it < iters; ++it) {
     // ratio = y / (H x + eps);  H x = convolve(x, psf) = correlate(x, flipped psf).
     // With init_from_y the first iteration reads x = y straight from the (padded) y volume.
@@ -463,12 +476,17 @@ extern "C" int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, 
     // x <- x * H^T ratio / H^T 1;  H^T r = correlate(r, psf).  The last update may go straight
     // to the dense result.
     const bool last = it + 1 == iters && x_out != nullptr;
-    rc = lsr_correlate_sep_strided_f32(rl, pitch, plane, xin, xin_pitch, xin_plane, last ? x_out : xl,
-                                       last ? X : pitch, last ? Y * X : plane, Z, Y, X, kz, pz, ky,
-                                       py, kx, px, LSR_EPI_UPDATE, eps, nz, ny, nx, stream);
+    rc = lsr_correlate_sep_strided_stats_f32(rl, pitch, plane, xin, xin_pitch, xin_plane, last ? x_out : xl,
+                                             last ? X : pitch, last ? Y * X : plane, Z, Y, X, kz, pz, ky,
+                                             py, kx, px, LSR_EPI_UPDATE, eps, nz, ny, nx,
+                                             stats ? stats + lsr::kRlStats * it : nullptr, stream);
     if (rc) return rc;
   }
   return LSR_OK;
+}
+
+extern "C" int lsr_rl_sep_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y, float* x_pad, float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X, const float* kz, const float* kz_flipped, int pz, const float* ky, const float* ky_flipped, int py, const float* kx, const float* kx_flipped, int px, const float* nz, const float* ny, const float* nx, int iters, float eps, lsr_stream_t stream) {
+  return lsr_rl_sep_stats_f32(y, y_pitch, y_plane, init_from_y, x_pad, ratio_pad, x_out, Z, Y, X, kz, kz_flipped, pz, ky, ky_flipped, py, kx, kx_flipped, px, nz, ny, nx, iters, eps, nullptr, stream);
 }
 
 namespace {
@@ -549,11 +567,7 @@ static unsigned long long* g_fused_probe = nullptr;
 extern "C" void lsr_debug_set_fused_probe(void* dev) { g_fused_probe = static_cast<unsigned long long*>(dev); }
 #endif
 
-extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y,
-                                    float* x_a, float* x_b, float* x_out, int64_t Z, int64_t Y,
-                                    int64_t X, const float* taps, int pz, int py, int px,
-                                    const float* nz, const float* ny, const float* nx, int iters,
-                                    float eps, lsr_stream_t stream) {
+extern "C" int lsr_rl_sep_fused_stats_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y, float* x_a, float* x_b, float* x_out, int64_t Z, int64_t Y, int64_t X, const float* taps, int pz, int py, int px, const float* nz, const float* ny, const float* nx, int iters, float eps, double* stats, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(y);
   LSR_REQUIRE_PTR(x_a);
   LSR_REQUIRE_PTR(x_b);
@@ -605,6 +619,7 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
   hipStream_t s = lsr::as_stream(stream);
 
   float* bufs[2] = {x_a + origin, x_b + origin};  // logical (0,0,0) of the two working volumes
+  if (int rc = zero_stats(stats, iters, stream)) return rc;
   for (int it = 0; it < iters; ++it) {
     const bool from_y = init_from_y && it == 0;
     const bool last = it + 1 == iters && x_out != nullptr;
@@ -615,6 +630,7 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
     p.out_pitch = static_cast<int>(last ? X : pitch);
     p.out_plane = last ? Y * X : plane;
     p.mask_out = last ? 1 : 0;
+    p.stats = stats ? stats + lsr::kRlStats * it : nullptr;
     bool ok = false;
     switch (PZ) {
       case 3: ok = lsr::launch_fused_pz3(PYX, p, blocks, s); break;
@@ -630,6 +646,10 @@ extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_p
     if (int rc = lsr::launch_status("lsr_rl_sep_fused_f32")) return rc;
   }
   return LSR_OK;
+}
+
+extern "C" int lsr_rl_sep_fused_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y, float* x_a, float* x_b, float* x_out, int64_t Z, int64_t Y, int64_t X, const float* taps, int pz, int py, int px, const float* nz, const float* ny, const float* nx, int iters, float eps, lsr_stream_t stream) {
+  return lsr_rl_sep_fused_stats_f32(y, y_pitch, y_plane, init_from_y, x_a, x_b, x_out, Z, Y, X, taps, pz, py, px, nz, ny, nx, iters, eps, nullptr, stream);
 }
 
 // ---- fused iteration for psf = ky (x) kzx (rl_fused_ysep.hip) --------------------------------------------
@@ -669,10 +689,7 @@ extern "C" int lsr_rl_ysep_fused_prepare_taps(const float* ky_host, int py, cons
   return LSR_OK;
 }
 
-extern "C" int lsr_rl_ysep_fused_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y, float* x_a,
-                                     float* x_b, float* x_out, int64_t Z, int64_t Y, int64_t X, const float* taps,
-                                     int pz, int py, int px, const double* norm_table, float norm_full, int iters,
-                                     float eps, lsr_stream_t stream) {
+extern "C" int lsr_rl_ysep_fused_stats_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y, float* x_a, float* x_b, float* x_out, int64_t Z, int64_t Y, int64_t X, const float* taps, int pz, int py, int px, const double* norm_table, float norm_full, int iters, float eps, double* stats, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(y);
   LSR_REQUIRE_PTR(x_a);
   LSR_REQUIRE_PTR(x_b);
@@ -723,6 +740,7 @@ extern "C" int lsr_rl_ysep_fused_f32(const float* y, int64_t y_pitch, int64_t y_
   hipStream_t s = lsr::as_stream(stream);
 
   float* bufs[2] = {x_a + origin, x_b + origin};  // logical (0,0,0) of the two working volumes
+  if (int rc = zero_stats(stats, iters, stream)) return rc;
   for (int it = 0; it < iters; ++it) {
     const bool from_y = init_from_y && it == 0;
     const bool last = it + 1 == iters && x_out != nullptr;
@@ -732,6 +750,7 @@ extern "C" int lsr_rl_ysep_fused_f32(const float* y, int64_t y_pitch, int64_t y_
     p.out = last ? x_out : bufs[(it + 1) & 1];
     p.out_pitch = static_cast<int>(last ? X : pitch);
     p.out_plane = last ? Y * X : plane;
+    p.stats = stats ? stats + lsr::kRlStats * it : nullptr;
     bool ok = false;
     switch (PZ) {
       case 3: ok = lsr::launch_ysep_pz3(PYX, p, blocks, s); break;
@@ -747,24 +766,30 @@ extern "C" int lsr_rl_ysep_fused_f32(const float* y, int64_t y_pitch, int64_t y_
   return LSR_OK;
 }
 
-extern "C" int lsr_rl_dense_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y,
-                                int64_t X, const float* psf, const float* psf_flipped, int pz,
-                                int py, int px, const double* norm_table, int iters, float eps,
-                                lsr_stream_t stream) {
+extern "C" int lsr_rl_ysep_fused_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y, float* x_a, float* x_b, float* x_out, int64_t Z, int64_t Y, int64_t X, const float* taps, int pz, int py, int px, const double* norm_table, float norm_full, int iters, float eps, lsr_stream_t stream) {
+  return lsr_rl_ysep_fused_stats_f32(y, y_pitch, y_plane, init_from_y, x_a, x_b, x_out, Z, Y, X, taps, pz, py, px, norm_table, norm_full, iters, eps, nullptr, stream);
+}
+
+extern "C" int lsr_rl_dense_stats_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X, const float* psf, const float* psf_flipped, int pz, int py, int px, const double* norm_table, int iters, float eps, double* stats, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(y);
   LSR_REQUIRE_PTR(x);
   LSR_REQUIRE_PTR(ratio);
   LSR_REQUIRE(iters >= 0, LSR_E_ARG, "iters %d must be >= 0", iters);
   LSR_REQUIRE(ratio != x && ratio != y && x != y, LSR_E_ARG, "y, x and ratio must be distinct");
+  if (int rc = zero_stats(stats, iters, stream)) return rc;
   for (int it = 0; it < iters; ++it) {
     int rc = lsr_correlate_dense_f32(x, ratio, y, Z, Y, X, psf_flipped, pz, py, px, LSR_EPI_RATIO,
                                      eps, nullptr, stream);
     if (rc) return rc;
-    rc = lsr_correlate_dense_f32(ratio, x, x, Z, Y, X, psf, pz, py, px, LSR_EPI_UPDATE, eps,
-                                 norm_table, stream);
+    rc = lsr_correlate_dense_stats_f32(ratio, x, x, Z, Y, X, psf, pz, py, px, LSR_EPI_UPDATE, eps,
+                                       norm_table, stats ? stats + lsr::kRlStats * it : nullptr, stream);
     if (rc) return rc;
   }
   return LSR_OK;
+}
+
+extern "C" int lsr_rl_dense_f32(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X, const float* psf, const float* psf_flipped, int pz, int py, int px, const double* norm_table, int iters, float eps, lsr_stream_t stream) {
+  return lsr_rl_dense_stats_f32(y, x, ratio, Z, Y, X, psf, psf_flipped, pz, py, px, norm_table, iters, eps, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -824,7 +849,7 @@ int dense_padded_launch(const char* what, int mode, const float* ky,
     const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch,
     int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y,
     int64_t X, const float* taps, int pz, int py, int px, int epilogue, float eps,
-    const double* norm_table, float norm_full, lsr_stream_t stream) {
+    const double* norm_table, float norm_full, double* stats, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(out);
   LSR_REQUIRE_PTR(taps);
@@ -874,6 +899,7 @@ int dense_padded_launch(const char* what, int mode, const float* ky,
   p.epilogue = epilogue; p.eps = eps;
   p.norm_full = norm_full;
   p.norm_table = norm_table;
+  p.stats = epilogue == LSR_EPI_UPDATE ? stats : nullptr;
   p.taps = taps;
   p.tiles_x = static_cast<int>(lsr::ceil_div(X, lsr::kSepTileX));
   p.tiles_y = static_cast<int>(lsr::ceil_div(Y, lsr::kSepTileY));
@@ -897,33 +923,27 @@ int dense_padded_launch(const char* what, int mode, const float* ky,
 }
 }  // namespace
 
-extern "C" int lsr_correlate_dense_padded_f32(
-    const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch,
-    int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y,
-    int64_t X, const float* taps, int pz, int py, int px, int epilogue, float eps,
-    const double* norm_table, float norm_full, lsr_stream_t stream) {
+extern "C" int lsr_correlate_dense_padded_stats_f32(const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch, int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y, int64_t X, const float* taps, int pz, int py, int px, int epilogue, float eps, const double* norm_table, float norm_full, double* stats, lsr_stream_t stream) {
   return dense_padded_launch("lsr_correlate_dense_padded_f32", 0, nullptr, in, in_pitch, in_plane, aux, aux_pitch,
                              aux_plane, out, out_pitch, out_plane, Z, Y, X, taps, pz, py, px, epilogue, eps,
-                             norm_table, norm_full, stream);
+                             norm_table, norm_full, stats, stream);
 }
 
-extern "C" int lsr_correlate_zxy_padded_f32(
-    const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch,
-    int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y,
-    int64_t X, const float* taps_zx, const float* ky, int pz, int py, int px, int epilogue, float eps,
-    const double* norm_table, float norm_full, lsr_stream_t stream) {
+extern "C" int lsr_correlate_dense_padded_f32(const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch, int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y, int64_t X, const float* taps, int pz, int py, int px, int epilogue, float eps, const double* norm_table, float norm_full, lsr_stream_t stream) {
+  return lsr_correlate_dense_padded_stats_f32(in, in_pitch, in_plane, aux, aux_pitch, aux_plane, out, out_pitch, out_plane, Z, Y, X, taps, pz, py, px, epilogue, eps, norm_table, norm_full, nullptr, stream);
+}
+
+extern "C" int lsr_correlate_zxy_padded_stats_f32(const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch, int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y, int64_t X, const float* taps_zx, const float* ky, int pz, int py, int px, int epilogue, float eps, const double* norm_table, float norm_full, double* stats, lsr_stream_t stream) {
   return dense_padded_launch("lsr_correlate_zxy_padded_f32", 2, ky, in, in_pitch, in_plane, aux, aux_pitch,
                              aux_plane, out, out_pitch, out_plane, Z, Y, X, taps_zx, pz, py, px, epilogue, eps,
-                             norm_table, norm_full, stream);
+                             norm_table, norm_full, stats, stream);
 }
 
-extern "C" int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane,
-                                       int init_from_y, float* x_pad, float* ratio_pad,
-                                       float* x_out, int64_t Z,
-                                       int64_t Y, int64_t X, const float* taps,
-                                       const float* taps_flipped, int pz, int py, int px,
-                                       const double* norm_table, float norm_full, int iters,
-                                       float eps, lsr_stream_t stream) {
+extern "C" int lsr_correlate_zxy_padded_f32(const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch, int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y, int64_t X, const float* taps_zx, const float* ky, int pz, int py, int px, int epilogue, float eps, const double* norm_table, float norm_full, lsr_stream_t stream) {
+  return lsr_correlate_zxy_padded_stats_f32(in, in_pitch, in_plane, aux, aux_pitch, aux_plane, out, out_pitch, out_plane, Z, Y, X, taps_zx, ky, pz, py, px, epilogue, eps, norm_table, norm_full, nullptr, stream);
+}
+
+extern "C" int lsr_rl_dense_padded_stats_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y, float* x_pad, float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X, const float* taps, const float* taps_flipped, int pz, int py, int px, const double* norm_table, float norm_full, int iters, float eps, double* stats, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(y);
   LSR_REQUIRE_PTR(x_pad);
   LSR_REQUIRE_PTR(ratio_pad);
@@ -935,6 +955,7 @@ extern "C" int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t 
   const int64_t origin = ps[2] * pitch + ps[3];
   float* xl = x_pad + origin;
   float* rl = ratio_pad + origin;
+  if (int rc = zero_stats(stats, iters, stream)) return rc;
   for (int it = 0; it < iters; ++it) {
     const bool from_y = init_from_y && it == 0;
     const float* xin = from_y ? y : xl;
@@ -944,10 +965,15 @@ extern "C" int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t 
                                             eps, nullptr, 0.0f, stream);
     if (rc) return rc;
     const bool last = it + 1 == iters && x_out != nullptr;
-    rc = lsr_correlate_dense_padded_f32(rl, pitch, plane, xin, xin_pitch, xin_plane, last ? x_out : xl,
-                                        last ? X : pitch, last ? Y * X : plane, Z, Y, X, taps, pz,
-                                        py, px, LSR_EPI_UPDATE, eps, norm_table, norm_full, stream);
+    rc = lsr_correlate_dense_padded_stats_f32(rl, pitch, plane, xin, xin_pitch, xin_plane, last ? x_out : xl,
+                                              last ? X : pitch, last ? Y * X : plane, Z, Y, X, taps, pz,
+                                              py, px, LSR_EPI_UPDATE, eps, norm_table, norm_full,
+                                              stats ? stats + lsr::kRlStats * it : nullptr, stream);
     if (rc) return rc;
   }
   return LSR_OK;
+}
+
+extern "C" int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane, int init_from_y, float* x_pad, float* ratio_pad, float* x_out, int64_t Z, int64_t Y, int64_t X, const float* taps, const float* taps_flipped, int pz, int py, int px, const double* norm_table, float norm_full, int iters, float eps, lsr_stream_t stream) {
+  return lsr_rl_dense_padded_stats_f32(y, y_pitch, y_plane, init_from_y, x_pad, ratio_pad, x_out, Z, Y, X, taps, taps_flipped, pz, py, px, norm_table, norm_full, iters, eps, nullptr, stream);
 }

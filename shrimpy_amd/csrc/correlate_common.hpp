@@ -24,6 +24,7 @@ struct CorrArgs {
   const double* norm_table;  // dense: (pz+1)(py+1)(px+1) prefix sums
   int64_t tiles_x, tiles_y;
   int64_t z_chunk;  // output planes per workgroup along z
+  double* stats;    // LSR_EPI_UPDATE: three running sums of this launch (rl_stats below) or NULL
 };
 
 // Tuned separable kernel: every volume is strided, `in` additionally carries a zero halo so that
@@ -46,6 +47,7 @@ struct SepArgs {
   const float* nx;
   int tiles_x, tiles_y;
   int z_chunk;
+  double* stats;    // LSR_EPI_UPDATE: three running sums of this launch (rl_stats below) or NULL
 };
 
 // Tuned dense kernel: like SepArgs.  `taps` is a small DEVICE array prepared by
@@ -70,6 +72,7 @@ struct DenseArgs {
   const float* taps;
   int ysep;                  // 1: a single y tap -- the (z, x)-stencil specialisation; 2: ky (x) kzx in one launch
   const float* ky;           // ysep == 2: the py y taps (device)
+  double* stats;             // LSR_EPI_UPDATE: three running sums of this launch (rl_stats below) or NULL
 };
 
 // Tile geometry of the tuned kernels, needed by the host to size the halo (lsr_sep_padded_shape).
@@ -113,6 +116,7 @@ struct FusedArgs {
   int n_full;   // tiles [0, n_full) are whole z columns, one workgroup each (dispatched first)
   int pieces;   // every other tile: `pieces` workgroups of z_chunk planes
   int z_chunk;
+  double* stats;  // three running sums of this iteration (rl_stats below) or NULL: the <.., STATS = false> kernel
 #ifdef LSR_FUSED_PROBE_TIME
   unsigned long long* probe;  // diagnostic build: 4 timestamps per workgroup (tools/fused_drift.py)
 #endif
@@ -150,11 +154,59 @@ struct YsepArgs {
   float norm_full;                    // sum of all taps (interior voxels)
   int tiles_x, tiles_y;
   int n_full, pieces, z_chunk;        // work split, as FusedArgs
+  double* stats;                      // three running sums of this iteration (rl_stats below) or NULL
   int narrow;                         // 1: 256-thread workgroups on 32 x 64 tiles (two per CU); 0: 512 threads, 32 x 128
 };
 // tile rows: the accumulators of both stencils (PZ planes each) must fit 256 VGPRs per thread
 constexpr int ysep_tile_rows(int PZ) { return PZ <= 9 ? 32 : 24; }
 constexpr int kYsepMaxPZ = 11, kYsepMaxPYX = 9;
+
+// ---- Richardson-Lucy reduction scalars (VERDICT r3 row g; north-star "wavefront reductions for the ratio /
+// normalisation") -----------------------------------------------------------------------------------------------------
+// Every kernel that finishes an iteration (the fused launches, any LSR_EPI_UPDATE epilogue) can add three sums over the
+// voxels it writes to a caller-supplied double[3]:
+//   [0] flux    sum x * H^T(ratio)   (= sum x_new * H^T 1: what the update conserves, -> sum y as eps -> 0)
+//   [1] change  sum |x_new - x|      (the update norm: / [2] it is the relative change a caller stops on)
+//   [2] total   sum x_new
+// The kernels have x * u in hand before the division by H^T 1, so the flux costs one add per voxel and no extra byte.
+// Per thread the sums run in f32 over the voxels it owns (a few hundred to ~1400, rounding errors independent from
+// thread to thread), then: DPP wave reduction -> LDS -> three double adds per workgroup -> ONE atomic per workgroup and
+// sum (global_atomic_add_f64; the order of the workgroups' doubles is the only run-to-run freedom, ~1e-16 relative).
+constexpr int kRlStats = 3;
+#if defined(__HIPCC__)
+struct RlStats {
+  float flux = 0.0f, change = 0.0f, total = 0.0f;
+  __device__ __forceinline__ void add(float x_old, float xu, float x_new) {
+    flux += xu;
+    change += __builtin_fabsf(x_new - x_old);
+    total += x_new;
+  }
+};
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// All threads of the workgroup call this once, after their last use of `lds` (>= 3 * NWAVES floats, any content).
+template <int NWAVES>
+__device__ __forceinline__ void rl_stats_flush(const RlStats& s, float* lds, double* dst) {
+  const float a = wave_sum(s.flux), b = wave_sum(s.change), c = wave_sum(s.total);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();   // every wave is done with the buffers this scratch may alias
+  if (lane == 0) {
+    lds[3 * wave] = a;
+    lds[3 * wave + 1] = b;
+    lds[3 * wave + 2] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x < kRlStats) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) t += static_cast<double>(lds[3 * w + threadIdx.x]);
+    unsafeAtomicAdd(dst + threadIdx.x, t);
+  }
+}
+#endif
 
 inline int sep_wide_stage_cols(int PX) { return kSepWideTileX - 4 + 4 * ((4 + PX - 1 + 3) / 4); }
 

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
 #pragma unroll
   for (int m = 0; m < kRun; ++m) aux0[m] = aux1[m] = 0.0f;
 
+  lsr::RlStats stats;   // UPDATE with p.stats: the launch's reduction scalars (correlate_common.hpp)
   const int zi_begin = max(zb - cz, 0);
   const int zi_end = ze + cz;
 
@@ -351,9 +352,12 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
             if (ok[m]) {
               const float nrm = (z_inside && yx_inside[m]) ? p.norm_full
                                                            : dense_norm(p, s_norm, z_out, gy_out0 + m, gx_out);
-              if constexpr (EPI == LSR_EPI_UPDATE)
-                o[o_off[m]] = aux_use[m] * acc0(m) * fast_rcp(nrm);
-              else
+              if constexpr (EPI == LSR_EPI_UPDATE) {
+                const float xu = aux_use[m] * acc0(m);
+                const float v = xu * fast_rcp(nrm);
+                o[o_off[m]] = v;
+                if (p.stats) stats.add(aux_use[m], xu, v);   // (kernel-uniform)
+              } else
                 o[o_off[m]] = acc0(m) * fast_rcp(nrm);
             }
           }
@@ -377,6 +381,9 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
     iteration(zi + 1, 1, st1, aux1, aux0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (EPI == LSR_EPI_UPDATE) {
+    if (p.stats) lsr::rl_stats_flush<kWaves>(stats, reinterpret_cast<float*>(bufA4), p.stats);
+  }
 }
 
 template <int PZ, int PYX>

@@ -268,6 +268,7 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
 
   const int zi_begin = max(zb - cz, 0);
   const int zi_end = ze + cz;  // exclusive; planes >= Z contribute zeros
+  lsr::RlStats stats;   // UPDATE with p.stats: the launch's reduction scalars (correlate_common.hpp)
 
   auto fetch = [&](int zplane, f32x4 (&st)[SL]) {  // SL loads
     const float* src = in_tile + static_cast<int64_t>(min(max(zplane, 0), Z - 1)) * p.in_plane;
@@ -394,7 +395,12 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
           const float rz = fast_rcp(nz_use);
 #pragma unroll
           for (int i = 0; i < kPts; ++i)
-            if (ok[i]) o[o_off[i]] = aux_use[i] * acc[0][i] * ((rz * rny[i % kRun]) * rnx[i / kRun]);
+            if (ok[i]) {
+              const float xu = aux_use[i] * acc[0][i];
+              const float v = xu * ((rz * rny[i % kRun]) * rnx[i / kRun]);
+              o[o_off[i]] = v;
+              if (p.stats) stats.add(aux_use[i], xu, v);   // (kernel-uniform)
+            }
         } else {
 #pragma unroll
           for (int i = 0; i < kPts; ++i)
@@ -418,6 +424,9 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
     iteration(zi + 1, 1, st1, aux1, nzv1, aux0, nzv0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land after the wave has ended
+  if constexpr (EPI == LSR_EPI_UPDATE) {
+    if (p.stats) lsr::rl_stats_flush<kWaves>(stats, reinterpret_cast<float*>(bufB4), p.stats);
+  }
 }
 
 template <int PZ, int PYX>

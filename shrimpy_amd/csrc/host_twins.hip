@@ -29,12 +29,14 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <system_error>
 #include <thread>
 #include <vector>
 
 #include "common.hpp"
+#include "correlate_common.hpp"
 #include "host_parallel.hpp"
 
 namespace {
@@ -334,10 +336,35 @@ extern "C" int lsr_average_slices_f32_cpu(const float* in, int64_t Zd, int64_t Y
   return LSR_OK;
 }
 
+// The reduction scalars of an UPDATE pass (correlate_common.hpp: flux, change, total), as the kernels add them: a
+// range's rows in f64 here, one locked add per range.
+namespace {
+struct HostStats {
+  double flux = 0.0, change = 0.0, total = 0.0;
+  void add(float x_old, float xu, float x_new) {
+    flux += xu;
+    change += std::fabs(static_cast<double>(x_new) - static_cast<double>(x_old));
+    total += x_new;
+  }
+  void flush(double* dst, std::mutex& m) const {
+    std::lock_guard<std::mutex> g(m);
+    dst[0] += flux; dst[1] += change; dst[2] += total;
+  }
+};
+}  // namespace
+
 extern "C" int lsr_correlate_sep_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y, int64_t X,
                                          const float* wz, int pz, const float* wy, int py, const float* wx, int px,
                                          int epilogue, float eps, const float* nz, const float* ny, const float* nx,
-                                         lsr_stream_t) {
+                                         lsr_stream_t stream) {
+  return lsr_correlate_sep_stats_f32_cpu(in, out, aux, Z, Y, X, wz, pz, wy, py, wx, px, epilogue, eps, nz, ny, nx, nullptr,
+                                         stream);
+}
+
+extern "C" int lsr_correlate_sep_stats_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y, int64_t X,
+                                               const float* wz, int pz, const float* wy, int py, const float* wx, int px,
+                                               int epilogue, float eps, const float* nz, const float* ny, const float* nx,
+                                               double* stats, lsr_stream_t) {
   LSR_REQUIRE_HOST_FMA();
   if (int rc = check_corr(in, out, aux, Z, Y, X, pz, py, px, epilogue)) return rc;
   LSR_REQUIRE_PTR(wz);
@@ -391,9 +418,11 @@ extern "C" int lsr_correlate_sep_f32_cpu(const float* in, float* out, const floa
     }
   }, failed);
   if (failed.load()) return lsr::fail(LSR_E_ARG, "out of host memory for the per-thread row buffers");
+  std::mutex stats_lock;
   parallel_ranges(Z * Y, [&](int64_t r_first, int64_t r_last) {
     std::vector<float> c_v(static_cast<size_t>(X));
     float* __restrict__ c = c_v.data();
+    HostStats st;
     for (int64_t zy = r_first; zy < r_last; ++zy) {
       const int64_t z = zy / Y, y = zy - z * Y;
       // the march of correlate.hip: the first plane's term is a plain product, the others FMAs onto it
@@ -419,11 +448,20 @@ extern "C" int lsr_correlate_sep_f32_cpu(const float* in, float* out, const floa
       } else if (epilogue == LSR_EPI_UPDATE) {
         const float* __restrict__ ax = aux + o;
         const float nzy = nz[z] * ny[y];
-        for (int64_t x = 0; x < X; ++x) dst[x] = ax[x] * c[x] / (nzy * nx[x]);
+        if (stats == nullptr) {
+          for (int64_t x = 0; x < X; ++x) dst[x] = ax[x] * c[x] / (nzy * nx[x]);
+        } else {   // (dst may be aux itself: read, then write)
+          for (int64_t x = 0; x < X; ++x) {
+            const float a = ax[x], ac = a * c[x], v = ac / (nzy * nx[x]);
+            dst[x] = v;
+            st.add(a, ac, v);
+          }
+        }
       } else {
         for (int64_t x = 0; x < X; ++x) dst[x] = c[x];
       }
     }
+    if (stats != nullptr && epilogue == LSR_EPI_UPDATE) st.flush(stats, stats_lock);
   }, failed);
   if (failed.load()) return lsr::fail(LSR_E_ARG, "out of host memory for the per-thread row buffers");
   return LSR_OK;
@@ -431,7 +469,13 @@ extern "C" int lsr_correlate_sep_f32_cpu(const float* in, float* out, const floa
 
 extern "C" int lsr_correlate_dense_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y, int64_t X,
                                            const float* w, int pz, int py, int px, int epilogue, float eps,
-                                           const double* norm_table, lsr_stream_t) {
+                                           const double* norm_table, lsr_stream_t stream) {
+  return lsr_correlate_dense_stats_f32_cpu(in, out, aux, Z, Y, X, w, pz, py, px, epilogue, eps, norm_table, nullptr, stream);
+}
+
+extern "C" int lsr_correlate_dense_stats_f32_cpu(const float* in, float* out, const float* aux, int64_t Z, int64_t Y,
+                                                 int64_t X, const float* w, int pz, int py, int px, int epilogue, float eps,
+                                                 const double* norm_table, double* stats, lsr_stream_t) {
   LSR_REQUIRE_HOST_FMA();
   if (int rc = check_corr(in, out, aux, Z, Y, X, pz, py, px, epilogue)) return rc;
   LSR_REQUIRE_PTR(w);
@@ -441,9 +485,11 @@ extern "C" int lsr_correlate_dense_f32_cpu(const float* in, float* out, const fl
   // per output row: taps outermost (planes in z order, within a plane y-major, then x: the order the march accumulates
   // in), x innermost -- every voxel's chain is the same sequence of FMAs, a row at a time (packed FMAs on the host)
   std::atomic<bool> failed{false};
+  std::mutex stats_lock;
   parallel_ranges(Z * Y, [&](int64_t r_first, int64_t r_last) {
     std::vector<float> c_v(static_cast<size_t>(X));
     float* __restrict__ c = c_v.data();
+    HostStats st;
     for (int64_t zy = r_first; zy < r_last; ++zy) {
       const int64_t z = zy / Y, y = zy - z * Y;
       for (int64_t x = 0; x < X; ++x) c[x] = 0.0f;
@@ -461,12 +507,17 @@ extern "C" int lsr_correlate_dense_f32_cpu(const float* in, float* out, const fl
       if (epilogue == LSR_EPI_RATIO) {
         for (int64_t x = 0; x < X; ++x) dst[x] = aux[o + x] / (c[x] + eps);
       } else if (epilogue == LSR_EPI_UPDATE) {
-        for (int64_t x = 0; x < X; ++x)
-          dst[x] = aux[o + x] * c[x] / static_cast<float>(dense_norm(norm_table, pz, py, px, Z, Y, X, z, y, x));
+        for (int64_t x = 0; x < X; ++x) {
+          const float a = aux[o + x], ac = a * c[x];
+          const float v = ac / static_cast<float>(dense_norm(norm_table, pz, py, px, Z, Y, X, z, y, x));
+          dst[x] = v;
+          if (stats != nullptr) st.add(a, ac, v);
+        }
       } else {
         for (int64_t x = 0; x < X; ++x) dst[x] = c[x];
       }
     }
+    if (stats != nullptr && epilogue == LSR_EPI_UPDATE) st.flush(stats, stats_lock);
   }, failed);
   if (failed.load()) return lsr::fail(LSR_E_ARG, "out of host memory for the per-thread row buffers");
   return LSR_OK;
@@ -477,16 +528,26 @@ extern "C" int lsr_correlate_dense_f32_cpu(const float* in, float* out, const fl
 extern "C" int lsr_rl_dense_f32_cpu(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X, const float* psf,
                                     const float* psf_flipped, int pz, int py, int px, const double* norm_table, int iters,
                                     float eps, lsr_stream_t stream) {
+  return lsr_rl_dense_stats_f32_cpu(y, x, ratio, Z, Y, X, psf, psf_flipped, pz, py, px, norm_table, iters, eps, nullptr, stream);
+}
+
+extern "C" int lsr_rl_dense_stats_f32_cpu(const float* y, float* x, float* ratio, int64_t Z, int64_t Y, int64_t X,
+                                          const float* psf, const float* psf_flipped, int pz, int py, int px,
+                                          const double* norm_table, int iters, float eps, double* stats,
+                                          lsr_stream_t stream) {
   LSR_REQUIRE_HOST_FMA();
   LSR_REQUIRE_PTR(y);
   LSR_REQUIRE_PTR(x);
   LSR_REQUIRE_PTR(ratio);
   LSR_REQUIRE(iters >= 0, LSR_E_ARG, "iters %d must be >= 0", iters);
   LSR_REQUIRE(ratio != x && ratio != y && x != y, LSR_E_ARG, "y, x and ratio must be distinct");
+  if (stats != nullptr)
+    for (int i = 0; i < lsr::kRlStats * iters; ++i) stats[i] = 0.0;
   for (int it = 0; it < iters; ++it) {
     int rc = lsr_correlate_dense_f32_cpu(x, ratio, y, Z, Y, X, psf_flipped, pz, py, px, LSR_EPI_RATIO, eps, nullptr, stream);
     if (rc) return rc;
-    rc = lsr_correlate_dense_f32_cpu(ratio, x, x, Z, Y, X, psf, pz, py, px, LSR_EPI_UPDATE, eps, norm_table, stream);
+    rc = lsr_correlate_dense_stats_f32_cpu(ratio, x, x, Z, Y, X, psf, pz, py, px, LSR_EPI_UPDATE, eps, norm_table,
+                                           stats ? stats + lsr::kRlStats * it : nullptr, stream);
     if (rc) return rc;
   }
   return LSR_OK;

@@ -190,7 +190,9 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int PZ, int PYX, int RUN>
+// STATS: the iteration's reduction scalars (correlate_common.hpp: RlStats) are summed in the epilogue and added to
+// p.stats[0..2] -- a separate instantiation, so that the kernel without them is the one it always was.
+template <int PZ, int PYX, int RUN, bool STATS>
 __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
   using T = Geo<PZ, PYX, RUN>;
   constexpr int C = T::C, CZ = T::CZ, TY = T::TY, RUN1 = T::RUN1, EP = T::EP;
@@ -349,6 +351,7 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
 #pragma unroll
   for (int i = 0; i < 2 * RUN; ++i) xc[i] = 0.0f;
   const f32x2 rnx2 = f32x2{rnx[0], rnx[1]};
+  lsr::RlStats st;
   __builtin_amdgcn_sched_barrier(0);  // setup loads (taps, norms) are consumed above this line
 
   auto clampz = [&](int z) { return min(max(z, 0), Z - 1); };
@@ -510,18 +513,28 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
           // x * u / n with x = 0 from the zero halo
 #pragma unroll
           for (int m = 0; m < RUN; ++m) {
-            const f32x2 v = f32x2{xc[m], xc[RUN + m]} * acc2[0][m] * (splat(rz * rny_lds[wave * RUN + m]) * rnx2);
+            const f32x2 xu = f32x2{xc[m], xc[RUN + m]} * acc2[0][m];
+            const f32x2 v = xu * (splat(rz * rny_lds[wave * RUN + m]) * rnx2);
             gstore<0>(obase, o_voff[m], v.x);
             gstore<256>(obase, o_voff[m], v.y);
+            if constexpr (STATS) {   // (points past the volume: x = 0 from the halo, all three terms 0)
+              st.add(xc[m], xu.x, v.x);
+              st.add(xc[RUN + m], xu.y, v.y);
+            }
           }
         } else {  // the dense result of the last iteration: masked to the volume
           const bool ok0 = x0 + lane < X, ok1 = x0 + lane + 64 < X;
 #pragma unroll
           for (int m = 0; m < RUN; ++m) {
             if (y0 + wave * RUN + m < Y) {  // wave-uniform
-              const f32x2 v = f32x2{xc[m], xc[RUN + m]} * acc2[0][m] * (splat(rz * rny_lds[wave * RUN + m]) * rnx2);
+              const f32x2 xu = f32x2{xc[m], xc[RUN + m]} * acc2[0][m];
+              const f32x2 v = xu * (splat(rz * rny_lds[wave * RUN + m]) * rnx2);
               if (ok0) gstore<0>(obase, o_voff[m], v.x);
               if (ok1) gstore<256>(obase, o_voff[m], v.y);
+              if constexpr (STATS) {
+                if (ok0) st.add(xc[m], xu.x, v.x);
+                if (ok1) st.add(xc[RUN + m], xu.y, v.y);
+              }
             }
           }
         }
@@ -626,6 +639,7 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
     slot = slot == 2 ? 0 : slot + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land after the wave has ended
+  if constexpr (STATS) lsr::rl_stats_flush<kWaves>(st, smem + T::OFF_B2, p.stats);
 #ifdef LSR_FUSED_PROBE_TIME
   if (p.probe && tid == 0) p.probe[4 * blockIdx.x + 3] = wall_clock64();
 #endif
@@ -635,7 +649,8 @@ template <int PZ, int PYX>
 bool launch_one(const FusedArgs& p, dim3 grid, hipStream_t s) {
   if constexpr (lsr::fused_compiled(PZ, PYX)) {
     constexpr int RUN = lsr::fused_run(PZ, PYX);
-    hipLaunchKernelGGL((rl_fused_sep_kernel<PZ, PYX, RUN>), grid, dim3(kThreads), 0, s, p);
+    if (p.stats != nullptr) hipLaunchKernelGGL((rl_fused_sep_kernel<PZ, PYX, RUN, true>), grid, dim3(kThreads), 0, s, p);
+    else hipLaunchKernelGGL((rl_fused_sep_kernel<PZ, PYX, RUN, false>), grid, dim3(kThreads), 0, s, p);
     return true;
   } else {
     return false;

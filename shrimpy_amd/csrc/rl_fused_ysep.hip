@@ -194,7 +194,8 @@ __device__ __forceinline__ constexpr int pair_row(int i, int h) { return NCG == 
 template <int NCG>
 __device__ __forceinline__ constexpr int pair_col(int h) { return NCG == 2 ? 64 * h : 0; }
 
-template <int PZ, int PYX, int NW, int NCG>
+// STATS: the iteration's reduction scalars (correlate_common.hpp: RlStats) are summed in the epilogue and added to p.stats.
+template <int PZ, int PYX, int NW, int NCG, bool STATS>
 __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {   // (2 waves per SIMD: <= 256 VGPRs)
   using T = Geo<PZ, PYX, NW, NCG>;
   constexpr int C = T::C, CZ = T::CZ, TY = T::TY, EP = T::EP, NT = T::NT, TXW = T::TXW;
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
 #pragma unroll
     for (int i = 0; i < NP2; ++i) acc2[j][i] = splat(0.0f);
   }
+  lsr::RlStats st;
   float yv[2 * NP1], ye[EP], xc[2 * NP2];   // [2 i + h] = half h of pair i
 #pragma unroll
   for (int i = 0; i < 2 * NP1; ++i) yv[i] = 0.0f;
@@ -462,11 +464,16 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
 #pragma unroll
         for (int i = 0; i < NP2; ++i) {
           // (x * u) * rcp(H^T 1): the two-launch UPDATE's order
-          if (y0 + wave * RPW + pair_row<NCG>(i, 0) < Y && okc[0])   // (row test wave-uniform)
-            gstore<0>(obase + pair_row<NCG>(i, 0) * p.out_pitch, lane_off, xc[2 * i] * acc2[0][i].x * rn[2 * i]);
-          if (y0 + wave * RPW + pair_row<NCG>(i, 1) < Y && okc[NCG == 2 ? 1 : 0])
-            gstore<4 * pair_col<NCG>(1)>(obase + pair_row<NCG>(i, 1) * p.out_pitch, lane_off,
-                                         xc[2 * i + 1] * acc2[0][i].y * rn[2 * i + 1]);
+          const float xu0 = xc[2 * i] * acc2[0][i].x, xu1 = xc[2 * i + 1] * acc2[0][i].y;
+          const float v0 = xu0 * rn[2 * i], v1 = xu1 * rn[2 * i + 1];
+          if (y0 + wave * RPW + pair_row<NCG>(i, 0) < Y && okc[0]) {   // (row test wave-uniform)
+            gstore<0>(obase + pair_row<NCG>(i, 0) * p.out_pitch, lane_off, v0);
+            if constexpr (STATS) st.add(xc[2 * i], xu0, v0);
+          }
+          if (y0 + wave * RPW + pair_row<NCG>(i, 1) < Y && okc[NCG == 2 ? 1 : 0]) {
+            gstore<4 * pair_col<NCG>(1)>(obase + pair_row<NCG>(i, 1) * p.out_pitch, lane_off, v1);
+            if constexpr (STATS) st.add(xc[2 * i + 1], xu1, v1);
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);  // the refill reuses xc
@@ -566,12 +573,18 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
     slot = slot == 2 ? 0 : slot + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land after the wave has ended
+  if constexpr (STATS) lsr::rl_stats_flush<NW>(st, smem + T::OFF_B2, p.stats);
 }
 
 template <int PZ, int PYX>
 bool launch_one(const YsepArgs& p, dim3 grid, hipStream_t s) {
-  if (p.narrow) hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 4, 1>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 8, 2>), grid, dim3(512), 0, s, p);
+  if (p.stats != nullptr) {
+    if (p.narrow) hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 4, 1, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 8, 2, true>), grid, dim3(512), 0, s, p);
+  } else {
+    if (p.narrow) hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 4, 1, false>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 8, 2, false>), grid, dim3(512), 0, s, p);
+  }
   return true;
 }
 

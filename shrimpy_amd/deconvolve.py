@@ -26,7 +26,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["richardson_lucy", "RichardsonLucyPlan", "factor_psf", "correlate3d", "prepare_psf",
+__all__ = ["richardson_lucy", "RichardsonLucyPlan", "RLStats", "factor_psf", "correlate3d", "prepare_psf",
            "padded_shape", "PaddedVolume"]
 
 MAX_TAPS = 15
@@ -169,6 +169,33 @@ class PaddedVolume:
 
     def logical_ptr(self) -> int:
         return self.view.data_ptr()
+
+
+@dataclass
+class RLStats:
+    """Per-iteration reduction scalars of a Richardson-Lucy run (``include/lsrecon.h``, ``lsr_rl_*_stats_f32``), summed
+    by the kernels in the epilogue that writes the new estimate -- no extra pass over the volume.
+
+    ``flux[i]   = sum x_i * H^T(ratio_i) = sum x_{i+1} * H^T 1`` (what the update conserves; ``-> sum y`` as ``eps -> 0``),
+    ``change[i] = sum |x_{i+1} - x_i|``, ``total[i] = sum x_{i+1}``; ``rel_change = change / total`` is what ``tol`` tests.
+    ``iterations`` = launches that ran (``< `` the requested count when ``tol`` stopped the loop)."""
+
+    flux: np.ndarray
+    change: np.ndarray
+    total: np.ndarray
+    iterations: int
+    stopped_by_tol: bool = False
+
+    @property
+    def rel_change(self) -> np.ndarray:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.where(self.total > 0, self.change / self.total, 0.0)
+
+    @classmethod
+    def from_array(cls, a, iterations: int, stopped: bool = False) -> "RLStats":
+        a = np.asarray(a, dtype=np.float64).reshape(-1, 3)[:iterations]
+        return cls(flux=a[:, 0].copy(), change=a[:, 1].copy(), total=a[:, 2].copy(), iterations=int(iterations),
+                   stopped_by_tol=bool(stopped))
 
 
 @dataclass
@@ -366,11 +393,12 @@ class RichardsonLucyPlan:
         return PaddedVolume(self.shape, self._psf.shape, self.device)
 
     def iterate_padded(self, y_pad: "PaddedVolume", src: "PaddedVolume", dst: "PaddedVolume",
-                       eps: float = 1e-6) -> None:
+                       eps: float = 1e-6, stats=None) -> None:
         """One fused RL iteration between padded volumes of this plan's geometry: reads ``src``
         (and ``y_pad``), writes the logical window of ``dst``; no copies, no allocation.  The
         building block of the slab split (``shrimpy_amd.slab``), where halo rows are refreshed
-        between iterations."""
+        between iterations.  ``stats``: a float64 device tensor of 3 elements that receives this
+        iteration's (flux, change, total) over THIS volume (a slab's share: sum over the slabs)."""
         import torch
 
         if not self.fused:
@@ -387,58 +415,80 @@ class RichardsonLucyPlan:
         nz, ny, nx = self._norm
         with torch.cuda.device(self.device):
             # x_a = src (iteration 0 reads it), x_b = dst (iteration 0 writes it)
+            if stats is not None and (stats.dtype != torch.float64 or stats.numel() < 3 or stats.device != self.device):
+                raise ValueError("stats must be a float64 tensor of >= 3 elements on the plan's device")
             _lib.call(
-                "lsr_rl_sep_fused_f32", y_pad.logical_ptr(), y_pad.pitch, y_pad.plane, 0,
+                "lsr_rl_sep_fused_stats_f32", y_pad.logical_ptr(), y_pad.pitch, y_pad.plane, 0,
                 src.full.data_ptr(), dst.full.data_ptr(), None, z, yy, xx, self._fused_taps.data_ptr(),
                 ps.shape[0], ps.shape[1], ps.shape[2], nz.data_ptr(), ny.data_ptr(), nx.data_ptr(), 1,
-                ctypes.c_float(eps), _lib.stream_ptr(self.device),
+                ctypes.c_float(eps), None if stats is None else stats.data_ptr(), _lib.stream_ptr(self.device),
             )
 
-    def _iterate_ysep(self, y_ptr, y_pitch, y_plane, init, x_out, iterations, eps, stream, events):
-        """RL with ``psf = ky (x) kzx``: each correlation is the dense (z, x) stencil (PZ * PX FMAs per
+    def _ysep_nzx(self):
+        """(Z, X) table of the (z, x) stencil's border normalisation (sum of the kzx taps that land inside), float64 on
+        the device -- only the four-launch path's flux needs it (its last launch divides by ny alone)."""
+        import torch
+
+        q = self._ysep
+        if "nzx" not in q:
+            z, _, x = self.shape
+            kzx = self.psf.astype(np.float64).sum(axis=1)          # ky sums to 1: the (z, x) stencil
+            pz, px = kzx.shape
+            cs = np.zeros((pz + 1, px + 1))
+            cs[1:, 1:] = kzx.cumsum(0).cumsum(1)
+            zi, xi = np.arange(z), np.arange(x)
+            a0, a1 = np.maximum(0, pz // 2 - zi), np.minimum(pz, z - zi + pz // 2)
+            c0, c1 = np.maximum(0, px // 2 - xi), np.minimum(px, x - xi + px // 2)
+            t = cs[a1][:, c1] - cs[a0][:, c1] - cs[a1][:, c0] + cs[a0][:, c0]
+            q["nzx"] = torch.as_tensor(t, device=self.device)
+        return q["nzx"]
+
+    def _iterate_ysep(self, y_ptr, y_pitch, y_plane, init, x_out, it0, n, eps, stream, stats):
+        """RL with ``psf = ky (x) kzx``, iterations ``it0 .. it0 + n - 1`` (the estimate lives in ``x_pad`` between
+        calls; ``init`` is copied in when ``it0 == 0``): each correlation is the dense (z, x) stencil (PZ * PX FMAs per
         voxel instead of PZ * PY * PX) followed by the y pass that carries the epilogue --
         ``H x = Y~(ZX~(x))`` with ``ratio = y / (. + eps)`` in the y pass; ``H^T r = Y(ZX(r))`` with the
         (z, x) border normalisation in the stencil launch (``LSR_EPI_SCALE``) and ``x * . / ny`` in
-        the y pass.  Four launches per iteration, all on zero-haloed padded volumes."""
+        the y pass.  Four launches per iteration (two where both factors fit one kernel), all on zero-haloed padded
+        volumes.  ``stats``: float64 device tensor (iterations, 3), zeroed by the caller, or ``None``."""
+        import torch
+
         q = self._ysep
         x_pad, ratio_pad = self._scratch()
+        if it0 == 0:
+            x_pad.view.copy_(init)
+        z, yy, xx = self.shape
+        pitch, plane = x_pad.pitch, x_pad.plane
+        ceps = ctypes.c_float(eps)
+
+        def sptr(it):
+            return None if stats is None else stats.data_ptr() + 24 * it
+
         if q["fused"] is not None:
             # both factors in one launch per correlation (lsr_correlate_zxy_padded_f32): the y pass
             # runs inside the stencil kernel, wave by wave, on the staged plane
             f = q["fused"]
-            x_pad.view.copy_(init)
-            z, yy, xx = self.shape
             pz, py, px = self._psf.shape
-            pitch, plane = x_pad.pitch, x_pad.plane
-            ceps = ctypes.c_float(eps)
-            if events:
-                events[0].record()
-            for it in range(iterations):
-                last = it + 1 == iterations
+            for it in range(it0, it0 + n):
+                last = x_out is not None and it + 1 == it0 + n
                 _lib.call("lsr_correlate_zxy_padded_f32", x_pad.logical_ptr(), pitch, plane, y_ptr, y_pitch, y_plane,
                           ratio_pad.logical_ptr(), pitch, plane, z, yy, xx, f["taps_flipped"].data_ptr(),
                           q["ky_flipped"].data_ptr(), pz, py, px, _lib.EPI_RATIO, ceps, None,
                           ctypes.c_float(1.0), stream)
                 out_ptr, out_pitch, out_plane = ((x_out.data_ptr(), xx, yy * xx) if last
                                                  else (x_pad.logical_ptr(), pitch, plane))
-                _lib.call("lsr_correlate_zxy_padded_f32", ratio_pad.logical_ptr(), pitch, plane, x_pad.logical_ptr(),
+                _lib.call("lsr_correlate_zxy_padded_stats_f32", ratio_pad.logical_ptr(), pitch, plane, x_pad.logical_ptr(),
                           pitch, plane, out_ptr, out_pitch, out_plane, z, yy, xx, f["taps"].data_ptr(),
                           q["ky"].data_ptr(), pz, py, px, _lib.EPI_UPDATE, ceps, f["norm_table"].data_ptr(),
-                          ctypes.c_float(f["norm_full"]), stream)
+                          ctypes.c_float(f["norm_full"]), sptr(it), stream)
             return
         if self._t_pad is None:
             self._t_pad = PaddedVolume(self.shape, self._psf.shape, self.device)
         t_pad = self._t_pad
-        x_pad.view.copy_(init)
-        z, yy, xx = self.shape
         pz, _, px = q["zx_shape"]
-        pitch, plane = x_pad.pitch, x_pad.plane
         one, f0 = q["one"].data_ptr(), ctypes.c_float(0.0)
-        ceps = ctypes.c_float(eps)
-        if events:
-            events[0].record()
-        for it in range(iterations):
-            last = it + 1 == iterations
+        for it in range(it0, it0 + n):
+            last = x_out is not None and it + 1 == it0 + n
             _lib.call("lsr_correlate_dense_padded_f32", x_pad.logical_ptr(), pitch, plane, None, 0, 0,
                       t_pad.logical_ptr(), pitch, plane, z, yy, xx, q["taps_flipped"].data_ptr(), pz, 1, px,
                       _lib.EPI_NONE, f0, None, ctypes.c_float(1.0), stream)
@@ -450,19 +500,91 @@ class RichardsonLucyPlan:
                       _lib.EPI_SCALE, f0, q["norm_table"].data_ptr(), ctypes.c_float(q["norm_full"]), stream)
             out_ptr, out_pitch, out_plane = ((x_out.data_ptr(), xx, yy * xx) if last
                                              else (x_pad.logical_ptr(), pitch, plane))
-            _lib.call("lsr_correlate_sep_strided_f32", t_pad.logical_ptr(), pitch, plane, x_pad.logical_ptr(), pitch,
+            _lib.call("lsr_correlate_sep_strided_stats_f32", t_pad.logical_ptr(), pitch, plane, x_pad.logical_ptr(), pitch,
                       plane, out_ptr, out_pitch, out_plane, z, yy, xx, one, 1, q["ky"].data_ptr(), q["py"], one, 1,
                       _lib.EPI_UPDATE, ceps, q["ones_z"].data_ptr(), q["ny"].data_ptr(), q["ones_x"].data_ptr(),
-                      stream)
+                      sptr(it), stream)
+            if stats is not None:
+                # this launch's x * u is x * H^T(ratio) / nzx (the (z, x) normalisation went into the stencil launch): the
+                # flux of the full update, sum x_new * nzx * ny, is formed here from the new estimate -- this path is the
+                # fallback for y extents beyond the one-launch kernels, an extra reduction does not matter to it
+                x_new = x_out if last else x_pad.view
+                rows = torch.einsum("zyx,y->zx", x_new, q["ny"])
+                stats[it, 0] = (rows.double() * self._ysep_nzx()).sum()
 
     def release(self) -> None:
         """Drop the scratch volumes."""
         self._ratio = self._x_pad = self._ratio_pad = self._y_pad = self._t_pad = None
 
-    def __call__(self, y, iterations: int = 20, eps: float = 1e-6, x0=None, out=None, events=None):
+    # ------------------------------------------------------------------------------------------ the loop
+    def _launch(self, st, it0: int, n: int, x_out, stats) -> None:
+        """Iterations ``it0 .. it0 + n - 1`` of the run described by ``st`` (set up by ``__call__``); the last one
+        writes the dense ``x_out`` when that is not ``None``, otherwise the estimate stays in the working volume
+        ``_result_view(it0 + n)`` names.  ``stats``: float64 device tensor (iterations, 3), zero where not yet run."""
+        z, yy, xx = self.shape
+        ps = self._psf
+        stream, eps = st["stream"], ctypes.c_float(st["eps"])
+        y_ptr, y_pitch, y_plane = st["y"]
+        from_y = int(st["from_y"] and it0 == 0)
+        xo = None if x_out is None else x_out.data_ptr()
+        sp = None if stats is None else stats.data_ptr() + 24 * it0
+        kind = st["kind"]
+        if kind in ("fused", "fused-ysep"):
+            x_pad, ratio_pad = self._scratch()
+            bufs = (x_pad.full.data_ptr(), ratio_pad.full.data_ptr())   # iteration i reads bufs[i & 1], writes the other
+            a, b = bufs[it0 & 1], bufs[(it0 + 1) & 1]
+            if kind == "fused":
+                nz, ny, nx = self._norm
+                _lib.call("lsr_rl_sep_fused_stats_f32", y_ptr, y_pitch, y_plane, from_y, a, b, xo, z, yy, xx,
+                          self._fused_taps.data_ptr(), ps.shape[0], ps.shape[1], ps.shape[2], nz.data_ptr(),
+                          ny.data_ptr(), nx.data_ptr(), n, eps, sp, stream)
+            else:
+                f = self._ysep["fused"]
+                _lib.call("lsr_rl_ysep_fused_stats_f32", y_ptr, y_pitch, y_plane, from_y, a, b, xo, z, yy, xx,
+                          self._ysep["iter_taps"].data_ptr(), ps.shape[0], ps.shape[1], ps.shape[2],
+                          f["norm_table"].data_ptr(), ctypes.c_float(f["norm_full"]), n, eps, sp, stream)
+        elif kind == "separable":
+            x_pad, ratio_pad = self._scratch()
+            (kz, ky, kx), (fz, fy, fx) = ps.k, ps.k_flipped
+            nz, ny, nx = self._norm
+            _lib.call("lsr_rl_sep_stats_f32", y_ptr, y_pitch, y_plane, from_y, x_pad.full.data_ptr(),
+                      ratio_pad.full.data_ptr(), xo, z, yy, xx, kz.data_ptr(), fz.data_ptr(), ps.shape[0],
+                      ky.data_ptr(), fy.data_ptr(), ps.shape[1], kx.data_ptr(), fx.data_ptr(), ps.shape[2],
+                      nz.data_ptr(), ny.data_ptr(), nx.data_ptr(), n, eps, sp, stream)
+        elif kind == "ysep":
+            self._iterate_ysep(y_ptr, y_pitch, y_plane, st["init"], x_out, it0, n, st["eps"], stream, stats)
+        elif kind == "dense":
+            x_pad, ratio_pad = self._scratch()
+            _lib.call("lsr_rl_dense_padded_stats_f32", y_ptr, y_pitch, y_plane, from_y, x_pad.full.data_ptr(),
+                      ratio_pad.full.data_ptr(), xo, z, yy, xx, ps.taps.data_ptr(), ps.taps_flipped.data_ptr(),
+                      ps.shape[0], ps.shape[1], ps.shape[2], ps.norm_table.data_ptr(), ctypes.c_float(ps.norm_full),
+                      n, eps, sp, stream)
+        else:   # generic: dense volumes, x updated in place
+            _lib.call("lsr_rl_dense_stats_f32", st["y_dense"].data_ptr(), st["x"].data_ptr(), self._scratch().data_ptr(),
+                      z, yy, xx, ps.w.data_ptr(), ps.w_flipped.data_ptr(), ps.shape[0], ps.shape[1], ps.shape[2],
+                      ps.norm_table.data_ptr(), n, eps, sp, stream)
+
+    def _result_view(self, st, done: int):
+        """Where the estimate is after ``done`` iterations that did not write the dense output."""
+        if st["kind"] == "generic":
+            return st["x"]
+        x_pad, ratio_pad = self._scratch()
+        if st["kind"] in ("fused", "fused-ysep"):
+            return (x_pad, ratio_pad)[done & 1].view
+        return x_pad.view
+
+    def __call__(self, y, iterations: int = 20, eps: float = 1e-6, x0=None, out=None, events=None, *,
+                 stats: bool = False, tol: float | None = None):
         """Run RL.  ``events`` = optional ``(start, end)`` torch events recorded on the launch
         stream right around the kernel launches (``iterations`` fused launches, or
-        ``2 * iterations`` ratio / update launches) -- what ``bench.py`` times."""
+        ``2 * iterations`` ratio / update launches) -- what ``bench.py`` times.
+
+        ``stats=True``: the kernels also sum the iteration's reduction scalars in their epilogues
+        (:class:`RLStats`; read them afterwards from ``plan.last_stats`` -- the device tensor is
+        ``plan.stats_device``, one row per iteration).  ``tol``: stop as soon as the relative change
+        ``sum|x_new - x| / sum x_new`` of an iteration falls below it.  The scalars of iteration i are read back while
+        iteration i + 1 runs, so the GPU never waits for the host; the estimate returned is therefore the one
+        iteration past the first that met ``tol`` (``plan.last_stats.iterations`` says how many ran)."""
         import torch
 
         y_padded = None
@@ -482,6 +604,8 @@ class RichardsonLucyPlan:
             raise ValueError("iterations must be >= 0")
         if not eps > 0:
             raise ValueError("eps must be > 0")
+        if tol is not None and not (tol >= 0 and np.isfinite(tol)):
+            raise ValueError("tol must be a finite number >= 0")
         # x0 = y with a padded y needs no initial copy: the first iteration reads y directly
         from_y = y_padded is not None and x0 is None and iterations > 0
         y_ptr, y_pitch, y_plane = ((y_padded.logical_ptr(), y_padded.pitch, y_padded.plane)
@@ -496,17 +620,24 @@ class RichardsonLucyPlan:
             x = _lib.require_device_f32(out, "out")
             if tuple(x.shape) != self.shape or x.data_ptr() == y.data_ptr():
                 raise ValueError("out must have the volume shape and must not alias y")
+        self.last_stats = None
+        self.stats_device = None
         if iterations == 0:
             x.copy_(init)
+            if stats or tol is not None:
+                self.last_stats = RLStats.from_array(np.zeros((0, 3)), 0)
             return x
-        z, yy, xx = self.shape
         ps = self._psf
+        want_stats = bool(stats) or tol is not None
         with torch.cuda.device(self.device):
-            stream = _lib.stream_ptr(self.device)
-            if ps.separable and self.fused:
+            st = dict(stream=_lib.stream_ptr(self.device), eps=float(eps), init=init)
+            padded_y_kinds = {"fused": ps.separable and self.fused,
+                              "fused-ysep": (not ps.separable) and self._ysep is not None and self.fused_ysep}
+            if padded_y_kinds["fused"] or padded_y_kinds["fused-ysep"]:
                 # one launch per iteration; y must be a zero-haloed padded volume (the kernel
                 # reads it on the tile grown by the PSF radius)
-                x_pad, ratio_pad = self._scratch()
+                st["kind"] = "fused" if padded_y_kinds["fused"] else "fused-ysep"
+                x_pad, _ = self._scratch()
                 if y_padded is None:
                     if self._y_pad is None:
                         self._y_pad = PaddedVolume(self.shape, ps.shape, self.device)
@@ -516,92 +647,75 @@ class RichardsonLucyPlan:
                     from_y = x0 is None
                 if not from_y:
                     x_pad.view.copy_(init)
-                nz, ny, nx = self._norm
-                if events:
-                    events[0].record()
-                _lib.call(
-                    "lsr_rl_sep_fused_f32", y_ptr, y_pitch, y_plane, int(from_y),
-                    x_pad.full.data_ptr(), ratio_pad.full.data_ptr(),
-                    x.data_ptr(), z, yy, xx, self._fused_taps.data_ptr(), ps.shape[0], ps.shape[1],
-                    ps.shape[2], nz.data_ptr(), ny.data_ptr(), nx.data_ptr(), iterations,
-                    ctypes.c_float(eps), stream,
-                )
-            elif ps.separable:
+            elif ps.separable or ps.taps is not None and self._ysep is None:
                 # working volumes carry a zero halo: the kernels never bounds-check a load
-                x_pad, ratio_pad = self._scratch()
+                st["kind"] = "separable" if ps.separable else "dense"
+                x_pad, _ = self._scratch()
                 if not from_y:
                     x_pad.view.copy_(init)
-                (kz, ky, kx), (fz, fy, fx) = ps.k, ps.k_flipped
-                nz, ny, nx = self._norm
-                if events:
-                    events[0].record()
-                _lib.call(
-                    "lsr_rl_sep_f32", y_ptr, y_pitch, y_plane, int(from_y),
-                    x_pad.full.data_ptr(), ratio_pad.full.data_ptr(),
-                    x.data_ptr(), z, yy, xx, kz.data_ptr(), fz.data_ptr(), ps.shape[0],
-                    ky.data_ptr(), fy.data_ptr(), ps.shape[1], kx.data_ptr(), fx.data_ptr(),
-                    ps.shape[2], nz.data_ptr(), ny.data_ptr(), nx.data_ptr(), iterations,
-                    ctypes.c_float(eps), stream,
-                )
-            elif self._ysep is not None and self.fused_ysep:
-                # one launch per iteration; y must be a zero-haloed padded volume, as for the separable fused kernel
-                x_pad, ratio_pad = self._scratch()
-                if y_padded is None:
-                    if self._y_pad is None:
-                        self._y_pad = PaddedVolume(self.shape, ps.shape, self.device)
-                    self._y_pad.view.copy_(y)
-                    y_padded = self._y_pad
-                    y_ptr, y_pitch, y_plane = y_padded.logical_ptr(), y_padded.pitch, y_padded.plane
-                    from_y = x0 is None
-                if not from_y:
-                    x_pad.view.copy_(init)
-                f = self._ysep["fused"]
-                if events:
-                    events[0].record()
-                _lib.call(
-                    "lsr_rl_ysep_fused_f32", y_ptr, y_pitch, y_plane, int(from_y), x_pad.full.data_ptr(),
-                    ratio_pad.full.data_ptr(), x.data_ptr(), z, yy, xx, self._ysep["iter_taps"].data_ptr(),
-                    ps.shape[0], ps.shape[1], ps.shape[2], f["norm_table"].data_ptr(), ctypes.c_float(f["norm_full"]),
-                    iterations, ctypes.c_float(eps), stream,
-                )
             elif self._ysep is not None:
-                self._iterate_ysep(y_ptr, y_pitch, y_plane, init, x, iterations, eps, stream, events)
-            elif ps.taps is not None:
-                x_pad, ratio_pad = self._scratch()
-                if not from_y:
-                    x_pad.view.copy_(init)
-                if events:
-                    events[0].record()
-                _lib.call(
-                    "lsr_rl_dense_padded_f32", y_ptr, y_pitch, y_plane, int(from_y), x_pad.full.data_ptr(),
-                    ratio_pad.full.data_ptr(), x.data_ptr(), z, yy, xx, ps.taps.data_ptr(),
-                    ps.taps_flipped.data_ptr(), ps.shape[0], ps.shape[1], ps.shape[2],
-                    ps.norm_table.data_ptr(), ctypes.c_float(ps.norm_full), iterations,
-                    ctypes.c_float(eps), stream,
-                )
+                st["kind"] = "ysep"
             else:
+                st["kind"] = "generic"
                 x.copy_(init)
-                ratio = self._scratch()
-                if events:
-                    events[0].record()
-                _lib.call(
-                    "lsr_rl_dense_f32", y.data_ptr(), x.data_ptr(), ratio.data_ptr(), z, yy, xx,
-                    ps.w.data_ptr(), ps.w_flipped.data_ptr(), ps.shape[0], ps.shape[1], ps.shape[2],
-                    ps.norm_table.data_ptr(), iterations, ctypes.c_float(eps), stream,
-                )
+                st["x"], st["y_dense"] = x, y
+            st["y"], st["from_y"] = (y_ptr, y_pitch, y_plane), from_y
+            dev_stats = None
+            if want_stats:
+                dev_stats = torch.zeros((iterations, 3), dtype=torch.float64, device=self.device)
+            if events:
+                events[0].record()
+            if tol is None:
+                self._launch(st, 0, iterations, None if st["kind"] == "generic" else x, dev_stats)
+                done, stopped = iterations, False
+            else:
+                done, stopped = self._run_to_tolerance(st, iterations, float(tol), dev_stats)
+                if st["kind"] != "generic":
+                    x.copy_(self._result_view(st, done))
             if events:
                 events[1].record()
+            if want_stats:
+                self.stats_device = dev_stats
+                self.last_stats = RLStats.from_array(dev_stats.cpu().numpy(), done, stopped)
         _lib.mark_written(x)
         return x
 
+    def _run_to_tolerance(self, st, iterations: int, tol: float, dev_stats):
+        """One launch group per iteration; iteration i's scalars travel to pinned host memory behind it and are looked at
+        after iteration i + 1 has been queued.  Returns (iterations run, stopped early)."""
+        import torch
+
+        host = torch.empty((iterations, 3), dtype=torch.float64).pin_memory()
+        arrived = [torch.cuda.Event() for _ in range(iterations)]
+
+        def met(i):
+            arrived[i].synchronize()
+            change, total = float(host[i, 1]), float(host[i, 2])
+            return total > 0 and change <= tol * total or total == 0
+
+        done = 0
+        for it in range(iterations):
+            self._launch(st, it, 1, None, dev_stats)
+            host[it].copy_(dev_stats[it], non_blocking=True)
+            arrived[it].record()
+            done = it + 1
+            if it >= 1 and met(it - 1):
+                return done, True
+        return done, bool(met(iterations - 1))
+
 
 def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=None, *,
-                    separable: str = "auto", separable_rtol: float = 1e-6, psf_factors=None):
+                    separable: str = "auto", separable_rtol: float = 1e-6, psf_factors=None,
+                    tol: float | None = None, return_stats: bool = False):
     """Richardson-Lucy deconvolution of a (Z, Y, X) float32 device tensor; returns a new tensor.
 
     ``psf`` is used as given (normalise it to sum 1 for flux conservation).  ``x0`` defaults to
     ``y``.  ``separable="auto"`` takes the rank-1 fast path when the PSF factorises within
     ``separable_rtol``; pass ``psf_factors=(kz, ky, kx)`` to skip the test.
+
+    ``tol``: stop before ``iterations`` once an iteration's relative change ``sum|x_new - x| / sum x_new`` is below
+    it (the kernels sum both in their epilogues; see :class:`RLStats`).  ``return_stats=True`` returns
+    ``(estimate, RLStats)`` -- flux, change and total per iteration that ran.
     """
     import torch
 
@@ -616,10 +730,11 @@ def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=Non
         from . import host
 
         return host.richardson_lucy(y, psf, iterations, eps, x0, separable=separable, separable_rtol=separable_rtol,
-                                    psf_factors=psf_factors)
+                                    psf_factors=psf_factors, tol=tol, return_stats=return_stats)
     plan = RichardsonLucyPlan(tuple(y.shape), psf, y.device, separable=separable,
                               separable_rtol=separable_rtol, psf_factors=psf_factors)
-    return plan(y, iterations=iterations, eps=eps, x0=x0)
+    x = plan(y, iterations=iterations, eps=eps, x0=x0, stats=return_stats, tol=tol)
+    return (x, plan.last_stats) if return_stats else x
 
 
 def correlate3d(volume, weights=None, *, weight_factors=None, tuned: bool = True):

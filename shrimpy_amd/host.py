@@ -169,13 +169,20 @@ def correlate3d(volume, weights=None, weight_factors=None):
 
 
 def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=None, *, separable: str = "auto",
-                    separable_rtol: float = 1e-6, psf_factors=None):
+                    separable_rtol: float = 1e-6, psf_factors=None, tol: float | None = None,
+                    return_stats: bool = False):
     """``deconvolve.richardson_lucy`` for a CPU tensor: ``x <- x * H^T(y / (H x + eps)) / H^T 1`` with the two
     correlations and their epilogues as the host twins of the device launches (rank-1 PSFs run the
-    separable form, others the dense one)."""
+    separable form, others the dense one).  ``tol`` / ``return_stats``: the iteration scalars of
+    ``deconvolve.RLStats``, summed by the twins' UPDATE pass; the loop stops after the first iteration whose relative
+    change is below ``tol``."""
     import torch
 
-    from .deconvolve import MAX_TAPS, _axis_norm, _prefix_table, factor_psf, prepare_psf
+    from .deconvolve import MAX_TAPS, RLStats, _axis_norm, _prefix_table, factor_psf, prepare_psf
+
+    if tol is not None and not (tol >= 0 and np.isfinite(tol)):
+        raise ValueError("tol must be a finite number >= 0")
+    want = bool(return_stats) or tol is not None
 
     y = _f32(y, "y")
     if separable not in ("auto", "force", "never"):
@@ -201,7 +208,11 @@ def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=Non
         raise ValueError(f"x0 must be {tuple(y.shape)}")
     x = init.clone()
     if iterations == 0:
-        return x
+        return (x, RLStats.from_array(np.zeros((0, 3)), 0)) if return_stats else x
+    stats = np.zeros((iterations, 3), dtype=np.float64) if want else None
+
+    def met(i):
+        return stats[i, 2] == 0 or stats[i, 1] <= tol * stats[i, 2]
     z, yy, xx = (int(v) for v in y.shape)
     ratio, nxt = torch.empty_like(y), torch.empty_like(y)
     e = ctypes.c_float(eps)
@@ -212,18 +223,32 @@ def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=Non
         norm = [_axis_norm(f, n) for f, n in zip(factors, (z, yy, xx))]
         sizes = [len(f) for f in k]
 
-        def corr(src, dst, aux, taps, epi):
-            _lib.call("lsr_correlate_sep_f32_cpu", src.data_ptr(), dst.data_ptr(), aux.data_ptr(), z, yy, xx,
+        def corr(src, dst, aux, taps, epi, srow=None):
+            _lib.call("lsr_correlate_sep_stats_f32_cpu", src.data_ptr(), dst.data_ptr(), aux.data_ptr(), z, yy, xx,
                       taps[0].ctypes.data, sizes[0], taps[1].ctypes.data, sizes[1], taps[2].ctypes.data, sizes[2], epi, e,
-                      norm[0].ctypes.data, norm[1].ctypes.data, norm[2].ctypes.data, None)
-    else:    # the dense loop is one native call (the twin of lsr_rl_dense_f32: x updated in place)
+                      norm[0].ctypes.data, norm[1].ctypes.data, norm[2].ctypes.data,
+                      None if srow is None else srow.ctypes.data, None)
+    else:    # the dense loop is one native call per chunk (the twin of lsr_rl_dense_f32: x updated in place)
         k, kf = _taps(w), _taps(w[::-1, ::-1, ::-1])
         table = np.ascontiguousarray(_prefix_table(w).ravel(), dtype=np.float64)
-        _lib.call("lsr_rl_dense_f32_cpu", y.data_ptr(), x.data_ptr(), ratio.data_ptr(), z, yy, xx, k.ctypes.data,
-                  kf.ctypes.data, w.shape[0], w.shape[1], w.shape[2], table.ctypes.data, iterations, e, None)
-        return x
-    for _ in range(iterations):
+        done, stopped = 0, False
+        step = iterations if tol is None else 1
+        while done < iterations:
+            _lib.call("lsr_rl_dense_stats_f32_cpu", y.data_ptr(), x.data_ptr(), ratio.data_ptr(), z, yy, xx, k.ctypes.data,
+                      kf.ctypes.data, w.shape[0], w.shape[1], w.shape[2], table.ctypes.data, step, e,
+                      None if stats is None else stats[done:].ctypes.data, None)
+            done += step
+            if tol is not None and met(done - 1):
+                stopped = True
+                break
+        return (x, RLStats.from_array(stats, done, stopped)) if return_stats else x
+    done, stopped = 0, False
+    for it in range(iterations):
         corr(x, ratio, y, kf, _lib.EPI_RATIO)       # ratio = y / (H x + eps): H = correlation with the flipped taps
-        corr(ratio, nxt, x, k, _lib.EPI_UPDATE)     # x <- x * H^T ratio / H^T 1
+        corr(ratio, nxt, x, k, _lib.EPI_UPDATE, None if stats is None else stats[it])     # x <- x * H^T ratio / H^T 1
         x, nxt = nxt, x
-    return x
+        done = it + 1
+        if tol is not None and met(it):
+            stopped = True
+            break
+    return (x, RLStats.from_array(stats, done, stopped)) if return_stats else x

@@ -97,6 +97,39 @@ def test_rl_full_size_is_finite_non_negative_and_conserves_weighted_flux(scene, 
     assert abs(float(flux / total) - 1.0) < 1e-4
 
 
+def test_rl_full_size_scalars_from_the_epilogue(scene, deconvolved, device):
+    """VERDICT r3 row g at config 2: the fused launch's own sums -- flux of every iteration within 1e-4 of sum y, the
+    last iteration's total / change equal to torch's fp64 reductions of the estimates (rel 1e-5), the two-launch form
+    the same scalars, the estimate untouched, and tol stops the loop where the relative change says."""
+    import torch
+
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+
+    _, deskewed = scene
+    plan, factors, x20 = deconvolved
+    x = plan(deskewed, iterations=20, stats=True)
+    assert torch.equal(x, x20)
+    s = plan.last_stats
+    total_y = float(deskewed.double().sum())
+    assert np.all(np.abs(s.flux / total_y - 1.0) < 1e-4), s.flux / total_y
+    x19 = plan(deskewed, iterations=19)
+    assert abs(s.total[19] / float(x20.double().sum()) - 1.0) < 1e-5
+    assert abs(s.total[18] / float(x19.double().sum()) - 1.0) < 1e-5
+    assert abs(s.change[19] / float((x20.double() - x19.double()).abs().sum()) - 1.0) < 1e-5
+    assert np.all(np.diff(s.rel_change) < 0), "the relative change of RL on a bead scene falls monotonically"
+    del x19
+    two = RichardsonLucyPlan(tuple(deskewed.shape), None, device, psf_factors=factors, fused="never")
+    two(deskewed, iterations=3, stats=True)
+    for name in ("flux", "change", "total"):
+        np.testing.assert_allclose(getattr(two.last_stats, name), getattr(s, name)[:3], rtol=1e-6, err_msg=name)
+    two.release()
+    tol = float(0.5 * (s.rel_change[9] + s.rel_change[10]))
+    xt = plan(deskewed, iterations=20, tol=tol)
+    st = plan.last_stats
+    assert st.stopped_by_tol and st.iterations in (11, 12), st.iterations
+    assert torch.equal(xt, plan(deskewed, iterations=st.iterations))
+
+
 @pytest.mark.parametrize("where", ["interior", "corner"])
 def test_rl_full_size_matches_the_oracle_on_a_crop_with_full_margin(scene, deconvolved, where):
     """20 iterations reach 20 * 2 * (4, 3, 3) = (160, 120, 120) voxels: all of z, 120 in the plane."""
