@@ -181,7 +181,21 @@ struct RlStats {
     change += __builtin_fabsf(x_new - x_old);
     total += x_new;
   }
+  __device__ __forceinline__ void pin() { asm volatile("" : "+v"(flux), "+v"(change), "+v"(total)); }
 };
+// The hand-pipelined kernels end with loads in flight into registers whose values nobody will read (the prefetches of
+// planes past the last one).  To the compiler those registers are dead after their last use, and the kernels' final
+// `s_waitcnt vmcnt(0)` is a volatile asm, which orders other volatile asms but no plain arithmetic: code that follows
+// the loop -- the reduction's lane arithmetic -- may be scheduled above the wait INTO such a register, and the load
+// then lands on top of it (round 4: one instance in forty-nine returned sums that were off by 1e-3, differently every
+// run).  Naming every in-flight destination in an (empty) volatile asm BEHIND the wait keeps it allocated up to there.
+template <typename V>
+__device__ __forceinline__ void keep_until_here(V& v) { asm volatile("" : "+v"(v)); }
+template <typename V, int K>
+__device__ __forceinline__ void keep_until_here(V (&a)[K]) {
+#pragma unroll
+  for (int i = 0; i < K; ++i) asm volatile("" : "+v"(a[i]));
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);

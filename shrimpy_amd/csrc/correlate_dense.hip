@@ -66,10 +66,10 @@ __device__ __forceinline__ const float* uniform_ptr(const float* p) {
   return reinterpret_cast<const float*>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 __device__ __forceinline__ void gload_x4(f32x4& dst, const float* sbase, int voff_bytes) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void gload_x1(float& dst, const float* sbase, int voff_bytes) {
-  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+  asm volatile("global_load_dword %0, %1, %2" : "+v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_loads(f32x4& a, f32x4& b) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
     s_voff[k] = (r * p.in_pitch + 4 * c) * 4;
     s_loff[k] = e;
   }
-  f32x4 st0[T::SL], st1[T::SL];
+  f32x4 st0[T::SL] = {}, st1[T::SL] = {};   // (initialised: in/out operands of the asm loads)
 
   // ---- compute / epilogue geometry: column `lane`, rows 4*wave .. 4*wave+3
   const int acol = (wave * kRun) * T::PA + lane;
@@ -382,6 +382,11 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (EPI == LSR_EPI_UPDATE) {
+    lsr::keep_until_here(st0);   // (in-flight prefetches: correlate_common.hpp, keep_until_here)
+    lsr::keep_until_here(st1);
+    lsr::keep_until_here(aux0);
+    lsr::keep_until_here(aux1);
+    stats.pin();
     if (p.stats) lsr::rl_stats_flush<kWaves>(stats, reinterpret_cast<float*>(bufA4), p.stats);
   }
 }

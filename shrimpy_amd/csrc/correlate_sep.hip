@@ -86,11 +86,16 @@ __device__ __forceinline__ float fast_rcp(float d) {
 }
 
 // ---- hand-managed global loads: scalar base + unsigned 32-bit byte offset per lane -------------
+// The destination is an IN/OUT operand ("+v"), as in rl_fused_sep.hip: a register that is loaded again before its value
+// was read -- the prologue's placeholder loads, the prefetches of the planes past the last one -- must stay the same
+// physical register while the older load is in flight.  As a pure output ("=v") the older value is dead to the compiler
+// and the register free between the two loads: round 4 found the <13, 9, 9> instance computing LDS offsets in such a
+// register, and the in-flight load landing on top of them (results that differed from run to run).
 __device__ __forceinline__ void gload_x4(f32x4& dst, const float* sbase, int voff_bytes) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void gload_x1(float& dst, const float* sbase, int voff_bytes) {
-  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+  asm volatile("global_load_dword %0, %1, %2" : "+v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
 }
 // Wait until at most N vector-memory operations are outstanding; the registers are passed
 // through so that every later use depends on this statement.
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
     s_voff[k] = (r * p.in_pitch + 4 * c) * 4;
     s_loff[k] = e;
   }
-  f32x4 st0[SL], st1[SL];  // plane q is staged in set q & 1
+  f32x4 st0[SL] = {}, st1[SL] = {};  // plane q is staged in set q & 1 (initialised: in/out operands of the loads)
 
   // ---- x pass: lane -> (row-segment, x group) by hardware b128 lane group; a row-segment is one
   // 64-column run of one staged row, item `it` of this thread is row-segment xrs0 + 32*it
@@ -425,6 +430,13 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land after the wave has ended
   if constexpr (EPI == LSR_EPI_UPDATE) {
+    lsr::keep_until_here(st0);   // (in-flight prefetches: correlate_common.hpp, keep_until_here)
+    lsr::keep_until_here(st1);
+    lsr::keep_until_here(aux0);
+    lsr::keep_until_here(aux1);
+    lsr::keep_until_here(nzv0);
+    lsr::keep_until_here(nzv1);
+    stats.pin();
     if (p.stats) lsr::rl_stats_flush<kWaves>(stats, reinterpret_cast<float*>(bufB4), p.stats);
   }
 }

@@ -351,7 +351,17 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
 #pragma unroll
   for (int i = 0; i < 2 * RUN; ++i) xc[i] = 0.0f;
   const f32x2 rnx2 = f32x2{rnx[0], rnx[1]};
-  lsr::RlStats st;
+  // the iteration's scalars (STATS): packed running sums -- a pair = the thread's two column groups, like everything else
+  // here -- so that a row pair costs five instructions (two v_pk_add, one v_pk_add with a negated operand, two v_add |.|)
+  f32x2 st_flux = splat(0.0f), st_total = splat(0.0f);
+  float st_change = 0.0f;
+  auto st_add = [&](f32x2 x_old, f32x2 xu, f32x2 v) {
+    st_flux += xu;
+    st_total += v;
+    const f32x2 d = v - x_old;
+    st_change += __builtin_fabsf(d.x);
+    st_change += __builtin_fabsf(d.y);
+  };
   __builtin_amdgcn_sched_barrier(0);  // setup loads (taps, norms) are consumed above this line
 
   auto clampz = [&](int z) { return min(max(z, 0), Z - 1); };
@@ -513,27 +523,25 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
           // x * u / n with x = 0 from the zero halo
 #pragma unroll
           for (int m = 0; m < RUN; ++m) {
-            const f32x2 xu = f32x2{xc[m], xc[RUN + m]} * acc2[0][m];
+            const f32x2 xo = f32x2{xc[m], xc[RUN + m]};
+            const f32x2 xu = xo * acc2[0][m];
             const f32x2 v = xu * (splat(rz * rny_lds[wave * RUN + m]) * rnx2);
             gstore<0>(obase, o_voff[m], v.x);
             gstore<256>(obase, o_voff[m], v.y);
-            if constexpr (STATS) {   // (points past the volume: x = 0 from the halo, all three terms 0)
-              st.add(xc[m], xu.x, v.x);
-              st.add(xc[RUN + m], xu.y, v.y);
-            }
+            if constexpr (STATS) st_add(xo, xu, v);   // (points past the volume: x = 0 from the halo, all three terms 0)
           }
         } else {  // the dense result of the last iteration: masked to the volume
           const bool ok0 = x0 + lane < X, ok1 = x0 + lane + 64 < X;
 #pragma unroll
           for (int m = 0; m < RUN; ++m) {
             if (y0 + wave * RUN + m < Y) {  // wave-uniform
-              const f32x2 xu = f32x2{xc[m], xc[RUN + m]} * acc2[0][m];
+              const f32x2 xo = f32x2{xc[m], xc[RUN + m]};
+              const f32x2 xu = xo * acc2[0][m];
               const f32x2 v = xu * (splat(rz * rny_lds[wave * RUN + m]) * rnx2);
               if (ok0) gstore<0>(obase, o_voff[m], v.x);
               if (ok1) gstore<256>(obase, o_voff[m], v.y);
-              if constexpr (STATS) {
-                if (ok0) st.add(xc[m], xu.x, v.x);
-                if (ok1) st.add(xc[RUN + m], xu.y, v.y);
+              if constexpr (STATS) {   // columns past the volume hold x = 0 (zero halo): they add nothing
+                st_add(xo, xu, v);
               }
             }
           }
@@ -639,7 +647,19 @@ __global__ __launch_bounds__(kThreads) void rl_fused_sep_kernel(FusedArgs p) {
     slot = slot == 2 ? 0 : slot + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land after the wave has ended
-  if constexpr (STATS) lsr::rl_stats_flush<kWaves>(st, smem + T::OFF_B2, p.stats);
+  if constexpr (STATS) {
+    // the registers the last prefetches land in stay allocated up to here, and the sums start from here (behind the wait)
+    lsr::keep_until_here(xc);
+    lsr::keep_until_here(yv);
+    lsr::keep_until_here(ye);
+    lsr::keep_until_here(nzv);
+    asm volatile("" : "+v"(st_flux), "+v"(st_total), "+v"(st_change));
+    lsr::RlStats st;
+    st.flux = st_flux.x + st_flux.y;
+    st.change = st_change;
+    st.total = st_total.x + st_total.y;
+    lsr::rl_stats_flush<kWaves>(st, smem + T::OFF_B2, p.stats);
+  }
 #ifdef LSR_FUSED_PROBE_TIME
   if (p.probe && tid == 0) p.probe[4 * blockIdx.x + 3] = wall_clock64();
 #endif

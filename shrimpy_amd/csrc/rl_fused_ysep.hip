@@ -573,7 +573,13 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
     slot = slot == 2 ? 0 : slot + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land after the wave has ended
-  if constexpr (STATS) lsr::rl_stats_flush<NW>(st, smem + T::OFF_B2, p.stats);
+  if constexpr (STATS) {
+    lsr::keep_until_here(xc);    // (in-flight prefetches: correlate_common.hpp, keep_until_here)
+    lsr::keep_until_here(yv);
+    lsr::keep_until_here(ye);
+    st.pin();
+    lsr::rl_stats_flush<NW>(st, smem + T::OFF_B2, p.stats);
+  }
 }
 
 template <int PZ, int PYX>

@@ -71,6 +71,38 @@ def test_rl_scalars_match_the_oracle_on_every_path(device, name, make_psf, kw, p
     _check(plan.last_stats, o.rl_iteration_scalars(y, psf, 2, x0=np.full(vshape, float(y.mean()), np.float32)), 2)
 
 
+@pytest.mark.parametrize("fused", ["always", "never"])
+def test_rl_scalars_equal_fp64_reductions_of_the_estimates_for_every_compiled_extent(device, fused):
+    """Every template instance of the one-launch and the two-launch kernels (tap counts 3 .. 15 per axis, all tile
+    classes), awkward volume extents: the epilogue's sums against torch's fp64 reductions of consecutive estimates.
+    (Round 4 found the sums of ONE instance corrupted by prefetches still in flight at the kernel's end -- the
+    reduction's temporaries had been given the registers those loads land in; see RlStats::pin.)"""
+    import torch
+
+    from shrimpy_amd import _lib
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+
+    rng = np.random.default_rng(11)
+    odd = [3, 5, 7, 9, 11, 13, 15]
+    cases = [(a, b, b) for a in odd for b in odd]
+    for i, pshape in enumerate(cases):
+        if fused == "always" and not _lib.call_value("lsr_rl_sep_fused_supported", *pshape):
+            continue
+        vshape = (int(rng.integers(6, 30)), int(rng.choice([17, 40, 64, 70])), int(rng.choice([64, 100, 128, 200])))
+        factors = [np.abs(rng.normal(1.0, 0.4, n)).astype(np.float32) + 0.05 for n in pshape]
+        factors = [f / f.sum() for f in factors]
+        y = _t((rng.random(vshape) * 80 + 1).astype(np.float32), device)
+        plan = RichardsonLucyPlan(vshape, None, device, psf_factors=factors, fused=fused)
+        xs = [y] + [plan(y, iterations=n) for n in (1, 2, 3)]
+        plan(y, iterations=3, stats=True)
+        s = plan.last_stats
+        for n in range(3):
+            tot = float(xs[n + 1].double().sum())
+            chg = float((xs[n + 1].double() - xs[n].double()).abs().sum())
+            assert abs(s.total[n] / tot - 1) < RTOL and abs(s.change[n] / chg - 1) < RTOL, (pshape, vshape, n, s)
+        np.testing.assert_allclose(s.flux, float(y.double().sum()), rtol=RTOL, err_msg=str((pshape, vshape)))
+
+
 def test_rl_tol_stops_early_and_returns_that_iterations_estimate(device):
     import torch
 

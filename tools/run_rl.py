@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--grid", default="171,2048,2270")
+    ap.add_argument("--stats", action="store_true", help="sum the iteration scalars in the epilogues (the *_stats entries)")
     args = ap.parse_args()
     import torch
 
@@ -44,7 +45,7 @@ def main():
     best = None
     for _ in range(args.reps):
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        plan(ypad, iterations=args.iters, out=out, events=ev)
+        plan(ypad, iterations=args.iters, out=out, events=ev, stats=args.stats)
         torch.cuda.synchronize()
         ms = ev[0].elapsed_time(ev[1])
         best = ms if best is None else min(best, ms)
@@ -52,6 +53,8 @@ def main():
     n = shape[0] * shape[1] * shape[2]
     print(json.dumps({"path": plan.path, "grid": list(shape), "iters": args.iters, "ms_per_launch": best / launches,
                       "ms_per_iteration": best / args.iters, "algorithmic_GBps_per_launch": 12.0 * n / (best / launches) / 1e6,
+                      "stats": args.stats, "flux_over_sum_y": (None if not args.stats else
+                                                               [float(v) / float(y.double().sum()) for v in plan.last_stats.flux]),
                       "checksum": float(out.double().mean())}))
 
 
