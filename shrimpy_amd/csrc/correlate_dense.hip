@@ -219,12 +219,12 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
   const int zi_begin = max(zb - cz, 0);
   const int zi_end = ze + cz;
 
-  auto fetch = [&](int zplane, f32x4 (&st)[T::SL]) {
+  auto fetch = [&](int zplane, f32x4 (&st)[T::SL]) __attribute__((always_inline)) {
     const float* src = uniform_ptr(in_tile + static_cast<int64_t>(min(max(zplane, 0), Z - 1)) * p.in_plane);
     gload_x4(st[0], src, s_voff[0]);
     gload_x4(st[1], src, s_voff[1]);
   };
-  auto fetch_aux = [&](int zout, float (&aux)[kRun]) {
+  auto fetch_aux = [&](int zout, float (&aux)[kRun]) __attribute__((always_inline)) {
     if constexpr (kAux) {
       const float* a = uniform_ptr(p.aux + static_cast<int64_t>(min(max(zout, 0), Z - 1)) * p.aux_plane);
 #pragma unroll
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
 
   // Iteration zi consumes plane zi+1 (committed one iteration earlier into A[par^1]).
   auto iteration = [&](const int zi, const int par, f32x4 (&st)[T::SL], float (&aux_use)[kRun],
-                       float (&aux_load)[kRun]) {
+                       float (&aux_load)[kRun]) __attribute__((always_inline)) {
     f32x4* A_commit = bufA4 + par * (T::ASZ / 4);  // plane zi+2
     const float* A_c = reinterpret_cast<const float*>(bufA4 + (par ^ 1) * (T::ASZ / 4)) + acol;
 

@@ -275,12 +275,12 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
   const int zi_end = ze + cz;  // exclusive; planes >= Z contribute zeros
   lsr::RlStats stats;   // UPDATE with p.stats: the launch's reduction scalars (correlate_common.hpp)
 
-  auto fetch = [&](int zplane, f32x4 (&st)[SL]) {  // SL loads
+  auto fetch = [&](int zplane, f32x4 (&st)[SL]) __attribute__((always_inline)) {  // SL loads
     const float* src = in_tile + static_cast<int64_t>(min(max(zplane, 0), Z - 1)) * p.in_plane;
 #pragma unroll
     for (int k = 0; k < SL; ++k) gload_x4(st[k], src, s_voff[k]);
   };
-  auto fetch_aux = [&](int zout, float (&aux)[kPts], float& nzv) {  // NA loads
+  auto fetch_aux = [&](int zout, float (&aux)[kPts], float& nzv) __attribute__((always_inline)) {  // NA loads
     if constexpr (EPI != LSR_EPI_NONE && NA != 0) {
       const int zc_ = min(max(zout, 0), Z - 1);
       const float* a = p.aux + static_cast<int64_t>(zc_) * p.aux_plane;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void correlate_sep_kernel(SepArgs p) {
 
   // One iteration; `par` = zi & 1 is a literal at both call sites.
   auto iteration = [&](const int zi, const int par, f32x4 (&st)[SL], float (&aux_use)[kPts],
-                       float& nz_use, float (&aux_load)[kPts], float& nz_load) {
+                       float& nz_use, float (&aux_load)[kPts], float& nz_load) __attribute__((always_inline)) {
     f32x4* A_commit = bufA4 + par * (T::ASZ / 4);            // plane zi+2
     const f32x4* A_x = bufA4 + (par ^ 1) * (T::ASZ / 4);     // plane zi+1
     f32x4* B_x = bufB4 + (par ^ 1) * (T::BSZ / 4);           // plane zi+1

@@ -717,6 +717,26 @@ def test_rl_dense_rotated_psf_20_iterations(device):
     _close(x.cpu().numpy(), ref, 2e-4, 1e-4)
 
 
+@pytest.mark.parametrize("pshape", [(11, 9, 9), (11, 7, 9), (9, 9, 9), (11, 9, 3)])
+def test_rl_tuned_dense_kernel_at_its_largest_extents_vs_oracle(device, pshape):
+    """The tuned dense kernel's biggest instances (11 z taps, 9 in plane: 891 FMAs per voxel).  Round 4's static check
+    (tools/asm_hazards.py) found <11, 9, UPDATE> compiled with its pipeline lambda out of line -- staging registers in
+    scratch memory, stored there before the loads into them had landed -- and no test had ever run that instance."""
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+
+    psf = o.rotated_psf(pshape, (2.3, 1.6, 1.6), 30.0)
+    psf[0, 0, 0] += 0.003            # neither rank-1 nor ky (x) kzx
+    psf /= psf.sum()
+    vshape = (14, 40, 70)
+    y = o.bead_scene(vshape, seed=sum(pshape), psf=o.gaussian_psf((5, 5, 5), (1.2, 1.0, 1.0))[0], density=2e-3)
+    plan = RichardsonLucyPlan(vshape, psf, device)
+    assert plan.path == "dense"
+    x = plan(_t(y, device), iterations=3)
+    _close(x.cpu().numpy(), o.richardson_lucy(y, psf, 3), 5e-5, 2e-5)
+    again = plan(_t(y, device), iterations=3)
+    assert np.array_equal(x.cpu().numpy(), again.cpu().numpy())
+
+
 def test_rl_edge_cases(device):
     import torch
 
