@@ -729,7 +729,7 @@ extern "C" int lsr_rl_ysep_fused_stats_f32(const float* y, int64_t y_pitch, int6
   // two shapes: 256-thread workgroups on 32 x 64 tiles, two per CU (default), or 512 threads on 32 x 128, one per
   // CU (LSR_YSEP_SHAPE=wide: measurement override)
   const char* shape_env = std::getenv("LSR_YSEP_SHAPE");
-  p.narrow = !(shape_env != nullptr && shape_env[0] == 'w') ? 1 : 0;
+  p.narrow = !(shape_env != nullptr && shape_env[0] == 'w') && lsr::ysep_narrow_compiled(PZ, PYX) ? 1 : 0;
   p.tiles_x = static_cast<int>(lsr::ceil_div(X, p.narrow ? 64 : lsr::kSepWideTileX));
   p.tiles_y = static_cast<int>(lsr::ceil_div(Y, lsr::ysep_tile_rows(PZ)));
   const int64_t tiles_xy = int64_t(p.tiles_x) * p.tiles_y;

@@ -305,6 +305,35 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
     for (int i = 0; i < NP2; ++i) acc2[j][i] = splat(0.0f);
   }
   lsr::RlStats st;
+  // 1 / (H^T 1) of the thread's 2 * NP2 output points on plane o.  Almost every point of almost every plane is interior
+  // (all taps land inside the volume: the tap sum); the rest take the prefix-sum table (global memory, a few hundred bytes
+  // that stay in cache) -- one rolled loop, so that its eight reads and their branch exist once in the code, not once
+  // per point.
+  auto plane_norms = [&](int o, float (&rn)[2 * NP2]) __attribute__((always_inline)) {
+    const float rfull = fast_rcp(p.norm_full);
+#pragma unroll
+    for (int i = 0; i < 2 * NP2; ++i) rn[i] = rfull;
+    if (!(tile_norm_interior && o >= rz && o < Z - rz)) {   // wave-uniform
+#pragma unroll 1
+      for (int k = 0; k < 2 * NP2; ++k) {
+        const int i = k >> 1, h = k & 1;
+        const int row = NCG == 2 ? i : 2 * i + h, col = NCG == 2 ? 64 * h : 0;
+        const int gy = min(y0 + wave * RPW + row, Y - 1), gx = min(x0 + lane + col, X - 1);
+        const bool inside = o >= rz && o < Z - rz && gy >= ry && gy < Y - ry && gx >= rx && gx < X - rx;
+        const float r = fast_rcp(inside ? p.norm_full : dense_norm(p, p.norm_table, o, gy, gx));
+#pragma unroll
+        for (int t = 0; t < 2 * NP2; ++t) rn[t] = k == t ? r : rn[t];
+      }
+    }
+  };
+  // The table walk costs eight dependent global reads per point and a full drain of the load pipeline -- per PLANE in
+  // round 3, in every tile that touches the volume's border: 14 % of config 2's tiles ran ~5 x slower than the others
+  // and set the launch time (4.0 ms with all arithmetic removed, against 2.4 ms for the separable kernel's skeleton).
+  // H^T 1 depends on z only within the PSF's z radius of the volume's ends, so the norms of a plane with all z taps
+  // inside are computed ONCE per workgroup, here, with the same formula (bit-identical values), and the walk runs for
+  // the first and last `rz` planes only.
+  float rn_mid[2 * NP2];
+  plane_norms(rz < Z - rz ? rz : 0, rn_mid);   // (a volume thinner than the PSF has no such plane: rn_mid unused)
   float yv[2 * NP1], ye[EP], xc[2 * NP2];   // [2 i + h] = half h of pair i
 #pragma unroll
   for (int i = 0; i < 2 * NP1; ++i) yv[i] = 0.0f;
@@ -441,25 +470,12 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
       tie(xc);
       if (o >= zb && o < ze) {
         float* obase = o_tile + (static_cast<int64_t>(o) * p.out_plane + static_cast<int64_t>(wave * RPW) * p.out_pitch);
-        // 1 / (H^T 1) of the thread's 2 * NP2 points.  Almost every point of almost every plane is interior (all
-        // taps land inside the volume: the tap sum); the rest take the prefix-sum table (global memory, a few
-        // hundred bytes that stay in cache) -- one rolled loop, so that its eight reads and their branch exist
-        // once in the code, not once per point.
         float rn[2 * NP2];
-        const float rfull = fast_rcp(p.norm_full);
+        if (o >= rz && o < Z - rz) {   // all z taps inside: the norms computed once, above
 #pragma unroll
-        for (int i = 0; i < 2 * NP2; ++i) rn[i] = rfull;
-        if (!(tile_norm_interior && o >= rz && o < Z - rz)) {   // wave-uniform
-#pragma unroll 1
-          for (int k = 0; k < 2 * NP2; ++k) {
-            const int i = k >> 1, h = k & 1;
-            const int row = NCG == 2 ? i : 2 * i + h, col = NCG == 2 ? 64 * h : 0;
-            const int gy = min(y0 + wave * RPW + row, Y - 1), gx = min(x0 + lane + col, X - 1);
-            const bool inside = o >= rz && o < Z - rz && gy >= ry && gy < Y - ry && gx >= rx && gx < X - rx;
-            const float r = fast_rcp(inside ? p.norm_full : dense_norm(p, p.norm_table, o, gy, gx));
-#pragma unroll
-            for (int t = 0; t < 2 * NP2; ++t) rn[t] = k == t ? r : rn[t];
-          }
+          for (int i = 0; i < 2 * NP2; ++i) rn[i] = rn_mid[i];
+        } else {
+          plane_norms(o, rn);
         }
 #pragma unroll
         for (int i = 0; i < NP2; ++i) {
@@ -584,13 +600,17 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
 
 template <int PZ, int PYX>
 bool launch_one(const YsepArgs& p, dim3 grid, hipStream_t s) {
-  if (p.stats != nullptr) {
-    if (p.narrow) hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 4, 1, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 8, 2, true>), grid, dim3(512), 0, s, p);
-  } else {
-    if (p.narrow) hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 4, 1, false>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 8, 2, false>), grid, dim3(512), 0, s, p);
+  // (the narrow shape exists where lsr::ysep_narrow_compiled says so: the host never asks for another)
+  if constexpr (lsr::ysep_narrow_compiled(PZ, PYX)) {
+    if (p.narrow) {
+      if (p.stats != nullptr) hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 4, 1, true>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 4, 1, false>), grid, dim3(256), 0, s, p);
+      return true;
+    }
   }
+  if (p.narrow) return false;
+  if (p.stats != nullptr) hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 8, 2, true>), grid, dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 8, 2, false>), grid, dim3(512), 0, s, p);
   return true;
 }
 
