@@ -108,7 +108,10 @@ __device__ float dense_norm(const DenseArgs& p, const double* P, int z, int y, i
 // MODE 2: the whole PSF ky (x) kzx in one launch: every wave first filters its own four rows of the
 //         staged plane along y (PYX taps, LDS -> LDS, rows only that wave reads: no barrier), then
 //         runs the (z, x) stencil of MODE 1 on the filtered rows.  PZ * PYX + PYX FMAs per voxel.
-template <int PZ, int PYX, int EPI, int MODE>
+// STATS (LSR_EPI_UPDATE only): the launch's Richardson-Lucy scalars are summed in the epilogue and added to p.stats
+// (correlate_common.hpp: RlStats) -- its own instantiation: a per-point test of p.stats in the epilogue, and three more
+// live registers, cost the plain launch 12 % (2.43 -> 2.73 ms on config 2's grid, round 4).
+template <int PZ, int PYX, int EPI, int MODE, bool STATS = false>
 __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) {
   using T = Tile<PYX>;
   __shared__ f32x4 bufA4[2 * T::ASZ / 4];
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
                 const float xu = aux_use[m] * acc0(m);
                 const float v = xu * fast_rcp(nrm);
                 o[o_off[m]] = v;
-                if (p.stats) stats.add(aux_use[m], xu, v);   // (kernel-uniform)
+                if constexpr (STATS) stats.add(aux_use[m], xu, v);
               } else
                 o[o_off[m]] = acc0(m) * fast_rcp(nrm);
             }
@@ -381,13 +384,13 @@ __global__ __launch_bounds__(kThreads) void correlate_dense_kernel(DenseArgs p) 
     iteration(zi + 1, 1, st1, aux1, aux0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (EPI == LSR_EPI_UPDATE) {
+  if constexpr (EPI == LSR_EPI_UPDATE && STATS) {
     lsr::keep_until_here(st0);   // (in-flight prefetches: correlate_common.hpp, keep_until_here)
     lsr::keep_until_here(st1);
     lsr::keep_until_here(aux0);
     lsr::keep_until_here(aux1);
     stats.pin();
-    if (p.stats) lsr::rl_stats_flush<kWaves>(stats, reinterpret_cast<float*>(bufA4), p.stats);
+    lsr::rl_stats_flush<kWaves>(stats, reinterpret_cast<float*>(bufA4), p.stats);
   }
 }
 
@@ -401,7 +404,8 @@ bool launch_one(const DenseArgs& p, dim3 grid, hipStream_t s) {
           hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_RATIO, 2>), grid, block, 0, s, p);
           return true;
         case LSR_EPI_UPDATE:
-          hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_UPDATE, 2>), grid, block, 0, s, p);
+          if (p.stats != nullptr) hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_UPDATE, 2, true>), grid, block, 0, s, p);
+          else hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_UPDATE, 2>), grid, block, 0, s, p);
           return true;
         default:
           return false;
@@ -427,7 +431,8 @@ bool launch_one(const DenseArgs& p, dim3 grid, hipStream_t s) {
         hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_RATIO, 0>), grid, block, 0, s, p);
         return true;
       case LSR_EPI_UPDATE:
-        hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_UPDATE, 0>), grid, block, 0, s, p);
+        if (p.stats != nullptr) hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_UPDATE, 0, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_UPDATE, 0>), grid, block, 0, s, p);
         return true;
       case LSR_EPI_SCALE:
         hipLaunchKernelGGL((correlate_dense_kernel<PZ, PYX, LSR_EPI_SCALE, 0>), grid, block, 0, s, p);

@@ -406,7 +406,11 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
     issue_glds(pz + 2, slot2);
     // y passes, LDS -> LDS: an item is one 16-byte column chunk of RY consecutive output rows -- RY + 2C input
     // chunks instead of RY * (2C + 1) (these passes are what the LDS pipe spends the phase on)
+#ifdef LSR_YSEP_PROBE_NOYPASS   // measurement build (results wrong): the two LDS -> LDS y passes are skipped
+    if (false) {
+#else
     if (x_live) {
+#endif
       float w1y[PYX];
 #pragma unroll
       for (int b = 0; b < PYX; ++b) LSR_TAP(w1y[b], 0, 112 + b);
@@ -416,7 +420,11 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
       for (int k = 0; k < T::XIT1; ++k)
         if (k + 1 < T::XIT1 || tid + k * NT < T::NIT1) B1_4[tid + k * NT] = f32x4{0, 0, 0, 0};
     }
+#ifdef LSR_YSEP_PROBE_NOYPASS
+    if (false) {
+#else
     if (r_live) {
+#endif
       float w2y[PYX];
 #pragma unroll
       for (int b = 0; b < PYX; ++b) LSR_TAP(w2y[b], 1, 112 + b);
@@ -440,8 +448,13 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
       f32x2 vb[2][NP2];   // two register sets, indexed by the (compile-time) parity of c: no copies
 #pragma unroll
       for (int i = 0; i < NP2; ++i) vb[0][i] = ld(i, 0);
+#ifdef LSR_YSEP_PROBE_NONEST2   // measurement build (results wrong): one column offset of the stage-2 nest instead of PYX
+      constexpr int kCols2 = 1;
+#else
+      constexpr int kCols2 = PYX;
+#endif
 #pragma unroll
-      for (int c = 0; c < PYX; ++c) {
+      for (int c = 0; c < kCols2; ++c) {
         f32x2 (&v)[NP2] = vb[c & 1];
         if (c + 1 < PYX) {
 #pragma unroll
@@ -507,8 +520,13 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
       for (int i = 0; i < NP1; ++i) vb[0][i] = ld(i, 0);
 #pragma unroll
       for (int e = 0; e < EP; ++e) veb[0][e] = B1[e_t1(e)];
+#ifdef LSR_YSEP_PROBE_NONEST1   // ... of the stage-1 nest
+      constexpr int kCols1 = 1;
+#else
+      constexpr int kCols1 = PYX;
+#endif
 #pragma unroll
-      for (int c = 0; c < PYX; ++c) {
+      for (int c = 0; c < kCols1; ++c) {
         f32x2 (&v)[NP1] = vb[c & 1];
         float (&ve)[EP] = veb[c & 1];
         if (c + 1 < PYX) {
