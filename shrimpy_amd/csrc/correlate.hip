@@ -660,7 +660,7 @@ extern "C" int lsr_rl_ysep_fused_supported(int pz, int py, int px) {
   return PZ <= lsr::kYsepMaxPZ && PYX <= lsr::kYsepMaxPYX ? 1 : 0;
 }
 
-extern "C" int lsr_rl_ysep_fused_taps_count(void) { return 256; }
+extern "C" int lsr_rl_ysep_fused_taps_count(void) { return 2 * lsr::kYsepTapStage; }
 
 extern "C" int lsr_rl_ysep_fused_prepare_taps(const float* ky_host, int py, const float* kzx_host, int pz, int px,
                                               float* taps_host) {
@@ -673,18 +673,19 @@ extern "C" int lsr_rl_ysep_fused_prepare_taps(const float* ky_host, int py, cons
               "lsr_correlate_zxy_padded_f32", pz, py, px, lsr::kYsepMaxPZ, lsr::kYsepMaxPYX);
   const int PZ = lsr::sep_round_taps(pz), PYX = lsr::sep_round_taps(py > px ? py : px);
   const int oz = (PZ - pz) / 2, oy = (PYX - py) / 2, ox = (PYX - px) / 2;
-  for (int i = 0; i < 256; ++i) taps_host[i] = 0.0f;
-  // two stages of 128 floats: stage 1 (H = correlation with the reversed PSF), stage 2 (H^T, the PSF itself);
-  // (z, x) taps at [c * PZ + j], j = PZ - 1 - a (the order a staged plane feeds the pending planes in), the y
-  // taps at 112 + b; each centred in its compiled extent, zeros elsewhere
+  for (int i = 0; i < 2 * lsr::kYsepTapStage; ++i) taps_host[i] = 0.0f;
+  // two stages of kYsepTapStage floats: stage 1 (H = correlation with the reversed PSF), stage 2 (H^T, the PSF itself);
+  // the (z, x) taps of column offset c at [kYsepTapGroup * c + j], j = PZ - 1 - a (the order a staged plane feeds the
+  // pending planes in) -- one 64-byte group per column offset, fetched by the kernel with one or two scalar loads --
+  // the y taps at kYsepTapY + b; each centred in its compiled extent, zeros elsewhere
   for (int stage = 0; stage < 2; ++stage) {
-    float* t = taps_host + 128 * stage;
+    float* t = taps_host + lsr::kYsepTapStage * stage;
     for (int a = 0; a < pz; ++a)
       for (int c = 0; c < px; ++c) {
         const float v = stage == 0 ? kzx_host[(pz - 1 - a) * px + (px - 1 - c)] : kzx_host[a * px + c];
-        t[(c + ox) * PZ + (PZ - 1 - (a + oz))] = v;
+        t[(c + ox) * lsr::kYsepTapGroup + (PZ - 1 - (a + oz))] = v;
       }
-    for (int b = 0; b < py; ++b) t[112 + b + oy] = stage == 0 ? ky_host[py - 1 - b] : ky_host[b];
+    for (int b = 0; b < py; ++b) t[lsr::kYsepTapY + b + oy] = stage == 0 ? ky_host[py - 1 - b] : ky_host[b];
   }
   return LSR_OK;
 }
@@ -726,10 +727,10 @@ extern "C" int lsr_rl_ysep_fused_stats_f32(const float* y, int64_t y_pitch, int6
   p.taps = taps; p.eps = eps;
   p.pz = pz; p.py = py; p.px = px;
   p.norm_table = norm_table; p.norm_full = norm_full;
-  // two shapes: 256-thread workgroups on 32 x 64 tiles, two per CU (default), or 512 threads on 32 x 128, one per
-  // CU (LSR_YSEP_SHAPE=wide: measurement override)
-  const char* shape_env = std::getenv("LSR_YSEP_SHAPE");
-  p.narrow = !(shape_env != nullptr && shape_env[0] == 'w') && lsr::ysep_narrow_compiled(PZ, PYX) ? 1 : 0;
+  // one shape: 512 threads on 32 x 128 tiles, one workgroup per CU.  (Rounds 3-4 also had 256-thread workgroups on
+  // 32 x 64 tiles, two per CU: once the border normalisation stopped setting the launch time it was the slower one --
+  // 4.98 against 4.63 ms per iteration on config 2, its halo is 1.72 x the tile against 1.55 x -- and is gone.)
+  p.narrow = 0;
   p.tiles_x = static_cast<int>(lsr::ceil_div(X, p.narrow ? 64 : lsr::kSepWideTileX));
   p.tiles_y = static_cast<int>(lsr::ceil_div(Y, lsr::ysep_tile_rows(PZ)));
   const int64_t tiles_xy = int64_t(p.tiles_x) * p.tiles_y;

@@ -160,10 +160,9 @@ struct YsepArgs {
 // tile rows: the accumulators of both stencils (PZ planes each) must fit 256 VGPRs per thread
 constexpr int ysep_tile_rows(int PZ) { return PZ <= 9 ? 32 : 24; }
 constexpr int kYsepMaxPZ = 11, kYsepMaxPYX = 9;
-// the 256-thread shape (32 x 64 tiles, a thread owns 8 rows of one column) holds twice the rows per thread: with 9
-// in-plane taps its accumulators do not fit the register file (tools/asm_hazards.py: spills, i.e. scratch traffic the
-// hand-counted waits know nothing of, of the staging registers of loads in flight among others)
-constexpr bool ysep_narrow_compiled(int PZ, int PYX) { return PYX <= 7; }
+// its tap block (lsr_rl_ysep_fused_prepare_taps): per stage kYsepMaxPYX groups of 16 floats ((z, x) taps of one column
+// offset), then the y taps
+constexpr int kYsepTapGroup = 16, kYsepTapY = kYsepTapGroup * kYsepMaxPYX, kYsepTapStage = kYsepTapY + 16;
 
 // ---- Richardson-Lucy reduction scalars (VERDICT r3 row g; north-star "wavefront reductions for the ratio /
 // normalisation") -----------------------------------------------------------------------------------------------------

@@ -95,7 +95,7 @@ struct Geo {
   static_assert(2 * C <= WL && WL <= lsr::kSepOriginCol && 2 * C <= 8, "halo columns");
   static_assert(SL + 2 * (NY + NXC) <= 63, "vmcnt is a 6-bit counter");
   static_assert(OFF_B1 % 4 == 0 && OFF_R % 4 == 0 && OFF_B2 % 4 == 0, "aligned buffers");
-  static_assert(NTAP + PYX <= 128, "a stage's taps fill two registers' lanes");
+  static_assert(PZ <= lsr::kYsepTapGroup && PYX <= lsr::kYsepMaxPYX, "the tap block's groups");
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -242,16 +242,15 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
   const int ty = band * kBand + (lb - tx * band_h);
   const int x0 = tx * TXW, y0 = ty * TY;
 
-  // taps: two stages of 128 floats (stage 1 = reversed taps, stage 2 = the PSF's): (z, x) taps [c][j],
-  // j = PZ - 1 - a, at 0 .. PYX * PZ - 1, the y taps at 112 .. 112 + PYX - 1.  They live across the lanes of
-  // four VGPRs; a pass pulls each tap into an SGPR with v_readlane right where it is used.
-  float tv[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) tv[i] = p.taps[64 * i + lane];
-  // (volatile asm, not the builtin: a readlane has no ordering of its own, and instruction selection floats
-  // all PZ * PYX of a pass to the top of the block -- past the scheduling fences -- where they spill)
-#define LSR_TAP(dst, stage, f)                                                                          \
-  asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(dst) : "v"(tv[((stage) * 128 + (f)) >> 6]), "n"(((stage) * 128 + (f)) & 63))
+  // taps: two stages (stage 1 = reversed taps, stage 2 = the PSF's) of kYsepTapStage floats: the (z, x) taps of column
+  // offset c at [16 c + j], j = PZ - 1 - a, the y taps at kYsepTapY.  They are read through the constant address space,
+  // i.e. by SCALAR loads (s_load_dwordx8 + x1 per column offset), one column offset ahead of the FMAs that use them: no
+  // VALU slot is spent on a tap (round 3 held them across the lanes of four VGPRs and pulled every tap out with a
+  // v_readlane: 140 of the ~1200 vector instructions per plane).  `opaque` (always 0) makes the address loop-variant, so
+  // that the loads stay inside the plane loop -- hoisted, the 2 * PZ * PYX taps would have to live in SGPRs.
+  typedef const float __attribute__((address_space(4))) cfloat;
+  const cfloat* const taps_c = (const cfloat*)p.taps;
+  int opaque = 0;
 
   // ---- staging (glds): chunk e = tid + NT k of the (AR x PA) window whose first element is (y0 - 2C, x0 - WL)
   const float* const x_tile = p.x + (static_cast<int64_t>(y0 - 2 * C) * p.pitch + (x0 - T::WL));
@@ -390,8 +389,9 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
   lds_barrier();
 
   for (int pz = p_lo; pz <= p_hi; ++pz) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(tv[i]));  // loop-variant for the optimiser: no hoisting of the taps
+    asm volatile("" : "+s"(opaque));   // loop-variant for the optimiser: the tap loads stay in the loop
+    const cfloat* const taps1 = taps_c + opaque;                       // stage 1
+    const cfloat* const taps2 = taps_c + lsr::kYsepTapStage + opaque;  // stage 2
 #pragma unroll
     for (int e = 0; e < EP; ++e) asm volatile("" : "+v"(e_rc[e]));   // ... nor of the offsets derived from e_rc
     asm volatile("" : "+v"(tid_v));                                  // ... and from the thread index
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
 #endif
       float w1y[PYX];
 #pragma unroll
-      for (int b = 0; b < PYX; ++b) LSR_TAP(w1y[b], 0, 112 + b);
+      for (int b = 0; b < PYX; ++b) w1y[b] = taps1[lsr::kYsepTapY + b];
       ypass<T::RY, PYX, NT>(smem4 + slot * (T::ASZ / 4), B1_4, T::CH, T::R1, T::NG1, w1y, tid);
     } else {  // a plane outside the volume: zeros
 #pragma unroll
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
 #endif
       float w2y[PYX];
 #pragma unroll
-      for (int b = 0; b < PYX; ++b) LSR_TAP(w2y[b], 1, 112 + b);
+      for (int b = 0; b < PYX; ++b) w2y[b] = taps2[lsr::kYsepTapY + b];
       ypass<T::RY, PYX, NT>(R_4, B2_4, T::CH2, TY, T::NG2, w2y, tid);
     } else {
 #pragma unroll
@@ -446,8 +446,11 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
         return f32x2{base[pair_row<NCG>(i, 0) * T::PR + c], base[pair_row<NCG>(i, 1) * T::PR + pair_col<NCG>(1) + c]};
       };
       f32x2 vb[2][NP2];   // two register sets, indexed by the (compile-time) parity of c: no copies
+      float wq[2][PZ];    // ... and two SGPR sets of taps
 #pragma unroll
       for (int i = 0; i < NP2; ++i) vb[0][i] = ld(i, 0);
+#pragma unroll
+      for (int j = 0; j < PZ; ++j) wq[0][j] = taps2[j];
 #ifdef LSR_YSEP_PROBE_NONEST2   // measurement build (results wrong): one column offset of the stage-2 nest instead of PYX
       constexpr int kCols2 = 1;
 #else
@@ -459,15 +462,12 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
         if (c + 1 < PYX) {
 #pragma unroll
           for (int i = 0; i < NP2; ++i) vb[(c + 1) & 1][i] = ld(i, c + 1);
+#pragma unroll
+          for (int j = 0; j < PZ; ++j) wq[(c + 1) & 1][j] = taps2[lsr::kYsepTapGroup * (c + 1) + j];
         }
-        // (the tap of plane j + 1 is fetched ahead of the FMAs of plane j: a VALU-written SGPR needs a wait
-        // state before a VALU reads it, which the FMAs in between provide)
-        float wnext;
-        LSR_TAP(wnext, 1, c * PZ);
 #pragma unroll
         for (int j = 0; j < PZ; ++j) {
-          const float ws = wnext;
-          if (j + 1 < PZ) LSR_TAP(wnext, 1, c * PZ + j + 1);
+          const float ws = wq[c & 1][j];
           const f32x2 w = splat(ws);
 #pragma unroll
           for (int i = 0; i < NP2; ++i) {
@@ -520,6 +520,9 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
       for (int i = 0; i < NP1; ++i) vb[0][i] = ld(i, 0);
 #pragma unroll
       for (int e = 0; e < EP; ++e) veb[0][e] = B1[e_t1(e)];
+      float wq[2][PZ];
+#pragma unroll
+      for (int j = 0; j < PZ; ++j) wq[0][j] = taps1[j];
 #ifdef LSR_YSEP_PROBE_NONEST1   // ... of the stage-1 nest
       constexpr int kCols1 = 1;
 #else
@@ -534,13 +537,12 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
           for (int i = 0; i < NP1; ++i) vb[(c + 1) & 1][i] = ld(i, c + 1);
 #pragma unroll
           for (int e = 0; e < EP; ++e) veb[(c + 1) & 1][e] = B1[e_t1(e) + c + 1];
+#pragma unroll
+          for (int j = 0; j < PZ; ++j) wq[(c + 1) & 1][j] = taps1[lsr::kYsepTapGroup * (c + 1) + j];
         }
-        float wnext;
-        LSR_TAP(wnext, 0, c * PZ);
 #pragma unroll
         for (int j = 0; j < PZ; ++j) {
-          const float ws = wnext;
-          if (j + 1 < PZ) LSR_TAP(wnext, 0, c * PZ + j + 1);
+          const float ws = wq[c & 1][j];
           const f32x2 w = splat(ws);
 #pragma unroll
           for (int i = 0; i < NP1; ++i) {
@@ -618,15 +620,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
 
 template <int PZ, int PYX>
 bool launch_one(const YsepArgs& p, dim3 grid, hipStream_t s) {
-  // (the narrow shape exists where lsr::ysep_narrow_compiled says so: the host never asks for another)
-  if constexpr (lsr::ysep_narrow_compiled(PZ, PYX)) {
-    if (p.narrow) {
-      if (p.stats != nullptr) hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 4, 1, true>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 4, 1, false>), grid, dim3(256), 0, s, p);
-      return true;
-    }
-  }
-  if (p.narrow) return false;
+  if (p.narrow) return false;   // (the 256-thread shape <PZ, PYX, 4, 1> is no longer instantiated)
   if (p.stats != nullptr) hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 8, 2, true>), grid, dim3(512), 0, s, p);
   else hipLaunchKernelGGL((rl_fused_ysep_kernel<PZ, PYX, 8, 2, false>), grid, dim3(512), 0, s, p);
   return true;

@@ -1,22 +1,25 @@
+"""One compiled <PZ, PYX> instance of the fused ky (x) kzx kernel per process: a few volume shapes, bit equality with the
+two-launch form.  python tools/probes/dbg_ysep.py PZ PYX"""
 import sys; sys.path.insert(0, '.')
 import numpy as np, torch
 from shrimpy_amd.deconvolve import RichardsonLucyPlan
-want = int(sys.argv[1])
+pz, pyx = int(sys.argv[1]), int(sys.argv[2])
 dev = torch.device("cuda:0")
-rng = np.random.default_rng(45)
-for case in range(10):
-    pz, py, px = int(rng.choice([3, 5, 7, 9, 11])), int(rng.choice([3, 5, 9, 13, 15])), int(rng.choice([3, 5, 7, 9]))
-    kzx = np.abs(rng.normal(1.0, 0.5, (pz, px))) + 0.05
-    ky = np.abs(rng.normal(1.0, 0.4, py)) + 0.05
-    psf = (ky[None, :, None] * kzx[:, None, :]).astype(np.float32)
-    psf /= psf.sum()
-    shape = (int(rng.integers(1, 30)), int(rng.integers(1, 80)), int(rng.integers(1, 200)))
-    y = (rng.random(shape) * 80 + 1).astype(np.float32)
-    iters = int(rng.integers(1, 4))
-    if case != want: continue
-    plan = RichardsonLucyPlan(shape, psf, dev, fused="always")
-    print("case", case, (pz, py, px), shape, iters, plan.path, flush=True)
-    got = plan(torch.as_tensor(y, device=dev), iterations=iters); torch.cuda.synchronize()
-    if py <= 9:
-        two = RichardsonLucyPlan(shape, psf, dev)(torch.as_tensor(y, device=dev), iterations=iters)
-        print("   equal", bool(torch.equal(got, two)), flush=True)
+rng = np.random.default_rng(100 * pz + pyx)
+ok = True
+for shape, iters in (((27, 9, 55), 3), ((7, 6, 59), 2), ((16, 54, 42), 1), ((5, 70, 300), 2), ((1, 1, 1), 1), ((30, 33, 129), 3)):
+    for (py, px) in ((pyx, max(pyx - 2, 1)), (max(pyx - 2, 1), pyx)):
+        kzx = np.abs(rng.normal(1.0, 0.5, (pz, px))) + 0.05
+        ky = np.abs(rng.normal(1.0, 0.4, py)) + 0.05
+        psf = (ky[None, :, None] * kzx[:, None, :]).astype(np.float32); psf /= psf.sum()
+        y = torch.as_tensor((rng.random(shape) * 80 + 1).astype(np.float32), device=dev)
+        plan = RichardsonLucyPlan(shape, psf, dev, fused="always")
+        if plan.path != "y-separable (fused)":
+            continue
+        a = plan(y, iterations=iters); torch.cuda.synchronize()
+        b = RichardsonLucyPlan(shape, psf, dev)(y, iterations=iters); torch.cuda.synchronize()
+        eq = bool(torch.equal(a, b))
+        ok &= eq
+        if not eq: print("MISMATCH", (pz, py, px), shape, iters, flush=True)
+print("instance", (pz, pyx), "ok" if ok else "BAD", flush=True)
+sys.exit(0 if ok else 1)
