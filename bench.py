@@ -393,7 +393,7 @@ def run_resident(args, rank, world, device, shared, backend, cpu):
         plan = RichardsonLucyPlan(out_shape, None, device, psf_factors=gaussian_factors(),
                                   fused="auto" if args.rl == "fused" else "never")
     elif args.psf == "rotated":
-        plan = RichardsonLucyPlan(out_shape, rotated_psf(), device, fused="always" if args.rl == "fused-ysep" else "auto")
+        plan = RichardsonLucyPlan(out_shape, rotated_psf(), device, fused="never" if args.rl == "two-launch" else "auto")
     else:
         plan = RichardsonLucyPlan(out_shape, rotated_psf(), device, separable="never")
     # the deskew kernel writes straight into the RL kernels' padded, line-aligned input volume
@@ -720,8 +720,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=None, help="cap the CPU baseline's worker count (default: all host cores)")
     ap.add_argument("--rl", default="fused", choices=["fused", "two-launch", "fused-ysep"],
-                    help="separable PSF: one launch per RL iteration (default) or the ratio / update pair; "
-                         "fused-ysep: with --psf rotated, the opt-in one-launch iteration for ky (x) kzx PSFs")
+                    help="one launch per RL iteration (default: rl_fused_sep / rl_fused_ysep kernels) or the ratio / "
+                         "update pair (two-launch); fused-ysep is accepted as a synonym of fused")
     ap.add_argument("--no-store-leg", action="store_true", help="config4/5: skip the store-to-store leg")
     ap.add_argument("--scratch", default=None, help="config4/5: directory for the temporary plates (default: TMPDIR)")
     ap.add_argument("--engine-format", action="store_true",

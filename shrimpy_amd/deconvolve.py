@@ -324,12 +324,12 @@ class RichardsonLucyPlan:
             self._norm = None
         if factors is not None:
             self._ysep = None
-        # ky (x) kzx with both factors inside the dense kernel's range: one launch per correlation by default.
-        # The one-launch-per-ITERATION kernel (rl_fused_ysep.hip, bit-identical results) is opt-in
-        # (fused="always"): it halves the HBM traffic, but with 140 FMAs per voxel its single workgroup per
-        # CU is VALU- and barrier-bound -- measured 5.8 ms per iteration against 2 x 2.28 ms
+        # ky (x) kzx with both factors inside the kernels' range: one launch per ITERATION (rl_fused_ysep.hip; results
+        # bit-identical to the pair) -- since round 4 the faster form at every compiled extent (config-2 grid, ms per
+        # iteration, one launch / pair: 3x3x3 2.27 / 4.71, 5x5x5 2.82 / 4.57, 9x7x7 4.37 / 5.02, 9x9x9 5.14 / 5.46,
+        # 11x9x9 6.19 / 6.95; profiles/r04_ysep_sweep.jsonl).  fused="never" keeps one launch per correlation.
         self.fused_ysep = False
-        if (self._ysep is not None and self._ysep["fused"] is not None and self._fused_mode == "always"
+        if (self._ysep is not None and self._ysep["fused"] is not None and self._fused_mode in ("auto", "always")
                 and _lib.call_value("lsr_rl_ysep_fused_supported", *self._psf.shape)):
             ky, kzx = ysep
             ky_c, kzx_c = np.ascontiguousarray(ky, dtype=np.float32), np.ascontiguousarray(kzx, dtype=np.float32)

@@ -1018,8 +1018,8 @@ def test_rl_y_separable_psf_takes_the_stencil_plus_y_pass_and_matches_dense(devi
     shape = (21, 70, 150)
     rng = np.random.default_rng(44)
     y = (rng.poisson(100 + 3000 * (rng.random(shape) > 0.999)).astype(np.float32))
-    auto = RichardsonLucyPlan(shape, psf, device, fused="always")
-    two = RichardsonLucyPlan(shape, psf, device)
+    auto = RichardsonLucyPlan(shape, psf, device)                 # the default: one launch per iteration (round 4)
+    two = RichardsonLucyPlan(shape, psf, device, fused="never")
     dense = RichardsonLucyPlan(shape, psf, device, separable="never")
     assert (auto.path, two.path, dense.path) == ("y-separable (fused)", "y-separable", "dense")
     a, b = auto(_t(y, device), iterations=8), dense(_t(y, device), iterations=8)
@@ -1043,20 +1043,20 @@ def test_rl_y_separable_psf_takes_the_stencil_plus_y_pass_and_matches_dense(devi
         assert p.path == "y-separable (fused)"
         got = p(_t(yt, device), iterations=2)
         _close(got.cpu().numpy(), o.richardson_lucy(yt, psf, 2), 2e-4, 1e-4)
-        assert torch.equal(got, RichardsonLucyPlan(thin, psf, device)(_t(yt, device), iterations=2))
+        assert torch.equal(got, RichardsonLucyPlan(thin, psf, device, fused="never")(_t(yt, device), iterations=2))
 
 
-@pytest.mark.parametrize("fused_shape", ["narrow", "wide"])
-def test_rl_y_separable_random_psf_shapes(device, fused_shape, monkeypatch):
-    """Both shapes of the fused ky (x) kzx kernel (256 threads on 32 x 64 tiles / 512 threads on 32 x 128,
-    ``LSR_YSEP_SHAPE``) against the oracle and, bit for bit, against the two-launch form."""
+@pytest.mark.parametrize("seed", [45, 46])
+def test_rl_y_separable_random_psf_shapes(device, seed):
+    """The fused ky (x) kzx kernel on random PSF extents and awkward volumes against the oracle and, bit for bit, against
+    the two-launch form.  (Rounds 3-4 also had a 256-thread shape on 32 x 64 tiles, selected by ``LSR_YSEP_SHAPE``: the
+    slower one once the border normalisation was fixed, and one of its instances faulted with the scalar-load taps --
+    removed; the variable is ignored.)"""
     import torch
 
     from shrimpy_amd.deconvolve import RichardsonLucyPlan
 
-    monkeypatch.setenv("LSR_YSEP_SHAPE", fused_shape)
-
-    rng = np.random.default_rng(45)
+    rng = np.random.default_rng(seed)
     for case in range(10):
         pz, py, px = int(rng.choice([3, 5, 7, 9, 11])), int(rng.choice([3, 5, 9, 13, 15])), int(rng.choice([3, 5, 7, 9]))
         kzx = np.abs(rng.normal(1.0, 0.5, (pz, px))) + 0.05
@@ -1071,7 +1071,7 @@ def test_rl_y_separable_random_psf_shapes(device, fused_shape, monkeypatch):
         got = plan(_t(y, device), iterations=iters)
         _close(got.cpu().numpy(), o.richardson_lucy(y, psf, iters), 2e-4, 1e-4)
         if py <= 9:   # every compiled extent: the fused iteration is the two-launch form, bit for bit
-            two = RichardsonLucyPlan(shape, psf, device)
+            two = RichardsonLucyPlan(shape, psf, device, fused="never")
             assert two.path == "y-separable"
             assert torch.equal(got, two(_t(y, device), iterations=iters)), (case, psf.shape, shape)
 

@@ -32,8 +32,8 @@ PATHS = [
     # (id, psf builder, plan kwargs, expected plan.path)
     ("fused", lambda: o.gaussian_psf((9, 7, 7), (2.0, 1.2, 1.2))[0], dict(), "fused"),
     ("separable", lambda: o.gaussian_psf((9, 7, 7), (2.0, 1.2, 1.2))[0], dict(fused="never"), "separable"),
-    ("y-separable", lambda: o.rotated_psf((9, 7, 7), (2.0, 1.2, 1.2), 30.0), dict(), "y-separable"),
-    ("y-separable-fused", lambda: o.rotated_psf((9, 7, 7), (2.0, 1.2, 1.2), 30.0), dict(fused="always"), None),
+    ("y-separable", lambda: o.rotated_psf((9, 7, 7), (2.0, 1.2, 1.2), 30.0), dict(fused="never"), "y-separable"),
+    ("y-separable-fused", lambda: o.rotated_psf((9, 7, 7), (2.0, 1.2, 1.2), 30.0), dict(), "y-separable (fused)"),
     ("y-separable-4", lambda: o.rotated_psf((7, 11, 5), (1.6, 2.0, 1.0), 25.0), dict(), "y-separable (4 launches)"),
     ("dense", lambda: o.rotated_psf((9, 7, 7), (2.0, 1.2, 1.2), 30.0), dict(separable="never"), "dense"),
     ("generic", lambda: o.rotated_psf((13, 5, 5), (2.5, 1.0, 1.0), 30.0), dict(separable="never"), "generic"),

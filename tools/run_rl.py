@@ -30,7 +30,7 @@ def main():
     shape = tuple(int(v) for v in args.grid.split(","))
     g = torch.Generator(device=dev).manual_seed(5)
     y = torch.poisson(torch.full(shape, 100.0, device=dev), generator=g)
-    fused = ("always" if args.psf == "rotated" else "auto") if args.rl == "fused" else ("auto" if args.psf == "rotated" else "never")
+    fused = "auto" if args.rl == "fused" else "never"
     if args.psf == "separable":
         plan = RichardsonLucyPlan(shape, None, dev, psf_factors=bench.gaussian_factors(), fused=fused)
     elif args.psf == "rotated":
