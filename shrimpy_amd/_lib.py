@@ -1,8 +1,11 @@
 """ctypes binding of ``liblsrecon.so`` (C ABI: ``include/lsrecon.h``).
 
-The HIP extension is the product: there is no CPU fallback and nothing here routes through a
-reference implementation.  If the shared library is missing, cannot be loaded, or a tensor is
-not on a HIP device, the call fails loudly with :class:`LsrError`.
+The extension is the product: nothing here routes through a reference implementation or the test oracle.
+A tensor on a HIP device runs the kernels; a CPU tensor (the reference's own ``cpu`` branch,
+``shrimpy/preprocessing.py:78-82``) runs the native host twins of the same entry points (``lsr_*_cpu``,
+``csrc/host_twins.hip``: the same arithmetic, bit-equal results).  If the shared library is missing, stale
+(its source stamp differs from this checkout's) or cannot be loaded, or a device-only object is handed a CPU
+tensor, the call fails loudly with :class:`LsrError` -- there is no silent fallback of any kind.
 
 PyTorch is plumbing only: tensors own the device memory (so callers can ``clone()`` them and
 ``torch.cuda.empty_cache()`` as the reference does, ``shrimpy/dynatrack/tracking.py:1097-1102``)
@@ -229,7 +232,8 @@ def load() -> ctypes.CDLL:
             raise LsrError(
                 "load", -1,
                 f"{LIB_PATH} is missing; build it with `make -C {CSRC_DIR}` or "
-                "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.",
+                "`python -c 'import __graft_entry__ as g; g.build()'`. Nothing else implements these entry points "
+                "(the host twins for CPU tensors live in the same library).",
             )
         # torch ships its own libamdhip64.so.7; import it first so this library binds to the
         # SAME HIP runtime (same SONAME) and streams / pointers are interchangeable.
@@ -311,8 +315,8 @@ def require_device_f32(t, name: str):
     if t.device.type != "cuda":
         raise LsrError(
             "require_device", -1,
-            f"{name} is on {t.device}; this path runs only on a HIP device (MI355X). "
-            "There is no CPU fallback.",
+            f"{name} is on {t.device}; this entry runs only on a HIP device (MI355X) -- CPU tensors go through "
+            "shrimpy_amd.host (the lsr_*_cpu twins) from the public functions, not through the device objects.",
         )
     if t.dtype != torch.float32:
         raise TypeError(f"{name} must be float32, got {t.dtype}")

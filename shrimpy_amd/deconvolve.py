@@ -13,7 +13,7 @@ epilogues (ratio; multiplicative update with analytic ``H^T 1``): 12 algorithmic
 per launch.  Rank-1 (separable) PSFs run ``pz+py+px`` FMAs per voxel and are HBM-bound; dense
 PSFs run ``pz*py*px`` FMAs per voxel and are fp32-VALU-bound.  float32 throughout; agreement
 with the float64-accumulating scipy loop is stated in ``tests/test_gpu_parity.py``.
-No CPU fallback.
+CPU tensors (no HIP device in play) run the native host twins of the same launches (``shrimpy_amd/host.py``).
 """
 
 from __future__ import annotations
@@ -244,7 +244,8 @@ class RichardsonLucyPlan:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.LsrError("RichardsonLucyPlan", -1,
-                                f"device {self.device} is not a GPU; there is no CPU fallback")
+                                f"device {self.device} is not a GPU: the plan owns padded DEVICE volumes; CPU tensors run the host "
+                                "twins through richardson_lucy() / shrimpy_amd.host")
         self.shape = tuple(int(v) for v in shape_zyx)
         if len(self.shape) != 3 or min(self.shape) <= 0:
             raise ValueError(f"shape_zyx must be three positive ints, got {self.shape}")

@@ -115,7 +115,7 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
     if u16:
         if raw_data.device.type != "cuda" or not raw_data.is_contiguous():
             raise _lib.LsrError("require_device", -1, "raw_data must be a contiguous tensor on a HIP device "
-                                "(MI355X). There is no CPU fallback.")
+                                "(MI355X); CPU tensors take the host twin earlier in this function.")
         raw = raw_data
     else:
         raw = _lib.require_device_f32(raw_data, "raw_data")

@@ -15,7 +15,7 @@ coarse to fine (Gaussian blur + strided sampling of the target grid).  Each iter
 ``lsr_affine_normal_equations_f32`` (``csrc/estimate_affine.hip``: trilinear taps, analytic gradient,
 the 14 x 14 normal equations accumulated in fp64 registers) and a 14 x 14 solve on the host; an
 optional phase cross-correlation (the DynaTrack kernels) supplies the starting translation.
-There is no CPU fallback.
+The estimate runs on a HIP device only (its host side is a 14 x 14 solve; no host twin of the normal-equations kernel).
 """
 
 from __future__ import annotations

@@ -63,7 +63,7 @@ def _require_raw(t, name):
 
     if t.device.type != "cuda":
         raise _lib.LsrError("require_device", -1, f"{name} is on {t.device}; this path runs only on a HIP "
-                            "device (MI355X). There is no CPU fallback.")
+                            "device (MI355X); CPU tensors take the host twins (shrimpy_amd.host) from the public functions.")
     return t.contiguous()
 
 

@@ -13,7 +13,10 @@ reference installed.  It is deliberately small:
 * when both stages are on, the flat-field median is its own launch and the division happens while
   the deskew kernel stages its input slab (``csrc/deskew.hip``), so the corrected raw volume is never
   written;
-* nothing here can run on a CPU tensor: a host without a HIP device fails in ``warm_up``.
+* the device is resolved the reference's way (``cuda`` when a HIP device is visible, else ``cpu``,
+  ``shrimpy/preprocessing.py:78-82``): on ``cpu`` every stage runs its native host twin
+  (``csrc/host_twins.hip``, bit-equal to the kernels) -- unless ``require_gpu`` is set, which then raises in
+  ``warm_up`` as the reference's check does (``:357-363``).
 
 Contract kept from the reference (names are its API): ``build_preprocessor``'s signature, the
 ``RECON_STEPS`` tuple (``:41``), the returned dict keyed by ``output_channel`` with the optional

@@ -72,7 +72,7 @@ class VolumeStager:
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise _lib.LsrError("VolumeStager", -1, f"device {self.device}: staging needs a HIP device "
-                                "(pinned host memory and copy streams). There is no CPU fallback.")
+                                "(pinned host memory and copy streams); a run without a GPU reads and writes volumes directly.")
         if depth < 2:
             raise ValueError("depth must be at least 2 (one slot in flight, one being filled)")
         self.depth = int(depth)
