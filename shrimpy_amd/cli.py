@@ -41,10 +41,85 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 CONTEXT = {"help_option_names": ["-h", "--help"]}
 
 
+class _EatAll(click.Option):
+    """An option that takes every following argument up to the next option -- what biahub's ``-i`` does
+    ([RECALLED] ``OptionEatAll``), so that a shell glob works: ``-i plate.zarr/*/*/*`` expands to one path per
+    position directory.  The value is a tuple of strings."""
+
+    def add_to_parser(self, parser, ctx):
+        result = super().add_to_parser(parser, ctx)
+        ours = None
+        for name in self.opts:
+            ours = parser._long_opt.get(name) or parser._short_opt.get(name)
+            if ours is not None:
+                break
+        if ours is None:
+            return result
+        previous = ours.process
+        prefixes = tuple(parser._opt_prefixes)
+
+        def process(value, state):
+            values = [value]
+            while state.rargs and not (state.rargs[0].startswith(prefixes) and len(state.rargs[0]) > 1):
+                values.append(state.rargs.pop(0))
+            previous(tuple(values), state)
+
+        ours.process = process
+        return result
+
+
+def resolve_inputs(paths) -> tuple[Path, tuple[str, ...]]:
+    """``(store root, position keys)`` of what ``-i`` was given: ONE store (an HCS plate or a single FOV: every
+    position, keys ``()``) or N position directories ``<plate>/<row>/<col>/<fov>`` of one plate (the expansion of
+    ``plate.zarr/*/*/*``), grouped by their common plate root."""
+    from .io.omezarr import _detect
+
+    paths = [Path(p) for p in ((paths,) if isinstance(paths, (str, os.PathLike)) else paths)]
+    if not paths:
+        raise click.ClickException("-i needs at least one path")
+    for p in paths:
+        if not p.exists():
+            raise click.ClickException(f"-i: {p} does not exist")
+    if len(paths) == 1:
+        p = paths[0]
+        try:
+            _, layout = _detect(p)
+        except (FileNotFoundError, ValueError) as exc:
+            raise click.ClickException(f"-i: {exc}") from exc
+        if layout == "fov" and len(p.resolve().parents) >= 3:
+            try:   # a position directory of a plate: process that position of the plate (its key is the plate's)
+                root = p.resolve().parents[2]
+                if _detect(root)[1] == "hcs":
+                    return root, ("/".join(p.resolve().parts[-3:]),)
+            except (FileNotFoundError, ValueError):
+                pass
+        return p, ()
+    roots, keys = set(), []
+    for p in paths:
+        r = p.resolve()
+        if len(r.parents) < 3:
+            raise click.ClickException(f"-i: {p} is not a <plate>/<row>/<col>/<fov> position directory")
+        roots.add(r.parents[2])
+        keys.append("/".join(r.parts[-3:]))
+    if len(roots) != 1:
+        raise click.ClickException(f"-i: the position directories belong to {len(roots)} different plates "
+                                   f"({sorted(str(r) for r in roots)}); run them one plate at a time")
+    root = roots.pop()
+    try:
+        if _detect(root)[1] != "hcs":
+            raise ValueError(f"{root} is not an HCS plate")
+    except (FileNotFoundError, ValueError) as exc:
+        raise click.ClickException(f"-i: several paths must be position directories of one plate: {exc}") from exc
+    if len(set(keys)) != len(keys):
+        raise click.ClickException("-i: a position directory is listed twice")
+    return root, tuple(keys)
+
+
 def _common(fn):
-    fn = click.option("-i", "--input-position-dirpaths", "input_path", required=True,
-                      type=click.Path(exists=True, path_type=Path),
-                      help="Input OME-Zarr store (HCS plate or single FOV).")(fn)
+    fn = click.option("-i", "--input-position-dirpaths", "input_path", required=True, cls=_EatAll,
+                      type=click.UNPROCESSED,
+                      help="Input OME-Zarr store (HCS plate or single FOV), or the position directories of one plate "
+                           "(a glob such as plate.zarr/*/*/*).")(fn)
     fn = click.option("-c", "--config-filepath", "config", required=True,
                       type=click.Path(exists=True, dir_okay=False, path_type=Path),
                       help="YAML settings file.")(fn)
@@ -53,8 +128,9 @@ def _common(fn):
                       help="Output OME-Zarr store (must not exist, unless --resume).")(fn)
     fn = click.option("-p", "--position", "positions", multiple=True,
                       help='Restrict to these position keys ("row/col/fov"); repeatable.')(fn)
-    fn = click.option("--zarr-version", type=click.Choice(["0.4", "0.5"]), default="0.4", show_default=True,
-                      help="NGFF version of the output store.")(fn)
+    fn = click.option("--zarr-version", type=click.Choice(["0.4", "0.5"]), default="0.5", show_default=True,
+                      help="NGFF version of the output store (0.5 = Zarr v3, what the reference writes: "
+                           "shrimpy/dynatrack/tracking.py:1337-1343).")(fn)
     fn = click.option("--resume", is_flag=True,
                       help="Continue an interrupted run: units already completed in the output store "
                            "(same input and settings) are skipped, unfinished ones are rewritten.")(fn)
@@ -63,8 +139,21 @@ def _common(fn):
                       help="Store access: this package's reader/writer, iohub, or native with iohub as the "
                            "fallback for codecs it does not implement.")(fn)
     fn = click.option("--compression", type=click.Choice(["none", "gzip", "zstd", "blosc-zstd"]),
-                      default="none", show_default=True, help="Chunk compression of the output (native writer).")(fn)
+                      default="blosc-zstd", show_default=True,
+                      help="Chunk compression of the output (native writer); blosc-zstd is what the acquisition engine "
+                           "writes (shrimpy/mantis/mantis_engine.py:474-481), none is the fastest.")(fn)
     return fn
+
+
+def _inputs(input_path, positions):
+    """The store and position selection of a command: ``-i`` (one store or N position directories) and ``-p``."""
+    root, keys = resolve_inputs(input_path)
+    if keys and positions:
+        missing = [p for p in positions if p not in keys]
+        if missing:
+            raise click.ClickException(f"-p {missing}: not among the position directories given to -i")
+        keys = tuple(k for k in keys if k in positions)
+    return root, tuple(keys) or tuple(positions)
 
 
 def _distributed():
@@ -404,6 +493,7 @@ def cli(verbose: bool):
 @_common
 def deskew(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression):
     """Deskew oblique-plane stacks (config: DeskewSettings YAML)."""
+    input_path, positions = _inputs(input_path, positions)
     s = ReconstructSettings(deskew=DeskewSettings.from_yaml(config))
     click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
                          io_backend=io_backend, compression=compression))
@@ -413,6 +503,7 @@ def deskew(input_path, config, output_path, positions, zarr_version, resume, io_
 @_common
 def register(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression):
     """Apply an affine registration (config: RegisterSettings YAML with affine_transform_zyx)."""
+    input_path, positions = _inputs(input_path, positions)
     s = ReconstructSettings(registration=RegisterSettings.from_yaml(config))
     click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
                          io_backend=io_backend, compression=compression))
@@ -422,6 +513,7 @@ def register(input_path, config, output_path, positions, zarr_version, resume, i
 @_common
 def deconvolve(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression):
     """Richardson-Lucy deconvolution (config: DeconvolveSettings YAML)."""
+    input_path, positions = _inputs(input_path, positions)
     s = ReconstructSettings(deconvolution=DeconvolveSettings.from_yaml(config))
     click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
                          io_backend=io_backend, compression=compression))
@@ -431,6 +523,7 @@ def deconvolve(input_path, config, output_path, positions, zarr_version, resume,
 @_common
 def reconstruct(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression):
     """deskew -> register -> deconvolve in one pass (config: ReconstructSettings YAML)."""
+    input_path, positions = _inputs(input_path, positions)
     s = ReconstructSettings.from_yaml(config)
     if s.deskew is None and s.registration is None and s.deconvolution is None:
         raise click.ClickException("the config enables no step")

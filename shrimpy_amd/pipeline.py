@@ -97,8 +97,10 @@ class VolumeReconstructor:
             # un-oriented output: the deskew kernel (either border rule) can write the RL input in place
             self._canonical_deskew = d.orientation in ("identity", "")
         self._register: RegisterSettings | None = settings.registration
-        if self._register is not None and self._register.output_shape_zyx is not None:
-            shape = tuple(self._register.output_shape_zyx)
+        self._register_matrix = None
+        self.register_origin = (0, 0, 0)    # target coordinate of output index 0 (non-zero with keep_overhang)
+        if self._register is not None:
+            self._register_matrix, shape, self.register_origin = self._register.resolved(shape)
         self.output_shape = tuple(shape)
         self._plan = None
         self._y_pad = None
@@ -194,7 +196,7 @@ class VolumeReconstructor:
                 if self._y_pad is None:
                     self._y_pad = self._plan.new_padded_input()
                 target = self._y_pad
-            vol = apply_affine_transform_zyx(vol, np.asarray(r.affine_transform_zyx), self.output_shape,
+            vol = apply_affine_transform_zyx(vol, self._register_matrix, self.output_shape,
                                              mode=r.mode, cval=r.cval, out=target)
         if self._plan is not None:
             dec = self.settings.deconvolution

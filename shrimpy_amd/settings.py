@@ -113,6 +113,11 @@ class RegisterSettings(_StrictModel):
     ``source_channel_names``: the channels the transform is applied to (empty = every channel);
     any other channel -- ``target_channel_name`` among them -- passes through unwarped
     (``cli._channel_plan``).
+
+    ``keep_overhang`` ([RECALLED] biahub ``register``): ``False`` crops the result to the target grid
+    (``output_shape_zyx``, default the moving volume's own shape); ``True`` grows the output to the UNION of the target
+    grid and the moving volume's footprint in target coordinates, so nothing of either is lost: the box's lower corner
+    is folded into the matrix (``resolved``), the output shape is the box's.
     """
 
     source_channel_names: list[str] = []
@@ -123,13 +128,29 @@ class RegisterSettings(_StrictModel):
     cval: float = 0.0
     keep_overhang: bool = False
 
-    @field_validator("keep_overhang")
-    @classmethod
-    def _no_overhang_yet(cls, v):
-        if v:
-            raise ValueError("keep_overhang=True (output grown to the union of both volumes) is not "
-                             "implemented; give output_shape_zyx and fold the shift into the matrix")
-        return v
+    def resolved(self, source_shape_zyx):
+        """``(matrix_4x4, output_shape_zyx, origin_zyx)`` this settings object applies to a moving volume of
+        ``source_shape_zyx``: the matrix maps OUTPUT indices to source coordinates, ``origin_zyx`` is where output
+        index 0 sits in target coordinates (all zero unless ``keep_overhang``)."""
+        m = np.asarray(self.affine_transform_zyx, dtype=np.float64)
+        src = tuple(int(v) for v in source_shape_zyx)
+        tgt = tuple(int(v) for v in (self.output_shape_zyx or src))
+        if not self.keep_overhang:
+            return m, tgt, (0, 0, 0)
+        a, t = m[:3, :3], m[:3, 3]
+        if abs(np.linalg.det(a)) < 1e-12:
+            raise ValueError("keep_overhang needs an invertible affine_transform_zyx")
+        # the moving volume's voxel centres span [0, n - 1] per axis: its corners in target coordinates
+        corners = np.array([[z, y, x] for z in (0, src[0] - 1) for y in (0, src[1] - 1) for x in (0, src[2] - 1)], dtype=np.float64)
+        in_target = (np.linalg.inv(a) @ (corners - t).T).T
+        lo = np.minimum(0.0, np.floor(in_target.min(axis=0) + 1e-9)).astype(np.int64)
+        hi = np.maximum(np.asarray(tgt) - 1.0, np.ceil(in_target.max(axis=0) - 1e-9)).astype(np.int64)
+        shape = tuple(int(v) for v in (hi - lo + 1))
+        if max(shape) >= 1 << 30:
+            raise ValueError(f"keep_overhang: the union box {shape} is absurd (a near-singular transform?)")
+        grown = m.copy()
+        grown[:3, 3] = a @ lo.astype(np.float64) + t        # output index i is target coordinate i + lo
+        return grown, shape, tuple(int(v) for v in lo)
 
     @field_validator("affine_transform_zyx")
     @classmethod

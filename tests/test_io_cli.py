@@ -437,8 +437,94 @@ def test_register_warps_only_the_source_channels(tmp_path, cpu_cli):
 
     with pytest.raises(click.ClickException, match="output_shape_zyx"):
         cpu_cli.run_store(src, tmp_path / "bad.zarr", s, reconstructor_factory=Reshaping)
-    with pytest.raises(ValueError, match="keep_overhang"):
-        RegisterSettings(affine_transform_zyx=eye, keep_overhang=True)
+
+
+def test_input_option_takes_one_store_or_the_position_directories_a_glob_expands_to(tmp_path, cpu_cli):
+    """[RECALLED] biahub ``-i/--input-position-dirpaths`` eats every following path (``plate.zarr/*/*/*``); both forms
+    select the same units, position directories are grouped by their plate, mixed plates are refused, ``-p`` narrows."""
+    import click
+
+    from click.testing import CliRunner
+
+    src = _make_plate(tmp_path / "raw.zarr", "0.5")
+    other = _make_plate(tmp_path / "other.zarr", "0.5")
+    assert cpu_cli.resolve_inputs([src]) == (src, ())
+    dirs = [src / k for k in KEYS]
+    assert cpu_cli.resolve_inputs(dirs) == (src.resolve(), tuple(KEYS))
+    assert cpu_cli.resolve_inputs([dirs[1]]) == (src.resolve(), (KEYS[1],))      # one position of a plate
+    for bad, why in (([dirs[0], other / KEYS[1]], "different plates"), ([dirs[0], dirs[0]], "twice"),
+                     ([tmp_path / "nope"], "does not exist"), ([src, other], "position director")):
+        with pytest.raises(click.ClickException, match=why):
+            cpu_cli.resolve_inputs(bad)
+    cfg = tmp_path / "deskew.yml"
+    cfg.write_text(yaml.safe_dump(dict(pixel_size_um=0.1133, ls_angle_deg=30.0, scan_step_um=0.15,
+                                       keep_overhang=True, average_n_slices=3)))
+    seen = []
+
+    def fake_run_store(input_path, output_path, settings, positions=(), zarr_version="0.5", **kw):
+        seen.append((input_path, tuple(positions), zarr_version, kw.get("compression")))
+        return {}
+
+    import shrimpy_amd.cli as real
+
+    real_run = real.run_store
+    real.run_store = fake_run_store
+    try:
+        run = CliRunner()
+        # the glob form: -i eats the paths up to the next option
+        r = run.invoke(real.cli, ["deskew", "-i", str(dirs[0]), str(dirs[1]), "-c", str(cfg), "-o", str(tmp_path / "a.zarr")])
+        assert r.exit_code == 0, r.output
+        r = run.invoke(real.cli, ["deskew", "-c", str(cfg), "-o", str(tmp_path / "b.zarr"), "-i", str(src)])
+        assert r.exit_code == 0, r.output
+        r = run.invoke(real.cli, ["deskew", "-i", str(dirs[0]), str(dirs[1]), "-p", KEYS[1], "-c", str(cfg), "-o", str(tmp_path / "c.zarr")])
+        assert r.exit_code == 0, r.output
+        r = run.invoke(real.cli, ["deskew", "-i", str(dirs[0]), "-p", KEYS[1], "-c", str(cfg), "-o", str(tmp_path / "d.zarr")])
+        assert r.exit_code != 0 and "not among the position directories" in r.output
+    finally:
+        real.run_store = real_run
+    assert seen[0][:2] == (src.resolve(), tuple(KEYS)) and seen[1][:2] == (src, ()) and seen[2][:2] == (src.resolve(), (KEYS[1],))
+    # the output defaults are the reference's own format: NGFF 0.5 (tracking.py:1337-1343), blosc-zstd (mantis_engine.py:474-481)
+    assert seen[0][2:] == ("0.5", "blosc-zstd")
+
+
+def test_registration_keep_overhang_grows_the_output_to_the_union_box(tmp_path):
+    """[RECALLED] biahub RegisterSettings.keep_overhang: the output covers the target grid AND the moving volume's
+    footprint; the box's corner is folded into the matrix.  Values against the oracle's affine apply on that box
+    (CPU tensors: the host twin, bit-equal to scipy)."""
+    import torch
+
+    from oracle import cpu_ref as o
+    from shrimpy_amd.pipeline import VolumeReconstructor
+    from shrimpy_amd.settings import ReconstructSettings, RegisterSettings
+
+    rng = np.random.default_rng(3)
+    vol = rng.random((6, 10, 14)).astype(np.float32)
+    th = np.deg2rad(10.0)
+    m = np.eye(4)
+    m[1:3, 1:3] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+    m[:3, 3] = [1.5, -2.0, 3.25]
+    plain = RegisterSettings(affine_transform_zyx=m.tolist())
+    assert plain.resolved(vol.shape)[1:] == (vol.shape, (0, 0, 0))
+    grown = RegisterSettings(affine_transform_zyx=m.tolist(), keep_overhang=True)
+    mat, shape, origin = grown.resolved(vol.shape)
+    # every corner of the moving volume lands inside the box, and so does the target grid
+    corners = np.array([[z, y, x] for z in (0, 5) for y in (0, 9) for x in (0, 13)], float)
+    in_target = (np.linalg.inv(m[:3, :3]) @ (corners - m[:3, 3]).T).T - np.asarray(origin)
+    assert np.all(in_target >= -1e-9) and np.all(in_target <= np.asarray(shape) - 1 + 1e-9)
+    assert all(o_ <= 0 for o_ in origin) and all(o_ + n >= t for o_, n, t in zip(origin, shape, vol.shape))
+    assert shape != vol.shape
+    rec = VolumeReconstructor(vol.shape, ReconstructSettings(registration=grown), "cpu")
+    assert rec.output_shape == shape and rec.register_origin == origin
+    got = rec(torch.as_tensor(vol)).numpy()
+    np.testing.assert_array_equal(got, o.affine_apply_4x4(vol, mat, shape))
+    # the target window of the grown output is the plain registration
+    z0, y0, x0 = (-v for v in origin)
+    want = VolumeReconstructor(vol.shape, ReconstructSettings(registration=plain), "cpu")(torch.as_tensor(vol)).numpy()
+    np.testing.assert_array_equal(got[z0:z0 + 6, y0:y0 + 10, x0:x0 + 14], want)
+    # the moving volume's content survives: its sum in the grown output is (close to) the whole of it, not a crop
+    assert got.sum() > want.sum() * 1.05
+    with pytest.raises(ValueError, match="invertible"):
+        RegisterSettings(affine_transform_zyx=np.diag([1, 0, 1, 1.0]).tolist(), keep_overhang=True).resolved(vol.shape)
 
 
 def test_heterogeneous_plates_are_refused_before_anything_is_written(tmp_path, cpu_cli):
