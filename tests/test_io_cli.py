@@ -191,7 +191,7 @@ def test_cli_commands_parse_configs_and_positions(tmp_path, cpu_cli, monkeypatch
                                     "--zarr-version", "0.5"])
     assert r.exit_code == 0, r.output
     assert seen["settings"].deconvolution.iterations == 7 and seen["version"] == "0.5"
-    assert (seen["resume"], seen["io_backend"], seen["compression"]) == (False, "auto", "none")
+    assert (seen["resume"], seen["io_backend"], seen["compression"]) == (False, "auto", "blosc-zstd")   # the reference's format
     r = runner.invoke(cpu_cli.cli, ["deconvolve", "-i", str(src), "-c", str(dec), "-o", str(tmp_path / "o2"),
                                     "--resume", "--io", "native", "--compression", "blosc-zstd"])
     assert r.exit_code == 0, r.output
