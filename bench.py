@@ -532,6 +532,42 @@ def _blosc_backend() -> str:
     return blosc_backend()
 
 
+def host_floor(root, key, out_shape):
+    """What the host side of one unit costs at best on this rank's cores: the unit's read (file reads + entropy
+    decoding + unshuffle into one buffer) and its write (chunk files of the float32 result) each timed on ONE thread,
+    added and divided by the core share -- the store-to-store time per unit if both pools scaled perfectly and the
+    kernels, copies and Python cost nothing.  The measured ``s_per_unit`` next to it says how far the pipeline is
+    from its host."""
+    import numpy as np
+
+    from shrimpy_amd.io.omezarr import as_volume_array, io_thread_budget, open_ome_zarr, rank_cores
+
+    prev = io_thread_budget(read=1, write=1)
+    try:
+        with open_ome_zarr(root / "in.zarr", mode="r", prefer_iohub=False) as plate:
+            arr = as_volume_array(dict(plate.positions())[key]["0"])
+            buf = np.empty(arr.shape[2:], dtype=arr.dtype)
+            arr.read_volume(0, 0, out=buf)            # (page cache warm, as in the run)
+            t0 = time.perf_counter()
+            arr.read_volume(0, 0, out=buf)
+            t_read = time.perf_counter() - t0
+        with open_ome_zarr(root / "out.zarr", mode="a", prefer_iohub=False) as plate:
+            arr = as_volume_array(dict(plate.positions())[key]["0"])
+            vol = np.zeros(tuple(out_shape), dtype=np.float32)
+            vol[::7] = 1.0
+            t0 = time.perf_counter()
+            arr.write_volume(0, 0, vol)
+            t_write = time.perf_counter() - t0
+    finally:
+        io_thread_budget(**prev)
+    cores = rank_cores()
+    return {"read_one_thread_s": round(t_read, 4), "write_one_thread_s": round(t_write, 4), "cores": cores,
+            "floor_s_per_unit": round((t_read + t_write) / cores, 4),
+            "read_GBps_per_core": round(buf.nbytes / t_read / 1e9, 2), "write_GBps_per_core": round(vol.nbytes / t_write / 1e9, 2),
+            "note": "(one-thread read + one-thread write of one unit) / cores of this rank: perfect scaling of both pools, "
+                    "nothing else on the cores"}
+
+
 def run_plate(args, rank, world, device, shared, backend, cpu):
     """Configs 4 / 5: (a) one unit per GPU with its uint16 stack resident in HBM through the
     production pipeline object (``VolumeReconstructor``); (b) the same kind of units store to store."""
@@ -618,6 +654,8 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
                           else "uncompressed chunks (input (1,1,32,ny,nx), output ~64 MB), ")
                        + f"scratch {root.parent}, input from the page cache; pinned staging slots + copy streams (cli.run_store)"),
             }
+            if rank == 0:
+                store["host_floor"] = host_floor(root, keys[0], out_shape)
             if world > 1:
                 dist.barrier()
         finally:

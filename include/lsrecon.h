@@ -403,6 +403,19 @@ int lsr_rl_dense_padded_f32(const float* y, int64_t y_pitch, int64_t y_plane, in
                             lsr_stream_t stream);
 
 /*
+ * Axial PSFs beyond 15 taps: 1-D correlation along z with up to lsr_correlate_z_max_taps() (31) odd taps and the RL
+ * epilogues (csrc/correlate_z.hip) -- the z half of a separable PSF whose in-plane factors run through
+ * lsr_correlate_sep_strided_f32 with ONE z tap: H x = Cz(Cyx(x)), two launches per correlation, four per iteration.
+ * Any strides (floats; rows may be padded), no halo needed, `in` != `out`; `out` may alias `aux`.  UPDATE divides by
+ * nz[z] * ny[y] * nx[x] and adds the launch's RL scalars to stats[0..2] when that is not NULL (see below).
+ */
+int lsr_correlate_z_max_taps(void);
+int lsr_correlate_z_f32(const float* in, int64_t in_pitch, int64_t in_plane, const float* aux, int64_t aux_pitch,
+                        int64_t aux_plane, float* out, int64_t out_pitch, int64_t out_plane, int64_t Z, int64_t Y,
+                        int64_t X, const float* wz, int pz, int epilogue, float eps, const float* nz, const float* ny,
+                        const float* nx, double* stats, lsr_stream_t stream);
+
+/*
  * Richardson-Lucy reduction scalars (the north-star's "wavefront reductions for the ratio / normalisation").
  * Every entry that finishes an RL iteration has a `_stats` form with one more argument, `double* stats` (DEVICE memory;
  * host memory for the *_cpu twins); NULL = the plain entry, the same kernels, no cost.  Per iteration i three sums over

@@ -91,6 +91,9 @@ SIGNATURES: dict[str, list] = {
                                         ctypes.c_void_p, _stream],
     "lsr_blosc_host_codec": [_int],
     "lsr_blosc_decode_host": [ctypes.c_void_p, _i64, ctypes.c_void_p, _i64, ctypes.POINTER(ctypes.c_int)],
+    "lsr_correlate_z_max_taps": [],
+    "lsr_correlate_z_f32": [_c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _c_f32p, _int,
+                            _int, _f32, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _stream],
     "lsr_crc32c_host": [ctypes.c_void_p, _i64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)],
     "lsr_crc32c_host_portable": [ctypes.c_void_p, _i64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)],
     "lsr_average_slices_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _int, _stream],

@@ -45,6 +45,7 @@ using lsr::parallel_ranges;
 std::atomic<int>& g_threads = lsr::g_host_threads;
 constexpr int kMaxAvg = 16;    // as deskew.hip
 constexpr int kMaxTaps = 15;   // as correlate.hip
+constexpr int kMaxZTaps = 31;  // as correlate_z.hip
 
 // acc[x] = fma(w, v(x + shift), acc[x]) over a whole row, v = row[...] inside [0, X) and 0 outside it (row == nullptr:
 // a row of zeros) -- the FMA with 0 is executed, as the kernels execute it; the middle part is a plain packed loop.
@@ -237,9 +238,11 @@ int check_corr(const float* in, float* out, const float* aux, int64_t Z, int64_t
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
               (long long)X);
   LSR_REQUIRE_VOLUME(Z, Y, X);
-  LSR_REQUIRE(pz >= 1 && py >= 1 && px >= 1 && (pz & 1) && (py & 1) && (px & 1) && pz <= kMaxTaps && py <= kMaxTaps &&
+  // (z: up to 31 taps, what the device runs through lsr_correlate_z_f32; the loops below take any count)
+  LSR_REQUIRE(pz >= 1 && py >= 1 && px >= 1 && (pz & 1) && (py & 1) && (px & 1) && pz <= kMaxZTaps && py <= kMaxTaps &&
                   px <= kMaxTaps,
-              LSR_E_UNSUPPORTED, "PSF taps (%d,%d,%d) must be odd and <= %d per axis", pz, py, px, kMaxTaps);
+              LSR_E_UNSUPPORTED, "PSF taps (%d,%d,%d) must be odd, <= %d in plane and <= %d along z", pz, py, px, kMaxTaps,
+              kMaxZTaps);
   LSR_REQUIRE(epilogue == LSR_EPI_NONE || epilogue == LSR_EPI_RATIO || epilogue == LSR_EPI_UPDATE, LSR_E_ARG,
               "unknown epilogue %d", epilogue);
   if (epilogue != LSR_EPI_NONE) LSR_REQUIRE_PTR(aux);

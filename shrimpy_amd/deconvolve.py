@@ -30,6 +30,7 @@ __all__ = ["richardson_lucy", "RichardsonLucyPlan", "RLStats", "factor_psf", "co
            "padded_shape", "PaddedVolume"]
 
 MAX_TAPS = 15
+MAX_Z_TAPS = 31     # separable PSFs only: the z factor runs as its own launch (csrc/correlate_z.hip)
 
 
 def prepare_psf(psf) -> np.ndarray:
@@ -45,8 +46,8 @@ def prepare_psf(psf) -> np.ndarray:
     pad = [(0, 1 - (s % 2)) for s in p.shape]
     if any(hi for _, hi in pad):
         p = np.pad(p, pad)
-    if max(p.shape) > MAX_TAPS:
-        raise ValueError(f"psf shape {p.shape} exceeds {MAX_TAPS} taps per axis")
+    if max(p.shape[1:]) > MAX_TAPS or p.shape[0] > MAX_Z_TAPS:
+        raise ValueError(f"psf shape {p.shape} exceeds {MAX_TAPS} taps in plane / {MAX_Z_TAPS} along z")
     return np.ascontiguousarray(p)
 
 
@@ -255,8 +256,9 @@ class RichardsonLucyPlan:
         factors = None
         if psf_factors is not None:
             factors = tuple(np.asarray(k, dtype=np.float32).ravel() for k in psf_factors)
-            if len(factors) != 3 or any(len(k) % 2 == 0 or len(k) > MAX_TAPS for k in factors):
-                raise ValueError("psf_factors must be three odd-length 1-D kernels (<= 15 taps)")
+            if (len(factors) != 3 or any(len(k) % 2 == 0 for k in factors) or len(factors[0]) > MAX_Z_TAPS
+                    or max(len(factors[1]), len(factors[2])) > MAX_TAPS):
+                raise ValueError("psf_factors must be three odd-length 1-D kernels (<= 31 taps along z, <= 15 in plane)")
             self.psf = (factors[0][:, None, None] * factors[1][None, :, None]
                         * factors[2][None, None, :]).astype(np.float32)
         else:
@@ -265,12 +267,18 @@ class RichardsonLucyPlan:
                 factors = factor_psf(self.psf, separable_rtol)
                 if factors is None and separable == "force":
                     raise ValueError("psf is not rank-1 within separable_rtol")
+            if factors is None and self.psf.shape[0] > MAX_TAPS:
+                raise ValueError(f"a PSF with {self.psf.shape[0]} z taps must be separable (kz x ky x kx within "
+                                 f"separable_rtol): the dense and ky (x) kzx stencils hold <= {MAX_TAPS} taps per axis")
 
         def dev(a, dtype=torch.float32):
             # (np.array copies: a reversed 1-element view keeps its negative stride otherwise)
             return torch.as_tensor(np.array(a, order="C"), device=self.device).to(dtype)
 
         z, y, x = self.shape
+        # an axial factor beyond the tiled kernels' 15 taps: every correlation = in-plane launch + z launch
+        self._long_z = factors is not None and len(factors[0]) > MAX_TAPS
+        self._t_dense = None
         if factors is not None:
             kz, ky, kx = factors
             self._psf = _DevicePsf(
@@ -286,6 +294,7 @@ class RichardsonLucyPlan:
                     raise ValueError(f"y_window {y_window} does not contain {y} rows")
                 ny = _axis_norm(ky, total)[first:first + y]
             self._norm = (dev(_axis_norm(kz, z)), dev(ny), dev(_axis_norm(kx, x)))
+            self._one = dev(np.ones(1, np.float32))
         else:
             w = self.psf
             ysep = factor_psf_y(w, separable_rtol) if separable == "auto" and y_window is None else None
@@ -345,7 +354,7 @@ class RichardsonLucyPlan:
         self._ratio_pad = None
         self._y_pad = None   # fused path: padded copy of a dense y
         # one launch per iteration (rl_fused_sep.hip) where the PSF fits its specialisations
-        self.fused = bool(self._psf.separable and self._fused_mode in ("auto", "always")
+        self.fused = bool(self._psf.separable and not self._long_z and self._fused_mode in ("auto", "always")
                           and _lib.call_value("lsr_rl_sep_fused_supported", *self._psf.shape)
                           and (self._fused_mode == "always" or fused_pays(*self._psf.shape)))
         if self.fused:
@@ -364,6 +373,8 @@ class RichardsonLucyPlan:
         """Which kernels an iteration runs: ``fused`` (one launch), ``separable`` (ratio / update
         pair), ``y-separable`` ((z, x) stencil + y pass, twice), ``dense`` or ``generic``."""
         if self._psf.separable:
+            if self._long_z:
+                return "separable (long z, 4 launches)"
             return "fused" if self.fused else "separable"
         if self._ysep is not None:
             if self.fused_ysep:
@@ -376,8 +387,8 @@ class RichardsonLucyPlan:
 
         if self._psf.separable or self._psf.taps is not None or self._ysep is not None:
             if self._x_pad is None:
-                self._x_pad = PaddedVolume(self.shape, self._psf.shape, self.device)
-                self._ratio_pad = PaddedVolume(self.shape, self._psf.shape, self.device)
+                self._x_pad = PaddedVolume(self.shape, self._pad_psf_shape(), self.device)
+                self._ratio_pad = PaddedVolume(self.shape, self._pad_psf_shape(), self.device)
             return self._x_pad, self._ratio_pad
         if self._ratio is None:
             self._ratio = torch.empty(self.shape, dtype=torch.float32, device=self.device)
@@ -385,13 +396,50 @@ class RichardsonLucyPlan:
 
     def padded_geometry(self):
         """(pitch, plane, rows, origin_row, origin_col) of this plan's padded working volumes."""
-        rows, pitch, oy, ox = padded_shape(self.shape, self._psf.shape)
+        rows, pitch, oy, ox = padded_shape(self.shape, self._pad_psf_shape())
         return pitch, rows * pitch, rows, oy, ox
 
     def new_padded_input(self) -> "PaddedVolume":
         """A zero-haloed volume in this plan's geometry, for a producer (the deskew kernel) to write
         ``y`` into; pass it to ``plan(...)`` to skip both the pad copy and the ``x0 = y`` copy."""
-        return PaddedVolume(self.shape, self._psf.shape, self.device)
+        return PaddedVolume(self.shape, self._pad_psf_shape(), self.device)
+
+    def _pad_psf_shape(self):
+        """The PSF extents the padded working volumes are laid out for (the z extent of a long-z PSF is not the tiled
+        kernels' business: they run with one z tap)."""
+        return (1,) + tuple(self._psf.shape[1:]) if self._long_z else tuple(self._psf.shape)
+
+    def _iterate_long_z(self, y_ptr, y_pitch, y_plane, init, x_out, it0, n, eps, stream, stats):
+        """RL for a separable PSF with 17 .. 31 z taps: H x = Cz(Cyx(x)) -- the in-plane factors through the tiled
+        separable kernel with a single z tap, the z factor through ``lsr_correlate_z_f32`` (a register march, no halo),
+        which also carries the epilogues.  Four launches and 48 algorithmic bytes per voxel and iteration."""
+        import torch
+
+        x_pad, ratio_pad = self._scratch()
+        if it0 == 0:
+            x_pad.view.copy_(init)
+        if self._t_dense is None:
+            self._t_dense = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        t = self._t_dense
+        z, yy, xx = self.shape
+        pitch, plane = x_pad.pitch, x_pad.plane
+        (kz, ky, kx), (fz, fy, fx) = self._psf.k, self._psf.k_flipped
+        nz, ny, nx = self._norm
+        pz, py, px = self._psf.shape
+        one = self._one
+        ceps, f0 = ctypes.c_float(eps), ctypes.c_float(0.0)
+        for it in range(it0, it0 + n):
+            last = x_out is not None and it + 1 == it0 + n
+            for src, wy, wx, wz, epi, aux, out in (
+                    (x_pad, fy, fx, fz, _lib.EPI_RATIO, (y_ptr, y_pitch, y_plane), (ratio_pad.logical_ptr(), pitch, plane)),
+                    (ratio_pad, ky, kx, kz, _lib.EPI_UPDATE, (x_pad.logical_ptr(), pitch, plane),
+                     (x_out.data_ptr(), xx, yy * xx) if last else (x_pad.logical_ptr(), pitch, plane))):
+                _lib.call("lsr_correlate_sep_strided_f32", src.logical_ptr(), pitch, plane, None, 0, 0, t.data_ptr(), xx,
+                          yy * xx, z, yy, xx, one.data_ptr(), 1, wy.data_ptr(), py, wx.data_ptr(), px, _lib.EPI_NONE, f0,
+                          None, None, None, stream)
+                _lib.call("lsr_correlate_z_f32", t.data_ptr(), xx, yy * xx, aux[0], aux[1], aux[2], out[0], out[1], out[2],
+                          z, yy, xx, wz.data_ptr(), pz, epi, ceps, nz.data_ptr(), ny.data_ptr(), nx.data_ptr(),
+                          None if (stats is None or epi != _lib.EPI_UPDATE) else stats.data_ptr() + 24 * it, stream)
 
     def iterate_padded(self, y_pad: "PaddedVolume", src: "PaddedVolume", dst: "PaddedVolume",
                        eps: float = 1e-6, stats=None) -> None:
@@ -515,7 +563,7 @@ class RichardsonLucyPlan:
 
     def release(self) -> None:
         """Drop the scratch volumes."""
-        self._ratio = self._x_pad = self._ratio_pad = self._y_pad = self._t_pad = None
+        self._ratio = self._x_pad = self._ratio_pad = self._y_pad = self._t_pad = self._t_dense = None
 
     # ------------------------------------------------------------------------------------------ the loop
     def _launch(self, st, it0: int, n: int, x_out, stats) -> None:
@@ -554,6 +602,8 @@ class RichardsonLucyPlan:
                       nz.data_ptr(), ny.data_ptr(), nx.data_ptr(), n, eps, sp, stream)
         elif kind == "ysep":
             self._iterate_ysep(y_ptr, y_pitch, y_plane, st["init"], x_out, it0, n, st["eps"], stream, stats)
+        elif kind == "longz":
+            self._iterate_long_z(y_ptr, y_pitch, y_plane, st["init"], x_out, it0, n, st["eps"], stream, stats)
         elif kind == "dense":
             x_pad, ratio_pad = self._scratch()
             _lib.call("lsr_rl_dense_padded_stats_f32", y_ptr, y_pitch, y_plane, from_y, x_pad.full.data_ptr(),
@@ -648,6 +698,8 @@ class RichardsonLucyPlan:
                     from_y = x0 is None
                 if not from_y:
                     x_pad.view.copy_(init)
+            elif self._long_z:
+                st["kind"] = "longz"
             elif ps.separable or ps.taps is not None and self._ysep is None:
                 # working volumes carry a zero halo: the kernels never bounds-check a load
                 st["kind"] = "separable" if ps.separable else "dense"

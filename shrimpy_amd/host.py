@@ -195,8 +195,11 @@ def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=Non
     factors = None
     if psf_factors is not None:
         factors = tuple(_taps(np.asarray(k).ravel()) for k in psf_factors)
-        if len(factors) != 3 or any(len(k) % 2 == 0 or len(k) > MAX_TAPS for k in factors):
-            raise ValueError("psf_factors must be three odd-length 1-D kernels (<= 15 taps)")
+        from .deconvolve import MAX_Z_TAPS
+
+        if (len(factors) != 3 or any(len(k) % 2 == 0 for k in factors) or len(factors[0]) > MAX_Z_TAPS
+                or max(len(factors[1]), len(factors[2])) > MAX_TAPS):
+            raise ValueError("psf_factors must be three odd-length 1-D kernels (<= 31 taps along z, <= 15 in plane)")
     else:
         w = prepare_psf(psf)
         if separable != "never":

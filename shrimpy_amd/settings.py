@@ -195,8 +195,9 @@ class DeconvolveSettings(_StrictModel):
     @field_validator("gaussian_shape_zyx", "psf_shape_zyx")
     @classmethod
     def _odd_taps(cls, v):
-        if v is not None and any(n % 2 == 0 or n > 15 for n in v):
-            raise ValueError("PSF extents must be odd and <= 15 per axis")
+        if v is not None and (any(n % 2 == 0 for n in v) or v[0] > 31 or max(v[1:]) > 15):
+            raise ValueError("PSF extents must be odd, <= 15 in plane and <= 31 along z (more than 15 z taps: separable "
+                             "PSFs only -- the Gaussian, or a measured PSF that factors within separable_rtol)")
         return v
 
     def load_psf(self):

@@ -737,6 +737,74 @@ def test_rl_tuned_dense_kernel_at_its_largest_extents_vs_oracle(device, pshape):
     assert np.array_equal(x.cpu().numpy(), again.cpu().numpy())
 
 
+@pytest.mark.parametrize("pshape,sigma", [((31, 7, 7), (6.0, 1.2, 1.2)), ((21, 15, 15), (4.0, 2.5, 2.5)), ((17, 3, 5), (3.0, 0.8, 1.1))])
+def test_rl_separable_psf_with_a_long_z_factor(device, pshape, sigma):
+    """Separable PSFs with 17 .. 31 z taps: every correlation = in-plane launch (one z tap) + the z march of
+    csrc/correlate_z.hip.  Against the oracle within the RL bar, scalars included; thin volumes (fewer planes than taps),
+    a padded y, an explicit x0, tol."""
+    import torch
+
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan
+
+    psf, factors = o.gaussian_psf(pshape, sigma)
+    vshape = (40, 37, 131)
+    y = o.bead_scene(vshape, seed=sum(pshape), psf=o.gaussian_psf((5, 5, 5), (1.2, 1.0, 1.0))[0], density=1e-3)
+    plan = RichardsonLucyPlan(vshape, psf, device)
+    assert plan.path == "separable (long z, 4 launches)" and plan.separable and not plan.fused
+    x = plan(_t(y, device), iterations=5, stats=True)
+    _close(x.cpu().numpy(), o.richardson_lucy(y, psf, 5), 5e-5, 2e-5)
+    want = o.rl_iteration_scalars(y, psf, 5)
+    for name in ("flux", "change", "total"):
+        np.testing.assert_allclose(getattr(plan.last_stats, name), want[name], rtol=1e-5, err_msg=name)
+    assert torch.equal(x, plan(_t(y, device), iterations=5))
+    ypad = plan.new_padded_input()
+    ypad.view.copy_(_t(y, device))
+    assert torch.equal(plan(ypad, iterations=5), x)
+    x0 = np.full(vshape, float(y.mean()), np.float32)
+    _close(plan(_t(y, device), iterations=2, x0=_t(x0, device)).cpu().numpy(), o.richardson_lucy(y, psf, 2, x0=x0), 5e-5, 2e-5)
+    by_factors = RichardsonLucyPlan(vshape, None, device, psf_factors=factors)
+    # (the plan factored the PSF itself -- an SVD: the same kernels to the last bit or two)
+    _close(by_factors(_t(y, device), iterations=3).cpu().numpy(), plan(_t(y, device), iterations=3).cpu().numpy(), 2e-5, 1e-6)
+    for thin in ((3, 9, 40), (1, 5, 7), (pshape[0] - 1, 20, 66)):
+        yt = o.bead_scene(thin, seed=3, psf=None, density=5e-3) if thin[0] > 1 else (np.random.default_rng(1).random(thin) * 50 + 1).astype(np.float32)
+        got = RichardsonLucyPlan(thin, psf, device)(_t(yt, device), iterations=2)
+        _close(got.cpu().numpy(), o.richardson_lucy(yt, psf, 2), 5e-5, 2e-5)
+    with pytest.raises(ValueError, match="must be separable"):
+        rot = psf.copy()
+        rot[0, 0, 0] += 0.01
+        RichardsonLucyPlan(vshape, rot / rot.sum(), device)
+
+
+def test_correlate_z_entry_against_scipy_on_ragged_and_strided_volumes(device):
+    """lsr_correlate_z_f32: every odd tap count up to 31, widths that are not multiples of four, padded rows, many z
+    chunks -- against scipy.ndimage.correlate1d(mode="constant")."""
+    import ctypes
+
+    import torch
+
+    from scipy import ndimage
+
+    from shrimpy_amd import _lib
+
+    rng = np.random.default_rng(8)
+    for pz, shape in ((31, (70, 9, 37)), (17, (5, 3, 6)), (1, (4, 4, 4)), (23, (300, 2, 130)), (29, (33, 17, 1027))):
+        w = rng.random(pz).astype(np.float32)
+        vol = rng.random(shape).astype(np.float32)
+        z, y, x = shape
+        pitch = x + 5
+        src = torch.zeros((z, y, pitch), device=device)
+        src[:, :, :x] = _t(vol, device)
+        out = torch.empty(shape, device=device)
+        wd = _t(w, device)
+        _lib.call("lsr_correlate_z_f32", src.data_ptr(), pitch, y * pitch, None, 0, 0, out.data_ptr(), x, y * x, z, y, x,
+                  wd.data_ptr(), pz, _lib.EPI_NONE, ctypes.c_float(0.0), None, None, None, None, _lib.stream_ptr(device))
+        np.testing.assert_allclose(out.cpu().numpy(), ndimage.correlate1d(vol, w, axis=0, mode="constant"), rtol=2e-6, atol=1e-6)
+    assert _lib.call_value("lsr_correlate_z_max_taps") == 31
+    with pytest.raises(_lib.LsrUnsupported):
+        _lib.call("lsr_correlate_z_f32", src.data_ptr(), pitch, y * pitch, None, 0, 0, out.data_ptr(), x, y * x, z, y, x,
+                  wd.data_ptr(), 33, _lib.EPI_NONE, ctypes.c_float(0.0), None, None, None, None, _lib.stream_ptr(device))
+
+
 def test_rl_edge_cases(device):
     import torch
 

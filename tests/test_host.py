@@ -284,8 +284,10 @@ def test_prepare_psf_pads_even_axes_and_bounds_size():
     from shrimpy_amd.deconvolve import prepare_psf
 
     assert prepare_psf(np.ones((2, 4, 3), np.float32)).shape == (3, 5, 3)
-    with pytest.raises(ValueError):
-        prepare_psf(np.ones((17, 3, 3), np.float32))
+    assert prepare_psf(np.ones((17, 3, 3), np.float32)).shape == (17, 3, 3)     # long z: separable PSFs (round 4)
+    for bad in ((33, 3, 3), (3, 17, 3), (3, 3, 17)):
+        with pytest.raises(ValueError):
+            prepare_psf(np.ones(bad, np.float32))
     with pytest.raises(ValueError):
         prepare_psf(np.ones((3, 3), np.float32))
 
