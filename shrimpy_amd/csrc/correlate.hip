@@ -732,7 +732,7 @@ extern "C" int lsr_rl_ysep_fused_stats_f32(const float* y, int64_t y_pitch, int6
   // 4.98 against 4.63 ms per iteration on config 2, its halo is 1.72 x the tile against 1.55 x -- and is gone.)
   p.narrow = 0;
   p.tiles_x = static_cast<int>(lsr::ceil_div(X, p.narrow ? 64 : lsr::kSepWideTileX));
-  p.tiles_y = static_cast<int>(lsr::ceil_div(Y, lsr::ysep_tile_rows(PZ)));
+  p.tiles_y = static_cast<int>(lsr::ceil_div(Y, lsr::ysep_tile_rows(PZ, PYX)));
   const int64_t tiles_xy = int64_t(p.tiles_x) * p.tiles_y;
   plan_fused_split(tiles_xy, Z, PZ, &p.n_full, &p.pieces, &p.z_chunk, p.narrow ? 2 : 1);
   const int64_t blocks64 = p.n_full + (tiles_xy - p.n_full) * p.pieces;

@@ -158,7 +158,8 @@ struct YsepArgs {
   int narrow;                         // 1: 256-thread workgroups on 32 x 64 tiles (two per CU); 0: 512 threads, 32 x 128
 };
 // tile rows: the accumulators of both stencils (PZ planes each) must fit 256 VGPRs per thread
-constexpr int ysep_tile_rows(int PZ) { return PZ <= 9 ? 32 : 24; }
+// (9 x 9 in-plane taps on 32 rows would be six pairs per thread in stage 1: 256 VGPRs and a spill)
+constexpr int ysep_tile_rows(int PZ, int PYX) { return PZ <= 9 && !(PZ == 9 && PYX == 9) ? 32 : 24; }
 constexpr int kYsepMaxPZ = 11, kYsepMaxPYX = 9;
 // its tap block (lsr_rl_ysep_fused_prepare_taps): per stage kYsepMaxPYX groups of 16 floats ((z, x) taps of one column
 // offset), then the y taps

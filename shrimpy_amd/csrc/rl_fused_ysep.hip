@@ -52,7 +52,7 @@ struct Geo {
   static constexpr int NT = 64 * NW;                      // threads
   static constexpr int TXW = 64 * NCG;                    // tile width
   static constexpr int C = PYX / 2, CZ = PZ / 2;
-  static constexpr int TY = lsr::ysep_tile_rows(PZ);      // tile rows
+  static constexpr int TY = lsr::ysep_tile_rows(PZ, PYX);      // tile rows
   static constexpr int RPW = TY / NW;                     // stage-2 rows per wave
   static constexpr int NP2 = RPW * NCG / 2;               // stage-2 packed pairs per thread
   static constexpr int WL = lsr::fused_window_halo(PYX);  // staged columns left/right of the tile
@@ -63,18 +63,25 @@ struct Geo {
   static constexpr int SL = cdiv(NCH, NT);                // glds per thread and plane
   static constexpr int ASZ = cdiv(NCH, 64) * 64 * 4;      // floats per ring slot (whole waves of chunks)
   static constexpr int R1 = TY + 2 * C;                   // stage-1 (ratio) rows
-  static constexpr int RPW1 = NCG == 2 ? cdiv(R1, NW) : 2 * cdiv(R1, 2 * NW);   // ratio rows per wave (even for row pairs)
-  static constexpr int NP1 = RPW1 * NCG / 2;              // stage-1 packed pairs per thread
+  // Stage 1 computes the ratio on the grown tile: R1 rows of TXW + E columns.  A thread holds NP1 packed pairs; a pair is
+  // (row, lane) and (row, lane + 64) of one row -- except the LAST pair of the waves that own one row fewer than the
+  // others: it holds two neighbouring EDGE columns (TXW + 2 k, TXW + 2 k + 1) of some row.  The rows are dealt so that
+  // every wave runs the same NP1 pairs: waves [0, NFULL) own NP1 rows, waves [NFULL, NW) own NP1 - 1 rows and 64 edge
+  // pairs each.  (Rounds 3-4 gave every wave ceil(R1 / NW) rows -- two of them padding for the last wave at 9 x 7 x 7 --
+  // and the edge columns to the first waves as an extra scalar chain: the waves the barrier waits for did 5 pairs + 63
+  // scalar FMAs per plane, the others 5 or 3 useful pairs.)
+  static constexpr int NP1 = R1 % NW == 0 ? R1 / NW + 1 : cdiv(R1, NW);   // stage-1 packed pairs per thread
+  static constexpr int NFULL = R1 - NW * (NP1 - 1);       // waves with NP1 rows (the others: NP1 - 1 rows + an edge pair)
   static constexpr int NIT1 = R1 * CH;                    // chunks of t1 (zero fill)
   static constexpr int XIT1 = cdiv(NIT1, NT);
-  static constexpr int B1SZ = NW * RPW1 * PA;             // (rows >= R1: padding the last wave reads, never uses)
+  static constexpr int B1SZ = R1 * PA;
   static constexpr int SH1 = WL - 2 * C;                  // B1 column of ratio column 0's first x tap
   static constexpr int E = 2 * C;                         // ratio columns beyond the 64-lane groups
-  static constexpr int NE = R1 * E;
-  static constexpr int EP = cdiv(NE, NT);                 // edge points per thread
+  static constexpr int HE = E / 2;                        // edge pairs per ratio row
+  static constexpr int NEP = R1 * HE;                     // edge pairs of the tile
   static constexpr int PR = TXW + 8;                      // pitch of R and B2 (ratio columns 0 .. TXW + 2C - 1)
   static constexpr int CH2 = PR / 4;
-  static constexpr int RSZ = NW * RPW1 * PR;
+  static constexpr int RSZ = R1 * PR;
   static constexpr int NIT2 = TY * CH2;
   static constexpr int XIT2 = cdiv(NIT2, NT);
   static constexpr int B2SZ = TY * PR;
@@ -87,10 +94,11 @@ struct Geo {
   static constexpr int OFF_B2 = OFF_R + RSZ;
   static constexpr int OFF_DUMP = OFF_B2 + B2SZ;          // 1 KB: where glds of waves past the window land
   static constexpr int TOTAL = OFF_DUMP + 256;
-  static constexpr int NY = 2 * NP1 + EP;                 // y loads per thread and iteration
+  static constexpr int NY = 2 * NP1;                      // y loads per thread and iteration
   static constexpr int NXC = 2 * NP2;                     // x (centre) loads
   static constexpr int NTAP = PYX * PZ;                   // (z, x) taps of one stage
-  static_assert(TY % NW == 0 && (NCG == 2 || RPW % 2 == 0), "rows per wave");
+  static_assert(TY % NW == 0 && NCG == 2, "rows per wave; pairs are the two column groups of a row");
+  static_assert(NFULL >= 0 && NFULL <= NW && (NW - NFULL) * 64 >= NEP && E % 2 == 0, "the edge pairs fit the short waves");
   static_assert(TOTAL * 4 <= 160 * 1024, "LDS per workgroup");
   static_assert(2 * C <= WL && WL <= lsr::kSepOriginCol && 2 * C <= 8, "halo columns");
   static_assert(SL + 2 * (NY + NXC) <= 63, "vmcnt is a 6-bit counter");
@@ -198,8 +206,8 @@ __device__ __forceinline__ constexpr int pair_col(int h) { return NCG == 2 ? 64 
 template <int PZ, int PYX, int NW, int NCG, bool STATS>
 __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {   // (2 waves per SIMD: <= 256 VGPRs)
   using T = Geo<PZ, PYX, NW, NCG>;
-  constexpr int C = T::C, CZ = T::CZ, TY = T::TY, EP = T::EP, NT = T::NT, TXW = T::TXW;
-  constexpr int NP1 = T::NP1, NP2 = T::NP2, RPW = T::RPW, RPW1 = T::RPW1;
+  constexpr int C = T::C, CZ = T::CZ, TY = T::TY, NT = T::NT, TXW = T::TXW;
+  constexpr int NP1 = T::NP1, NP2 = T::NP2, RPW = T::RPW, LP = T::NP1 - 1;
   constexpr int NY = T::NY, NXC = T::NXC, SL = T::SL;
   __shared__ f32x4 smem4[T::TOTAL / 4 + 1];
   float* const smem = reinterpret_cast<float*>(smem4);
@@ -262,25 +270,26 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
     const int r = e / T::CH, c = e - r * T::CH;
     return (r * p.pitch + 4 * c) * 4;
   };
-  // ---- stage-1 points.  Main: the wave's ratio rows r1_row0 .. r1_row0 + RPW1 - 1, ratio columns lane (+ 64).
+  // ---- stage-1 points: the wave's ratio rows r1_row0 .. (NP1 or NP1 - 1 of them), ratio columns lane and lane + 64.
   // Ratio row r <-> tile row r - C; ratio column rho <-> tile column rho - C <-> window column rho - C + WL.
-  const int r1_row0 = wave * RPW1;                                  // scalar
+  const bool short_wave = wave >= T::NFULL;                         // scalar: NP1 - 1 rows and an edge pair
+  const int r1_row0 = short_wave ? T::NFULL * NP1 + (wave - T::NFULL) * LP : wave * NP1;   // scalar
   const int t1_col = r1_row0 * T::PA + lane + T::SH1;               // B1 float index of the first x tap of (row0, lane)
   const int r_col = r1_row0 * T::PR + lane;                         // R float index of the same point
   const bool interior = x0 - C >= 0 && x0 + TXW + C <= X && y0 - C >= 0 && y0 + TY + C <= Y;
-  // edge points: t = tid + NT e -> (row t / E, ratio column TXW + t % E), kept as ONE packed register per point;
-  // the three offsets derived from it are recomputed where they are used (registers are what this kernel
-  // is short of: two more live values spill, and a spill reload drains the whole load pipeline)
-  int e_rc[EP];              // (row << 16) | column of the edge point in the ratio region
-#pragma unroll
-  for (int e = 0; e < EP; ++e) {
-    const int t = min(tid + e * NT, T::NE - 1);
-    const int er = t / T::E, ec = t - er * T::E;
-    e_rc[e] = (er << 16) | (TXW + ec);
+  // the LAST pair of a thread: (row r1_row0 + LP, columns lane / lane + 64) in the full waves, an edge pair in the
+  // short ones -- so its two halves are addressed through per-lane registers: (row << 16) | ratio column of each half;
+  // the B1 / R / y offsets are derived from them where they are used
+  int lp_rc[2];
+  {
+    const int et = min(max((wave - T::NFULL) * 64 + lane, 0), T::NEP - 1);   // (threads past the last edge pair repeat it)
+    const int er = et / T::HE, ec = TXW + 2 * (et - er * T::HE);
+    lp_rc[0] = short_wave ? (er << 16) | ec : ((r1_row0 + LP) << 16) | lane;
+    lp_rc[1] = short_wave ? (er << 16) | (ec + 1) : ((r1_row0 + LP) << 16) | (lane + 64);
   }
-  auto e_t1 = [&](int e) { return (e_rc[e] >> 16) * T::PA + (e_rc[e] & 0xffff) + T::SH1; };   // B1 index of its first x tap
-  auto e_r = [&](int e) { return (e_rc[e] >> 16) * T::PR + (e_rc[e] & 0xffff); };               // R index
-  auto e_voff = [&](int e) { return ((e_rc[e] >> 16) * p.y_pitch + (e_rc[e] & 0xffff)) * 4; };  // from the y window's first element
+  auto lp_t1 = [&](int h) { return (lp_rc[h] >> 16) * T::PA + (lp_rc[h] & 0xffff) + T::SH1; };   // B1 index of its first x tap
+  auto lp_r = [&](int h) { return (lp_rc[h] >> 16) * T::PR + (lp_rc[h] & 0xffff); };               // R index
+  auto lp_voff = [&](int h) { return ((lp_rc[h] >> 16) * p.y_pitch + (lp_rc[h] & 0xffff)) * 4; };  // from the y window's first element
   // ---- stage-2 points: the wave's tile rows wave * RPW .. + RPW - 1, tile columns lane (+ 64)
   const int t2_col = (wave * RPW) * T::PR + lane;
   // rows of a wave differ by a wave-uniform stride: one lane offset register per stream, the row term goes
@@ -293,13 +302,10 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
   const bool okc[2] = {x0 + lane < X, x0 + lane + pair_col<NCG>(1) < X};
 
   f32x2 acc1[PZ][NP1], acc2[PZ][NP2];
-  float acc1e[PZ][EP];
 #pragma unroll
   for (int j = 0; j < PZ; ++j) {
 #pragma unroll
     for (int i = 0; i < NP1; ++i) acc1[j][i] = splat(0.0f);
-#pragma unroll
-    for (int i = 0; i < EP; ++i) acc1e[j][i] = 0.0f;
 #pragma unroll
     for (int i = 0; i < NP2; ++i) acc2[j][i] = splat(0.0f);
   }
@@ -333,11 +339,9 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
   // the first and last `rz` planes only.
   float rn_mid[2 * NP2];
   plane_norms(rz < Z - rz ? rz : 0, rn_mid);   // (a volume thinner than the PSF has no such plane: rn_mid unused)
-  float yv[2 * NP1], ye[EP], xc[2 * NP2];   // [2 i + h] = half h of pair i
+  float yv[2 * NP1], xc[2 * NP2];   // [2 i + h] = half h of pair i
 #pragma unroll
   for (int i = 0; i < 2 * NP1; ++i) yv[i] = 0.0f;
-#pragma unroll
-  for (int i = 0; i < EP; ++i) ye[i] = 0.0f;
 #pragma unroll
   for (int i = 0; i < 2 * NP2; ++i) xc[i] = 0.0f;
   __builtin_amdgcn_sched_barrier(0);
@@ -366,12 +370,12 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
   auto issue_y = [&](int q) {  // NY loads: y at the ratio points of plane q
     const float* base = y_tile + static_cast<int64_t>(clampz(q)) * p.y_plane;
 #pragma unroll
-    for (int i = 0; i < NP1; ++i) {
-      gload<0>(yv[2 * i], base + min(r1_row0 + pair_row<NCG>(i, 0), T::R1 - 1) * p.y_pitch, lane_off);   // (scalar rows)
-      gload<4 * pair_col<NCG>(1)>(yv[2 * i + 1], base + min(r1_row0 + pair_row<NCG>(i, 1), T::R1 - 1) * p.y_pitch, lane_off);
+    for (int i = 0; i < LP; ++i) {
+      gload<0>(yv[2 * i], base + (r1_row0 + i) * p.y_pitch, lane_off);   // (scalar rows)
+      gload<4 * 64>(yv[2 * i + 1], base + (r1_row0 + i) * p.y_pitch, lane_off);
     }
-#pragma unroll
-    for (int e = 0; e < EP; ++e) gload<0>(ye[e], base, e_voff(e));
+    gload<0>(yv[2 * LP], base, lp_voff(0));
+    gload<0>(yv[2 * LP + 1], base, lp_voff(1));
   };
 
   const int q_lo = max(zb - CZ, 0), q_hi = min(ze - 1 + CZ, Z - 1);  // ratio planes that matter
@@ -392,8 +396,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
     asm volatile("" : "+s"(opaque));   // loop-variant for the optimiser: the tap loads stay in the loop
     const cfloat* const taps1 = taps_c + opaque;                       // stage 1
     const cfloat* const taps2 = taps_c + lsr::kYsepTapStage + opaque;  // stage 2
-#pragma unroll
-    for (int e = 0; e < EP; ++e) asm volatile("" : "+v"(e_rc[e]));   // ... nor of the offsets derived from e_rc
+    asm volatile("" : "+v"(lp_rc[0]), "+v"(lp_rc[1]));   // ... nor of the offsets derived from lp_rc
     asm volatile("" : "+v"(tid_v));                                  // ... and from the thread index
     const int qr = pz - 1 - CZ;      // ratio plane in R (written by the previous iteration)
     const int o = qr - CZ;           // output plane completed by this iteration
@@ -511,15 +514,15 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
     // stage 1: absorb t1 of x plane pz into the pending ratio planes, finish ratio plane q
     {
       const float* base = B1 + t1_col;
+      const float* const lp0 = B1 + lp_t1(0);
+      const float* const lp1 = B1 + lp_t1(1);
       auto ld = [&](int i, int c) {
-        return f32x2{base[pair_row<NCG>(i, 0) * T::PA + c], base[pair_row<NCG>(i, 1) * T::PA + pair_col<NCG>(1) + c]};
+        if (i == LP) return f32x2{lp0[c], lp1[c]};
+        return f32x2{base[i * T::PA + c], base[i * T::PA + 64 + c]};
       };
       f32x2 vb[2][NP1];
-      float veb[2][EP];
 #pragma unroll
       for (int i = 0; i < NP1; ++i) vb[0][i] = ld(i, 0);
-#pragma unroll
-      for (int e = 0; e < EP; ++e) veb[0][e] = B1[e_t1(e)];
       float wq[2][PZ];
 #pragma unroll
       for (int j = 0; j < PZ; ++j) wq[0][j] = taps1[j];
@@ -531,12 +534,9 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
 #pragma unroll
       for (int c = 0; c < kCols1; ++c) {
         f32x2 (&v)[NP1] = vb[c & 1];
-        float (&ve)[EP] = veb[c & 1];
         if (c + 1 < PYX) {
 #pragma unroll
           for (int i = 0; i < NP1; ++i) vb[(c + 1) & 1][i] = ld(i, c + 1);
-#pragma unroll
-          for (int e = 0; e < EP; ++e) veb[(c + 1) & 1][e] = B1[e_t1(e) + c + 1];
 #pragma unroll
           for (int j = 0; j < PZ; ++j) wq[(c + 1) & 1][j] = taps1[lsr::kYsepTapGroup * (c + 1) + j];
         }
@@ -550,56 +550,46 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
             else acc1[j][i] = pk_fma(w, v[i], acc1[j][i]);
             pin(acc1[j][i]);
           }
-#pragma unroll
-          for (int e = 0; e < EP; ++e) {
-            if (c == 0) acc1e[j][e] = j + 1 < PZ ? fmaf(ws, ve[e], acc1e[j + 1][e]) : ws * ve[e];
-            else acc1e[j][e] = fmaf(ws, ve[e], acc1e[j][e]);
-            pin(acc1e[j][e]);
-          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       // y(q): requested by the previous iteration; issued since: this iteration's glds and x loads
       wait_vm<SL + NXC>();
       tie(yv);
-      tie(ye);
       const bool q_in = q >= q_lo && q <= q_hi;  // wave-uniform; planes outside are zero
       if (q_in && interior) {
 #pragma unroll
         for (int i = 0; i < NP1; ++i) {
           const f32x2 r = f32x2{yv[2 * i], yv[2 * i + 1]} * fast_rcp2(acc1[0][i] + splat(p.eps));
-          Rw[r_col + pair_row<NCG>(i, 0) * T::PR] = r.x;
-          Rw[r_col + pair_row<NCG>(i, 1) * T::PR + pair_col<NCG>(1)] = r.y;
+          if (i == LP) {
+            Rw[lp_r(0)] = r.x;
+            Rw[lp_r(1)] = r.y;
+          } else {
+            Rw[r_col + i * T::PR] = r.x;
+            Rw[r_col + i * T::PR + 64] = r.y;
+          }
         }
-#pragma unroll
-        for (int e = 0; e < EP; ++e)
-          if (e + 1 < EP || tid + e * NT < T::NE) Rw[e_r(e)] = ye[e] * fast_rcp(acc1e[0][e] + p.eps);
       } else {
         // border tiles and planes outside the volume: ratio is zero wherever its point is outside
         const int gx0 = x0 + lane - C;
-        const bool inc[2] = {q_in && gx0 >= 0 && gx0 < X, q_in && gx0 + pair_col<NCG>(1) >= 0 && gx0 + pair_col<NCG>(1) < X};
+        const bool inc[2] = {q_in && gx0 >= 0 && gx0 < X, q_in && gx0 + 64 >= 0 && gx0 + 64 < X};
 #pragma unroll
         for (int i = 0; i < NP1; ++i) {
           const f32x2 r = f32x2{yv[2 * i], yv[2 * i + 1]} * fast_rcp2(acc1[0][i] + splat(p.eps));
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const int row = r1_row0 + pair_row<NCG>(i, h);
-            const int gy = y0 + row - C;
-            const bool row_in = gy >= 0 && gy < Y && row < T::R1;  // wave-uniform
-            Rw[r_col + pair_row<NCG>(i, h) * T::PR + (h ? pair_col<NCG>(1) : 0)] =
-                (row_in && inc[NCG == 2 ? h : 0]) ? (h ? r.y : r.x) : 0.0f;
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < EP; ++e) {
-          if (e + 1 < EP || tid + e * NT < T::NE) {
-            const int gy = y0 + (e_rc[e] >> 16) - C, gx = x0 + (e_rc[e] & 0xffff) - C;
-            const float r = ye[e] * fast_rcp(acc1e[0][e] + p.eps);
-            Rw[e_r(e)] = (q_in && gy >= 0 && gy < Y && gx >= 0 && gx < X) ? r : 0.0f;
+            if (i == LP) {   // the per-lane pair: its own row and column
+              const int gy = y0 + (lp_rc[h] >> 16) - C, gx = x0 + (lp_rc[h] & 0xffff) - C;
+              Rw[lp_r(h)] = (q_in && gy >= 0 && gy < Y && gx >= 0 && gx < X) ? (h ? r.y : r.x) : 0.0f;
+            } else {
+              const int gy = y0 + r1_row0 + i - C;
+              const bool row_in = gy >= 0 && gy < Y;  // wave-uniform
+              Rw[r_col + i * T::PR + 64 * h] = (row_in && inc[h]) ? (h ? r.y : r.x) : 0.0f;
+            }
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);  // the refill reuses yv / ye
+      __builtin_amdgcn_sched_barrier(0);  // the refill reuses yv
       issue_y(q + 1);
     }
     // plane pz+1 (requested one iteration ago); issued since: x, y loads of the previous iteration, this
@@ -612,7 +602,6 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
   if constexpr (STATS) {
     lsr::keep_until_here(xc);    // (in-flight prefetches: correlate_common.hpp, keep_until_here)
     lsr::keep_until_here(yv);
-    lsr::keep_until_here(ye);
     st.pin();
     lsr::rl_stats_flush<NW>(st, smem + T::OFF_B2, p.stats);
   }
