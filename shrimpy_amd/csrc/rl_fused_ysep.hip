@@ -262,14 +262,23 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
 
   // ---- staging (glds): chunk e = tid + NT k of the (AR x PA) window whose first element is (y0 - 2C, x0 - WL)
   const float* const x_tile = p.x + (static_cast<int64_t>(y0 - 2 * C) * p.pitch + (x0 - T::WL));
-  // (its byte offset inside the plane is recomputed per plane from the thread index -- a few integer operations
-  // against SL registers held across the loop)
+  // (byte offsets inside the plane, held across the loop: round 3 recomputed them per plane to save SL registers; since
+  // the edge columns moved into the last pair there is room, and the divisions were ~30 vector instructions per plane)
+  // (... except the largest instance, 11 x 9 x 9: its accumulators leave no room, tools/asm_hazards.py found it
+  // spilling; it keeps recomputing)
+  constexpr bool HOLD = !(PZ >= 11 && PYX >= 9);
   int tid_v = tid;
-  auto s_voff = [&](int k) {
+  auto s_voff_of = [&](int k) {
     const int e = min(tid_v + k * NT, T::NCH - 1);
     const int r = e / T::CH, c = e - r * T::CH;
     return (r * p.pitch + 4 * c) * 4;
   };
+  int s_voff_r[HOLD ? SL : 1];
+  if constexpr (HOLD) {
+#pragma unroll
+    for (int k = 0; k < SL; ++k) s_voff_r[k] = s_voff_of(k);
+  }
+  auto s_voff = [&](int k) { return HOLD ? s_voff_r[HOLD ? k : 0] : s_voff_of(k); };
   // ---- stage-1 points: the wave's ratio rows r1_row0 .. (NP1 or NP1 - 1 of them), ratio columns lane and lane + 64.
   // Ratio row r <-> tile row r - C; ratio column rho <-> tile column rho - C <-> window column rho - C + WL.
   const bool short_wave = wave >= T::NFULL;                         // scalar: NP1 - 1 rows and an edge pair
@@ -287,9 +296,21 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
     lp_rc[0] = short_wave ? (er << 16) | ec : ((r1_row0 + LP) << 16) | lane;
     lp_rc[1] = short_wave ? (er << 16) | (ec + 1) : ((r1_row0 + LP) << 16) | (lane + 64);
   }
-  auto lp_t1 = [&](int h) { return (lp_rc[h] >> 16) * T::PA + (lp_rc[h] & 0xffff) + T::SH1; };   // B1 index of its first x tap
-  auto lp_r = [&](int h) { return (lp_rc[h] >> 16) * T::PR + (lp_rc[h] & 0xffff); };               // R index
-  auto lp_voff = [&](int h) { return ((lp_rc[h] >> 16) * p.y_pitch + (lp_rc[h] & 0xffff)) * 4; };  // from the y window's first element
+  auto lp_t1_of = [&](int h) { return (lp_rc[h] >> 16) * T::PA + (lp_rc[h] & 0xffff) + T::SH1; };   // B1 index of its first x tap
+  auto lp_r_of = [&](int h) { return (lp_rc[h] >> 16) * T::PR + (lp_rc[h] & 0xffff); };               // R index
+  auto lp_voff_of = [&](int h) { return ((lp_rc[h] >> 16) * p.y_pitch + (lp_rc[h] & 0xffff)) * 4; };  // from the y window's first element
+  int lp_t1_r[2] = {0, 0}, lp_r_r[2] = {0, 0}, lp_voff_r[2] = {0, 0};
+  if constexpr (HOLD) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      lp_t1_r[h] = lp_t1_of(h);
+      lp_r_r[h] = lp_r_of(h);
+      lp_voff_r[h] = lp_voff_of(h);
+    }
+  }
+  auto lp_t1 = [&](int h) { return HOLD ? lp_t1_r[h] : lp_t1_of(h); };
+  auto lp_r = [&](int h) { return HOLD ? lp_r_r[h] : lp_r_of(h); };
+  auto lp_voff = [&](int h) { return HOLD ? lp_voff_r[h] : lp_voff_of(h); };
   // ---- stage-2 points: the wave's tile rows wave * RPW .. + RPW - 1, tile columns lane (+ 64)
   const int t2_col = (wave * RPW) * T::PR + lane;
   // rows of a wave differ by a wave-uniform stride: one lane offset register per stream, the row term goes
@@ -396,8 +417,10 @@ __global__ __launch_bounds__(64 * NW, 2) void rl_fused_ysep_kernel(YsepArgs p) {
     asm volatile("" : "+s"(opaque));   // loop-variant for the optimiser: the tap loads stay in the loop
     const cfloat* const taps1 = taps_c + opaque;                       // stage 1
     const cfloat* const taps2 = taps_c + lsr::kYsepTapStage + opaque;  // stage 2
-    asm volatile("" : "+v"(lp_rc[0]), "+v"(lp_rc[1]));   // ... nor of the offsets derived from lp_rc
-    asm volatile("" : "+v"(tid_v));                                  // ... and from the thread index
+    if constexpr (!HOLD) {   // loop-variant for the optimiser: no hoisting of the offsets derived from these
+      asm volatile("" : "+v"(lp_rc[0]), "+v"(lp_rc[1]));
+      asm volatile("" : "+v"(tid_v));
+    }
     const int qr = pz - 1 - CZ;      // ratio plane in R (written by the previous iteration)
     const int o = qr - CZ;           // output plane completed by this iteration
     const int q = pz - CZ;           // ratio plane completed by this iteration
