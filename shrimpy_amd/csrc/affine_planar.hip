@@ -29,9 +29,13 @@
 
 namespace {
 
-constexpr int kTY = 32, kTX = 128;
+// Tiles: (8 NR) x (64 NC) pixels, NR * NC per thread (columns lane + 64 c, rows wave + 8 r).  32 x 128 (NR = 4, NC = 2) is
+// the shape of the registrations between two modalities of one instrument; maps that DECIMATE in the plane (a 2 x
+// coarser target grid) have source boxes of 160+ KB at that size and used to fall to the gather
+// kernel: they take the largest of 32 x 64, 16 x 128, 16 x 64 whose ring fits (lsr::affine_planar_geometry).
 constexpr int kThreads = 512;
-constexpr int kPts = 8;  // pixels per thread: columns lane, lane + 64; rows wave, wave + 8, ...
+struct TileShape { int nr, nc; };
+constexpr TileShape kTiles[] = {{4, 2}, {4, 1}, {2, 2}, {2, 1}};
 
 struct PlanarArgs {
   const float* in;
@@ -85,8 +89,9 @@ __device__ __forceinline__ double plane_coord(double yo, double xo, double m1, d
 // cval times its weight and samples up to one voxel outside still blend (mode="constant" drops the whole
 // sample).  The box then starts at source index -1 at the earliest: row / column 0 of the box may stand for
 // index -1 (a duplicate of index 0 in LDS, replaced by cval through the tap's flag).
-template <bool F32, bool GRID>
+template <bool F32, bool GRID, int NR, int NC>
 __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p) {  // (two workgroups per CU: <= 128 VGPRs)
+  constexpr int kTY = 8 * NR, kTX = 64 * NC, kPts = NR * NC;
   extern __shared__ f32x4 smem4[];
   const float* const smem = reinterpret_cast<const float*>(smem4);
   const unsigned lds_base =
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
   double wy0[kPts], wy1[kPts], wx0[kPts], wx1[kPts];
 #pragma unroll
   for (int i = 0; i < kPts; ++i) {
-    const int yo = y0 + wave + 8 * (i >> 1), xo = x0 + lane + 64 * (i & 1);
+    const int yo = y0 + wave + 8 * (i / NC), xo = x0 + lane + 64 * (i % NC);
     const double cy = plane_coord(static_cast<double>(yo), static_cast<double>(xo), p.b, p.c, p.ty);
     const double cx = plane_coord(static_cast<double>(yo), static_cast<double>(xo), p.d, p.e, p.tx);
     const bool in_output = yo < p.Yo && xo < p.Xo;
@@ -179,8 +184,29 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
     ok[i] = GRID ? in_output : inside;
   }
   const bool tile_full = y0 + kTY <= p.Yo && x0 + kTX <= p.Xo;   // every thread stores all its pixels
-  const bool in_out[kPts / 2] = {y0 + wave < p.Yo, y0 + wave + 8 < p.Yo, y0 + wave + 16 < p.Yo, y0 + wave + 24 < p.Yo};
-  const bool col_out[2] = {x0 + lane < p.Xo, x0 + lane + 64 < p.Xo};
+  bool in_out[NR], col_out[NC];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) in_out[r] = y0 + wave + 8 * r < p.Yo;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) col_out[c] = x0 + lane + 64 * c < p.Xo;
+  if constexpr (!GRID) {
+    // mode "constant": a tile none of whose pixels maps into the moving plane is cval on every plane -- no staging, no
+    // arithmetic.  (A target grid larger than the moving volume's footprint -- keep_overhang, a decimating map kept at
+    // the source's shape -- is mostly such tiles; they used to run the whole pipeline and drop its results.)
+    bool any_inside = false;
+#pragma unroll
+    for (int i = 0; i < kPts; ++i) any_inside |= ok[i];
+    if (!__syncthreads_or(any_inside)) {
+      for (int zo = zo_begin; zo < zo_end; ++zo) {
+        float* orow = p.out + static_cast<int64_t>(zo) * p.oplane + static_cast<int64_t>(y0) * p.opitch + x0;
+#pragma unroll
+        for (int i = 0; i < kPts; ++i)
+          if (in_out[i / NC] && col_out[i % NC])
+            store_one(orow + static_cast<int64_t>(wave + 8 * (i / NC)) * p.opitch + lane + 64 * (i % NC), p.cval);
+      }
+      return;
+    }
+  }
 
   // ---- staging: 16-byte chunks of the box, lane-linear in LDS -------------------------------
   const int chunks_x = box_x >> 2;
@@ -283,7 +309,8 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
     // G pixels at a time: all their LDS reads first, then the arithmetic -- nothing in between is
     // conditional, so the pixels overlap (an `if (inside)` per pixel made hipcc run them one by one,
     // each waiting for its own reads)
-    constexpr int G = F32 ? 4 : 2;   // (the fp64 corner sums of four pixels at once do not fit 128 VGPRs)
+    constexpr int G = kPts < (F32 ? 4 : 2) ? kPts : (F32 ? 4 : 2);   // (the fp64 corner sums of four pixels at once do not fit 128 VGPRs)
+    static_assert(kPts % G == 0, "pixels per thread come in whole groups");
 #pragma unroll
     for (int h = 0; h < kPts; h += G) {
       f32x2 v[G][4];
@@ -345,8 +372,8 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
 #pragma unroll
       for (int k = 0; k < G; ++k) {
         const int i = h + k;
-        if (in_out[i >> 1] && col_out[i & 1])
-          store_one(orow + static_cast<int64_t>(wave + 8 * (i >> 1)) * p.opitch + lane + 64 * (i & 1), res[k]);
+        if (in_out[i / NC] && col_out[i % NC])
+          store_one(orow + static_cast<int64_t>(wave + 8 * (i / NC)) * p.opitch + lane + 64 * (i % NC), res[k]);
       }
     }
     // (no barrier here: the next iteration's DMAs are issued behind its own barrier, which every
@@ -362,35 +389,41 @@ namespace lsr {
 // Returns true if the planar kernel took the launch; false = not applicable, use the general one.
 // Geometry of the planar path for this matrix and moving volume; false = not applicable.
 bool affine_planar_geometry(int64_t Yi, int64_t Xi, int64_t pitch, const double M[12], int* box_y_out, int* box_x_out,
-                            int* slots_out, int64_t* lds_bytes_out) {
+                            int* slots_out, int64_t* lds_bytes_out, int* tile_out) {
   if (!volume_in_range(1, Yi, Xi) || !strides_in_range(pitch, 0)) return false;
   if (M[1] != 0.0 || M[2] != 0.0 || M[4] != 0.0 || M[8] != 0.0) return false;
   const double a = M[0] < 0 ? -M[0] : M[0];
   // rows start on 16-byte boundaries (LDS-DMA moves 16-byte chunks) and hold whole chunks up to the last column
   if (a > 1.5 || pitch % 4 != 0 || pitch < ((Xi + 3) & ~int64_t(3)) || Xi < 8 || Yi < 2) return false;
   auto ab = [](double v) { return v < 0 ? -v : v; };
-  // source box of a 32 x 128 tile: span of floor() over the tile (<= floor(extent) + 2; the 1e-6
-  // absorbs the different summation order on the device) + 1 for the upper neighbour [+ 3 + 3: 16-byte
-  // alignment of the first column, rows rounded up to whole chunks]
-  const double ey = ab(M[5]) * (kTY - 1) + ab(M[6]) * (kTX - 1), ex = ab(M[9]) * (kTY - 1) + ab(M[10]) * (kTX - 1);
-  if (!(ey < 4096.0) || !(ex < 4096.0)) return false;
-  const int box_y = static_cast<int>(ey + 1e-6) + 3;
-  const int box_x = (static_cast<int>(ex + 1e-6) + 3 + 3 + 3) & ~3;
-  const int slots = a <= 1.0 ? 3 : 4;
-  const int64_t lds_bytes = int64_t(slots) * ((int64_t(box_y) * box_x + 255) & ~int64_t(255)) * 4;
-  if (lds_bytes > 150 * 1024 || int64_t(box_y) * (box_x / 4) > 8 * kThreads) return false;
   if (Yi * pitch * 4 >= (int64_t(1) << 31)) return false;  // 32-bit in-plane byte offsets
-  *box_y_out = box_y; *box_x_out = box_x; *slots_out = slots; *lds_bytes_out = lds_bytes;
-  return true;
+  const int slots = a <= 1.0 ? 3 : 4;
+  // the largest tile whose ring fits.  Source box of a tile: span of floor() over the tile (<= floor(extent) + 2; the
+  // 1e-6 absorbs the different summation order on the device) + 1 for the upper neighbour [+ 3 + 3: 16-byte alignment
+  // of the first column, rows rounded up to whole chunks]
+  for (int t = 0; t < static_cast<int>(sizeof(kTiles) / sizeof(kTiles[0])); ++t) {
+    const int ty = 8 * kTiles[t].nr, tx = 64 * kTiles[t].nc;
+    const double ey = ab(M[5]) * (ty - 1) + ab(M[6]) * (tx - 1), ex = ab(M[9]) * (ty - 1) + ab(M[10]) * (tx - 1);
+    if (!(ey < 4096.0) || !(ex < 4096.0)) continue;
+    const int box_y = static_cast<int>(ey + 1e-6) + 3;
+    const int box_x = (static_cast<int>(ex + 1e-6) + 3 + 3 + 3) & ~3;
+    const int64_t lds_bytes = int64_t(slots) * ((int64_t(box_y) * box_x + 255) & ~int64_t(255)) * 4;
+    if (lds_bytes > 150 * 1024 || int64_t(box_y) * (box_x / 4) > 8 * kThreads) continue;
+    *box_y_out = box_y; *box_x_out = box_x; *slots_out = slots; *lds_bytes_out = lds_bytes;
+    if (tile_out != nullptr) *tile_out = t;
+    return true;
+  }
+  return false;
 }
 
 bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane,
                           float* out, int64_t Zo, int64_t Yo, int64_t Xo, int64_t opitch, int64_t oplane,
                           const double M[12], float cval, bool f32, bool grid, hipStream_t s) {
-  int box_y, box_x, slots;
+  int box_y, box_x, slots, tile = 0;
   int64_t lds_bytes;
   if (plane % 4 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return false;
-  if (!affine_planar_geometry(Yi, Xi, pitch, M, &box_y, &box_x, &slots, &lds_bytes)) return false;
+  if (!affine_planar_geometry(Yi, Xi, pitch, M, &box_y, &box_x, &slots, &lds_bytes, &tile)) return false;
+  const int kTY = 8 * kTiles[tile].nr, kTX = 64 * kTiles[tile].nc;
 
   PlanarArgs p;
   p.in = in; p.out = out;
@@ -425,10 +458,16 @@ bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, i
   if (padded >= (int64_t(1) << 30)) return false;
   p.per_xcd = static_cast<int>(ceil_div(padded, 8));
   const int64_t blocks = f32 ? tiles * ceil_div(Zo, chunk) : int64_t(p.per_xcd) * 8;
-  static std::atomic<uint64_t> lds_allowed[4] = {{0}, {0}, {0}, {0}};
-  auto kernel = f32 ? (grid ? affine_planar_kernel<true, true> : affine_planar_kernel<true, false>)
-                    : (grid ? affine_planar_kernel<false, true> : affine_planar_kernel<false, false>);
-  if (lsr::allow_dynamic_lds(reinterpret_cast<const void*>(kernel), 150 * 1024, lds_allowed[2 * grid + f32],
+  static std::atomic<uint64_t> lds_allowed[16] = {};
+  using Kernel = void (*)(PlanarArgs);
+#define LSR_PLANAR_TILE(NR, NC)                                                                       \
+  {affine_planar_kernel<false, false, NR, NC>, affine_planar_kernel<true, false, NR, NC>,              \
+   affine_planar_kernel<false, true, NR, NC>, affine_planar_kernel<true, true, NR, NC>}
+  static const Kernel kernels[4][4] = {LSR_PLANAR_TILE(4, 2), LSR_PLANAR_TILE(4, 1), LSR_PLANAR_TILE(2, 2),
+                                       LSR_PLANAR_TILE(2, 1)};   // [tile][2 * grid + f32], tiles as kTiles
+#undef LSR_PLANAR_TILE
+  const Kernel kernel = kernels[tile][2 * grid + f32];
+  if (lsr::allow_dynamic_lds(reinterpret_cast<const void*>(kernel), 150 * 1024, lds_allowed[4 * tile + 2 * grid + f32],
                              "affine_planar_kernel") != LSR_OK)
     return false;   // the caller runs the gather kernel
   hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),

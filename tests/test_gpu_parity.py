@@ -277,6 +277,10 @@ def _planar_matrix(theta_deg, scale_zyx, shift_zyx, shear=0.0):
     dict(shape=(5, 20, 16), out=(5, 45, 300), theta=30.0, scale=(1.0, 0.4, 0.05), shift=(0.0, 0.0, 0.0)),
     dict(shape=(4, 300, 2000), out=(4, 20, 140), theta=5.0, scale=(1.0, 9.0, 14.0), shift=(0.0, 3.0, 1.0)),  # box > LDS
     dict(shape=(8, 48, 96), theta=12.0, scale=(1.0, 1.0, 1.0), shift=(0.0, 500.0, 0.0)),          # everything outside
+    # maps that decimate in the plane: the smaller tiles of round 4 (32 x 64, 16 x 128, 16 x 64) keep them off the gather kernel
+    dict(shape=(6, 200, 520), out=(6, 100, 260), theta=0.0, scale=(1.0, 2.0, 2.0), shift=(0.0, 0.25, 0.5)),
+    dict(shape=(5, 260, 532), out=(7, 70, 200), theta=3.0, scale=(0.9, 3.0, 2.5), shift=(0.5, 4.0, 3.0), shear=0.03),
+    dict(shape=(4, 300, 700), out=(4, 61, 129), theta=-2.0, scale=(1.0, 4.5, 5.0), shift=(0.0, 2.0, 1.0)),
 ])
 @pytest.mark.parametrize("exact", [True, False])
 @pytest.mark.parametrize("mode", ["constant", "grid-constant"])
@@ -291,7 +295,8 @@ def test_affine_planar_kernel_vs_oracle(device, case, exact, mode):
     planar = _lib.call_value("lsr_affine_kernel_choice", case["shape"][1], case["shape"][2],
                              _lib.matrix12(as_matrix_3x4(_planar_matrix(case["theta"], case["scale"], case["shift"],
                                                                         case.get("shear", 0.0)))), code)
-    assert planar == (0 if case["scale"][2] > 10 else 1)   # 14x decimation: the source box exceeds LDS
+    # (beyond ~4x decimation the source box of even a 16 x 64 tile exceeds the ring's LDS: the gather kernel)
+    assert planar == (0 if case["scale"][2] > 4 else 1)
     rng = np.random.default_rng(hash(str(case)) % 2**32)
     vol = (rng.random(case["shape"]) * 1000 - 100).astype(np.float32)
     m = _planar_matrix(case["theta"], case["scale"], case["shift"], case.get("shear", 0.0))

@@ -106,6 +106,7 @@ def main():
     matrices = [("identity", np.eye(4)), ("integer shift", shift(2, -7, 13)), ("fractional shift", shift(0.5, -7.25, 13.125)),
                 ("config 3", config3), ("flip x", flip_x), ("zoom 2x (samples every 0.5)", about_centre(np.diag([0.5, 0.5, 0.5, 1.0]))),
                 ("decimate 2x in the plane", about_centre(np.diag([1.0, 2.0, 2.0, 1.0]))),
+                ("decimate 2x in the plane, half-size target", np.diag([1.0, 2.0, 2.0, 1.0])),
                 ("decimate 2x along z", about_centre(np.diag([2.0, 1.0, 1.0, 1.0]))),
                 ("rotate 30 deg in the plane", about_centre(rot(0, 30.0))), ("rotate 10 deg in the plane", about_centre(rot(0, 10.0))),
                 ("tilt 10 deg about y", about_centre(rot(1, 10.0))), ("tilt 5 deg about x", about_centre(rot(2, 5.0))),
@@ -114,9 +115,11 @@ def main():
         for mode in ("constant", "grid-constant"):
             path = _lib.call_value("lsr_affine_path", *shape, _lib.matrix12(as_matrix_3x4(m)),
                                    _lib.MODE_CONSTANT if mode == "constant" else _lib.MODE_GRID_CONSTANT)
+            half = name.endswith("half-size target")
+            target = out[:, :shape[1] // 2, :shape[2] // 2].contiguous() if half else out
             for exact in (True, False):
-                ms = timed(lambda: apply_affine_transform_zyx(vol, m, mode=mode, out=out, exact=exact), args.reps)
-                nbytes = 8.0 * vol.numel()
+                ms = timed(lambda: apply_affine_transform_zyx(vol, m, tuple(target.shape), mode=mode, out=target, exact=exact), args.reps)
+                nbytes = 4.0 * vol.numel() + 4.0 * target.numel()
                 print(json.dumps({"kernel": "affine apply", "map": name, "mode": mode, "arithmetic": "exact fp64" if exact else "f32",
                                   "path": {1: "planar", 2: "box", 0: "gather"}[path], "shape": shape, "ms": ms,
                                   "algorithmic_GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / 8000}), flush=True)
