@@ -168,7 +168,7 @@ def main():
         psf /= psf.sum()
         shape = (int(r.integers(1, 24)), int(r.integers(1, 90)), int(r.integers(1, 160)))
         y = (r.random(shape) * 80 + 1).astype(np.float32)
-        plan = RichardsonLucyPlan(shape, psf, dev)
+        plan = RichardsonLucyPlan(shape, psf, dev)      # the default: one launch per iteration where it is compiled
         if not plan.path.startswith("y-separable"):
             return False, (psf.shape, shape, plan.path)
         iters = int(r.integers(1, 4))
@@ -176,13 +176,53 @@ def main():
         got = dev_out.cpu().numpy().astype(np.float64)
         want = o.richardson_lucy(y, psf, iters).astype(np.float64)
         ok = bool(np.all(np.abs(got - want) <= 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max()))
-        if ok and py <= 9:     # the one-launch-per-iteration kernel, both shapes: the two-launch form's bits
-            for shape_name in ("narrow", "wide"):
-                os.environ["LSR_YSEP_SHAPE"] = shape_name
-                fused = RichardsonLucyPlan(shape, psf, dev, fused="always")
-                ok = ok and fused.path == "y-separable (fused)" and bool(torch.equal(fused(t(y), iterations=iters), dev_out))
-            os.environ.pop("LSR_YSEP_SHAPE", None)
+        if ok and py <= 9:     # ... which must carry the two-launch form's bits
+            two = RichardsonLucyPlan(shape, psf, dev, fused="never")
+            ok = plan.path == "y-separable (fused)" and two.path == "y-separable" and bool(torch.equal(two(t(y), iterations=iters), dev_out))
         return ok, (psf.shape, shape, iters, plan.path)
+
+    def rl_stats_case(r):
+        """The RL scalars of the update epilogues (flux, change, total) on a random path against torch's fp64 reductions
+        of consecutive estimates; asking for them must not change the estimate."""
+        kind = int(r.integers(0, 4))
+        vshape = (int(r.integers(1, 40)), int(r.integers(1, 90)), int(r.integers(1, 260)))
+        y = t((r.random(vshape) * 80 + 1).astype(np.float32))
+        if kind <= 1:       # separable: one launch / pair
+            pshape = tuple(int(v) for v in r.choice(odd, 3))
+            if pshape[0] >= 15 and max(pshape[1:]) >= 11:
+                pshape = (13,) + pshape[1:]
+            factors = [np.abs(r.normal(1.0, 0.4, n)).astype(np.float32) + 0.05 for n in pshape]
+            plan = RichardsonLucyPlan(vshape, None, dev, psf_factors=[f / f.sum() for f in factors],
+                                      fused="always" if kind == 0 else "never")
+        else:               # ky (x) kzx: one launch / pair
+            pz, py, px = int(r.choice([3, 5, 7, 9, 11])), int(r.choice([3, 5, 7, 9])), int(r.choice([3, 5, 7, 9]))
+            psf = ((np.abs(r.normal(1.0, 0.4, py)) + 0.05)[None, :, None] * (np.abs(r.normal(1.0, 0.5, (pz, px))) + 0.05)[:, None, :])
+            psf = (psf / psf.sum()).astype(np.float32)
+            plan = RichardsonLucyPlan(vshape, psf, dev, fused="auto" if kind == 2 else "never")
+        xs = [y] + [plan(y, iterations=n) for n in (1, 2, 3)]
+        x3 = plan(y, iterations=3, stats=True)
+        s_ = plan.last_stats
+        ok = bool(torch.equal(x3, xs[3]))
+        for n in range(3):
+            tot = float(xs[n + 1].double().sum())
+            chg = float((xs[n + 1].double() - xs[n].double()).abs().sum())
+            ok = ok and abs(s_.total[n] / tot - 1) < 1e-5 and (chg == 0 or abs(s_.change[n] / chg - 1) < 1e-5)
+        ok = ok and bool(np.all(np.abs(s_.flux / float(y.double().sum()) - 1) < 1e-5))
+        return ok, (kind, plan.path, vshape)
+
+    def rl_long_z_case(r):
+        """Separable PSFs with 17 .. 31 z taps (in-plane launch + z march) against the oracle."""
+        pshape = (int(r.choice([17, 19, 21, 23, 25, 27, 29, 31])), int(r.choice([1, 3, 5, 9, 15])), int(r.choice([1, 3, 7, 11])))
+        vshape = (int(r.integers(1, 70)), int(r.integers(1, 50)), int(r.integers(1, 140)))
+        factors = [np.abs(r.normal(1.0, 0.4, n)).astype(np.float32) + 0.05 for n in pshape]
+        factors = [f / f.sum() for f in factors]
+        y = (r.random(vshape) * 80 + 1).astype(np.float32)
+        plan = RichardsonLucyPlan(vshape, None, dev, psf_factors=factors)
+        iters = int(r.integers(1, 4))
+        got = plan(t(y), iterations=iters).cpu().numpy().astype(np.float64)
+        want = o.richardson_lucy_separable(y, factors, iterations=iters).astype(np.float64)
+        ok = plan.path.startswith("separable (long z") and bool(np.all(np.abs(got - want) <= 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max()))
+        return ok, (pshape, vshape, iters)
 
     def host_twin_case(r):
         """CPU tensors through the public functions (csrc/host_twins.hip) against the device kernels: same bits."""
@@ -242,7 +282,8 @@ def main():
         return ok, (shape, angle, ratio, keep, avg, x0)
 
     families = {"deskew": deskew_case, "affine": affine_case, "rl": rl_case, "flatfield": flat_case,
-                "blur": blur_case, "estimators": estimator_case, "rl_ysep": rl_ysep_case, "host_twins": host_twin_case}
+                "blur": blur_case, "estimators": estimator_case, "rl_ysep": rl_ysep_case, "host_twins": host_twin_case,
+                "rl_stats": rl_stats_case, "rl_long_z": rl_long_z_case}
     if args.only:
         families = {k: v for k, v in families.items() if k in args.only.split(",")}
     if args.large:
