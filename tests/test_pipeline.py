@@ -250,7 +250,7 @@ def test_stager_refuses_cpu_devices():
     from shrimpy_amd._lib import LsrError
     from shrimpy_amd.staging import VolumeStager
 
-    with pytest.raises(LsrError, match="no CPU fallback"):
+    with pytest.raises(LsrError, match="needs a HIP device"):
         VolumeStager((4, 4, 4), np.uint16, (4, 4, 4), "cpu")
 
 
