@@ -97,11 +97,15 @@ struct Tap {
   bool inside;
   unsigned out; // GRID only
 };
-template <bool GRID>
+template <bool GRID, bool INTERIOR = false>
 __device__ __forceinline__ Tap axis_tap(double c, double last) {
   Tap t;
   t.f = __builtin_amdgcn_fract(c);
-  if constexpr (GRID) {
+  if constexpr (INTERIOR) {   // the block's corner coordinates all lie in [0, n - 1): nothing to test
+    t.i = static_cast<int>(c);
+    t.inside = true;
+    t.out = 0;
+  } else if constexpr (GRID) {
     const int i = static_cast<int>(fmin(fmax(floor(c), -2.0), last + 2.0));
     const int n = static_cast<int>(last) + 1;
     t.i = i;
@@ -193,16 +197,18 @@ __device__ __forceinline__ void stage(const BoxArgs& p, const Blk& b, unsigned l
 // DEP: bit k set = source coordinate k (z, y, x) depends on zo.  A coordinate that does not is
 // worked out once per pixel instead of once per voxel (a tilt about y leaves y_in free of zo, a tilt
 // about x leaves x_in).
-template <bool F32, int TZ, int DEP, int NT, bool GRID>
+template <bool F32, int TZ, int DEP, int NT, bool GRID, bool INTERIOR = false>
 __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const float* smem, int tid, int probe) {
   constexpr int P = kBlockVoxels / TZ / NT;   // output pixels per thread
   static_assert(P >= 1 && P * TZ * NT == kBlockVoxels, "block shape");
-  if constexpr (GRID) {
+  if constexpr (!INTERIOR) {
     // Most blocks of a registration never see the border: both taps of every axis are inside the volume, the two
-    // border rules are the same arithmetic there, and the flag-free path does it (workgroup-uniform branch; the
-    // clamp to [-2, n + 1], the six flags and the eight selects per voxel had cost 1.0 of 4.3 ms on a tilted map).
+    // border rules are the same arithmetic there, and the test-free walk does it (workgroup-uniform branch).
+    // grid-constant: the clamp to [-2, n + 1], the six flags and the eight selects per voxel had cost 1.0 of 4.3 ms
+    // on a tilted map.  constant: the six fp64 compares of the inside test go too -- worth 0-2 % (round 4: 3.30 ms
+    // either way at config-3 size; the walk is not bound by how many fp64 instructions it issues).
     if (b.interior) {
-      compute<F32, TZ, DEP, NT, false>(p, b, smem, tid, probe);
+      compute<F32, TZ, DEP, NT, false, true>(p, b, smem, tid, probe);
       return;
     }
   }
@@ -234,9 +240,9 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
     const double zd = static_cast<double>(z0);
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-      hz[j] = axis_tap<GRID>(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[0]), tzy[j]), tzx[j]), p.m[3]), Zl);
-      hy[j] = axis_tap<GRID>(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[4]), tyy[j]), tyx[j]), p.m[7]), Yl);
-      hx[j] = axis_tap<GRID>(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[8]), txy[j]), txx[j]), p.m[11]), Xl);
+      hz[j] = axis_tap<GRID, INTERIOR>(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[0]), tzy[j]), tzx[j]), p.m[3]), Zl);
+      hy[j] = axis_tap<GRID, INTERIOR>(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[4]), tyy[j]), tyx[j]), p.m[7]), Yl);
+      hx[j] = axis_tap<GRID, INTERIOR>(lsr::dadd(lsr::dadd(lsr::dadd(lsr::dmul(zd, p.m[8]), txy[j]), txx[j]), p.m[11]), Xl);
     }
   }
 
@@ -275,13 +281,13 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
       for (int j = 0; j < P; ++j) {
         const int g = u * P + j;
         // scipy's order: ((zo*m0 + yo*m1) + xo*m2) + shift
-        if constexpr (DEP & 1) az[g] = axis_tap<GRID>(lsr::dadd(lsr::dadd(lsr::dadd(tzz, tzy[j]), tzx[j]), p.m[3]), Zl);
+        if constexpr (DEP & 1) az[g] = axis_tap<GRID, INTERIOR>(lsr::dadd(lsr::dadd(lsr::dadd(tzz, tzy[j]), tzx[j]), p.m[3]), Zl);
         else az[g] = hz[j];
-        if constexpr (DEP & 2) ay[g] = axis_tap<GRID>(lsr::dadd(lsr::dadd(lsr::dadd(tyz, tyy[j]), tyx[j]), p.m[7]), Yl);
+        if constexpr (DEP & 2) ay[g] = axis_tap<GRID, INTERIOR>(lsr::dadd(lsr::dadd(lsr::dadd(tyz, tyy[j]), tyx[j]), p.m[7]), Yl);
         else ay[g] = hy[j];
-        if constexpr (DEP & 4) ax[g] = axis_tap<GRID>(lsr::dadd(lsr::dadd(lsr::dadd(txz, txy[j]), txx[j]), p.m[11]), Xl);
+        if constexpr (DEP & 4) ax[g] = axis_tap<GRID, INTERIOR>(lsr::dadd(lsr::dadd(lsr::dadd(txz, txy[j]), txx[j]), p.m[11]), Xl);
         else ax[g] = hx[j];
-        inside[g] = GRID ? true
+        inside[g] = (GRID || INTERIOR) ? true
                          : static_cast<bool>(static_cast<int>(live) & static_cast<int>(az[g].inside) &
                                              static_cast<int>(ay[g].inside) & static_cast<int>(ax[g].inside));
         // the box covers every inside voxel's taps by construction; the clamp keeps an out-of-range
@@ -362,7 +368,11 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
 #define LSR_BOX_PROBE_VALUE(p) 0
 #endif
 
-// One block per workgroup.  Two or three such workgroups share a CU when the box is under 78 / 52 KB:
+// One block per workgroup.  (Round 4: letting the walk along zo start as soon as the planes of its first output
+// planes had landed -- the image is plane-major and LDS-DMA loads return in order, so a counted s_waitcnt plus a
+// barrier per step is enough -- ran 3-8 % SLOWER, 3.49 against 3.30 ms exact and 2.41 against 2.33 ms f32 on the
+// 1.5 deg tilt: the per-step waits also wait for the previous step's stores, and the extra barriers cost more than
+// the earlier start buys.)  Two or three such workgroups share a CU when the box is under 78 / 52 KB:
 // one computes while another's box is in flight.  (A persistent, double-buffered form of the same walk
 // -- one workgroup per CU, the DMA of block n + 1 issued before the arithmetic of block n -- was
 // measured at 512 and at 1024 threads and ran 8-30 % SLOWER: 3.97 / 3.09 ms and 3.83 / 2.86 ms
