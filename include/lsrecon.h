@@ -551,6 +551,33 @@ int lsr_rfft_rows_t_c64(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, flo
                         int64_t X, const float* tw_half, const float* tw_x, lsr_stream_t stream);
 int lsr_irfft_rows_peak(const float* spec, int64_t Z, int64_t Y, int64_t X, const float* tw_half, const float* tw_x,
                         long long* out_index, void* scratch, lsr_stream_t stream);
+/*
+ * Richardson-Lucy in the Fourier domain (shrimpy_amd/deconvolve_fft.py): PSFs beyond the stencil kernels' extents --
+ * a measured bead PSF is a dense 15 x 18 x 18 ... 30 x 36 x 18 voxel patch (/root/reference/scripts/measure_psf.py:187-190)
+ * -- cost the same as any other there.  No reference code for RL itself (/root/reference/docs/data_structure.md:58-62);
+ * the arithmetic is that of the stencil path: x <- x * H^T( y / (H x + eps) ) / H^T 1, zero-padded
+ * borders, with H x and H^T r evaluated as products of spectra on a grid (Z, Y, X) >= volume + PSF radius per axis.
+ * lsr_rfft_rows_zero_t_c64: as lsr_rfft_rows_t_c64 with the source ((Zi, Yi, Xi) <= grid) at the grid's origin and
+ *   zeros behind it -- a linear convolution, not a circular one; tiles of pure padding store zeros without a transform.
+ * lsr_spectrum_multiply_z_c64: g <- N * IFFT_z( f1 * FFT_z(g) ) (conj_f1 = 0: H x) or N * IFFT_z( conj(f1) * FFT_z(g) )
+ *   (conj_f1 = 1: H^T r); layouts and lengths as lsr_cross_correlate_z_c64, f1 = the PSF's spectrum (its centre tap at
+ *   the grid's origin, wrapped).
+ * lsr_irfft_rows_rl_f32: the inverse x leg with the iteration's epilogue.  v = scale * (complex-to-real inverse of
+ *   spec along x) on the grid's first (Zo, Yo, Xo) points, scale = 1 / (Z Y X);
+ *     LSR_EPI_RATIO:  out = aux / (max(v, 0) + eps)    aux = y
+ *     LSR_EPI_UPDATE: out = aux * v / H^T 1            aux = x; H^T 1 = norm_full inside, from norm_table ((pz+1)(py+1)
+ *                     (px+1) prefix sums of the PSF, float64, device) within a PSF radius of the border; stats = 3 doubles
+ *                     the launch ADDS the iteration's flux / change / total to (as lsr_correlate_*_stats_f32) or NULL.
+ *   out may be aux (in place).  The convolved volume is never written.
+ */
+int lsr_rfft_rows_zero_t_c64(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* spec, int64_t Z, int64_t Y,
+                             int64_t X, const float* tw_half, const float* tw_x, lsr_stream_t stream);
+int lsr_spectrum_multiply_z_c64(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC,
+                                int conj_f1, lsr_stream_t stream);
+int lsr_irfft_rows_rl_f32(const float* spec, int64_t Z, int64_t Y, int64_t X, const float* tw_half, const float* tw_x,
+                          int epilogue, const float* aux, float* out, int64_t Zo, int64_t Yo, int64_t Xo, float scale,
+                          float eps, int pz, int py, int px, const double* norm_table, float norm_full, double* stats,
+                          lsr_stream_t stream);
 /* b <- a * conj(b): the same product written over the second operand, so that `a` (the spectrum of
  * a reference volume that is compared against many timepoints) can be kept. */
 int lsr_cross_power_into_c64(const float* a, float* b, int64_t n, lsr_stream_t stream);

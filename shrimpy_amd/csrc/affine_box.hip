@@ -8,15 +8,17 @@
 // with f32 interpolation (LSR_MODE_F32_INTERP): coordinates ((zo*m0 + yo*m1) + xo*m2) + shift in
 // fp64, the border rule on them, weights w0 = 1 - f, w1 = 1 - w0, corners summed in scipy's order.
 //
-// Structure: a 512-thread workgroup owns a TZ x TY x TX block of 8192 OUTPUT voxels (the host picks
+// Structure: a 256-thread workgroup owns a TZ x TY x TX block of 4096 OUTPUT voxels (the host picks
 // the shape that makes the source box smallest for this matrix: a tilt about y wants a short TX, a
 // tilt about x a short TY).  The source voxels the block can touch lie in the bounding box of its 8
 // corners' coordinates -- the map is linear and every rounding in the coordinate expression is
 // monotone, so the corner values, evaluated with the same expression, ARE the extremes: no slack.
 // The workgroup stages that box into LDS with LDS-DMA (global_load_lds_dwordx4: whole
 // 16-byte-aligned row pieces, no staging registers), waits once, and then every tap is an LDS read.
-// Two workgroups fit on a CU when the box is under 80 KB (near-identity maps: ~45 KB), so one
-// computes while the other's box is in flight; there is no ring and no per-plane barrier.
+// Four workgroups fit on a CU when the box is under 39 KB (near-identity maps: ~28 KB), so three
+// compute while the fourth's box is in flight; there is no ring and no per-plane barrier.
+// (Rounds 2-3 ran blocks of 8192 voxels on 512 threads, two per CU: 2-6 % slower in exact mode and up to
+// 12 % in f32 mode on a rotated + tilted map, equal on a pure tilt -- round 4, profiles/r04_affine_kernels.jsonl.)
 //
 // A thread owns 16 / TZ output pixels (yo, xo) and walks them along zo: yo*m1 and xo*m2 are per
 // pixel, zo*m0 per plane -- scipy's sum order makes those prefixes exact to hoist -- so a voxel costs
@@ -32,12 +34,13 @@
 
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
 
-constexpr int kThreads = 512;
-constexpr int kBlockVoxels = 8192;
+constexpr int kThreads = 256;
+constexpr int kVoxelsPerThread = 16;         // blocks of 4096 output voxels
 constexpr int kMaxLoads = 20;                // 16-byte chunks per thread: boxes up to 160 KB
 constexpr int kPatch = 4;                    // blocks per patch edge
 
@@ -162,7 +165,7 @@ __device__ __forceinline__ Blk locate(const BoxArgs& p, int g) {
   return b;
 }
 
-// Issue the LDS-DMA of a block's source box: chunk e = tid + 512 k, LDS image linear in e.
+// Issue the LDS-DMA of a block's source box: chunk e = tid + NT k, LDS image linear in e.
 template <int NT>
 __device__ __forceinline__ void stage(const BoxArgs& p, const Blk& b, unsigned lds_byte_base, int tid, int wave) {
   const int box_x = p.box_x, box_y = p.box_y, box_z = p.box_z;
@@ -199,8 +202,8 @@ __device__ __forceinline__ void stage(const BoxArgs& p, const Blk& b, unsigned l
 // about x leaves x_in).
 template <bool F32, int TZ, int DEP, int NT, bool GRID, bool INTERIOR = false>
 __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const float* smem, int tid, int probe) {
-  constexpr int P = kBlockVoxels / TZ / NT;   // output pixels per thread
-  static_assert(P >= 1 && P * TZ * NT == kBlockVoxels, "block shape");
+  constexpr int P = kVoxelsPerThread / TZ;   // output pixels per thread
+  static_assert(P >= 1 && P * TZ == kVoxelsPerThread, "block shape");
   if constexpr (!INTERIOR) {
     // Most blocks of a registration never see the border: both taps of every axis are inside the volume, the two
     // border rules are the same arithmetic there, and the test-free walk does it (workgroup-uniform branch).
@@ -218,7 +221,7 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
   const double Zl = static_cast<double>(p.Zi - 1), Yl = static_cast<double>(p.Yi - 1), Xl = static_cast<double>(p.Xi - 1);
 
   // ---- per-pixel constants -------------------------------------------------------------------
-  // pixel q = tid + 512 j of the block's TY x TX plane: consecutive lanes are consecutive xo
+  // pixel q = tid + NT j of the block's TY x TX plane: consecutive lanes are consecutive xo
   unsigned pix[P];   // yo * opitch + xo: the output offset inside a plane (host: Yo * opitch < 2^31)
   double tzy[P], tyy[P], txy[P], tzx[P], tyx[P], txx[P];
   bool ok[P];
@@ -372,14 +375,14 @@ __device__ __forceinline__ void compute(const BoxArgs& p, const Blk& b, const fl
 // planes had landed -- the image is plane-major and LDS-DMA loads return in order, so a counted s_waitcnt plus a
 // barrier per step is enough -- ran 3-8 % SLOWER, 3.49 against 3.30 ms exact and 2.41 against 2.33 ms f32 on the
 // 1.5 deg tilt: the per-step waits also wait for the previous step's stores, and the extra barriers cost more than
-// the earlier start buys.)  Two or three such workgroups share a CU when the box is under 78 / 52 KB:
-// one computes while another's box is in flight.  (A persistent, double-buffered form of the same walk
+// the earlier start buys.)  Up to four such workgroups share a CU (boxes under 39 KB): the others compute while
+// one's box is in flight.  (A persistent, double-buffered form of the same walk
 // -- one workgroup per CU, the DMA of block n + 1 issued before the arithmetic of block n -- was
-// measured at 512 and at 1024 threads and ran 8-30 % SLOWER: 3.97 / 3.09 ms and 3.83 / 2.86 ms
+// measured in round 2 at 512 and at 1024 threads and ran 8-30 % SLOWER: 3.97 / 3.09 ms and 3.83 / 2.86 ms
 // against 3.30 / 2.30 ms (exact / f32, 1.5 deg tilt, config-3 size).  The arithmetic wants more
 // resident waves than one workgroup brings)
-template <bool F32, int TZ, int DEP, bool GRID>
-__global__ __launch_bounds__(kThreads, 4) void affine_box_kernel(BoxArgs p) {
+template <bool F32, int TZ, int DEP, bool GRID, int NT>
+__global__ __launch_bounds__(NT, 4) void affine_box_kernel(BoxArgs p) {
   extern __shared__ f32x4 smem4[];
   const float* const smem = reinterpret_cast<const float*>(smem4);
   const unsigned lds_base =
@@ -392,10 +395,10 @@ __global__ __launch_bounds__(kThreads, 4) void affine_box_kernel(BoxArgs p) {
   const int bid = blockIdx.x;
   const Blk b = locate<TZ, GRID>(p, p.linear ? bid : (bid & 7) * p.per_xcd + (bid >> 3));
   if (!b.valid) return;
-  if (!b.blind && probe != 1) stage<kThreads>(p, b, lds_base, tid, wave);
+  if (!b.blind && probe != 1) stage<NT>(p, b, lds_base, tid, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  compute<F32, TZ, DEP, kThreads, GRID>(p, b, smem, tid, probe);
+  compute<F32, TZ, DEP, NT, GRID>(p, b, smem, tid, probe);
 }
 
 struct BoxShape {
@@ -430,19 +433,21 @@ bool pick_shape(int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane
   // rows start on 16-byte boundaries (LDS-DMA moves 16-byte chunks) and hold whole chunks up to the last column
   if (pitch % 4 != 0 || plane % 4 != 0 || pitch < ((Xi + 3) & ~int64_t(3)) || Xi < 8 || Yi < 2 || Zi < 2) return false;
   if (plane >= (int64_t(1) << 32)) return false;
-  // 8192 voxels, tx >= 32 (stores stay 128-byte runs), tz in {8, 16} (the compiled walks)
-  static const int shapes[][3] = {{8, 16, 64}, {16, 16, 32}, {8, 32, 32}, {16, 8, 64}, {8, 8, 128}, {16, 4, 128}};
+  // 4096 voxels, tx >= 32 (stores stay 128-byte runs), tz in {8, 16} (the compiled walks)
+  static const int shapes[][3] = {{8, 8, 64}, {16, 8, 32}, {8, 16, 32}, {16, 4, 64}, {8, 4, 128}, {16, 2, 128}};
+  // workgroups per CU: four by registers (256 threads on up to 128 VGPRs), by LDS as many boxes as fit into
+  // 156 KB -- more resident boxes first, then the smaller box
+  auto resident = [](int64_t lds) { return static_cast<int>(std::min<int64_t>(4, (156 * 1024) / lds)); };
   bool found = false;
   for (const auto& sh : shapes) {
     BoxShape s;
     if (!box_of(M, sh[0], sh[1], sh[2], &s)) continue;
     if (s.lds_bytes > 150 * 1024 || lsr::ceil_div(s.lds_bytes / 16, kThreads) > kMaxLoads) continue;
     if (int64_t(s.bz) * plane * 4 >= (int64_t(1) << 32)) continue;   // 32-bit byte offsets inside a box
-    // two workgroups per CU (box <= 78 KB) beat any single-workgroup shape; then the smaller box
     // (first listed wins a tie: pricing the 160-byte rows of tx = 32 shapes higher than their byte
-    // count picked 16x8x64 over 16x16x32 at equal bytes and ran 12 % slower)
-    const bool two = s.lds_bytes <= 78 * 1024, best_two = found && best->lds_bytes <= 78 * 1024;
-    if (!found || (two && !best_two) || (two == best_two && s.lds_bytes < best->lds_bytes)) {
+    // count picked the longer rows at equal bytes and ran 12 % slower)
+    const int r = resident(s.lds_bytes), best_r = found ? resident(best->lds_bytes) : 0;
+    if (!found || r > best_r || (r == best_r && s.lds_bytes < best->lds_bytes)) {
       *best = s;
       found = true;
     }
@@ -451,13 +456,13 @@ bool pick_shape(int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane
 }
 
 // false: the device refuses the LDS budget (message in lsr_last_error()); the caller runs the gather kernel
-template <bool F32, int TZ, int DEP, bool GRID = false>
+template <bool F32, int TZ, int DEP, int NT, bool GRID = false>
 bool launch_one(const BoxArgs& p, unsigned blocks, size_t lds_bytes, hipStream_t s) {
   static std::atomic<uint64_t> lds_allowed{0};
-  auto kernel = affine_box_kernel<F32, TZ, DEP, GRID>;
+  auto kernel = affine_box_kernel<F32, TZ, DEP, GRID, NT>;
   if (lsr::allow_dynamic_lds(reinterpret_cast<const void*>(kernel), 150 * 1024, lds_allowed, "affine_box_kernel") != LSR_OK)
     return false;
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds_bytes, s, p);
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(NT), lds_bytes, s, p);
   return true;
 }
 
@@ -467,13 +472,13 @@ bool launch_shape(const BoxArgs& p, unsigned blocks, size_t lds_bytes, bool grid
   // (tilt about x); other patterns run the general walk (their zo * 0 terms are exact zeros).
   const bool dz = p.m[0] != 0.0, dy = p.m[4] != 0.0, dx = p.m[8] != 0.0;
   if (grid) {
-    if (dz && !dy && dx) return launch_one<F32, TZ, 5, true>(p, blocks, lds_bytes, s);
-    if (dz && dy && !dx) return launch_one<F32, TZ, 3, true>(p, blocks, lds_bytes, s);
-    return launch_one<F32, TZ, 7, true>(p, blocks, lds_bytes, s);
+    if (dz && !dy && dx) return launch_one<F32, TZ, 5, kThreads, true>(p, blocks, lds_bytes, s);
+    if (dz && dy && !dx) return launch_one<F32, TZ, 3, kThreads, true>(p, blocks, lds_bytes, s);
+    return launch_one<F32, TZ, 7, kThreads, true>(p, blocks, lds_bytes, s);
   }
-  if (dz && !dy && dx) return launch_one<F32, TZ, 5>(p, blocks, lds_bytes, s);
-  if (dz && dy && !dx) return launch_one<F32, TZ, 3>(p, blocks, lds_bytes, s);
-  return launch_one<F32, TZ, 7>(p, blocks, lds_bytes, s);
+  if (dz && !dy && dx) return launch_one<F32, TZ, 5, kThreads>(p, blocks, lds_bytes, s);
+  if (dz && dy && !dx) return launch_one<F32, TZ, 3, kThreads>(p, blocks, lds_bytes, s);
+  return launch_one<F32, TZ, 7, kThreads>(p, blocks, lds_bytes, s);
 }
 
 }  // namespace

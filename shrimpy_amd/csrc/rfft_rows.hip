@@ -12,10 +12,21 @@
 //                          reduces |corr| with its fftshift-ed flat index to one candidate per workgroup --
 //                          the correlation volume is never written.
 //
+// The same two kernels carry the x leg of a Richardson-Lucy iteration done in the Fourier domain
+// (shrimpy_amd/deconvolve_fft.py: PSFs beyond the stencil kernels' extents, e.g. measured bead PSFs):
+//
+//   lsr_rfft_rows_zero_t_c64:  the forward kernel with the source placed at the grid's origin and ZERO padding
+//                              behind it (linear, not circular, convolution); tiles past the source store zeros;
+//   lsr_irfft_rows_rl_f32:     the inverse kernel with a Richardson-Lucy epilogue instead of the peak search: the
+//                              rows are scaled, cropped to the volume and leave as ratio = y / (H x + eps) or as
+//                              x_new = x * H^T(ratio) / H^T 1 (+ the iteration's reduction scalars); the convolved
+//                              volume is never written.
+//
 // Unnormalised, like hipFFT: forward X[k] = sum_n x[n] exp(-2 pi i k n / X); the inverse carries a factor
 // 2 X / 2 = X (irrelevant to an argmax, and the same for every voxel).
 // Lengths: X a multiple of 4 with X / 2 5-smooth and <= 2048 (lsr_rfft_rows_supported); others keep rocFFT.
 
+#include "correlate_common.hpp"
 #include "fft_lds.hpp"
 
 namespace {
@@ -37,6 +48,15 @@ struct RowsArgs {
   Factors f;
   float* pval;            // inverse: one candidate per workgroup
   unsigned long long* pidx;
+  // Richardson-Lucy epilogue (irfft_rows_rl_kernel)
+  const float* aux;       // ratio epilogue: y; update epilogue: x  ((Zo, Yo, Xo) float32)
+  float* out;             // (Zo, Yo, Xo) float32; may be aux (every voxel is read and written by one thread)
+  int Zo, Yo, Xo;         // the volume: the grid's first Zo x Yo x Xo points
+  float scale, eps;       // 1 / (Z Y X) (the transforms are unnormalised); eps of the ratio
+  int pz, py, px;         // PSF extents (geometry of the normalisation table)
+  const double* norm_table;   // (pz+1)(py+1)(px+1) prefix sums of the PSF (border voxels)
+  float norm_full;        // sum of all taps (interior voxels)
+  double* stats;          // update epilogue: three running sums of the iteration (correlate_common.hpp) or NULL
 };
 
 __device__ __forceinline__ int reflect_index(int i, int n) {
@@ -73,6 +93,8 @@ __device__ __forceinline__ float2 tw_m(const float2* tw, int half, int i) {
   return hi ? float2{-v.x, -v.y} : v;
 }
 
+// ZERO: the source sits at the grid's origin, zeros behind it (no index map)
+template <bool ZERO>
 __global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
   extern __shared__ float2 smem[];
   const int M = p.M, half = M / 2;
@@ -82,8 +104,30 @@ __global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
   const int z = blockIdx.x / tiles_y, y0 = (blockIdx.x - z * tiles_y) * kRows;
   const int nrows = min(kRows, p.Y - y0);
 
+  if constexpr (ZERO) {
+    if (z >= p.Zi || y0 >= p.Yi) {   // (uniform) a tile of padding: its spectrum is zero
+      const int r = tid & (kRows - 1), k0 = tid / kRows;
+      if (r < nrows) {
+        float2* out = p.spec + static_cast<int64_t>(z) * p.XC * p.Y + y0 + r;
+        for (int k = k0; k <= M; k += kThreads / kRows) out[static_cast<int64_t>(k) * p.Y] = float2{0.0f, 0.0f};
+      }
+      return;
+    }
+  }
   for (int k = tid; k < half; k += kThreads) t.tw[k] = p.tw_half[k];
-  {  // gather: row r of the tile <- source row (match(z), match(y0 + r)), columns through match(x); (even, odd) packed
+  if constexpr (ZERO) {
+    const int r = tid / kPerRow, lane = tid & (kPerRow - 1);
+    float2* row = t.buf + r * t.pitch;
+    if (r < nrows && y0 + r < p.Yi) {
+      const float* src = p.in + (static_cast<int64_t>(z) * p.Yi + y0 + r) * p.Xi;
+      for (int m = lane; m < M; m += kPerRow) {
+        const int x0 = 2 * m;
+        row[m] = float2{x0 < p.Xi ? src[x0] : 0.0f, x0 + 1 < p.Xi ? src[x0 + 1] : 0.0f};
+      }
+    } else {
+      for (int m = lane; m < M; m += kPerRow) row[m] = float2{0.0f, 0.0f};
+    }
+  } else {  // gather: row r of the tile <- source row (match(z), match(y0 + r)), columns through match(x); (even, odd) packed
     const int r = tid / kPerRow, lane = tid & (kPerRow - 1);
     float2* row = t.buf + r * t.pitch;
     if (r < nrows) {
@@ -197,6 +241,103 @@ __global__ __launch_bounds__(kThreads) void irfft_rows_peak_kernel(RowsArgs p) {
   }
 }
 
+// H^T 1 at a border voxel from the PSF's prefix sums (the taps that stay inside the volume): as dense_norm of
+// correlate_dense.hip
+__device__ __forceinline__ float rl_border_norm(const RowsArgs& p, int z, int y, int x) {
+  const double* P = p.norm_table;
+  const int cz = p.pz / 2, cy = p.py / 2, cx = p.px / 2;
+  const int a0 = max(0, cz - z), a1 = min(p.pz, p.Zo - z + cz);
+  const int b0 = max(0, cy - y), b1 = min(p.py, p.Yo - y + cy);
+  const int c0 = max(0, cx - x), c1 = min(p.px, p.Xo - x + cx);
+  const int sb = p.px + 1, sa = (p.py + 1) * sb;
+  return static_cast<float>(((P[a1 * sa + b1 * sb + c1] - P[a0 * sa + b1 * sb + c1]) -
+                             (P[a1 * sa + b0 * sb + c1] - P[a0 * sa + b0 * sb + c1])) -
+                            ((P[a1 * sa + b1 * sb + c0] - P[a0 * sa + b1 * sb + c0]) -
+                             (P[a1 * sa + b0 * sb + c0] - P[a0 * sa + b0 * sb + c0])));
+}
+
+// The inverse x leg with a Richardson-Lucy epilogue.  v = scale * (the complex-to-real inverse of the tile's rows),
+// i.e. H x or H^T(ratio) on the volume's first Zo x Yo x Xo grid points:
+//   EPI = LSR_EPI_RATIO:   out = aux / (max(v, 0) + eps)          (aux = y; a float32 transform can leave a tiny
+//                                                                  negative where H x is 0: clamped, H x >= 0)
+//   EPI = LSR_EPI_UPDATE:  out = aux * v / H^T 1                  (aux = x; STATS: the iteration's three sums)
+// Tiles past the volume (the padding planes and rows of the grid) are not even loaded.
+template <int EPI, bool STATS>
+__global__ __launch_bounds__(kThreads) void irfft_rows_rl_kernel(RowsArgs p) {
+  extern __shared__ float2 smem[];
+  const int M = p.M, half = M / 2;
+  const Tile t = carve(smem, M);
+  const int tid = threadIdx.x;
+  const int tiles_y = (p.Y + kRows - 1) / kRows;
+  const int z = blockIdx.x / tiles_y, y0 = (blockIdx.x - z * tiles_y) * kRows;
+  if (z >= p.Zo || y0 >= p.Yo) return;   // (uniform)
+  const int nrows = min(kRows, p.Yo - y0);
+
+  for (int k = tid; k < half; k += kThreads) t.tw[k] = p.tw_half[k];
+  {
+    const int r = tid & (kRows - 1), k0 = tid / kRows;
+    float2* row = t.buf + r * t.pitch;
+    const float2* in = p.spec + static_cast<int64_t>(z) * p.XC * p.Y + y0 + r;
+    for (int k = k0; k <= M; k += kThreads / kRows)
+      row[k] = y0 + r < p.Y ? in[static_cast<int64_t>(k) * p.Y] : float2{0.0f, 0.0f};
+  }
+  __syncthreads();
+  {  // complex-to-real pre step (as irfft_rows_peak_kernel)
+    const int r = tid / kPerRow, lane = tid & (kPerRow - 1);
+    float2* row = t.buf + r * t.pitch;
+    for (int m = lane; m <= half; m += kPerRow) {
+      const int mm = M - m;
+      const float2 xa = row[m], xb = row[mm];
+      const float2 wa = cconj(p.tw_x[m]), wb = cconj(p.tw_x[mm]);
+      const float2 za = cadd(cadd(xa, cconj(xb)), mul_i(cmul(wa, csub(xa, cconj(xb)))));
+      const float2 zb = cadd(cadd(xb, cconj(xa)), mul_i(cmul(wb, csub(xb, cconj(xa)))));
+      row[m] = cconj(za);
+      if (m != 0 && mm != m) row[mm] = cconj(zb);
+    }
+  }
+  __syncthreads();
+
+  const float2* twl = t.tw;
+  transform<kMaxM, kPerRow>(t.buf + (tid / kPerRow) * t.pitch, M, p.f, [twl, half](int i) { return tw_m(twl, half, i); },
+                            tid & (kPerRow - 1));
+
+  // conj(FFT(conj(Zt)))[m] = v[2m] + i v[2m + 1]: the row holds its conjugate
+  lsr::RlStats stats;
+  {
+    const int r = tid / kPerRow, lane = tid & (kPerRow - 1);
+    if (r < nrows) {
+      const float2* row = t.buf + r * t.pitch;
+      const int y = y0 + r;
+      const int64_t base = (static_cast<int64_t>(z) * p.Yo + y) * p.Xo;
+      const float* aux = p.aux + base;
+      float* out = p.out + base;
+      const int cz = p.pz / 2, cy = p.py / 2, cx = p.px / 2;
+      const bool zy_inside = z >= cz && z < p.Zo - cz && y >= cy && y < p.Yo - cy;
+      for (int m = lane; 2 * m < p.Xo; m += kPerRow) {
+        const float2 c = row[m];
+        const float v[2] = {c.x * p.scale, -c.y * p.scale};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int x = 2 * m + h;
+          if (x < p.Xo) {
+            const float a = aux[x];
+            if constexpr (EPI == LSR_EPI_RATIO) {
+              out[x] = a / (fmaxf(v[h], 0.0f) + p.eps);
+            } else {
+              const float nrm = (zy_inside && x >= cx && x < p.Xo - cx) ? p.norm_full : rl_border_norm(p, z, y, x);
+              const float xu = a * v[h];
+              const float xn = xu / nrm;
+              out[x] = xn;
+              if constexpr (STATS) stats.add(a, xu, xn);
+            }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (STATS) lsr::rl_stats_flush<kThreads / 64>(stats, reinterpret_cast<float*>(smem), p.stats);
+}
+
 __global__ __launch_bounds__(256) void rows_peak_final_kernel(const float* __restrict__ pval,
                                                              const unsigned long long* __restrict__ pidx, int64_t nb,
                                                              long long* __restrict__ out) {
@@ -281,9 +422,9 @@ extern "C" int lsr_rfft_rows_t_c64(const float* in, int64_t Zi, int64_t Yi, int6
   p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
   p.spec = reinterpret_cast<float2*>(spec);
   static std::atomic<uint64_t> lds_allowed{0};
-  if (int rc = allow_lds(rfft_rows_kernel, lds_allowed, "lsr_rfft_rows_t_c64")) return rc;
+  if (int rc = allow_lds(rfft_rows_kernel<false>, lds_allowed, "lsr_rfft_rows_t_c64")) return rc;
   const unsigned blocks = static_cast<unsigned>(Z * lsr::ceil_div(Y, kRows));
-  hipLaunchKernelGGL(rfft_rows_kernel, dim3(blocks), dim3(kThreads), lds_bytes(p.M), lsr::as_stream(stream), p);
+  hipLaunchKernelGGL(rfft_rows_kernel<false>, dim3(blocks), dim3(kThreads), lds_bytes(p.M), lsr::as_stream(stream), p);
   return lsr::launch_status("lsr_rfft_rows_t_c64");
 }
 
@@ -304,4 +445,69 @@ extern "C" int lsr_irfft_rows_peak(const float* spec, int64_t Z, int64_t Y, int6
   hipLaunchKernelGGL(irfft_rows_peak_kernel, dim3(static_cast<unsigned>(nb)), dim3(kThreads), lds_bytes(p.M), s, p);
   hipLaunchKernelGGL(rows_peak_final_kernel, dim3(1), dim3(256), 0, s, p.pval, p.pidx, nb, out_index);
   return lsr::launch_status("lsr_irfft_rows_peak");
+}
+
+extern "C" int lsr_rfft_rows_zero_t_c64(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* spec, int64_t Z,
+                                        int64_t Y, int64_t X, const float* tw_half, const float* tw_x,
+                                        lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(spec);
+  LSR_REQUIRE(Zi > 0 && Yi > 0 && Xi > 0, LSR_E_SHAPE, "source shape (%lld,%lld,%lld) must be positive", (long long)Zi,
+              (long long)Yi, (long long)Xi);
+  LSR_REQUIRE_VOLUME(Zi, Yi, Xi);
+  LSR_REQUIRE(Zi <= Z && Yi <= Y && Xi <= X, LSR_E_SHAPE, "the source (%lld,%lld,%lld) must fit the grid (%lld,%lld,%lld)",
+              (long long)Zi, (long long)Yi, (long long)Xi, (long long)Z, (long long)Y, (long long)X);
+  RowsArgs p{};
+  if (int rc = fill(p, Z, Y, X, tw_half, tw_x)) return rc;
+  p.in = in;
+  p.Zi = static_cast<int>(Zi); p.Yi = static_cast<int>(Yi); p.Xi = static_cast<int>(Xi);
+  p.spec = reinterpret_cast<float2*>(spec);
+  static std::atomic<uint64_t> lds_allowed{0};
+  if (int rc = allow_lds(rfft_rows_kernel<true>, lds_allowed, "lsr_rfft_rows_zero_t_c64")) return rc;
+  const unsigned blocks = static_cast<unsigned>(Z * lsr::ceil_div(Y, kRows));
+  hipLaunchKernelGGL(rfft_rows_kernel<true>, dim3(blocks), dim3(kThreads), lds_bytes(p.M), lsr::as_stream(stream), p);
+  return lsr::launch_status("lsr_rfft_rows_zero_t_c64");
+}
+
+extern "C" int lsr_irfft_rows_rl_f32(const float* spec, int64_t Z, int64_t Y, int64_t X, const float* tw_half,
+                                     const float* tw_x, int epilogue, const float* aux, float* out, int64_t Zo, int64_t Yo,
+                                     int64_t Xo, float scale, float eps, int pz, int py, int px, const double* norm_table,
+                                     float norm_full, double* stats, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(spec);
+  LSR_REQUIRE_PTR(aux);
+  LSR_REQUIRE_PTR(out);
+  LSR_REQUIRE(epilogue == LSR_EPI_RATIO || epilogue == LSR_EPI_UPDATE, LSR_E_ARG,
+              "epilogue must be LSR_EPI_RATIO or LSR_EPI_UPDATE, got %d", epilogue);
+  LSR_REQUIRE(Zo > 0 && Yo > 0 && Xo > 0 && Zo <= Z && Yo <= Y && Xo <= X, LSR_E_SHAPE,
+              "the volume (%lld,%lld,%lld) must be positive and fit the grid (%lld,%lld,%lld)", (long long)Zo, (long long)Yo,
+              (long long)Xo, (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE(scale > 0.0f && eps > 0.0f, LSR_E_ARG, "scale and eps must be positive");
+  RowsArgs p{};
+  if (int rc = fill(p, Z, Y, X, tw_half, tw_x)) return rc;
+  if (epilogue == LSR_EPI_UPDATE) {
+    LSR_REQUIRE_PTR(norm_table);
+    LSR_REQUIRE(pz > 0 && py > 0 && px > 0 && pz % 2 == 1 && py % 2 == 1 && px % 2 == 1 && pz < 4096 && py < 4096 &&
+                    px < 4096, LSR_E_ARG, "PSF extents (%d,%d,%d) must be odd and positive", pz, py, px);
+    LSR_REQUIRE(norm_full > 0.0f, LSR_E_ARG, "norm_full must be positive");
+  }
+  p.spec = const_cast<float2*>(reinterpret_cast<const float2*>(spec));
+  p.aux = aux; p.out = out;
+  p.Zo = static_cast<int>(Zo); p.Yo = static_cast<int>(Yo); p.Xo = static_cast<int>(Xo);
+  p.scale = scale; p.eps = eps;
+  p.pz = pz; p.py = py; p.px = px;
+  p.norm_table = norm_table; p.norm_full = norm_full; p.stats = stats;
+  const unsigned blocks = static_cast<unsigned>(Z * lsr::ceil_div(Y, kRows));
+  hipStream_t s = lsr::as_stream(stream);
+  static std::atomic<uint64_t> a0{0}, a1{0}, a2{0};
+  if (epilogue == LSR_EPI_RATIO) {
+    if (int rc = allow_lds(irfft_rows_rl_kernel<LSR_EPI_RATIO, false>, a0, "lsr_irfft_rows_rl_f32")) return rc;
+    hipLaunchKernelGGL((irfft_rows_rl_kernel<LSR_EPI_RATIO, false>), dim3(blocks), dim3(kThreads), lds_bytes(p.M), s, p);
+  } else if (stats == nullptr) {
+    if (int rc = allow_lds(irfft_rows_rl_kernel<LSR_EPI_UPDATE, false>, a1, "lsr_irfft_rows_rl_f32")) return rc;
+    hipLaunchKernelGGL((irfft_rows_rl_kernel<LSR_EPI_UPDATE, false>), dim3(blocks), dim3(kThreads), lds_bytes(p.M), s, p);
+  } else {
+    if (int rc = allow_lds(irfft_rows_rl_kernel<LSR_EPI_UPDATE, true>, a2, "lsr_irfft_rows_rl_f32")) return rc;
+    hipLaunchKernelGGL((irfft_rows_rl_kernel<LSR_EPI_UPDATE, true>), dim3(blocks), dim3(kThreads), lds_bytes(p.M), s, p);
+  }
+  return lsr::launch_status("lsr_irfft_rows_rl_f32");
 }

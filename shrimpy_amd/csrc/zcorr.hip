@@ -35,6 +35,7 @@ struct ZcorrArgs {
   int N, Y, XC;
   Factors f;
   float inv_n;                     // 1 / N
+  int mode;                        // 0: f1 * conj(G) (cross-correlation), 1: f1 * G, 2: conj(f1) * G (spectrum products)
 };
 
 __global__ __launch_bounds__(kThreads) void zcorr_kernel(ZcorrArgs p) {
@@ -70,7 +71,13 @@ __global__ __launch_bounds__(kThreads) void zcorr_kernel(ZcorrArgs p) {
     if (round == 0) {
       if (my < ncols) {
         const float2* ref = f1 + static_cast<int64_t>(my) * N;
-        for (int k = t; k < N; k += kPerCol) my_col[k] = cmul(cconj(ref[k]), my_col[k]);
+        // (what the second transform needs is conj(v) of the product v wanted: conj(FFT(conj(v))) = N IFFT(v))
+        if (p.mode == 0)
+          for (int k = t; k < N; k += kPerCol) my_col[k] = cmul(cconj(ref[k]), my_col[k]);          // v = f1 conj(G)
+        else if (p.mode == 1)
+          for (int k = t; k < N; k += kPerCol) my_col[k] = cconj(cmul(ref[k], my_col[k]));          // v = f1 G
+        else
+          for (int k = t; k < N; k += kPerCol) my_col[k] = cmul(ref[k], cconj(my_col[k]));          // v = conj(f1) G
       }
       sequence_sync();
     }
@@ -93,8 +100,26 @@ extern "C" int lsr_cross_correlate_z_supported(int64_t n) {
   return n == 1 && lsr::lds_fits(lds);
 }
 
+namespace {
+int z_leg(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC, int mode, lsr_stream_t stream);
+}
+
 extern "C" int lsr_cross_correlate_z_c64(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC,
                                          lsr_stream_t stream) {
+  return z_leg(f1, g, twiddles, N, Y, XC, 0, stream);
+}
+
+// g <- N * IFFT_z( f1 * FFT_z(g) )  (conj_f1 = 0)  or  N * IFFT_z( conj(f1) * FFT_z(g) )  (conj_f1 = 1): the z leg of a
+// convolution / correlation with the volume behind f1 done in the Fourier domain (deconvolve_fft.py); layouts as
+// lsr_cross_correlate_z_c64.
+extern "C" int lsr_spectrum_multiply_z_c64(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y,
+                                           int64_t XC, int conj_f1, lsr_stream_t stream) {
+  LSR_REQUIRE(conj_f1 == 0 || conj_f1 == 1, LSR_E_ARG, "conj_f1 must be 0 or 1, got %d", conj_f1);
+  return z_leg(f1, g, twiddles, N, Y, XC, conj_f1 ? 2 : 1, stream);
+}
+
+namespace {
+int z_leg(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC, int mode, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(f1);
   LSR_REQUIRE_PTR(g);
   LSR_REQUIRE_PTR(twiddles);
@@ -132,6 +157,7 @@ extern "C" int lsr_cross_correlate_z_c64(const float* f1, float* g, const float*
     }
   }
   p.inv_n = 1.0f / static_cast<float>(p.N);
+  p.mode = mode;
   const int64_t blocks = XC * lsr::ceil_div(Y, kCols);
   LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large", (long long)blocks);
   const size_t lds = (static_cast<size_t>(kCols) * (p.N + 1) + p.N) * sizeof(float2);
@@ -143,3 +169,4 @@ extern "C" int lsr_cross_correlate_z_c64(const float* f1, float* g, const float*
   hipLaunchKernelGGL(zcorr_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), lds, lsr::as_stream(stream), p);
   return lsr::launch_status("lsr_cross_correlate_z_c64");
 }
+}  // namespace
