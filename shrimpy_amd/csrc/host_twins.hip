@@ -44,8 +44,10 @@ namespace {
 using lsr::parallel_ranges;
 std::atomic<int>& g_threads = lsr::g_host_threads;
 constexpr int kMaxAvg = 16;    // as deskew.hip
-constexpr int kMaxTaps = 15;   // as correlate.hip
-constexpr int kMaxZTaps = 31;  // as correlate_z.hip
+// the stencil kernels hold 15 taps per axis (31 along z, correlate_z.hip); larger dense PSFs run in the Fourier
+// domain on the device (deconvolve_fft.py, up to 129 taps per axis) -- the twins' loops take any count
+constexpr int kMaxTaps = 129;
+constexpr int kMaxZTaps = 129;
 
 // acc[x] = fma(w, v(x + shift), acc[x]) over a whole row, v = row[...] inside [0, X) and 0 outside it (row == nullptr:
 // a row of zeros) -- the FMA with 0 is executed, as the kernels execute it; the middle part is a plain packed loop.
@@ -238,7 +240,6 @@ int check_corr(const float* in, float* out, const float* aux, int64_t Z, int64_t
   LSR_REQUIRE(Z > 0 && Y > 0 && X > 0, LSR_E_SHAPE, "shape (%lld,%lld,%lld) must be positive", (long long)Z, (long long)Y,
               (long long)X);
   LSR_REQUIRE_VOLUME(Z, Y, X);
-  // (z: up to 31 taps, what the device runs through lsr_correlate_z_f32; the loops below take any count)
   LSR_REQUIRE(pz >= 1 && py >= 1 && px >= 1 && (pz & 1) && (py & 1) && (px & 1) && pz <= kMaxZTaps && py <= kMaxTaps &&
                   px <= kMaxTaps,
               LSR_E_UNSUPPORTED, "PSF taps (%d,%d,%d) must be odd, <= %d in plane and <= %d along z", pz, py, px, kMaxTaps,

@@ -27,13 +27,13 @@ import numpy as np
 from . import _lib
 
 __all__ = ["richardson_lucy", "RichardsonLucyPlan", "RLStats", "factor_psf", "correlate3d", "prepare_psf",
-           "padded_shape", "PaddedVolume"]
+           "padded_shape", "PaddedVolume", "make_plan"]
 
 MAX_TAPS = 15
 MAX_Z_TAPS = 31     # separable PSFs only: the z factor runs as its own launch (csrc/correlate_z.hip)
 
 
-def prepare_psf(psf) -> np.ndarray:
+def prepare_psf(psf, max_in_plane: int = MAX_TAPS, max_z: int = MAX_Z_TAPS) -> np.ndarray:
     """float32 (pz, py, px) with every axis odd: even axes get one trailing zero plane.
 
     With ``center = size // 2`` the padded kernel produces the same correlation.
@@ -46,8 +46,8 @@ def prepare_psf(psf) -> np.ndarray:
     pad = [(0, 1 - (s % 2)) for s in p.shape]
     if any(hi for _, hi in pad):
         p = np.pad(p, pad)
-    if max(p.shape[1:]) > MAX_TAPS or p.shape[0] > MAX_Z_TAPS:
-        raise ValueError(f"psf shape {p.shape} exceeds {MAX_TAPS} taps in plane / {MAX_Z_TAPS} along z")
+    if max(p.shape[1:]) > max_in_plane or p.shape[0] > max_z:
+        raise ValueError(f"psf shape {p.shape} exceeds {max_in_plane} taps in plane / {max_z} along z")
     return np.ascontiguousarray(p)
 
 
@@ -367,6 +367,11 @@ class RichardsonLucyPlan:
     @property
     def separable(self) -> bool:
         return self._psf.separable
+
+    @property
+    def padded_input(self) -> bool:
+        """``plan(y)`` can take a zero-haloed :class:`PaddedVolume` written in place by the producer of ``y``."""
+        return self.path != "generic"
 
     @property
     def path(self) -> str:
@@ -757,14 +762,59 @@ class RichardsonLucyPlan:
         return done, bool(met(iterations - 1))
 
 
+def make_plan(shape_zyx, psf, device, *, separable: str = "auto", separable_rtol: float = 1e-6, psf_factors=None,
+              fused: str = "auto", method: str = "auto"):
+    """The plan that runs RL for this volume shape and PSF on a HIP device.
+
+    ``method="direct"``: the stencil kernels (:class:`RichardsonLucyPlan`; PSFs up to 15 taps per axis, 31 along z
+    when separable).  ``"fft"``: the two convolutions of an iteration as products of spectra
+    (:class:`shrimpy_amd.deconvolve_fft.FftRichardsonLucyPlan`; any PSF the transform grid holds).  ``"auto"``: the
+    stencil kernels wherever a tuned one takes the PSF (three 1-D factors, ``ky (x) kzx``, dense up to 11 x 9 x 9);
+    a dense PSF beyond them -- a measured bead PSF -- goes to the Fourier domain, where its size costs nothing
+    (``profiles/r04_rl_fft.jsonl``), and only falls back to the bounds-checked generic stencil when the grid is
+    outside the transform kernels' lengths."""
+    if method not in ("auto", "direct", "fft"):
+        raise ValueError("method must be 'auto', 'direct' or 'fft'")
+    from .deconvolve_fft import MAX_FFT_TAPS, FftRichardsonLucyPlan, fft_supported
+
+    def dense_psf():
+        if psf_factors is not None:
+            kz, ky, kx = (np.asarray(k, dtype=np.float32).ravel() for k in psf_factors)
+            return (kz[:, None, None] * ky[None, :, None] * kx[None, None, :]).astype(np.float32)
+        return prepare_psf(psf, MAX_FFT_TAPS, MAX_FFT_TAPS)
+
+    if method == "fft":
+        return FftRichardsonLucyPlan(shape_zyx, dense_psf(), device)
+    direct, refused = None, None
+    try:
+        direct = RichardsonLucyPlan(shape_zyx, psf, device, separable=separable, separable_rtol=separable_rtol,
+                                    psf_factors=psf_factors, fused=fused)
+    except ValueError as exc:      # more taps than the stencil kernels hold
+        if method == "direct" or psf_factors is not None or psf is None:
+            raise
+        refused = exc
+    if method == "direct" or (direct is not None and direct.path != "generic"):
+        return direct
+    w = dense_psf()
+    if fft_supported(shape_zyx, w.shape):
+        return FftRichardsonLucyPlan(shape_zyx, w, device)
+    if direct is None:
+        raise refused
+    return direct
+
+
 def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=None, *,
                     separable: str = "auto", separable_rtol: float = 1e-6, psf_factors=None,
-                    tol: float | None = None, return_stats: bool = False):
+                    tol: float | None = None, return_stats: bool = False, method: str = "auto"):
     """Richardson-Lucy deconvolution of a (Z, Y, X) float32 device tensor; returns a new tensor.
 
     ``psf`` is used as given (normalise it to sum 1 for flux conservation).  ``x0`` defaults to
     ``y``.  ``separable="auto"`` takes the rank-1 fast path when the PSF factorises within
     ``separable_rtol``; pass ``psf_factors=(kz, ky, kx)`` to skip the test.
+
+    ``method``: ``"auto"`` (default) runs the stencil kernels where a tuned one takes the PSF and the Fourier-domain
+    iteration for dense PSFs beyond them (:func:`make_plan`); ``"direct"`` / ``"fft"`` insist on one.  CPU tensors
+    always run the host twins of the stencil arithmetic.
 
     ``tol``: stop before ``iterations`` once an iteration's relative change ``sum|x_new - x| / sum x_new`` is below
     it (the kernels sum both in their epilogues; see :class:`RLStats`).  ``return_stats=True`` returns
@@ -784,8 +834,8 @@ def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=Non
 
         return host.richardson_lucy(y, psf, iterations, eps, x0, separable=separable, separable_rtol=separable_rtol,
                                     psf_factors=psf_factors, tol=tol, return_stats=return_stats)
-    plan = RichardsonLucyPlan(tuple(y.shape), psf, y.device, separable=separable,
-                              separable_rtol=separable_rtol, psf_factors=psf_factors)
+    plan = make_plan(tuple(y.shape), psf, y.device, separable=separable, separable_rtol=separable_rtol,
+                     psf_factors=psf_factors, method=method)
     x = plan(y, iterations=iterations, eps=eps, x0=x0, stats=return_stats, tol=tol)
     return (x, plan.last_stats) if return_stats else x
 

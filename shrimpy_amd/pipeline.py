@@ -122,14 +122,15 @@ class VolumeReconstructor:
                     else:
                         self._host_rl = dict(psf=None, psf_factors=factors)
         elif dec is not None and dec.iterations > 0:
-            from .deconvolve import RichardsonLucyPlan
+            from .deconvolve import RichardsonLucyPlan, make_plan
 
             if dec.psf_path:
                 psf = dec.load_psf()
-                self._plan = RichardsonLucyPlan(
+                # (a measured PSF beyond the stencil kernels' extents runs in the Fourier domain: deconvolve_fft.py)
+                self._plan = make_plan(
                     self.output_shape, psf, self.device,
                     separable={"auto": "auto", "force": "force", "never": "never"}[dec.separable],
-                    separable_rtol=dec.separable_rtol)
+                    separable_rtol=dec.separable_rtol, method=dec.method)
             else:
                 factors = gaussian_psf_factors(dec.gaussian_shape_zyx, dec.gaussian_sigma_zyx)
                 if dec.separable == "never":
@@ -166,7 +167,7 @@ class VolumeReconstructor:
         if self._geo is not None:
             target = None
             d = self.settings.deskew
-            if (self._plan is not None and self._register is None and self._plan.path != "generic"
+            if (self._plan is not None and self._register is None and self._plan.padded_input
                     and self._canonical_deskew):
                 # deskew straight into the RL kernels' padded, line-aligned input volume
                 if self._y_pad is None:
@@ -191,7 +192,7 @@ class VolumeReconstructor:
         if self._register is not None:
             r = self._register
             target = None
-            if self._plan is not None and self._plan.path != "generic":
+            if self._plan is not None and self._plan.padded_input:
                 # resample straight into the RL kernels' padded, line-aligned input volume
                 if self._y_pad is None:
                     self._y_pad = self._plan.new_padded_input()

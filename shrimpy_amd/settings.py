@@ -172,8 +172,10 @@ class DeconvolveSettings(_StrictModel):
     volume as the PSF-characterisation tools around the reference write them with iohub,
     ``scripts/measure_psf.py:273-287``: HCS layout, first position, array ``"0"``, T = C = 0) -- or, when
     absent, is the separable anisotropic Gaussian ``gaussian_sigma_zyx`` truncated to
-    ``gaussian_shape_zyx``.  A measured PSF larger than the kernels' 15 taps per axis is cut to
-    ``psf_shape_zyx`` (odd, <= 15) around its brightest voxel and renormalised to sum 1 (``load_psf``).
+    ``gaussian_shape_zyx``.  ``psf_shape_zyx`` (odd) cuts a measured PSF around its brightest voxel and renormalises
+    it to sum 1 (``load_psf``).  PSFs of up to 15 taps per axis run through the stencil kernels; larger dense ones -- the
+    15 x 18 x 18 ... 30 x 36 x 18 bead patches of ``scripts/measure_psf.py:187-190`` -- run the iteration in the
+    Fourier domain (``method``, ``shrimpy_amd/deconvolve_fft.py``), at a cost that does not depend on their size.
 
     ``separable="auto"`` picks the cheapest exact form of the PSF: three 1-D kernels (one fused launch
     per iteration), else ``ky (x) kzx`` -- a y kernel times a dense (z, x) stencil, the shape of a
@@ -191,13 +193,23 @@ class DeconvolveSettings(_StrictModel):
     gaussian_shape_zyx: tuple[PositiveInt, PositiveInt, PositiveInt] = (9, 7, 7)
     separable: Literal["auto", "force", "never"] = "auto"
     separable_rtol: PositiveFloat = 1e-6
+    # "auto": stencil kernels where a tuned one takes the PSF, the Fourier-domain iteration for dense PSFs beyond
+    # them (deconvolve.make_plan); "direct" / "fft" insist on one
+    method: Literal["auto", "direct", "fft"] = "auto"
 
-    @field_validator("gaussian_shape_zyx", "psf_shape_zyx")
+    @field_validator("gaussian_shape_zyx")
     @classmethod
     def _odd_taps(cls, v):
         if v is not None and (any(n % 2 == 0 for n in v) or v[0] > 31 or max(v[1:]) > 15):
-            raise ValueError("PSF extents must be odd, <= 15 in plane and <= 31 along z (more than 15 z taps: separable "
-                             "PSFs only -- the Gaussian, or a measured PSF that factors within separable_rtol)")
+            raise ValueError("the Gaussian's extents must be odd, <= 15 in plane and <= 31 along z")
+        return v
+
+    @field_validator("psf_shape_zyx")
+    @classmethod
+    def _odd_cut(cls, v):
+        if v is not None and (any(n % 2 == 0 for n in v) or max(v) > 129):
+            raise ValueError("psf_shape_zyx must be odd and <= 129 per axis (beyond 15 taps per axis -- 31 along z for a "
+                             "PSF that factors -- the iteration runs in the Fourier domain)")
         return v
 
     def load_psf(self):
@@ -237,9 +249,11 @@ class DeconvolveSettings(_StrictModel):
             if not total > 0:
                 raise ValueError(f"psf_path {path}: the cut PSF is empty")
             psf = (psf / total).astype(np.float32)
-        elif max(psf.shape) > 15:
-            raise ValueError(f"psf_path {path}: shape {psf.shape} exceeds 15 taps per axis; give psf_shape_zyx "
-                             "(odd, <= 15) to cut it around its peak")
+        elif max(psf.shape) > 129 or (self.method == "direct" and max(psf.shape) > 15):
+            raise ValueError(f"psf_path {path}: shape {psf.shape} exceeds "
+                             + ("the stencil kernels' 15 taps per axis (method='direct')" if max(psf.shape) <= 129
+                                else "129 taps per axis")
+                             + "; give psf_shape_zyx (odd) to cut it around its peak")
         return np.ascontiguousarray(psf, dtype=np.float32)
 
 

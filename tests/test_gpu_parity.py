@@ -10,6 +10,7 @@ Bars (stated here, as the north-star requires):
 """
 
 import ctypes
+import math
 
 import numpy as np
 import pytest
@@ -778,6 +779,113 @@ def test_rl_separable_psf_with_a_long_z_factor(device, pshape, sigma):
         rot = psf.copy()
         rot[0, 0, 0] += 0.01
         RichardsonLucyPlan(vshape, rot / rot.sum(), device)
+
+
+def _measured_like_psf(shape, seed):
+    """A dense, asymmetric, non-separable PSF: a tilted Gaussian with a weak off-axis lobe, normalised to sum 1."""
+    rng = np.random.default_rng(seed)
+    z, y, x = np.meshgrid(*[np.arange(n) - n // 2 for n in shape], indexing="ij")
+    a = math.radians(25.0)
+    zr, xr = math.cos(a) * z + math.sin(a) * x, -math.sin(a) * z + math.cos(a) * x
+    s = [max(n / 5.0, 0.8) for n in shape]
+    w = np.exp(-0.5 * ((zr / s[0]) ** 2 + (y / s[1]) ** 2 + (xr / s[2]) ** 2))
+    w += 0.05 * np.exp(-0.5 * (((z - 1) / s[0]) ** 2 + ((y + 2) / s[1]) ** 2 + ((x - 2) / (0.7 * s[2])) ** 2))
+    w *= 1.0 + 0.02 * rng.standard_normal(shape)
+    w = np.clip(w, 0.0, None)
+    return (w / w.sum()).astype(np.float32)
+
+
+@pytest.mark.parametrize("vshape,pshape", [((20, 40, 52), (13, 15, 17)), ((7, 9, 11), (3, 5, 3)), ((12, 33, 131), (21, 19, 9)),
+                                           ((5, 6, 9), (9, 13, 17)), ((30, 17, 64), (1, 1, 31))])
+def test_rl_in_the_fourier_domain_vs_oracle(device, vshape, pshape):
+    """Dense PSFs beyond the stencil kernels (csrc/rfft_rows.hip, zcorr.hip, shrimpy_amd/deconvolve_fft.py): the
+    iteration with both convolutions as products of spectra, against the oracle's DIRECT stencil (the definition) within
+    the RL bar and against its use_fft form; reduction scalars to 1e-5; odd widths, volumes thinner than the PSF,
+    an explicit x0, in-place output, repeatability."""
+    import torch
+
+    from shrimpy_amd.deconvolve import make_plan
+    from shrimpy_amd.deconvolve_fft import FftRichardsonLucyPlan, fft_grid
+
+    psf = _measured_like_psf(pshape, sum(pshape))
+    y = o.bead_scene(vshape, seed=sum(vshape), psf=o.gaussian_psf((5, 5, 5), (1.2, 1.0, 1.0))[0], density=2e-3)
+    plan = make_plan(vshape, psf, device, method="fft")
+    assert isinstance(plan, FftRichardsonLucyPlan) and plan.path == "fft" and not plan.padded_input
+    assert all(g >= max(n + p // 2, p) for g, n, p in zip(plan.grid, vshape, pshape)) and plan.grid == fft_grid(vshape, pshape)
+    yd = _t(y, device)
+    x = plan(yd, iterations=5, stats=True)
+    ref = o.richardson_lucy(y, psf, 5)
+    _close(x.cpu().numpy(), ref, 2e-4, 1e-4)
+    _close(x.cpu().numpy(), o.richardson_lucy(y, psf, 5, use_fft=True), 2e-4, 1e-4)
+    assert float(x.min()) >= 0 and bool(torch.isfinite(x).all())
+    want = o.rl_iteration_scalars(y, psf, 5)
+    for name in ("flux", "change", "total"):
+        np.testing.assert_allclose(getattr(plan.last_stats, name), want[name], rtol=1e-5, err_msg=name)
+    assert torch.equal(x, plan(yd, iterations=5))                      # no atomics on the data path: bit-repeatable
+    assert torch.equal(yd, _t(y, device))                              # y is read, never written
+    x0 = np.full(vshape, float(y.mean()), np.float32)
+    out = torch.empty(vshape, device=device)
+    got = plan(yd, iterations=2, x0=_t(x0, device), out=out)
+    assert got.data_ptr() == out.data_ptr()
+    _close(out.cpu().numpy(), o.richardson_lucy(y, psf, 2, x0=x0), 5e-5, 2e-5)
+    one = plan(yd, iterations=1)
+    _close(one.cpu().numpy(), o.richardson_lucy(y, psf, 1), 2e-5, 5e-6)
+
+
+def test_rl_method_auto_sends_large_dense_psfs_to_the_fourier_domain(device):
+    """make_plan / richardson_lucy(method=): tuned stencils where they take the PSF, the Fourier-domain iteration for
+    dense PSFs beyond them (also beyond 15 taps, which the stencil plan refuses), "direct" / "fft" on request; an
+    all-zero stack stays zero (/root/reference/shrimpy/tests/test_mantis_integration.py:285-341); tol stops early."""
+    import torch
+
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan, make_plan, richardson_lucy
+
+    vshape = (16, 30, 44)
+    sep, _ = o.gaussian_psf((9, 7, 7), (2.0, 1.2, 1.2))
+    assert make_plan(vshape, sep, device).path == "fused"
+    assert make_plan(vshape, o.rotated_psf((9, 7, 7)), device).path.startswith("y-separable")
+    mid = _measured_like_psf((13, 13, 13), 1)
+    assert RichardsonLucyPlan(vshape, mid, device).path == "generic"
+    assert make_plan(vshape, mid, device).path == "fft" and make_plan(vshape, mid, device, method="direct").path == "generic"
+    big = _measured_like_psf((17, 19, 19), 2)
+    with pytest.raises(ValueError, match="exceeds 15 taps"):
+        make_plan(vshape, big, device, method="direct")
+    assert make_plan(vshape, big, device).path == "fft"
+    assert make_plan(vshape, sep, device, method="fft").path == "fft"
+    y = o.bead_scene(vshape, seed=11, psf=sep, density=2e-3)
+    yd = _t(y, device)
+    # the two routes agree with each other where both exist
+    a = richardson_lucy(yd, mid, iterations=4, method="fft")
+    b = richardson_lucy(yd, mid, iterations=4, method="direct")
+    _close(a.cpu().numpy(), b.cpu().numpy(), 2e-4, 1e-4)
+    _close(richardson_lucy(yd, big, iterations=3).cpu().numpy(), o.richardson_lucy(y, big, 3), 2e-4, 1e-4)
+    zeros = richardson_lucy(torch.zeros(vshape, device=device), big, iterations=20)
+    assert float(zeros.abs().max()) == 0.0
+    full, st_full = richardson_lucy(yd, big, iterations=12, return_stats=True)
+    x, st = richardson_lucy(yd, big, iterations=12, tol=float(st_full.rel_change[3]) * 1.0001, return_stats=True)
+    assert st.stopped_by_tol and 4 <= st.iterations <= 6 and st.iterations < 12
+    np.testing.assert_allclose(st.flux, st_full.flux[:st.iterations], rtol=1e-12)
+
+
+def test_reconstructor_takes_a_measured_psf_through_the_fourier_domain(device, tmp_path):
+    """DeconvolveSettings.psf_path with a bead patch of the size scripts/measure_psf.py:187-190 cuts (15 x 18 x 18:
+    even extents are padded to odd): the pipeline object plans the Fourier-domain iteration and its output is the
+    oracle's chain."""
+    from shrimpy_amd.pipeline import VolumeReconstructor
+    from shrimpy_amd.settings import DeconvolveSettings, DeskewSettings, ReconstructSettings
+
+    patch = _measured_like_psf((15, 19, 19), 5)[:, :18, :18]
+    patch = (patch / patch.sum()).astype(np.float32)
+    np.save(tmp_path / "beads.npy", patch)
+    raw = o.bead_scene((40, 12, 16), seed=9, psf=None, density=5e-3)
+    desk = DeskewSettings(pixel_size_um=0.1133, ls_angle_deg=30.0, scan_step_um=0.15, keep_overhang=False, average_n_slices=3)
+    settings = ReconstructSettings(deskew=desk, deconvolution=DeconvolveSettings(psf_path=str(tmp_path / "beads.npy"), iterations=4))
+    rec = VolumeReconstructor(raw.shape, settings, device)
+    assert rec._plan.path == "fft" and rec._plan.psf.shape == (15, 19, 19)
+    got = rec(raw).cpu().numpy()
+    ref = o.richardson_lucy(o.deskew(raw, 30.0, 0.755, False, 3), np.pad(patch, ((0, 0), (0, 1), (0, 1))), 4)
+    assert got.shape == ref.shape
+    _close(got, ref, 2e-4, 1e-4)
 
 
 def test_correlate_z_entry_against_scipy_on_ragged_and_strided_volumes(device):

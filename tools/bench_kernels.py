@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--only-affine", action="store_true", help="only the affine apply section")
     ap.add_argument("--rl-grid", default="171,2048,2270", help="Z,Y,X of the RL launch section")
     ap.add_argument("--psf-sweep", action="store_true", help="only: ms per RL iteration over separable PSF sizes")
+    ap.add_argument("--rl-fft", action="store_true", help="only: ms per RL iteration in the Fourier domain (dense PSFs "
+                    "beyond the stencil kernels) next to the generic / dense stencils where they exist")
     ap.add_argument("--psf-sweep-wide", action="store_true", help="with --psf-sweep: every pz for in-plane extents 9-15")
     args = ap.parse_args()
 
@@ -54,6 +56,9 @@ def main():
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(3)
 
+    if args.rl_fft:
+        _rl_fft(args, torch, dev, g, tuple(int(v) for v in args.rl_grid.split(",")))
+        return
     if args.psf_sweep:
         _psf_sweep(args, torch, dev, g, RichardsonLucyPlan, tuple(int(v) for v in args.rl_grid.split(",")))
         return
@@ -270,6 +275,40 @@ def _psf_sweep(args, torch, dev, g, RichardsonLucyPlan, oshape):
                               "frac_of_8TBps": 12.0 * y.numel() / ms / 1e6 / 8000}), flush=True)
             if fused == "auto" and path != "fused":
                 break      # (the two-launch form was what ran)
+
+
+def _rl_fft(args, torch, dev, g, oshape):
+    """ms per RL iteration with both convolutions in the Fourier domain (shrimpy_amd/deconvolve_fft.py), over dense PSF
+    extents from the stencil kernels' range to a measured bead patch; the stencil route beside it where one exists."""
+    from shrimpy_amd.deconvolve import make_plan
+
+    y = torch.poisson(torch.full(oshape, 100.0, device=dev), generator=g)
+    rng = np.random.default_rng(4)
+    for size in [(9, 7, 7), (11, 9, 9), (13, 13, 13), (15, 15, 15), (15, 19, 19), (21, 15, 15), (31, 37, 19)]:
+        zz, yy, xx = np.meshgrid(*[np.arange(n) - n // 2 for n in size], indexing="ij")
+        zr, xr = 0.9 * zz + 0.43 * xx, -0.43 * zz + 0.9 * xx
+        w = np.exp(-0.5 * ((zr / (size[0] / 5)) ** 2 + (yy / (size[1] / 5)) ** 2 + (xr / (size[2] / 5)) ** 2))
+        w = (w * (1 + 0.02 * rng.standard_normal(size))).clip(0).astype(np.float32)
+        w /= w.sum()
+        for method in ("fft", "direct"):
+            if method == "direct" and (max(size) > 15 or size[0] * size[1] * size[2] > 2200):
+                continue      # (refused by the stencil plan / minutes per iteration through the generic stencil)
+            plan = make_plan(oshape, w, dev, separable="never", method=method)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            plan(y, iterations=1)
+            torch.cuda.synchronize()
+            iters = 3 if plan.path != "generic" else 1
+            plan(y, iterations=iters, events=ev)
+            torch.cuda.synchronize()
+            ms = ev[0].elapsed_time(ev[1]) / iters
+            row = {"kernel": "RL iteration, dense PSF", "psf": list(size), "method": method, "path": plan.path, "grid": oshape,
+                   "ms_per_iteration": ms}
+            if plan.path == "fft":
+                row["fft_grid"] = list(plan.grid)
+            plan.release()
+            del plan
+            torch.cuda.empty_cache()
+            print(json.dumps(row), flush=True)
 
 
 if __name__ == "__main__":
