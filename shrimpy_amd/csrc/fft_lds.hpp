@@ -40,6 +40,28 @@ __device__ __forceinline__ float2 cconj(float2 a) { return float2{a.x, -a.y}; }
 __device__ __forceinline__ float2 mul_mi(float2 a) { return float2{a.y, -a.x}; }   // a * (-i)
 __device__ __forceinline__ float2 mul_i(float2 a) { return float2{-a.y, a.x}; }    // a * i
 
+// A strided loop whose iterations begin with a global load: U loads are issued before the first one is used.  Written
+// as a plain loop, hipcc waits for each iteration's load before it issues the next -- ONE load in flight per wave, and
+// the kernels around these transforms spent most of their time in exactly that (round 4: s_waitcnt vmcnt(0) inside every
+// tile-load, twiddle and epilogue loop of rfft_rows.hip / zcorr.hip).  `load(j)` must be valid for every j the loop
+// visits; the unused slots of the last batch re-read its last index.
+template <int U, typename L, typename S>
+__device__ __forceinline__ void batched_loop(int first, int end, int step, L&& load, S&& use) {
+  for (int i = first; i < end; i += U * step) {
+    decltype(load(0)) v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = i + u * step;
+      v[u] = load(j < end ? j : end - 1);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = i + u * step;
+      if (j < end) use(j, v[u]);
+    }
+  }
+}
+
 // DFT of R points, forward sign
 template <int R>
 __device__ __forceinline__ void dft(float2 (&a)[R]) {

@@ -93,6 +93,16 @@ __device__ __forceinline__ float2 tw_m(const float2* tw, int half, int i) {
   return hi ? float2{-v.x, -v.y} : v;
 }
 
+// Workgroups b, b + 8, ... land on the same XCD (round-robin dispatch).  Neighbouring y tiles share every 128-byte
+// line of the transposed spectrum (64-byte runs each): each XCD takes a CONTIGUOUS run of the tile order, so that the
+// two halves of a line meet in one L2 instead of being fetched from HBM by two.  Grid = 8 * ceil(tiles / 8).
+__device__ __forceinline__ int xcd_tile(int n_tiles, int block) {
+  const int per = (n_tiles + 7) >> 3;
+  const int t = (block & 7) * per + (block >> 3);
+  return t < n_tiles ? t : -1;
+}
+__host__ __device__ inline unsigned xcd_grid(int64_t n_tiles) { return static_cast<unsigned>(8 * ((n_tiles + 7) / 8)); }
+
 // ZERO: the source sits at the grid's origin, zeros behind it (no index map)
 template <bool ZERO>
 __global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
@@ -101,7 +111,35 @@ __global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
   const Tile t = carve(smem, M);
   const int tid = threadIdx.x;
   const int tiles_y = (p.Y + kRows - 1) / kRows;
-  const int z = blockIdx.x / tiles_y, y0 = (blockIdx.x - z * tiles_y) * kRows;
+  int z, y0;
+  if constexpr (ZERO) {
+    // tiles that hold source rows first, in XCD runs; then the tiles of pure padding (they only store zeros), so
+    // that no XCD's run is mostly padding
+    const int ty_src = (p.Yi + kRows - 1) / kRows, n_src = p.Zi * ty_src;
+    const int first_pad = static_cast<int>(xcd_grid(n_src));
+    if (static_cast<int>(blockIdx.x) < first_pad) {
+      const int tile = xcd_tile(n_src, blockIdx.x);
+      if (tile < 0) return;
+      z = tile / ty_src;
+      y0 = (tile - z * ty_src) * kRows;
+    } else {
+      const int q = static_cast<int>(blockIdx.x) - first_pad, beside = tiles_y - ty_src, n_beside = p.Zi * beside;
+      if (q < n_beside) {
+        z = q / beside;
+        y0 = (ty_src + q - z * beside) * kRows;
+      } else {
+        const int r = q - n_beside;
+        z = p.Zi + r / tiles_y;
+        y0 = (r - (z - p.Zi) * tiles_y) * kRows;
+      }
+      if (z >= p.Z) return;
+    }
+  } else {
+    const int tile = xcd_tile(p.Z * tiles_y, blockIdx.x);
+    if (tile < 0) return;
+    z = tile / tiles_y;
+    y0 = (tile - z * tiles_y) * kRows;
+  }
   const int nrows = min(kRows, p.Y - y0);
 
   if constexpr (ZERO) {
@@ -120,10 +158,11 @@ __global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
     float2* row = t.buf + r * t.pitch;
     if (r < nrows && y0 + r < p.Yi) {
       const float* src = p.in + (static_cast<int64_t>(z) * p.Yi + y0 + r) * p.Xi;
-      for (int m = lane; m < M; m += kPerRow) {
-        const int x0 = 2 * m;
-        row[m] = float2{x0 < p.Xi ? src[x0] : 0.0f, x0 + 1 < p.Xi ? src[x0 + 1] : 0.0f};
-      }
+      const int last = p.Xi - 1, n_src = (p.Xi + 1) / 2;      // packed pairs that touch the source
+      batched_loop<8>(lane, n_src, kPerRow,
+                      [src, last](int m) { return float2{src[2 * m], src[min(2 * m + 1, last)]}; },
+                      [row, last](int m, float2 v) { row[m] = float2{v.x, 2 * m + 1 <= last ? v.y : 0.0f}; });
+      for (int m = lane + ((n_src - lane + kPerRow - 1) / kPerRow) * kPerRow; m < M; m += kPerRow) row[m] = float2{0.0f, 0.0f};
     } else {
       for (int m = lane; m < M; m += kPerRow) row[m] = float2{0.0f, 0.0f};
     }
@@ -133,11 +172,14 @@ __global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
     if (r < nrows) {
       const float* src = p.in + (static_cast<int64_t>(match_index(z, p.Zi, p.Z)) * p.Yi + match_index(y0 + r, p.Yi, p.Y)) * p.Xi;
       const int shift = p.X > p.Xi ? -((p.X - p.Xi) / 2) : (p.Xi - p.X) / 2;   // source column of grid column 0 (before reflection)
-      for (int m = lane; m < M; m += kPerRow) {
-        const int x0 = 2 * m + shift, x1 = x0 + 1;
-        const bool inside = x0 >= 0 && x1 < p.Xi;
-        row[m] = float2{src[inside ? x0 : reflect_index(x0, p.Xi)], src[inside ? x1 : reflect_index(x1, p.Xi)]};
-      }
+      const int xi = p.Xi;
+      batched_loop<8>(lane, M, kPerRow,
+                      [src, shift, xi](int m) {
+                        const int x0 = 2 * m + shift, x1 = x0 + 1;
+                        const bool inside = x0 >= 0 && x1 < xi;
+                        return float2{src[inside ? x0 : reflect_index(x0, xi)], src[inside ? x1 : reflect_index(x1, xi)]};
+                      },
+                      [row](int m, float2 v) { row[m] = v; });
     } else {
       for (int m = lane; m < M; m += kPerRow) row[m] = float2{0.0f, 0.0f};
     }
@@ -155,13 +197,52 @@ __global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
   if (r < nrows) {
     const float2* row = t.buf + r * t.pitch;
     float2* out = p.spec + static_cast<int64_t>(z) * p.XC * p.Y + y0 + r;
-    for (int k = k0; k <= M; k += kThreads / kRows) {
-      const float2 a = row[k == M ? 0 : k], b = cconj(row[k == 0 ? 0 : M - k]);
-      const float2 e = float2{0.5f * (a.x + b.x), 0.5f * (a.y + b.y)};
-      const float2 o = mul_mi(float2{0.5f * (a.x - b.x), 0.5f * (a.y - b.y)});
-      out[static_cast<int64_t>(k) * p.Y] = cadd(e, cmul(p.tw_x[k], o));
-    }
+    const float2* twx = p.tw_x;
+    const int64_t ystride = p.Y;
+    batched_loop<8>(k0, M + 1, kThreads / kRows, [twx](int k) { return twx[k]; },
+                    [row, out, M, ystride](int k, float2 w) {
+                      const float2 a = row[k == M ? 0 : k], b = cconj(row[k == 0 ? 0 : M - k]);
+                      const float2 e = float2{0.5f * (a.x + b.x), 0.5f * (a.y + b.y)};
+                      const float2 o = mul_mi(float2{0.5f * (a.x - b.x), 0.5f * (a.y - b.y)});
+                      out[static_cast<int64_t>(k) * ystride] = cadd(e, cmul(w, o));
+                    });
   }
+}
+
+// Tile of the spectrum for the inverse kernels: X[k], k = 0 .. M, of eight neighbouring y (64-byte runs); rows at or
+// past `y_end` are zeros.
+__device__ __forceinline__ void load_spectrum_tile(const RowsArgs& p, const Tile& t, int z, int y0, int y_end, int tid) {
+  const int M = p.M;
+  const int r = tid & (kRows - 1), k0 = tid / kRows;
+  float2* row = t.buf + r * t.pitch;
+  if (y0 + r < y_end) {
+    const float2* in = p.spec + static_cast<int64_t>(z) * p.XC * p.Y + y0 + r;
+    const int64_t ystride = p.Y;
+    batched_loop<10>(k0, M + 1, kThreads / kRows, [in, ystride](int k) { return in[static_cast<int64_t>(k) * ystride]; },
+                     [row](int k, float2 v) { row[k] = v; });
+  } else {
+    for (int k = k0; k <= M; k += kThreads / kRows) row[k] = float2{0.0f, 0.0f};
+  }
+}
+
+// complex-to-real pre step, pairs (m, M - m) by one thread; conjugated on the way for the conj-FFT-conj inverse:
+//   Zt[m] = (X[m] + conj(X[M - m])) + i conj(w_X^m) (X[m] - conj(X[M - m]))        (= 2 x the packed signal's spectrum)
+__device__ __forceinline__ void c2r_pre_step(const RowsArgs& p, const Tile& t, int tid) {
+  const int M = p.M, half = M / 2;
+  const int r = tid / kPerRow, lane = tid & (kPerRow - 1);
+  float2* row = t.buf + r * t.pitch;
+  const float2* twx = p.tw_x;
+  struct Pair { float2 a, b; };
+  batched_loop<5>(lane, half + 1, kPerRow, [twx, M](int m) { return Pair{twx[m], twx[M - m]}; },
+                  [row, M](int m, Pair w) {
+                    const int mm = M - m;                       // partner; m == 0 pairs with X[M], m == M / 2 with itself
+                    const float2 xa = row[m], xb = row[mm];
+                    const float2 wa = cconj(w.a), wb = cconj(w.b);
+                    const float2 za = cadd(cadd(xa, cconj(xb)), mul_i(cmul(wa, csub(xa, cconj(xb)))));
+                    const float2 zb = cadd(cadd(xb, cconj(xa)), mul_i(cmul(wb, csub(xb, cconj(xa)))));
+                    row[m] = cconj(za);
+                    if (m != 0 && mm != m) row[mm] = cconj(zb);
+                  });
 }
 
 __device__ __forceinline__ void peak_merge(float& v, unsigned long long& i, float v2, unsigned long long i2) {
@@ -181,28 +262,9 @@ __global__ __launch_bounds__(kThreads) void irfft_rows_peak_kernel(RowsArgs p) {
   const int nrows = min(kRows, p.Y - y0);
 
   for (int k = tid; k < half; k += kThreads) t.tw[k] = p.tw_half[k];
-  {  // tile of the spectrum: X[k], k = 0 .. M, for eight neighbouring y (64-byte runs)
-    const int r = tid & (kRows - 1), k0 = tid / kRows;
-    float2* row = t.buf + r * t.pitch;
-    const float2* in = p.spec + static_cast<int64_t>(z) * p.XC * p.Y + y0 + r;
-    for (int k = k0; k <= M; k += kThreads / kRows)
-      row[k] = r < nrows ? in[static_cast<int64_t>(k) * p.Y] : float2{0.0f, 0.0f};
-  }
+  load_spectrum_tile(p, t, z, y0, p.Y, tid);
   __syncthreads();
-  {  // complex-to-real pre step, pairs (m, M - m) by one thread; conjugated on the way for the conj-FFT-conj inverse:
-     //   Zt[m] = (X[m] + conj(X[M - m])) + i conj(w_X^m) (X[m] - conj(X[M - m]))        (= 2 x the packed signal's spectrum)
-    const int r = tid / kPerRow, lane = tid & (kPerRow - 1);
-    float2* row = t.buf + r * t.pitch;
-    for (int m = lane; m <= half; m += kPerRow) {
-      const int mm = M - m;                       // partner; m == 0 pairs with X[M], m == M / 2 with itself
-      const float2 xa = row[m], xb = row[mm];
-      const float2 wa = cconj(p.tw_x[m]), wb = cconj(p.tw_x[mm]);
-      const float2 za = cadd(cadd(xa, cconj(xb)), mul_i(cmul(wa, csub(xa, cconj(xb)))));
-      const float2 zb = cadd(cadd(xb, cconj(xa)), mul_i(cmul(wb, csub(xb, cconj(xa)))));
-      row[m] = cconj(za);
-      if (m != 0 && mm != m) row[mm] = cconj(zb);
-    }
-  }
+  c2r_pre_step(p, t, tid);
   __syncthreads();
 
   const float2* twl = t.tw;
@@ -268,33 +330,17 @@ __global__ __launch_bounds__(kThreads) void irfft_rows_rl_kernel(RowsArgs p) {
   const int M = p.M, half = M / 2;
   const Tile t = carve(smem, M);
   const int tid = threadIdx.x;
-  const int tiles_y = (p.Y + kRows - 1) / kRows;
-  const int z = blockIdx.x / tiles_y, y0 = (blockIdx.x - z * tiles_y) * kRows;
-  if (z >= p.Zo || y0 >= p.Yo) return;   // (uniform)
+  // only the tiles that hold rows of the volume are launched (the padding planes and rows are never read)
+  const int ty_out = (p.Yo + kRows - 1) / kRows;
+  const int tile = xcd_tile(p.Zo * ty_out, blockIdx.x);
+  if (tile < 0) return;
+  const int z = tile / ty_out, y0 = (tile - z * ty_out) * kRows;
   const int nrows = min(kRows, p.Yo - y0);
 
   for (int k = tid; k < half; k += kThreads) t.tw[k] = p.tw_half[k];
-  {
-    const int r = tid & (kRows - 1), k0 = tid / kRows;
-    float2* row = t.buf + r * t.pitch;
-    const float2* in = p.spec + static_cast<int64_t>(z) * p.XC * p.Y + y0 + r;
-    for (int k = k0; k <= M; k += kThreads / kRows)
-      row[k] = y0 + r < p.Y ? in[static_cast<int64_t>(k) * p.Y] : float2{0.0f, 0.0f};
-  }
+  load_spectrum_tile(p, t, z, y0, p.Y, tid);
   __syncthreads();
-  {  // complex-to-real pre step (as irfft_rows_peak_kernel)
-    const int r = tid / kPerRow, lane = tid & (kPerRow - 1);
-    float2* row = t.buf + r * t.pitch;
-    for (int m = lane; m <= half; m += kPerRow) {
-      const int mm = M - m;
-      const float2 xa = row[m], xb = row[mm];
-      const float2 wa = cconj(p.tw_x[m]), wb = cconj(p.tw_x[mm]);
-      const float2 za = cadd(cadd(xa, cconj(xb)), mul_i(cmul(wa, csub(xa, cconj(xb)))));
-      const float2 zb = cadd(cadd(xb, cconj(xa)), mul_i(cmul(wb, csub(xb, cconj(xa)))));
-      row[m] = cconj(za);
-      if (m != 0 && mm != m) row[mm] = cconj(zb);
-    }
-  }
+  c2r_pre_step(p, t, tid);
   __syncthreads();
 
   const float2* twl = t.tw;
@@ -313,14 +359,18 @@ __global__ __launch_bounds__(kThreads) void irfft_rows_rl_kernel(RowsArgs p) {
       float* out = p.out + base;
       const int cz = p.pz / 2, cy = p.py / 2, cx = p.px / 2;
       const bool zy_inside = z >= cz && z < p.Zo - cz && y >= cy && y < p.Yo - cy;
-      for (int m = lane; 2 * m < p.Xo; m += kPerRow) {
+      const int last = p.Xo - 1;
+      batched_loop<6>(lane, (p.Xo + 1) / 2, kPerRow,
+                      [aux, last](int m) { return float2{aux[2 * m], aux[min(2 * m + 1, last)]}; },
+                      [&](int m, float2 av) {
         const float2 c = row[m];
         const float v[2] = {c.x * p.scale, -c.y * p.scale};
+        const float a2[2] = {av.x, av.y};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int x = 2 * m + h;
           if (x < p.Xo) {
-            const float a = aux[x];
+            const float a = a2[h];
             if constexpr (EPI == LSR_EPI_RATIO) {
               out[x] = a / (fmaxf(v[h], 0.0f) + p.eps);
             } else {
@@ -332,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void irfft_rows_rl_kernel(RowsArgs p) {
             }
           }
         }
-      }
+      });
     }
   }
   if constexpr (STATS) lsr::rl_stats_flush<kThreads / 64>(stats, reinterpret_cast<float*>(smem), p.stats);
@@ -423,7 +473,7 @@ extern "C" int lsr_rfft_rows_t_c64(const float* in, int64_t Zi, int64_t Yi, int6
   p.spec = reinterpret_cast<float2*>(spec);
   static std::atomic<uint64_t> lds_allowed{0};
   if (int rc = allow_lds(rfft_rows_kernel<false>, lds_allowed, "lsr_rfft_rows_t_c64")) return rc;
-  const unsigned blocks = static_cast<unsigned>(Z * lsr::ceil_div(Y, kRows));
+  const unsigned blocks = xcd_grid(Z * lsr::ceil_div(Y, kRows));
   hipLaunchKernelGGL(rfft_rows_kernel<false>, dim3(blocks), dim3(kThreads), lds_bytes(p.M), lsr::as_stream(stream), p);
   return lsr::launch_status("lsr_rfft_rows_t_c64");
 }
@@ -464,7 +514,8 @@ extern "C" int lsr_rfft_rows_zero_t_c64(const float* in, int64_t Zi, int64_t Yi,
   p.spec = reinterpret_cast<float2*>(spec);
   static std::atomic<uint64_t> lds_allowed{0};
   if (int rc = allow_lds(rfft_rows_kernel<true>, lds_allowed, "lsr_rfft_rows_zero_t_c64")) return rc;
-  const unsigned blocks = static_cast<unsigned>(Z * lsr::ceil_div(Y, kRows));
+  const int64_t tiles = Z * lsr::ceil_div(Y, kRows), src_tiles = Zi * lsr::ceil_div(Yi, kRows);
+  const unsigned blocks = xcd_grid(src_tiles) + static_cast<unsigned>(tiles - src_tiles);
   hipLaunchKernelGGL(rfft_rows_kernel<true>, dim3(blocks), dim3(kThreads), lds_bytes(p.M), lsr::as_stream(stream), p);
   return lsr::launch_status("lsr_rfft_rows_zero_t_c64");
 }
@@ -496,7 +547,7 @@ extern "C" int lsr_irfft_rows_rl_f32(const float* spec, int64_t Z, int64_t Y, in
   p.scale = scale; p.eps = eps;
   p.pz = pz; p.py = py; p.px = px;
   p.norm_table = norm_table; p.norm_full = norm_full; p.stats = stats;
-  const unsigned blocks = static_cast<unsigned>(Z * lsr::ceil_div(Y, kRows));
+  const unsigned blocks = xcd_grid(Zo * lsr::ceil_div(Yo, kRows));
   hipStream_t s = lsr::as_stream(stream);
   static std::atomic<uint64_t> a0{0}, a1{0}, a2{0};
   if (epilogue == LSR_EPI_RATIO) {

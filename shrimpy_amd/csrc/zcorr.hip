@@ -53,8 +53,13 @@ __global__ __launch_bounds__(kThreads) void zcorr_kernel(ZcorrArgs p) {
   const int c = tid & (kCols - 1), z0 = tid / kCols;
   const int64_t row = static_cast<int64_t>(p.XC) * p.Y;
   const float2* g = p.g + static_cast<int64_t>(xc) * p.Y + y0 + c;
-  for (int z = z0; z < N; z += kThreads / kCols)
-    buf[c * pitch + z] = c < ncols ? g[z * row] : float2{0.0f, 0.0f};
+  // (batched: eleven dependent load -> LDS-store rounds per thread otherwise, one load in flight per wave)
+  if (c < ncols) {
+    float2* col = buf + c * pitch;
+    batched_loop<8>(z0, N, kThreads / kCols, [g, row](int z) { return g[z * row]; }, [col](int z, float2 v) { col[z] = v; });
+  } else {
+    for (int z = z0; z < N; z += kThreads / kCols) buf[c * pitch + z] = float2{0.0f, 0.0f};
+  }
   __syncthreads();
 
   float2* const my_col = buf + (tid / kPerCol) * pitch;      // the column this thread works on in the passes
@@ -72,12 +77,12 @@ __global__ __launch_bounds__(kThreads) void zcorr_kernel(ZcorrArgs p) {
       if (my < ncols) {
         const float2* ref = f1 + static_cast<int64_t>(my) * N;
         // (what the second transform needs is conj(v) of the product v wanted: conj(FFT(conj(v))) = N IFFT(v))
-        if (p.mode == 0)
-          for (int k = t; k < N; k += kPerCol) my_col[k] = cmul(cconj(ref[k]), my_col[k]);          // v = f1 conj(G)
-        else if (p.mode == 1)
-          for (int k = t; k < N; k += kPerCol) my_col[k] = cconj(cmul(ref[k], my_col[k]));          // v = f1 G
-        else
-          for (int k = t; k < N; k += kPerCol) my_col[k] = cmul(ref[k], cconj(my_col[k]));          // v = conj(f1) G
+        const int mode = p.mode;
+        batched_loop<8>(t, N, kPerCol, [ref](int k) { return ref[k]; }, [my_col, mode](int k, float2 f) {
+          if (mode == 0) my_col[k] = cmul(cconj(f), my_col[k]);            // v = f1 conj(G)
+          else if (mode == 1) my_col[k] = cconj(cmul(f, my_col[k]));       // v = f1 G
+          else my_col[k] = cmul(f, cconj(my_col[k]));                      // v = conj(f1) G
+        });
       }
       sequence_sync();
     }
