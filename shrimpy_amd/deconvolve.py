@@ -793,7 +793,10 @@ def make_plan(shape_zyx, psf, device, *, separable: str = "auto", separable_rtol
         if method == "direct" or psf_factors is not None or psf is None:
             raise
         refused = exc
-    if method == "direct" or (direct is not None and direct.path != "generic"):
+    # (the tuned dense stencil costs one FMA per tap: at 11 x 9 x 9 = 891 taps it is the slower route -- 26.9 against
+    # 23.1 ms per iteration on the config-2 grid, 15.2 against 23.0 ms at 9 x 7 x 7; profiles/r04_rl_fft.jsonl)
+    if method == "direct" or (direct is not None and direct.path != "generic"
+                              and not (direct.path == "dense" and int(np.prod(direct.psf.shape)) > 800)):
         return direct
     w = dense_psf()
     if fft_supported(shape_zyx, w.shape):
