@@ -201,7 +201,10 @@ def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=Non
                 or max(len(factors[1]), len(factors[2])) > MAX_TAPS):
             raise ValueError("psf_factors must be three odd-length 1-D kernels (<= 31 taps along z, <= 15 in plane)")
     else:
-        w = prepare_psf(psf)
+        # (up to the extents the device takes through the Fourier domain: the loops below take any count)
+        from .deconvolve_fft import MAX_FFT_TAPS
+
+        w = prepare_psf(psf, MAX_FFT_TAPS, MAX_FFT_TAPS)
         if separable != "never":
             factors = factor_psf(w, separable_rtol)
             if factors is None and separable == "force":

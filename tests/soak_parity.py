@@ -224,6 +224,25 @@ def main():
         ok = plan.path.startswith("separable (long z") and bool(np.all(np.abs(got - want) <= 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max()))
         return ok, (pshape, vshape, iters)
 
+    def rl_fft_case(r):
+        """Dense random PSFs of any odd extents through the Fourier-domain iteration against the oracle's direct stencil,
+        reduction scalars included; volumes thinner than the PSF, odd widths."""
+        from shrimpy_amd.deconvolve import make_plan
+
+        pshape = tuple(int(v) for v in r.choice([1, 3, 5, 7, 9, 11, 13, 17, 21, 25], 3))
+        vshape = (int(r.integers(1, 40)), int(r.integers(1, 50)), int(r.integers(1, 120)))
+        w = np.abs(r.normal(1.0, 0.5, pshape)).astype(np.float32) + 0.02
+        w /= w.sum()
+        y = (r.random(vshape) * 80 + 1).astype(np.float32)
+        plan = make_plan(vshape, w, dev, method="fft")
+        iters = int(r.integers(1, 4))
+        got = plan(t(y), iterations=iters, stats=True).cpu().numpy().astype(np.float64)
+        want = o.richardson_lucy(y, w, iterations=iters).astype(np.float64)
+        ok = plan.path == "fft" and bool(np.all(np.abs(got - want) <= 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max()))
+        ref = o.rl_iteration_scalars(y, w, iters)
+        ok = ok and all(np.allclose(getattr(plan.last_stats, k), ref[k], rtol=2e-5) for k in ("flux", "change", "total"))
+        return ok, (pshape, vshape, iters)
+
     def host_twin_case(r):
         """CPU tensors through the public functions (csrc/host_twins.hip) against the device kernels: same bits."""
         from shrimpy_amd.flatfield import flat_field_pattern as ffp
@@ -283,7 +302,7 @@ def main():
 
     families = {"deskew": deskew_case, "affine": affine_case, "rl": rl_case, "flatfield": flat_case,
                 "blur": blur_case, "estimators": estimator_case, "rl_ysep": rl_ysep_case, "host_twins": host_twin_case,
-                "rl_stats": rl_stats_case, "rl_long_z": rl_long_z_case}
+                "rl_stats": rl_stats_case, "rl_long_z": rl_long_z_case, "rl_fft": rl_fft_case}
     if args.only:
         families = {k: v for k, v in families.items() if k in args.only.split(",")}
     if args.large:

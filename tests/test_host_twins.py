@@ -124,6 +124,12 @@ def test_richardson_lucy_on_a_cpu_tensor_meets_the_rl_bar(golden_dir):
     _rl_close(richardson_lucy(_t(y), psf_factors=factors, iterations=4).numpy(),
               o.richardson_lucy_separable(y, factors, iterations=4))
     assert not richardson_lucy(_t(np.zeros((6, 8, 8), np.float32)), psf, iterations=3).numpy().any()
+    # a dense PSF beyond the stencil kernels' 15 taps (on a device: the Fourier-domain iteration; here the twins' dense loop)
+    rng = np.random.default_rng(5)
+    wide = (np.abs(rng.normal(1.0, 0.4, (17, 5, 19))) + 0.05).astype(np.float32)
+    wide /= wide.sum()
+    ys = o.bead_scene((6, 9, 12), seed=4, psf=None, density=2e-2)
+    _rl_close(richardson_lucy(_t(ys), wide, iterations=3).numpy(), o.richardson_lucy(ys, wide, iterations=3))
     # the building block is scipy's correlate(mode="constant")
     from scipy import ndimage
 
