@@ -569,12 +569,20 @@ int lsr_irfft_rows_peak(const float* spec, int64_t Z, int64_t Y, int64_t X, cons
  *                     (px+1) prefix sums of the PSF, float64, device) within a PSF radius of the border; stats = 3 doubles
  *                     the launch ADDS the iteration's flux / change / total to (as lsr_correlate_*_stats_f32) or NULL.
  *   out may be aux (in place).  The convolved volume is never written.
+ * lsr_rl_rows_chain_f32: the same, CHAINED into the forward x leg of the iteration's next convolution: the epilogue's
+ *   output row is zero-padded, transformed and stored back over its tile of `spec`, which afterwards holds what
+ *   lsr_rfft_rows_zero_t_c64(out) would have produced (tiles of pure padding: zeros).  LSR_EPI_RATIO: `out` may be NULL --
+ *   the ratio then never exists in memory; LSR_EPI_UPDATE stores x_new once and nobody reads it back for the transform.
  */
 int lsr_rfft_rows_zero_t_c64(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* spec, int64_t Z, int64_t Y,
                              int64_t X, const float* tw_half, const float* tw_x, lsr_stream_t stream);
 int lsr_spectrum_multiply_z_c64(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC,
                                 int conj_f1, lsr_stream_t stream);
 int lsr_irfft_rows_rl_f32(const float* spec, int64_t Z, int64_t Y, int64_t X, const float* tw_half, const float* tw_x,
+                          int epilogue, const float* aux, float* out, int64_t Zo, int64_t Yo, int64_t Xo, float scale,
+                          float eps, int pz, int py, int px, const double* norm_table, float norm_full, double* stats,
+                          lsr_stream_t stream);
+int lsr_rl_rows_chain_f32(float* spec, int64_t Z, int64_t Y, int64_t X, const float* tw_half, const float* tw_x,
                           int epilogue, const float* aux, float* out, int64_t Zo, int64_t Yo, int64_t Xo, float scale,
                           float eps, int pz, int py, int px, const double* norm_table, float norm_full, double* stats,
                           lsr_stream_t stream);

@@ -77,6 +77,8 @@ SIGNATURES: dict[str, list] = {
     "lsr_spectrum_multiply_z_c64": [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _int, _stream],
     "lsr_irfft_rows_rl_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _c_f32p, _c_f32p, _i64, _i64, _i64, _f32,
                               _f32, _int, _int, _int, ctypes.c_void_p, _f32, ctypes.c_void_p, _stream],
+    "lsr_rl_rows_chain_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _c_f32p, _c_f32p, _i64, _i64, _i64, _f32,
+                              _f32, _int, _int, _int, ctypes.c_void_p, _f32, ctypes.c_void_p, _stream],
     "lsr_cross_correlate_z_supported": [_i64],
     "lsr_cross_correlate_z_c64": [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _stream],
     "lsr_transpose_last2_c64": [_c_f32p, _c_f32p, _i64, _i64, _i64, _stream],

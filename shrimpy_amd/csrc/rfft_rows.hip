@@ -103,6 +103,35 @@ __device__ __forceinline__ int xcd_tile(int n_tiles, int block) {
 }
 __host__ __device__ inline unsigned xcd_grid(int64_t n_tiles) { return static_cast<unsigned>(8 * ((n_tiles + 7) / 8)); }
 
+// A tile of zeros in the transposed spectrum (rows y0 .. y0 + nrows - 1 of plane z).
+__device__ __forceinline__ void store_zero_tile(const RowsArgs& p, int z, int y0, int nrows, int tid) {
+  const int r = tid & (kRows - 1), k0 = tid / kRows;
+  if (r < nrows) {
+    float2* out = p.spec + static_cast<int64_t>(z) * p.XC * p.Y + y0 + r;
+    for (int k = k0; k <= p.M; k += kThreads / kRows) out[static_cast<int64_t>(k) * p.Y] = float2{0.0f, 0.0f};
+  }
+}
+
+// real-to-complex post step of the transformed tile, stored transposed: X[k] = E[k] + w_X^k O[k],
+//   E = (Z[k] + conj(Z[M - k])) / 2,  O = -i (Z[k] - conj(Z[M - k])) / 2,  Z[M] = Z[0]
+__device__ __forceinline__ void r2c_post_store(const RowsArgs& p, const Tile& t, int z, int y0, int nrows, int tid) {
+  const int M = p.M;
+  const int r = tid & (kRows - 1), k0 = tid / kRows;
+  if (r < nrows) {
+    const float2* row = t.buf + r * t.pitch;
+    float2* out = p.spec + static_cast<int64_t>(z) * p.XC * p.Y + y0 + r;
+    const float2* twx = p.tw_x;
+    const int64_t ystride = p.Y;
+    batched_loop<8>(k0, M + 1, kThreads / kRows, [twx](int k) { return twx[k]; },
+                    [row, out, M, ystride](int k, float2 w) {
+                      const float2 a = row[k == M ? 0 : k], b = cconj(row[k == 0 ? 0 : M - k]);
+                      const float2 e = float2{0.5f * (a.x + b.x), 0.5f * (a.y + b.y)};
+                      const float2 o = mul_mi(float2{0.5f * (a.x - b.x), 0.5f * (a.y - b.y)});
+                      out[static_cast<int64_t>(k) * ystride] = cadd(e, cmul(w, o));
+                    });
+  }
+}
+
 // ZERO: the source sits at the grid's origin, zeros behind it (no index map)
 template <bool ZERO>
 __global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
@@ -144,11 +173,7 @@ __global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
 
   if constexpr (ZERO) {
     if (z >= p.Zi || y0 >= p.Yi) {   // (uniform) a tile of padding: its spectrum is zero
-      const int r = tid & (kRows - 1), k0 = tid / kRows;
-      if (r < nrows) {
-        float2* out = p.spec + static_cast<int64_t>(z) * p.XC * p.Y + y0 + r;
-        for (int k = k0; k <= M; k += kThreads / kRows) out[static_cast<int64_t>(k) * p.Y] = float2{0.0f, 0.0f};
-      }
+      store_zero_tile(p, z, y0, nrows, tid);
       return;
     }
   }
@@ -191,22 +216,7 @@ __global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
                             tid & (kPerRow - 1));
 
   __syncthreads();            // the post step below reads rows across wavefronts
-  // real-to-complex post step, stored transposed: X[k] = E[k] + w_X^k O[k],
-  //   E = (Z[k] + conj(Z[M - k])) / 2,  O = -i (Z[k] - conj(Z[M - k])) / 2,  Z[M] = Z[0]
-  const int r = tid & (kRows - 1), k0 = tid / kRows;
-  if (r < nrows) {
-    const float2* row = t.buf + r * t.pitch;
-    float2* out = p.spec + static_cast<int64_t>(z) * p.XC * p.Y + y0 + r;
-    const float2* twx = p.tw_x;
-    const int64_t ystride = p.Y;
-    batched_loop<8>(k0, M + 1, kThreads / kRows, [twx](int k) { return twx[k]; },
-                    [row, out, M, ystride](int k, float2 w) {
-                      const float2 a = row[k == M ? 0 : k], b = cconj(row[k == 0 ? 0 : M - k]);
-                      const float2 e = float2{0.5f * (a.x + b.x), 0.5f * (a.y + b.y)};
-                      const float2 o = mul_mi(float2{0.5f * (a.x - b.x), 0.5f * (a.y - b.y)});
-                      out[static_cast<int64_t>(k) * ystride] = cadd(e, cmul(w, o));
-                    });
-  }
+  r2c_post_store(p, t, z, y0, nrows, tid);
 }
 
 // Tile of the spectrum for the inverse kernels: X[k], k = 0 .. M, of eight neighbouring y (64-byte runs); rows at or
@@ -324,17 +334,39 @@ __device__ __forceinline__ float rl_border_norm(const RowsArgs& p, int z, int y,
 //                                                                  negative where H x is 0: clamped, H x >= 0)
 //   EPI = LSR_EPI_UPDATE:  out = aux * v / H^T 1                  (aux = x; STATS: the iteration's three sums)
 // Tiles past the volume (the padding planes and rows of the grid) are not even loaded.
-template <int EPI, bool STATS>
+// CHAIN: the epilogue's output row goes straight back through the FORWARD x leg (zero padding, transform, post step)
+// and replaces the tile of the spectrum it came from: what the next convolution of the iteration starts from.  The
+// ratio then never exists in memory at all (p.out may be NULL), x_new is stored once and not read again by a separate
+// forward launch; the tiles of pure padding, which the unchained kernel does not even launch, store zeros.
+template <int EPI, bool STATS, bool CHAIN = false>
 __global__ __launch_bounds__(kThreads) void irfft_rows_rl_kernel(RowsArgs p) {
   extern __shared__ float2 smem[];
   const int M = p.M, half = M / 2;
   const Tile t = carve(smem, M);
   const int tid = threadIdx.x;
-  // only the tiles that hold rows of the volume are launched (the padding planes and rows are never read)
-  const int ty_out = (p.Yo + kRows - 1) / kRows;
-  const int tile = xcd_tile(p.Zo * ty_out, blockIdx.x);
-  if (tile < 0) return;
-  const int z = tile / ty_out, y0 = (tile - z * ty_out) * kRows;
+  // only the tiles that hold rows of the volume are transformed (the padding planes and rows are never read)
+  const int ty_out = (p.Yo + kRows - 1) / kRows, n_out = p.Zo * ty_out;
+  int z, y0;
+  if (!CHAIN || static_cast<int>(blockIdx.x) < static_cast<int>(xcd_grid(n_out))) {
+    const int tile = xcd_tile(n_out, blockIdx.x);
+    if (tile < 0) return;
+    z = tile / ty_out;
+    y0 = (tile - z * ty_out) * kRows;
+  } else {   // CHAIN: a tile of padding beside or behind the volume (dealt as in rfft_rows_kernel<true>)
+    const int tiles_y = (p.Y + kRows - 1) / kRows;
+    const int q = static_cast<int>(blockIdx.x) - static_cast<int>(xcd_grid(n_out)), beside = tiles_y - ty_out;
+    const int n_beside = p.Zo * beside;
+    if (q < n_beside) {
+      z = q / beside;
+      y0 = (ty_out + q - z * beside) * kRows;
+    } else {
+      const int r = q - n_beside;
+      z = p.Zo + r / tiles_y;
+      y0 = (r - (z - p.Zo) * tiles_y) * kRows;
+    }
+    if (z < p.Z) store_zero_tile(p, z, y0, min(kRows, p.Y - y0), tid);
+    return;
+  }
   const int nrows = min(kRows, p.Yo - y0);
 
   for (int k = tid; k < half; k += kThreads) t.tw[k] = p.tw_half[k];
@@ -352,11 +384,11 @@ __global__ __launch_bounds__(kThreads) void irfft_rows_rl_kernel(RowsArgs p) {
   {
     const int r = tid / kPerRow, lane = tid & (kPerRow - 1);
     if (r < nrows) {
-      const float2* row = t.buf + r * t.pitch;
+      float2* row = t.buf + r * t.pitch;
       const int y = y0 + r;
       const int64_t base = (static_cast<int64_t>(z) * p.Yo + y) * p.Xo;
       const float* aux = p.aux + base;
-      float* out = p.out + base;
+      float* out = p.out == nullptr ? nullptr : p.out + base;
       const int cz = p.pz / 2, cy = p.py / 2, cx = p.px / 2;
       const bool zy_inside = z >= cz && z < p.Zo - cz && y >= cy && y < p.Yo - cy;
       const int last = p.Xo - 1;
@@ -366,24 +398,41 @@ __global__ __launch_bounds__(kThreads) void irfft_rows_rl_kernel(RowsArgs p) {
         const float2 c = row[m];
         const float v[2] = {c.x * p.scale, -c.y * p.scale};
         const float a2[2] = {av.x, av.y};
+        float res[2] = {0.0f, 0.0f};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int x = 2 * m + h;
           if (x < p.Xo) {
             const float a = a2[h];
             if constexpr (EPI == LSR_EPI_RATIO) {
-              out[x] = a / (fmaxf(v[h], 0.0f) + p.eps);
+              res[h] = a / (fmaxf(v[h], 0.0f) + p.eps);
+              if (!CHAIN || out != nullptr) out[x] = res[h];
             } else {
               const float nrm = (zy_inside && x >= cx && x < p.Xo - cx) ? p.norm_full : rl_border_norm(p, z, y, x);
               const float xu = a * v[h];
-              const float xn = xu / nrm;
-              out[x] = xn;
-              if constexpr (STATS) stats.add(a, xu, xn);
+              res[h] = xu / nrm;
+              out[x] = res[h];
+              if constexpr (STATS) stats.add(a, xu, res[h]);
             }
           }
         }
+        if constexpr (CHAIN) row[m] = float2{res[0], res[1]};     // the packed (even, odd) samples of the forward leg
       });
+      if constexpr (CHAIN) {   // zero padding behind the row
+        const int n_src = (p.Xo + 1) / 2;
+        for (int m = lane + ((n_src - lane + kPerRow - 1) / kPerRow) * kPerRow; m < M; m += kPerRow) row[m] = float2{0.0f, 0.0f};
+      }
+    } else if constexpr (CHAIN) {   // a row of the tile past the volume: padding
+      float2* row = t.buf + r * t.pitch;
+      for (int m = lane; m < M; m += kPerRow) row[m] = float2{0.0f, 0.0f};
     }
+  }
+  if constexpr (CHAIN) {
+    __syncthreads();
+    transform<kMaxM, kPerRow>(t.buf + (tid / kPerRow) * t.pitch, M, p.f, [twl, half](int i) { return tw_m(twl, half, i); },
+                              tid & (kPerRow - 1));
+    __syncthreads();
+    r2c_post_store(p, t, z, y0, min(kRows, p.Y - y0), tid);
   }
   if constexpr (STATS) lsr::rl_stats_flush<kThreads / 64>(stats, reinterpret_cast<float*>(smem), p.stats);
 }
@@ -561,4 +610,51 @@ extern "C" int lsr_irfft_rows_rl_f32(const float* spec, int64_t Z, int64_t Y, in
     hipLaunchKernelGGL((irfft_rows_rl_kernel<LSR_EPI_UPDATE, true>), dim3(blocks), dim3(kThreads), lds_bytes(p.M), s, p);
   }
   return lsr::launch_status("lsr_irfft_rows_rl_f32");
+}
+
+// As lsr_irfft_rows_rl_f32, CHAINED into the forward x leg of the next convolution: the epilogue's output (zero-padded
+// to the grid) is transformed and stored back over `spec`, which afterwards holds what lsr_rfft_rows_zero_t_c64 would
+// have produced from `out`.  LSR_EPI_RATIO: `out` may be NULL (the ratio is then never written).
+extern "C" int lsr_rl_rows_chain_f32(float* spec, int64_t Z, int64_t Y, int64_t X, const float* tw_half, const float* tw_x,
+                                     int epilogue, const float* aux, float* out, int64_t Zo, int64_t Yo, int64_t Xo,
+                                     float scale, float eps, int pz, int py, int px, const double* norm_table,
+                                     float norm_full, double* stats, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(spec);
+  LSR_REQUIRE_PTR(aux);
+  LSR_REQUIRE(epilogue == LSR_EPI_RATIO || epilogue == LSR_EPI_UPDATE, LSR_E_ARG,
+              "epilogue must be LSR_EPI_RATIO or LSR_EPI_UPDATE, got %d", epilogue);
+  if (epilogue == LSR_EPI_UPDATE) LSR_REQUIRE_PTR(out);
+  LSR_REQUIRE(Zo > 0 && Yo > 0 && Xo > 0 && Zo <= Z && Yo <= Y && Xo <= X, LSR_E_SHAPE,
+              "the volume (%lld,%lld,%lld) must be positive and fit the grid (%lld,%lld,%lld)", (long long)Zo, (long long)Yo,
+              (long long)Xo, (long long)Z, (long long)Y, (long long)X);
+  LSR_REQUIRE(scale > 0.0f && eps > 0.0f, LSR_E_ARG, "scale and eps must be positive");
+  RowsArgs p{};
+  if (int rc = fill(p, Z, Y, X, tw_half, tw_x)) return rc;
+  if (epilogue == LSR_EPI_UPDATE) {
+    LSR_REQUIRE_PTR(norm_table);
+    LSR_REQUIRE(pz > 0 && py > 0 && px > 0 && pz % 2 == 1 && py % 2 == 1 && px % 2 == 1 && pz < 4096 && py < 4096 &&
+                    px < 4096, LSR_E_ARG, "PSF extents (%d,%d,%d) must be odd and positive", pz, py, px);
+    LSR_REQUIRE(norm_full > 0.0f, LSR_E_ARG, "norm_full must be positive");
+  }
+  p.spec = reinterpret_cast<float2*>(spec);
+  p.aux = aux; p.out = out;
+  p.Zo = static_cast<int>(Zo); p.Yo = static_cast<int>(Yo); p.Xo = static_cast<int>(Xo);
+  p.scale = scale; p.eps = eps;
+  p.pz = pz; p.py = py; p.px = px;
+  p.norm_table = norm_table; p.norm_full = norm_full; p.stats = stats;
+  const int64_t tiles = Z * lsr::ceil_div(Y, kRows), out_tiles = Zo * lsr::ceil_div(Yo, kRows);
+  const unsigned blocks = xcd_grid(out_tiles) + static_cast<unsigned>(tiles - out_tiles);
+  hipStream_t s = lsr::as_stream(stream);
+  static std::atomic<uint64_t> a0{0}, a1{0}, a2{0};
+  if (epilogue == LSR_EPI_RATIO) {
+    if (int rc = allow_lds(irfft_rows_rl_kernel<LSR_EPI_RATIO, false, true>, a0, "lsr_rl_rows_chain_f32")) return rc;
+    hipLaunchKernelGGL((irfft_rows_rl_kernel<LSR_EPI_RATIO, false, true>), dim3(blocks), dim3(kThreads), lds_bytes(p.M), s, p);
+  } else if (stats == nullptr) {
+    if (int rc = allow_lds(irfft_rows_rl_kernel<LSR_EPI_UPDATE, false, true>, a1, "lsr_rl_rows_chain_f32")) return rc;
+    hipLaunchKernelGGL((irfft_rows_rl_kernel<LSR_EPI_UPDATE, false, true>), dim3(blocks), dim3(kThreads), lds_bytes(p.M), s, p);
+  } else {
+    if (int rc = allow_lds(irfft_rows_rl_kernel<LSR_EPI_UPDATE, true, true>, a2, "lsr_rl_rows_chain_f32")) return rc;
+    hipLaunchKernelGGL((irfft_rows_rl_kernel<LSR_EPI_UPDATE, true, true>), dim3(blocks), dim3(kThreads), lds_bytes(p.M), s, p);
+  }
+  return lsr::launch_status("lsr_rl_rows_chain_f32");
 }

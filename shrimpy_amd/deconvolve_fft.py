@@ -12,7 +12,11 @@ axis (a linear convolution: what wraps around lands in the padding), at a cost t
 size.  There is no reference code for RL (``/root/reference/docs/data_structure.md:58-62``); the arithmetic is that
 of the stencil path, and the test oracle is ``oracle.cpu_ref.richardson_lucy`` (direct and ``use_fft=True``).
 
-One convolution = five launches, none of which writes a real-space volume other than the iteration's own output:
+One convolution = five launches, none of which writes a real-space volume other than the iteration's own ``ratio`` and
+``x``.  (``LSR_FFT_RL_CHAIN=1`` runs steps 5 and 1 of consecutive convolutions as ONE kernel, ``lsr_rl_rows_chain_f32``:
+eight launches per iteration, the ratio never in memory, the same bits -- and 23.5 instead of 23.0 ms per iteration on
+the config-2 grid: the row kernels are bound by the latency chain load -> transform -> epilogue inside a workgroup, two
+of which fit a CU, not by the 6.4 GB the chaining saves.  Kept as the form to start from once the transforms are faster.)
 
 1. ``lsr_rfft_rows_zero_t_c64``    zero padding + real-to-complex transform along x + transpose (LDS-resident rows)
 2. hipFFT, batched 1-D, in place   the long y axis (the one leg left to the library, as in :mod:`shrimpy_amd.fft3`)
@@ -126,33 +130,72 @@ class FftRichardsonLucyPlan:
     def _scratch(self):
         import torch
 
+        import os
+
         if self._b is None:
             gz, gy, _ = self.grid
             self._b = torch.empty((gz, self._xc, gy), dtype=torch.complex64, device=self.device)
+        if self._ratio is None and os.environ.get("LSR_FFT_RL_CHAIN", "0") != "1":
             self._ratio = torch.empty(self.shape, dtype=torch.float32, device=self.device)
         return self._b, self._ratio
 
-    def _convolve(self, src, conj: int, epilogue: int, aux, out, eps: float, stats_ptr: int) -> None:
-        """``out = epilogue(H src, aux)`` (``conj = 0``) or ``epilogue(H^T src, aux)`` (``conj = 1``)."""
+    def _forward(self, src) -> None:
+        """``b`` <- the x leg of ``src``'s spectrum (zero padding + transform + transpose)."""
+        gz, gy, gx = self.grid
+        z, y, x = self.shape
+        b, _ = self._scratch()
+        _lib.call("lsr_rfft_rows_zero_t_c64", src.data_ptr(), z, y, x, b.data_ptr(), gz, gy, gx, self._half.data_ptr(),
+                  self._full.data_ptr(), _lib.stream_ptr(self.device))
+
+    def _middle(self, conj: int) -> None:
+        """``b`` (x leg done) <- y transform, z transform x PSF spectrum (or its conjugate) x inverse z, y back."""
+        gz, gy, _ = self.grid
+        b, _ = self._scratch()
+        dev = self.device
+        fft3._exec(dev, fft3._HIPFFT_C2C, gy, gz * self._xc, b.data_ptr(), b.data_ptr(), fft3._FORWARD)
+        _lib.call("lsr_spectrum_multiply_z_c64", self._otf.data_ptr(), b.data_ptr(), self._tw_z.data_ptr(), gz, gy,
+                  self._xc, conj, _lib.stream_ptr(dev))
+        fft3._exec(dev, fft3._HIPFFT_C2C, gy, gz * self._xc, b.data_ptr(), b.data_ptr(), fft3._BACKWARD)
+
+    def _epilogue(self, entry: str, epilogue: int, aux, out, eps: float, stats_ptr) -> None:
         gz, gy, gx = self.grid
         z, y, x = self.shape
         pz, py, px = self.psf.shape
         b, _ = self._scratch()
-        dev, stream = self.device, _lib.stream_ptr(self.device)
-        _lib.call("lsr_rfft_rows_zero_t_c64", src.data_ptr(), z, y, x, b.data_ptr(), gz, gy, gx, self._half.data_ptr(),
-                  self._full.data_ptr(), stream)
-        fft3._exec(dev, fft3._HIPFFT_C2C, gy, gz * self._xc, b.data_ptr(), b.data_ptr(), fft3._FORWARD)
-        _lib.call("lsr_spectrum_multiply_z_c64", self._otf.data_ptr(), b.data_ptr(), self._tw_z.data_ptr(), gz, gy,
-                  self._xc, conj, stream)
-        fft3._exec(dev, fft3._HIPFFT_C2C, gy, gz * self._xc, b.data_ptr(), b.data_ptr(), fft3._BACKWARD)
-        _lib.call("lsr_irfft_rows_rl_f32", b.data_ptr(), gz, gy, gx, self._half.data_ptr(), self._full.data_ptr(), epilogue,
-                  aux.data_ptr(), out.data_ptr(), z, y, x, ctypes.c_float(self._scale), ctypes.c_float(eps), pz, py, px,
-                  self._norm_table.data_ptr(), ctypes.c_float(self._norm_full), stats_ptr, stream)
+        _lib.call(entry, b.data_ptr(), gz, gy, gx, self._half.data_ptr(), self._full.data_ptr(), epilogue,
+                  aux.data_ptr(), None if out is None else out.data_ptr(), z, y, x, ctypes.c_float(self._scale),
+                  ctypes.c_float(eps), pz, py, px, self._norm_table.data_ptr(), ctypes.c_float(self._norm_full), stats_ptr,
+                  _lib.stream_ptr(self.device))
 
-    def _iteration(self, x, y, eps: float, stats_row) -> None:
+    def _iteration(self, x, y, eps: float, stats_row, first: bool) -> None:
+        """``LSR_FFT_RL_CHAIN=1``: one iteration in eight launches.  ``b`` holds the x leg of the current estimate's spectrum on entry (``first``:
+        made here) and of the new estimate's on exit: both inverse x legs are chained into the next forward one
+        (``lsr_rl_rows_chain_f32``), the ratio is never written, x_new is not read back for its transform."""
+        if first:
+            self._forward(x)
+        self._middle(0)
+        self._epilogue("lsr_rl_rows_chain_f32", _lib.EPI_RATIO, y, None, eps, None)            # b <- x leg of y / (H x + eps)
+        self._middle(1)
+        self._epilogue("lsr_rl_rows_chain_f32", _lib.EPI_UPDATE, x, x, eps,                     # x <- x H^T r / H^T 1
+                       None if stats_row is None else stats_row.data_ptr())
+
+    def _iteration_unchained(self, x, y, eps: float, stats_row) -> None:
+        """The iteration as ten launches with the ratio volume in memory: the default (see the module docstring)."""
         _, ratio = self._scratch()
-        self._convolve(x, 0, _lib.EPI_RATIO, y, ratio, eps, None)
-        self._convolve(ratio, 1, _lib.EPI_UPDATE, x, x, eps, None if stats_row is None else stats_row.data_ptr())
+        self._forward(x)
+        self._middle(0)
+        self._epilogue("lsr_irfft_rows_rl_f32", _lib.EPI_RATIO, y, ratio, eps, None)
+        self._forward(ratio)
+        self._middle(1)
+        self._epilogue("lsr_irfft_rows_rl_f32", _lib.EPI_UPDATE, x, x, eps, None if stats_row is None else stats_row.data_ptr())
+
+    def _step(self, x, y, eps, stats_row, first):
+        import os
+
+        if os.environ.get("LSR_FFT_RL_CHAIN", "0") != "1":
+            self._iteration_unchained(x, y, eps, stats_row)
+        else:
+            self._iteration(x, y, eps, stats_row, first)
 
     def __call__(self, y, iterations: int = 20, eps: float = 1e-6, x0=None, out=None, events=None, *,
                  stats: bool = False, tol: float | None = None):
@@ -190,7 +233,7 @@ class FftRichardsonLucyPlan:
             done, stopped = iterations, False
             if tol is None:
                 for it in range(iterations):
-                    self._iteration(out, y, float(eps), None if dev_stats is None else dev_stats[it])
+                    self._step(out, y, float(eps), None if dev_stats is None else dev_stats[it], it == 0)
             else:
                 done, stopped = self._run_to_tolerance(out, y, float(eps), iterations, float(tol), dev_stats)
             if events:
@@ -218,7 +261,7 @@ class FftRichardsonLucyPlan:
 
         done = 0
         for it in range(iterations):
-            self._iteration(x, y, eps, dev_stats[it])
+            self._step(x, y, eps, dev_stats[it], it == 0)
             host[it].copy_(dev_stats[it], non_blocking=True)
             arrived[it].record()
             done = it + 1

@@ -797,7 +797,7 @@ def _measured_like_psf(shape, seed):
 
 @pytest.mark.parametrize("vshape,pshape", [((20, 40, 52), (13, 15, 17)), ((7, 9, 11), (3, 5, 3)), ((12, 33, 131), (21, 19, 9)),
                                            ((5, 6, 9), (9, 13, 17)), ((30, 17, 64), (1, 1, 31))])
-def test_rl_in_the_fourier_domain_vs_oracle(device, vshape, pshape):
+def test_rl_in_the_fourier_domain_vs_oracle(device, vshape, pshape, monkeypatch):
     """Dense PSFs beyond the stencil kernels (csrc/rfft_rows.hip, zcorr.hip, shrimpy_amd/deconvolve_fft.py): the
     iteration with both convolutions as products of spectra, against the oracle's DIRECT stencil (the definition) within
     the RL bar and against its use_fft form; reduction scalars to 1e-5; odd widths, volumes thinner than the PSF,
@@ -814,6 +814,7 @@ def test_rl_in_the_fourier_domain_vs_oracle(device, vshape, pshape):
     assert all(g >= max(n + p // 2, p) for g, n, p in zip(plan.grid, vshape, pshape)) and plan.grid == fft_grid(vshape, pshape)
     yd = _t(y, device)
     x = plan(yd, iterations=5, stats=True)
+    chained_stats = plan.last_stats
     ref = o.richardson_lucy(y, psf, 5)
     _close(x.cpu().numpy(), ref, 2e-4, 1e-4)
     _close(x.cpu().numpy(), o.richardson_lucy(y, psf, 5, use_fft=True), 2e-4, 1e-4)
@@ -830,6 +831,11 @@ def test_rl_in_the_fourier_domain_vs_oracle(device, vshape, pshape):
     _close(out.cpu().numpy(), o.richardson_lucy(y, psf, 2, x0=x0), 5e-5, 2e-5)
     one = plan(yd, iterations=1)
     _close(one.cpu().numpy(), o.richardson_lucy(y, psf, 1), 2e-5, 5e-6)
+    # the chained form (LSR_FFT_RL_CHAIN=1: inverse x leg -> epilogue -> forward x leg in one kernel, the ratio never in
+    # memory) does the arithmetic of the ten-launch form: the same bits, scalars included
+    monkeypatch.setenv("LSR_FFT_RL_CHAIN", "1")
+    assert torch.equal(plan(yd, iterations=5, stats=True), x)
+    np.testing.assert_allclose(plan.last_stats.flux, chained_stats.flux, rtol=1e-12)
 
 
 def test_rl_method_auto_sends_large_dense_psfs_to_the_fourier_domain(device):
