@@ -89,6 +89,20 @@ def rotated_psf():
     return (g / g.sum()).astype(np.float32)
 
 
+def measured_psf(shape=(15, 19, 19)):
+    """A dense, non-separable PSF of the size of a measured bead patch (15 x 18 x 18 voxels, padded to odd:
+    /root/reference/scripts/measure_psf.py:187-190 at run time of the survey): a tilted Gaussian with a weak off-axis
+    lobe.  Runs the RL iteration in the Fourier domain (shrimpy_amd/deconvolve_fft.py)."""
+    import numpy as np
+
+    z, y, x = np.meshgrid(*[np.arange(n) - n // 2 for n in shape], indexing="ij")
+    a = math.radians(30.0)
+    zr, xr = math.cos(a) * z + math.sin(a) * x, -math.sin(a) * z + math.cos(a) * x
+    g = np.exp(-0.5 * ((zr / 3.0) ** 2 + (y / 2.2) ** 2 + (xr / 2.2) ** 2))
+    g += 0.04 * np.exp(-0.5 * (((z - 2) / 2.5) ** 2 + ((y + 3) / 2.0) ** 2 + ((x - 3) / 1.8) ** 2))
+    return (g / g.sum()).astype(np.float32)
+
+
 def registration_matrix():
     """rotation 2 deg about Z, scale (1, .98, 1.02), translation (3.5, -12.25, 20.75)."""
     import numpy as np
@@ -394,10 +408,15 @@ def run_resident(args, rank, world, device, shared, backend, cpu):
                                   fused="auto" if args.rl == "fused" else "never")
     elif args.psf == "rotated":
         plan = RichardsonLucyPlan(out_shape, rotated_psf(), device, fused="never" if args.rl == "two-launch" else "auto")
+    elif args.psf == "measured":
+        from shrimpy_amd.deconvolve import make_plan
+
+        plan = make_plan(out_shape, measured_psf(), device)
     else:
         plan = RichardsonLucyPlan(out_shape, rotated_psf(), device, separable="never")
-    # the deskew kernel writes straight into the RL kernels' padded, line-aligned input volume
-    deskewed = plan.new_padded_input()
+    # the deskew kernel writes straight into the RL kernels' padded, line-aligned input volume (the Fourier-domain
+    # plan takes a plain dense one)
+    deskewed = plan.new_padded_input() if plan.padded_input else torch.empty(out_shape, dtype=torch.float32, device=device)
     estimate = torch.empty(out_shape, dtype=torch.float32, device=device)
     geo = deskew_geometry(raw_shape, **DESKEW)
 
@@ -429,6 +448,8 @@ def run_resident(args, rank, world, device, shared, backend, cpu):
     fused = bool(getattr(plan, "fused", False)) or bool(getattr(plan, "fused_ysep", False))
     ysep = plan.path.startswith("y-separable")
     launches = RL_ITERS if fused else (4 * RL_ITERS if plan.path.endswith("(4 launches)") else 2 * RL_ITERS)
+    if plan.path == "fft":
+        launches = RL_ITERS      # the roofline unit below is one ITERATION (ten launches: two convolutions of five)
     launch_s = rl_kernels_ms * 1e-3 / launches  # HIP events right around the launches, / count
     # fused iteration: x, y in, x_new out; ratio / update launch: in + aux + out
     bytes_per_launch = 12.0 * n_o
@@ -439,7 +460,17 @@ def run_resident(args, rank, world, device, shared, backend, cpu):
     survey_bytes = 4.0 * n_in + 4.0 * n_o + 24.0 * RL_ITERS * n_o + 8.0 * n_o
     min_bytes = 4.0 * n_in + 4.0 * n_o + 12.0 * launches * n_o
     ms_per_step = elapsed / args.steps * 1e3
-    if args.psf == "separable":
+    if plan.path == "fft":
+        # per convolution: rows forward 4 N_o + 8 G, y 16 G, z leg 16 G + 8 G (the PSF's spectrum), y 16 G, rows
+        # inverse 8 G + 8 N_o  (G = complex points of the half spectrum on the transform grid); two per iteration
+        gz, gy, gx = plan.grid
+        g_c = gz * gy * (gx // 2 + 1)
+        bytes_per_launch = 2.0 * (12.0 * n_o + 72.0 * g_c)
+        achieved = bytes_per_launch / launch_s / 1e9
+        min_bytes = 4.0 * n_in + 4.0 * n_o + RL_ITERS * bytes_per_launch
+        kernel, symbol = ("Fourier-domain RL iteration: 2 x (rfft_rows_kernel, rocFFT y, zcorr_kernel, rocFFT y, "
+                          "irfft_rows_rl_kernel) on grid %s" % (tuple(plan.grid),)), "irfft_rows_rl_kernel"
+    elif args.psf == "separable":
         kernel = ("rl_fused_sep_kernel<9,7> (one RL iteration per launch)" if fused
                   else "correlate_sep_kernel<9,7,7> (RL ratio / update launch)")
         symbol = "rl_fused_sep_kernel" if fused else "correlate_sep_kernel"
@@ -451,7 +482,7 @@ def run_resident(args, rank, world, device, shared, backend, cpu):
         kernel, symbol = "correlate_dense_kernel<9,7> (dense RL ratio / update launch)", "correlate_dense_kernel"
     key = ("fused" if fused else "two-launch") if args.psf == "separable" else args.psf
     traffic, traffic_note = pmc_traffic(key, args.workload, symbol)
-    if args.psf == "separable" or ysep:
+    if args.psf == "separable" or ysep or plan.path == "fft":
         roofline = {
             "kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_record": traffic_note,
@@ -482,7 +513,7 @@ def run_resident(args, rank, world, device, shared, backend, cpu):
         "config": {
             "workload": (f"{args.workload}: raw (Z_scan,Y_tilt,X)={raw_shape} f32 -> deskew 30deg "
                          f"r=0.755 no-overhang avg3 -> {tuple(out_shape)} -> {RL_ITERS}-iter RL, "
-                         f"{args.psf} 9x7x7 PSF; one position per GPU"),
+                         f"{args.psf} {'x'.join(str(n) for n in (plan.psf.shape if plan.path == 'fft' else PSF_SHAPE))} PSF; one position per GPU"),
             "raw_shape": list(raw_shape),
             "deskewed_shape": list(out_shape),
             "psf": args.psf,
@@ -761,11 +792,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
-    ap.add_argument("--psf", default="separable", choices=["separable", "dense", "rotated"],
+    ap.add_argument("--psf", default="separable", choices=["separable", "dense", "rotated", "measured"],
                     help="separable = the declared default Gaussian (rank-1 path); dense = the "
                          "rotated non-separable PSF through the 441-tap dense stencil; rotated = the "
                          "same PSF with the plan free to split it (it separates along y: a (z, x) "
-                         "stencil plus a y pass per correlation)")
+                         "stencil plus a y pass per correlation); measured = a dense 15x19x19 bead-patch PSF "
+                         "(the RL iteration in the Fourier domain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=None, help="cap the CPU baseline's worker count (default: all host cores)")
     ap.add_argument("--rl", default="fused", choices=["fused", "two-launch", "fused-ysep"],
