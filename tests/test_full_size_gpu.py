@@ -369,3 +369,55 @@ def test_rl_full_size_y_separable_path_agrees_with_the_dense_kernel(scene, devic
     assert np.all(np.abs(got - want) <= 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max())
     del a, b
     torch.cuda.empty_cache()
+
+
+def test_rl_full_size_in_the_fourier_domain_agrees_with_the_dense_stencil_and_the_oracle(scene, device):
+    """A dense 11 x 9 x 9 PSF at config-2 size through the Fourier-domain iteration (shrimpy_amd/deconvolve_fft.py,
+    grid 180 x 2160 x 2304) against the tuned dense stencil over the WHOLE volume, against the oracle on a crop with
+    full margin, and flux against sum y; then a bead-patch-sized 15 x 19 x 19 PSF, which only this route takes,
+    against the oracle on a crop."""
+    import torch
+
+    import bench
+    from shrimpy_amd.deconvolve import RichardsonLucyPlan, make_plan
+
+    _, deskewed = scene
+    psf = bench.measured_psf((11, 9, 9))
+    iters = 4
+    fft = make_plan(tuple(deskewed.shape), psf, device)
+    assert fft.path == "fft" and fft.grid == (180, 2160, 2304)      # (891 taps: past the stencil's break-even)
+    a = fft(deskewed, iterations=iters, stats=True)
+    flux = fft.last_stats.flux
+    fft.release()
+    del fft
+    dense = RichardsonLucyPlan(tuple(deskewed.shape), psf, device, separable="never")
+    assert dense.path == "dense"
+    b = dense(deskewed, iterations=iters)
+    dense.release()
+    del dense
+    tol = 2e-4 * b.abs() + 1e-4 * float(b.max())
+    assert bool(((a - b).abs() <= tol).all())
+    np.testing.assert_allclose(flux, float(deskewed.sum(dtype=torch.float64)), rtol=1e-4)
+    del b
+    torch.cuda.empty_cache()
+
+    def crop_check(got, kernel, n, y0, x0, core=32):
+        ry, rx = kernel.shape[1] // 2, kernel.shape[2] // 2
+        my, mx = n * 2 * ry, n * 2 * rx          # n iterations reach 2 n r voxels in the plane, all of z
+        crop = deskewed[:, y0 - my:y0 + core + my, x0 - mx:x0 + core + mx].contiguous().cpu().numpy()
+        want = o.richardson_lucy(crop, kernel, n, use_fft=True)[:, my:my + core, mx:mx + core].astype(np.float64)
+        have = got[:, y0:y0 + core, x0:x0 + core].cpu().numpy().astype(np.float64)
+        assert np.all(np.abs(have - want) <= 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max())
+
+    crop_check(a, psf, iters, 900, 1300)
+    del a
+    torch.cuda.empty_cache()
+    patch = bench.measured_psf((15, 19, 19))
+    plan = make_plan(tuple(deskewed.shape), patch, device)
+    assert plan.path == "fft"
+    c = plan(deskewed, iterations=2)
+    plan.release()
+    crop_check(c, patch, 2, 400, 700)
+    crop_check(c, patch, 2, 0 + 2 * 2 * 9, 2270 - 32 - 2 * 2 * 9, core=32)      # near the y = 0 / x = X corner region
+    del c
+    torch.cuda.empty_cache()
