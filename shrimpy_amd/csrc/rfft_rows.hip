@@ -375,6 +375,32 @@ __global__ __launch_bounds__(kThreads) void irfft_rows_rl_kernel(RowsArgs p) {
   c2r_pre_step(p, t, tid);
   __syncthreads();
 
+  // UPDATE: H^T 1 of the border voxels this lane will write, looked up BEFORE the transform so that the table's loads
+  // (eight dependent float64 reads per voxel) are long back when the epilogue wants them.  A lane's m = lane + 64 k
+  // meets the left border (x < cx <= 64) only at k = 0 and the right border (the last cx <= 64 columns: at most 33
+  // values of m) at most once; every other voxel of the row shares one value.  (Looked up inside the epilogue loop,
+  // the 19 % of wave-iterations that touch a border each waited a microsecond: 3.75 against 2.98 ms for the ratio form.)
+  float n_left[2] = {1.0f, 1.0f}, n_right[2] = {1.0f, 1.0f}, n_row = 1.0f;
+  int m_right = -1;
+  if constexpr (EPI == LSR_EPI_UPDATE) {
+    const int r = tid / kPerRow, lane = tid & (kPerRow - 1);
+    if (r < nrows) {
+      const int y = y0 + r;
+      const int cz = p.pz / 2, cy = p.py / 2, cx = p.px / 2;
+      const bool zy_inside = z >= cz && z < p.Zo - cz && y >= cy && y < p.Yo - cy;
+      n_row = zy_inside ? p.norm_full : rl_border_norm(p, z, y, min(cx, p.Xo - 1));
+      const int m_lo = max(p.Xo - cx, 0) >> 1, m_hi = (p.Xo - 1) >> 1;
+      m_right = m_lo + ((lane - m_lo) & (kPerRow - 1));
+      if (m_right > m_hi) m_right = -1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int xl = 2 * lane + h, xr = 2 * m_right + h;
+        n_left[h] = (xl < cx && xl < p.Xo) ? rl_border_norm(p, z, y, xl) : n_row;
+        n_right[h] = (m_right >= 0 && xr >= p.Xo - cx && xr < p.Xo) ? rl_border_norm(p, z, y, xr) : n_row;
+      }
+    }
+  }
+
   const float2* twl = t.tw;
   transform<kMaxM, kPerRow>(t.buf + (tid / kPerRow) * t.pitch, M, p.f, [twl, half](int i) { return tw_m(twl, half, i); },
                             tid & (kPerRow - 1));
@@ -389,8 +415,7 @@ __global__ __launch_bounds__(kThreads) void irfft_rows_rl_kernel(RowsArgs p) {
       const int64_t base = (static_cast<int64_t>(z) * p.Yo + y) * p.Xo;
       const float* aux = p.aux + base;
       float* out = p.out == nullptr ? nullptr : p.out + base;
-      const int cz = p.pz / 2, cy = p.py / 2, cx = p.px / 2;
-      const bool zy_inside = z >= cz && z < p.Zo - cz && y >= cy && y < p.Yo - cy;
+      const int cx = p.px / 2;
       const int last = p.Xo - 1;
       batched_loop<6>(lane, (p.Xo + 1) / 2, kPerRow,
                       [aux, last](int m) { return float2{aux[2 * m], aux[min(2 * m + 1, last)]}; },
@@ -408,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void irfft_rows_rl_kernel(RowsArgs p) {
               res[h] = a / (fmaxf(v[h], 0.0f) + p.eps);
               if (!CHAIN || out != nullptr) out[x] = res[h];
             } else {
-              const float nrm = (zy_inside && x >= cx && x < p.Xo - cx) ? p.norm_full : rl_border_norm(p, z, y, x);
+              const float nrm = (m == lane && x < cx) ? n_left[h] : ((m == m_right && x >= p.Xo - cx) ? n_right[h] : n_row);
               const float xu = a * v[h];
               res[h] = xu / nrm;
               out[x] = res[h];

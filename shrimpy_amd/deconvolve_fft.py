@@ -61,7 +61,8 @@ def fft_grid(shape_zyx, psf_shape) -> tuple[int, int, int]:
     take."""
     (z, y, x), (pz, py, px) = (tuple(int(v) for v in shape_zyx), tuple(int(v) for v in psf_shape))
     nz, ny, nx = max(z + pz // 2, pz), max(y + py // 2, py), max(x + px // 2, px)
-    return (_next_smooth(nz), _next_smooth(ny), 4 * _next_smooth(-(-nx // 4)))
+    # (the z leg transforms at least 2 points, the x leg at least 8)
+    return (_next_smooth(max(nz, 2)), _next_smooth(ny), 4 * _next_smooth(max(-(-nx // 4), 2)))
 
 
 def fft_supported(shape_zyx, psf_shape) -> bool:

@@ -796,7 +796,8 @@ def _measured_like_psf(shape, seed):
 
 
 @pytest.mark.parametrize("vshape,pshape", [((20, 40, 52), (13, 15, 17)), ((7, 9, 11), (3, 5, 3)), ((12, 33, 131), (21, 19, 9)),
-                                           ((5, 6, 9), (9, 13, 17)), ((30, 17, 64), (1, 1, 31))])
+                                           ((5, 6, 9), (9, 13, 17)), ((30, 17, 64), (1, 1, 31)), ((1, 35, 86), (1, 9, 25)),
+                                           ((2, 1, 3), (3, 1, 1))])
 def test_rl_in_the_fourier_domain_vs_oracle(device, vshape, pshape, monkeypatch):
     """Dense PSFs beyond the stencil kernels (csrc/rfft_rows.hip, zcorr.hip, shrimpy_amd/deconvolve_fft.py): the
     iteration with both convolutions as products of spectra, against the oracle's DIRECT stencil (the definition) within
