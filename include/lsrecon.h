@@ -558,10 +558,13 @@ int lsr_irfft_rows_peak(const float* spec, int64_t Z, int64_t Y, int64_t X, cons
  * the arithmetic is that of the stencil path: x <- x * H^T( y / (H x + eps) ) / H^T 1, zero-padded
  * borders, with H x and H^T r evaluated as products of spectra on a grid (Z, Y, X) >= volume + PSF radius per axis.
  * lsr_rfft_rows_zero_t_c64: as lsr_rfft_rows_t_c64 with the source ((Zi, Yi, Xi) <= grid) at the grid's origin and
- *   zeros behind it -- a linear convolution, not a circular one; tiles of pure padding store zeros without a transform.
+ *   zeros behind it -- a linear convolution, not a circular one; tiles of padding rows (y >= Yi) in the source's planes
+ *   store zeros without a transform, planes z >= Zi are NOT written (see z_valid below).
  * lsr_spectrum_multiply_z_c64: g <- N * IFFT_z( f1 * FFT_z(g) ) (conj_f1 = 0: H x) or N * IFFT_z( conj(f1) * FFT_z(g) )
  *   (conj_f1 = 1: H^T r); layouts and lengths as lsr_cross_correlate_z_c64, f1 = the PSF's spectrum (its centre tap at
- *   the grid's origin, wrapped).
+ *   the grid's origin, wrapped).  z_valid: planes [z_valid, N) of g are the zero padding behind the volume -- taken as
+ *   zeros and never read, so the forward x and y legs need not produce them; z_keep: only planes [0, z_keep) of the
+ *   result are stored -- the inverse y and x legs read no others (N, N = everything).
  * lsr_irfft_rows_rl_f32: the inverse x leg with the iteration's epilogue.  v = scale * (complex-to-real inverse of
  *   spec along x) on the grid's first (Zo, Yo, Xo) points, scale = 1 / (Z Y X);
  *     LSR_EPI_RATIO:  out = aux / (max(v, 0) + eps)    aux = y
@@ -577,7 +580,7 @@ int lsr_irfft_rows_peak(const float* spec, int64_t Z, int64_t Y, int64_t X, cons
 int lsr_rfft_rows_zero_t_c64(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* spec, int64_t Z, int64_t Y,
                              int64_t X, const float* tw_half, const float* tw_x, lsr_stream_t stream);
 int lsr_spectrum_multiply_z_c64(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC,
-                                int conj_f1, lsr_stream_t stream);
+                                int conj_f1, int64_t z_valid, int64_t z_keep, lsr_stream_t stream);
 int lsr_irfft_rows_rl_f32(const float* spec, int64_t Z, int64_t Y, int64_t X, const float* tw_half, const float* tw_x,
                           int epilogue, const float* aux, float* out, int64_t Zo, int64_t Yo, int64_t Xo, float scale,
                           float eps, int pz, int py, int px, const double* norm_table, float norm_full, double* stats,

@@ -74,7 +74,7 @@ SIGNATURES: dict[str, list] = {
     "lsr_rfft_rows_t_c64": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _stream],
     "lsr_irfft_rows_peak": [_c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, ctypes.c_void_p, ctypes.c_void_p, _stream],
     "lsr_rfft_rows_zero_t_c64": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _stream],
-    "lsr_spectrum_multiply_z_c64": [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _int, _stream],
+    "lsr_spectrum_multiply_z_c64": [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _i64, _int, _i64, _i64, _stream],
     "lsr_irfft_rows_rl_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _c_f32p, _c_f32p, _i64, _i64, _i64, _f32,
                               _f32, _int, _int, _int, ctypes.c_void_p, _f32, ctypes.c_void_p, _stream],
     "lsr_rl_rows_chain_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _c_f32p, _int, _c_f32p, _c_f32p, _i64, _i64, _i64, _f32,

@@ -16,7 +16,8 @@
 // (shrimpy_amd/deconvolve_fft.py: PSFs beyond the stencil kernels' extents, e.g. measured bead PSFs):
 //
 //   lsr_rfft_rows_zero_t_c64:  the forward kernel with the source placed at the grid's origin and ZERO padding
-//                              behind it (linear, not circular, convolution); tiles past the source store zeros;
+//                              behind it (linear, not circular, convolution); tiles of padding rows store zeros, the
+//                              planes behind the source are left unwritten (the z leg takes them as zeros);
 //   lsr_irfft_rows_rl_f32:     the inverse kernel with a Richardson-Lucy epilogue instead of the peak search: the
 //                              rows are scaled, cropped to the volume and leave as ratio = y / (H x + eps) or as
 //                              x_new = x * H^T(ratio) / H^T 1 (+ the iteration's reduction scalars); the convolved
@@ -153,15 +154,9 @@ __global__ __launch_bounds__(kThreads) void rfft_rows_kernel(RowsArgs p) {
       y0 = (tile - z * ty_src) * kRows;
     } else {
       const int q = static_cast<int>(blockIdx.x) - first_pad, beside = tiles_y - ty_src, n_beside = p.Zi * beside;
-      if (q < n_beside) {
-        z = q / beside;
-        y0 = (ty_src + q - z * beside) * kRows;
-      } else {
-        const int r = q - n_beside;
-        z = p.Zi + r / tiles_y;
-        y0 = (r - (z - p.Zi) * tiles_y) * kRows;
-      }
-      if (z >= p.Z) return;
+      if (q >= n_beside) return;   // (the planes behind the source are not written: lsr_spectrum_multiply_z_c64's z_valid)
+      z = q / beside;
+      y0 = (ty_src + q - z * beside) * kRows;
     }
   } else {
     const int tile = xcd_tile(p.Z * tiles_y, blockIdx.x);
@@ -356,15 +351,11 @@ __global__ __launch_bounds__(kThreads) void irfft_rows_rl_kernel(RowsArgs p) {
     const int tiles_y = (p.Y + kRows - 1) / kRows;
     const int q = static_cast<int>(blockIdx.x) - static_cast<int>(xcd_grid(n_out)), beside = tiles_y - ty_out;
     const int n_beside = p.Zo * beside;
-    if (q < n_beside) {
+    if (q < n_beside) {           // (the planes behind the volume are not written: z_valid of the z leg)
       z = q / beside;
       y0 = (ty_out + q - z * beside) * kRows;
-    } else {
-      const int r = q - n_beside;
-      z = p.Zo + r / tiles_y;
-      y0 = (r - (z - p.Zo) * tiles_y) * kRows;
+      store_zero_tile(p, z, y0, min(kRows, p.Y - y0), tid);
     }
-    if (z < p.Z) store_zero_tile(p, z, y0, min(kRows, p.Y - y0), tid);
     return;
   }
   const int nrows = min(kRows, p.Yo - y0);
@@ -588,8 +579,9 @@ extern "C" int lsr_rfft_rows_zero_t_c64(const float* in, int64_t Zi, int64_t Yi,
   p.spec = reinterpret_cast<float2*>(spec);
   static std::atomic<uint64_t> lds_allowed{0};
   if (int rc = allow_lds(rfft_rows_kernel<true>, lds_allowed, "lsr_rfft_rows_zero_t_c64")) return rc;
-  const int64_t tiles = Z * lsr::ceil_div(Y, kRows), src_tiles = Zi * lsr::ceil_div(Yi, kRows);
-  const unsigned blocks = xcd_grid(src_tiles) + static_cast<unsigned>(tiles - src_tiles);
+  // tiles with source rows, then the tiles of padding rows beside them; nothing for the planes behind the source
+  const int64_t src_tiles = Zi * lsr::ceil_div(Yi, kRows), beside = Zi * (lsr::ceil_div(Y, kRows) - lsr::ceil_div(Yi, kRows));
+  const unsigned blocks = xcd_grid(src_tiles) + static_cast<unsigned>(beside);
   hipLaunchKernelGGL(rfft_rows_kernel<true>, dim3(blocks), dim3(kThreads), lds_bytes(p.M), lsr::as_stream(stream), p);
   return lsr::launch_status("lsr_rfft_rows_zero_t_c64");
 }
@@ -667,8 +659,8 @@ extern "C" int lsr_rl_rows_chain_f32(float* spec, int64_t Z, int64_t Y, int64_t 
   p.scale = scale; p.eps = eps;
   p.pz = pz; p.py = py; p.px = px;
   p.norm_table = norm_table; p.norm_full = norm_full; p.stats = stats;
-  const int64_t tiles = Z * lsr::ceil_div(Y, kRows), out_tiles = Zo * lsr::ceil_div(Yo, kRows);
-  const unsigned blocks = xcd_grid(out_tiles) + static_cast<unsigned>(tiles - out_tiles);
+  const int64_t out_tiles = Zo * lsr::ceil_div(Yo, kRows), beside = Zo * (lsr::ceil_div(Y, kRows) - lsr::ceil_div(Yo, kRows));
+  const unsigned blocks = xcd_grid(out_tiles) + static_cast<unsigned>(beside);
   hipStream_t s = lsr::as_stream(stream);
   static std::atomic<uint64_t> a0{0}, a1{0}, a2{0};
   if (epilogue == LSR_EPI_RATIO) {

@@ -36,6 +36,7 @@ struct ZcorrArgs {
   Factors f;
   float inv_n;                     // 1 / N
   int mode;                        // 0: f1 * conj(G) (cross-correlation), 1: f1 * G, 2: conj(f1) * G (spectrum products)
+  int z_valid, z_keep;             // planes [z_valid, N) of g are zeros (not read); only planes [0, z_keep) are stored
 };
 
 __global__ __launch_bounds__(kThreads) void zcorr_kernel(ZcorrArgs p) {
@@ -56,7 +57,9 @@ __global__ __launch_bounds__(kThreads) void zcorr_kernel(ZcorrArgs p) {
   // (batched: eleven dependent load -> LDS-store rounds per thread otherwise, one load in flight per wave)
   if (c < ncols) {
     float2* col = buf + c * pitch;
-    batched_loop<8>(z0, N, kThreads / kCols, [g, row](int z) { return g[z * row]; }, [col](int z, float2 v) { col[z] = v; });
+    batched_loop<8>(z0, p.z_valid, kThreads / kCols, [g, row](int z) { return g[z * row]; }, [col](int z, float2 v) { col[z] = v; });
+    for (int z = z0 + ((p.z_valid - z0 + kThreads / kCols - 1) / (kThreads / kCols)) * (kThreads / kCols); z < N; z += kThreads / kCols)
+      col[z] = float2{0.0f, 0.0f};      // zero padding behind the volume: known, not read
   } else {
     for (int z = z0; z < N; z += kThreads / kCols) buf[c * pitch + z] = float2{0.0f, 0.0f};
   }
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void zcorr_kernel(ZcorrArgs p) {
 
   float2* out = p.g + static_cast<int64_t>(xc) * p.Y + y0 + c;
   if (c < ncols)
-    for (int z = z0; z < N; z += kThreads / kCols) out[z * row] = cconj(buf[c * pitch + z]);
+    for (int z = z0; z < p.z_keep; z += kThreads / kCols) out[z * row] = cconj(buf[c * pitch + z]);
 }
 
 }  // namespace
@@ -106,25 +109,32 @@ extern "C" int lsr_cross_correlate_z_supported(int64_t n) {
 }
 
 namespace {
-int z_leg(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC, int mode, lsr_stream_t stream);
+int z_leg(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC, int mode, int64_t z_valid,
+          int64_t z_keep, lsr_stream_t stream);
 }
 
 extern "C" int lsr_cross_correlate_z_c64(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC,
                                          lsr_stream_t stream) {
-  return z_leg(f1, g, twiddles, N, Y, XC, 0, stream);
+  return z_leg(f1, g, twiddles, N, Y, XC, 0, N, N, stream);
 }
 
 // g <- N * IFFT_z( f1 * FFT_z(g) )  (conj_f1 = 0)  or  N * IFFT_z( conj(f1) * FFT_z(g) )  (conj_f1 = 1): the z leg of a
 // convolution / correlation with the volume behind f1 done in the Fourier domain (deconvolve_fft.py); layouts as
 // lsr_cross_correlate_z_c64.
+// z_valid: planes [z_valid, N) of g are the zero padding behind the volume -- taken as zeros, never read (the forward x
+// and y legs need not produce them); z_keep: only planes [0, z_keep) of the result are stored (the inverse y and x legs
+// read no others).  N, N = everything.
 extern "C" int lsr_spectrum_multiply_z_c64(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y,
-                                           int64_t XC, int conj_f1, lsr_stream_t stream) {
+                                           int64_t XC, int conj_f1, int64_t z_valid, int64_t z_keep, lsr_stream_t stream) {
   LSR_REQUIRE(conj_f1 == 0 || conj_f1 == 1, LSR_E_ARG, "conj_f1 must be 0 or 1, got %d", conj_f1);
-  return z_leg(f1, g, twiddles, N, Y, XC, conj_f1 ? 2 : 1, stream);
+  LSR_REQUIRE(z_valid >= 1 && z_valid <= N && z_keep >= 1 && z_keep <= N, LSR_E_ARG,
+              "z_valid %lld and z_keep %lld must lie in [1, N = %lld]", (long long)z_valid, (long long)z_keep, (long long)N);
+  return z_leg(f1, g, twiddles, N, Y, XC, conj_f1 ? 2 : 1, z_valid, z_keep, stream);
 }
 
 namespace {
-int z_leg(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC, int mode, lsr_stream_t stream) {
+int z_leg(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y, int64_t XC, int mode, int64_t z_valid,
+          int64_t z_keep, lsr_stream_t stream) {
   LSR_REQUIRE_PTR(f1);
   LSR_REQUIRE_PTR(g);
   LSR_REQUIRE_PTR(twiddles);
@@ -163,6 +173,7 @@ int z_leg(const float* f1, float* g, const float* twiddles, int64_t N, int64_t Y
   }
   p.inv_n = 1.0f / static_cast<float>(p.N);
   p.mode = mode;
+  p.z_valid = static_cast<int>(z_valid); p.z_keep = static_cast<int>(z_keep);
   const int64_t blocks = XC * lsr::ceil_div(Y, kCols);
   LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large", (long long)blocks);
   const size_t lds = (static_cast<size_t>(kCols) * (p.N + 1) + p.N) * sizeof(float2);

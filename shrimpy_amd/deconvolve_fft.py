@@ -151,12 +151,15 @@ class FftRichardsonLucyPlan:
     def _middle(self, conj: int) -> None:
         """``b`` (x leg done) <- y transform, z transform x PSF spectrum (or its conjugate) x inverse z, y back."""
         gz, gy, _ = self.grid
+        z = self.shape[0]
         b, _ = self._scratch()
         dev = self.device
-        fft3._exec(dev, fft3._HIPFFT_C2C, gy, gz * self._xc, b.data_ptr(), b.data_ptr(), fft3._FORWARD)
+        # only the volume's z planes exist before the z transform (the padding behind them is zeros: z_valid) and
+        # only they are wanted after it (z_keep): the y legs run on those planes alone
+        fft3._exec(dev, fft3._HIPFFT_C2C, gy, z * self._xc, b.data_ptr(), b.data_ptr(), fft3._FORWARD)
         _lib.call("lsr_spectrum_multiply_z_c64", self._otf.data_ptr(), b.data_ptr(), self._tw_z.data_ptr(), gz, gy,
-                  self._xc, conj, _lib.stream_ptr(dev))
-        fft3._exec(dev, fft3._HIPFFT_C2C, gy, gz * self._xc, b.data_ptr(), b.data_ptr(), fft3._BACKWARD)
+                  self._xc, conj, z, z, _lib.stream_ptr(dev))
+        fft3._exec(dev, fft3._HIPFFT_C2C, gy, z * self._xc, b.data_ptr(), b.data_ptr(), fft3._BACKWARD)
 
     def _epilogue(self, entry: str, epilogue: int, aux, out, eps: float, stats_ptr) -> None:
         gz, gy, gx = self.grid
