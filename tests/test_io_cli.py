@@ -825,6 +825,45 @@ def test_cli_deskew_register_deconvolve_chain_on_gpu(tmp_path, version):
 
 
 @pytest.mark.gpu
+def test_cli_deconvolve_with_a_measured_bead_psf_from_a_store_on_gpu(tmp_path):
+    """``deconvolve`` with ``psf_path`` naming an OME-Zarr bead volume the size the PSF tools around the reference
+    average (15 x 18 x 18, ``scripts/measure_psf.py:187-190, 273-287``): beyond the stencil kernels, so the plan runs the
+    iteration in the Fourier domain; store to store against the oracle's direct stencil."""
+    from click.testing import CliRunner
+
+    from oracle import cpu_ref as o
+    from shrimpy_amd.cli import cli
+
+    rng = np.random.default_rng(21)
+    z, y, x = np.meshgrid(np.arange(15) - 7, np.arange(18) - 9, np.arange(18) - 9, indexing="ij")
+    beads = np.exp(-0.5 * (((0.9 * z + 0.43 * x) / 2.5) ** 2 + (y / 2.0) ** 2 + ((-0.43 * z + 0.9 * x) / 2.0) ** 2))
+    beads = (beads * (1 + 0.02 * rng.standard_normal(beads.shape))).clip(0).astype(np.float32)
+    beads /= beads.sum()
+    with open_ome_zarr(tmp_path / "psf.zarr", layout="hcs", mode="w", channel_names=["beads"], prefer_iohub=False) as store:
+        arr = store.create_position("0", "0", "0").create_zeros("0", shape=(1, 1) + beads.shape, dtype="float32",
+                                                                  scale=(1, 1, 0.17, 0.1133, 0.1133))
+        arr.write_volume(0, 0, beads)
+    src = tmp_path / "deskewed.zarr"
+    vols = {}
+    with open_ome_zarr(src, layout="hcs", mode="w", channel_names=["LS"], version="0.5", prefer_iohub=False) as plate:
+        for key in KEYS[:2]:
+            pos = plate.create_position(*key.split("/"))
+            arr = pos.create_zeros("0", shape=(1, 1, 12, 30, 44), dtype="float32", scale=(1, 1, 0.17, 0.1133, 0.1133))
+            vols[key] = o.bead_scene((12, 30, 44), seed=len(vols) + 3, psf=None, density=4e-3)
+            arr.write_volume(0, 0, vols[key])
+    (tmp_path / "deconvolve.yml").write_text(yaml.safe_dump(dict(iterations=3, psf_path=str(tmp_path / "psf.zarr"))))
+    r = CliRunner().invoke(cli, ["deconvolve", "-i", str(src), "-c", str(tmp_path / "deconvolve.yml"), "-o",
+                                 str(tmp_path / "x.zarr")])
+    assert r.exit_code == 0, (r.output, r.exception)
+    psf = np.pad(beads, ((0, 0), (0, 1), (0, 1)))          # even extents get one trailing zero plane (prepare_psf)
+    with open_ome_zarr(tmp_path / "x.zarr", prefer_iohub=False) as out:
+        for key, pos in out.positions():
+            ref = o.richardson_lucy(vols[key], psf, 3).astype(np.float64)
+            got = pos["0"].read_volume(0, 0).astype(np.float64)
+            assert np.all(np.abs(got - ref) <= 2e-4 * np.abs(ref) + 1e-4 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
 def test_staged_run_over_a_store_in_the_acquisition_format_on_gpu(tmp_path):
     """deskew + 3 RL iterations store to store with the input as the acquisition writes it -- Zarr v3,
     one shard per (t, c) volume around blosc-zstd chunks (``shrimpy/mantis/mantis_engine.py:474-481``)
