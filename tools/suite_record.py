@@ -19,7 +19,7 @@ sys.path.insert(0, str(ROOT))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
-    ap.add_argument("--dir", default="gpurun_out/r3")
+    ap.add_argument("--dir", default="gpurun_out/final")
     args = ap.parse_args()
     d = ROOT / args.dir
     head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
@@ -52,9 +52,7 @@ kernel_source_sha16 printed by the run: see the smoke section; stamp of profiles
 {smoke}
 
 ---- earlier full-suite runs of this round, each on its own fresh box
-{chr(10).join(earlier)}
-(suite2.log = the round-2 abort reproduced: rc 134 inside test_plate_gpu.py::test_config4_plate_deskew_rl_through_the_staged_store_path,
- before the staging slots moved from hipHostRegister to hipHostMalloc; every run after that change is green)
+{chr(10).join(earlier) if earlier else "(none kept)"}
 
 ---- every test with its start / finish time (tests/conftest.py, LSR_TEST_TRACE)
 {trace}"""
