@@ -122,7 +122,7 @@ class VolumeReconstructor:
                     else:
                         self._host_rl = dict(psf=None, psf_factors=factors)
         elif dec is not None and dec.iterations > 0:
-            from .deconvolve import RichardsonLucyPlan, make_plan
+            from .deconvolve import make_plan
 
             if dec.psf_path:
                 psf = dec.load_psf()
@@ -135,9 +135,9 @@ class VolumeReconstructor:
                 factors = gaussian_psf_factors(dec.gaussian_shape_zyx, dec.gaussian_sigma_zyx)
                 if dec.separable == "never":
                     psf = factors[0][:, None, None] * factors[1][None, :, None] * factors[2][None, None, :]
-                    self._plan = RichardsonLucyPlan(self.output_shape, psf, self.device, separable="never")
+                    self._plan = make_plan(self.output_shape, psf, self.device, separable="never", method=dec.method)
                 else:
-                    self._plan = RichardsonLucyPlan(self.output_shape, None, self.device, psf_factors=factors)
+                    self._plan = make_plan(self.output_shape, None, self.device, psf_factors=factors, method=dec.method)
 
     def __call__(self, raw, rl_events=None):
         """``raw``: (Z, Y, X) numpy array or tensor -> reconstructed float32 tensor on ``device``.

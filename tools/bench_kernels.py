@@ -141,7 +141,7 @@ def _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_ge
     del dst
     geo = deskew_geometry(raw_shape, **bench.DESKEW)
     dsk = torch.empty(geo.output_shape, device=dev)
-    for name, kw in (("deskew_kernel<false>", {}), ("deskew_kernel<true> (flat-field fused)", {"flat_field": ff})):
+    for name, kw in (("deskew_kernel<false>, dense output rows", {}), ("deskew_kernel<true> (flat-field fused), dense output rows", {"flat_field": ff})):
         ms = timed(lambda: deskew_with_matrix(raw, geo.matrix_3x4, geo.pre_average_shape, 3, out=dsk, **kw), args.reps)
         print(json.dumps({"kernel": name, "raw": raw_shape, "ms": ms}))
     raw16 = raw.to(torch.uint16)
@@ -167,7 +167,9 @@ def _affine_and_deskew(args, torch, dev, g, bench, deskew_with_matrix, deskew_ge
         for border in ("constant", "grid-constant"):
             ms = timed(lambda: deskew_with_matrix(raw, geo.matrix_3x4, geo.pre_average_shape, 3, out=dst, border=border),
                        args.reps)
-            print(json.dumps({"kernel": "deskew_kernel" + ("" if border == "constant" else " (border grid-constant)"),
+            # (dense output: rows of Xo floats, 2270 at config 2 -- not a multiple of four, so the stores of a tile row
+            # straddle 16-byte boundaries; bench.py's step writes the RL plan's padded, line-aligned volume: 2.3 ms)
+            print(json.dumps({"kernel": "deskew_kernel, dense output rows" + ("" if border == "constant" else " (border grid-constant)"),
                               "workload": name, "raw": raw_shape,
                               "out": geo.output_shape, "ms": ms, "algorithmic_GBps": nbytes / ms / 1e6,
                               "frac_of_8TBps": nbytes / ms / 1e6 / 8000}))
