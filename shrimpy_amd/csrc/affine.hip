@@ -208,7 +208,7 @@ bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, i
                           float* out, int64_t Zo, int64_t Yo, int64_t Xo, int64_t opitch, int64_t oplane,
                           const double M[12], float cval, bool f32, bool grid, hipStream_t s);
 bool affine_planar_geometry(int64_t Yi, int64_t Xi, int64_t pitch, const double M[12], int* box_y, int* box_x,
-                            int* slots, int64_t* lds_bytes, int* tile = nullptr);
+                            int* slots, int64_t* lds_bytes, int* tile = nullptr, int waves = 8);
 // affine_box.hip: any map whose per-block source box fits in LDS (z-coupled maps included),
 // either border rule; false = not applicable
 bool launch_affine_box(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, int64_t pitch, int64_t plane, float* out,

@@ -33,7 +33,7 @@ namespace {
 // the shape of the registrations between two modalities of one instrument; maps that DECIMATE in the plane (a 2 x
 // coarser target grid) have source boxes of 160+ KB at that size and used to fall to the gather
 // kernel: they take the largest of 32 x 64, 16 x 128, 16 x 64 whose ring fits (lsr::affine_planar_geometry).
-constexpr int kThreads = 512;
+constexpr int kWaves = 8;         // the default workgroup: 8 waves; 4 for maps with large source boxes (launch_affine_planar)
 struct TileShape { int nr, nc; };
 constexpr TileShape kTiles[] = {{4, 2}, {4, 1}, {2, 2}, {2, 1}};
 
@@ -89,9 +89,11 @@ __device__ __forceinline__ double plane_coord(double yo, double xo, double m1, d
 // cval times its weight and samples up to one voxel outside still blend (mode="constant" drops the whole
 // sample).  The box then starts at source index -1 at the earliest: row / column 0 of the box may stand for
 // index -1 (a duplicate of index 0 in LDS, replaced by cval through the tap's flag).
-template <bool F32, bool GRID, int NR, int NC>
-__global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p) {  // (two workgroups per CU: <= 128 VGPRs)
-  constexpr int kTY = 8 * NR, kTX = 64 * NC, kPts = NR * NC;
+// NW waves per workgroup (8, or 4: half-height tiles, twice the workgroups per CU)
+template <bool F32, bool GRID, int NR, int NC, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void affine_planar_kernel(PlanarArgs p) {  // (<= 128 VGPRs: four waves per SIMD)
+  constexpr int kThreads = 64 * NW;
+  constexpr int kTY = NW * NR, kTX = 64 * NC, kPts = NR * NC;
   extern __shared__ f32x4 smem4[];
   const float* const smem = reinterpret_cast<const float*>(smem4);
   const unsigned lds_base =
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
   double wy0[kPts], wy1[kPts], wx0[kPts], wx1[kPts];
 #pragma unroll
   for (int i = 0; i < kPts; ++i) {
-    const int yo = y0 + wave + 8 * (i / NC), xo = x0 + lane + 64 * (i % NC);
+    const int yo = y0 + wave + NW * (i / NC), xo = x0 + lane + 64 * (i % NC);
     const double cy = plane_coord(static_cast<double>(yo), static_cast<double>(xo), p.b, p.c, p.ty);
     const double cx = plane_coord(static_cast<double>(yo), static_cast<double>(xo), p.d, p.e, p.tx);
     const bool in_output = yo < p.Yo && xo < p.Xo;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
   const bool tile_full = y0 + kTY <= p.Yo && x0 + kTX <= p.Xo;   // every thread stores all its pixels
   bool in_out[NR], col_out[NC];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) in_out[r] = y0 + wave + 8 * r < p.Yo;
+  for (int r = 0; r < NR; ++r) in_out[r] = y0 + wave + NW * r < p.Yo;
 #pragma unroll
   for (int c = 0; c < NC; ++c) col_out[c] = x0 + lane + 64 * c < p.Xo;
   if constexpr (!GRID) {
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
 #pragma unroll
         for (int i = 0; i < kPts; ++i)
           if (in_out[i / NC] && col_out[i % NC])
-            store_one(orow + static_cast<int64_t>(wave + 8 * (i / NC)) * p.opitch + lane + 64 * (i % NC), p.cval);
+            store_one(orow + static_cast<int64_t>(wave + NW * (i / NC)) * p.opitch + lane + 64 * (i % NC), p.cval);
       }
       return;
     }
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
   // ---- staging: 16-byte chunks of the box, lane-linear in LDS -------------------------------
   const int chunks_x = box_x >> 2;
   const int n_chunks = box_y * chunks_x;
-  constexpr int kMaxLoads = 8;  // host keeps n_chunks <= 8 * 512
+  constexpr int kMaxLoads = 8;  // host keeps n_chunks <= 8 * threads
   int s_voff[kMaxLoads];
 #pragma unroll
   for (int k = 0; k < kMaxLoads; ++k) {
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(kThreads, 4) void affine_planar_kernel(PlanarArgs p
       for (int k = 0; k < G; ++k) {
         const int i = h + k;
         if (in_out[i / NC] && col_out[i % NC])
-          store_one(orow + static_cast<int64_t>(wave + 8 * (i / NC)) * p.opitch + lane + 64 * (i % NC), res[k]);
+          store_one(orow + static_cast<int64_t>(wave + NW * (i / NC)) * p.opitch + lane + 64 * (i % NC), res[k]);
       }
     }
     // (no barrier here: the next iteration's DMAs are issued behind its own barrier, which every
@@ -389,7 +391,7 @@ namespace lsr {
 // Returns true if the planar kernel took the launch; false = not applicable, use the general one.
 // Geometry of the planar path for this matrix and moving volume; false = not applicable.
 bool affine_planar_geometry(int64_t Yi, int64_t Xi, int64_t pitch, const double M[12], int* box_y_out, int* box_x_out,
-                            int* slots_out, int64_t* lds_bytes_out, int* tile_out) {
+                            int* slots_out, int64_t* lds_bytes_out, int* tile_out, int waves) {
   if (!volume_in_range(1, Yi, Xi) || !strides_in_range(pitch, 0)) return false;
   if (M[1] != 0.0 || M[2] != 0.0 || M[4] != 0.0 || M[8] != 0.0) return false;
   const double a = M[0] < 0 ? -M[0] : M[0];
@@ -402,13 +404,13 @@ bool affine_planar_geometry(int64_t Yi, int64_t Xi, int64_t pitch, const double 
   // 1e-6 absorbs the different summation order on the device) + 1 for the upper neighbour [+ 3 + 3: 16-byte alignment
   // of the first column, rows rounded up to whole chunks]
   for (int t = 0; t < static_cast<int>(sizeof(kTiles) / sizeof(kTiles[0])); ++t) {
-    const int ty = 8 * kTiles[t].nr, tx = 64 * kTiles[t].nc;
+    const int ty = waves * kTiles[t].nr, tx = 64 * kTiles[t].nc;
     const double ey = ab(M[5]) * (ty - 1) + ab(M[6]) * (tx - 1), ex = ab(M[9]) * (ty - 1) + ab(M[10]) * (tx - 1);
     if (!(ey < 4096.0) || !(ex < 4096.0)) continue;
     const int box_y = static_cast<int>(ey + 1e-6) + 3;
     const int box_x = (static_cast<int>(ex + 1e-6) + 3 + 3 + 3) & ~3;
     const int64_t lds_bytes = int64_t(slots) * ((int64_t(box_y) * box_x + 255) & ~int64_t(255)) * 4;
-    if (lds_bytes > 150 * 1024 || int64_t(box_y) * (box_x / 4) > 8 * kThreads) continue;
+    if (lds_bytes > 150 * 1024 || int64_t(box_y) * (box_x / 4) > 8 * 64 * waves) continue;
     *box_y_out = box_y; *box_x_out = box_x; *slots_out = slots; *lds_bytes_out = lds_bytes;
     if (tile_out != nullptr) *tile_out = t;
     return true;
@@ -422,8 +424,26 @@ bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, i
   int box_y, box_x, slots, tile = 0;
   int64_t lds_bytes;
   if (plane % 4 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return false;
-  if (!affine_planar_geometry(Yi, Xi, pitch, M, &box_y, &box_x, &slots, &lds_bytes, &tile)) return false;
-  const int kTY = 8 * kTiles[tile].nr, kTX = 64 * kTiles[tile].nc;
+  int waves = kWaves;
+  if (!affine_planar_geometry(Yi, Xi, pitch, M, &box_y, &box_x, &slots, &lds_bytes, &tile, waves)) return false;
+  // Maps whose source box is much larger than the tile because they ROTATE in the plane (10 degrees and more) run 3-16 %
+  // faster on half-height tiles with four waves (twice the workgroups per CU, their per-plane barriers independent);
+  // near-identity maps (config 3: box 1.3 x the tile) lose 2-6 % there (round 4, profiles/r04_sweep_geometry.jsonl).
+  {
+    const int64_t tile_px = int64_t(waves * kTiles[tile].nr) * (64 * kTiles[tile].nc);
+    // (with fewer tiles than CUs the z chunks already spread the work; halving the tiles there lost 11-28 %)
+    const int64_t tiles8 = ceil_div(Yo, int64_t(waves * kTiles[tile].nr)) * ceil_div(Xo, int64_t(64 * kTiles[tile].nc));
+    // (rotations only: a 2x decimation gains 5-13 % on a full-size target and loses 10-25 % on a half-size one)
+    auto mag = [](double v) { return v < 0 ? -v : v; };
+    bool four = int64_t(box_y) * box_x * 10 > tile_px * 16 && tiles8 >= 256 && (mag(M[6]) > 0.1 || mag(M[9]) > 0.1);
+    if (const char* e = std::getenv("LSR_PLANAR_WAVES")) four = std::atoi(e) == 4;      // measurement override
+    int by, bx, sl, tl = 0;
+    int64_t lb;
+    if (four && affine_planar_geometry(Yi, Xi, pitch, M, &by, &bx, &sl, &lb, &tl, 4)) {
+      waves = 4; box_y = by; box_x = bx; slots = sl; lds_bytes = lb; tile = tl;
+    }
+  }
+  const int kTY = waves * kTiles[tile].nr, kTX = 64 * kTiles[tile].nc;
 
   PlanarArgs p;
   p.in = in; p.out = out;
@@ -458,19 +478,21 @@ bool launch_affine_planar(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, i
   if (padded >= (int64_t(1) << 30)) return false;
   p.per_xcd = static_cast<int>(ceil_div(padded, 8));
   const int64_t blocks = f32 ? tiles * ceil_div(Zo, chunk) : int64_t(p.per_xcd) * 8;
-  static std::atomic<uint64_t> lds_allowed[16] = {};
+  static std::atomic<uint64_t> lds_allowed[32] = {};
   using Kernel = void (*)(PlanarArgs);
-#define LSR_PLANAR_TILE(NR, NC)                                                                       \
-  {affine_planar_kernel<false, false, NR, NC>, affine_planar_kernel<true, false, NR, NC>,              \
-   affine_planar_kernel<false, true, NR, NC>, affine_planar_kernel<true, true, NR, NC>}
-  static const Kernel kernels[4][4] = {LSR_PLANAR_TILE(4, 2), LSR_PLANAR_TILE(4, 1), LSR_PLANAR_TILE(2, 2),
-                                       LSR_PLANAR_TILE(2, 1)};   // [tile][2 * grid + f32], tiles as kTiles
-#undef LSR_PLANAR_TILE
-  const Kernel kernel = kernels[tile][2 * grid + f32];
-  if (lsr::allow_dynamic_lds(reinterpret_cast<const void*>(kernel), 150 * 1024, lds_allowed[4 * tile + 2 * grid + f32],
-                             "affine_planar_kernel") != LSR_OK)
+#define LSR_PLANAR_TILE(NR, NC, NW)                                                                            \
+  {affine_planar_kernel<false, false, NR, NC, NW>, affine_planar_kernel<true, false, NR, NC, NW>,              \
+   affine_planar_kernel<false, true, NR, NC, NW>, affine_planar_kernel<true, true, NR, NC, NW>}
+  static const Kernel kernels[2][4][4] = {
+      {LSR_PLANAR_TILE(4, 2, 8), LSR_PLANAR_TILE(4, 1, 8), LSR_PLANAR_TILE(2, 2, 8), LSR_PLANAR_TILE(2, 1, 8)},
+      {LSR_PLANAR_TILE(4, 2, 4), LSR_PLANAR_TILE(4, 1, 4), LSR_PLANAR_TILE(2, 2, 4), LSR_PLANAR_TILE(2, 1, 4)}};
+#undef LSR_PLANAR_TILE                                          // [waves == 4][tile][2 * grid + f32], tiles as kTiles
+  const int w4 = waves == 4 ? 1 : 0;
+  const Kernel kernel = kernels[w4][tile][2 * grid + f32];
+  if (lsr::allow_dynamic_lds(reinterpret_cast<const void*>(kernel), 150 * 1024,
+                             lds_allowed[16 * w4 + 4 * tile + 2 * grid + f32], "affine_planar_kernel") != LSR_OK)
     return false;   // the caller runs the gather kernel
-  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
+  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(64 * waves),
                      static_cast<size_t>(lds_bytes), s, p);
   return true;
 }
