@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -44,6 +45,8 @@ struct DeskewArgs {
   int grid;                 // border rule: 0 = scipy "constant", 1 = "grid-constant" (blend towards 0 across the z border)
   int tile_x;               // X' handled per workgroup (<= kTileX, chosen so the slab fits)
   int64_t tiles_x, tiles_y; // workgroup grid, flattened: x fastest, then y, then zo
+  int64_t blocks;           // tiles_x * tiles_y * Zo
+  int xcd_swizzle;          // 1: XCD-contiguous tile order (the grid is padded to a multiple of 8)
   const float* flat_pattern;  // FLAT: (Y, X) per-pixel median over Z (flatfield.hip)
   const float* flat_mean;     // FLAT: its mean, a device scalar
 };
@@ -62,7 +65,16 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
   if (threadIdx.x < kPitch) zero_row[threadIdx.x] = 0.0f;   // visible after the first barrier below
 
   const int tid = threadIdx.x;
+  // Workgroups b, b + 8, ... run on one XCD: each XCD takes a contiguous run of the tile order (x fastest), so that
+  // neighbouring X' tiles -- whose 256-byte store runs share a cache line wherever the output row pitch is not a
+  // multiple of 32 floats (a dense (171, 2048, 2270) volume: every row) -- complete that line in ONE L2 instead of
+  // evicting two partial lines to HBM, and the slab rows they share are fetched once.  p.xcd_swizzle = 0: as numbered.
   int64_t bid = blockIdx.x;
+  if (p.xcd_swizzle) {
+    const int64_t per = (p.blocks + 7) >> 3;
+    bid = (bid & 7) * per + (bid >> 3);
+    if (bid >= p.blocks) return;
+  }
   const int64_t tx = bid % p.tiles_x;
   bid /= p.tiles_x;
   const int64_t ty = bid % p.tiles_y;
@@ -270,7 +282,10 @@ int deskew_impl(const char* what, const void* in, bool u16, int64_t Z, int64_t Y
 
   p.flat_pattern = flat_pattern;
   p.flat_mean = flat_mean;
-  const dim3 grid(static_cast<unsigned>(blocks)), block(kThreads);
+  p.blocks = blocks;
+  p.xcd_swizzle = 1;
+  if (const char* e = std::getenv("LSR_DESKEW_SWIZZLE")) p.xcd_swizzle = e[0] != '0';   // measurement override
+  const dim3 grid(static_cast<unsigned>(p.xcd_swizzle ? 8 * ((blocks + 7) / 8) : blocks)), block(kThreads);
   hipStream_t s = lsr::as_stream(stream);
   if (u16 && flat_pattern != nullptr) hipLaunchKernelGGL((deskew_kernel<true, true>), grid, block, 0, s, p);
   else if (u16) hipLaunchKernelGGL((deskew_kernel<false, true>), grid, block, 0, s, p);
