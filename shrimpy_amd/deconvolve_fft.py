@@ -224,6 +224,8 @@ class FftRichardsonLucyPlan:
         elif (tuple(out.shape) != self.shape or out.dtype != torch.float32 or out.device != self.device
               or not out.is_contiguous()):
             raise ValueError(f"out must be a contiguous float32 {self.shape} tensor on {self.device}")
+        if out.data_ptr() == y.data_ptr():
+            raise ValueError("out must not alias y (y is read by every iteration)")
         init = y if x0 is None else _lib.require_device_f32(x0, "x0")
         if tuple(init.shape) != self.shape:
             raise ValueError(f"x0 must be {self.shape}, got {tuple(init.shape)}")
