@@ -548,3 +548,23 @@ def test_absurd_sizes_are_refused_before_anything_is_computed_with_them():
     assert lib.lsr_affine_path(huge, huge, huge, m, 0) == 0
     lib.lsr_rfft_rows_scratch_bytes.restype = ctypes.c_int64
     assert lib.lsr_rfft_rows_scratch_bytes(ctypes.c_int64(huge), ctypes.c_int64(huge)) == -1
+
+
+def test_fourier_domain_rl_grid_and_method_arguments():
+    """``deconvolve_fft.fft_grid``: per axis max(n + p // 2, p) rounded up to a length the transform kernels take (z and
+    y 5-smooth, x four times a 5-smooth number, at least 2 x . x 8); ``make_plan`` refuses an unknown method before it
+    touches a device."""
+    from shrimpy_amd.deconvolve import make_plan
+    from shrimpy_amd.deconvolve_fft import _next_smooth, fft_grid
+
+    assert [_next_smooth(n) for n in (1, 7, 11, 171, 178, 2055, 2057)] == [1, 8, 12, 180, 180, 2160, 2160]
+    assert fft_grid((171, 2048, 2270), (9, 7, 7)) == (180, 2160, 2304)          # config 2, the declared PSF's extents
+    assert fft_grid((171, 2048, 2270), (31, 37, 19)) == (192, 2160, 2304)       # a 30 x 36 x 18 bead patch, padded to odd
+    assert fft_grid((1, 35, 86), (1, 9, 25)) == (2, 40, 100)                    # single plane: the z leg transforms >= 2 points
+    assert fft_grid((2, 1, 3), (3, 1, 1)) == (3, 1, 8)                          # the x leg transforms >= 8 points
+    assert fft_grid((5, 6, 9), (9, 13, 17)) == (9, 15, 20)                      # thinner than the PSF: at least the PSF itself
+    for (shape, psf) in (((86, 2048, 2491), (15, 19, 19)), ((67, 2048, 2540), (15, 19, 19))):   # configs 4 and 5
+        g = fft_grid(shape, psf)
+        assert all(a >= n + p // 2 for a, n, p in zip(g, shape, psf)) and g[0] <= 256 and g[2] <= 4096 and g[2] % 4 == 0
+    with pytest.raises(ValueError, match="method"):
+        make_plan((8, 8, 8), np.ones((3, 3, 3), np.float32) / 27, "cpu", method="spectral")
