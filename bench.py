@@ -681,7 +681,9 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
             torch.cuda.empty_cache()
             if world > 1:
                 dist.barrier()
-            res = cli.run_store(root / "in.zarr", root / "out.zarr", settings)
+            res = cli.run_store(root / "in.zarr", root / "out.zarr", settings,
+                                compression=None if args.output_compression == "none" else args.output_compression,
+                                zarr_version="0.5" if args.output_compression != "none" else "0.4")
             units = res["units_total"]
             store = {
                 "positions": n_p, "timepoints": n_t, "units": units, "seconds": res["job_seconds"],
@@ -694,6 +696,7 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
                        + ("input in the acquisition's format (Zarr v3, one shard per volume, blosc-zstd chunks (1,1,32,ny,nx), "
                           f"frames decoded by {_blosc_backend()}), output uncompressed ~64 MB chunks, " if args.engine_format
                           else "uncompressed chunks (input (1,1,32,ny,nx), output ~64 MB), ")
+                       + (f"OUTPUT chunks {args.output_compression}, " if args.output_compression != "none" else "")
                        + f"scratch {root.parent}, input from the page cache; pinned staging slots + copy streams (cli.run_store)"),
             }
             if rank == 0:
@@ -808,6 +811,9 @@ def main():
     ap.add_argument("--engine-format", action="store_true",
                     help="config4/5 store leg: input plate as the acquisition writes it (Zarr v3, one shard per "
                          "volume around blosc-zstd chunks) instead of uncompressed chunks")
+    ap.add_argument("--output-compression", default="none", choices=["none", "zstd", "blosc-zstd"],
+                    help="config4/5 store leg: chunk compression of the OUTPUT plate (the CLI's own default is blosc-zstd, "
+                         "what the acquisition engine writes; the bench line's default leaves the float32 result raw)")
     ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"],
                     help="cpu: BASELINE configs[0] (config1, deskew only) through the product's host twins, no GPU touched")
     args = ap.parse_args()

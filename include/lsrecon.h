@@ -189,6 +189,19 @@ int lsr_affine_normal_equations_f32(const float* moving, int64_t Zi, int64_t Yi,
  */
 int lsr_blosc_host_codec(int compressor); /* 1 when the decoder of blosc compressor code 1 (lz4) / 3 (zlib) / 4 (zstd) is loadable */
 int lsr_blosc_decode_host(const uint8_t* frame, int64_t frame_bytes, uint8_t* out, int64_t out_bytes, int* typesize);
+/*
+ * The writer's side (host code): one c-blosc 1.x frame of `src` with zstd streams, one per block (not split), byte
+ * shuffle (shuffle = 1, typesize > 1) or none (0) -- the format the acquisition engine writes and the CLI's default
+ * output (mantis_engine.py:474-481).  Byte for byte the frames of the Python encoder (shrimpy_amd/io/codecs.py:
+ * blocksize or 256 KB cut to whole elements, a block zstd does not shrink stored verbatim, a frame that does not shrink
+ * in the "memcpyed" form), but callable from many threads at once.  dst: lsr_blosc_encode_bound(nbytes, typesize,
+ * blocksize) bytes; *out_bytes = the frame's size.  LSR_E_UNSUPPORTED: libzstd's compressor is not loadable, or a
+ * shuffle other than 0 / 1 (callers keep the Python encoder).
+ */
+int lsr_blosc_host_encoder(void);
+int64_t lsr_blosc_encode_bound(int64_t nbytes, int typesize, int64_t blocksize);
+int lsr_blosc_encode_host(const uint8_t* src, int64_t nbytes, int typesize, int clevel, int shuffle, int64_t blocksize,
+                          uint8_t* dst, int64_t cap, int64_t* out_bytes);
 /* CRC-32C (Castagnoli, the Zarr v3 `crc32c` codec: shard index, optionally every chunk) of n host bytes; seed = 0, or
  * the value of the bytes before `data` when a buffer is checked in pieces.  SSE4.2 crc32 instruction where the CPU has
  * it, slice-by-8 tables otherwise (lsr_crc32c_host_portable: always the tables -- the cross-check). */

@@ -97,6 +97,10 @@ SIGNATURES: dict[str, list] = {
                                         ctypes.c_void_p, _stream],
     "lsr_blosc_host_codec": [_int],
     "lsr_blosc_decode_host": [ctypes.c_void_p, _i64, ctypes.c_void_p, _i64, ctypes.POINTER(ctypes.c_int)],
+    "lsr_blosc_host_encoder": [],
+    "lsr_blosc_encode_bound": [_i64, _int, _i64],
+    "lsr_blosc_encode_host": [ctypes.c_void_p, _i64, _int, _int, _int, _i64, ctypes.c_void_p, _i64,
+                              ctypes.POINTER(ctypes.c_int64)],
     "lsr_correlate_z_max_taps": [],
     "lsr_correlate_z_f32": [_c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _c_f32p, _int,
                             _int, _f32, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _stream],

@@ -20,6 +20,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -29,12 +30,22 @@ namespace {
 
 using zstd_decompress_t = size_t (*)(void*, size_t, const void*, size_t);
 using zstd_is_error_t = unsigned (*)(size_t);
+using zstd_compress_t = size_t (*)(void*, size_t, const void*, size_t, int);
+using zstd_bound_t = size_t (*)(size_t);
+using zstd_create_cctx_t = void* (*)();
+using zstd_free_cctx_t = size_t (*)(void*);
+using zstd_compress_cctx_t = size_t (*)(void*, void*, size_t, const void*, size_t, int);
 using lz4_decompress_t = int (*)(const char*, char*, int, int);
 using zlib_uncompress_t = int (*)(unsigned char*, unsigned long*, const unsigned char*, unsigned long);
 
 struct Decoders {
   zstd_decompress_t zstd = nullptr;
   zstd_is_error_t zstd_is_error = nullptr;
+  zstd_compress_t zstd_compress = nullptr;     // the writer's side (lsr_blosc_encode_host)
+  zstd_bound_t zstd_bound = nullptr;
+  zstd_create_cctx_t zstd_create_cctx = nullptr;   // one context per frame: ZSTD_compress alone builds and frees one per
+  zstd_free_cctx_t zstd_free_cctx = nullptr;       // call -- an mmap / munmap pair per 256 KB block, serialised process-wide
+  zstd_compress_cctx_t zstd_compress_cctx = nullptr;
   lz4_decompress_t lz4 = nullptr;
   zlib_uncompress_t zlib = nullptr;
 };
@@ -55,6 +66,13 @@ const Decoders& decoders() {
       r.zstd = reinterpret_cast<zstd_decompress_t>(dlsym(h, "ZSTD_decompress"));
       r.zstd_is_error = reinterpret_cast<zstd_is_error_t>(dlsym(h, "ZSTD_isError"));
       if (r.zstd == nullptr || r.zstd_is_error == nullptr) r.zstd = nullptr;
+      r.zstd_compress = reinterpret_cast<zstd_compress_t>(dlsym(h, "ZSTD_compress"));
+      r.zstd_bound = reinterpret_cast<zstd_bound_t>(dlsym(h, "ZSTD_compressBound"));
+      r.zstd_create_cctx = reinterpret_cast<zstd_create_cctx_t>(dlsym(h, "ZSTD_createCCtx"));
+      r.zstd_free_cctx = reinterpret_cast<zstd_free_cctx_t>(dlsym(h, "ZSTD_freeCCtx"));
+      r.zstd_compress_cctx = reinterpret_cast<zstd_compress_cctx_t>(dlsym(h, "ZSTD_compressCCtx"));
+      if (r.zstd_is_error == nullptr || r.zstd_bound == nullptr) r.zstd_compress = nullptr;
+      if (r.zstd_create_cctx == nullptr || r.zstd_free_cctx == nullptr) r.zstd_compress_cctx = nullptr;
     }
     if (void* h = open_first("LSR_LIBLZ4", "liblz4.so.1", "liblz4.so"))
       r.lz4 = reinterpret_cast<lz4_decompress_t>(dlsym(h, "LZ4_decompress_safe"));
@@ -93,7 +111,123 @@ void unshuffle_block(const uint8_t* src, uint8_t* dst, int64_t nbytes, int T) {
   std::memcpy(dst + n * T, src + n * T, static_cast<size_t>(nbytes - n * T));
 }
 
+// dst[k * n + i] = src[i * T + k]; trailing nbytes % T bytes verbatim (the inverse of unshuffle_block)
+void shuffle_block(const uint8_t* src, uint8_t* dst, int64_t nbytes, int T) {
+  const int64_t n = nbytes / T;
+  if (T == 4) {
+    uint8_t *a = dst, *b = dst + n, *c = dst + 2 * n, *d = dst + 3 * n;
+    for (int64_t i = 0; i < n; ++i) {
+      a[i] = src[4 * i];
+      b[i] = src[4 * i + 1];
+      c[i] = src[4 * i + 2];
+      d[i] = src[4 * i + 3];
+    }
+  } else if (T == 2) {
+    uint8_t *lo = dst, *hi = dst + n;
+    for (int64_t i = 0; i < n; ++i) {
+      lo[i] = src[2 * i];
+      hi[i] = src[2 * i + 1];
+    }
+  } else {
+    for (int k = 0; k < T; ++k)
+      for (int64_t i = 0; i < n; ++i) dst[k * n + i] = src[i * T + k];
+  }
+  std::memcpy(dst + n * T, src + n * T, static_cast<size_t>(nbytes - n * T));
+}
+
+inline void put32(uint8_t* p, uint32_t v) {
+  p[0] = static_cast<uint8_t>(v); p[1] = static_cast<uint8_t>(v >> 8); p[2] = static_cast<uint8_t>(v >> 16);
+  p[3] = static_cast<uint8_t>(v >> 24);
+}
+
 }  // namespace
+
+// 1 when lsr_blosc_encode_host can write zstd streams here (libzstd's compressor is loadable)
+extern "C" int lsr_blosc_host_encoder(void) { return decoders().zstd_compress != nullptr; }
+
+// The writer's side: one c-blosc 1.x frame of `src` (nbytes < 2 GiB) with zstd streams, one per block (blocks are not
+// split -- what c-blosc itself does for zstd), byte shuffle for typesize > 1 when `shuffle` is 1, none when 0.  The
+// frames the Python encoder of shrimpy_amd/io/codecs.py writes, byte for byte (same block size rule: `blocksize` or
+// 256 KB, cut to whole elements; a block zstd does not shrink is stored verbatim; a frame that does not shrink at all
+// takes the "memcpyed" form) -- but with the GIL released, so the writer's thread pool scales: the CLI's default output
+// (blosc-zstd, what the acquisition engine writes: shrimpy/mantis/mantis_engine.py:474-481) took 0.60 s per config-4
+// result through the Python encoder on 16 threads.  `dst`: at least nbytes + 16 + 4 * blocks + 4 * blocks bytes
+// (lsr_blosc_encode_bound); *out_bytes receives the frame's size.
+extern "C" int64_t lsr_blosc_encode_bound(int64_t nbytes, int typesize, int64_t blocksize) {
+  if (nbytes < 0 || nbytes > 0x7FFFFFFF - 16) return -1;
+  const int T = typesize >= 1 && typesize <= 255 ? typesize : 1;
+  int64_t bs = blocksize > 0 ? blocksize : 256 * 1024;
+  bs = nbytes >= T ? std::max<int64_t>(T, std::min(bs, nbytes) / T * T) : std::max<int64_t>(nbytes, 1);
+  const int64_t nblocks = nbytes ? (nbytes + bs - 1) / bs : 0;
+  return 16 + nbytes + 8 * nblocks + 64;
+}
+
+extern "C" int lsr_blosc_encode_host(const uint8_t* src, int64_t nbytes, int typesize, int clevel, int shuffle,
+                                     int64_t blocksize, uint8_t* dst, int64_t cap, int64_t* out_bytes) {
+  LSR_REQUIRE_PTR(dst);
+  LSR_REQUIRE_PTR(out_bytes);
+  LSR_REQUIRE(nbytes >= 0 && nbytes <= 0x7FFFFFFF - 16, LSR_E_ARG, "a blosc 1.x frame holds less than 2 GiB, got %lld bytes",
+              (long long)nbytes);
+  if (nbytes > 0) LSR_REQUIRE_PTR(src);
+  LSR_REQUIRE(shuffle == 0 || shuffle == 1, LSR_E_UNSUPPORTED, "shuffle %d: the native encoder writes byte shuffle (1) or none (0)",
+              shuffle);
+  LSR_REQUIRE(clevel >= 0 && clevel <= 22, LSR_E_ARG, "zstd level %d outside [0, 22]", clevel);
+  const Decoders& z = decoders();
+  LSR_REQUIRE(z.zstd_compress != nullptr, LSR_E_UNSUPPORTED, "libzstd's compressor is not loadable here (dlopen)");
+  const int T = typesize >= 1 && typesize <= 255 ? typesize : 1;
+  int64_t bs = blocksize > 0 ? blocksize : 256 * 1024;
+  bs = nbytes >= T ? std::max<int64_t>(T, std::min(bs, nbytes) / T * T) : std::max<int64_t>(nbytes, 1);
+  const int64_t nblocks = nbytes ? (nbytes + bs - 1) / bs : 0;
+  LSR_REQUIRE(cap >= lsr_blosc_encode_bound(nbytes, typesize, blocksize), LSR_E_ARG,
+              "destination of %lld bytes is smaller than lsr_blosc_encode_bound", (long long)cap);
+  int flags = 0x10 | (4 << 5);                       // blocks not split, zstd
+  const bool shuffled = shuffle == 1 && T > 1;
+  if (shuffled) flags |= 0x1;
+  const size_t bound = z.zstd_bound(static_cast<size_t>(bs));
+  uint8_t* scratch = static_cast<uint8_t*>(std::malloc(static_cast<size_t>(bs) + bound));
+  LSR_REQUIRE(scratch != nullptr, LSR_E_ARG, "out of memory for a %lld-byte block", (long long)bs);
+  uint8_t* const shuf = scratch;
+  uint8_t* const comp = scratch + bs;
+  void* const cctx = z.zstd_compress_cctx != nullptr ? z.zstd_create_cctx() : nullptr;
+  int64_t pos = 16 + 4 * nblocks;
+  bool stored_whole = false;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    const int64_t off = b * bs, n = std::min(bs, nbytes - off);
+    const uint8_t* block = src + off;
+    if (shuffled) {
+      shuffle_block(block, shuf, n, T);
+      block = shuf;
+    }
+    const size_t c = cctx != nullptr ? z.zstd_compress_cctx(cctx, comp, bound, block, static_cast<size_t>(n), clevel)
+                                     : z.zstd_compress(comp, bound, block, static_cast<size_t>(n), clevel);
+    const bool verbatim = z.zstd_is_error(c) || static_cast<int64_t>(c) >= n;
+    const int64_t cb = verbatim ? n : static_cast<int64_t>(c);
+    if (pos + 4 + cb > cap || pos + 4 + cb >= nbytes + 16) {   // not shrinking: the memcpyed form below
+      stored_whole = true;
+      break;
+    }
+    put32(dst + 16 + 4 * b, static_cast<uint32_t>(pos));
+    put32(dst + pos, static_cast<uint32_t>(cb));
+    std::memcpy(dst + pos + 4, verbatim ? block : comp, static_cast<size_t>(cb));
+    pos += 4 + cb;
+  }
+  std::free(scratch);
+  if (cctx != nullptr) z.zstd_free_cctx(cctx);
+  if (stored_whole || pos >= nbytes + 16) {
+    flags |= 0x2;
+    if (nbytes) std::memcpy(dst + 16, src, static_cast<size_t>(nbytes));
+    pos = 16 + nbytes;
+  }
+  dst[0] = 2;                                        // BLOSC_VERSION_FORMAT
+  dst[1] = 1;                                        // zstd format version
+  dst[2] = static_cast<uint8_t>(flags);
+  dst[3] = static_cast<uint8_t>(T);
+  put32(dst + 4, static_cast<uint32_t>(nbytes));
+  put32(dst + 8, static_cast<uint32_t>(bs));
+  put32(dst + 12, static_cast<uint32_t>(pos));
+  *out_bytes = pos;
+  return LSR_OK;
+}
 
 // 1 when the decoder of blosc compressor code `compressor` (1 lz4, 3 zlib, 4 zstd) is loadable here
 extern "C" int lsr_blosc_host_codec(int compressor) {

@@ -361,6 +361,28 @@ def _native_decode(frame, dest: np.ndarray) -> bool:
     return True
 
 
+def _native_encode(arr: np.ndarray, typesize: int, clevel: int, shuffle: int, blocksize: int):
+    """One frame through ``lsr_blosc_encode_host`` (zstd streams, byte shuffle or none: the frames of
+    :func:`_py_blosc_encode`, byte for byte, with the GIL released); ``None`` when the library is not built or
+    libzstd's compressor is not loadable."""
+    lib = _native_lib()
+    if lib is None or not hasattr(lib, "lsr_blosc_encode_host") or not lib.lsr_blosc_host_encoder():
+        return None
+    lib.lsr_blosc_encode_bound.restype = ctypes.c_int64
+    cap = int(lib.lsr_blosc_encode_bound(arr.size, typesize, blocksize))
+    if cap < 0:
+        return None
+    buf = np.empty(cap, dtype=np.uint8)
+    n = ctypes.c_int64(0)
+    rc = lib.lsr_blosc_encode_host(arr.ctypes.data, arr.size, typesize, clevel, 1 if shuffle == SHUFFLE_BYTE else 0,
+                                   blocksize, buf.ctypes.data, cap, ctypes.byref(n))
+    if rc == -3:                                     # LSR_E_UNSUPPORTED
+        return None
+    if rc != 0:
+        raise ValueError(lib.lsr_last_error().decode("utf-8", "replace"))
+    return buf[:n.value].tobytes()
+
+
 def blosc_backend() -> str:
     """Who decodes blosc frames: ``"libblosc"`` (ctypes) or ``"numcodecs"`` when a C blosc is
     loadable, ``"lsrecon"`` for this package's own frame walker over the system zstd, else
@@ -617,4 +639,10 @@ def blosc_encode(data, typesize: int, cname: str = "zstd", clevel: int = 1, shuf
         if n <= 0:
             raise RuntimeError(f"blosc_compress_ctx failed ({n})")
         return buf.raw[:n]
+    if backend in (None, "lsrecon") and cname == "zstd" and int(shuffle) in (SHUFFLE_NONE, SHUFFLE_BYTE):
+        frame = _native_encode(arr, typesize, int(clevel), int(shuffle), int(blocksize))
+        if frame is not None:
+            return frame
+    if backend == "lsrecon":
+        raise CodecUnavailable("the native frame encoder (liblsrecon) is not built or does not take these parameters")
     return _py_blosc_encode(arr, typesize, cname, int(clevel), int(shuffle), int(blocksize))

@@ -504,3 +504,40 @@ def test_a_damaged_stream_is_a_value_error_whichever_decoder_meets_it():
             except ValueError:
                 refused += 1
         assert refused > 0
+
+
+@pytest.mark.parametrize("dtype,n", [("float32", 1000), ("uint16", (1 << 20) + 3), ("uint8", 7), ("float32", 0),
+                                     ("float32", 300000), ("float64", 5000)])
+def test_native_frame_encoder_writes_the_python_encoders_frames(dtype, n):
+    """``lsr_blosc_encode_host`` (csrc/blosc_frame.hip): the writer's side of the blosc-zstd output the CLI defaults to.
+    Same header fields and block structure as the Python encoder (the zstd streams themselves may differ with the zstd
+    library behind each), decoded back by the native walker, by the Python walker and -- where one is loadable -- by
+    c-blosc itself; an incompressible array takes the memcpyed form; many threads at once."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    if codecs._native_lib() is None or not codecs._native_lib().lsr_blosc_host_encoder():
+        pytest.skip("liblsrecon is not built or libzstd's compressor is not loadable")
+    rng = np.random.default_rng(n + 1)
+    a = np.round(rng.random(n) * 100).astype(dtype)
+    for shuffle in (codecs.SHUFFLE_BYTE, codecs.SHUFFLE_NONE):
+        for blocksize in (0, 4096, 1000):
+            nat = codecs.blosc_encode(a, a.itemsize, shuffle=shuffle, blocksize=blocksize, backend="lsrecon")
+            py = codecs._py_blosc_encode(a.view(np.uint8), a.itemsize, "zstd", 1, shuffle, blocksize)
+            hn, hp = codecs.blosc_header(nat), codecs.blosc_header(py)
+            for key in ("version", "versionlz", "typesize", "nbytes", "blocksize", "compressor"):
+                assert hn[key] == hp[key], key
+            assert hn["flags"] & ~2 == hp["flags"] & ~2 and hn["cbytes"] == len(nat)
+            for backend in ("lsrecon", "python", None):
+                np.testing.assert_array_equal(codecs.blosc_decode(nat, backend=backend), a.view(np.uint8))
+    noise = rng.integers(0, 256, 50000, dtype=np.uint8)
+    frame = codecs.blosc_encode(noise, 1, backend="lsrecon")
+    assert codecs.blosc_header(frame)["flags"] & 2 and len(frame) == noise.size + 16        # memcpyed
+    np.testing.assert_array_equal(codecs.blosc_decode(frame, backend="python"), noise)
+    if n >= 1000:
+        parts = [np.ascontiguousarray(a[i::4]) for i in range(4)]
+        with ThreadPoolExecutor(4) as pool:
+            frames = list(pool.map(lambda p: codecs.blosc_encode(p, p.itemsize, backend="lsrecon"), parts))
+        for p, f in zip(parts, frames):
+            np.testing.assert_array_equal(codecs.blosc_decode(f, backend="lsrecon"), p.view(np.uint8))
+    with pytest.raises(codecs.CodecUnavailable):
+        codecs.blosc_encode(a, a.itemsize, shuffle=codecs.SHUFFLE_BIT, backend="lsrecon")
