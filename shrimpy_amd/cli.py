@@ -18,6 +18,7 @@ Every (position, timepoint, channel) volume is an independent unit.  Launched un
 
 from __future__ import annotations
 
+import functools
 import logging
 import os
 
@@ -115,8 +116,9 @@ def resolve_inputs(paths) -> tuple[Path, tuple[str, ...]]:
     return root, tuple(keys)
 
 
-def _common(fn):
-    fn = click.option("-i", "--input-position-dirpaths", "input_path", required=True, cls=_EatAll,
+def _common(fn, input_required: bool = True):
+    fn = click.option("-i", "--input-position-dirpaths", "input_path", required=input_required, cls=_EatAll,
+                      default=None,
                       type=click.UNPROCESSED,
                       help="Input OME-Zarr store (HCS plate or single FOV), or the position directories of one plate "
                            "(a glob such as plate.zarr/*/*/*).")(fn)
@@ -499,22 +501,55 @@ def deskew(input_path, config, output_path, positions, zarr_version, resume, io_
                          io_backend=io_backend, compression=compression))
 
 
+def _target_shape_zyx(target_path) -> tuple[int, int, int]:
+    """(Z, Y, X) of the first position of the store (or position directories) ``-t`` names."""
+    from .io.omezarr import as_volume_array
+
+    root, keys = resolve_inputs(target_path)
+    store, positions_of = _open_source(root, "auto")
+    try:
+        for key, pos in positions_of.items():
+            if not keys or key in keys:
+                return tuple(int(v) for v in as_volume_array(pos["0"]).shape[-3:])
+    finally:
+        if hasattr(store, "close"):
+            store.close()
+    raise click.ClickException(f"-t: no position found in {root}")
+
+
 @cli.command()
-@_common
-def register(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression):
+@click.option("-s", "--source-position-dirpaths", "source_path", cls=_EatAll, type=click.UNPROCESSED, default=None,
+              help="The MOVING store / position directories ([RECALLED] biahub's spelling; the same as -i).")
+@click.option("-t", "--target-position-dirpaths", "target_path", cls=_EatAll, type=click.UNPROCESSED, default=None,
+              help="The TARGET store / position directories: its (Z, Y, X) is the output shape when the config gives "
+                   "no output_shape_zyx.")
+@functools.partial(_common, input_required=False)
+def register(input_path, source_path, target_path, config, output_path, positions, zarr_version, resume, io_backend,
+             compression):
     """Apply an affine registration (config: RegisterSettings YAML with affine_transform_zyx)."""
-    input_path, positions = _inputs(input_path, positions)
-    s = ReconstructSettings(registration=RegisterSettings.from_yaml(config))
+    if (input_path is None) == (source_path is None):
+        raise click.ClickException("name the moving store once: -i or -s")
+    input_path, positions = _inputs(input_path if input_path is not None else source_path, positions)
+    reg = RegisterSettings.from_yaml(config)
+    if target_path is not None and reg.output_shape_zyx is None:
+        reg = reg.model_copy(update={"output_shape_zyx": _target_shape_zyx(target_path)})
+    s = ReconstructSettings(registration=reg)
     click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
                          io_backend=io_backend, compression=compression))
 
 
 @cli.command()
+@click.option("--psf-dirpath", "psf_dirpath", default=None, type=click.Path(exists=True, path_type=Path),
+              help="A measured PSF: an OME-Zarr bead volume (as scripts/measure_psf.py:273-287 writes them) or a .npy "
+                   "ZYX array; overrides psf_path of the config ([RECALLED] biahub's -p, which is the position filter here).")
 @_common
-def deconvolve(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression):
+def deconvolve(input_path, psf_dirpath, config, output_path, positions, zarr_version, resume, io_backend, compression):
     """Richardson-Lucy deconvolution (config: DeconvolveSettings YAML)."""
     input_path, positions = _inputs(input_path, positions)
-    s = ReconstructSettings(deconvolution=DeconvolveSettings.from_yaml(config))
+    dec = DeconvolveSettings.from_yaml(config)
+    if psf_dirpath is not None:
+        dec = dec.model_copy(update={"psf_path": str(psf_dirpath)})
+    s = ReconstructSettings(deconvolution=dec)
     click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
                          io_backend=io_backend, compression=compression))
 

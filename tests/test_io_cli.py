@@ -197,6 +197,28 @@ def test_cli_commands_parse_configs_and_positions(tmp_path, cpu_cli, monkeypatch
     assert r.exit_code == 0, r.output
     assert (seen["resume"], seen["io_backend"], seen["compression"]) == (True, "native", "blosc-zstd")
 
+    # [RECALLED] biahub spellings: register -s (moving) / -t (target: its (Z, Y, X) is the output shape when the config
+    # names none); deconvolve --psf-dirpath overrides the config's psf_path
+    tgt = tmp_path / "target.zarr"
+    with open_ome_zarr(tgt, layout="hcs", mode="w", channel_names=["LF"], prefer_iohub=False) as plate:
+        plate.create_position("A", "1", "0").create_zeros("0", shape=(1, 1, 9, 21, 33), dtype="float32")
+    r = runner.invoke(cpu_cli.cli, ["register", "-s", str(src), "-t", str(tgt), "-c", str(reg), "-o", str(tmp_path / "o4")])
+    assert r.exit_code == 0, r.output
+    assert tuple(seen["settings"].registration.output_shape_zyx) == (9, 21, 33)
+    pinned = tmp_path / "register_shape.yml"
+    pinned.write_text(yaml.safe_dump(dict(affine_transform_zyx=np.eye(4).tolist(), output_shape_zyx=[4, 5, 6])))
+    r = runner.invoke(cpu_cli.cli, ["register", "-s", str(src), "-t", str(tgt), "-c", str(pinned), "-o", str(tmp_path / "o5")])
+    assert r.exit_code == 0 and tuple(seen["settings"].registration.output_shape_zyx) == (4, 5, 6)      # the config wins
+    r = runner.invoke(cpu_cli.cli, ["register", "-i", str(src), "-s", str(src), "-c", str(reg), "-o", str(tmp_path / "o6")])
+    assert r.exit_code != 0 and "-i or -s" in r.output
+    r = runner.invoke(cpu_cli.cli, ["register", "-c", str(reg), "-o", str(tmp_path / "o6")])
+    assert r.exit_code != 0 and "-i or -s" in r.output
+    np.save(tmp_path / "beads.npy", np.ones((3, 3, 3), np.float32) / 27)
+    r = runner.invoke(cpu_cli.cli, ["deconvolve", "-i", str(src), "-c", str(dec), "-o", str(tmp_path / "o7"),
+                                    "--psf-dirpath", str(tmp_path / "beads.npy")])
+    assert r.exit_code == 0, r.output
+    assert seen["settings"].deconvolution.psf_path == str(tmp_path / "beads.npy") and seen["settings"].deconvolution.iterations == 7
+
     bad = tmp_path / "bad.yml"
     bad.write_text(yaml.safe_dump(dict(iterations=7, bogus=1)))  # extra="forbid"
     r = runner.invoke(cpu_cli.cli, ["deconvolve", "-i", str(src), "-c", str(bad), "-o", str(tmp_path / "o3")])
