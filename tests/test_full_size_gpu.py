@@ -421,3 +421,32 @@ def test_rl_full_size_in_the_fourier_domain_agrees_with_the_dense_stencil_and_th
     crop_check(c, patch, 2, 0 + 2 * 2 * 9, 2270 - 32 - 2 * 2 * 9, core=32)      # near the y = 0 / x = X corner region
     del c
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("shape,grid", [((86, 2048, 2491), (96, 2160, 2500)), ((67, 2048, 2540), (75, 2160, 2560)),
+                                        ((33, 1001, 1777), (40, 1024, 1800))])
+def test_rl_in_the_fourier_domain_at_the_other_configs_sizes(device, shape, grid):
+    """The deskewed sizes of BASELINE configs 4 and 5 (and an odd one): x legs of 1250 = 2 5^4, 1280 = 2^8 5 and
+    900 = 2^2 3^2 5^2 points -- other radix mixes than config 2's 1152 = 2^7 3^2 -- two iterations with a bead-patch PSF
+    against the oracle on crops with full margin, at a corner, in the middle and at the far corner."""
+    import torch
+
+    import bench
+    from shrimpy_amd.deconvolve import make_plan
+
+    psf = bench.measured_psf((15, 19, 19))
+    g = torch.Generator(device=device).manual_seed(5)
+    y = torch.poisson(torch.rand(shape, device=device, generator=g) * 300 + 50, generator=g)
+    plan = make_plan(shape, psf, device)
+    assert plan.path == "fft" and plan.grid == grid
+    x = plan(y, iterations=2)
+    plan.release()
+    n, core = 2, 24
+    my = mx = n * 2 * 9
+    for (y0, x0) in ((my, mx), (shape[1] // 2, shape[2] // 2), (shape[1] - core - my, shape[2] - core - mx)):
+        crop = y[:, y0 - my:y0 + core + my, x0 - mx:x0 + core + mx].contiguous().cpu().numpy()
+        want = o.richardson_lucy(crop, psf, n, use_fft=True)[:, my:my + core, mx:mx + core].astype(np.float64)
+        got = x[:, y0:y0 + core, x0:x0 + core].cpu().numpy().astype(np.float64)
+        assert np.all(np.abs(got - want) <= 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max())
+    del x, y, plan
+    torch.cuda.empty_cache()
