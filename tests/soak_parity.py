@@ -240,7 +240,10 @@ def main():
         want = o.richardson_lucy(y, w, iterations=iters).astype(np.float64)
         ok = plan.path == "fft" and bool(np.all(np.abs(got - want) <= 2e-4 * np.abs(want) + 1e-4 * np.abs(want).max()))
         ref = o.rl_iteration_scalars(y, w, iters)
-        ok = ok and all(np.allclose(getattr(plan.last_stats, k), ref[k], rtol=2e-5) for k in ("flux", "change", "total"))
+        # (at a fixed point -- a one-tap PSF, a volume one voxel thick along the PSF's only long axis -- the true change is
+        # 0 and the transforms' rounding, 1e-7 of every voxel, is all there is to sum: an absolute floor of 2e-6 of the total)
+        floor = 2e-6 * float(np.max(ref["total"]))
+        ok = ok and all(np.allclose(getattr(plan.last_stats, k), ref[k], rtol=2e-5, atol=floor) for k in ("flux", "change", "total"))
         return ok, (pshape, vshape, iters)
 
     def host_twin_case(r):
