@@ -202,6 +202,27 @@ int lsr_blosc_host_encoder(void);
 int64_t lsr_blosc_encode_bound(int64_t nbytes, int typesize, int64_t blocksize);
 int lsr_blosc_encode_host(const uint8_t* src, int64_t nbytes, int typesize, int clevel, int shuffle, int64_t blocksize,
                           uint8_t* dst, int64_t cap, int64_t* out_bytes);
+/*
+ * The writer's side ON THE DEVICE (csrc/blosc_encode.hip): the volume at `src` (src_bytes of `typesize`-byte elements,
+ * 1 / 2 / 4) cut into consecutive chunks of frame_bytes -- the Zarr chunks of whole z planes -- each written as one
+ * c-blosc 1.x frame (zstd, byte shuffle, blocks of `blocksize` bytes, 0 = 64 K elements; at most 64 K elements per
+ * block), the last chunk zero-padded to frame_bytes as Zarr pads edge chunks.  Every shuffled byte plane of a block is
+ * one zstd block: RLE, Huffman-coded literals (four streams, no sequences) or Raw -- a subset of the format that any
+ * zstd decoder reads and that matches zstd level 1 (the acquisition's setting, mantis_engine.py:474-481) on shuffled
+ * image data to ~1 %.  Replaces numcodecs' Blosc(cname="zstd").encode behind iohub's writer
+ * (shrimpy/dynatrack/tracking.py:1337-1367) for results that are already in HBM.
+ * lsr_blosc_encode_device_plan: the frame count, the scratch bytes and the capacity of `out` the call needs.
+ * On return (stream order) frames[2 f] = byte offset of frame f in `out` (16-byte aligned), frames[2 f + 1] = its size.
+ * scratch / out / frames: device memory, 16-byte aligned.  The _cpu twin takes host pointers and writes the same bytes.
+ */
+int lsr_blosc_encode_device_plan(int64_t src_bytes, int typesize, int64_t frame_bytes, int64_t blocksize,
+                                 int64_t* n_frames, int64_t* scratch_bytes, int64_t* out_cap);
+int lsr_blosc_encode_device(const void* src, int64_t src_bytes, int typesize, int64_t frame_bytes, int64_t blocksize,
+                            void* scratch, int64_t scratch_bytes, uint8_t* out, int64_t out_cap, int64_t* frames,
+                            lsr_stream_t stream);
+int lsr_blosc_encode_device_cpu(const void* src, int64_t src_bytes, int typesize, int64_t frame_bytes, int64_t blocksize,
+                                void* scratch, int64_t scratch_bytes, uint8_t* out, int64_t out_cap, int64_t* frames,
+                                lsr_stream_t stream);
 /* CRC-32C (Castagnoli, the Zarr v3 `crc32c` codec: shard index, optionally every chunk) of n host bytes; seed = 0, or
  * the value of the bytes before `data` when a buffer is checked in pieces.  SSE4.2 crc32 instruction where the CPU has
  * it, slice-by-8 tables otherwise (lsr_crc32c_host_portable: always the tables -- the cross-check). */

@@ -101,6 +101,10 @@ SIGNATURES: dict[str, list] = {
     "lsr_blosc_encode_bound": [_i64, _int, _i64],
     "lsr_blosc_encode_host": [ctypes.c_void_p, _i64, _int, _int, _int, _i64, ctypes.c_void_p, _i64,
                               ctypes.POINTER(ctypes.c_int64)],
+    "lsr_blosc_encode_device_plan": [_i64, _int, _i64, _i64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                     ctypes.POINTER(ctypes.c_int64)],
+    "lsr_blosc_encode_device": [ctypes.c_void_p, _i64, _int, _i64, _i64, ctypes.c_void_p, _i64, ctypes.c_void_p, _i64,
+                                ctypes.c_void_p, _stream],
     "lsr_correlate_z_max_taps": [],
     "lsr_correlate_z_f32": [_c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _c_f32p, _int,
                             _int, _f32, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _stream],
@@ -175,7 +179,9 @@ for _name in ("lsr_deskew_f32", "lsr_deskew_u16", "lsr_affine_f32", "lsr_average
               # ... and of the DynaTrack estimators (csrc/estimators_host.hip)
               "lsr_minmax_f32", "lsr_histogram_f32", "lsr_weighted_centroid_f32", "lsr_mask_centroid_f32",
               "lsr_blur_reflect_f32", "lsr_match_shape_f32", "lsr_cross_power_c64", "lsr_cross_power_into_c64",
-              "lsr_peak_abs_shifted_f32"):
+              "lsr_peak_abs_shifted_f32",
+              # ... and of the device-side chunk codecs (csrc/blosc_encode.hip)
+              "lsr_blosc_encode_device"):
     SIGNATURES[_name + "_cpu"] = SIGNATURES[_name]
 
 
