@@ -667,7 +667,8 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
         try:
             keys = [f"A/{p + 1}/0" for p in range(n_p)]
             if rank == 0:
-                fmt = dict(compress="blosc-zstd", shards="volume") if args.engine_format else {}
+                # the acquisition's layout: one shard per volume, blosc-zstd chunks of 32 planes, c-blosc's own 32 KB blocks
+                fmt = dict(compress="blosc-zstd", shards="volume", blocksize=32768) if args.engine_format else {}
                 with open_ome_zarr(root / "in.zarr", layout="hcs", mode="w", channel_names=["LS"],
                                    prefer_iohub=False, version="0.5" if args.engine_format else "0.4") as plate:
                     for p, key in enumerate(keys):
@@ -692,6 +693,7 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
                 # rank 0's stage clocks, seconds per unit (loader thread: wait_slot, load, stage_in; caller: wait_load,
                 # process, wait_store, stage_out; writer thread: collect, write)
                 "stage_s_per_unit": {k: round(v / max(res["units"], 1), 4) for k, v in res.get("stage_seconds", {}).items()},
+                "device_codec": res.get("device_codec"),
                 "io": ("native OME-Zarr reader/writer, "
                        + ("input in the acquisition's format (Zarr v3, one shard per volume, blosc-zstd chunks (1,1,32,ny,nx), "
                           f"frames decoded by {_blosc_backend()}), output uncompressed ~64 MB chunks, " if args.engine_format

@@ -223,6 +223,28 @@ int lsr_blosc_encode_device(const void* src, int64_t src_bytes, int typesize, in
 int lsr_blosc_encode_device_cpu(const void* src, int64_t src_bytes, int typesize, int64_t frame_bytes, int64_t blocksize,
                                 void* scratch, int64_t scratch_bytes, uint8_t* out, int64_t out_cap, int64_t* frames,
                                 lsr_stream_t stream);
+/*
+ * The reader's side ON THE DEVICE (csrc/blosc_decode.hip, csrc/zstd_lane.hpp): `comp` holds the compressed chunks of
+ * one volume as the reader threads pread() them from the shard (device memory, comp_bytes long); frames[2 f], frames[2 f + 1]
+ * = byte offset and size of chunk f's c-blosc frame in it (size 0: an absent chunk, zero-filled).  Every frame must
+ * decode to frame_nbytes bytes in blocks of `blocksize` with elements of `typesize` (1 / 2 / 4) -- the values of the first
+ * frame's header, which the host reads before the upload -- and use the zstd compressor (byte shuffle or none); chunk f
+ * lands at out + f * frame_nbytes, the last one cut at out_bytes.  One lane per blosc block runs a complete zstd decoder
+ * (RFC 8878: Huffman / FSE literals, sequences, repeat offsets), a second launch undoes the shuffle.  Replaces
+ * numcodecs' Blosc.decode behind iohub's reader (shrimpy/replay_camera.py:176-268) for stacks on their way into HBM.
+ * *status (device, 8 bytes) is 0 afterwards, or (block + 1) << 8 | code of the first block that failed (1 corrupt,
+ * 2 destination too small, 3 unsupported, 4 size mismatch) -- a damaged chunk never faults.  The _cpu twin runs the same
+ * decoder from host pointers.  lsr_zstd_lane_decode_cpu: one bare zstd frame through that decoder (tests, fuzzing).
+ */
+int lsr_blosc_decode_device_plan(int64_t n_frames, int64_t frame_nbytes, int64_t blocksize, int typesize,
+                                 int64_t* scratch_bytes);
+int lsr_blosc_decode_device(const uint8_t* comp, int64_t comp_bytes, const int64_t* frames, int64_t n_frames,
+                            int64_t frame_nbytes, int64_t blocksize, int typesize, uint8_t* out, int64_t out_bytes,
+                            void* scratch, int64_t scratch_bytes, unsigned long long* status, lsr_stream_t stream);
+int lsr_blosc_decode_device_cpu(const uint8_t* comp, int64_t comp_bytes, const int64_t* frames, int64_t n_frames,
+                                int64_t frame_nbytes, int64_t blocksize, int typesize, uint8_t* out, int64_t out_bytes,
+                                void* scratch, int64_t scratch_bytes, unsigned long long* status, lsr_stream_t stream);
+int lsr_zstd_lane_decode_cpu(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap, int64_t* out_n);
 /* CRC-32C (Castagnoli, the Zarr v3 `crc32c` codec: shard index, optionally every chunk) of n host bytes; seed = 0, or
  * the value of the bytes before `data` when a buffer is checked in pieces.  SSE4.2 crc32 instruction where the CPU has
  * it, slice-by-8 tables otherwise (lsr_crc32c_host_portable: always the tables -- the cross-check). */

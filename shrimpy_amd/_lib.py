@@ -105,6 +105,10 @@ SIGNATURES: dict[str, list] = {
                                      ctypes.POINTER(ctypes.c_int64)],
     "lsr_blosc_encode_device": [ctypes.c_void_p, _i64, _int, _i64, _i64, ctypes.c_void_p, _i64, ctypes.c_void_p, _i64,
                                 ctypes.c_void_p, _stream],
+    "lsr_blosc_decode_device_plan": [_i64, _i64, _i64, _int, ctypes.POINTER(ctypes.c_int64)],
+    "lsr_blosc_decode_device": [ctypes.c_void_p, _i64, ctypes.c_void_p, _i64, _i64, _i64, _int, ctypes.c_void_p, _i64,
+                                ctypes.c_void_p, _i64, ctypes.c_void_p, _stream],
+    "lsr_zstd_lane_decode_cpu": [ctypes.c_void_p, _i64, ctypes.c_void_p, _i64, ctypes.POINTER(ctypes.c_int64)],
     "lsr_correlate_z_max_taps": [],
     "lsr_correlate_z_f32": [_c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _c_f32p, _int,
                             _int, _f32, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _stream],
@@ -181,7 +185,7 @@ for _name in ("lsr_deskew_f32", "lsr_deskew_u16", "lsr_affine_f32", "lsr_average
               "lsr_blur_reflect_f32", "lsr_match_shape_f32", "lsr_cross_power_c64", "lsr_cross_power_into_c64",
               "lsr_peak_abs_shifted_f32",
               # ... and of the device-side chunk codecs (csrc/blosc_encode.hip)
-              "lsr_blosc_encode_device"):
+              "lsr_blosc_encode_device", "lsr_blosc_decode_device"):
     SIGNATURES[_name + "_cpu"] = SIGNATURES[_name]
 
 

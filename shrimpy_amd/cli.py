@@ -319,8 +319,12 @@ class _DoneLedger:
 
 def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings, positions=(),
               zarr_version: str = "0.4", reconstructor_factory=None, stage_through_pinned: bool = True,
-              resume: bool = False, io_backend: str = "auto", compression: str | None = None) -> dict:
+              resume: bool = False, io_backend: str = "auto", compression: str | None = None,
+              device_codec: bool | None = None) -> dict:
     """Apply ``settings`` to every (position, t, c) volume of ``input_path`` -> ``output_path``.
+
+    ``device_codec`` (default: on, ``LSR_DEVICE_CODEC=0`` turns it off): with a blosc-zstd output on a GPU the chunk
+    frames are written by the device (``io/device_codec.py``) and the host stores them as they are.
 
     On a GPU the volumes pass through pinned staging slots and copy streams
     (``staging.VolumeStager``) so that reading, upload, kernels, download and writing overlap.
@@ -331,8 +335,10 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
     """
     rank, world, device, created = _distributed()
     try:
+        if device_codec is None:
+            device_codec = os.environ.get("LSR_DEVICE_CODEC", "1") != "0"
         return _run_store(input_path, output_path, settings, positions, zarr_version, reconstructor_factory,
-                          stage_through_pinned, resume, io_backend, compression, rank, world, device)
+                          stage_through_pinned, resume, io_backend, compression, rank, world, device, device_codec)
     finally:
         if created:
             import torch.distributed as dist
@@ -341,7 +347,7 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
 
 
 def _run_store(input_path, output_path, settings, positions, zarr_version, reconstructor_factory,
-               stage_through_pinned, resume, io_backend, compression, rank, world, device) -> dict:
+               stage_through_pinned, resume, io_backend, compression, rank, world, device, device_codec=True) -> dict:
     import torch
 
     from .io.omezarr import as_volume_array, create_level, open_ome_zarr, position_scale
@@ -442,12 +448,21 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
     if skipped:
         logger.info("resume: %d of %d units already complete", skipped, len(units))
 
+    frames_in = [False]      # set below: the stager decodes the store's chunk frames on the device
+
     def load(u: Unit, out=None):
+        if frames_in[0] and out is not None:
+            return arrays[u.position].read_volume_frames(u.t, u.c, out=out)   # file reads only
         return arrays[u.position].read_volume(u.t, u.c, out=out)
 
     def store(u: Unit, vol):
-        host = vol if isinstance(vol, np.ndarray) else vol.cpu().numpy()
-        dst_arrays[u.position].write_volume(u.t, u.c, host)
+        from .staging import EncodedVolume
+
+        if isinstance(vol, EncodedVolume):      # chunk frames written on the device: stored as they are
+            dst_arrays[u.position].write_encoded_volume(u.t, u.c, vol.frames)
+        else:
+            host = vol if isinstance(vol, np.ndarray) else vol.cpu().numpy()
+            dst_arrays[u.position].write_volume(u.t, u.c, host)
         ledger.mark(u)
 
     def process(data, unit: Unit):
@@ -458,11 +473,30 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
             and raw_dtype in (np.dtype("uint16"), np.dtype("float32")) and len(todo) > world):
         from .staging import VolumeStager
 
-        try:
-            stager = VolumeStager((nz, ny, nx), raw_dtype, (oz, oy, ox), device)
-        except (RuntimeError, MemoryError) as exc:   # not enough pinnable host memory for the slots
-            logger.warning("staging slots unavailable (%s): volumes are handed over synchronously", exc)
-            stager = None
+        # a blosc-zstd output whose chunks are whole planes: the device writes the frames (None: host encoding)
+        frame_bytes = None
+        if device_codec and not use_iohub_out:
+            sizes = {getattr(a, "encoded_frame_bytes", lambda: None)() for a in dst_arrays.values()}
+            frame_bytes = sizes.pop() if len(sizes) == 1 else None
+        # ... and an input stored as blosc-zstd chunk frames of whole planes is decoded on the device
+        layout = None
+        if device_codec and todo:
+            layout = getattr(arrays[todo[0].position], "compressed_layout", lambda *a: None)(todo[0].t, todo[0].c)
+        from ._lib import LsrUnsupported
+
+        attempts = [(frame_bytes, layout)] + ([(None, layout)] if frame_bytes and layout else []) \
+            + ([(frame_bytes, None)] if frame_bytes and layout else []) + ([(None, None)] if frame_bytes or layout else [])
+        for fb, lay in attempts:
+            try:
+                stager = VolumeStager((nz, ny, nx), raw_dtype, (oz, oy, ox), device, encode_frame_bytes=fb, decode_layout=lay)
+                frames_in[0] = lay is not None
+                break
+            except LsrUnsupported as exc:                # a chunk / block size outside the device codecs' range
+                logger.info("device codec not used for %s (%s)", "the output" if fb else "the input", exc)
+            except (RuntimeError, MemoryError) as exc:   # not enough pinnable host memory for the slots
+                logger.warning("staging slots unavailable (%s): volumes are handed over synchronously", exc)
+                stager = None
+                break
     try:
         on_gpu = torch.device(device).type == "cuda"
         report = run_sharded(todo, load, process, store, synchronize=torch.cuda.synchronize if on_gpu else None,
@@ -480,6 +514,8 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
     return {"rank": rank, "world_size": world, "units": len(report.units), "units_total": len(units),
             "units_skipped": skipped, "seconds": report.seconds, "job_seconds": report.max_seconds,
             "stage_seconds": {k: round(v, 4) for k, v in report.stage_seconds.items()},
+            "device_codec": {"encode": bool(stager is not None and getattr(stager, "encode_frame_bytes", None)),
+                             "decode": bool(frames_in[0])},
             "output_shape": (oz, oy, ox)}
 
 

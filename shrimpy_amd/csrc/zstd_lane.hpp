@@ -1,0 +1,751 @@
+// A zstd frame decoder (RFC 8878) written as scalar code that one LANE runs: on the MI355X every lane of the decode
+// kernel (csrc/blosc_decode.hip) decodes one blosc block -- one zstd frame of <= 128 KB per block is how c-blosc, and
+// therefore the acquisition engine, stores zstd data (shrimpy/mantis/mantis_engine.py:474-481) -- so a config-4 volume
+// is 65 536 independent frames, one per lane of 1 024 waves.  The same functions compile for the host, where the
+// GPU-less container checks them against frames the system libzstd wrote (tests/test_device_codec.py) and where they
+// run under the address sanitiser on damaged input (tools/fuzz_zstd_lane.py): every read is checked against the end
+// of the source, every write against the end of the destination; a damaged frame is an error code, never a fault.
+//
+// Covered: single frames (magic, header with or without window descriptor / content size / checksum flag; dictionary
+// IDs are refused), Raw / RLE / Compressed blocks; literals Raw, RLE, Huffman (one or four streams, direct or FSE-coded
+// weights) and "treeless"; sequences with predefined, RLE, FSE-compressed and repeat tables, repeat offsets.
+// The frame checksum is skipped, not verified.  This states the published format; it is not libzstd's code.
+//
+// Layout choices for the lane: the Huffman code is decoded canonically (12 thresholds in registers + the 256 symbols
+// in rank order: LDS on the device) instead of through a 2^11-entry table; the three sequence tables live in a
+// per-lane workspace (global memory, entries interleaved by lane); literals are decoded INTO the tail of the block's
+// output range, which the sequence execution provably never overtakes, so there is no literal buffer.
+#pragma once
+
+#include <stdint.h>
+
+#include "zstd_huf.hpp"   // LSR_HD, highbit
+
+namespace lsr {
+namespace zd {
+
+enum : int {
+  kOk = 0,
+  kErrCorrupt = -1,      // the source does not follow the format / ends early
+  kErrDstSmall = -2,     // the frame decodes to more than the destination holds
+  kErrUnsupported = -3,  // a dictionary, or not a zstd frame
+  kErrSize = -4,         // decoded size differs from the expected one
+};
+
+constexpr int kLLLogMax = 9, kOFLogMax = 8, kMLLogMax = 9;
+// 32-bit entries of the lane workspace: the three sequence tables (they persist from block to block: Repeat_Mode), the
+// Huffman weights while a tree description is read (eight 4-bit weights per entry) and their FSE table
+constexpr int kLLBase = 0, kOFBase = 512, kMLBase = 768, kWeightBase = 1280, kWeightTabBase = 1312, kWorkEntries = 1376;
+constexpr int kBlockMax = 128 * 1024;
+
+LSR_HD uint64_t load_le(const uint8_t* p, int n) {   // n <= 8 bytes, little endian
+  uint64_t v = 0;
+  for (int i = 0; i < n; ++i) v |= static_cast<uint64_t>(p[i]) << (8 * i);
+  return v;
+}
+LSR_HD uint64_t load64(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+// ---- bit readers --------------------------------------------------------------------------------------------------------
+// Backward reader of a stream that ends with a '1' mark (Huffman and FSE payloads): `pos` unread bits below the mark.
+struct BackBits {
+  const uint8_t* p;
+  int len;
+  int pos;        // bits still unread; negative once more were asked for than the stream holds
+  uint64_t win;   // bits [lo, lo + 64) of the stream
+  int lo;
+};
+LSR_HD void back_refill(BackBits& b) {
+  if (b.len >= 8) {
+    int sb = b.pos > 0 ? ((b.pos - 1) >> 3) - 7 : 0;
+    if (sb < 0) sb = 0;
+    b.win = load64(b.p + sb);
+    b.lo = 8 * sb;
+  } else {
+    b.win = load_le(b.p, b.len);
+    b.lo = 0;
+  }
+}
+LSR_HD bool back_init(BackBits& b, const uint8_t* p, int len) {
+  if (len <= 0) return false;
+  const uint8_t last = p[len - 1];
+  if (last == 0) return false;
+  b.p = p;
+  b.len = len;
+  b.pos = 8 * (len - 1) + zs::highbit(last);
+  back_refill(b);
+  return true;
+}
+// the next n bits (n <= 32) without consuming them; bits "before the start" read as zero (the format's rule)
+LSR_HD uint32_t back_peek(BackBits& b, int n) {
+  if (n == 0) return 0;
+  if (b.pos >= n) {
+    if (b.pos - n < b.lo) back_refill(b);
+    return static_cast<uint32_t>(b.win >> (b.pos - n - b.lo)) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u));
+  }
+  if (b.pos <= 0) return 0;
+  if (b.lo > 0) back_refill(b);
+  const uint32_t have = static_cast<uint32_t>(b.win) & ((1u << b.pos) - 1u);   // pos < n <= 32
+  return have << (n - b.pos);
+}
+LSR_HD uint32_t back_read(BackBits& b, int n) {
+  const uint32_t v = back_peek(b, n);
+  b.pos -= n;
+  return v;
+}
+
+// Forward little-endian reader (the normalised-count header)
+struct FwdBits {
+  const uint8_t* p;
+  int len, pos;   // bytes, bit position
+};
+LSR_HD uint32_t fwd_peek(const FwdBits& f, int n) {   // n <= 25; zero beyond the end
+  const int byte = f.pos >> 3;
+  uint64_t v = 0;
+  for (int i = 0; i < 5; ++i)
+    if (byte + i < f.len) v |= static_cast<uint64_t>(f.p[byte + i]) << (8 * i);
+  return static_cast<uint32_t>(v >> (f.pos & 7)) & ((1u << n) - 1u);
+}
+
+// ---- FSE ------------------------------------------------------------------------------------------------------------------
+// normalised counts of up to 53 symbols; -1 = "less than one"
+struct NCount {
+  int16_t norm[64];
+  int max_symbol, log;
+};
+// Returns the bytes used (> 0) or an error.
+LSR_HD int read_ncount(const uint8_t* p, int len, int max_symbol_allowed, int max_log, NCount& nc) {
+  FwdBits f{p, len, 0};
+  const int log = 5 + static_cast<int>(fwd_peek(f, 4));
+  f.pos += 4;
+  if (log > max_log) return kErrCorrupt;
+  int remaining = (1 << log) + 1, threshold = 1 << log, nb = log + 1, sym = 0;
+  bool prev0 = false;
+  for (int i = 0; i < 64; ++i) nc.norm[i] = 0;
+  while (remaining > 1 && sym <= max_symbol_allowed) {
+    if (prev0) {
+      for (;;) {
+        const int r = static_cast<int>(fwd_peek(f, 2));
+        f.pos += 2;
+        sym += r;
+        if (r < 3) break;
+        if (sym > max_symbol_allowed) return kErrCorrupt;
+      }
+      if (sym > max_symbol_allowed) return kErrCorrupt;
+    }
+    const int max = (2 * threshold - 1) - remaining;
+    int count;
+    const int low = static_cast<int>(fwd_peek(f, nb - 1));
+    if (low < max) {
+      count = low;
+      f.pos += nb - 1;
+    } else {
+      count = static_cast<int>(fwd_peek(f, nb));
+      if (count >= threshold) count -= max;
+      f.pos += nb;
+    }
+    --count;
+    remaining -= count < 0 ? -count : count;
+    nc.norm[sym++] = static_cast<int16_t>(count);
+    prev0 = count == 0;
+    if (remaining < 1) return kErrCorrupt;
+    while (remaining < threshold) { --nb; threshold >>= 1; }
+    if ((f.pos >> 3) > len) return kErrCorrupt;
+  }
+  if (remaining != 1 || sym > max_symbol_allowed + 1) return kErrCorrupt;
+  nc.max_symbol = sym - 1;
+  nc.log = log;
+  const int used = (f.pos + 7) >> 3;
+  return used <= len ? used : kErrCorrupt;
+}
+
+// decoding-table entry: symbol | bits << 8 | base << 16
+LSR_HD uint32_t fse_entry(int symbol, int bits, int base) {
+  return static_cast<uint32_t>(symbol) | static_cast<uint32_t>(bits) << 8 | static_cast<uint32_t>(base) << 16;
+}
+
+// `T` addresses 32-bit table entries: T.get(i) / T.set(i, v)
+template <class T>
+LSR_HD void fse_build(T tab, const NCount& nc) {
+  const int size = 1 << nc.log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+  uint16_t next[64];
+  int high = size - 1;
+  for (int s = 0; s <= nc.max_symbol; ++s) {
+    if (nc.norm[s] == -1) {
+      tab.set(high--, static_cast<uint32_t>(s));
+      next[s] = 1;
+    } else {
+      next[s] = static_cast<uint16_t>(nc.norm[s]);
+    }
+  }
+  int pos = 0;
+  for (int s = 0; s <= nc.max_symbol; ++s) {
+    for (int i = 0; i < nc.norm[s]; ++i) {
+      tab.set(pos, static_cast<uint32_t>(s));
+      do { pos = (pos + step) & mask; } while (pos > high);
+    }
+  }
+  for (int u = 0; u < size; ++u) {
+    const int s = static_cast<int>(tab.get(u) & 0xFF);
+    const int x = next[s]++;
+    const int bits = nc.log - zs::highbit(static_cast<uint32_t>(x));
+    tab.set(u, fse_entry(s, bits, (x << bits) - size));
+  }
+}
+
+// ---- sequences: code -> (baseline, extra bits) --------------------------------------------------------------------------------
+LSR_HD void ll_code(int code, uint32_t& base, int& bits) {
+  if (code < 16) { base = static_cast<uint32_t>(code); bits = 0; return; }
+  const uint32_t b[20] = {16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+  const uint8_t n[20] = {1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+  base = b[code - 16];
+  bits = n[code - 16];
+}
+LSR_HD void ml_code(int code, uint32_t& base, int& bits) {
+  if (code < 32) { base = static_cast<uint32_t>(code + 3); bits = 0; return; }
+  const uint32_t b[21] = {35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+  const uint8_t n[21] = {1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+  base = b[code - 32];
+  bits = n[code - 32];
+}
+
+LSR_HD void predefined_ncount(int which /* 0 LL, 1 OF, 2 ML */, NCount& nc) {
+  const int8_t ll[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+  const int8_t of[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+  const int8_t ml[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                         1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+  for (int i = 0; i < 64; ++i) nc.norm[i] = 0;
+  if (which == 0) { for (int i = 0; i < 36; ++i) nc.norm[i] = ll[i]; nc.max_symbol = 35; nc.log = 6; }
+  else if (which == 1) { for (int i = 0; i < 29; ++i) nc.norm[i] = of[i]; nc.max_symbol = 28; nc.log = 5; }
+  else { for (int i = 0; i < 53; ++i) nc.norm[i] = ml[i]; nc.max_symbol = 52; nc.log = 6; }
+}
+
+// The three predefined tables, built once by the host (plain arrays) and handed to every lane.
+struct Predefined {
+  uint32_t ll[64], of[32], ml[64];
+};
+struct PlainTab {
+  uint32_t* t;
+  LSR_HD uint32_t get(int i) const { return t[i]; }
+  LSR_HD void set(int i, uint32_t v) const { t[i] = v; }
+};
+inline void build_predefined(Predefined& p) {
+  NCount nc;
+  predefined_ncount(0, nc); fse_build(PlainTab{p.ll}, nc);
+  predefined_ncount(1, nc); fse_build(PlainTab{p.of}, nc);
+  predefined_ncount(2, nc); fse_build(PlainTab{p.ml}, nc);
+}
+
+// ---- the lane's state ----------------------------------------------------------------------------------------------------------
+// Store: where the lane keeps its tables.
+//   ws_get(i) / ws_set(i, v)    32-bit entries, i < kWorkEntries (LL | OF | ML sequence tables; scratch while the Huffman
+//                               weights are decoded)
+//   sym_get(i) / sym_set(i, v)  the 256 Huffman symbols in rank order
+template <class Store>
+struct WsTab {
+  Store* s;
+  int base;
+  LSR_HD uint32_t get(int i) const { return s->ws_get(base + i); }
+  LSR_HD void set(int i, uint32_t v) const { s->ws_set(base + i, v); }
+};
+
+struct HufCode {         // canonical code of the literals: classes by weight 1 .. 11 (weight w <-> length max_bits + 1 - w)
+  uint16_t end[12];      // end[w]: first code-space position (max_bits wide) past the symbols of weight <= w
+  uint16_t rank_end[12]; // symbols of weight <= w
+  int max_bits;          // 0 = no table yet
+};
+
+struct SeqTable {        // one of LL / OF / ML as currently in force
+  int mode;              // 0 predefined, 1 RLE, 2 in the workspace
+  int log;
+  int rle_symbol;
+};
+
+template <class Store>
+struct Lane {
+  Store store;
+  const Predefined* pre;
+  HufCode huf;
+  SeqTable tab[3];
+  uint32_t rep[3];
+  bool have_tab[3];
+};
+
+template <class Store>
+LSR_HD void lane_reset(Lane<Store>& L) {
+  L.huf.max_bits = 0;
+  L.rep[0] = 1; L.rep[1] = 4; L.rep[2] = 8;
+  for (int i = 0; i < 3; ++i) { L.have_tab[i] = false; L.tab[i].mode = 0; L.tab[i].log = 0; L.tab[i].rle_symbol = 0; }
+}
+
+// ---- Huffman tree description ----------------------------------------------------------------------------------------------------
+// Weights -> HufCode + symbols in rank order.  Returns bytes of the description, or an error.
+template <class Store>
+LSR_HD int weight_get(Store& st, int i) {
+  return static_cast<int>((st.ws_get(kWeightBase + (i >> 3)) >> (4 * (i & 7))) & 15);
+}
+template <class Store>
+LSR_HD void weight_set(Store& st, int i, uint32_t w) {
+  const int e = kWeightBase + (i >> 3), sh = 4 * (i & 7);
+  const uint32_t old = (i & 7) ? st.ws_get(e) : 0;          // weights are written in order: entry starts empty
+  st.ws_set(e, (old & ~(15u << sh)) | (w & 15u) << sh);
+}
+
+template <class Store>
+LSR_HD int read_huf_description(Lane<Store>& L, const uint8_t* p, int len) {
+  if (len < 1) return kErrCorrupt;
+  const int hb = p[0];
+  int used, nw;
+  if (hb >= 128) {
+    nw = hb - 127;
+    used = 1 + (nw + 1) / 2;
+    if (used > len) return kErrCorrupt;
+    for (int i = 0; i < nw; ++i) {
+      const int byte = p[1 + i / 2];
+      weight_set(L.store, i, static_cast<uint32_t>((i & 1) ? (byte & 15) : (byte >> 4)));
+    }
+  } else {
+    used = 1 + hb;
+    if (hb < 1 || used > len) return kErrCorrupt;
+    NCount nc;
+    const int h = read_ncount(p + 1, hb, 255, 6, nc);
+    if (h < 0) return h;
+    if (nc.max_symbol > 12) return kErrCorrupt;
+    WsTab<Store> t{&L.store, kWeightTabBase};
+    fse_build(t, nc);
+    BackBits b;
+    if (!back_init(b, p + 1 + h, hb - h)) return kErrCorrupt;
+    uint32_t s1 = back_read(b, nc.log), s2 = back_read(b, nc.log);
+    if (b.pos < 0) return kErrCorrupt;
+    nw = 0;
+    for (;;) {
+      // two interleaved states; the stream is used up exactly when the last two weights sit in the states
+      const uint32_t e1 = t.get(static_cast<int>(s1));
+      if (nw >= 255) return kErrCorrupt;
+      if ((e1 & 0xFF) > 11) return kErrCorrupt;
+      weight_set(L.store, nw++, e1 & 0xFF);
+      s1 = (e1 >> 16) + back_read(b, static_cast<int>((e1 >> 8) & 0xFF));
+      if (b.pos < 0) {
+        if (nw >= 255) return kErrCorrupt;
+        weight_set(L.store, nw++, t.get(static_cast<int>(s2)) & 0xFF);
+        break;
+      }
+      const uint32_t e2 = t.get(static_cast<int>(s2));
+      if (nw >= 255) return kErrCorrupt;
+      if ((e2 & 0xFF) > 11) return kErrCorrupt;
+      weight_set(L.store, nw++, e2 & 0xFF);
+      s2 = (e2 >> 16) + back_read(b, static_cast<int>((e2 >> 8) & 0xFF));
+      if (b.pos < 0) {
+        if (nw >= 255) return kErrCorrupt;
+        weight_set(L.store, nw++, t.get(static_cast<int>(s1)) & 0xFF);
+        break;
+      }
+    }
+  }
+  // the implied last weight completes the sum of 2^(w-1) to a power of two
+  uint32_t total = 0;
+  int per_weight[13];
+  for (int w = 0; w < 13; ++w) per_weight[w] = 0;
+  for (int i = 0; i < nw; ++i) {
+    const int w = weight_get(L.store, i);
+    if (w > 11) return kErrCorrupt;
+    ++per_weight[w];
+    if (w) total += 1u << (w - 1);
+  }
+  if (total == 0) return kErrCorrupt;
+  const int max_bits = zs::highbit(total) + 1;
+  if (max_bits > 11) return kErrCorrupt;
+  const uint32_t rest = (1u << max_bits) - total;
+  if (rest == 0 || (rest & (rest - 1))) return kErrCorrupt;
+  const int last_w = zs::highbit(rest) + 1;
+  weight_set(L.store, nw, static_cast<uint32_t>(last_w));
+  ++per_weight[last_w];
+  ++nw;
+  if (per_weight[1] < 2 || (per_weight[1] & 1)) return kErrCorrupt;
+  // rank order: weight ascending (longest codes first), symbol ascending inside a weight
+  int rank_start[13];
+  uint32_t code_pos = 0;
+  int rank = 0;
+  L.huf.end[0] = 0;
+  L.huf.rank_end[0] = 0;
+  for (int w = 1; w <= 11; ++w) {
+    rank_start[w] = rank;
+    rank += per_weight[w];
+    code_pos += static_cast<uint32_t>(per_weight[w]) << (w - 1);
+    L.huf.end[w] = static_cast<uint16_t>(code_pos);
+    L.huf.rank_end[w] = static_cast<uint16_t>(rank);
+  }
+  for (int i = 0; i < nw; ++i) {
+    const int w = weight_get(L.store, i);
+    if (w) L.store.sym_set(rank_start[w]++, static_cast<uint8_t>(i));
+  }
+  L.huf.max_bits = max_bits;
+  return used;
+}
+
+// one literal from the top of the stream
+template <class Store>
+LSR_HD uint8_t huf_decode_one(Lane<Store>& L, BackBits& b) {
+  const HufCode& h = L.huf;
+  const uint32_t v = back_peek(b, h.max_bits);
+  int w = 1;
+  uint32_t start = 0, rstart = 0;
+#pragma unroll
+  for (int k = 1; k <= 10; ++k) {
+    const bool ge = v >= h.end[k];
+    start = ge ? h.end[k] : start;
+    rstart = ge ? h.rank_end[k] : rstart;
+    w += ge;
+  }
+  b.pos -= h.max_bits + 1 - w;
+  return L.store.sym_get(static_cast<int>(rstart + ((v - start) >> (w - 1))));
+}
+
+template <class Store>
+LSR_HD int huf_decode_stream(Lane<Store>& L, const uint8_t* p, int len, uint8_t* out, int n) {
+  BackBits b;
+  if (!back_init(b, p, len)) return kErrCorrupt;
+  for (int i = 0; i < n; ++i) out[i] = huf_decode_one(L, b);
+  return b.pos == 0 ? kOk : kErrCorrupt;
+}
+
+// four streams side by side: four independent dependency chains per lane
+template <class Store>
+LSR_HD int huf_decode_4(Lane<Store>& L, const uint8_t* p, int len, uint8_t* out, int n) {
+  if (len < 10) return kErrCorrupt;
+  const int s0 = static_cast<int>(load_le(p, 2)), s1 = static_cast<int>(load_le(p + 2, 2)), s2 = static_cast<int>(load_le(p + 4, 2));
+  const int s3 = len - 6 - s0 - s1 - s2;
+  if (s3 < 1 || s0 < 1 || s1 < 1 || s2 < 1) return kErrCorrupt;
+  const int q = (n + 3) / 4;
+  const int n3 = n - 3 * q;
+  if (n3 < 0) return kErrCorrupt;
+  BackBits b0, b1, b2, b3;
+  const uint8_t* s = p + 6;
+  if (!back_init(b0, s, s0) || !back_init(b1, s + s0, s1) || !back_init(b2, s + s0 + s1, s2) ||
+      !back_init(b3, s + s0 + s1 + s2, s3))
+    return kErrCorrupt;
+  uint8_t* o0 = out;
+  uint8_t* o1 = out + q;
+  uint8_t* o2 = out + 2 * q;
+  uint8_t* o3 = out + 3 * q;
+  for (int i = 0; i < n3; ++i) {
+    o0[i] = huf_decode_one(L, b0);
+    o1[i] = huf_decode_one(L, b1);
+    o2[i] = huf_decode_one(L, b2);
+    o3[i] = huf_decode_one(L, b3);
+  }
+  for (int i = n3; i < q; ++i) {
+    o0[i] = huf_decode_one(L, b0);
+    o1[i] = huf_decode_one(L, b1);
+    o2[i] = huf_decode_one(L, b2);
+  }
+  return (b0.pos == 0 && b1.pos == 0 && b2.pos == 0 && b3.pos == 0) ? kOk : kErrCorrupt;
+}
+
+// ---- literals section ----------------------------------------------------------------------------------------------------------
+struct Literals {
+  const uint8_t* ptr;   // where the literals are (source for Raw, destination tail for Huffman); unused for RLE
+  int size;
+  bool rle;
+  uint8_t rle_value;
+};
+
+// `room`: bytes of the destination from `op` on.  Huffman literals are written to op + room' - size where room' =
+// min(room, kBlockMax): the block's output cannot overtake them (see the header of this file).
+template <class Store>
+LSR_HD int read_literals(Lane<Store>& L, const uint8_t* p, int len, uint8_t* op, int room, Literals& lit) {
+  if (len < 1) return kErrCorrupt;
+  const int type = p[0] & 3, fmt = (p[0] >> 2) & 3;
+  if (type < 2) {                          // Raw / RLE
+    int hs, size;
+    if ((fmt & 1) == 0) { hs = 1; size = p[0] >> 3; }
+    else if (fmt == 1) { if (len < 2) return kErrCorrupt; hs = 2; size = static_cast<int>(load_le(p, 2) >> 4); }
+    else { if (len < 3) return kErrCorrupt; hs = 3; size = static_cast<int>(load_le(p, 3) >> 4); }
+    if (size > kBlockMax) return kErrCorrupt;
+    lit.size = size;
+    if (type == 0) {
+      if (hs + size > len) return kErrCorrupt;
+      lit.rle = false;
+      lit.ptr = p + hs;
+      return hs + size;
+    }
+    if (hs + 1 > len) return kErrCorrupt;
+    lit.rle = true;
+    lit.rle_value = p[hs];
+    lit.ptr = p + hs;
+    return hs + 1;
+  }
+  int hs, regen, csize;
+  bool four = true;
+  if (fmt < 2) {
+    if (len < 3) return kErrCorrupt;
+    const uint32_t v = static_cast<uint32_t>(load_le(p, 3));
+    hs = 3; regen = (v >> 4) & 0x3FF; csize = (v >> 14) & 0x3FF; four = fmt == 1;
+  } else if (fmt == 2) {
+    if (len < 4) return kErrCorrupt;
+    const uint32_t v = static_cast<uint32_t>(load_le(p, 4));
+    hs = 4; regen = (v >> 4) & 0x3FFF; csize = v >> 18;
+  } else {
+    if (len < 5) return kErrCorrupt;
+    const uint64_t v = load_le(p, 5);
+    hs = 5; regen = static_cast<int>((v >> 4) & 0x3FFFF); csize = static_cast<int>(v >> 22);
+  }
+  if (regen > kBlockMax || regen < 1 || hs + csize > len) return kErrCorrupt;
+  const uint8_t* body = p + hs;
+  int body_len = csize;
+  if (type == 2) {
+    const int d = read_huf_description(L, body, body_len);
+    if (d < 0) return d;
+    body += d;
+    body_len -= d;
+  } else if (L.huf.max_bits == 0) {
+    return kErrCorrupt;                    // "treeless" without a previous tree
+  }
+  const int span = room < kBlockMax ? room : kBlockMax;
+  if (regen > span) return kErrDstSmall;
+  uint8_t* dst = op + span - regen;
+  const int rc = four ? huf_decode_4(L, body, body_len, dst, regen) : huf_decode_stream(L, body, body_len, dst, regen);
+  if (rc < 0) return rc;
+  lit.rle = false;
+  lit.ptr = dst;
+  lit.size = regen;
+  return hs + csize;
+}
+
+// ---- sequences --------------------------------------------------------------------------------------------------------------------
+template <class Store>
+LSR_HD uint32_t seq_entry(Lane<Store>& L, int which, uint32_t state) {
+  const SeqTable& t = L.tab[which];
+  if (t.mode == 0) return which == 0 ? L.pre->ll[state] : which == 1 ? L.pre->of[state] : L.pre->ml[state];
+  if (t.mode == 1) return fse_entry(t.rle_symbol, 0, 0);
+  return L.store.ws_get((which == 0 ? kLLBase : which == 1 ? kOFBase : kMLBase) + static_cast<int>(state));
+}
+
+// table `which` in `mode` (0 predefined, 1 RLE, 2 FSE, 3 repeat); returns the bytes used
+template <class Store>
+LSR_HD int read_seq_table(Lane<Store>& L, int which, int mode, const uint8_t* p, int len) {
+  const int max_sym = which == 0 ? 35 : which == 1 ? 31 : 52;
+  const int max_log = which == 0 ? kLLLogMax : which == 1 ? kOFLogMax : kMLLogMax;
+  SeqTable& t = L.tab[which];
+  if (mode == 0) {
+    t.mode = 0;
+    t.log = which == 1 ? 5 : 6;
+    L.have_tab[which] = true;
+    return 0;
+  }
+  if (mode == 1) {
+    if (len < 1 || p[0] > max_sym) return kErrCorrupt;
+    t.mode = 1;
+    t.log = 0;
+    t.rle_symbol = p[0];
+    L.have_tab[which] = true;
+    return 1;
+  }
+  if (mode == 3) return L.have_tab[which] ? 0 : kErrCorrupt;
+  NCount nc;
+  const int used = read_ncount(p, len, max_sym, max_log, nc);
+  if (used < 0) return used;
+  WsTab<Store> tab{&L.store, which == 0 ? kLLBase : which == 1 ? kOFBase : kMLBase};
+  fse_build(tab, nc);
+  t.mode = 2;
+  t.log = nc.log;
+  L.have_tab[which] = true;
+  return used;
+}
+
+// copy n bytes within the destination from `offset` back (may overlap: the pattern repeats)
+LSR_HD void copy_match(uint8_t* o, uint32_t offset, int n) {
+  const uint8_t* m = o - offset;
+  if (offset >= 8) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+      uint64_t v;
+      __builtin_memcpy(&v, m + i, 8);
+      __builtin_memcpy(o + i, &v, 8);
+    }
+    for (; i < n; ++i) o[i] = m[i];
+    return;
+  }
+  // period < 8: the pattern in a register, eight bytes per store, advancing by the largest multiple of the period
+  uint64_t pat = 0;
+  for (int i = 0; i < 8; ++i) pat |= static_cast<uint64_t>(m[i % static_cast<int>(offset)]) << (8 * i);
+  const int step = (8 / static_cast<int>(offset)) * static_cast<int>(offset);
+  int i = 0;
+  for (; i + 8 <= n; i += step) __builtin_memcpy(o + i, &pat, 8);
+  for (int k = 0; i < n; ++i, ++k) o[i] = static_cast<uint8_t>(pat >> (8 * (k % static_cast<int>(offset))));
+}
+
+LSR_HD void copy_forward(uint8_t* o, const uint8_t* s, int n) {   // s >= o or disjoint: exact length, eight bytes at a time
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t v;
+    __builtin_memcpy(&v, s + i, 8);
+    __builtin_memcpy(o + i, &v, 8);
+  }
+  for (; i < n; ++i) o[i] = s[i];
+}
+
+// Decode and execute the sequences of one block.  `dst0`: start of the frame's output (matches may reach back to it),
+// `op`: where this block's output starts, `room`: bytes available from op.  Returns the bytes produced.
+template <class Store>
+LSR_HD int run_sequences(Lane<Store>& L, const uint8_t* p, int len, const Literals& lit, uint8_t* dst0, uint8_t* op, int room) {
+  if (len < 1) return kErrCorrupt;
+  int nseq = p[0], hs = 1;
+  if (nseq >= 128) {
+    if (nseq == 255) {
+      if (len < 3) return kErrCorrupt;
+      nseq = static_cast<int>(load_le(p + 1, 2)) + 0x7F00;
+      hs = 3;
+    } else {
+      if (len < 2) return kErrCorrupt;
+      nseq = ((nseq - 128) << 8) + p[1];
+      hs = 2;
+    }
+  }
+  uint8_t* o = op;
+  uint8_t* const oend = op + room;
+  int lit_at = 0;
+  if (nseq > 0) {
+    if (hs + 1 > len) return kErrCorrupt;
+    const int modes = p[hs];
+    if (modes & 3) return kErrCorrupt;
+    int at = hs + 1;
+    for (int which = 0; which < 3; ++which) {
+      const int mode = (modes >> (6 - 2 * which)) & 3;
+      const int used = read_seq_table(L, which, mode, p + at, len - at);
+      if (used < 0) return used;
+      at += used;
+    }
+    BackBits b;
+    if (!back_init(b, p + at, len - at)) return kErrCorrupt;
+    uint32_t s_ll = back_read(b, L.tab[0].log), s_of = back_read(b, L.tab[1].log), s_ml = back_read(b, L.tab[2].log);
+    if (b.pos < 0) return kErrCorrupt;
+    for (int i = 0; i < nseq; ++i) {
+      const uint32_t e_ll = seq_entry(L, 0, s_ll), e_of = seq_entry(L, 1, s_of), e_ml = seq_entry(L, 2, s_ml);
+      const int of_code = static_cast<int>(e_of & 0xFF);
+      if (of_code > 31) return kErrCorrupt;
+      uint32_t offset_value = (1u << of_code) + back_read(b, of_code);
+      uint32_t ml_base, ll_base;
+      int ml_bits, ll_bits;
+      ml_code(static_cast<int>(e_ml & 0xFF), ml_base, ml_bits);
+      ll_code(static_cast<int>(e_ll & 0xFF), ll_base, ll_bits);
+      const int match_len = static_cast<int>(ml_base + back_read(b, ml_bits));
+      const int lit_len = static_cast<int>(ll_base + back_read(b, ll_bits));
+      if (i + 1 < nseq) {
+        s_ll = (e_ll >> 16) + back_read(b, static_cast<int>((e_ll >> 8) & 0xFF));
+        s_ml = (e_ml >> 16) + back_read(b, static_cast<int>((e_ml >> 8) & 0xFF));
+        s_of = (e_of >> 16) + back_read(b, static_cast<int>((e_of >> 8) & 0xFF));
+      }
+      if (b.pos < 0) return kErrCorrupt;
+      uint32_t offset;
+      if (offset_value > 3) {
+        offset = offset_value - 3;
+        L.rep[2] = L.rep[1]; L.rep[1] = L.rep[0]; L.rep[0] = offset;
+      } else {
+        const uint32_t idx = offset_value + (lit_len == 0 ? 1 : 0);
+        if (idx == 1) {
+          offset = L.rep[0];
+        } else {
+          offset = idx == 4 ? L.rep[0] - 1 : L.rep[idx - 1];
+          if (offset == 0) return kErrCorrupt;
+          if (idx != 2) L.rep[2] = L.rep[1];
+          L.rep[1] = L.rep[0];
+          L.rep[0] = offset;
+        }
+      }
+      if (lit_len > lit.size - lit_at) return kErrCorrupt;
+      if (lit_len + match_len > oend - o) return kErrDstSmall;
+      if (lit.rle) { for (int k = 0; k < lit_len; ++k) o[k] = lit.rle_value; }
+      else copy_forward(o, lit.ptr + lit_at, lit_len);
+      o += lit_len;
+      lit_at += lit_len;
+      if (offset > static_cast<uint32_t>(o - dst0)) return kErrCorrupt;
+      copy_match(o, offset, match_len);
+      o += match_len;
+    }
+    if (b.pos != 0) return kErrCorrupt;
+  } else if (hs != len) {
+    return kErrCorrupt;
+  }
+  const int rest = lit.size - lit_at;
+  if (rest > oend - o) return kErrDstSmall;
+  if (lit.rle) { for (int k = 0; k < rest; ++k) o[k] = lit.rle_value; }
+  else if (o != lit.ptr + lit_at) copy_forward(o, lit.ptr + lit_at, rest);
+  o += rest;
+  return static_cast<int>(o - op);
+}
+
+// ---- frame ------------------------------------------------------------------------------------------------------------------------
+// One zstd frame src[0, len) -> dst[0, cap).  Returns the decoded size or an error code.
+template <class Store>
+LSR_HD int decode_frame(Lane<Store>& L, const uint8_t* src, int len, uint8_t* dst, int cap) {
+  if (len < 6) return kErrCorrupt;
+  if (src[0] != 0x28 || src[1] != 0xB5 || src[2] != 0x2F || src[3] != 0xFD) return kErrUnsupported;
+  const int fhd = src[4];
+  const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, dict_flag = fhd & 3;
+  if (fhd & 0x08) return kErrCorrupt;                 // reserved bit
+  int at = 5;
+  if (!single) ++at;                                  // window descriptor: the destination bounds every match anyway
+  const int dict_bytes = dict_flag == 3 ? 4 : dict_flag;
+  if (at + dict_bytes > len) return kErrCorrupt;
+  if (dict_bytes && load_le(src + at, dict_bytes) != 0) return kErrUnsupported;
+  at += dict_bytes;
+  const int fcs_bytes = fcs_flag == 0 ? single : 1 << fcs_flag;
+  if (at + fcs_bytes > len) return kErrCorrupt;
+  int64_t content = -1;
+  if (fcs_bytes) {
+    content = static_cast<int64_t>(load_le(src + at, fcs_bytes));
+    if (fcs_bytes == 2) content += 256;
+    if (content < 0 || content > cap) return kErrDstSmall;
+  }
+  at += fcs_bytes;
+  lane_reset(L);
+  uint8_t* o = dst;
+  for (;;) {
+    if (at + 3 > len) return kErrCorrupt;
+    const uint32_t bh = static_cast<uint32_t>(load_le(src + at, 3));
+    at += 3;
+    const int last = bh & 1, type = (bh >> 1) & 3, size = static_cast<int>(bh >> 3);
+    const int room = static_cast<int>(dst + cap - o);
+    if (type == 0) {
+      if (at + size > len) return kErrCorrupt;
+      if (size > room) return kErrDstSmall;
+      copy_forward(o, src + at, size);
+      o += size;
+      at += size;
+    } else if (type == 1) {
+      if (at + 1 > len) return kErrCorrupt;
+      if (size > room) return kErrDstSmall;
+      const uint8_t v = src[at];
+      uint64_t pat = v * 0x0101010101010101ull;
+      int i = 0;
+      for (; i + 8 <= size; i += 8) __builtin_memcpy(o + i, &pat, 8);
+      for (; i < size; ++i) o[i] = v;
+      o += size;
+      at += 1;
+    } else if (type == 2) {
+      if (size > kBlockMax || at + size > len) return kErrCorrupt;
+      Literals lit;
+      const int lu = read_literals(L, src + at, size, o, room, lit);
+      if (lu < 0) return lu;
+      const int produced = run_sequences(L, src + at + lu, size - lu, lit, dst, o, room);
+      if (produced < 0) return produced;
+      o += produced;
+      at += size;
+    } else {
+      return kErrCorrupt;
+    }
+    if (last) break;
+  }
+  if (checksum) at += 4;
+  if (at > len) return kErrCorrupt;
+  const int64_t total = o - dst;
+  if (content >= 0 && total != content) return kErrCorrupt;
+  return static_cast<int>(total);
+}
+
+}  // namespace zd
+}  // namespace lsr

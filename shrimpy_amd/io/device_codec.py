@@ -24,7 +24,66 @@ import numpy as np
 
 from .. import _lib
 
-__all__ = ["DeviceBloscEncoder", "encode_frames_host", "plan_frames"]
+__all__ = ["DeviceBloscEncoder", "DeviceBloscDecoder", "CompressedVolume", "encode_frames_host", "decode_frames_host",
+           "plan_frames", "frame_layout", "DecodeError"]
+
+
+class DecodeError(ValueError):
+    """A chunk did not decode (damaged bytes, or a frame that differs from the layout the decoder was planned for)."""
+
+    _CODES = {1: "corrupt stream", 2: "decodes to more than the chunk holds", 3: "not a zstd stream / unsupported feature",
+              4: "size differs from the chunk layout"}
+
+    def __init__(self, status: int, blocks_per_frame: int):
+        self.block = (int(status) >> 8) - 1
+        self.code = int(status) & 0xFF
+        self.frame = self.block // max(int(blocks_per_frame), 1)
+        super().__init__(f"chunk {self.frame} (blosc block {self.block}): {self._CODES.get(self.code, f'code {self.code}')}")
+
+
+class CompressedVolume:
+    """One (t, c) volume as it lies in the store: ``table[f] = (offset, size)`` of z-chunk f's blosc frame inside the
+    byte buffer the reader filled (``size == 0``: the chunk is absent, i.e. zeros); ``used`` = bytes of the buffer in use."""
+
+    def __init__(self, table: np.ndarray, used: int):
+        self.table = np.ascontiguousarray(table, dtype=np.int64).reshape(-1, 2)
+        self.used = int(used)
+
+
+def frame_layout(frame) -> dict | None:
+    """(nbytes, blocksize, typesize) of a blosc frame the device decoder takes (zstd, byte shuffle or none), else None."""
+    from . import codecs
+
+    if len(frame) < 16:
+        return None
+    h = codecs.blosc_header(bytes(frame[:16]))
+    flags = h["flags"]
+    if flags & 0x2:                         # stored frames carry no usable blocksize: any layout decodes them
+        return None
+    if (flags >> 5) != 4 or ((flags & 0x4) and not ((flags & 0x1) and h["typesize"] > 1)):
+        return None
+    if h["typesize"] not in (1, 2, 4) or h["blocksize"] <= 0 or h["nbytes"] % h["typesize"] or h["blocksize"] % h["typesize"]:
+        return None
+    return dict(nbytes=h["nbytes"], blocksize=h["blocksize"], typesize=h["typesize"])
+
+
+def decode_frames_host(frames, frame_nbytes: int, blocksize: int, typesize: int, out_bytes: int) -> np.ndarray:
+    """The host twin of :class:`DeviceBloscDecoder` (``lsr_blosc_decode_device_cpu``: the lane decoder of
+    ``csrc/zstd_lane.hpp``, block by block): ``frames`` = the blosc frames of consecutive chunks (``b""`` = absent)."""
+    table = np.zeros((len(frames), 2), dtype=np.int64)
+    at = 0
+    for f, fr in enumerate(frames):
+        table[f] = (at, len(fr))
+        at += len(fr)
+    comp = np.frombuffer(b"".join(bytes(f) for f in frames) or b"\0", dtype=np.uint8)
+    out = np.empty(int(out_bytes), dtype=np.uint8)
+    status = ctypes.c_uint64(0)
+    _lib.call("lsr_blosc_decode_device_cpu", comp.ctypes.data, at, table.ctypes.data, len(frames), int(frame_nbytes),
+              int(blocksize), int(typesize), out.ctypes.data, out.size, None, 0, ctypes.byref(status), None)
+    if status.value:
+        raise DecodeError(status.value, -(-int(frame_nbytes) // int(blocksize)))
+    return out
+
 
 
 def plan_frames(src_bytes: int, typesize: int, frame_bytes: int, blocksize: int = 0) -> tuple[int, int, int]:
@@ -91,3 +150,55 @@ class DeviceBloscEncoder:
         end = int(table[-1, 0] + table[-1, 1])
         host = out[:end].cpu().numpy()
         return [host[o:o + n].tobytes() for o, n in table]
+
+
+class DeviceBloscDecoder:
+    """The chunks of one volume layout, decoded by the GPU (``lsr_blosc_decode_device``).
+
+    ``decode(comp, table, out)`` launches on the current stream: ``comp`` = device uint8 tensor with the compressed
+    chunks, ``table`` = device int64 ``(n_frames, 2)`` of (offset, size), ``out`` = the volume's device tensor.  The
+    status word comes back with ``status_async`` / ``check``; nothing here synchronises."""
+
+    def __init__(self, out_bytes: int, frame_nbytes: int, blocksize: int, typesize: int, device):
+        import torch
+
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.LsrError("DeviceBloscDecoder", -1, f"device {self.device}: the device decoder needs a HIP device "
+                                "(host arrays go through decode_frames_host or the blosc codecs)")
+        self.out_bytes, self.frame_nbytes, self.blocksize, self.typesize = int(out_bytes), int(frame_nbytes), int(blocksize), int(typesize)
+        self.n_frames = -(-self.out_bytes // self.frame_nbytes)
+        self.blocks_per_frame = -(-self.frame_nbytes // self.blocksize)
+        sb = ctypes.c_int64()
+        _lib.call("lsr_blosc_decode_device_plan", self.n_frames, self.frame_nbytes, self.blocksize, self.typesize, ctypes.byref(sb))
+        self._scratch = torch.empty(int(sb.value), dtype=torch.uint8, device=self.device)
+        self.status = torch.zeros(1, dtype=torch.int64, device=self.device)
+        # what the compressed chunks of one volume can take at most (c-blosc: nbytes + 16 per frame; this package's
+        # device encoder: 12 bytes per block more)
+        self.comp_capacity = self.n_frames * (self.frame_nbytes + 16 + 12 * self.blocks_per_frame + 64)
+
+    def decode(self, comp, comp_bytes: int, table, out) -> None:
+        if out.numel() * out.element_size() != self.out_bytes or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous tensor of {self.out_bytes} bytes")
+        if tuple(table.shape) != (self.n_frames, 2):
+            raise ValueError(f"table must be ({self.n_frames}, 2), got {tuple(table.shape)}")
+        _lib.call("lsr_blosc_decode_device", comp.data_ptr(), int(comp_bytes), table.data_ptr(), self.n_frames, self.frame_nbytes,
+                  self.blocksize, self.typesize, out.data_ptr(), self.out_bytes, self._scratch.data_ptr(), self._scratch.numel(),
+                  self.status.data_ptr(), _lib.stream_ptr(self.device))
+
+    def check(self, status_value: int) -> None:
+        if status_value:
+            raise DecodeError(int(status_value), self.blocks_per_frame)
+
+    def decode_from_host(self, frames, out) -> None:
+        """Convenience (tests, small volumes): upload ``frames`` (list of bytes), decode into ``out``, synchronise, check."""
+        import torch
+
+        table = np.zeros((len(frames), 2), dtype=np.int64)
+        at = 0
+        for f, fr in enumerate(frames):
+            table[f] = (at, len(fr))
+            at += len(fr)
+        comp = torch.frombuffer(bytearray(b"".join(bytes(f) for f in frames) or b"\0"), dtype=torch.uint8).to(self.device)
+        self.decode(comp, at, torch.as_tensor(table).to(self.device), out)
+        self.check(int(self.status.cpu().item()))

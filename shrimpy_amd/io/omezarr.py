@@ -220,8 +220,10 @@ class _BlockCodec:
         return None
 
     @classmethod
-    def named(cls, name: str | None, dtype: np.dtype) -> "_BlockCodec":
-        """``None`` | "gzip" | "zlib" | "zstd" | "blosc-zstd" (the acquisition's) | "blosc-lz4"."""
+    def named(cls, name: str | None, dtype: np.dtype, blocksize: int = 0) -> "_BlockCodec":
+        """``None`` | "gzip" | "zlib" | "zstd" | "blosc-zstd" (the acquisition's) | "blosc-lz4".  ``blocksize``: bytes
+        per blosc block (0: this package's default of 256 KB; c-blosc itself picks 32 KB for zstd at level 1, which is
+        what the acquisition's frames have)."""
         if name in (None, "", "raw", "none"):
             return cls(None)
         if name in ("gzip", "zlib"):
@@ -231,7 +233,7 @@ class _BlockCodec:
         if name.startswith("blosc"):
             cname = name.split("-", 1)[1] if "-" in name else "zstd"
             return cls("blosc", cname=cname, clevel=1, shuffle=1, typesize=int(np.dtype(dtype).itemsize),
-                       blocksize=0)
+                       blocksize=int(blocksize))
         raise ValueError(f"unknown compression {name!r}")
 
     # -- data -------------------------------------------------------------------------------
@@ -403,12 +405,12 @@ class ZarrArray:
     # -- creation ---------------------------------------------------------------------------
     @classmethod
     def create(cls, path: Path, version: str, shape, chunks, dtype, compress: str | None = None,
-               shards=None):
+               shards=None, blocksize: int = 0):
         """``compress``: see ``_BlockCodec.named``.  ``shards`` (NGFF 0.5 only): shape of the files,
         a multiple of ``chunks`` -- ``compress="blosc-zstd"`` with shards is the acquisition's layout."""
         path = Path(path)
         dtype = np.dtype(dtype)
-        codec = _BlockCodec.named(compress, dtype)
+        codec = _BlockCodec.named(compress, dtype, blocksize)
         if version == "0.5":
             inner = codec.to_v3()
             if shards is not None:
@@ -596,7 +598,7 @@ class ZarrArray:
 
             self._fan_out(one, self._inner_of(lead, fidx), threads)
 
-    def _write_shard(self, lead, fidx, vol: np.ndarray, threads: int = 1) -> None:
+    def _write_shard(self, lead, fidx, vol, threads: int = 1, encoded: dict | None = None) -> None:
         k = len(lead)
         path = self._file_path(tuple(i // s for i, s in zip(lead, self.shards[:k])) + tuple(fidx))
         if any(s > 1 for s in self.shards[:k]):
@@ -604,11 +606,11 @@ class ZarrArray:
             # writer threads of a streamed run, or ranks, may hold different volumes of this shard
             path.parent.mkdir(parents=True, exist_ok=True)
             with _shard_lock(path):
-                self._write_shard_locked(path, lead, fidx, vol, threads, merge=True)
+                self._write_shard_locked(path, lead, fidx, vol, threads, merge=True, encoded=encoded)
         else:
-            self._write_shard_locked(path, lead, fidx, vol, threads, merge=False)
+            self._write_shard_locked(path, lead, fidx, vol, threads, merge=False, encoded=encoded)
 
-    def _write_shard_locked(self, path, lead, fidx, vol, threads, merge: bool) -> None:
+    def _write_shard_locked(self, path, lead, fidx, vol, threads, merge: bool, encoded: dict | None = None) -> None:
         from .codecs import crc32c
 
         k = len(lead)
@@ -633,7 +635,10 @@ class ZarrArray:
                 block[tuple(slice(0, s.stop - s.start) for s in sl)] = vol[sl]
             return inner, self._codec.encode(np.ascontiguousarray(block, dtype=self.dtype))
 
-        blobs.update(self._fan_out(encode, self._inner_of(lead, fidx), threads))
+        if encoded is not None:        # chunks that arrive as frames (written on the device): stored as they are
+            blobs.update(encoded)
+        else:
+            blobs.update(self._fan_out(encode, self._inner_of(lead, fidx), threads))
         index = np.full(counts + (2,), _MISSING, dtype="<u8")
         ilen = index.nbytes + (4 if self._index_crc else 0)
         pos = ilen if self._index_location == "start" else 0
@@ -741,6 +746,175 @@ class ZarrArray:
 
         self._map_chunks(write_one, files, vol.nbytes, "write")
 
+    # -- volumes as they lie in the store (for the device-side decoder) -----------------------
+    def _frame_sources(self, lead):
+        """[(z-chunk index, path, offset, nbytes)] of every stored chunk of the volume at ``lead`` (absent chunks are
+        left out); offset / nbytes are ``None`` for a chunk that is a whole file."""
+        k = len(lead)
+        zc = self.chunks[k]
+        nz = -(-self.shape[k] // zc)
+        out = []
+        if self.shards is None:
+            for i in range(nz):
+                path = self._file_path(lead + (i, 0, 0))
+                try:
+                    out.append((i, path, 0, os.stat(path).st_size))
+                except FileNotFoundError:
+                    pass
+            return out
+        per = self.shards[k] // zc
+        head = tuple(i % s for i, s in zip(lead, self.shards[:k]))
+        for fz in range(-(-nz // per)):
+            path = self._file_path(tuple(i // s for i, s in zip(lead, self.shards[:k])) + (fz, 0, 0))
+            try:
+                with open(path, "rb", buffering=0) as f:
+                    size = os.fstat(f.fileno()).st_size
+                    index = self._read_shard_index(f, size)
+            except FileNotFoundError:
+                continue
+            for i in range(fz * per, min((fz + 1) * per, nz)):
+                off, nb = (int(v) for v in index[head + (i - fz * per, 0, 0)])
+                if off == _MISSING and nb == _MISSING:
+                    continue
+                if off + nb > size:
+                    raise OSError(f"shard {path}: chunk {i} runs past the end of the file")
+                out.append((i, path, off, nb))
+        return out
+
+    def compressed_layout(self, *lead) -> dict | None:
+        """What the device-side decoder (``io/device_codec.DeviceBloscDecoder``) needs to take this array's volumes as
+        they lie in the store -- ``dict(nbytes, blocksize, typesize, n_frames)`` read from the first stored chunk of the
+        volume at ``lead`` -- or ``None`` when the chunks are not blosc-zstd frames of whole (Y, X) planes."""
+        from .device_codec import frame_layout
+
+        k = len(self.shape) - 3
+        if self._codec.kind != "blosc" or self.dtype.itemsize not in (1, 2, 4):
+            return None
+        if any(v != 1 for v in self.chunks[:k]) or tuple(self.chunks[k + 1:]) != tuple(self.shape[k + 1:]):
+            return None
+        if self.shards is not None and tuple(self.shards[k + 1:]) != tuple(self.shape[k + 1:]):
+            return None
+        lead = self._check_lead(lead)
+        want = int(np.prod(self.chunks[k:])) * self.dtype.itemsize
+        for _, path, off, nb in self._frame_sources(lead):
+            with open(path, "rb", buffering=0) as f:
+                head = os.pread(f.fileno(), 16, off)
+            lay = frame_layout(head)
+            if lay is None or lay["nbytes"] != want or lay["typesize"] != self.dtype.itemsize:
+                return None
+            lay["n_frames"] = -(-self.shape[k] // self.chunks[k])
+            return lay
+        return None
+
+    def read_volume_frames(self, *lead, out: np.ndarray):
+        """The volume at ``lead`` as its stored chunk frames: the compressed bytes are read one after the other into
+        ``out`` (uint8, e.g. a pinned staging slot) and a ``device_codec.CompressedVolume`` says where each z-chunk's
+        frame lies (absent chunks: size 0).  No entropy decoding happens on the host; a CRC-32C suffix, where the codec
+        chain has one, is checked and left out."""
+        from .codecs import crc32c
+        from .device_codec import CompressedVolume
+
+        lead = self._check_lead(lead)
+        k = len(lead)
+        nz = -(-self.shape[k] // self.chunks[k])
+        crc = bool(self._codec.params.get("crc32c"))
+        buf = out.reshape(-1).view(np.uint8)
+        sources = self._frame_sources(lead)
+        table = np.zeros((nz, 2), dtype=np.int64)
+        at = 0
+        for i, _, _, nb in sources:
+            table[i] = (at, nb - (4 if crc else 0))
+            at += (nb + 15) // 16 * 16
+        if at > buf.size:
+            raise ValueError(f"the compressed chunks take {at} bytes, the buffer holds {buf.size}")
+
+        def read_one(item):
+            i, path, off, nb = item
+            dest = memoryview(buf[int(table[i, 0]):int(table[i, 0]) + nb])
+            with open(path, "rb", buffering=0) as f:
+                got = 0
+                while got < nb:
+                    n = os.preadv(f.fileno(), [dest[got:]], off + got)
+                    if n <= 0:
+                        raise OSError(f"{path}: short read of chunk {i}")
+                    got += n
+            if crc:
+                if nb < 4 or int(crc32c(dest[:nb - 4])) != int.from_bytes(dest[nb - 4:nb], "little"):
+                    raise ValueError(f"{path}: chunk {i}: CRC-32C mismatch")
+
+        self._map_chunks(read_one, sources, at, "read")
+        return CompressedVolume(table, at)
+
+    def encoded_frame_bytes(self) -> int | None:
+        """Decoded bytes of one chunk when this array can store chunks that arrive as blosc-zstd frames written on
+        the device (``io/device_codec.py``): blosc / zstd / byte shuffle of the array's own element size, chunks that
+        are whole (Y, X) planes -- else ``None`` (the volume is then encoded on the host, chunk by chunk)."""
+        k = len(self.shape) - 3
+        c = self._codec
+        if c.kind != "blosc" or c.params.get("cname") != "zstd" or self.dtype.itemsize not in (1, 2, 4):
+            return None
+        if (c.params.get("typesize") or self.dtype.itemsize) != self.dtype.itemsize:
+            return None
+        if self.dtype.itemsize > 1 and c.params.get("shuffle", 1) != 1:     # (one-byte elements: nothing to shuffle)
+            return None
+        if any(v != 1 for v in self.chunks[:k]) or tuple(self.chunks[k + 1:]) != tuple(self.shape[k + 1:]):
+            return None
+        if self.shards is not None and tuple(self.shards[k + 1:]) != tuple(self.shape[k + 1:]):
+            return None
+        return int(np.prod(self.chunks[k:])) * self.dtype.itemsize
+
+    def write_encoded_volume(self, *args) -> None:
+        """``write_encoded_volume(t, c, frames)``: store one volume whose chunks are already blosc frames
+        (``frames[i]`` = z-chunk i, each decoding to ``encoded_frame_bytes()`` bytes, the last one zero-padded) --
+        what ``staging.EncodedVolume.frames`` holds.  The host only writes bytes (plus the CRC-32C suffix where the
+        store's codec chain asks for one)."""
+        if self.mode == "r":
+            raise PermissionError("store opened read-only")
+        *lead, frames = args
+        lead = self._check_lead(lead)
+        k = len(lead)
+        want = self.encoded_frame_bytes()
+        if want is None:
+            raise UnsupportedCodec(f"{self.path}: chunks of this array cannot be stored as device-written blosc-zstd frames")
+        zc = self.chunks[k]
+        nz = -(-self.shape[k] // zc)
+        if len(frames) != nz:
+            raise ValueError(f"expected {nz} frames (z chunks of {zc} planes), got {len(frames)}")
+        from . import codecs
+
+        crc = bool(self._codec.params.get("crc32c"))
+
+        def blob(i):
+            f = frames[i]
+            head = codecs.blosc_header(bytes(f[:16]))
+            if head["nbytes"] != want or head["cbytes"] != len(f):
+                raise ValueError(f"frame {i}: holds {head['nbytes']} bytes in {head['cbytes']}, expected {want} in {len(f)}")
+            return f if not crc else bytes(f) + int(codecs.crc32c(f)).to_bytes(4, "little")
+
+        if self.shards is not None:
+            per = self.shards[k] // zc
+            counts = self._shard_counts()
+            head = tuple(i % s for i, s in zip(lead, self.shards[:k]))
+
+            def write_shard(fz):
+                enc = {head + (i - fz * per,) + (0,) * (len(counts) - k - 1): bytes(blob(i))
+                       for i in range(fz * per, min((fz + 1) * per, nz))}
+                self._write_shard(lead, (fz, 0, 0), None, 1, encoded=enc)
+
+            self._map_chunks(write_shard, list(range(-(-nz // per))), sum(len(f) for f in frames), "write")
+            return
+
+        def write_one(i):
+            path = self._file_path(lead + (i, 0, 0))
+            path.parent.mkdir(parents=True, exist_ok=True)
+            view = memoryview(blob(i))
+            with open(path, "wb", buffering=0) as f:
+                done = 0
+                while done < len(view):
+                    done += f.write(view[done:])
+
+        self._map_chunks(write_one, list(range(nz)), sum(len(f) for f in frames), "write")
+
     def __getitem__(self, key):
         """Convenience for tests: ``arr[t, c]`` -> volume; ``arr[:]`` -> everything."""
         k = len(self.shape) - 3
@@ -784,7 +958,7 @@ class Position(_Node):
         return self["0"]
 
     def create_zeros(self, name: str, shape, dtype="float32", chunks=None, scale=None,
-                     compress: str | None = None, shards=None) -> ZarrArray:
+                     compress: str | None = None, shards=None, blocksize: int = 0) -> ZarrArray:
         """Create level ``name`` (TCZYX).  Default chunks follow the reference:
         ``(1, 1, min(32, nz), ny, nx)`` (``shrimpy/dynatrack/tracking.py:1362``).
         ``compress="blosc-zstd"`` with ``shards="volume"`` (one shard file per (t, c) volume) or an
@@ -799,7 +973,7 @@ class Position(_Node):
             if shards != "volume":
                 raise ValueError("shards must be a shape or 'volume'")
             shards = (1, 1) + tuple(-(-n // c) * c for n, c in zip(shape[2:], chunks[2:]))
-        arr = ZarrArray.create(self.path / name, self.version, shape, chunks, dtype, compress, shards)
+        arr = ZarrArray.create(self.path / name, self.version, shape, chunks, dtype, compress, shards, blocksize)
         scale = [float(s) for s in (scale if scale is not None else (1, 1, 1, 1, 1))]
         attrs = {
             "multiscales": [{

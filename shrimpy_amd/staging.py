@@ -22,7 +22,20 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["VolumeStager"]
+__all__ = ["VolumeStager", "EncodedVolume"]
+
+
+class EncodedVolume:
+    """One result as the chunk frames the device wrote (``io/device_codec.DeviceBloscEncoder``): ``frames[k]`` is a
+    uint8 numpy view (pinned host memory) of chunk k's blosc frame, chunks being consecutive z-ranges of
+    ``frame_bytes`` decoded bytes each.  Valid until the staging slot is reused."""
+
+    def __init__(self, frames, frame_bytes: int, shape, dtype=np.float32):
+        self.frames, self.frame_bytes, self.shape, self.dtype = frames, int(frame_bytes), tuple(shape), np.dtype(dtype)
+
+    @property
+    def nbytes(self) -> int:
+        return int(sum(f.size for f in self.frames))
 
 
 def _pinned_tensor(shape, dtype):
@@ -53,8 +66,20 @@ class VolumeStager:
     Slot ``k`` serves units ``k, k + depth, ...``; calls for one slot must come in unit order.
     """
 
-    def __init__(self, raw_shape, raw_dtype, out_shape, device, depth: int = 2, pin: str = "exact"):
+    def __init__(self, raw_shape, raw_dtype, out_shape, device, depth: int = 2, pin: str = "exact",
+                 encode_frame_bytes: int | None = None, encode_blocksize: int = 0, decode_layout: dict | None = None):
         """``depth`` slots each way (default 2; more only helps when load times vary a lot).
+
+        ``encode_frame_bytes``: the result leaves the device as blosc-zstd chunk frames of that many decoded bytes
+        each (``csrc/blosc_encode.hip``): ``stage_out`` runs the encoder on the download stream, ``collect`` returns
+        an :class:`EncodedVolume` whose frames the writer stores as they are -- the host never sees the float32
+        volume and never runs zstd.
+
+        ``decode_layout`` (``dict(nbytes, blocksize, typesize)``, from ``ZarrArray.compressed_layout``): the raw stack
+        arrives as the blosc-zstd chunk frames of the store.  ``host_in`` is then a pinned BYTE buffer the loader fills
+        with ``ZarrArray.read_volume_frames`` (file reads only), ``stage_in`` takes the resulting ``CompressedVolume``,
+        uploads the compressed bytes and runs the decoder (``csrc/blosc_decode.hip``) on the upload stream, and
+        ``acquire`` checks the decoder's status word before the kernels use the stack.
 
         ``pin``: ``"exact"`` takes page-locked allocations of exactly the slot size from the HIP runtime
         (``lsr_pinned_alloc`` = ``hipHostMalloc``) -- torch's caching host allocator rounds every pinned
@@ -83,9 +108,39 @@ class VolumeStager:
             raise TypeError(f"raw dtype {raw_dtype}: uint16 (camera counts) or float32")
         if pin not in ("exact", "torch", "none"):
             raise ValueError("pin must be 'exact', 'torch' or 'none'")
+        self._encoders = None
+        self.encode_frame_bytes = None
+        out_slot_shape, out_slot_dtype = self.out_shape, torch.float32
+        if encode_frame_bytes:
+            from .io.device_codec import DeviceBloscEncoder
+
+            nbytes = 4 * int(np.prod(self.out_shape))
+            self.encode_frame_bytes = int(encode_frame_bytes)
+            self._encoders = [DeviceBloscEncoder(nbytes, 4, self.encode_frame_bytes, self.device, encode_blocksize)
+                              for _ in range(depth)]
+            out_slot_shape, out_slot_dtype = (self._encoders[0].capacity,), torch.uint8
+            self._table_host = [torch.empty((self._encoders[0].n_frames, 2), dtype=torch.int64).pin_memory()
+                                for _ in range(depth)]
+            self._table_ready = [None] * depth
+        self._decoder = None
+        in_slot_shape, in_slot_dtype = self.raw_shape, dt
+        if decode_layout:
+            from .io.device_codec import DeviceBloscDecoder
+
+            raw_bytes = int(np.prod(self.raw_shape)) * np.dtype(raw_dtype).itemsize
+            if int(decode_layout["typesize"]) != np.dtype(raw_dtype).itemsize:
+                raise ValueError(f"chunk frames of {decode_layout['typesize']}-byte elements for a {np.dtype(raw_dtype)} stack")
+            self._decoder = DeviceBloscDecoder(raw_bytes, decode_layout["nbytes"], decode_layout["blocksize"],
+                                               decode_layout["typesize"], self.device)
+            cap = self._decoder.comp_capacity + 16 * self._decoder.n_frames
+            in_slot_shape, in_slot_dtype = (cap,), torch.uint8
+            self._comp_dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            self._table_in_dev = torch.empty((self._decoder.n_frames, 2), dtype=torch.int64, device=self.device)
+            self._table_in_host = [torch.empty((self._decoder.n_frames, 2), dtype=torch.int64).pin_memory() for _ in range(depth)]
+            self._status_host = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(depth)]
         with torch.cuda.device(self.device):
-            self._host_in = [self._host_slot(self.raw_shape, dt, pin) for _ in range(depth)]
-            self._host_out = [self._host_slot(self.out_shape, torch.float32, pin) for _ in range(depth)]
+            self._host_in = [self._host_slot(in_slot_shape, in_slot_dtype, pin) for _ in range(depth)]
+            self._host_out = [self._host_slot(out_slot_shape, out_slot_dtype, pin) for _ in range(depth)]
         self._dev_in = [torch.empty(self.raw_shape, dtype=dt, device=self.device) for _ in range(depth)]
         self._up = torch.cuda.Stream(self.device)
         self._down = torch.cuda.Stream(self.device)
@@ -111,6 +166,12 @@ class VolumeStager:
         last view dies -- a numpy view a caller still holds (``host_in`` / ``collect``) keeps it valid."""
         self.drain()
         self._host_in, self._host_out, self._dev_in = [], [], []
+        self._encoders = self._decoder = None
+
+    @property
+    def takes_frames(self) -> bool:
+        """True when ``host_in`` is a byte buffer for ``ZarrArray.read_volume_frames`` (``decode_layout`` was given)."""
+        return self._decoder is not None
 
     # ---- host -> device --------------------------------------------------------------------
     def host_in(self, slot: int) -> np.ndarray:
@@ -127,6 +188,27 @@ class VolumeStager:
         import torch
 
         view = self.host_in(slot)
+        if self._decoder is not None:
+            from .io.device_codec import CompressedVolume
+
+            if not isinstance(data, CompressedVolume):
+                raise TypeError("a stager with decode_layout takes the CompressedVolume that read_volume_frames returned "
+                                "for this slot's buffer")
+            if data.used > view.size or tuple(data.table.shape) != tuple(self._table_in_host[slot].shape):
+                raise ValueError(f"compressed volume of {data.used} bytes / {data.table.shape[0]} chunks does not fit the slot")
+            self._table_in_host[slot].numpy()[...] = data.table
+            with torch.cuda.stream(self._up):
+                if self._consumed[slot] is not None:
+                    self._up.wait_event(self._consumed[slot])
+                used = max(int(data.used), 1)
+                self._comp_dev[:used].copy_(self._host_in[slot][:used], non_blocking=True)
+                self._table_in_dev.copy_(self._table_in_host[slot], non_blocking=True)
+                self._decoder.decode(self._comp_dev, int(data.used), self._table_in_dev, self._dev_in[slot])
+                self._status_host[slot].copy_(self._decoder.status, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._up)
+            self._uploaded[slot] = ev
+            return slot
         if data is not None and not (isinstance(data, np.ndarray) and np.shares_memory(data, view)):
             arr = np.asarray(data)
             if arr.shape != view.shape:
@@ -146,6 +228,11 @@ class VolumeStager:
         import torch
 
         torch.cuda.current_stream(self.device).wait_event(self._uploaded[slot])
+        if self._decoder is not None:
+            # the decoder's verdict on this unit's chunks: known once its launches have run (the kernels of this unit
+            # could not start before that anyway)
+            self._uploaded[slot].synchronize()
+            self._decoder.check(int(self._status_host[slot].item()))
         return self._dev_in[slot]
 
     def release(self, slot: int) -> None:
@@ -175,6 +262,19 @@ class VolumeStager:
                 break
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
+        if self._encoders is not None:
+            # frames are written on the download stream (beside the next unit's kernels); only the (offset, size)
+            # table comes down now -- collect() then copies exactly the compressed bytes
+            with torch.cuda.stream(self._down):
+                self._down.wait_event(done)
+                _, table = self._encoders[slot].encode(result.contiguous())
+                result.record_stream(self._down)
+                self._table_host[slot].copy_(table, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._down)
+            self._table_ready[slot] = ev
+            self._downloaded[slot] = None
+            return
         with torch.cuda.stream(self._down):
             self._down.wait_event(done)
             self._host_out[slot].copy_(result, non_blocking=True)
@@ -183,9 +283,25 @@ class VolumeStager:
             ev.record(self._down)
         self._downloaded[slot] = ev
 
-    def collect(self, slot: int) -> np.ndarray:
+    def collect(self, slot: int):
         """The slot's result on the host (pinned numpy view), after its download has finished.
-        Valid until the slot's next ``stage_out``."""
+        Valid until the slot's next ``stage_out``.  With ``encode_frame_bytes``: an :class:`EncodedVolume`."""
+        if self._encoders is not None:
+            import torch
+
+            self._table_ready[slot].synchronize()
+            table = self._table_host[slot].numpy()
+            end = int(table[-1, 0] + table[-1, 1])
+            if end > self._host_out[slot].numel():
+                raise _lib.LsrError("VolumeStager.collect", -1, f"frames end at byte {end}, the slot holds {self._host_out[slot].numel()}")
+            with torch.cuda.stream(self._down):
+                self._host_out[slot][:end].copy_(self._encoders[slot].out[:end], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._down)
+            self._downloaded[slot] = ev
+            ev.synchronize()
+            host = self._host_out[slot].numpy()
+            return EncodedVolume([host[int(o):int(o) + int(n)] for o, n in table], self.encode_frame_bytes, self.out_shape)
         self._downloaded[slot].synchronize()
         return self._host_out[slot].numpy()
 

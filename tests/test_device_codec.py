@@ -149,3 +149,260 @@ def test_device_encoder_on_a_hot_path_result(device):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         total += len(frame)
     assert total < 0.8 * host.nbytes
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# decoder (csrc/zstd_lane.hpp, csrc/blosc_decode.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _lane_decode(frame: bytes, n: int) -> np.ndarray:
+    lib = _lib.load()
+    src = np.frombuffer(frame, np.uint8)
+    dst = np.empty(max(n, 1), np.uint8)
+    got = ctypes.c_int64()
+    rc = lib.lsr_zstd_lane_decode_cpu(src.ctypes.data, src.size, dst.ctypes.data, n, ctypes.byref(got))
+    if rc != 0:
+        raise ValueError(lib.lsr_last_error().decode())
+    return dst[:got.value]
+
+
+def _structured(rng, kind, n):
+    if kind == 0:
+        return rng.integers(0, 256, n, dtype=np.uint8)
+    if kind == 1:
+        return rng.integers(0, int(rng.integers(1, 20)), n).astype(np.uint8)
+    if kind == 2:
+        return (np.arange(n) % int(rng.integers(1, 300))).astype(np.uint8)
+    if kind == 3:     # shuffled camera counts
+        a = rng.poisson(rng.uniform(1, 200), n // 2 + 1).astype(np.uint16)
+        return a.view(np.uint8).reshape(-1, 2).T.copy().reshape(-1)[:n]
+    if kind == 4:     # shuffled float32
+        a = (rng.standard_normal(n // 4 + 1) * rng.uniform(0.1, 1e4) + rng.uniform(0, 1e3)).astype(np.float32)
+        return a.view(np.uint8).reshape(-1, 4).T.copy().reshape(-1)[:n]
+    if kind == 5:     # phrases: many short matches, repeat offsets
+        words = [bytes(rng.integers(97, 123, int(rng.integers(2, 12)), dtype=np.uint8)) for _ in range(int(rng.integers(2, 200)))]
+        out = bytearray()
+        while len(out) < n:
+            out += words[int(rng.integers(0, len(words)))] + b" "
+        return np.frombuffer(bytes(out[:n]), np.uint8)
+    out = np.repeat(rng.integers(0, 256, n // 50 + 1, dtype=np.uint8), rng.integers(1, 100, n // 50 + 1))   # runs
+    return np.resize(out, n)
+
+
+@pytest.mark.parametrize("level", [1, 3, 9, 19, -5])
+def test_lane_decoder_reads_what_libzstd_writes(level):
+    """Every block and literal type, predefined / RLE / FSE / repeat sequence tables, repeat offsets, multi-block frames
+    (level 19 splits a 128 KB input; 400 KB inputs have four blocks): frames from the system libzstd at several levels."""
+    if not codecs.have_zstd():
+        pytest.skip("no zstd compressor on this host")
+    rng = np.random.default_rng(100 + level)
+    for case in range(60):
+        n = int(rng.choice([0, 1, 17, 300, 5000, 32768, 65536, 131072, 131073, 200000, 400000]))
+        data = _structured(rng, case % 7, n) if n else np.zeros(0, np.uint8)
+        frame = codecs.zstd_compress(data.tobytes(), level)
+        assert np.array_equal(_lane_decode(frame, n), data), (case, n, level)
+
+
+def test_lane_decoder_refuses_damaged_frames_without_faulting():
+    """Truncations, bit flips and a destination that is too small: an error (or, for a flip the format cannot see,
+    different bytes) -- never an access outside the two buffers (tools/host_sanitize.sh runs this under ASan)."""
+    rng = np.random.default_rng(9)
+    data = _structured(rng, 5, 60000)
+    frame = bytearray(codecs.zstd_compress(data.tobytes(), 3))
+    for cut in (0, 3, 5, 9, len(frame) // 2, len(frame) - 1):
+        with pytest.raises(ValueError):
+            _lane_decode(bytes(frame[:cut]), data.size)
+    with pytest.raises(ValueError):
+        _lane_decode(bytes(frame), data.size - 1)
+    flips = refused = 0
+    for _ in range(300):
+        bad = bytearray(frame)
+        for _ in range(int(rng.integers(1, 4))):
+            bad[int(rng.integers(4, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        flips += 1
+        try:
+            got = _lane_decode(bytes(bad), data.size)
+            assert got.size <= data.size
+        except ValueError:
+            refused += 1
+    assert refused > flips // 2
+
+
+def test_decoder_twin_reads_c_blosc_golden_frames(golden_dir):
+    """Frames a real c-blosc 1.21.0 wrote (``oracle/make_blosc_golden.py``): split and unsplit blocks, a leftover block, no
+    shuffle -- every zstd frame of the fixture the device decoder's layout covers."""
+    from shrimpy_amd.io.device_codec import decode_frames_host, frame_layout
+
+    g = np.load(golden_dir / "blosc_frames.npz")
+    taken = 0
+    for name in sorted({k.rsplit(".", 1)[0] for k in g.files}):
+        frame, want = g[name + ".frame"].tobytes(), g[name + ".data"]
+        lay = frame_layout(frame)
+        if lay is None:
+            continue
+        got = decode_frames_host([frame], lay["nbytes"], lay["blocksize"], lay["typesize"], want.nbytes)
+        np.testing.assert_array_equal(got.view(want.dtype), want.reshape(-1), err_msg=name)
+        taken += 1
+    assert taken >= 4
+
+
+@pytest.mark.parametrize("dtype,blocksize", [("uint16", 32768), ("uint16", 0), ("float32", 0), ("float32", 65536), ("uint8", 4096)])
+def test_decoder_twin_on_volumes_of_frames(dtype, blocksize):
+    """A volume as consecutive chunk frames -- written by the host zstd encoder (what a real store holds) and by this
+    package's device encoder twin -- with a ragged last chunk, an absent chunk and a damaged one."""
+    from shrimpy_amd.io.device_codec import DecodeError, decode_frames_host, frame_layout
+
+    rng = np.random.default_rng(5)
+    arr = rng.poisson(120, 300_000).astype(dtype) if dtype != "float32" else _rl_like(200_000)
+    T = arr.dtype.itemsize
+    raw = arr.view(np.uint8)
+    fb = 1 << 18
+    chunks = [np.zeros(fb, np.uint8) for _ in range(-(-raw.size // fb))]
+    for f, c in enumerate(chunks):
+        seg = raw[f * fb:(f + 1) * fb]
+        c[:seg.size] = seg
+    for writer in ("zstd-1", "device twin"):
+        if writer == "zstd-1":
+            frames = [codecs.blosc_encode(c.view(arr.dtype), T, "zstd", 1, codecs.SHUFFLE_BYTE, blocksize, backend="lsrecon") for c in chunks]
+        else:
+            frames = encode_frames_host(arr, fb, blocksize)
+        lay = frame_layout(frames[0])
+        assert lay is not None and lay["nbytes"] == fb
+        got = decode_frames_host(frames, fb, lay["blocksize"], T, raw.size)
+        assert np.array_equal(got, raw), writer
+        holed = list(frames)
+        holed[1] = b""
+        got = decode_frames_host(holed, fb, lay["blocksize"], T, raw.size)
+        assert not got[fb:2 * fb].any() and np.array_equal(got[:fb], raw[:fb]) and np.array_equal(got[2 * fb:], raw[2 * fb:])
+        bad = bytearray(frames[0])
+        bad[20] ^= 0xFF            # a bstart: the block table no longer points at a stream
+        with pytest.raises(DecodeError) as err:
+            decode_frames_host([bytes(bad)] + frames[1:], fb, lay["blocksize"], T, raw.size)
+        assert err.value.frame == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,blocksize", [("uint16", 32768), ("uint16", 0), ("float32", 0), ("uint8", 4096)])
+def test_device_decoder_equals_the_volume(device, dtype, blocksize):
+    """The kernels on frames of the host zstd encoder (32 KB blocks = the acquisition's), bit for bit, with an absent chunk;
+    a damaged chunk is reported through the status word and nothing faults."""
+    import torch
+
+    from shrimpy_amd.io.device_codec import DecodeError, DeviceBloscDecoder, frame_layout
+
+    rng = np.random.default_rng(6)
+    arr = rng.poisson(120, 3_000_000).astype(dtype) if dtype != "float32" else _rl_like(1_500_000)
+    T = arr.dtype.itemsize
+    raw = arr.view(np.uint8)
+    fb = 1 << 20
+    chunks = [np.zeros(fb, np.uint8) for _ in range(-(-raw.size // fb))]
+    for f, c in enumerate(chunks):
+        seg = raw[f * fb:(f + 1) * fb]
+        c[:seg.size] = seg
+    frames = [codecs.blosc_encode(c.view(arr.dtype), T, "zstd", 1, codecs.SHUFFLE_BYTE, blocksize, backend="lsrecon") for c in chunks]
+    frames[2] = b""
+    lay = frame_layout(frames[0])
+    dec = DeviceBloscDecoder(raw.size, fb, lay["blocksize"], T, device)
+    out = torch.empty(raw.size, dtype=torch.uint8, device=device)
+    dec.decode_from_host(frames, out)
+    want = raw.copy()
+    want[2 * fb:3 * fb] = 0
+    assert np.array_equal(out.cpu().numpy(), want)
+    # frames of this package's own device encoder twin decode too
+    mine = encode_frames_host(arr, fb, blocksize)
+    dec2 = DeviceBloscDecoder(raw.size, fb, frame_layout(mine[0])["blocksize"], T, device)
+    dec2.decode_from_host(mine, out)
+    assert np.array_equal(out.cpu().numpy(), raw)
+    bad = bytearray(frames[0])
+    bad[len(bad) // 2] ^= 0x5A
+    bad[20] ^= 0xFF
+    with pytest.raises(DecodeError):
+        dec.decode_from_host([bytes(bad)] + frames[1:], out)
+    dec.decode_from_host(frames, out)           # and the decoder is fine afterwards
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_device_decoder_reads_libzstd_frames_of_every_kind(device):
+    """The lane decoder on the device against libzstd at several levels (sequences, repeat offsets, all table modes):
+    blocks of structured bytes, one zstd frame per blosc block."""
+    import torch
+
+    from shrimpy_amd.io.device_codec import DeviceBloscDecoder
+
+    rng = np.random.default_rng(12)
+    bs, nblocks = 65536, 96
+    blocks = [_structured(rng, k % 7, bs) for k in range(nblocks)]
+    data = np.concatenate(blocks)
+    for level in (1, 5, 19):
+        body, starts = b"", []
+        pos = 16 + 4 * nblocks
+        for b in blocks:
+            z = codecs.zstd_compress(b.tobytes(), level)
+            if len(z) >= bs:
+                z = b.tobytes()
+            starts.append(pos)
+            body += len(z).to_bytes(4, "little") + z
+            pos += 4 + len(z)
+        head = bytes([2, 1, 0x10 | (4 << 5), 1]) + data.size.to_bytes(4, "little") + bs.to_bytes(4, "little") + pos.to_bytes(4, "little")
+        frame = head + b"".join(s.to_bytes(4, "little") for s in starts) + body
+        assert np.array_equal(codecs.blosc_decode(frame, backend="lsrecon"), data)       # the frame is well formed
+        dec = DeviceBloscDecoder(data.size, data.size, bs, 1, device)
+        out = torch.empty(data.size, dtype=torch.uint8, device=device)
+        dec.decode_from_host([frame], out)
+        assert np.array_equal(out.cpu().numpy(), data), level
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# store to store through the device codecs (cli.run_store)
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", ["volume", None])
+def test_store_to_store_with_device_codecs_equals_the_host_codec_run(tmp_path, device, shards):
+    """An input plate in the acquisition's format (Zarr v3, blosc-zstd chunks of 32 planes with 32 KB blocks, one shard per
+    volume) -> deskew + RL -> blosc-zstd output.  With the device codecs the host neither decodes nor encodes a byte; the
+    output store must hold the same volumes, bit for bit, as the run with the host codecs, and every chunk file of it must
+    decode with the system libzstd."""
+    import torch
+
+    import bench
+    from shrimpy_amd import cli
+    from shrimpy_amd.io.omezarr import as_volume_array, open_ome_zarr
+    from shrimpy_amd.settings import DeconvolveSettings, DeskewSettings, ReconstructSettings
+
+    raw_shape = (320, 48, 192)
+    keys = ["A/1/0", "A/2/0", "B/1/0"]
+    with open_ome_zarr(tmp_path / "in.zarr", layout="hcs", mode="w", channel_names=["LS"], prefer_iohub=False, version="0.5") as plate:
+        for p, key in enumerate(keys):
+            arr = plate.create_position(*key.split("/")).create_zeros(
+                "0", shape=(2, 1) + raw_shape, dtype="uint16", scale=(1, 1, 0.15, 0.1133, 0.1133), compress="blosc-zstd",
+                shards=shards, blocksize=32768)
+            for t in range(2):
+                if (p, t) == (1, 1):
+                    continue                                    # a volume that was never written: fill value
+                arr.write_volume(t, 0, bench.synthetic_raw(raw_shape, seed=77 + 7 * p + t, device=device).to(torch.uint16).cpu().numpy())
+    settings = ReconstructSettings(
+        deskew=DeskewSettings(pixel_size_um=0.1133, scan_step_um=0.15, ls_angle_deg=30.0, keep_overhang=False, average_n_slices=3),
+        deconvolution=DeconvolveSettings(iterations=5))
+    res = cli.run_store(tmp_path / "in.zarr", tmp_path / "dev.zarr", settings, compression="blosc-zstd", zarr_version="0.5")
+    assert res["device_codec"] == {"encode": True, "decode": True} and res["units"] == 6
+    ref = cli.run_store(tmp_path / "in.zarr", tmp_path / "host.zarr", settings, compression="blosc-zstd", zarr_version="0.5",
+                        device_codec=False)
+    assert ref["device_codec"] == {"encode": False, "decode": False}
+    with open_ome_zarr(tmp_path / "dev.zarr", prefer_iohub=False) as a, open_ome_zarr(tmp_path / "host.zarr", prefer_iohub=False) as b:
+        pa, pb = dict(a.positions()), dict(b.positions())
+        for key in keys:
+            va, vb = as_volume_array(pa[key]["0"]), as_volume_array(pb[key]["0"])
+            assert va.shape == vb.shape and va._codec.kind == "blosc"
+            for t in range(2):
+                x, y = va.read_volume(t, 0), vb.read_volume(t, 0)
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (key, t)
+            assert not va.read_volume(1, 0).any() if key == "A/2/0" else va.read_volume(1, 0).any()
+    # every chunk the device wrote is a frame libzstd reads (read_volume above went through lsr_blosc_decode_host);
+    # and the Python walker agrees on one of them
+    chunk = next(p for p in sorted((tmp_path / "dev.zarr").rglob("*")) if p.is_file() and p.name.isdigit())
+    raw = chunk.read_bytes()
+    out = np.empty(codecs.blosc_header(raw)["nbytes"], np.uint8)
+    codecs._py_blosc_decode(raw, out)
+    assert np.array_equal(out, codecs.blosc_decode(raw, backend="lsrecon"))

@@ -35,6 +35,68 @@ def rl_like(shape, device, seed=0):
     return x.reshape(shape).contiguous()
 
 
+def bench_decode(args, dev):
+    """A config-4 camera stack (2048, 256, 2048) uint16 as 64 chunks of 32 planes, each a blosc-zstd frame written by the
+    HOST zstd encoder at level 1 with 32 KB blocks (what c-blosc, and so the acquisition, writes) -> decoded on the device."""
+    import torch
+
+    from concurrent.futures import ThreadPoolExecutor
+
+    import bench
+
+    from shrimpy_amd import _lib
+    from shrimpy_amd.io import codecs
+    from shrimpy_amd.io.device_codec import DeviceBloscDecoder
+
+    shape = (2048, 256, 2048)
+    raw = bench.synthetic_raw(shape, seed=4000, device=dev).to(torch.uint16).cpu().numpy()
+    zc = 32
+    fb = zc * shape[1] * shape[2] * 2
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(16) as pool:
+        frames = list(pool.map(lambda i: codecs.blosc_encode(raw[i:i + zc], 2, "zstd", 1, codecs.SHUFFLE_BYTE, args.decode_blocksize,
+                                                             backend="lsrecon"), range(0, shape[0], zc)))
+    t_enc = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(16) as pool:
+        outs = list(pool.map(lambda f: codecs.blosc_decode(f, backend="lsrecon"), frames))
+    t_host = time.perf_counter() - t0
+    del outs
+    dec = DeviceBloscDecoder(raw.nbytes, fb, args.decode_blocksize, 2, dev)
+    table = np.zeros((len(frames), 2), np.int64)
+    at = 0
+    for f, fr in enumerate(frames):
+        table[f] = (at, len(fr))
+        at += (len(fr) + 15) // 16 * 16
+    blob = np.zeros(at, np.uint8)
+    for (o, n), fr in zip(table, frames):
+        blob[o:o + n] = np.frombuffer(fr, np.uint8)
+    comp = torch.as_tensor(blob).to(dev)
+    tab = torch.as_tensor(table).to(dev)
+    out = torch.empty(shape, dtype=torch.uint16, device=dev)
+    dec.decode(comp, at, tab, out)
+    torch.cuda.synchronize()
+    dec.check(int(dec.status.cpu().item()))
+    assert np.array_equal(out.cpu().numpy(), raw), "device decode differs from the stack"
+    stream = torch.cuda.current_stream(dev)
+    times = []
+    for _ in range(args.reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        dec.decode(comp, at, tab, out)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    print(json.dumps({
+        "what": "lsr_blosc_decode_device", "shape": list(shape), "dtype": "uint16", "frames": len(frames), "frame_bytes": fb,
+        "blocksize": args.decode_blocksize, "blocks": len(frames) * (fb // args.decode_blocksize),
+        "compressed_bytes": int(table[:, 1].sum()), "ratio": round(float(table[:, 1].sum()) / raw.nbytes, 4),
+        "ms": round(float(np.median(times)), 3), "ms_all": [round(t, 3) for t in times],
+        "decoded_GBps": round(raw.nbytes / (np.median(times) * 1e-3) / 1e9, 1),
+        "host_16_threads_decode_s": round(t_host, 3), "host_16_threads_encode_s": round(t_enc, 3),
+        "checked": "bit-equal to the stack", "library": _lib.library_source_sha16()}))
+
+
 def main():
     import torch
 
@@ -49,8 +111,12 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", action="store_true", help="decode every frame with libzstd and compare")
     ap.add_argument("--from-pipeline", action="store_true", help="encode a real deskew + RL result (config-4 unit)")
+    ap.add_argument("--decode", action="store_true", help="time lsr_blosc_decode_device on a config-4 camera stack instead")
+    ap.add_argument("--decode-blocksize", type=int, default=32768, help="blosc block size of the frames (c-blosc's own for zstd level 1)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.decode:
+        return bench_decode(args, dev)
     if args.from_pipeline:
         sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
         import bench
