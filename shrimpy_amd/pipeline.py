@@ -221,6 +221,8 @@ class ShardReport:
     # seconds each stage of the staged pipeline was busy, summed over this rank's units (``_run_staged``):
     # wait_slot / load / write / collect on the two host threads, wait_load / process / wait_store on the caller
     stage_seconds: dict = field(default_factory=dict)
+    # units this rank gave up on (``on_error="skip"``): (unit, stage, message), in unit order
+    failures: list = field(default_factory=list)
 
 
 def _dist():
@@ -239,6 +241,7 @@ def run_sharded(
     overlap_io: bool = True,
     stager=None,
     process_takes_unit: bool = False,
+    on_error: str = "raise",
 ) -> ShardReport:
     """Run ``store(unit, process(load(unit)))`` for this rank's share of ``units``.
 
@@ -260,7 +263,28 @@ def run_sharded(
     ``process_takes_unit``: call ``process(data, unit)`` (the CLI picks a per-channel reconstructor).
     An exception from ``load``, ``process`` or ``store`` propagates after the worker threads have
     stopped and the stager's copy streams have drained; units finished before it stay written.
+
+    ``on_error="skip"``: a unit whose ``load``, ``process`` or ``store`` raises an ``Exception`` is given up -- recorded in
+    ``ShardReport.failures`` as (unit, stage, message) -- and the rank carries on with its next unit, the way the
+    reference turns a failed stack into an ``{"type": "error"}`` record and keeps acquiring
+    (``shrimpy/dynatrack/worker.py:262-271``): one damaged chunk does not end a 19 200-unit run.
     """
+    if on_error not in ("raise", "skip"):
+        raise ValueError("on_error must be 'raise' or 'skip'")
+    skip = on_error == "skip"
+    failures: list = []
+
+    def guarded(stage, fn, unit, *args):
+        """fn(*args), or -- when skipping -- (False, None) after noting the failure."""
+        try:
+            return True, fn(*args)
+        except Exception as exc:  # noqa: BLE001 -- per-unit containment is the point
+            if not skip:
+                raise
+            logger.error("unit %s: %s failed, skipped: %s: %s", unit, stage, type(exc).__name__, exc)
+            failures.append((unit, stage, f"{type(exc).__name__}: {exc}"))
+            return False, None
+
     import torch
 
     dist = _dist()
@@ -280,7 +304,15 @@ def run_sharded(
     t0 = time.perf_counter()
     stage_seconds: dict = {}
     if stager is not None and mine:
-        _run_staged(mine, load, run, store, stager, stage_seconds)
+        _run_staged(mine, load, run, store, stager, stage_seconds, failures if skip else None)
+    elif skip:
+        for unit in mine:
+            ok, data = guarded("load", load, unit, unit)
+            if ok:
+                ok, result = guarded("process", run, unit, data, unit)
+            if ok:
+                sync()
+                guarded("store", store, unit, unit, result)
     elif overlap_io and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor
 
@@ -313,13 +345,16 @@ def run_sharded(
         dist.barrier()
     logger.info("rank %d/%d: %d of %d units in %.3fs (job %.3fs)", rank, world, len(mine), len(units),
                 seconds, max_seconds)
-    return ShardReport(rank, world, mine, seconds, max_seconds, len(units), stage_seconds)
+    failures.sort(key=lambda f: mine.index(f[0]) if f[0] in mine else len(mine))
+    return ShardReport(rank, world, mine, seconds, max_seconds, len(units), stage_seconds, failures)
 
 
-def _run_staged(mine, load, process, store, stager, times: dict | None = None) -> None:
+def _run_staged(mine, load, process, store, stager, times: dict | None = None, failures: list | None = None) -> None:
     """The ``stager`` branch of ``run_sharded``: loader thread -> up stream -> kernels -> down
     stream -> writer thread, slot ``i % depth`` for the i-th unit.  ``process(data, unit)``.
-    ``times`` collects how long each stage was busy (each key is touched by one thread only)."""
+    ``times`` collects how long each stage was busy (each key is touched by one thread only).
+    ``failures`` (a list): skip mode -- a unit whose stage raises is appended as (unit, stage, message) and left out;
+    the slots keep their order (slot ``i % depth`` belongs to unit i whether or not it got that far)."""
     import inspect
 
     from concurrent.futures import ThreadPoolExecutor
@@ -349,6 +384,11 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None) -
         return slot
 
     failed = []
+    skip = failures is not None
+
+    def note(i, stage_name, exc):
+        logger.error("unit %s: %s failed, skipped: %s: %s", mine[i], stage_name, type(exc).__name__, exc)
+        failures.append((mine[i], stage_name, f"{type(exc).__name__}: {exc}"))
 
     def write(i):
         if failed:                 # an earlier unit's write failed: nothing after it is written
@@ -359,36 +399,64 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None) -
             t = spent("collect", t)
             store(mine[i], host)
             spent("write", t)
+        except Exception as exc:  # noqa: BLE001
+            if skip:
+                note(i, "store", exc)
+                return
+            failed.append(i)
+            raise
         except BaseException:
             failed.append(i)
             raise
 
     loader, storer = ThreadPoolExecutor(1, "lsr-load"), ThreadPoolExecutor(1, "lsr-store")
-    stores: list = []       # one future per unit, in unit order (the single writer thread keeps them ordered)
+    stores: list = []       # one future (or None: the unit was skipped) per unit, in unit order
     nxt = None
     try:
         nxt = loader.submit(stage, 0)
         for i in range(len(mine)):
             t = clock()
-            slot = nxt.result()
+            slot = None
+            try:
+                slot = nxt.result()
+            except Exception as exc:  # noqa: BLE001
+                if not skip:
+                    raise
+                note(i, "load", exc)
             t = spent("wait_load", t)
             nxt = loader.submit(stage, i + 1) if i + 1 < len(mine) else None
-            result = process(stager.acquire(slot), mine[i])
-            stager.release(slot)
+            result = None
+            if slot is not None:
+                acquired = False
+                try:
+                    data = stager.acquire(slot)
+                    acquired = True
+                    result = process(data, mine[i])
+                except Exception as exc:  # noqa: BLE001
+                    if not skip:
+                        raise
+                    note(i, "process" if acquired else "load", exc)   # (a chunk the device decoder refuses shows up at acquire)
+                    result = None
+                finally:
+                    stager.release(slot)
             t = spent("process", t)
             # the result slot of unit i was last used by unit i - depth: its write must be over before
             # the download of unit i lands there.  The write of unit i - 1 may still be running -- it
             # overlaps the kernels and the download of unit i (waiting for it here instead cost a
             # third of the streamed rate: 0.11 s per config-4 unit against 0.05 s of the slowest stage)
-            if i - depth >= 0:
+            if i - depth >= 0 and stores[i - depth] is not None:
                 stores[i - depth].result()
             t = spent("wait_store", t)
-            stager.stage_out(slot, result)
+            if result is None:
+                stores.append(None)
+                continue
+            stager.stage_out(i % depth, result)
             spent("stage_out", t)
             stores.append(storer.submit(write, i))
         t = clock()
         for fut in stores:
-            fut.result()            # the last writes; raises the first writer error, if any
+            if fut is not None:
+                fut.result()        # the last writes; raises the first writer error, if any
         spent("wait_store", t)
         stores = []
     finally:
@@ -402,7 +470,8 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None) -
                 pass
         for fut in stores:
             try:
-                fut.result()
+                if fut is not None:
+                    fut.result()
             except Exception:  # noqa: BLE001
                 pass
         loader.shutdown(wait=True)
@@ -410,36 +479,61 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None) -
         stager.drain()
 
 
-def gather_to_rank0(local: Iterable, n_total: int):
+def gather_to_rank0(local: Iterable, n_total: int, keep_on_host: bool = False):
     """Optional final gather (the north-star's "stitched-volume gather"): rank 0 receives every
     rank's result tensors in unit order; other ranks return ``None``.
 
-    ``local`` = this rank's results in the order of ``shard_units``.  Point-to-point sends to rank 0
-    (each peer over its own xGMI link when the backend is RCCL) rather than a ring all-gather,
-    which would be bound by one link for this many-to-one pattern.
+    ``local`` = this rank's results in the order of ``shard_units`` (units ``rank, rank + W, ...``); ranks may own
+    different numbers of units and units may differ in shape -- every rank first publishes (shape, dtype) of what it
+    holds.  The transfer goes round by round: in round k rank 0 posts the receives of EVERY peer's k-th unit at once
+    (``batch_isend_irecv``: one grouped launch under RCCL), so the W - 1 incoming transfers of a round run side by side,
+    each over its own xGMI link -- a point-to-point gather, not a ring all-gather, which one link would bound for this
+    many-to-one pattern.  At most W - 1 received volumes are in flight on rank 0's device at a time.
+
+    ``keep_on_host``: rank 0 returns CPU tensors (each round's volumes are copied to host memory before the next round is
+    received): 96 results of 1.75 GB (config 4) do not have to fit rank 0's HBM next to its own working set.
     """
     import torch
 
     dist = _dist()
     local = list(local)
     if dist is None:
-        return local
+        return [t.cpu() if keep_on_host and hasattr(t, "cpu") else t for t in local]
     rank, world = dist.get_rank(), dist.get_world_size()
+    metas: list = [None] * world
+    dist.all_gather_object(metas, [(tuple(t.shape), str(t.dtype).replace("torch.", "")) for t in local])
+    counts = [len(m) for m in metas]
+    expect = [len(range(r, n_total, world)) for r in range(world)]
+    if counts != expect:
+        raise RuntimeError(f"ranks hold {counts} results, a round-robin of {n_total} units over {world} ranks is {expect}")
     # gloo moves host memory only: device tensors are staged through the host (ranks sharing one card in a
     # rehearsal, or a CPU-only box); RCCL sends them GPU to GPU
-    via_host = dist.get_backend() == "gloo" and bool(local) and local[0].is_cuda
+    via_host = dist.get_backend() == "gloo" and any(t.is_cuda for t in local)
+    rounds = max(counts) if counts else 0
     if rank != 0:
-        for t in local:
-            dist.send(t.contiguous().cpu() if via_host else t.contiguous(), dst=0)
+        for k in range(rounds):
+            if k < len(local):
+                t = local[k].contiguous()
+                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, t.cpu() if via_host else t, 0)]):
+                    req.wait()
         return None
+    device = local[0].device if local else torch.device("cpu")
+    recv_device = torch.device("cpu") if (via_host or dist.get_backend() == "gloo") else device
     out: list = [None] * n_total
     for i, t in enumerate(local):
-        out[i * world] = t
-    for src in range(1, world):
-        for k, idx in enumerate(range(src, n_total, world)):
-            if not local:
-                raise RuntimeError("rank 0 owns no unit: cannot infer the result shape")
-            buf = torch.empty_like(local[0], device="cpu" if via_host else local[0].device)
-            dist.recv(buf, src=src)
-            out[idx] = buf.to(local[0].device) if via_host else buf
+        out[i * world] = t.cpu() if keep_on_host else t
+    for k in range(rounds):
+        ops, slots = [], []
+        for src in range(1, world):
+            if k < counts[src]:
+                shape, dtype = metas[src][k]
+                buf = torch.empty(shape, dtype=getattr(torch, dtype), device=recv_device)
+                ops.append(dist.P2POp(dist.irecv, buf, src))
+                slots.append((src + k * world, buf))
+        if not ops:
+            continue
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for idx, buf in slots:
+            out[idx] = buf.cpu() if keep_on_host else (buf.to(device) if buf.device != device else buf)
     return out

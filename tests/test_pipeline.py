@@ -96,6 +96,80 @@ def test_run_sharded_world_size_2_gloo(tmp_path, world):
     np.testing.assert_array_equal(np.load(tmp_path / "gathered.npy"), [2 * i + 1 for i in range(7)])
 
 
+def _gather_worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+
+    from shrimpy_amd.pipeline import gather_to_rank0
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_total = 8                                            # 3 + 3 + 2 units: unequal shares
+        mine = list(range(rank, n_total, world))
+        # every unit its own shape and value (the gather may not assume rank 0's first shape)
+        local = [torch.full((2 + u, 3, 1 + u % 3), float(u), dtype=torch.float32 if u % 2 else torch.float64) for u in mine]
+        for keep in (False, True):
+            got = gather_to_rank0(local, n_total, keep_on_host=keep)
+            if rank == 0:
+                assert [tuple(t.shape) for t in got] == [(2 + u, 3, 1 + u % 3) for u in range(n_total)]
+                assert all(float(t.flatten()[0]) == u and bool((t == u).all()) for u, t in enumerate(got))
+                assert [t.dtype for t in got] == [torch.float32 if u % 2 else torch.float64 for u in range(n_total)]
+            else:
+                assert got is None
+        # a rank that holds the wrong number of results is reported on every rank, nobody hangs
+        try:
+            gather_to_rank0(local[:-1] if rank == 1 else local, n_total)
+            raise AssertionError("expected a RuntimeError")
+        except RuntimeError as exc:
+            assert "round-robin" in str(exc)
+        with open(os.path.join(tmp, f"gok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_to_rank0_unequal_counts_and_shapes_world_3_gloo(tmp_path):
+    """Round-4 verdict: the gather posted one blocking receive at a time and assumed every unit had rank 0's first shape.
+    Three ranks, 3 + 3 + 2 units, every unit a different shape and dtype; every receive of a round is posted at once."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_gather_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    assert all((tmp_path / f"gok{r}").read_text() == "ok" for r in range(3))
+
+
+def test_run_sharded_skips_failed_units_and_reports_them():
+    """``on_error="skip"`` (the reference keeps acquiring after a failed stack, shrimpy/dynatrack/worker.py:262-271): a unit
+    whose load, process or store raises is left out and listed; every other unit is stored."""
+    from shrimpy_amd.pipeline import run_sharded
+
+    out = {}
+
+    def load(u):
+        if u == 2:
+            raise OSError("chunk 2 is damaged")
+        return u
+
+    def process(v):
+        if v == 4:
+            raise ValueError("bad volume")
+        return v * v
+
+    def store(u, v):
+        if u == 6:
+            raise OSError("disk full")
+        out[u] = v
+
+    rep = run_sharded(list(range(8)), load, process, store, on_error="skip")
+    assert out == {u: u * u for u in (0, 1, 3, 5, 7)}
+    assert [(u, stage) for u, stage, _ in rep.failures] == [(2, "load"), (4, "process"), (6, "store")]
+    assert "damaged" in rep.failures[0][2] and "OSError" in rep.failures[0][2]
+    with pytest.raises(OSError):
+        run_sharded(list(range(8)), load, process, store)          # the default still raises
+    with pytest.raises(ValueError):
+        run_sharded([1], load, process, store, on_error="ignore")
+
+
 def test_run_sharded_single_process():
     from shrimpy_amd.pipeline import gather_to_rank0, run_sharded
 
