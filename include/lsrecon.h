@@ -117,6 +117,19 @@ int lsr_deskew_border(const void* in, int in_u16, int64_t Z, int64_t Y, int64_t 
                       int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd,
                       const double M[12], int avg_n, int mode, const float* flat_pattern,
                       const float* flat_mean, lsr_stream_t stream);
+/* ... with the value outside the stack (scipy's `cval`; [RECALLED] biahub's deskew_data takes one and fills with the
+ * stack's minimum when it is None): `cval` is a DEVICE scalar -- a constant the caller uploaded, or out2[0] of
+ * lsr_minmax_f32 / lsr_minmax_u16 over the stack, so that "min" needs no host round trip -- NULL = 0 (the entries above).
+ * Under "grid-constant" the outside neighbour is cval * weight, as scipy sums it.  The _cpu twin reads a host scalar and
+ * has the "constant" border only. */
+int lsr_deskew_cval(const void* in, int in_u16, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo, int64_t Yo,
+                    int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd, const double M[12], int avg_n, int mode,
+                    const float* flat_pattern, const float* flat_mean, const float* cval, lsr_stream_t stream);
+int lsr_deskew_cval_cpu(const void* in, int in_u16, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo, int64_t Yo,
+                        int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd, const double M[12], int avg_n,
+                        int mode, const float* flat_pattern, const float* flat_mean, const float* cval, lsr_stream_t stream);
+/* min / max of uint16 camera counts as two floats (exact), scratch as lsr_minmax_f32 */
+int lsr_minmax_u16(const uint16_t* in, int64_t n, float* out2, void* scratch, lsr_stream_t stream);
 
 /*
  * General order-1 (trilinear) affine resample; any 3x4 matrix.

@@ -140,17 +140,20 @@ def orient(volume, orientation="identity"):
 
 
 def deskew(raw, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices=1,
-           orientation="identity", border="constant"):
+           orientation="identity", border="constant", cval=0.0):
     """Deskew a raw ``(Z_scan, Y_tilt, X)`` stack -> ``(ceil(Y/avg), X, Xp)`` float32.
 
     ``border`` is scipy's ``mode`` (``"constant"``: no blending, the north-star's path;
-    ``"grid-constant"``: blend towards zero, the torch ``grid_sample`` behaviour)."""
+    ``"grid-constant"``: blend towards zero, the torch ``grid_sample`` behaviour).  ``cval``: scipy's fill value, or
+    ``"min"`` / ``None`` for the stack's minimum ([RECALLED] biahub ``deskew_data``'s rule when its cval is None)."""
+    if cval is None or isinstance(cval, str):
+        cval = float(np.asarray(raw).min())
     matrix, offset, pre_shape = deskew_geometry(
         raw.shape, ls_angle_deg, px_to_scan_ratio, keep_overhang
     )
     if pre_shape[2] <= 0:
         raise ValueError(f"deskewed scan extent is not positive: {pre_shape}")
-    out = affine_apply(raw, matrix, offset, pre_shape, mode=border)
+    out = affine_apply(raw, matrix, offset, pre_shape, cval=cval, mode=border)
     return orient(average_slices(out, average_n_slices), orientation)
 
 

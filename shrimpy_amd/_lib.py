@@ -50,6 +50,9 @@ SIGNATURES: dict[str, list] = {
     "lsr_deskew_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p, _int, _stream],
     "lsr_deskew_border": [ctypes.c_void_p, _int, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p,
                           _int, _int, ctypes.c_void_p, ctypes.c_void_p, _stream],
+    "lsr_deskew_cval": [ctypes.c_void_p, _int, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p,
+                        _int, _int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _stream],
+    "lsr_minmax_u16": [ctypes.c_void_p, _i64, _c_f32p, ctypes.c_void_p, _stream],
     "lsr_deskew_u16": [ctypes.c_void_p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p, _int, _stream],
     "lsr_deskew_flat_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _i64, _i64, _i64, _f64p, _int,
                             _c_f32p, _c_f32p, _stream],
@@ -176,7 +179,7 @@ for _name in ("lsr_rl_sep_fused_f32", "lsr_rl_sep_f32", "lsr_rl_ysep_fused_f32",
               "lsr_correlate_dense_padded_f32", "lsr_correlate_zxy_padded_f32"):
     SIGNATURES[_name.replace("_f32", "_stats_f32")] = SIGNATURES[_name][:-1] + [ctypes.c_void_p, _stream]
 # host twins (csrc/host_twins.hip): the device entry point's signature, host pointers
-for _name in ("lsr_deskew_f32", "lsr_deskew_u16", "lsr_affine_f32", "lsr_average_slices_f32", "lsr_correlate_sep_f32",
+for _name in ("lsr_deskew_f32", "lsr_deskew_u16", "lsr_deskew_cval", "lsr_affine_f32", "lsr_average_slices_f32", "lsr_correlate_sep_f32",
               "lsr_correlate_dense_f32", "lsr_rl_dense_f32", "lsr_correlate_sep_stats_f32", "lsr_correlate_dense_stats_f32",
               "lsr_rl_dense_stats_f32", "lsr_flatfield_pattern_f32", "lsr_flatfield_pattern_u16",
               "lsr_flatfield_apply_f32", "lsr_flatfield_apply_u16",

@@ -144,7 +144,22 @@ def _common(fn, input_required: bool = True):
                       default="blosc-zstd", show_default=True,
                       help="Chunk compression of the output (native writer); blosc-zstd is what the acquisition engine "
                            "writes (shrimpy/mantis/mantis_engine.py:474-481), none is the fastest.")(fn)
+    fn = click.option("--on-error", "on_error", type=click.Choice(["raise", "skip"]), default="raise", show_default=True,
+                      help="skip: a unit whose chunks do not read, whose kernels fail or whose result cannot be written is "
+                           "left out and recorded under <output>/.lsr_failed/ (every other unit is written; the command "
+                           "exits with status 3 and --resume retries only the failed units) -- the reference likewise "
+                           "turns a failed stack into an error record and carries on (shrimpy/dynatrack/worker.py:262-271).")(fn)
     return fn
+
+
+def _finish(result: dict) -> None:
+    """Print a command's result; exit with status 3 when units were skipped (``--on-error skip``)."""
+    click.echo(result)
+    failed = result.get("failed") or []
+    if failed:
+        for f in failed:
+            click.echo(f"FAILED {f['position']} t={f['t']} c={f['c']} [{f['stage']}]: {f['error']}", err=True)
+        raise SystemExit(3)
 
 
 def _inputs(input_path, positions):
@@ -317,14 +332,45 @@ class _DoneLedger:
         os.replace(tmp, f)
 
 
+class _FailLedger:
+    """Units given up under ``--on-error skip``: one JSON file per (position, t, c) under ``<store>/.lsr_failed/`` with
+    the stage and the message; removed again when the unit is written by a later (``--resume``) run."""
+
+    def __init__(self, store_path: Path):
+        self.dir = Path(store_path) / ".lsr_failed"
+
+    def _file(self, u) -> Path:
+        return self.dir / u.position.replace("/", "__") / f"t{u.t}_c{u.c}.json"
+
+    def mark(self, u, stage: str, error: str) -> None:
+        import json
+
+        f = self._file(u)
+        f.parent.mkdir(parents=True, exist_ok=True)
+        f.write_text(json.dumps({"position": u.position, "t": u.t, "c": u.c, "stage": stage, "error": error}) + "\n")
+
+    def clear(self, u) -> None:
+        try:
+            self._file(u).unlink()
+        except FileNotFoundError:
+            pass
+
+    def listed(self) -> list[dict]:
+        import json
+
+        return [json.loads(f.read_text()) for f in sorted(self.dir.glob("*/*.json"))] if self.dir.exists() else []
+
+
 def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings, positions=(),
               zarr_version: str = "0.4", reconstructor_factory=None, stage_through_pinned: bool = True,
               resume: bool = False, io_backend: str = "auto", compression: str | None = None,
-              device_codec: bool | None = None) -> dict:
+              device_codec: bool | None = None, on_error: str = "raise") -> dict:
     """Apply ``settings`` to every (position, t, c) volume of ``input_path`` -> ``output_path``.
 
     ``device_codec`` (default: on, ``LSR_DEVICE_CODEC=0`` turns it off): with a blosc-zstd output on a GPU the chunk
     frames are written by the device (``io/device_codec.py``) and the host stores them as they are.
+    ``on_error="skip"``: see ``pipeline.run_sharded``; skipped units are listed in the result's ``failed`` (all ranks')
+    and recorded under ``<output>/.lsr_failed/``.
 
     On a GPU the volumes pass through pinned staging slots and copy streams
     (``staging.VolumeStager``) so that reading, upload, kernels, download and writing overlap.
@@ -338,7 +384,8 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
         if device_codec is None:
             device_codec = os.environ.get("LSR_DEVICE_CODEC", "1") != "0"
         return _run_store(input_path, output_path, settings, positions, zarr_version, reconstructor_factory,
-                          stage_through_pinned, resume, io_backend, compression, rank, world, device, device_codec)
+                          stage_through_pinned, resume, io_backend, compression, rank, world, device, device_codec,
+                          on_error)
     finally:
         if created:
             import torch.distributed as dist
@@ -347,7 +394,8 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
 
 
 def _run_store(input_path, output_path, settings, positions, zarr_version, reconstructor_factory,
-               stage_through_pinned, resume, io_backend, compression, rank, world, device, device_codec=True) -> dict:
+               stage_through_pinned, resume, io_backend, compression, rank, world, device, device_codec=True,
+               on_error="raise") -> dict:
     import torch
 
     from .io.omezarr import as_volume_array, create_level, open_ome_zarr, position_scale
@@ -398,6 +446,7 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
         out_scale[2:] = [float(v) for v in orient_voxel(voxel, d.orientation)]
 
     ledger = _DoneLedger(output_path, _fingerprint(input_path, settings, shape5, raw_dtype, keys))
+    fail_ledger = _FailLedger(output_path)
     out_shape5 = (nt, nc, oz, oy, ox)
 
     def open_output(mode):
@@ -464,6 +513,7 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
             host = vol if isinstance(vol, np.ndarray) else vol.cpu().numpy()
             dst_arrays[u.position].write_volume(u.t, u.c, host)
         ledger.mark(u)
+        fail_ledger.clear(u)
 
     def process(data, unit: Unit):
         return (rec if warp[unit.c] else rec_unwarped)(data)
@@ -500,7 +550,7 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
     try:
         on_gpu = torch.device(device).type == "cuda"
         report = run_sharded(todo, load, process, store, synchronize=torch.cuda.synchronize if on_gpu else None,
-                             stager=stager, process_takes_unit=True)
+                             stager=stager, process_takes_unit=True, on_error=on_error)
     finally:
         if stager is not None:
             stager.close()
@@ -508,11 +558,20 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
             close = getattr(s, "close", None)
             if close:
                 close()
-    nvox = len(report.units) * nz * ny * nx
+    failed = [{"position": u.position, "t": u.t, "c": u.c, "stage": stage, "error": msg} for u, stage, msg in report.failures]
+    for u, stage, msg in report.failures:
+        fail_ledger.mark(u, stage, msg)
+    if world > 1:                       # every rank returns the whole job's list
+        import torch.distributed as dist
+
+        box: list = [None] * world
+        dist.all_gather_object(box, failed)
+        failed = [f for part in box for f in part]
+    nvox = (len(report.units) - len(report.failures)) * nz * ny * nx
     logger.info("rank %d: %d units, %.3g input voxels/s (job %.2fs)", rank, len(report.units),
                 nvox / max(report.seconds, 1e-9), report.max_seconds)
     return {"rank": rank, "world_size": world, "units": len(report.units), "units_total": len(units),
-            "units_skipped": skipped, "seconds": report.seconds, "job_seconds": report.max_seconds,
+            "units_skipped": skipped, "failed": failed, "seconds": report.seconds, "job_seconds": report.max_seconds,
             "stage_seconds": {k: round(v, 4) for k, v in report.stage_seconds.items()},
             "device_codec": {"encode": bool(stager is not None and getattr(stager, "encode_frame_bytes", None)),
                              "decode": bool(frames_in[0])},
@@ -529,12 +588,12 @@ def cli(verbose: bool):
 
 @cli.command()
 @_common
-def deskew(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression):
+def deskew(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression, on_error):
     """Deskew oblique-plane stacks (config: DeskewSettings YAML)."""
     input_path, positions = _inputs(input_path, positions)
     s = ReconstructSettings(deskew=DeskewSettings.from_yaml(config))
-    click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
-                         io_backend=io_backend, compression=compression))
+    _finish(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
+                      io_backend=io_backend, compression=compression, on_error=on_error))
 
 
 def _target_shape_zyx(target_path) -> tuple[int, int, int]:
@@ -561,7 +620,7 @@ def _target_shape_zyx(target_path) -> tuple[int, int, int]:
                    "no output_shape_zyx.")
 @functools.partial(_common, input_required=False)
 def register(input_path, source_path, target_path, config, output_path, positions, zarr_version, resume, io_backend,
-             compression):
+             compression, on_error):
     """Apply an affine registration (config: RegisterSettings YAML with affine_transform_zyx)."""
     if (input_path is None) == (source_path is None):
         raise click.ClickException("name the moving store once: -i or -s")
@@ -570,8 +629,8 @@ def register(input_path, source_path, target_path, config, output_path, position
     if target_path is not None and reg.output_shape_zyx is None:
         reg = reg.model_copy(update={"output_shape_zyx": _target_shape_zyx(target_path)})
     s = ReconstructSettings(registration=reg)
-    click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
-                         io_backend=io_backend, compression=compression))
+    _finish(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
+                      io_backend=io_backend, compression=compression, on_error=on_error))
 
 
 @cli.command()
@@ -579,27 +638,28 @@ def register(input_path, source_path, target_path, config, output_path, position
               help="A measured PSF: an OME-Zarr bead volume (as scripts/measure_psf.py:273-287 writes them) or a .npy "
                    "ZYX array; overrides psf_path of the config ([RECALLED] biahub's -p, which is the position filter here).")
 @_common
-def deconvolve(input_path, psf_dirpath, config, output_path, positions, zarr_version, resume, io_backend, compression):
+def deconvolve(input_path, psf_dirpath, config, output_path, positions, zarr_version, resume, io_backend, compression,
+               on_error):
     """Richardson-Lucy deconvolution (config: DeconvolveSettings YAML)."""
     input_path, positions = _inputs(input_path, positions)
     dec = DeconvolveSettings.from_yaml(config)
     if psf_dirpath is not None:
         dec = dec.model_copy(update={"psf_path": str(psf_dirpath)})
     s = ReconstructSettings(deconvolution=dec)
-    click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
-                         io_backend=io_backend, compression=compression))
+    _finish(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
+                      io_backend=io_backend, compression=compression, on_error=on_error))
 
 
 @cli.command()
 @_common
-def reconstruct(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression):
+def reconstruct(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression, on_error):
     """deskew -> register -> deconvolve in one pass (config: ReconstructSettings YAML)."""
     input_path, positions = _inputs(input_path, positions)
     s = ReconstructSettings.from_yaml(config)
     if s.deskew is None and s.registration is None and s.deconvolution is None:
         raise click.ClickException("the config enables no step")
-    click.echo(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
-                         io_backend=io_backend, compression=compression))
+    _finish(run_store(input_path, output_path, s, positions, zarr_version, resume=resume,
+                      io_backend=io_backend, compression=compression, on_error=on_error))
 
 
 @cli.command("estimate-registration")

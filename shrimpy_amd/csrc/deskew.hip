@@ -49,6 +49,7 @@ struct DeskewArgs {
   int xcd_swizzle;          // 1: XCD-contiguous tile order (the grid is padded to a multiple of 8)
   const float* flat_pattern;  // FLAT: (Y, X) per-pixel median over Z (flatfield.hip)
   const float* flat_mean;     // FLAT: its mean, a device scalar
+  const float* cval;          // the value outside the stack: a device scalar (e.g. the stack's minimum, lsr_minmax_*); NULL = 0
 };
 
 // FLAT fuses the bright-field flat-field correction into the staging pass: every raw sample
@@ -61,8 +62,9 @@ template <bool FLAT, bool U16 = false>
 __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
   using raw_t = std::conditional_t<U16, unsigned short, float>;
   __shared__ float slab[kSlabRows * kPitch];
-  __shared__ float zero_row[kPitch];
-  if (threadIdx.x < kPitch) zero_row[threadIdx.x] = 0.0f;   // visible after the first barrier below
+  __shared__ float zero_row[kPitch];   // a row of the fill value (zero unless the caller names another: scipy's cval)
+  const float cv = p.cval ? p.cval[0] : 0.0f;
+  if (threadIdx.x < kPitch) zero_row[threadIdx.x] = cv;   // visible after the first barrier below
 
   const int tid = threadIdx.x;
   // Workgroups b, b + 8, ... run on one XCD: each XCD takes a contiguous run of the tile order (x fastest), so that
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
           if (zl < n_rows) {
             float w = v[i];
             if constexpr (FLAT) w = w / pat * mean;
-            slab[zl * kPitch + j] = col_ok ? w : 0.0f;
+            slab[zl * kPitch + j] = col_ok ? w : cv;
           }
         }
       }
@@ -179,6 +181,10 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(DeskewArgs p) {
         const float d = static_cast<float>(t);
         acc[m] = (k == 0) ? d : (acc[m] + d);
       }
+    } else {
+      // outside the stack: the fill value, added like any other sample of the group (scipy returns cval there)
+#pragma unroll
+      for (int m = 0; m < kRowsPerThread; ++m) acc[m] = (k == 0) ? cv : (acc[m] + cv);
     }
   }
 
@@ -222,7 +228,7 @@ namespace {
 int deskew_impl(const char* what, const void* in, bool u16, int64_t Z, int64_t Y, int64_t X, float* out,
                 int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane,
                 int64_t Zd, const double M[12], int avg_n, const float* flat_pattern,
-                const float* flat_mean, lsr_stream_t stream, int mode = LSR_MODE_CONSTANT) {
+                const float* flat_mean, lsr_stream_t stream, int mode = LSR_MODE_CONSTANT, const float* cval = nullptr) {
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE(mode == LSR_MODE_CONSTANT || mode == LSR_MODE_GRID_CONSTANT, LSR_E_ARG,
               "mode %d: LSR_MODE_CONSTANT or LSR_MODE_GRID_CONSTANT", mode);
@@ -282,6 +288,7 @@ int deskew_impl(const char* what, const void* in, bool u16, int64_t Z, int64_t Y
 
   p.flat_pattern = flat_pattern;
   p.flat_mean = flat_mean;
+  p.cval = cval;
   p.blocks = blocks;
   p.xcd_swizzle = 1;
   if (const char* e = std::getenv("LSR_DESKEW_SWIZZLE")) p.xcd_swizzle = e[0] != '0';   // measurement override
@@ -342,6 +349,16 @@ extern "C" int lsr_deskew_border(const void* in, int in_u16, int64_t Z, int64_t 
               "flat_pattern and flat_mean come together (both NULL: no flat-field correction)");
   return deskew_impl("lsr_deskew_border", in, in_u16 != 0, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M,
                      avg_n, flat_pattern, flat_mean, stream, mode);
+}
+
+extern "C" int lsr_deskew_cval(const void* in, int in_u16, int64_t Z, int64_t Y, int64_t X, float* out,
+                               int64_t Zo, int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane,
+                               int64_t Zd, const double M[12], int avg_n, int mode, const float* flat_pattern,
+                               const float* flat_mean, const float* cval, lsr_stream_t stream) {
+  LSR_REQUIRE((flat_pattern == nullptr) == (flat_mean == nullptr), LSR_E_NULL,
+              "flat_pattern and flat_mean come together (both NULL: no flat-field correction)");
+  return deskew_impl("lsr_deskew_cval", in, in_u16 != 0, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M,
+                     avg_n, flat_pattern, flat_mean, stream, mode, cval);
 }
 
 extern "C" int lsr_average_slices_f32(const float* in, int64_t Zd, int64_t Y, int64_t X,

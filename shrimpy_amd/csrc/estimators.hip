@@ -70,6 +70,49 @@ __global__ __launch_bounds__(kThreads) void minmax_partial_kernel(const float* _
     partial[2 * blockIdx.x + 1] = s_hi[0];
   }
 }
+// ... of uint16 camera counts (the fill value of a deskew with cval = "min"): 16-byte loads, eight counts each
+__global__ __launch_bounds__(kThreads) void minmax_u16_partial_kernel(const unsigned short* __restrict__ in, int64_t n,
+                                                                      float* __restrict__ partial) {
+  __shared__ float s_lo[kThreads], s_hi[kThreads];
+  unsigned lo = 0xFFFFu, hi = 0u;
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  const int64_t nthreads = static_cast<int64_t>(gridDim.x) * kThreads;
+  int64_t done = 0;
+  if ((reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+    const int64_t n8 = n >> 3;
+    const uint4* in8 = reinterpret_cast<const uint4*>(in);
+    for (int64_t i = tid; i < n8; i += nthreads) {
+      const uint4 v = in8[i];
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned a = w[k] & 0xFFFFu, b = w[k] >> 16;
+        lo = min(lo, min(a, b));
+        hi = max(hi, max(a, b));
+      }
+    }
+    done = n8 << 3;
+  }
+  for (int64_t i = done + tid; i < n; i += nthreads) {
+    const unsigned a = in[i];
+    lo = min(lo, a);
+    hi = max(hi, a);
+  }
+  s_lo[threadIdx.x] = static_cast<float>(lo);
+  s_hi[threadIdx.x] = static_cast<float>(hi);
+  __syncthreads();
+  for (int w = kThreads / 2; w > 0; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w) {
+      s_lo[threadIdx.x] = fminf(s_lo[threadIdx.x], s_lo[threadIdx.x + w]);
+      s_hi[threadIdx.x] = fmaxf(s_hi[threadIdx.x], s_hi[threadIdx.x + w]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = s_lo[0];
+    partial[2 * blockIdx.x + 1] = s_hi[0];
+  }
+}
 __global__ __launch_bounds__(kThreads) void minmax_final_kernel(const float* __restrict__ partial, int nb,
                                                                 float* __restrict__ out) {
   __shared__ float s_lo[kThreads], s_hi[kThreads];
@@ -694,6 +737,20 @@ extern "C" int lsr_minmax_f32(const float* in, int64_t n, float* out2, void* scr
   hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb), dim3(kThreads), 0, s, in, n, partial);
   hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(kThreads), 0, s, partial, nb, out2);
   return lsr::launch_status("lsr_minmax_f32");
+}
+
+extern "C" int lsr_minmax_u16(const uint16_t* in, int64_t n, float* out2, void* scratch, lsr_stream_t stream) {
+  LSR_REQUIRE_PTR(in);
+  LSR_REQUIRE_PTR(out2);
+  LSR_REQUIRE_PTR(scratch);
+  LSR_REQUIRE(n > 0, LSR_E_SHAPE, "n = %lld must be positive", (long long)n);
+  LSR_REQUIRE_COUNT(n);
+  const int nb = grid_for((n + 1) / 2);
+  hipStream_t s = lsr::as_stream(stream);
+  float* partial = static_cast<float*>(scratch);
+  hipLaunchKernelGGL(minmax_u16_partial_kernel, dim3(nb), dim3(kThreads), 0, s, in, n, partial);
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(kThreads), 0, s, partial, nb, out2);
+  return lsr::launch_status("lsr_minmax_u16");
 }
 
 extern "C" int lsr_histogram_f32(const float* in, int64_t n, float vmin, float vmax, int nbins,

@@ -138,7 +138,7 @@ int check_matrix(const double M[12]) {
 
 template <typename T>
 int deskew_cpu(const T* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo, int64_t Yo, int64_t Xo,
-               int64_t out_pitch, int64_t out_plane, int64_t Zd, const double M[12], int avg_n) {
+               int64_t out_pitch, int64_t out_plane, int64_t Zd, const double M[12], int avg_n, float cval = 0.0f) {
   LSR_REQUIRE_PTR(in);
   LSR_REQUIRE_PTR(out);
   if (int rc = check_matrix(M)) return rc;
@@ -204,12 +204,12 @@ int deskew_cpu(const T* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t
           float* const row = out + zo * out_plane + yo * out_pitch;
           const int64_t xi = xin[yo];
           if (xi < 0) {
-            for (int64_t xo = 0; xo < Xo; ++xo) d[xo] = 0.0f;
+            for (int64_t xo = 0; xo < Xo; ++xo) d[xo] = cval;
           } else {
             const T* const col = in + xi;
             for (int64_t xo = 0; xo < Xo; ++xo) {
               if (o0[xo] < 0) {
-                d[xo] = 0.0f;
+                d[xo] = cval;
                 continue;
               }
               double t = 0.0 + static_cast<double>(col[o0[xo]]) * w0[xo];
@@ -279,6 +279,19 @@ extern "C" int lsr_deskew_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t
                                   int avg_n, lsr_stream_t) {
   LSR_REQUIRE_HOST_FMA();
   return deskew_cpu(in, Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M, avg_n);
+}
+
+// ... with the value outside the stack (scipy's cval; `cval` is a HOST scalar here, NULL = 0): "constant" border only
+extern "C" int lsr_deskew_cval_cpu(const void* in, int in_u16, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo,
+                                   int64_t Yo, int64_t Xo, int64_t out_pitch, int64_t out_plane, int64_t Zd,
+                                   const double M[12], int avg_n, int mode, const float* flat_pattern,
+                                   const float* flat_mean, const float* cval, lsr_stream_t) {
+  LSR_REQUIRE_HOST_FMA();
+  LSR_REQUIRE(mode == LSR_MODE_CONSTANT, LSR_E_UNSUPPORTED, "the host deskew twin has the \"constant\" border only");
+  LSR_REQUIRE(flat_pattern == nullptr && flat_mean == nullptr, LSR_E_UNSUPPORTED, "the host deskew twin takes a corrected stack");
+  const float cv = cval ? cval[0] : 0.0f;
+  if (in_u16) return deskew_cpu(static_cast<const uint16_t*>(in), Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M, avg_n, cv);
+  return deskew_cpu(static_cast<const float*>(in), Z, Y, X, out, Zo, Yo, Xo, out_pitch, out_plane, Zd, M, avg_n, cv);
 }
 
 extern "C" int lsr_deskew_u16_cpu(const uint16_t* in, int64_t Z, int64_t Y, int64_t X, float* out, int64_t Zo, int64_t Yo,

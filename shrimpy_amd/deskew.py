@@ -72,8 +72,36 @@ def orient_volume(volume, orientation: str = "identity"):
     return (torch.flip(out, dims) if dims else out).contiguous()
 
 
+def fill_value(raw, cval):
+    """The ``cval`` argument as what the kernels take: ``None`` for zero, else a one-element float32 tensor on ``raw``'s
+    device -- the number itself, or for ``"min"`` / ``None``-as-minimum the stack's minimum, reduced on the device
+    (``lsr_minmax_f32`` / ``lsr_minmax_u16``) without a host round trip."""
+    import torch
+
+    if cval is None:
+        cval = "min"
+    if isinstance(cval, str):
+        if cval != "min":
+            raise ValueError(f'cval must be a number or "min", got {cval!r}')
+        if host.is_host(raw):
+            src = raw.to(torch.int32) if raw.dtype == torch.uint16 else raw
+            return src.min().to(torch.float32).reshape(1)
+        out2 = torch.empty(2, dtype=torch.float32, device=raw.device)
+        scratch = torch.empty(_lib.call_value("lsr_reduce_scratch_bytes"), dtype=torch.uint8, device=raw.device)
+        with torch.cuda.device(raw.device):
+            _lib.call("lsr_minmax_u16" if raw.dtype == torch.uint16 else "lsr_minmax_f32", raw.data_ptr(), raw.numel(),
+                      out2.data_ptr(), scratch.data_ptr(), _lib.stream_ptr(raw.device))
+        return out2[:1]
+    value = float(cval)
+    if value != value or value in (float("inf"), float("-inf")):
+        raise ValueError(f"cval must be finite, got {cval!r}")
+    if value == 0.0:
+        return None
+    return torch.full((1,), value, dtype=torch.float32, device=raw.device)
+
+
 def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices: int = 1, out=None,
-                       flat_field=None, border: str = "constant"):
+                       flat_field=None, border: str = "constant", cval=0.0):
     """Deskew with an explicit output->input matrix over the pre-average grid.
 
     ``flat_field`` = a :class:`shrimpy_amd.flatfield.FlatFieldPattern` of ``raw_data``: the
@@ -91,6 +119,11 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
     (SURVEY.md section 7).  Both rules run the fused transpose kernel (``lsr_deskew_border``) and may
     write into a padded RL volume; matrices that are not a deskew shear fall back to the general
     trilinear kernel under either rule.
+
+    ``cval``: the value outside the stack -- a number (default 0) or ``"min"`` / ``None`` for the stack's minimum
+    (scipy's ``cval``; [RECALLED] biahub's ``deskew_data(cval=None)`` fills with the minimum: the third unpinned
+    convention beside ``orientation`` and ``border``).  With flat-field fusion the minimum is
+    that of the uncorrected stack.
     """
     import torch
 
@@ -107,7 +140,7 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
                 f"deskewed shape {tuple(int(v) for v in pre_average_shape)} is empty: the scan is too short for this "
                 "tilt (use keep_overhang=True or a longer scan)")
         return host.deskew_with_matrix(raw_data, as_matrix_3x4(matrix_3x4), pre_average_shape, avg, out=out,
-                                       flat_field=flat_field, border=border)
+                                       flat_field=flat_field, border=border, cval=fill_value(raw_data, cval))
 
     # uint16 camera counts are deskewed as they are (converted to float32 inside the kernel, exact):
     # half the HBM read and, upstream, half the PCIe upload of a float32 stack
@@ -146,12 +179,21 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
             raise ValueError(f"out must be {(zo, yo, xo)} on {raw.device}")
         out_ptr, out_pitch, out_plane = out.data_ptr(), xo, yo * xo
     z, y, x = (int(v) for v in raw.shape)
+    fill = fill_value(raw, cval)
     with torch.cuda.device(raw.device):
         stream = _lib.stream_ptr(raw.device)
         if flat_field is not None and tuple(flat_field.pattern.shape) != (y, x):
             raise ValueError(f"flat_field pattern must be {(y, x)}, got {tuple(flat_field.pattern.shape)}")
         try:
-            if border != "constant":
+            if fill is not None:
+                _lib.call(
+                    "lsr_deskew_cval", raw.data_ptr(), 1 if u16 else 0, z, y, x, out_ptr, zo, yo, xo, out_pitch,
+                    out_plane, zd, _lib.matrix12(m), avg,
+                    _lib.MODE_CONSTANT if border == "constant" else _lib.MODE_GRID_CONSTANT,
+                    flat_field.pattern.data_ptr() if flat_field is not None else None,
+                    flat_field.mean.data_ptr() if flat_field is not None else None, fill.data_ptr(), stream,
+                )
+            elif border != "constant":
                 _lib.call(
                     "lsr_deskew_border", raw.data_ptr(), 1 if u16 else 0, z, y, x, out_ptr, zo, yo, xo, out_pitch,
                     out_plane, zd, _lib.matrix12(m), avg, _lib.MODE_GRID_CONSTANT,
@@ -180,7 +222,7 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
             pre = out if avg == 1 else torch.empty((zd, yo, xo), dtype=torch.float32, device=raw.device)
             _lib.call(
                 "lsr_affine_f32", raw.data_ptr(), z, y, x, pre.data_ptr(), zd, yo, xo,
-                _lib.matrix12(m), ctypes.c_float(0.0),
+                _lib.matrix12(m), ctypes.c_float(0.0 if fill is None else float(fill.item())),
                 _lib.MODE_CONSTANT if border == "constant" else _lib.MODE_GRID_CONSTANT, stream,
             )
             if avg > 1:
@@ -221,13 +263,15 @@ def fast_deskew_zyx(
     average_n_slices: int = 1,
     orientation: str = "identity",
     border: str = "constant",
+    cval=0.0,
 ):
     """Deskew a raw ``(Z_scan, Y_tilt, X)`` float32 device tensor; returns a tensor on the same device.
 
     Output axes ``(Z', Y', X')``: ``Z'`` = reversed tilt rows averaged in groups of
     ``average_n_slices``, ``Y'`` = reversed raw X, ``X'`` = scan direction (the interpolated axis).
     ``orientation`` re-orients that canonical result afterwards (``orient_volume``); ``border``
-    selects the border rule (``deskew_with_matrix``).  The reference filters the kwargs it passes by
+    selects the border rule and ``cval`` the value outside the stack -- a number or ``"min"``
+    (``deskew_with_matrix``).  The reference filters the kwargs it passes by
     this signature (``shrimpy/preprocessing.py:44-56``): settings fields that are not parameters
     here never arrive, fields that are (these two, when ``DeskewSettings`` carries them) do.
     """
@@ -244,7 +288,7 @@ def fast_deskew_zyx(
         tuple(raw_data.shape), ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices
     )
     out = deskew_with_matrix(raw_data, geo.matrix_3x4, geo.pre_average_shape, average_n_slices,
-                             border=border)
+                             border=border, cval=cval)
     return orient_volume(out, orientation)
 
 
@@ -257,6 +301,7 @@ def deskew_data(
     device="cuda",
     orientation: str = "identity",
     border: str = "constant",
+    cval=0.0,
 ):
     """Older biahub entry point: numpy in, numpy out, compute on ``device`` (``"cpu"`` runs the host twin)."""
     import torch
@@ -264,5 +309,5 @@ def deskew_data(
     dev = torch.device(device)
     vol = torch.as_tensor(np.ascontiguousarray(raw_data, dtype=np.float32), device=dev)
     out = fast_deskew_zyx(vol, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices,
-                          orientation=orientation, border=border)
+                          orientation=orientation, border=border, cval=cval)
     return out.cpu().numpy()

@@ -77,8 +77,9 @@ def average_n_slices(data, avg: int):
     return out
 
 
-def deskew_with_matrix(raw, m, pre_average_shape, avg: int, out=None, flat_field=None, border: str = "constant"):
-    """``deskew.deskew_with_matrix`` for a CPU tensor (float32 or uint16 counts), dense ``out`` only."""
+def deskew_with_matrix(raw, m, pre_average_shape, avg: int, out=None, flat_field=None, border: str = "constant", cval=None):
+    """``deskew.deskew_with_matrix`` for a CPU tensor (float32 or uint16 counts), dense ``out`` only.
+    ``cval``: ``None`` (zero) or a one-element float32 CPU tensor (``deskew.fill_value``)."""
     import torch
 
     if flat_field is not None:     # (the fusion is a kernel matter; the values are those of correcting first)
@@ -103,14 +104,18 @@ def deskew_with_matrix(raw, m, pre_average_shape, avg: int, out=None, flat_field
     try:
         if border != "constant":
             raise _lib.LsrUnsupported("lsr_deskew_f32_cpu", _lib.E_UNSUPPORTED, "grid-constant border")
-        _lib.call("lsr_deskew_u16_cpu" if u16 else "lsr_deskew_f32_cpu", raw.data_ptr(), z, y, x, out.data_ptr(),
-                  zo, yo, xo, xo, yo * xo, zd, _lib.matrix12(m), avg, None)
+        if cval is not None:
+            _lib.call("lsr_deskew_cval_cpu", raw.data_ptr(), 1 if u16 else 0, z, y, x, out.data_ptr(), zo, yo, xo, xo, yo * xo,
+                      zd, _lib.matrix12(m), avg, _lib.MODE_CONSTANT, None, None, cval.data_ptr(), None)
+        else:
+            _lib.call("lsr_deskew_u16_cpu" if u16 else "lsr_deskew_f32_cpu", raw.data_ptr(), z, y, x, out.data_ptr(),
+                      zo, yo, xo, xo, yo * xo, zd, _lib.matrix12(m), avg, None)
     except _lib.LsrUnsupported:
         # a general matrix, or the blending border rule: trilinear resample, then average
         src = raw.to(torch.float32) if u16 else raw
         pre = out if avg == 1 else torch.empty((zd, yo, xo), dtype=torch.float32)
         _lib.call("lsr_affine_f32_cpu", src.data_ptr(), z, y, x, pre.data_ptr(), zd, yo, xo, _lib.matrix12(m),
-                  ctypes.c_float(0.0), _MODES[border], None)
+                  ctypes.c_float(0.0 if cval is None else float(cval.item())), _MODES[border], None)
         if avg > 1:
             _lib.call("lsr_average_slices_f32_cpu", pre.data_ptr(), zd, yo, xo, out.data_ptr(), zo, avg, None)
     _lib.mark_written(out)

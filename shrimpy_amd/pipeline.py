@@ -184,7 +184,7 @@ class VolumeReconstructor:
                 target = self._pitched
             # (with flat-field on, its division rides along inside the deskew kernel)
             vol = deskew_with_matrix(vol, self._geo.matrix_3x4, self._geo.pre_average_shape,
-                                     d.average_n_slices, out=target, flat_field=flat, border=d.border)
+                                     d.average_n_slices, out=target, flat_field=flat, border=d.border, cval=d.cval)
             if not self._canonical_deskew:
                 from .deskew import orient_volume
 

@@ -17,7 +17,7 @@ deconvolution are "being developed", ``docs/data_structure.md:58-62``); they fol
 from __future__ import annotations
 
 from pathlib import Path
-from typing import Literal, Optional
+from typing import Union, Literal, Optional
 
 import numpy as np
 import yaml
@@ -68,6 +68,9 @@ class DeskewSettings(_StrictModel):
     # reference's signature filter like every other field.
     orientation: str = "identity"
     border: Literal["constant", "grid-constant"] = "constant"
+    # the value outside the stack (scipy's cval): a number, or "min" = the stack's minimum ([RECALLED] what biahub's
+    # deskew_data fills with when its cval is None, so None is taken as "min" too)
+    cval: Union[float, Literal["min"], None] = 0.0
 
     @field_validator("orientation")
     @classmethod

@@ -47,9 +47,9 @@ def test_get_deskewed_data_shape_signature_is_the_reference_call():
                       "average_n_slices", "pixel_size_um", "orientation"]
     params = list(inspect.signature(fast_deskew_zyx).parameters)
     assert params == ["raw_data", "ls_angle_deg", "px_to_scan_ratio", "keep_overhang", "average_n_slices",
-                      "orientation", "border"]
+                      "orientation", "border", "cval"]
     sig = inspect.signature(fast_deskew_zyx).parameters
-    assert sig["orientation"].default == "identity" and sig["border"].default == "constant"
+    assert sig["orientation"].default == "identity" and sig["border"].default == "constant" and sig["cval"].default == 0.0
     shape, voxel = get_deskewed_data_shape(
         raw_data_shape=(2048, 512, 2048), ls_angle_deg=30, px_to_scan_ratio=0.755,
         keep_overhang=False, average_n_slices=3, pixel_size_um=0.1133)
@@ -89,8 +89,8 @@ def test_deskew_settings_derive_ratio_like_the_reference_scripts():
     assert s.px_to_scan_ratio == 0.755
     d = s.model_dump()
     assert set(d) == {"pixel_size_um", "ls_angle_deg", "px_to_scan_ratio", "scan_step_um",
-                      "keep_overhang", "average_n_slices", "orientation", "border"}
-    assert (d["orientation"], d["border"]) == ("identity", "constant")
+                      "keep_overhang", "average_n_slices", "orientation", "border", "cval"}
+    assert (d["orientation"], d["border"], d["cval"]) == ("identity", "constant", 0.0)
     # attributes the reference reads by getattr (shrimpy/preprocessing.py:240-242)
     assert (s.px_to_scan_ratio, s.pixel_size_um, s.scan_step_um) == (0.755, 0.1133, 0.15)
 
@@ -125,8 +125,12 @@ def test_settings_kwargs_filtering_keeps_exactly_the_callee_params(golden_dir):
                                       "pixel_size_um", "scan_step_um")}
 
     assert sorted(accepted_kwargs(fast_deskew_zyx, BiahubShaped())) == ref
-    # our own model adds exactly the two convention switches, and they do reach the callee
-    assert sorted(accepted_kwargs(fast_deskew_zyx, s)) == sorted(ref + ["orientation", "border"])
+    # our own model adds exactly the three convention switches, and they do reach the callee
+    assert sorted(accepted_kwargs(fast_deskew_zyx, s)) == sorted(ref + ["orientation", "border", "cval"])
+    assert DeskewSettings(ls_angle_deg=30.0, pixel_size_um=0.1, px_to_scan_ratio=0.7, cval="min").cval == "min"
+    assert DeskewSettings(ls_angle_deg=30.0, pixel_size_um=0.1, px_to_scan_ratio=0.7, cval=None).cval is None
+    with pytest.raises(ValueError):
+        DeskewSettings(ls_angle_deg=30.0, pixel_size_um=0.1, px_to_scan_ratio=0.7, cval="max")
 
 
 def test_register_and_deconvolve_settings(tmp_path):

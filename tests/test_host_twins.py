@@ -81,6 +81,35 @@ def test_deskew_borders_and_the_general_matrix_route(border, keep_overhang, avg)
     np.testing.assert_array_equal(got.numpy(), o.average_slices(pre, avg))
 
 
+@pytest.mark.parametrize("avg", [1, 3])
+@pytest.mark.parametrize("cval", [7.25, -3.0, "min", None])
+def test_deskew_fill_value_on_a_cpu_tensor_is_scipys_cval(cval, avg):
+    """``cval`` (a number, or "min" / None = the stack's minimum: the third [RECALLED] biahub convention, round-4 verdict
+    item 6) on the host twin: bit for bit ``scipy.ndimage.affine_transform(cval=...)`` + the slice average, float32 and
+    uint16 stacks, the shear kernel and the general-matrix route."""
+    import torch
+
+    from shrimpy_amd.deskew import deskew_with_matrix, fast_deskew_zyx
+    from shrimpy_amd.geometry import deskew_geometry
+
+    rng = np.random.default_rng(17)
+    raw = rng.integers(90, 600, (70, 20, 33)).astype(np.float32)
+    for keep in (False, True):
+        want = o.deskew(raw, 30.0, 0.755, keep, avg, cval=cval)
+        got = fast_deskew_zyx(torch.as_tensor(raw), 30.0, 0.755, keep, avg, cval=cval).numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        got16 = fast_deskew_zyx(torch.as_tensor(raw.astype(np.uint16)), 30.0, 0.755, keep, avg, cval=cval).numpy()
+        assert np.array_equal(got16.view(np.uint32), want.view(np.uint32))
+    # the grid-constant border has no shear twin on the host: the generic resampler takes the same fill value
+    want = o.deskew(raw, 30.0, 0.755, True, avg, border="grid-constant", cval=cval)
+    got = fast_deskew_zyx(torch.as_tensor(raw), 30.0, 0.755, True, avg, border="grid-constant", cval=cval).numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    with pytest.raises(ValueError):
+        fast_deskew_zyx(torch.as_tensor(raw), 30.0, 0.755, True, avg, cval="max")
+    with pytest.raises(ValueError):
+        fast_deskew_zyx(torch.as_tensor(raw), 30.0, 0.755, True, avg, cval=float("nan"))
+
+
 @pytest.mark.parametrize("mode", ["constant", "grid-constant"])
 def test_affine_apply_on_a_cpu_tensor_is_scipy_bit_for_bit(golden_dir, mode):
     from shrimpy_amd.register import affine_transform, apply_affine_transform_zyx

@@ -170,9 +170,9 @@ def test_cli_commands_parse_configs_and_positions(tmp_path, cpu_cli, monkeypatch
     seen = {}
 
     def fake_run_store(input_path, output_path, settings, positions, zarr_version, resume=False,
-                       io_backend="auto", compression=None):
+                       io_backend="auto", compression=None, on_error="raise"):
         seen.update(settings=settings, positions=positions, version=zarr_version, resume=resume,
-                    io_backend=io_backend, compression=compression)
+                    io_backend=io_backend, compression=compression, on_error=on_error)
         return {"ok": True}
 
     monkeypatch.setattr(cpu_cli, "run_store", fake_run_store)
@@ -195,7 +195,9 @@ def test_cli_commands_parse_configs_and_positions(tmp_path, cpu_cli, monkeypatch
     r = runner.invoke(cpu_cli.cli, ["deconvolve", "-i", str(src), "-c", str(dec), "-o", str(tmp_path / "o2"),
                                     "--resume", "--io", "native", "--compression", "blosc-zstd"])
     assert r.exit_code == 0, r.output
-    assert (seen["resume"], seen["io_backend"], seen["compression"]) == (True, "native", "blosc-zstd")
+    assert (seen["resume"], seen["io_backend"], seen["compression"], seen["on_error"]) == (True, "native", "blosc-zstd", "raise")
+    r = runner.invoke(cpu_cli.cli, ["deconvolve", "-i", str(src), "-c", str(dec), "-o", str(tmp_path / "o3"), "--on-error", "skip"])
+    assert r.exit_code == 0 and seen["on_error"] == "skip"
 
     # [RECALLED] biahub spellings: register -s (moving) / -t (target: its (Z, Y, X) is the output shape when the config
     # names none); deconvolve --psf-dirpath overrides the config's psf_path
@@ -310,6 +312,56 @@ def test_resume_after_a_failed_store_equals_an_uninterrupted_run(tmp_path, cpu_c
     # a second --resume has nothing left to do
     res = cpu_cli.run_store(src, out, _settings(), zarr_version=version, reconstructor_factory=Counting, resume=True)
     assert res["units_skipped"] == n and res["units"] == 0
+
+
+def test_on_error_skip_leaves_out_the_unit_with_a_corrupt_chunk_and_resume_retries_only_it(tmp_path, cpu_cli):
+    """Round-4 verdict: one damaged chunk ended a whole run.  With ``on_error="skip"`` the unit whose chunk does not decode
+    is listed (result, ``.lsr_failed/``), every other unit is written, the CLI exits 3; after the chunk is repaired
+    ``--resume`` reconstructs that one unit only.  Reference: a failed stack becomes an error record and the acquisition
+    carries on (``shrimpy/dynatrack/worker.py:262-271``)."""
+    import json
+
+    from click.testing import CliRunner
+
+    src = _make_plate(tmp_path / "raw.zarr", "0.5", compress="zlib")
+    n = len(KEYS) * N_T * N_C
+    want = tmp_path / "whole.zarr"
+    cpu_cli.run_store(src, want, _settings(), zarr_version="0.5", reconstructor_factory=_FakeReconstructor)
+    # damage one chunk of position 1, (t, c) = (1, 0)
+    victim = next(f for f in sorted((src / "0" / "1" / "000" / "0" / "c" / "1" / "0").rglob("*")) if f.is_file())
+    good = victim.read_bytes()
+    victim.write_bytes(good[:len(good) // 2])
+    out = tmp_path / "out.zarr"
+    with pytest.raises(Exception):                                     # the default: the run stops at the damaged unit
+        cpu_cli.run_store(src, tmp_path / "stops.zarr", _settings(), zarr_version="0.5", reconstructor_factory=_FakeReconstructor)
+    res = cpu_cli.run_store(src, out, _settings(), zarr_version="0.5", reconstructor_factory=_FakeReconstructor, on_error="skip")
+    assert [(f["position"], f["t"], f["c"], f["stage"]) for f in res["failed"]] == [(KEYS[1], 1, 0, "load")]
+    record = json.loads((out / ".lsr_failed" / KEYS[1].replace("/", "__") / "t1_c0.json").read_text())
+    assert record["stage"] == "load" and record["error"]
+    got, ref = _read_all(out), _read_all(want)
+    bad_key = next(k for k in ref if not np.array_equal(got[k], ref[k]))
+    assert all(np.array_equal(got[k], ref[k]) for k in ref if k != bad_key)    # every other unit is there
+    # the same through the command line: exit status 3, the failure on stderr
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text("deskew:\n  pixel_size_um: 0.1133\n  scan_step_um: 0.15\n  ls_angle_deg: 30.0\n  average_n_slices: 1\n")
+    run = CliRunner().invoke(cpu_cli.cli, ["reconstruct", "-i", str(src), "-c", str(cfg), "-o", str(tmp_path / "cli.zarr"),
+                                           "--on-error", "skip", "--compression", "none"])
+    assert run.exit_code == 3 and "FAILED" in run.output and KEYS[1] in run.output
+    # repaired: --resume does the one unit, and the failure record goes away
+    victim.write_bytes(good)
+    calls = []
+
+    class Counting(_FakeReconstructor):
+        def __call__(self, raw):
+            calls.append(1)
+            return super().__call__(raw)
+
+    res = cpu_cli.run_store(src, out, _settings(), zarr_version="0.5", reconstructor_factory=Counting, resume=True, on_error="skip")
+    assert res["failed"] == [] and res["units_skipped"] == n - 1 and len(calls) == 1
+    assert not list((out / ".lsr_failed").glob("*/*.json"))
+    got = _read_all(out)
+    for k in ref:
+        np.testing.assert_array_equal(got[k], ref[k])
 
 
 def test_resume_refuses_a_store_written_with_other_settings(tmp_path, cpu_cli):
