@@ -412,6 +412,78 @@ LSR_HD int huf_decode_stream(Lane<Store>& L, const uint8_t* p, int len, uint8_t*
   return b.pos == 0 ? kOk : kErrCorrupt;
 }
 
+// ---- the fast path of the four-stream decoder ------------------------------------------------------------------------------
+// A lane that waits for every 8-byte window and stores every literal as a byte spends its time in memory latency
+// (measured: 70 000 dependent global operations per 32 KB block, ~1 000 cycles each).  Here each stream keeps 128 bits
+// of its tail in two registers plus the next 64 already on their way (loaded one batch before they are needed), a batch
+// decodes four symbols per stream from one 64-bit extract without touching memory, and the four literals leave as one
+// dword.  The slow path above finishes the last symbols of every stream (and takes streams shorter than 24 bytes).
+struct FastStream {
+  const uint8_t* p;
+  int pos;            // unread bits
+  int base;           // stream bit index of lo's bit 0
+  uint64_t hi, lo, nxt;
+};
+LSR_HD bool fast_init(FastStream& f, const BackBits& b) {
+  const int top = (b.pos + 7) >> 3;           // bytes that still hold unread bits
+  if (top < 24 || b.pos < 64) return false;
+  f.p = b.p;
+  f.pos = b.pos;
+  f.base = 8 * (top - 16);
+  f.hi = load64(b.p + top - 8);
+  f.lo = load64(b.p + top - 16);
+  f.nxt = load64(b.p + top - 24);
+  return true;
+}
+// Before a batch: make sure the unread tail starts in `hi`.  False when the next window would lie before the stream.
+LSR_HD bool fast_step(FastStream& f) {
+  if (f.pos - f.base > 64) return true;
+  if (f.base < 128) return false;
+  f.hi = f.lo;
+  f.lo = f.nxt;
+  f.base -= 64;
+  f.nxt = load64(f.p + (f.base >> 3) - 8);
+  return true;
+}
+LSR_HD uint64_t fast_extract(const FastStream& f) {      // stream bits [pos - 64, pos)
+  const int sh = f.pos - f.base - 64;                     // 1 .. 64
+  return sh >= 64 ? f.hi : ((f.hi << (64 - sh)) | (f.lo >> sh));
+}
+
+// the canonical search on a value already aligned to max_bits; returns the symbol's rank and its length
+LSR_HD void huf_rank(const HufCode& h, uint32_t v, uint32_t& rank, int& length) {
+  int w = 1;
+  uint32_t start = 0, rstart = 0;
+#pragma unroll
+  for (int k = 1; k <= 10; ++k) {
+    const bool ge = v >= h.end[k];
+    start = ge ? h.end[k] : start;
+    rstart = ge ? h.rank_end[k] : rstart;
+    w += ge;
+  }
+  rank = rstart + ((v - start) >> (w - 1));
+  length = h.max_bits + 1 - w;
+}
+
+template <class Store>
+LSR_HD uint32_t fast_four(Lane<Store>& L, FastStream& f) {   // four literals of one stream, first in the low byte
+  uint64_t cur = fast_extract(f);
+  uint32_t out = 0;
+  const int mb = L.huf.max_bits;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t rank;
+    int length;
+    huf_rank(L.huf, static_cast<uint32_t>(cur >> (64 - mb)), rank, length);
+    out |= static_cast<uint32_t>(L.store.sym_get(static_cast<int>(rank))) << (8 * k);
+    cur <<= length;
+    f.pos -= length;
+  }
+  return out;
+}
+
+LSR_HD void store32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
 // four streams side by side: four independent dependency chains per lane
 template <class Store>
 LSR_HD int huf_decode_4(Lane<Store>& L, const uint8_t* p, int len, uint8_t* out, int n) {
@@ -431,13 +503,31 @@ LSR_HD int huf_decode_4(Lane<Store>& L, const uint8_t* p, int len, uint8_t* out,
   uint8_t* o1 = out + q;
   uint8_t* o2 = out + 2 * q;
   uint8_t* o3 = out + 3 * q;
-  for (int i = 0; i < n3; ++i) {
+  int i = 0;
+  {
+    FastStream f0, f1, f2, f3;
+    if (fast_init(f0, b0) && fast_init(f1, b1) && fast_init(f2, b2) && fast_init(f3, b3)) {
+      // a batch needs four more symbols in every stream (the fourth is the shortest) and 44 unread bits in each
+      while (i + 4 <= n3 && f0.pos >= 64 && f1.pos >= 64 && f2.pos >= 64 && f3.pos >= 64 &&
+             fast_step(f0) && fast_step(f1) && fast_step(f2) && fast_step(f3)) {
+        const uint32_t a = fast_four(L, f0), b = fast_four(L, f1), c = fast_four(L, f2), d = fast_four(L, f3);
+        store32(o0 + i, a);
+        store32(o1 + i, b);
+        store32(o2 + i, c);
+        store32(o3 + i, d);
+        i += 4;
+      }
+      b0.pos = f0.pos; b1.pos = f1.pos; b2.pos = f2.pos; b3.pos = f3.pos;
+      back_refill(b0); back_refill(b1); back_refill(b2); back_refill(b3);
+    }
+  }
+  for (; i < n3; ++i) {
     o0[i] = huf_decode_one(L, b0);
     o1[i] = huf_decode_one(L, b1);
     o2[i] = huf_decode_one(L, b2);
     o3[i] = huf_decode_one(L, b3);
   }
-  for (int i = n3; i < q; ++i) {
+  for (i = n3 > i ? n3 : i; i < q; ++i) {
     o0[i] = huf_decode_one(L, b0);
     o1[i] = huf_decode_one(L, b1);
     o2[i] = huf_decode_one(L, b2);
@@ -556,11 +646,25 @@ LSR_HD int read_seq_table(Lane<Store>& L, int which, int mode, const uint8_t* p,
   return used;
 }
 
+struct Bytes16 { uint64_t a, b; };
+LSR_HD Bytes16 load16(const uint8_t* p) { Bytes16 v; __builtin_memcpy(&v, p, 16); return v; }
+LSR_HD void store16(uint8_t* p, const Bytes16& v) { __builtin_memcpy(p, &v, 16); }
+
 // copy n bytes within the destination from `offset` back (may overlap: the pattern repeats)
 LSR_HD void copy_match(uint8_t* o, uint32_t offset, int n) {
   const uint8_t* m = o - offset;
+  int i = 0;
+  if (offset >= 32) {          // two independent 16-byte loads in flight
+    for (; i + 32 <= n; i += 32) {
+      const Bytes16 x = load16(m + i), y = load16(m + i + 16);
+      store16(o + i, x);
+      store16(o + i + 16, y);
+    }
+  }
+  if (offset >= 16) {
+    for (; i + 16 <= n; i += 16) store16(o + i, load16(m + i));
+  }
   if (offset >= 8) {
-    int i = 0;
     for (; i + 8 <= n; i += 8) {
       uint64_t v;
       __builtin_memcpy(&v, m + i, 8);
@@ -569,17 +673,27 @@ LSR_HD void copy_match(uint8_t* o, uint32_t offset, int n) {
     for (; i < n; ++i) o[i] = m[i];
     return;
   }
-  // period < 8: the pattern in a register, eight bytes per store, advancing by the largest multiple of the period
-  uint64_t pat = 0;
-  for (int i = 0; i < 8; ++i) pat |= static_cast<uint64_t>(m[i % static_cast<int>(offset)]) << (8 * i);
-  const int step = (8 / static_cast<int>(offset)) * static_cast<int>(offset);
-  int i = 0;
-  for (; i + 8 <= n; i += step) __builtin_memcpy(o + i, &pat, 8);
-  for (int k = 0; i < n; ++i, ++k) o[i] = static_cast<uint8_t>(pat >> (8 * (k % static_cast<int>(offset))));
+  // period < 8: the pattern in registers, sixteen bytes per store, advancing by the largest multiple of the period
+  const int p = static_cast<int>(offset);
+  uint8_t hist[8];
+  for (int k = 0; k < p; ++k) hist[k] = m[k];
+  Bytes16 pat{0, 0};
+  for (int k = 0; k < 8; ++k) {
+    pat.a |= static_cast<uint64_t>(hist[k % p]) << (8 * k);
+    pat.b |= static_cast<uint64_t>(hist[(k + 8) % p]) << (8 * k);
+  }
+  const int step = (16 / p) * p;
+  for (; i + 16 <= n; i += step) store16(o + i, pat);
+  for (int k = 0; i < n; ++i, ++k) o[i] = hist[k % p];
 }
 
-LSR_HD void copy_forward(uint8_t* o, const uint8_t* s, int n) {   // s >= o or disjoint: exact length, eight bytes at a time
+LSR_HD void copy_forward(uint8_t* o, const uint8_t* s, int n) {   // s >= o or disjoint: exact length, 16 bytes at a time
   int i = 0;
+  for (; i + 32 <= n; i += 32) {          // (both loads before the stores: s >= o, so no store lands on unread source)
+    const Bytes16 x = load16(s + i), y = load16(s + i + 16);
+    store16(o + i, x);
+    store16(o + i + 16, y);
+  }
   for (; i + 8 <= n; i += 8) {
     uint64_t v;
     __builtin_memcpy(&v, s + i, 8);

@@ -390,13 +390,18 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None, f
         logger.error("unit %s: %s failed, skipped: %s: %s", mine[i], stage_name, type(exc).__name__, exc)
         failures.append((mine[i], stage_name, f"{type(exc).__name__}: {exc}"))
 
-    def write(i):
+    def collect(i):
+        t = clock()
+        host = stager.collect(i % depth)        # waits for the download of unit i (device-encoded results: starts it)
+        spent("collect", t)
+        return host
+
+    def write(i, collected):
         if failed:                 # an earlier unit's write failed: nothing after it is written
             return
         try:
+            host = collected.result()
             t = clock()
-            host = stager.collect(i % depth)    # waits for the download of unit i
-            t = spent("collect", t)
             store(mine[i], host)
             spent("write", t)
         except Exception as exc:  # noqa: BLE001
@@ -409,7 +414,10 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None, f
             failed.append(i)
             raise
 
+    # the collector runs ahead of the writer: the download of unit i (for a device-encoded result it can only be sized
+    # once the frame table is on the host) proceeds while unit i - 1 is still being written
     loader, storer = ThreadPoolExecutor(1, "lsr-load"), ThreadPoolExecutor(1, "lsr-store")
+    collector = ThreadPoolExecutor(1, "lsr-collect")
     stores: list = []       # one future (or None: the unit was skipped) per unit, in unit order
     nxt = None
     try:
@@ -452,7 +460,7 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None, f
                 continue
             stager.stage_out(i % depth, result)
             spent("stage_out", t)
-            stores.append(storer.submit(write, i))
+            stores.append(storer.submit(write, i, collector.submit(collect, i)))
         t = clock()
         for fut in stores:
             if fut is not None:
@@ -475,6 +483,7 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None, f
             except Exception:  # noqa: BLE001
                 pass
         loader.shutdown(wait=True)
+        collector.shutdown(wait=True)
         storer.shutdown(wait=True)
         stager.drain()
 
