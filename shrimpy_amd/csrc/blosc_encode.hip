@@ -125,6 +125,9 @@ void build_plane_code_host(const uint32_t* count, int plane_len, PlaneCode& pc) 
   if (distinct == 1) { pc.mode = kPlaneRle; pc.rle_value = static_cast<uint8_t>(only); return; }
   pc.mode = kPlaneRaw;
   if (plane_len < kMinHufPlane || distinct < 2) return;
+  uint64_t sum_sq = 0;
+  for (int s = 0; s < 256; ++s) sum_sq += uint64_t(count[s]) * count[s];
+  if (huf_hopeless(sum_sq, static_cast<uint64_t>(plane_len))) return;
   uint16_t order[256];
   int ns = 0;
   for (int i = 0; i < 256; ++i) {
@@ -147,7 +150,8 @@ void build_plane_code_host(const uint32_t* count, int plane_len, PlaneCode& pc) 
     pc.ct[i] = huf_code_of(nbits, first, i);
     payload_bits += int64_t(count[i]) * nbits[i];
   }
-  pc.desc_size = huf_write_description(nbits, max_bits, pc.desc);
+  HufScratch scratch;
+  pc.desc_size = huf_write_description(nbits, max_bits, pc.desc, scratch);
   if (pc.desc_size > 0 && huf_pays(plane_len, payload_bits, pc.desc_size)) pc.mode = kPlaneHuf;
 }
 
@@ -294,6 +298,7 @@ struct __attribute__((aligned(16))) EncShared {
   uint32_t per_depth[kMaxType][kDepthSlots];
   uint16_t first[kMaxType][kHufMaxBits + 5];
   uint32_t payload_bits[kMaxType];
+  unsigned long long sum_sq[kMaxType];
   int mode[kMaxType], desc_size[kMaxType], ns[kMaxType], max_bits[kMaxType], rle[kMaxType];
   int stream_bytes[4];
   int pos;
@@ -303,6 +308,7 @@ struct __attribute__((aligned(16))) TreeScratch {
   uint32_t node_cnt[512];
   uint16_t parent[512];
   uint16_t order[256];
+  HufScratch desc;
 };
 
 inline size_t encode_lds_bytes(int64_t blocksize, int T) {
@@ -371,18 +377,26 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
       present += __popcll(__ballot(r >= 0));
       if (own) { S.nbits[pw][i] = 0; S.ct[pw][i] = 0; }
     }
+    unsigned long long sq = 0;
+    for (int q = 0; q < 4; ++q) {
+      const unsigned long long c = own ? count[lane + 64 * q] : 0;
+      sq += c * c;
+    }
+    for (int d = 32; d > 0; d >>= 1) sq += __shfl_down(sq, d);
     if (own && lane == 0) {
       S.ns[pw] = present;
       S.mode[pw] = kPlaneRaw;
       S.desc_size[pw] = 0;
       S.payload_bits[pw] = 0;
       S.max_bits[pw] = 0;
+      S.sum_sq[pw] = sq;
     }
     if (own && lane < kDepthSlots) S.per_depth[pw][lane] = 0;
   }
   __syncthreads();
   const int ns = own ? S.ns[pw] : 0;
-  const bool coded = own && ns >= 2 && plane_len >= kMinHufPlane;
+  const bool coded = own && ns >= 2 && plane_len >= kMinHufPlane &&
+                     !huf_hopeless(S.sum_sq[own ? pw : 0], static_cast<uint64_t>(plane_len));
   if (coded)
     for (int k = lane; k < ns; k += 64) W.node_cnt[k] = count[W.order[k]];
   if (own && ns == 1 && lane == 0) {
@@ -415,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
   }
   __syncthreads();
   if (coded && lane == 0) {
-    const int ds = huf_write_description(S.nbits[pw], S.max_bits[pw], S.desc[pw]);
+    const int ds = huf_write_description(S.nbits[pw], S.max_bits[pw], S.desc[pw], W.desc);
     S.desc_size[pw] = ds;
     if (ds > 0 && huf_pays(plane_len, S.payload_bits[pw], ds)) S.mode[pw] = kPlaneHuf;
   }

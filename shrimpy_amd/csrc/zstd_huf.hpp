@@ -50,14 +50,27 @@ LSR_HD int huf_rank_of(const uint32_t* count, int i) {
 // node k < ns is leaf order[k]; nodes ns .. 2 ns - 2 are internal, created in non-decreasing weight; parent[] of every
 // node but the root (2 ns - 2).  node_cnt: 2 ns - 1 entries, the first ns filled by the caller with the leaf counts.
 LSR_HD void huf_merge(uint32_t* node_cnt, uint16_t* parent, int ns) {
+  // the heads of the two queues stay in registers: one pair of (independent) loads per merge instead of four
+  // dependent ones -- on the device this loop is ONE lane talking to LDS, ~100 cycles per round trip
   int leaf = 0, inner = ns, next = ns;
+  uint32_t leaf_cnt = node_cnt[0], inner_cnt = 0xFFFFFFFFu;     // an empty inner queue never wins
   for (int k = 0; k < ns - 1; ++k) {
     int pick[2];
+    uint32_t sum = 0;
     for (int t = 0; t < 2; ++t) {
-      const bool take_leaf = leaf < ns && (inner >= next || node_cnt[leaf] <= node_cnt[inner]);
-      pick[t] = take_leaf ? leaf++ : inner++;
+      const bool take_leaf = leaf < ns && (inner >= next || leaf_cnt <= inner_cnt);
+      if (take_leaf) {
+        pick[t] = leaf++;
+        sum += leaf_cnt;
+        leaf_cnt = leaf < ns ? node_cnt[leaf] : 0xFFFFFFFFu;
+      } else {
+        pick[t] = inner++;
+        sum += inner_cnt;
+        inner_cnt = inner < next ? node_cnt[inner] : 0xFFFFFFFFu;
+      }
     }
-    node_cnt[next] = node_cnt[pick[0]] + node_cnt[pick[1]];
+    node_cnt[next] = sum;
+    if (inner == next) inner_cnt = sum;          // the node just made is the head of the inner queue
     parent[pick[0]] = static_cast<uint16_t>(next);
     parent[pick[1]] = static_cast<uint16_t>(next);
     ++next;
@@ -224,11 +237,20 @@ struct FseEnc {            // encoding table of one distribution over <= 13 symb
   uint16_t next_state[64];
   int delta_bits[13];
   int delta_state[13];
+  uint8_t spread[64];
+};
+
+// Work space of huf_write_description: LDS on the device (one per wave), the stack on the host -- as function-local
+// arrays they would be per-lane scratch memory on the device, ~500 cycles per access for a single lane
+struct HufScratch {
+  uint8_t w[256];
+  uint8_t tmp[kHufHeaderMax];
+  FseEnc enc;
 };
 
 LSR_HD void fse_build_enc(FseEnc& t, const int* norm, int max_symbol, int log) {
   const int table = 1 << log, mask = table - 1, step = (table >> 1) + (table >> 3) + 3;
-  uint8_t spread[64];
+  uint8_t* const spread = t.spread;
   int cumul[14];
   cumul[0] = 0;
   for (int s = 0; s <= max_symbol; ++s) cumul[s + 1] = cumul[s] + norm[s];
@@ -287,12 +309,13 @@ LSR_HD int fse_encode_weights(const FseEnc& t, const uint8_t* w, int n, int log,
 // ---- step 8 (serial): the Huffman tree description ----------------------------------------------------------------------
 // nbits[256] / max_bits as built above.  Writes the description into hdr (kHufHeaderMax bytes) and returns its size, or
 // -1 when the weights can be written neither as nibbles (more than 128 of them) nor as an FSE stream below 128 bytes.
-LSR_HD int huf_write_description(const uint8_t* nbits, int max_bits, uint8_t* hdr) {
+LSR_HD int huf_write_description(const uint8_t* nbits, int max_bits, uint8_t* hdr, HufScratch& scratch) {
   int last = 255;
   while (last > 0 && nbits[last] == 0) --last;
   const int nw = last;                       // weights of symbols 0 .. last - 1; the last one is implied
   if (nw < 1) return -1;
-  uint8_t w[256];
+  uint8_t* const w = scratch.w;
+  uint8_t* const tmp = scratch.tmp;
   int hist[13];
   for (int s = 0; s < 13; ++s) hist[s] = 0;
   for (int s = 0; s < nw; ++s) {
@@ -300,7 +323,6 @@ LSR_HD int huf_write_description(const uint8_t* nbits, int max_bits, uint8_t* hd
     ++hist[w[s]];
   }
   int fse_size = -1;
-  uint8_t tmp[kHufHeaderMax];
   if (nw >= 2) {
     int norm[13], top = 0;
     if (fse_normalise_weights(hist, nw, norm, &top)) {
@@ -309,9 +331,8 @@ LSR_HD int huf_write_description(const uint8_t* nbits, int max_bits, uint8_t* hd
       fse_write_ncount(head, norm, top, kWeightLog);
       const int hb = bit_close(head, false);
       if (hb > 0) {
-        FseEnc enc;
-        fse_build_enc(enc, norm, top, kWeightLog);
-        const int body = fse_encode_weights(enc, w, nw, kWeightLog, tmp + hb, 127 - hb);
+        fse_build_enc(scratch.enc, norm, top, kWeightLog);
+        const int body = fse_encode_weights(scratch.enc, w, nw, kWeightLog, tmp + hb, 127 - hb);
         if (body > 0) fse_size = hb + body;
       }
     }
@@ -380,6 +401,11 @@ LSR_HD bool huf_pays(int plane_len, int64_t payload_bits, int desc_size) {
   const int64_t upper = desc_size + 6 + (payload_bits + 7) / 8 + 4 + 5 + 1;   // + jump table, stream round-ups, literals header, sequences byte
   return upper < plane_len - plane_len / 64;
 }
+
+// A plane whose collision entropy -log2(sum p^2) -- a lower bound of its Shannon entropy -- is at least 7.875 bits cannot
+// save 1/64 with any prefix code: no tree is built for it (the noise planes of float32 / uint16 data).
+// sum_sq = sum of count^2 over the 256 symbols, n = their sum:  sum p^2 <= 2^-7.875  <=>  235 * sum_sq <= n^2 (rounded safe).
+LSR_HD bool huf_hopeless(uint64_t sum_sq, uint64_t n) { return 235ull * sum_sq <= n * n; }
 
 constexpr int kMinHufPlane = 2048;  // shorter planes (the tail block of a chunk) are written Raw / RLE: every lane of
                                     // the encode kernel then owns a run of at least 8 symbols of its stream
