@@ -272,6 +272,31 @@ __device__ __forceinline__ void load_block16(const uint8_t* blk, int64_t off, in
   }
 }
 
+// The streaming loops of the encode kernel walk the block in 16-byte vectors, kThreads of them side by side.  With one
+// vector in flight per thread a pass costs a memory round trip per step (the kernel runs two workgroups per CU: nothing
+// else hides it); kAhead vectors are loaded before the first is used.
+constexpr int kAhead = 4;
+__device__ __forceinline__ void load_ahead(const uint8_t* blk, int64_t off0, int64_t bsize, int64_t valid, int tid,
+                                           uint32_t w[kAhead][4]) {
+  if (off0 + int64_t(kAhead) * kThreads * 16 <= valid) {
+    // the whole batch lies inside the source (a workgroup-uniform test): unconditional loads, all issued before the
+    // first use -- under a per-lane condition hipcc waits for every load before it issues the next
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const uint8_t* q = blk + off0 + (int64_t(u) * kThreads + tid) * 16;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[u][k] = load_u32_any(q + 4 * k);
+    }
+    return;
+  }
+#pragma unroll
+  for (int u = 0; u < kAhead; ++u) {
+    const int64_t off = off0 + (int64_t(u) * kThreads + tid) * 16;
+    w[u][0] = w[u][1] = w[u][2] = w[u][3] = 0;
+    if (off < bsize) load_block16(blk, off, valid, w[u]);
+  }
+}
+
 // the 16 / T symbols of plane p in the vector, packed low byte first (T = 4: one dword; 2: two; 1: four)
 template <int T>
 __device__ __forceinline__ void plane_symbols(const uint32_t w[4], int p, uint32_t s[4]) {
@@ -320,6 +345,14 @@ inline size_t encode_lds_bytes(int64_t blocksize, int T) {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t enc_dyn_lds[];
 
+// Measurement build (make EXTRA=-DLSR_ENC_PROBE): cycle stamps of the phases of the first 1 024 workgroups
+#ifdef LSR_ENC_PROBE
+__device__ long long lsr_enc_probe_cycles[1024 * 16];
+#define LSR_ENC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) lsr_enc_probe_cycles[blockIdx.x * 16 + (k)] = clock64(); } while (0)
+#else
+#define LSR_ENC_STAMP(k) do { } while (0)
+#endif
+
 template <int T>
 __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
   static_assert(T <= kMaxType && kMaxType <= kWaves, "one wave per plane");
@@ -337,32 +370,38 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
   const int plane_len = static_cast<int>(bsize / T);
   constexpr int kPer = 16 / T;                  // symbols of one plane in a 16-byte vector
 
+  LSR_ENC_STAMP(0);
   // ---- histograms of all planes: one coalesced pass --------------------------------------------------------------
   for (int i = tid; i < kMaxType * 256; i += kThreads) (&S.hist[0][0])[i] = 0;
   __syncthreads();
-  for (int64_t off0 = 0; off0 < bsize; off0 += int64_t(kThreads) * 16) {
-    const int64_t off = off0 + int64_t(tid) * 16;
-    const bool in = off < bsize;
-    uint32_t w[4] = {0, 0, 0, 0};
-    if (in) load_block16(blk, off, valid, w);
-    const int nsym = in ? static_cast<int>(imin64(16, bsize - off)) / T : 0;
-    for (int p = 0; p < T; ++p) {
-      uint32_t s[4];
-      plane_symbols<T>(w, p, s);
-      // one atomic for the whole wave when all its symbols of this plane agree (the exponent plane of float32 data)
-      const uint32_t s0 = s[0] & 0xFF;
-      bool same = nsym == kPer;
-      for (int k = 0; k < (kPer + 3) / 4; ++k) same = same && s[k] == s0 * 0x01010101u;
-      const uint32_t lead = __builtin_amdgcn_readfirstlane(s0);
-      if (__all(same && s0 == lead)) {
-        if (lane == 0) atomicAdd(&S.hist[p][lead], 64u * kPer);
-      } else {
-        for (int k = 0; k < nsym; ++k) atomicAdd(&S.hist[p][(s[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
+  for (int64_t off0 = 0; off0 < bsize; off0 += int64_t(kAhead) * kThreads * 16) {
+    uint32_t wa[kAhead][4];
+    load_ahead(blk, off0, bsize, valid, tid, wa);
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const int64_t off = off0 + (int64_t(u) * kThreads + tid) * 16;
+      const bool in = off < bsize;
+      const uint32_t* w = wa[u];
+      const int nsym = in ? static_cast<int>(imin64(16, bsize - off)) / T : 0;
+      for (int p = 0; p < T; ++p) {
+        uint32_t s[4];
+        plane_symbols<T>(w, p, s);
+        // one atomic for the whole wave when all its symbols of this plane agree (the exponent plane of float32 data)
+        const uint32_t s0 = s[0] & 0xFF;
+        bool same = nsym == kPer;
+        for (int k = 0; k < (kPer + 3) / 4; ++k) same = same && s[k] == s0 * 0x01010101u;
+        const uint32_t lead = __builtin_amdgcn_readfirstlane(s0);
+        if (__all(same && s0 == lead)) {
+          if (lane == 0) atomicAdd(&S.hist[p][lead], 64u * kPer);
+        } else {
+          for (int k = 0; k < nsym; ++k) atomicAdd(&S.hist[p][(s[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
+        }
       }
     }
   }
   __syncthreads();
 
+  LSR_ENC_STAMP(1);
   // ---- code tables: wave w builds plane w (steps 1-8 of zstd_huf.hpp; the per-element steps on the 64 lanes) ------
   TreeScratch& W = *reinterpret_cast<TreeScratch*>(symbuf + size_t(wave) * sizeof(TreeScratch));
   const int pw = wave;
@@ -404,8 +443,10 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
     S.rle[pw] = W.order[0];
   }
   __syncthreads();
+  LSR_ENC_STAMP(2);
   if (coded && lane == 0) huf_merge(W.node_cnt, W.parent, ns);
   __syncthreads();
+  LSR_ENC_STAMP(3);
   if (coded)
     for (int k = lane; k < ns; k += 64) atomicAdd(&S.per_depth[pw][huf_depth_of(W.parent, ns, k)], 1u);
   __syncthreads();
@@ -428,6 +469,7 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
     atomicAdd(&S.payload_bits[pw], bits);
   }
   __syncthreads();
+  LSR_ENC_STAMP(4);
   if (coded && lane == 0) {
     const int ds = huf_write_description(S.nbits[pw], S.max_bits[pw], S.desc[pw], W.desc);
     S.desc_size[pw] = ds;
@@ -435,6 +477,7 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
   }
   __syncthreads();
 
+  LSR_ENC_STAMP(5);
   // ---- the block's stream, plane by plane ---------------------------------------------------------------------------
   bool any = false;
   for (int p = 0; p < T; ++p) any = any || S.mode[p] != kPlaneRaw;
@@ -455,16 +498,22 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
       const int hdr = any ? 3 : 0;
       if (any && tid == 0) block_header(out + pos, 0, plane_len, last);
       uint8_t* const dst = out + pos + hdr;
-      for (int64_t off = int64_t(tid) * 16; off < bsize; off += int64_t(kThreads) * 16) {
-        uint32_t w[4], s[4];
-        load_block16(blk, off, valid, w);
-        plane_symbols<T>(w, p, s);
-        const int nsym = static_cast<int>(imin64(16, bsize - off)) / T;
-        const int64_t s_at = off / T;
-        if (nsym == kPer) {
-          for (int k = 0; k < (kPer + 3) / 4; ++k) store_u32_any(dst + s_at + 4 * k, s[k]);
-        } else {
-          for (int k = 0; k < nsym; ++k) dst[s_at + k] = static_cast<uint8_t>(s[k >> 2] >> (8 * (k & 3)));
+      for (int64_t off0 = 0; off0 < bsize; off0 += int64_t(kAhead) * kThreads * 16) {
+        uint32_t wa[kAhead][4];
+        load_ahead(blk, off0, bsize, valid, tid, wa);
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+          const int64_t off = off0 + (int64_t(u) * kThreads + tid) * 16;
+          if (off >= bsize) continue;
+          uint32_t s[4];
+          plane_symbols<T>(wa[u], p, s);
+          const int nsym = static_cast<int>(imin64(16, bsize - off)) / T;
+          const int64_t s_at = off / T;
+          if (nsym == kPer) {
+            for (int k = 0; k < (kPer + 3) / 4; ++k) store_u32_any(dst + s_at + 4 * k, s[k]);
+          } else {
+            for (int k = 0; k < nsym; ++k) dst[s_at + k] = static_cast<uint8_t>(s[k >> 2] >> (8 * (k & 3)));
+          }
         }
       }
       next_pos = pos + hdr + plane_len;
@@ -476,20 +525,38 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
       next_pos = pos + 4;
     } else {
       // stage the plane: symbol s of the plane -> stream j, lane l, place `within` of that lane's run
-      for (int64_t off = int64_t(tid) * 16; off < bsize; off += int64_t(kThreads) * 16) {
-        uint32_t w[4], s[4];
-        load_block16(blk, off, valid, w);
-        plane_symbols<T>(w, p, s);
-        const int nsym = static_cast<int>(imin64(16, bsize - off)) / T;
-        const int s_at = static_cast<int>(off / T);
-        for (int k = 0; k < nsym; ++k) {
-          const int si = s_at + k;
-          const int j = (si >= q4) + (si >= 2 * q4) + (si >= 3 * q4);
-          const int idx = si - j * q4;
-          const Runs& r = j < 3 ? ra : rb;
-          int l = idx >> r.shift, within = idx & (r.c - 1);
-          if (l >= r.lanes) { l = r.lanes - 1; within = idx - l * r.c; }
-          symbuf[(j * 64 + l) * c_pad + within] = static_cast<uint8_t>(s[k >> 2] >> (8 * (k & 3)));
+      for (int64_t off0 = 0; off0 < bsize; off0 += int64_t(kAhead) * kThreads * 16) {
+        uint32_t wa[kAhead][4];
+        load_ahead(blk, off0, bsize, valid, tid, wa);
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+          const int64_t off = off0 + (int64_t(u) * kThreads + tid) * 16;
+          if (off >= bsize) continue;
+          uint32_t s[4];
+          plane_symbols<T>(wa[u], p, s);
+          const int nsym = static_cast<int>(imin64(16, bsize - off)) / T;
+          const int s_at = static_cast<int>(off / T);
+          // (the kPer symbols of a vector are consecutive: they share stream and lane unless a boundary falls among them)
+          const int j0 = (s_at >= q4) + (s_at >= 2 * q4) + (s_at >= 3 * q4);
+          const Runs& r0 = j0 < 3 ? ra : rb;
+          const int idx0 = s_at - j0 * q4;
+          const int l0 = idx0 >> r0.shift;
+          const int last = s_at + nsym - 1;
+          const bool together = nsym == kPer && kPer <= 4 && l0 < r0.lanes - 1 && ((idx0 + nsym - 1) >> r0.shift) == l0 &&
+                                last < (j0 + 1) * q4 && (idx0 & 3) == 0;
+          if (together) {             // one aligned dword store
+            *reinterpret_cast<uint32_t*>(symbuf + (j0 * 64 + l0) * c_pad + (idx0 & (r0.c - 1))) = s[0];
+            continue;
+          }
+          for (int k = 0; k < nsym; ++k) {
+            const int si = s_at + k;
+            const int j = (si >= q4) + (si >= 2 * q4) + (si >= 3 * q4);
+            const int idx = si - j * q4;
+            const Runs& r = j < 3 ? ra : rb;
+            int l = idx >> r.shift, within = idx & (r.c - 1);
+            if (l >= r.lanes) { l = r.lanes - 1; within = idx - l * r.c; }
+            symbuf[(j * 64 + l) * c_pad + within] = static_cast<uint8_t>(s[k >> 2] >> (8 * (k & 3)));
+          }
         }
       }
       __syncthreads();
@@ -501,7 +568,15 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
       const uint8_t* const run = symbuf + (j * 64 + lane) * c_pad;
       const uint32_t* const ct = S.ct[p];
       uint32_t my_bits = 0;
-      for (int i = 0; i < n_l; ++i) my_bits += ct[run[i]] >> 16;
+      {
+        int i = 0;
+        for (; i + 4 <= n_l; i += 4) {         // the run starts on a dword of LDS: four symbols, four independent look-ups
+          const uint32_t four = *reinterpret_cast<const uint32_t*>(run + i);
+          const uint32_t e0 = ct[four & 0xFF], e1 = ct[(four >> 8) & 0xFF], e2 = ct[(four >> 16) & 0xFF], e3 = ct[four >> 24];
+          my_bits += (e0 >> 16) + (e1 >> 16) + (e2 >> 16) + (e3 >> 16);
+        }
+        for (; i < n_l; ++i) my_bits += ct[run[i]] >> 16;
+      }
       uint32_t suffix = my_bits;                       // inclusive sum over lanes >= this one
       for (int d = 1; d < 64; d <<= 1) {
         const uint32_t t = __shfl_down(suffix, d);
@@ -547,16 +622,24 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
       if (n_l > 0) {
         acc >>= skip;
         nb -= static_cast<int>(skip);
-        for (; i >= 0; --i) {
-          const uint32_t e = ct[run[i]];
+        auto put = [&](uint32_t e) {
           acc |= uint64_t(e & 0xFFFF) << nb;
           nb += static_cast<int>(e >> 16);
+        };
+        auto flush = [&]() {
           if (nb >= 32) {
             store_u32_any(wp, static_cast<uint32_t>(acc));
             wp += 4;
             acc >>= 32;
             nb -= 32;
           }
+        };
+        for (; i >= 0 && ((i + 1) & 3); --i) { put(ct[run[i]]); flush(); }
+        for (; i >= 3; i -= 4) {                 // symbols i-3 .. i: one dword of LDS, four look-ups in flight
+          const uint32_t four = *reinterpret_cast<const uint32_t*>(run + i - 3);
+          const uint32_t e3 = ct[four >> 24], e2 = ct[(four >> 16) & 0xFF], e1 = ct[(four >> 8) & 0xFF], e0 = ct[four & 0xFF];
+          put(e3); put(e2); flush();
+          put(e1); put(e0); flush();
         }
         acc |= uint64_t(recv) << nb;
         nb += static_cast<int>(recv_bits);
@@ -566,8 +649,10 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
     }
     __syncthreads();
     if (tid == 0) S.pos = next_pos;
+    LSR_ENC_STAMP(6 + p);
   }
   __syncthreads();
+  LSR_ENC_STAMP(10);
   if (tid == 0) {
     const int total = S.pos;
     const uint32_t cbytes = static_cast<uint32_t>(total - 4);
@@ -715,6 +800,12 @@ extern "C" int lsr_blosc_encode_device(const void* src, int64_t src_bytes, int t
   hipLaunchKernelGGL(gather_frames_kernel, grid, block, 0, s, ga);
   return lsr::launch_status("lsr_blosc_encode_device");
 }
+
+#ifdef LSR_ENC_PROBE
+extern "C" int lsr_debug_enc_probe(long long* out, int n) {
+  return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(lsr_enc_probe_cycles), sizeof(long long) * static_cast<size_t>(n)));
+}
+#endif
 
 // The host twin: the same frames, byte for byte, from and to host memory (`frames`: 2 n_frames int64 as above).
 extern "C" int lsr_blosc_encode_device_cpu(const void* src, int64_t src_bytes, int typesize, int64_t frame_bytes,

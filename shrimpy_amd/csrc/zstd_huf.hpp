@@ -238,6 +238,7 @@ struct FseEnc {            // encoding table of one distribution over <= 13 symb
   int delta_bits[13];
   int delta_state[13];
   uint8_t spread[64];
+  int fill[14];            // (work space of fse_build_enc)
 };
 
 // Work space of huf_write_description: LDS on the device (one per wave), the stack on the host -- as function-local
@@ -246,22 +247,23 @@ struct HufScratch {
   uint8_t w[256];
   uint8_t tmp[kHufHeaderMax];
   FseEnc enc;
+  int hist[13], norm[13];
 };
 
 LSR_HD void fse_build_enc(FseEnc& t, const int* norm, int max_symbol, int log) {
   const int table = 1 << log, mask = table - 1, step = (table >> 1) + (table >> 3) + 3;
   uint8_t* const spread = t.spread;
-  int cumul[14];
-  cumul[0] = 0;
-  for (int s = 0; s <= max_symbol; ++s) cumul[s + 1] = cumul[s] + norm[s];
-  int pos = 0;
-  for (int s = 0; s <= max_symbol; ++s)
-    for (int i = 0; i < norm[s]; ++i) {
+  int* const fill = t.fill;
+  int pos = 0, cumul = 0;
+  for (int s = 0; s <= max_symbol; ++s) {
+    const int n = norm[s];
+    fill[s] = cumul;
+    cumul += n;
+    for (int i = 0; i < n; ++i) {
       spread[pos] = static_cast<uint8_t>(s);
       pos = (pos + step) & mask;
     }
-  int fill[14];
-  for (int s = 0; s <= max_symbol; ++s) fill[s] = cumul[s];
+  }
   for (int u = 0; u < table; ++u) t.next_state[fill[spread[u]]++] = static_cast<uint16_t>(table + u);
   int total = 0;
   for (int s = 0; s <= max_symbol; ++s) {
@@ -316,15 +318,18 @@ LSR_HD int huf_write_description(const uint8_t* nbits, int max_bits, uint8_t* hd
   if (nw < 1) return -1;
   uint8_t* const w = scratch.w;
   uint8_t* const tmp = scratch.tmp;
-  int hist[13];
+  int* const hist = scratch.hist;
+  int* const norm = scratch.norm;
   for (int s = 0; s < 13; ++s) hist[s] = 0;
   for (int s = 0; s < nw; ++s) {
     w[s] = nbits[s] ? static_cast<uint8_t>(max_bits + 1 - nbits[s]) : 0;
     ++hist[w[s]];
   }
   int fse_size = -1;
-  if (nw >= 2) {
-    int norm[13], top = 0;
+  // up to 128 weights fit the nibble form (at most 64 bytes; an FSE stream would save a few dozen of them per plane of
+  // tens of kilobytes -- not worth ~250 dependent steps of one lane); more than 128 need the FSE form
+  if (nw > 128) {
+    int top = 0;
     if (fse_normalise_weights(hist, nw, norm, &top)) {
       BitOut head;
       bit_init(head, tmp, 127);

@@ -35,7 +35,10 @@ enum : int {
 constexpr int kLLLogMax = 9, kOFLogMax = 8, kMLLogMax = 9;
 // 32-bit entries of the lane workspace: the three sequence tables (they persist from block to block: Repeat_Mode), the
 // Huffman weights while a tree description is read (eight 4-bit weights per entry) and their FSE table
-constexpr int kLLBase = 0, kOFBase = 512, kMLBase = 768, kWeightBase = 1280, kWeightTabBase = 1312, kWorkEntries = 1376;
+constexpr int kLLBase = 0, kOFBase = 512, kMLBase = 768, kWeightBase = 1280, kWeightTabBase = 1312, kSeqBase = 1376;
+// ... and the decoded sequences of a block (literal length, match length, offset: three entries each) when there are
+// few enough of them to place the literals directly (see decode_block_direct)
+constexpr int kMaxDirectSeq = 192, kWorkEntries = kSeqBase + 3 * kMaxDirectSeq;
 constexpr int kBlockMax = 128 * 1024;
 
 LSR_HD uint64_t load_le(const uint8_t* p, int n) {   // n <= 8 bytes, little endian
@@ -484,9 +487,19 @@ LSR_HD uint32_t fast_four(Lane<Store>& L, FastStream& f) {   // four literals of
 
 LSR_HD void store32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
-// four streams side by side: four independent dependency chains per lane
-template <class Store>
-LSR_HD int huf_decode_4(Lane<Store>& L, const uint8_t* p, int len, uint8_t* out, int n) {
+// Where decoded literals go.  PlainSink: literal i at out[i] (the literal buffer).  The direct sink further down writes
+// every literal at its final place in the block.
+struct PlainSink {
+  uint8_t* out;
+  LSR_HD void put4(int, int i, uint32_t v) { store32(out + i, v); }
+  LSR_HD void put1(int, int i, uint8_t v) { out[i] = v; }
+};
+
+// four streams side by side: four independent dependency chains per lane.  Literal i of stream s is literal s * q + i
+// of the section; sink.put4(s, index, four literals) / sink.put1(s, index, literal) receive them in increasing order
+// per stream.
+template <class Store, class Sink>
+LSR_HD int huf_decode_4(Lane<Store>& L, const uint8_t* p, int len, int n, Sink& sink) {
   if (len < 10) return kErrCorrupt;
   const int s0 = static_cast<int>(load_le(p, 2)), s1 = static_cast<int>(load_le(p + 2, 2)), s2 = static_cast<int>(load_le(p + 4, 2));
   const int s3 = len - 6 - s0 - s1 - s2;
@@ -499,10 +512,6 @@ LSR_HD int huf_decode_4(Lane<Store>& L, const uint8_t* p, int len, uint8_t* out,
   if (!back_init(b0, s, s0) || !back_init(b1, s + s0, s1) || !back_init(b2, s + s0 + s1, s2) ||
       !back_init(b3, s + s0 + s1 + s2, s3))
     return kErrCorrupt;
-  uint8_t* o0 = out;
-  uint8_t* o1 = out + q;
-  uint8_t* o2 = out + 2 * q;
-  uint8_t* o3 = out + 3 * q;
   int i = 0;
   {
     FastStream f0, f1, f2, f3;
@@ -511,10 +520,10 @@ LSR_HD int huf_decode_4(Lane<Store>& L, const uint8_t* p, int len, uint8_t* out,
       while (i + 4 <= n3 && f0.pos >= 64 && f1.pos >= 64 && f2.pos >= 64 && f3.pos >= 64 &&
              fast_step(f0) && fast_step(f1) && fast_step(f2) && fast_step(f3)) {
         const uint32_t a = fast_four(L, f0), b = fast_four(L, f1), c = fast_four(L, f2), d = fast_four(L, f3);
-        store32(o0 + i, a);
-        store32(o1 + i, b);
-        store32(o2 + i, c);
-        store32(o3 + i, d);
+        sink.put4(0, i, a);
+        sink.put4(1, q + i, b);
+        sink.put4(2, 2 * q + i, c);
+        sink.put4(3, 3 * q + i, d);
         i += 4;
       }
       b0.pos = f0.pos; b1.pos = f1.pos; b2.pos = f2.pos; b3.pos = f3.pos;
@@ -522,15 +531,15 @@ LSR_HD int huf_decode_4(Lane<Store>& L, const uint8_t* p, int len, uint8_t* out,
     }
   }
   for (; i < n3; ++i) {
-    o0[i] = huf_decode_one(L, b0);
-    o1[i] = huf_decode_one(L, b1);
-    o2[i] = huf_decode_one(L, b2);
-    o3[i] = huf_decode_one(L, b3);
+    sink.put1(0, i, huf_decode_one(L, b0));
+    sink.put1(1, q + i, huf_decode_one(L, b1));
+    sink.put1(2, 2 * q + i, huf_decode_one(L, b2));
+    sink.put1(3, 3 * q + i, huf_decode_one(L, b3));
   }
   for (i = n3 > i ? n3 : i; i < q; ++i) {
-    o0[i] = huf_decode_one(L, b0);
-    o1[i] = huf_decode_one(L, b1);
-    o2[i] = huf_decode_one(L, b2);
+    sink.put1(0, i, huf_decode_one(L, b0));
+    sink.put1(1, q + i, huf_decode_one(L, b1));
+    sink.put1(2, 2 * q + i, huf_decode_one(L, b2));
   }
   return (b0.pos == 0 && b1.pos == 0 && b2.pos == 0 && b3.pos == 0) ? kOk : kErrCorrupt;
 }
@@ -543,30 +552,33 @@ struct Literals {
   uint8_t rle_value;
 };
 
-// `room`: bytes of the destination from `op` on.  Huffman literals are written to op + room' - size where room' =
-// min(room, kBlockMax): the block's output cannot overtake them (see the header of this file).
+struct LitHeader {
+  int type;               // 0 Raw, 1 RLE, 2 Huffman with a tree description, 3 Huffman with the previous tree
+  bool four;              // four streams
+  int size;               // literals of the section
+  const uint8_t* body;    // Raw: the literals; RLE: the value; Huffman: the streams (behind the description)
+  int body_len;
+};
+
+// The header of the literals section (a Huffman tree description is read, nothing is decoded).  Returns the bytes the
+// whole section takes.
 template <class Store>
-LSR_HD int read_literals(Lane<Store>& L, const uint8_t* p, int len, uint8_t* op, int room, Literals& lit) {
+LSR_HD int parse_literals(Lane<Store>& L, const uint8_t* p, int len, LitHeader& h) {
   if (len < 1) return kErrCorrupt;
   const int type = p[0] & 3, fmt = (p[0] >> 2) & 3;
+  h.type = type;
+  h.four = false;
   if (type < 2) {                          // Raw / RLE
     int hs, size;
     if ((fmt & 1) == 0) { hs = 1; size = p[0] >> 3; }
     else if (fmt == 1) { if (len < 2) return kErrCorrupt; hs = 2; size = static_cast<int>(load_le(p, 2) >> 4); }
     else { if (len < 3) return kErrCorrupt; hs = 3; size = static_cast<int>(load_le(p, 3) >> 4); }
     if (size > kBlockMax) return kErrCorrupt;
-    lit.size = size;
-    if (type == 0) {
-      if (hs + size > len) return kErrCorrupt;
-      lit.rle = false;
-      lit.ptr = p + hs;
-      return hs + size;
-    }
-    if (hs + 1 > len) return kErrCorrupt;
-    lit.rle = true;
-    lit.rle_value = p[hs];
-    lit.ptr = p + hs;
-    return hs + 1;
+    h.size = size;
+    h.body = p + hs;
+    h.body_len = type == 0 ? size : 1;
+    if (hs + h.body_len > len) return kErrCorrupt;
+    return hs + h.body_len;
   }
   int hs, regen, csize;
   bool four = true;
@@ -584,25 +596,38 @@ LSR_HD int read_literals(Lane<Store>& L, const uint8_t* p, int len, uint8_t* op,
     hs = 5; regen = static_cast<int>((v >> 4) & 0x3FFFF); csize = static_cast<int>(v >> 22);
   }
   if (regen > kBlockMax || regen < 1 || hs + csize > len) return kErrCorrupt;
-  const uint8_t* body = p + hs;
-  int body_len = csize;
+  h.body = p + hs;
+  h.body_len = csize;
   if (type == 2) {
-    const int d = read_huf_description(L, body, body_len);
+    const int d = read_huf_description(L, h.body, h.body_len);
     if (d < 0) return d;
-    body += d;
-    body_len -= d;
+    h.body += d;
+    h.body_len -= d;
   } else if (L.huf.max_bits == 0) {
     return kErrCorrupt;                    // "treeless" without a previous tree
   }
-  const int span = room < kBlockMax ? room : kBlockMax;
-  if (regen > span) return kErrDstSmall;
-  uint8_t* dst = op + span - regen;
-  const int rc = four ? huf_decode_4(L, body, body_len, dst, regen) : huf_decode_stream(L, body, body_len, dst, regen);
-  if (rc < 0) return rc;
-  lit.rle = false;
-  lit.ptr = dst;
-  lit.size = regen;
+  h.four = four;
+  h.size = regen;
   return hs + csize;
+}
+
+// The literals as a buffer: Raw ones stay in the source; Huffman ones are decoded to op + room' - size where room' =
+// min(room, kBlockMax) -- the block's output cannot overtake them (see the header of this file).
+template <class Store>
+LSR_HD int literals_in_place(Lane<Store>& L, const LitHeader& h, uint8_t* op, int room, Literals& lit) {
+  lit.size = h.size;
+  lit.rle = h.type == 1;
+  lit.rle_value = h.type == 1 ? h.body[0] : 0;
+  lit.ptr = h.body;
+  if (h.type < 2) return kOk;
+  const int span = room < kBlockMax ? room : kBlockMax;
+  if (h.size > span) return kErrDstSmall;
+  uint8_t* dst = op + span - h.size;
+  PlainSink sink{dst};
+  const int rc = h.four ? huf_decode_4(L, h.body, h.body_len, h.size, sink) : huf_decode_stream(L, h.body, h.body_len, dst, h.size);
+  if (rc < 0) return rc;
+  lit.ptr = dst;
+  return kOk;
 }
 
 // ---- sequences --------------------------------------------------------------------------------------------------------------------
@@ -702,10 +727,15 @@ LSR_HD void copy_forward(uint8_t* o, const uint8_t* s, int n) {   // s >= o or d
   for (; i < n; ++i) o[i] = s[i];
 }
 
-// Decode and execute the sequences of one block.  `dst0`: start of the frame's output (matches may reach back to it),
-// `op`: where this block's output starts, `room`: bytes available from op.  Returns the bytes produced.
+// The sequences section: header, tables, then the sequences one by one.
+struct SeqReader {
+  BackBits b;
+  uint32_t s_ll, s_of, s_ml;
+  int nseq, i;
+};
+
 template <class Store>
-LSR_HD int run_sequences(Lane<Store>& L, const uint8_t* p, int len, const Literals& lit, uint8_t* dst0, uint8_t* op, int room) {
+LSR_HD int seq_open(Lane<Store>& L, const uint8_t* p, int len, SeqReader& r) {
   if (len < 1) return kErrCorrupt;
   int nseq = p[0], hs = 1;
   if (nseq >= 128) {
@@ -719,70 +749,87 @@ LSR_HD int run_sequences(Lane<Store>& L, const uint8_t* p, int len, const Litera
       hs = 2;
     }
   }
+  r.nseq = nseq;
+  r.i = 0;
+  if (nseq == 0) return hs == len ? kOk : kErrCorrupt;
+  if (hs + 1 > len) return kErrCorrupt;
+  const int modes = p[hs];
+  if (modes & 3) return kErrCorrupt;
+  int at = hs + 1;
+  for (int which = 0; which < 3; ++which) {
+    const int mode = (modes >> (6 - 2 * which)) & 3;
+    const int used = read_seq_table(L, which, mode, p + at, len - at);
+    if (used < 0) return used;
+    at += used;
+  }
+  if (!back_init(r.b, p + at, len - at)) return kErrCorrupt;
+  r.s_ll = back_read(r.b, L.tab[0].log);
+  r.s_of = back_read(r.b, L.tab[1].log);
+  r.s_ml = back_read(r.b, L.tab[2].log);
+  return r.b.pos < 0 ? kErrCorrupt : kOk;
+}
+
+// the next sequence (repeat offsets resolved); after the last one the stream must be used up exactly
+template <class Store>
+LSR_HD int seq_next(Lane<Store>& L, SeqReader& r, int& lit_len, int& match_len, uint32_t& offset) {
+  BackBits& b = r.b;
+  const uint32_t e_ll = seq_entry(L, 0, r.s_ll), e_of = seq_entry(L, 1, r.s_of), e_ml = seq_entry(L, 2, r.s_ml);
+  const int of_code = static_cast<int>(e_of & 0xFF);
+  if (of_code > 31) return kErrCorrupt;
+  const uint32_t offset_value = (1u << of_code) + back_read(b, of_code);
+  uint32_t ml_base, ll_base;
+  int ml_bits, ll_bits;
+  ml_code(static_cast<int>(e_ml & 0xFF), ml_base, ml_bits);
+  ll_code(static_cast<int>(e_ll & 0xFF), ll_base, ll_bits);
+  match_len = static_cast<int>(ml_base + back_read(b, ml_bits));
+  lit_len = static_cast<int>(ll_base + back_read(b, ll_bits));
+  if (++r.i < r.nseq) {
+    r.s_ll = (e_ll >> 16) + back_read(b, static_cast<int>((e_ll >> 8) & 0xFF));
+    r.s_ml = (e_ml >> 16) + back_read(b, static_cast<int>((e_ml >> 8) & 0xFF));
+    r.s_of = (e_of >> 16) + back_read(b, static_cast<int>((e_of >> 8) & 0xFF));
+    if (b.pos < 0) return kErrCorrupt;
+  } else if (b.pos != 0) {
+    return kErrCorrupt;
+  }
+  if (offset_value > 3) {
+    offset = offset_value - 3;
+    L.rep[2] = L.rep[1]; L.rep[1] = L.rep[0]; L.rep[0] = offset;
+  } else {
+    const uint32_t idx = offset_value + (lit_len == 0 ? 1 : 0);
+    if (idx == 1) {
+      offset = L.rep[0];
+    } else {
+      offset = idx == 4 ? L.rep[0] - 1 : L.rep[idx - 1];
+      if (offset == 0) return kErrCorrupt;
+      if (idx != 2) L.rep[2] = L.rep[1];
+      L.rep[1] = L.rep[0];
+      L.rep[0] = offset;
+    }
+  }
+  return kOk;
+}
+
+// The general execution: literals from a buffer, sequence by sequence.  `dst0`: start of the frame's output (matches may
+// reach back to it), `op`: where this block's output starts, `room`: bytes available from op.  Returns the bytes produced.
+template <class Store>
+LSR_HD int run_sequences(Lane<Store>& L, SeqReader& r, const Literals& lit, uint8_t* dst0, uint8_t* op, int room) {
   uint8_t* o = op;
   uint8_t* const oend = op + room;
   int lit_at = 0;
-  if (nseq > 0) {
-    if (hs + 1 > len) return kErrCorrupt;
-    const int modes = p[hs];
-    if (modes & 3) return kErrCorrupt;
-    int at = hs + 1;
-    for (int which = 0; which < 3; ++which) {
-      const int mode = (modes >> (6 - 2 * which)) & 3;
-      const int used = read_seq_table(L, which, mode, p + at, len - at);
-      if (used < 0) return used;
-      at += used;
-    }
-    BackBits b;
-    if (!back_init(b, p + at, len - at)) return kErrCorrupt;
-    uint32_t s_ll = back_read(b, L.tab[0].log), s_of = back_read(b, L.tab[1].log), s_ml = back_read(b, L.tab[2].log);
-    if (b.pos < 0) return kErrCorrupt;
-    for (int i = 0; i < nseq; ++i) {
-      const uint32_t e_ll = seq_entry(L, 0, s_ll), e_of = seq_entry(L, 1, s_of), e_ml = seq_entry(L, 2, s_ml);
-      const int of_code = static_cast<int>(e_of & 0xFF);
-      if (of_code > 31) return kErrCorrupt;
-      uint32_t offset_value = (1u << of_code) + back_read(b, of_code);
-      uint32_t ml_base, ll_base;
-      int ml_bits, ll_bits;
-      ml_code(static_cast<int>(e_ml & 0xFF), ml_base, ml_bits);
-      ll_code(static_cast<int>(e_ll & 0xFF), ll_base, ll_bits);
-      const int match_len = static_cast<int>(ml_base + back_read(b, ml_bits));
-      const int lit_len = static_cast<int>(ll_base + back_read(b, ll_bits));
-      if (i + 1 < nseq) {
-        s_ll = (e_ll >> 16) + back_read(b, static_cast<int>((e_ll >> 8) & 0xFF));
-        s_ml = (e_ml >> 16) + back_read(b, static_cast<int>((e_ml >> 8) & 0xFF));
-        s_of = (e_of >> 16) + back_read(b, static_cast<int>((e_of >> 8) & 0xFF));
-      }
-      if (b.pos < 0) return kErrCorrupt;
-      uint32_t offset;
-      if (offset_value > 3) {
-        offset = offset_value - 3;
-        L.rep[2] = L.rep[1]; L.rep[1] = L.rep[0]; L.rep[0] = offset;
-      } else {
-        const uint32_t idx = offset_value + (lit_len == 0 ? 1 : 0);
-        if (idx == 1) {
-          offset = L.rep[0];
-        } else {
-          offset = idx == 4 ? L.rep[0] - 1 : L.rep[idx - 1];
-          if (offset == 0) return kErrCorrupt;
-          if (idx != 2) L.rep[2] = L.rep[1];
-          L.rep[1] = L.rep[0];
-          L.rep[0] = offset;
-        }
-      }
-      if (lit_len > lit.size - lit_at) return kErrCorrupt;
-      if (lit_len + match_len > oend - o) return kErrDstSmall;
-      if (lit.rle) { for (int k = 0; k < lit_len; ++k) o[k] = lit.rle_value; }
-      else copy_forward(o, lit.ptr + lit_at, lit_len);
-      o += lit_len;
-      lit_at += lit_len;
-      if (offset > static_cast<uint32_t>(o - dst0)) return kErrCorrupt;
-      copy_match(o, offset, match_len);
-      o += match_len;
-    }
-    if (b.pos != 0) return kErrCorrupt;
-  } else if (hs != len) {
-    return kErrCorrupt;
+  for (int i = 0; i < r.nseq; ++i) {
+    int lit_len, match_len;
+    uint32_t offset;
+    const int rc = seq_next(L, r, lit_len, match_len, offset);
+    if (rc < 0) return rc;
+    if (lit_len > lit.size - lit_at) return kErrCorrupt;
+    if (lit_len + match_len > oend - o) return kErrDstSmall;
+    if (lit.rle) { for (int k = 0; k < lit_len; ++k) o[k] = lit.rle_value; }
+    else copy_forward(o, lit.ptr + lit_at, lit_len);
+    o += lit_len;
+    lit_at += lit_len;
+    if (offset > static_cast<uint32_t>(o - dst0)) return kErrCorrupt;
+    copy_match(o, offset, match_len);
+    o += match_len;
   }
   const int rest = lit.size - lit_at;
   if (rest > oend - o) return kErrDstSmall;
@@ -790,6 +837,146 @@ LSR_HD int run_sequences(Lane<Store>& L, const uint8_t* p, int len, const Litera
   else if (o != lit.ptr + lit_at) copy_forward(o, lit.ptr + lit_at, rest);
   o += rest;
   return static_cast<int>(o - op);
+}
+
+// ---- the direct execution ----------------------------------------------------------------------------------------------------
+// For a block with four Huffman streams and at most kMaxDirectSeq sequences (camera stacks: 20-30 per 32 KB block):
+// the sequences are decoded FIRST into the workspace, every literal is then decoded straight to its final place (no
+// literal buffer, no copy of 16 KB through memory per block), and the matches are executed in one loop whose trip count
+// is the lane's own total -- lanes of a wave whose long matches sit at different sequence numbers do not wait for each
+// other sequence by sequence.
+template <class Store>
+struct DirectSink {
+  Store* st;
+  uint8_t* op;
+  int nseq;
+  int k[4], run_end[4], shift[4];    // per stream: literals below run_end[s] belong to run k[s] and go to op[i + shift[s]]
+  LSR_HD int lit_of(int i) const { return static_cast<int>(st->ws_get(kSeqBase + 3 * i)); }
+  LSR_HD int match_of(int i) const { return static_cast<int>(st->ws_get(kSeqBase + 3 * i + 1)); }
+  LSR_HD void seek(int s, int li) {               // the run literal li belongs to
+    int kk = 0, sh = 0, end = nseq > 0 ? lit_of(0) : 0x7FFFFFFF;
+    while (kk < nseq && li >= end) {
+      sh += match_of(kk);
+      ++kk;
+      end = kk < nseq ? end + lit_of(kk) : 0x7FFFFFFF;
+    }
+    k[s] = kk; shift[s] = sh; run_end[s] = end;
+  }
+  LSR_HD void advance(int s) {
+    shift[s] += match_of(k[s]);
+    ++k[s];
+    run_end[s] = k[s] < nseq ? run_end[s] + lit_of(k[s]) : 0x7FFFFFFF;
+  }
+  LSR_HD void put1(int s, int i, uint8_t v) {
+    while (i >= run_end[s]) advance(s);
+    op[i + shift[s]] = v;
+  }
+  LSR_HD void put4(int s, int i, uint32_t v) {
+    if (i + 4 <= run_end[s]) {
+      store32(op + i + shift[s], v);
+    } else {
+      for (int b = 0; b < 4; ++b) put1(s, i + b, static_cast<uint8_t>(v >> (8 * b)));
+    }
+  }
+};
+
+// matches of the sequences in the workspace, executed over literals that are already in place
+template <class Store>
+LSR_HD int execute_matches(Lane<Store>& L, int nseq, uint8_t* dst0, uint8_t* op) {
+  uint8_t* o = op;
+  int k = 0, rem = 0, step = 16;
+  uint32_t off = 16;
+  Bytes16 pat{0, 0};
+  for (;;) {
+    if (rem == 0) {
+      if (k == nseq) break;
+      o += static_cast<int>(L.store.ws_get(kSeqBase + 3 * k));
+      rem = static_cast<int>(L.store.ws_get(kSeqBase + 3 * k + 1));
+      off = L.store.ws_get(kSeqBase + 3 * k + 2);
+      ++k;
+      if (off == 0 || off > static_cast<uint32_t>(o - dst0)) return kErrCorrupt;
+      if (off < 16 && rem > 0) {              // a short period: the pattern in registers
+        const int p = static_cast<int>(off);
+        pat.a = pat.b = 0;
+        for (int i = 0; i < 8; ++i) {
+          pat.a |= static_cast<uint64_t>((o - p)[i % p]) << (8 * i);
+          pat.b |= static_cast<uint64_t>((o - p)[(i + 8) % p]) << (8 * i);
+        }
+        step = (16 / p) * p;
+      }
+      continue;
+    }
+    if (off >= 16) {
+      if (off >= 32 && rem >= 32) {
+        const Bytes16 x = load16(o - off), y = load16(o - off + 16);
+        store16(o, x);
+        store16(o + 16, y);
+        o += 32;
+        rem -= 32;
+      } else if (rem >= 16) {
+        store16(o, load16(o - off));
+        o += 16;
+        rem -= 16;
+      } else {
+        for (int i = 0; i < rem; ++i) o[i] = (o - off)[i];
+        o += rem;
+        rem = 0;
+      }
+    } else if (rem >= 16) {
+      store16(o, pat);
+      o += step;
+      rem -= step;
+    } else {
+      for (int i = 0; i < rem; ++i) o[i] = static_cast<uint8_t>((i < 8 ? pat.a >> (8 * i) : pat.b >> (8 * (i - 8))));
+      o += rem;
+      rem = 0;
+    }
+  }
+  return static_cast<int>(o - op);
+}
+
+// One compressed block.  Returns the bytes produced.
+template <class Store>
+LSR_HD int decode_block_body(Lane<Store>& L, const uint8_t* p, int size, uint8_t* dst0, uint8_t* op, int room) {
+  LitHeader h;
+  const int lu = parse_literals(L, p, size, h);
+  if (lu < 0) return lu;
+  SeqReader r;
+  const int so = seq_open(L, p + lu, size - lu, r);
+  if (so < 0) return so;
+  if (h.type >= 2 && h.four && r.nseq >= 1 && r.nseq <= kMaxDirectSeq) {
+    // sequences first: lengths and offsets into the workspace, with the totals checked before anything is written
+    int lits = 0, total = 0;
+    for (int i = 0; i < r.nseq; ++i) {
+      int lit_len, match_len;
+      uint32_t offset;
+      const int rc = seq_next(L, r, lit_len, match_len, offset);
+      if (rc < 0) return rc;
+      L.store.ws_set(kSeqBase + 3 * i, static_cast<uint32_t>(lit_len));
+      L.store.ws_set(kSeqBase + 3 * i + 1, static_cast<uint32_t>(match_len));
+      L.store.ws_set(kSeqBase + 3 * i + 2, offset);
+      lits += lit_len;
+      total += lit_len + match_len;
+      if (lits > h.size || total > room) return lits > h.size ? kErrCorrupt : kErrDstSmall;
+    }
+    total += h.size - lits;
+    if (total > room) return kErrDstSmall;
+    DirectSink<Store> sink;
+    sink.st = &L.store;
+    sink.op = op;
+    sink.nseq = r.nseq;
+    const int q = (h.size + 3) / 4;
+    for (int s = 0; s < 4; ++s) sink.seek(s, s * q < h.size ? s * q : h.size);
+    const int rc = huf_decode_4(L, h.body, h.body_len, h.size, sink);
+    if (rc < 0) return rc;
+    const int done = execute_matches(L, r.nseq, dst0, op);
+    if (done < 0) return done;
+    return done + (h.size - lits);
+  }
+  Literals lit;
+  const int rc = literals_in_place(L, h, op, room, lit);
+  if (rc < 0) return rc;
+  return run_sequences(L, r, lit, dst0, op, room);
 }
 
 // ---- frame ------------------------------------------------------------------------------------------------------------------------
@@ -842,10 +1029,7 @@ LSR_HD int decode_frame(Lane<Store>& L, const uint8_t* src, int len, uint8_t* ds
       at += 1;
     } else if (type == 2) {
       if (size > kBlockMax || at + size > len) return kErrCorrupt;
-      Literals lit;
-      const int lu = read_literals(L, src + at, size, o, room, lit);
-      if (lu < 0) return lu;
-      const int produced = run_sequences(L, src + at + lu, size - lu, lit, dst, o, room);
+      const int produced = decode_block_body(L, src + at, size, dst, o, room);
       if (produced < 0) return produced;
       o += produced;
       at += size;
