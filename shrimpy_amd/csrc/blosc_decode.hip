@@ -24,6 +24,9 @@
 
 #include "common.hpp"
 #include "host_parallel.hpp"
+#ifdef LSR_DEC_PROBE
+__device__ long long lsr_dec_probe_cycles[1024 * 8];
+#endif
 #include "zstd_lane.hpp"
 
 namespace {
@@ -55,8 +58,13 @@ inline int frames_geometry(Frames& g, int64_t n_frames, int64_t frame_nbytes, in
   return LSR_OK;
 }
 
-// scratch: [shuffled blocks: n_frames * frame_nbytes (16-byte rounded)][block flags: n_blocks bytes][lane workspace]
-inline int64_t flags_offset(const Frames& g) { return (g.n_frames * g.frame_nbytes + 15) / 16 * 16; }
+// The 64 lanes of a wave work through 64 blocks at about the same pace: were the blocks' scratch images `blocksize` apart
+// (a power of two: 32 KB), every store of the wave would fall into addresses that are equal modulo 32 KB -- one memory
+// channel.  kChannelSkew bytes between the images spread them over the channels (measured: see DESIGN.md section 5).
+constexpr int64_t kChannelSkew = 256;
+inline int64_t block_stride(const Frames& g) { return g.blocksize + kChannelSkew; }
+// scratch: [shuffled blocks: n_blocks * block_stride (16-byte rounded)][block flags: n_blocks bytes][lane workspace]
+inline int64_t flags_offset(const Frames& g) { return (g.n_blocks * block_stride(g) + 15) / 16 * 16; }
 inline int64_t work_offset(const Frames& g) { return flags_offset(g) + (g.n_blocks + 15) / 16 * 16; }
 inline int64_t lane_slots(const Frames& g) { return lsr::ceil_div(g.n_blocks, 64) * 64; }
 inline int64_t decode_scratch_bytes(const Frames& g) { return work_offset(g) + lane_slots(g) * kWorkEntries * 4 + 64; }
@@ -161,9 +169,9 @@ struct DecArgs {
   const uint8_t* comp;
   const int64_t* frames;    // (offset, size) per frame; size 0 = absent chunk
   int64_t comp_bytes;
-  int64_t n_blocks, blocks_per_frame, frame_nbytes, blocksize;
+  int64_t n_blocks, blocks_per_frame, frame_nbytes, blocksize, block_stride;
   int typesize;
-  uint8_t* shuffled;        // n_frames * frame_nbytes
+  uint8_t* shuffled;        // n_blocks * block_stride
   uint8_t* flags;           // per block
   uint32_t* work;           // lane workspace
   const Predefined* pre;
@@ -187,9 +195,10 @@ __global__ __launch_bounds__(kThreads) void decode_blocks_kernel(DecArgs a) {
   if (at < 0 || size < 0 || at + size > a.comp_bytes) {
     rc = kErrCorrupt;
   } else {
-    BlockJob job{a.comp + at, size, b % a.blocks_per_frame, a.shuffled + f * a.frame_nbytes + (b % a.blocks_per_frame) * a.blocksize};
+    BlockJob job{a.comp + at, size, b % a.blocks_per_frame, a.shuffled + b * a.block_stride};
     rc = decode_block(L, job, a.frame_nbytes, a.blocksize, a.typesize, &flag);
   }
+  LSR_DEC_STAMP(6);
   a.flags[b] = flag;
   if (rc != kOk) atomicCAS(a.status, 0ull, static_cast<unsigned long long>(status_of(b, rc)));
 }
@@ -198,7 +207,7 @@ struct UnshuffleArgs {
   const uint8_t* shuffled;
   const uint8_t* flags;
   uint8_t* out;
-  int64_t out_bytes, n_blocks, blocks_per_frame, frame_nbytes, blocksize;
+  int64_t out_bytes, n_blocks, blocks_per_frame, frame_nbytes, blocksize, block_stride;
 };
 
 // one workgroup per block; lane: 16 output bytes = 16 / T elements
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void unshuffle_kernel(UnshuffleArgs a) {
   const int64_t base = f * a.frame_nbytes + off;
   if (base >= a.out_bytes) return;                            // the zero padding of an edge chunk
   const int64_t room = a.out_bytes - base < bsize ? a.out_bytes - base : bsize;
-  const uint8_t* src = a.shuffled + base;
+  const uint8_t* src = a.shuffled + b * a.block_stride;
   uint8_t* dst = a.out + base;
   const bool plain = T == 1 || a.flags[b];
   const int64_t n = bsize / T;                                // elements per plane
@@ -310,12 +319,13 @@ extern "C" int lsr_blosc_decode_device(const uint8_t* comp, int64_t comp_bytes, 
   if (pre == nullptr) return st;
   hipStream_t s = lsr::as_stream(stream);
   uint8_t* const base = static_cast<uint8_t*>(scratch);
-  DecArgs a{comp, frames, comp_bytes, g.n_blocks, g.blocks_per_frame, g.frame_nbytes, g.blocksize, g.typesize, base,
+  DecArgs a{comp, frames, comp_bytes, g.n_blocks, g.blocks_per_frame, g.frame_nbytes, g.blocksize, block_stride(g), g.typesize, base,
             base + flags_offset(g), reinterpret_cast<uint32_t*>(base + work_offset(g)), pre, status};
   hipError_t e = hipMemsetAsync(status, 0, sizeof(unsigned long long), s);
   if (e != hipSuccess) return lsr::fail(static_cast<int>(e), "lsr_blosc_decode_device: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(decode_blocks_kernel, dim3(static_cast<unsigned>(lsr::ceil_div(g.n_blocks, kThreads))), dim3(kThreads), 0, s, a);
-  UnshuffleArgs u{base, base + flags_offset(g), out, out_bytes, g.n_blocks, g.blocks_per_frame, g.frame_nbytes, g.blocksize};
+  UnshuffleArgs u{base, base + flags_offset(g), out, out_bytes, g.n_blocks, g.blocks_per_frame, g.frame_nbytes, g.blocksize,
+                  block_stride(g)};
   const dim3 grid(static_cast<unsigned>(g.n_blocks)), block(kThreads);
   if (g.typesize == 4) hipLaunchKernelGGL(unshuffle_kernel<4>, grid, block, 0, s, u);
   else if (g.typesize == 2) hipLaunchKernelGGL(unshuffle_kernel<2>, grid, block, 0, s, u);
@@ -382,6 +392,12 @@ extern "C" int lsr_blosc_decode_device_cpu(const uint8_t* comp, int64_t comp_byt
   *status = first.load();
   return LSR_OK;
 }
+
+#ifdef LSR_DEC_PROBE
+extern "C" int lsr_debug_dec_probe(long long* out, int n) {
+  return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(lsr_dec_probe_cycles), sizeof(long long) * static_cast<size_t>(n)));
+}
+#endif
 
 // One zstd frame through the lane decoder on the host (tests and fuzzing of csrc/zstd_lane.hpp): *out_n = decoded bytes.
 // Returns LSR_OK, or LSR_E_ARG with the decoder's code in the message.

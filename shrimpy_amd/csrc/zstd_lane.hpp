@@ -21,6 +21,19 @@
 
 #include "zstd_huf.hpp"   // LSR_HD, highbit
 
+// Measurement build (-DLSR_DEC_PROBE, device code only): cycle stamps of the phases of a block, taken by lane 0 of the
+// first waves (csrc/blosc_decode.hip defines the buffer)
+#if defined(LSR_DEC_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ long long lsr_dec_probe_cycles[1024 * 8];
+#define LSR_DEC_STAMP(k)                                                                                          \
+  do {                                                                                                            \
+    const long long w_ = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;                    \
+    if ((threadIdx.x & 63) == 0 && w_ < 1024) lsr_dec_probe_cycles[w_ * 8 + (k)] = clock64();                     \
+  } while (0)
+#else
+#define LSR_DEC_STAMP(k) do { } while (0)
+#endif
+
 namespace lsr {
 namespace zd {
 
@@ -489,9 +502,13 @@ LSR_HD void store32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
 // Where decoded literals go.  PlainSink: literal i at out[i] (the literal buffer).  The direct sink further down writes
 // every literal at its final place in the block.
+struct Bytes16 { uint64_t a, b; };
+LSR_HD Bytes16 load16(const uint8_t* p) { Bytes16 v; __builtin_memcpy(&v, p, 16); return v; }
+LSR_HD void store16(uint8_t* p, const Bytes16& v) { __builtin_memcpy(p, &v, 16); }
+
 struct PlainSink {
   uint8_t* out;
-  LSR_HD void put4(int, int i, uint32_t v) { store32(out + i, v); }
+  LSR_HD void put16(int, int i, const Bytes16& v) { store16(out + i, v); }
   LSR_HD void put1(int, int i, uint8_t v) { out[i] = v; }
 };
 
@@ -516,15 +533,27 @@ LSR_HD int huf_decode_4(Lane<Store>& L, const uint8_t* p, int len, int n, Sink& 
   {
     FastStream f0, f1, f2, f3;
     if (fast_init(f0, b0) && fast_init(f1, b1) && fast_init(f2, b2) && fast_init(f3, b3)) {
-      // a batch needs four more symbols in every stream (the fourth is the shortest) and 44 unread bits in each
-      while (i + 4 <= n3 && f0.pos >= 64 && f1.pos >= 64 && f2.pos >= 64 && f3.pos >= 64 &&
-             fast_step(f0) && fast_step(f1) && fast_step(f2) && fast_step(f3)) {
-        const uint32_t a = fast_four(L, f0), b = fast_four(L, f1), c = fast_four(L, f2), d = fast_four(L, f3);
-        sink.put4(0, i, a);
-        sink.put4(1, q + i, b);
-        sink.put4(2, 2 * q + i, c);
-        sink.put4(3, 3 * q + i, d);
-        i += 4;
+      // A group = four batches of four literals per stream: 16 literals leave as ONE 16-byte store per stream.  Stores
+      // and loads share the wave's memory counter in issue order, so every wait for a window load also waits for the
+      // stores in front of it -- ~5 us each for 64 lanes on 64 cache lines; one store per 16 literals instead of per 4
+      // is what that costs less (measured: DESIGN.md section 5).  A group needs 16 more literals in every stream,
+      // 176 unread bits, and room for three window steps.
+      while (i + 16 <= n3 && f0.pos >= 200 && f1.pos >= 200 && f2.pos >= 200 && f3.pos >= 200 &&
+             f0.base >= 320 && f1.base >= 320 && f2.base >= 320 && f3.base >= 320) {
+        uint32_t g0[4], g1[4], g2[4], g3[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          fast_step(f0); fast_step(f1); fast_step(f2); fast_step(f3);
+          g0[k] = fast_four(L, f0);
+          g1[k] = fast_four(L, f1);
+          g2[k] = fast_four(L, f2);
+          g3[k] = fast_four(L, f3);
+        }
+        sink.put16(0, i, Bytes16{g0[0] | static_cast<uint64_t>(g0[1]) << 32, g0[2] | static_cast<uint64_t>(g0[3]) << 32});
+        sink.put16(1, q + i, Bytes16{g1[0] | static_cast<uint64_t>(g1[1]) << 32, g1[2] | static_cast<uint64_t>(g1[3]) << 32});
+        sink.put16(2, 2 * q + i, Bytes16{g2[0] | static_cast<uint64_t>(g2[1]) << 32, g2[2] | static_cast<uint64_t>(g2[3]) << 32});
+        sink.put16(3, 3 * q + i, Bytes16{g3[0] | static_cast<uint64_t>(g3[1]) << 32, g3[2] | static_cast<uint64_t>(g3[3]) << 32});
+        i += 16;
       }
       b0.pos = f0.pos; b1.pos = f1.pos; b2.pos = f2.pos; b3.pos = f3.pos;
       back_refill(b0); back_refill(b1); back_refill(b2); back_refill(b3);
@@ -670,10 +699,6 @@ LSR_HD int read_seq_table(Lane<Store>& L, int which, int mode, const uint8_t* p,
   L.have_tab[which] = true;
   return used;
 }
-
-struct Bytes16 { uint64_t a, b; };
-LSR_HD Bytes16 load16(const uint8_t* p) { Bytes16 v; __builtin_memcpy(&v, p, 16); return v; }
-LSR_HD void store16(uint8_t* p, const Bytes16& v) { __builtin_memcpy(p, &v, 16); }
 
 // copy n bytes within the destination from `offset` back (may overlap: the pattern repeats)
 LSR_HD void copy_match(uint8_t* o, uint32_t offset, int n) {
@@ -871,11 +896,12 @@ struct DirectSink {
     while (i >= run_end[s]) advance(s);
     op[i + shift[s]] = v;
   }
-  LSR_HD void put4(int s, int i, uint32_t v) {
-    if (i + 4 <= run_end[s]) {
-      store32(op + i + shift[s], v);
+  LSR_HD void put16(int s, int i, const Bytes16& v) {
+    if (i + 16 <= run_end[s]) {
+      store16(op + i + shift[s], v);
     } else {
-      for (int b = 0; b < 4; ++b) put1(s, i + b, static_cast<uint8_t>(v >> (8 * b)));
+      for (int b = 0; b < 8; ++b) put1(s, i + b, static_cast<uint8_t>(v.a >> (8 * b)));
+      for (int b = 0; b < 8; ++b) put1(s, i + 8 + b, static_cast<uint8_t>(v.b >> (8 * b)));
     }
   }
 };
@@ -884,53 +910,13 @@ struct DirectSink {
 template <class Store>
 LSR_HD int execute_matches(Lane<Store>& L, int nseq, uint8_t* dst0, uint8_t* op) {
   uint8_t* o = op;
-  int k = 0, rem = 0, step = 16;
-  uint32_t off = 16;
-  Bytes16 pat{0, 0};
-  for (;;) {
-    if (rem == 0) {
-      if (k == nseq) break;
-      o += static_cast<int>(L.store.ws_get(kSeqBase + 3 * k));
-      rem = static_cast<int>(L.store.ws_get(kSeqBase + 3 * k + 1));
-      off = L.store.ws_get(kSeqBase + 3 * k + 2);
-      ++k;
-      if (off == 0 || off > static_cast<uint32_t>(o - dst0)) return kErrCorrupt;
-      if (off < 16 && rem > 0) {              // a short period: the pattern in registers
-        const int p = static_cast<int>(off);
-        pat.a = pat.b = 0;
-        for (int i = 0; i < 8; ++i) {
-          pat.a |= static_cast<uint64_t>((o - p)[i % p]) << (8 * i);
-          pat.b |= static_cast<uint64_t>((o - p)[(i + 8) % p]) << (8 * i);
-        }
-        step = (16 / p) * p;
-      }
-      continue;
-    }
-    if (off >= 16) {
-      if (off >= 32 && rem >= 32) {
-        const Bytes16 x = load16(o - off), y = load16(o - off + 16);
-        store16(o, x);
-        store16(o + 16, y);
-        o += 32;
-        rem -= 32;
-      } else if (rem >= 16) {
-        store16(o, load16(o - off));
-        o += 16;
-        rem -= 16;
-      } else {
-        for (int i = 0; i < rem; ++i) o[i] = (o - off)[i];
-        o += rem;
-        rem = 0;
-      }
-    } else if (rem >= 16) {
-      store16(o, pat);
-      o += step;
-      rem -= step;
-    } else {
-      for (int i = 0; i < rem; ++i) o[i] = static_cast<uint8_t>((i < 8 ? pat.a >> (8 * i) : pat.b >> (8 * (i - 8))));
-      o += rem;
-      rem = 0;
-    }
+  for (int k = 0; k < nseq; ++k) {
+    o += static_cast<int>(L.store.ws_get(kSeqBase + 3 * k));
+    const int n = static_cast<int>(L.store.ws_get(kSeqBase + 3 * k + 1));
+    const uint32_t off = L.store.ws_get(kSeqBase + 3 * k + 2);
+    if (off == 0 || off > static_cast<uint32_t>(o - dst0)) return kErrCorrupt;
+    copy_match(o, off, n);
+    o += n;
   }
   return static_cast<int>(o - op);
 }
@@ -938,12 +924,15 @@ LSR_HD int execute_matches(Lane<Store>& L, int nseq, uint8_t* dst0, uint8_t* op)
 // One compressed block.  Returns the bytes produced.
 template <class Store>
 LSR_HD int decode_block_body(Lane<Store>& L, const uint8_t* p, int size, uint8_t* dst0, uint8_t* op, int room) {
+  LSR_DEC_STAMP(0);
   LitHeader h;
   const int lu = parse_literals(L, p, size, h);
   if (lu < 0) return lu;
+  LSR_DEC_STAMP(1);
   SeqReader r;
   const int so = seq_open(L, p + lu, size - lu, r);
   if (so < 0) return so;
+  LSR_DEC_STAMP(2);
   if (h.type >= 2 && h.four && r.nseq >= 1 && r.nseq <= kMaxDirectSeq) {
     // sequences first: lengths and offsets into the workspace, with the totals checked before anything is written
     int lits = 0, total = 0;
@@ -961,6 +950,7 @@ LSR_HD int decode_block_body(Lane<Store>& L, const uint8_t* p, int size, uint8_t
     }
     total += h.size - lits;
     if (total > room) return kErrDstSmall;
+    LSR_DEC_STAMP(3);
     DirectSink<Store> sink;
     sink.st = &L.store;
     sink.op = op;
@@ -969,8 +959,10 @@ LSR_HD int decode_block_body(Lane<Store>& L, const uint8_t* p, int size, uint8_t
     for (int s = 0; s < 4; ++s) sink.seek(s, s * q < h.size ? s * q : h.size);
     const int rc = huf_decode_4(L, h.body, h.body_len, h.size, sink);
     if (rc < 0) return rc;
+    LSR_DEC_STAMP(4);
     const int done = execute_matches(L, r.nseq, dst0, op);
     if (done < 0) return done;
+    LSR_DEC_STAMP(5);
     return done + (h.size - lits);
   }
   Literals lit;
