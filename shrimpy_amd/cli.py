@@ -536,9 +536,13 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
 
         attempts = [(frame_bytes, layout)] + ([(None, layout)] if frame_bytes and layout else []) \
             + ([(frame_bytes, None)] if frame_bytes and layout else []) + ([(None, None)] if frame_bytes or layout else [])
+        # slots each way: with the chunks decoded on the device a unit passes through read -> upload -> decode before the
+        # kernels can start, and three slots let the reader work two units ahead of them (LSR_STAGE_DEPTH overrides)
+        depth = int(os.environ.get("LSR_STAGE_DEPTH", "0") or 0)
         for fb, lay in attempts:
             try:
-                stager = VolumeStager((nz, ny, nx), raw_dtype, (oz, oy, ox), device, encode_frame_bytes=fb, decode_layout=lay)
+                stager = VolumeStager((nz, ny, nx), raw_dtype, (oz, oy, ox), device, encode_frame_bytes=fb, decode_layout=lay,
+                                      depth=depth if depth >= 2 else (3 if lay is not None else 2))
                 frames_in[0] = lay is not None
                 break
             except LsrUnsupported as exc:                # a chunk / block size outside the device codecs' range

@@ -419,12 +419,18 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None, f
     loader, storer = ThreadPoolExecutor(1, "lsr-load"), ThreadPoolExecutor(1, "lsr-store")
     collector = ThreadPoolExecutor(1, "lsr-collect")
     stores: list = []       # one future (or None: the unit was skipped) per unit, in unit order
-    nxt = None
+    # the loader works up to depth - 1 units ahead of the kernels (slot i % depth is free again once unit i - depth has
+    # been uploaded and consumed: stage() waits for exactly that)
+    ahead: list = []
+    submitted = 0
     try:
-        nxt = loader.submit(stage, 0)
+        while submitted < min(depth - 1, len(mine)):
+            ahead.append(loader.submit(stage, submitted))
+            submitted += 1
         for i in range(len(mine)):
             t = clock()
             slot = None
+            nxt = ahead.pop(0)
             try:
                 slot = nxt.result()
             except Exception as exc:  # noqa: BLE001
@@ -432,7 +438,9 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None, f
                     raise
                 note(i, "load", exc)
             t = spent("wait_load", t)
-            nxt = loader.submit(stage, i + 1) if i + 1 < len(mine) else None
+            if submitted < len(mine):
+                ahead.append(loader.submit(stage, submitted))
+                submitted += 1
             result = None
             if slot is not None:
                 acquired = False
@@ -471,11 +479,12 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None, f
         # whatever happened: no thread is left filling a slot, no copy is left in flight on the
         # up / down streams, before the caller sees the exception (or the result)
         # (a queued load is dropped; a queued write belongs to a finished unit and is completed)
-        if nxt is not None and not nxt.cancel():
-            try:
-                nxt.result()
-            except Exception:  # noqa: BLE001 -- the first failure is the one that propagates
-                pass
+        for fut in ahead:
+            if not fut.cancel():
+                try:
+                    fut.result()
+                except Exception:  # noqa: BLE001 -- the first failure is the one that propagates
+                    pass
         for fut in stores:
             try:
                 if fut is not None:
