@@ -144,6 +144,10 @@ class VolumeStager:
         self._dev_in = [torch.empty(self.raw_shape, dtype=dt, device=self.device) for _ in range(depth)]
         self._up = torch.cuda.Stream(self.device)
         self._down = torch.cuda.Stream(self.device)
+        # the encoder's launches get a stream of their own: on the download stream the frames of unit i + 1 (queued as soon
+        # as its kernels are launched) would sit in front of the download of unit i (queued only once its frame table is
+        # on the host) and hold it back by a whole unit of kernels
+        self._enc = torch.cuda.Stream(self.device) if self._encoders is not None else None
         self._uploaded = [None] * depth      # recorded on `up` after the H2D copy of the slot
         self._consumed = [None] * depth      # recorded on the compute stream when the raw slot is dead
         self._downloaded = [None] * depth    # recorded on `down` after the D2H copy of the slot
@@ -265,13 +269,13 @@ class VolumeStager:
         if self._encoders is not None:
             # frames are written on the download stream (beside the next unit's kernels); only the (offset, size)
             # table comes down now -- collect() then copies exactly the compressed bytes
-            with torch.cuda.stream(self._down):
-                self._down.wait_event(done)
+            with torch.cuda.stream(self._enc):
+                self._enc.wait_event(done)
                 _, table = self._encoders[slot].encode(result.contiguous())
-                result.record_stream(self._down)
+                result.record_stream(self._enc)
                 self._table_host[slot].copy_(table, non_blocking=True)
                 ev = torch.cuda.Event()
-                ev.record(self._down)
+                ev.record(self._enc)
             self._table_ready[slot] = ev
             self._downloaded[slot] = None
             return
@@ -308,3 +312,5 @@ class VolumeStager:
     def drain(self) -> None:
         self._up.synchronize()
         self._down.synchronize()
+        if self._enc is not None:
+            self._enc.synchronize()
