@@ -42,31 +42,40 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 CONTEXT = {"help_option_names": ["-h", "--help"]}
 
 
-class _EatAll(click.Option):
-    """An option that takes every following argument up to the next option -- what biahub's ``-i`` does
-    ([RECALLED] ``OptionEatAll``), so that a shell glob works: ``-i plate.zarr/*/*/*`` expands to one path per
-    position directory.  The value is a tuple of strings."""
+class _EatAllCommand(click.Command):
+    """A command whose ``eat_all`` options take every following argument up to the next option -- what biahub's ``-i``
+    does ([RECALLED] ``OptionEatAll``), so that a shell glob works: ``-i plate.zarr/*/*/*`` expands to one path per
+    position directory.  Done with click's public surface only (the earlier version patched the parser's
+    private tables): ``parse_args`` rewrites ``-i a b c`` into ``-i a -i b -i c`` before click sees it, and the options
+    are ordinary ``multiple=True`` ones.  An argument that starts with ``-`` ends the list (a directory named ``-x`` has
+    to be written ``./-x``)."""
 
-    def add_to_parser(self, parser, ctx):
-        result = super().add_to_parser(parser, ctx)
-        ours = None
-        for name in self.opts:
-            ours = parser._long_opt.get(name) or parser._short_opt.get(name)
-            if ours is not None:
+    eat_all: tuple = ()
+
+    def parse_args(self, ctx, args):
+        out, i = [], 0
+        args = list(args)
+        while i < len(args):
+            a = args[i]
+            out.append(a)
+            i += 1
+            if a == "--":                       # everything behind it is positional
+                out.extend(args[i:])
                 break
-        if ours is None:
-            return result
-        previous = ours.process
-        prefixes = tuple(parser._opt_prefixes)
+            if a in self.eat_all:
+                first = True
+                while i < len(args) and not (args[i].startswith("-") and len(args[i]) > 1):
+                    if not first:
+                        out.append(a)
+                    out.append(args[i])
+                    first = False
+                    i += 1
+        return super().parse_args(ctx, out)
 
-        def process(value, state):
-            values = [value]
-            while state.rargs and not (state.rargs[0].startswith(prefixes) and len(state.rargs[0]) > 1):
-                values.append(state.rargs.pop(0))
-            previous(tuple(values), state)
 
-        ours.process = process
-        return result
+def _eat_all_command(*names):
+    """``cls=`` for ``@cli.command``: an :class:`_EatAllCommand` whose options ``names`` eat every following argument."""
+    return type("_EatAllCommand_" + "_".join(n.strip("-").replace("-", "_") for n in names), (_EatAllCommand,), {"eat_all": tuple(names)})
 
 
 def resolve_inputs(paths) -> tuple[Path, tuple[str, ...]]:
@@ -117,8 +126,7 @@ def resolve_inputs(paths) -> tuple[Path, tuple[str, ...]]:
 
 
 def _common(fn, input_required: bool = True):
-    fn = click.option("-i", "--input-position-dirpaths", "input_path", required=input_required, cls=_EatAll,
-                      default=None,
+    fn = click.option("-i", "--input-position-dirpaths", "input_path", required=input_required, multiple=True,
                       type=click.UNPROCESSED,
                       help="Input OME-Zarr store (HCS plate or single FOV), or the position directories of one plate "
                            "(a glob such as plate.zarr/*/*/*).")(fn)
@@ -431,9 +439,12 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
     if settings.registration is not None and not all(warp):
         rec_unwarped = factory((nz, ny, nx), settings.model_copy(update={"registration": None}), device)
         if tuple(rec_unwarped.output_shape) != tuple(rec.output_shape):
+            hint = ("keep_overhang grows the registered channels to the union box, which an unwarped channel cannot share: "
+                    "warp every channel (leave source_channel_names empty) or set keep_overhang: false"
+                    if settings.registration.keep_overhang else "drop output_shape_zyx or warp every channel")
             raise click.ClickException(
                 f"registered channels come out as {tuple(rec.output_shape)} but the unwarped ones as "
-                f"{tuple(rec_unwarped.output_shape)}: drop output_shape_zyx or warp every channel")
+                f"{tuple(rec_unwarped.output_shape)}: {hint}")
     oz, oy, ox = rec.output_shape
     out_scale = list(position_scale(first))
     if settings.deskew is not None:
@@ -445,6 +456,9 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
         # scale metadata as scripts/measure_psf.py:273-276
         out_scale[2:] = [float(v) for v in orient_voxel(voxel, d.orientation)]
 
+    # where output index 0 sits in the target's physical frame: non-zero only when keep_overhang grew the grid below zero
+    origin = tuple(getattr(rec, "register_origin", (0, 0, 0)))
+    out_translation = [0.0, 0.0] + [float(o) * float(sc) for o, sc in zip(origin, out_scale[2:])] if any(origin) else None
     ledger = _DoneLedger(output_path, _fingerprint(input_path, settings, shape5, raw_dtype, keys))
     fail_ledger = _FailLedger(output_path)
     out_shape5 = (nt, nc, oz, oy, ox)
@@ -480,7 +494,7 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
                 row, col, fov = key.split("/")
                 pos = dst.create_position(row, col, fov)
                 extra = {} if use_iohub_out or compression in (None, "none") else {"compress": compression}
-                create_level(pos, out_shape5, "float32", out_scale, **extra)
+                create_level(pos, out_shape5, "float32", out_scale, translation=out_translation, **extra)
             dst.close()
             ledger.begin()
         except click.ClickException as exc:
@@ -590,7 +604,7 @@ def cli(verbose: bool):
                         format="%(asctime)s %(levelname)s %(name)s: %(message)s")
 
 
-@cli.command()
+@cli.command(cls=_eat_all_command("-i", "--input-position-dirpaths"))
 @_common
 def deskew(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression, on_error):
     """Deskew oblique-plane stacks (config: DeskewSettings YAML)."""
@@ -616,16 +630,17 @@ def _target_shape_zyx(target_path) -> tuple[int, int, int]:
     raise click.ClickException(f"-t: no position found in {root}")
 
 
-@cli.command()
-@click.option("-s", "--source-position-dirpaths", "source_path", cls=_EatAll, type=click.UNPROCESSED, default=None,
+@cli.command(cls=_eat_all_command("-i", "--input-position-dirpaths", "-s", "--source-position-dirpaths", "-t", "--target-position-dirpaths"))
+@click.option("-s", "--source-position-dirpaths", "source_path", multiple=True, type=click.UNPROCESSED,
               help="The MOVING store / position directories ([RECALLED] biahub's spelling; the same as -i).")
-@click.option("-t", "--target-position-dirpaths", "target_path", cls=_EatAll, type=click.UNPROCESSED, default=None,
+@click.option("-t", "--target-position-dirpaths", "target_path", multiple=True, type=click.UNPROCESSED,
               help="The TARGET store / position directories: its (Z, Y, X) is the output shape when the config gives "
                    "no output_shape_zyx.")
 @functools.partial(_common, input_required=False)
 def register(input_path, source_path, target_path, config, output_path, positions, zarr_version, resume, io_backend,
              compression, on_error):
     """Apply an affine registration (config: RegisterSettings YAML with affine_transform_zyx)."""
+    input_path, source_path, target_path = (input_path or None), (source_path or None), (target_path or None)
     if (input_path is None) == (source_path is None):
         raise click.ClickException("name the moving store once: -i or -s")
     input_path, positions = _inputs(input_path if input_path is not None else source_path, positions)
@@ -637,7 +652,7 @@ def register(input_path, source_path, target_path, config, output_path, position
                       io_backend=io_backend, compression=compression, on_error=on_error))
 
 
-@cli.command()
+@cli.command(cls=_eat_all_command("-i", "--input-position-dirpaths"))
 @click.option("--psf-dirpath", "psf_dirpath", default=None, type=click.Path(exists=True, path_type=Path),
               help="A measured PSF: an OME-Zarr bead volume (as scripts/measure_psf.py:273-287 writes them) or a .npy "
                    "ZYX array; overrides psf_path of the config ([RECALLED] biahub's -p, which is the position filter here).")
@@ -654,7 +669,7 @@ def deconvolve(input_path, psf_dirpath, config, output_path, positions, zarr_ver
                       io_backend=io_backend, compression=compression, on_error=on_error))
 
 
-@cli.command()
+@cli.command(cls=_eat_all_command("-i", "--input-position-dirpaths"))
 @_common
 def reconstruct(input_path, config, output_path, positions, zarr_version, resume, io_backend, compression, on_error):
     """deskew -> register -> deconvolve in one pass (config: ReconstructSettings YAML)."""

@@ -242,6 +242,9 @@ def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=Non
     else:    # the dense loop is one native call per chunk (the twin of lsr_rl_dense_f32: x updated in place)
         k, kf = _taps(w), _taps(w[::-1, ::-1, ::-1])
         table = np.ascontiguousarray(_prefix_table(w).ravel(), dtype=np.float64)
+        # ``tol`` as the device plans read it (deconvolve.RichardsonLucyPlan._run_to_tolerance): the scalars of iteration i
+        # are looked at after iteration i + 1 has run, so the estimate returned is the one iteration PAST the first that
+        # met tol -- the same iterate, and the same RLStats.iterations, whichever device the tensor lives on
         done, stopped = 0, False
         step = iterations if tol is None else 1
         while done < iterations:
@@ -249,9 +252,11 @@ def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=Non
                       kf.ctypes.data, w.shape[0], w.shape[1], w.shape[2], table.ctypes.data, step, e,
                       None if stats is None else stats[done:].ctypes.data, None)
             done += step
-            if tol is not None and met(done - 1):
+            if tol is not None and done >= 2 and met(done - 2):
                 stopped = True
                 break
+        if tol is not None and not stopped:
+            stopped = bool(met(done - 1))
         return (x, RLStats.from_array(stats, done, stopped)) if return_stats else x
     done, stopped = 0, False
     for it in range(iterations):
@@ -259,7 +264,9 @@ def richardson_lucy(y, psf=None, iterations: int = 20, eps: float = 1e-6, x0=Non
         corr(ratio, nxt, x, k, _lib.EPI_UPDATE, None if stats is None else stats[it])     # x <- x * H^T ratio / H^T 1
         x, nxt = nxt, x
         done = it + 1
-        if tol is not None and met(it):
+        if tol is not None and it >= 1 and met(it - 1):     # (one iteration past the first that met tol: see above)
             stopped = True
             break
+    if tol is not None and not stopped:
+        stopped = bool(met(done - 1))
     return (x, RLStats.from_array(stats, done, stopped)) if return_stats else x

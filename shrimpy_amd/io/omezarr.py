@@ -293,7 +293,7 @@ class _BlockCodec:
 _MISSING = 0xFFFFFFFFFFFFFFFF   # (offset, nbytes) of an absent inner chunk in a shard index
 
 _shard_locks_guard = threading.Lock()
-_shard_locks: dict[str, threading.Lock] = {}
+_shard_locks: dict[str, list] = {}     # directory -> [lock, threads that hold or wait for it]
 
 
 @contextlib.contextmanager
@@ -308,39 +308,54 @@ def _shard_lock(path: Path):
     still holds, with one warning -- a multi-node run must give every shard that spans several (t, c) volumes to ONE rank
     (``pipeline.run_sharded`` deals whole volumes; keep ``shards[:2] == (1, 1)``, what the acquisition writes, or shard
     the units by shard)."""
-    import fcntl
-
     folder = path.parent
     key = str(folder)
+    # An entry is counted while a thread holds OR waits for its lock and is dropped by the last one to leave: an entry
+    # can never be purged between a thread fetching its lock and acquiring it (which would let a second Lock for the same
+    # directory into the table and two threads into one shard's read-modify-write), and a long plate run, which visits
+    # every array directory once, does not keep them all.
     with _shard_locks_guard:
-        if len(_shard_locks) > 4096:       # a long plate run visits every array directory once: do not keep them all
-            for k in [k for k, v in _shard_locks.items() if not v.locked()]:
-                del _shard_locks[k]
-        lock = _shard_locks.setdefault(key, threading.Lock())
-    with lock:
-        fd = None
-        try:
-            fd = os.open(str(folder), os.O_RDONLY)
-            fcntl.flock(fd, fcntl.LOCK_EX)
-        except OSError as exc:
-            if fd is not None:
-                os.close(fd)
-                fd = None
-            global _flock_warned
-            if not _flock_warned:
-                _flock_warned = True
-                import warnings
+        entry = _shard_locks.setdefault(key, [threading.Lock(), 0])
+        entry[1] += 1
+    try:
+        with entry[0]:
+            with _flocked(folder):
+                yield
+    finally:
+        with _shard_locks_guard:
+            entry[1] -= 1
+            if entry[1] == 0 and _shard_locks.get(key) is entry:
+                del _shard_locks[key]
 
-                warnings.warn(f"flock on {folder} failed ({exc}); shards that span several volumes are protected against "
-                              "this process's threads only", RuntimeWarning, stacklevel=3)
-        try:
-            yield
-        finally:
-            if fd is not None:
-                try:
-                    fcntl.flock(fd, fcntl.LOCK_UN)
-                finally:
-                    os.close(fd)
+
+@contextlib.contextmanager
+def _flocked(folder: Path):
+    """``flock`` on the directory (other processes on this host); a refusal is reported once and tolerated."""
+    import fcntl
+
+    fd = None
+    try:
+        fd = os.open(str(folder), os.O_RDONLY)
+        fcntl.flock(fd, fcntl.LOCK_EX)
+    except OSError as exc:
+        if fd is not None:
+            os.close(fd)
+            fd = None
+        global _flock_warned
+        if not _flock_warned:
+            _flock_warned = True
+            import warnings
+
+            warnings.warn(f"flock on {folder} failed ({exc}); shards that span several volumes are protected against "
+                          "this process's threads only", RuntimeWarning, stacklevel=4)
+    try:
+        yield
+    finally:
+        if fd is not None:
+            try:
+                fcntl.flock(fd, fcntl.LOCK_UN)
+            finally:
+                os.close(fd)
 
 
 _flock_warned = False
@@ -958,7 +973,7 @@ class Position(_Node):
         return self["0"]
 
     def create_zeros(self, name: str, shape, dtype="float32", chunks=None, scale=None,
-                     compress: str | None = None, shards=None, blocksize: int = 0) -> ZarrArray:
+                     compress: str | None = None, shards=None, blocksize: int = 0, translation=None) -> ZarrArray:
         """Create level ``name`` (TCZYX).  Default chunks follow the reference:
         ``(1, 1, min(32, nz), ny, nx)`` (``shrimpy/dynatrack/tracking.py:1362``).
         ``compress="blosc-zstd"`` with ``shards="volume"`` (one shard file per (t, c) volume) or an
@@ -975,11 +990,14 @@ class Position(_Node):
             shards = (1, 1) + tuple(-(-n // c) * c for n, c in zip(shape[2:], chunks[2:]))
         arr = ZarrArray.create(self.path / name, self.version, shape, chunks, dtype, compress, shards, blocksize)
         scale = [float(s) for s in (scale if scale is not None else (1, 1, 1, 1, 1))]
+        transforms = [{"type": "scale", "scale": scale}]
+        if translation is not None and any(float(v) != 0.0 for v in translation):
+            # NGFF: scale first, then translation, in physical units (where index 0 of this level sits)
+            transforms.append({"type": "translation", "translation": [float(v) for v in translation]})
         attrs = {
             "multiscales": [{
                 "version": self.version, "axes": AXES, "name": "0",
-                "datasets": [{"path": name,
-                              "coordinateTransformations": [{"type": "scale", "scale": scale}]}],
+                "datasets": [{"path": name, "coordinateTransformations": transforms}],
             }],
             "omero": {"channels": [{"label": n, "active": True, "color": "FFFFFF",
                                     "window": {"start": 0, "end": 65535, "min": 0, "max": 65535}}
@@ -1181,7 +1199,7 @@ def position_scale(position) -> tuple[float, ...]:
     return (1.0,) * 5
 
 
-def create_level(position, shape, dtype, scale, chunks=None, name: str = "0", **kw):
+def create_level(position, shape, dtype, scale, chunks=None, name: str = "0", translation=None, **kw):
     """``position.create_zeros`` with the scale metadata, for this module's ``Position`` (``scale=``)
     and for iohub's (``transform=[TransformationMeta(type="scale", ...)]``,
     ``scripts/measure_psf.py:273-287``)."""
@@ -1196,8 +1214,10 @@ def create_level(position, shape, dtype, scale, chunks=None, name: str = "0", **
         zc = max(1, min(32, shape[2], (64 << 20) // max(plane_bytes, 1)))
         chunks = (1, 1, zc, shape[3], shape[4])
     if isinstance(position, Position):
-        return position.create_zeros(name, shape=shape, dtype=dtype, chunks=chunks, scale=scale, **kw)
+        return position.create_zeros(name, shape=shape, dtype=dtype, chunks=chunks, scale=scale, translation=translation, **kw)
     from iohub.ngff.models import TransformationMeta
 
     transform = [TransformationMeta(type="scale", scale=[float(v) for v in scale])]
+    if translation is not None and any(float(v) != 0.0 for v in translation):
+        transform.append(TransformationMeta(type="translation", translation=[float(v) for v in translation]))
     return position.create_zeros(name, shape=shape, dtype=dtype, chunks=chunks, transform=transform)

@@ -76,3 +76,25 @@ def test_the_compilers_output_for_the_instances_that_were_broken_is_clean(tmp_pa
     # none of these kernels may leave the register file: a hand-counted wait does not cover the compiler's scratch traffic
     text = (tmp_path / f"{tu}_pz{pz}.s").read_text()
     assert "scratch_store" not in text and "s_swappc_b64" not in text
+
+
+@pytest.mark.skipif(shutil.which(ah.HIPCC) is None, reason="needs hipcc")
+def test_every_stencil_translation_unit_is_free_of_hazards(tmp_path):
+    """the three instances above guard what broke once; a toolchain bump or a new specialisation can bring the
+    hazard back anywhere.  The whole sweep -- every SEP / DENSE / FUSED / YSEP translation unit the Makefile builds, loop
+    bodies included (the analyser carries the in-flight loads around back edges) -- runs here, eight compilations side by
+    side (~1 minute), and as ``make -C shrimpy_amd/csrc hazards``."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    todo = [(tu, pz) for tu in sorted(ah.UNITS) for pz in ah.UNITS[tu][1]]
+    assert len(todo) == 24
+    with ThreadPoolExecutor(8) as pool:
+        results = list(pool.map(lambda a: ah.check_unit(*a, tmp_path), todo))
+    bad = {f"{tu} pz={pz}": hazards[:3] for tu, pz, _, hazards in results if hazards}
+    assert not bad, bad
+    assert sum(nk for _, _, nk, _ in results) >= 24 * 8
+    # the Makefile's tap counts and the tool's are the same lists
+    mk = (ROOT / "shrimpy_amd" / "csrc" / "Makefile").read_text()
+    for var, unit in (("SEP_PZ", "correlate_sep"), ("DENSE_PZ", "correlate_dense"), ("FUSED_PZ", "rl_fused_sep"), ("YSEP_PZ", "rl_fused_ysep")):
+        line = next(ln for ln in mk.splitlines() if ln.startswith(var + " :="))
+        assert tuple(int(v) for v in line.split(":=")[1].split()) == ah.UNITS[unit][1], var

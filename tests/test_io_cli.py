@@ -601,6 +601,37 @@ def test_registration_keep_overhang_grows_the_output_to_the_union_box(tmp_path):
         RegisterSettings(affine_transform_zyx=np.diag([1, 0, 1, 1.0]).tolist(), keep_overhang=True).resolved(vol.shape)
 
 
+def test_keep_overhang_store_records_where_the_grown_grid_sits(tmp_path, cpu_cli):
+    """``register_origin`` was computed and dropped -- the grown output's place in target coordinates was lost.
+    It is now the NGFF ``translation`` (origin x scale, after the scale transform) of the output level; and a run that
+    passes a channel through unwarped is told that keep_overhang is the reason its shapes cannot agree."""
+    import click
+
+    from shrimpy_amd.settings import ReconstructSettings, RegisterSettings
+
+    src = _make_plate(tmp_path / "raw.zarr", "0.5", dtype=np.float32)
+    m = np.eye(4)
+    m[:3, 3] = [1.5, -2.0, 3.25]
+    reg = RegisterSettings(affine_transform_zyx=m.tolist(), keep_overhang=True)
+    _, shape, origin = reg.resolved((N_Z, N_Y, N_X))
+    assert any(origin)
+    res = cpu_cli.run_store(src, tmp_path / "out.zarr", ReconstructSettings(registration=reg), zarr_version="0.5")
+    assert tuple(res["output_shape"]) == tuple(shape)
+    meta = json.loads((tmp_path / "out.zarr" / "0" / "0" / "000" / "zarr.json").read_text())
+    tr = meta["attributes"]["ome"]["multiscales"][0]["datasets"][0]["coordinateTransformations"]
+    assert [t["type"] for t in tr] == ["scale", "translation"]
+    scale = tr[0]["scale"]
+    assert tr[1]["translation"] == [0.0, 0.0] + [float(o) * float(s) for o, s in zip(origin, scale[2:])]
+    # without keep_overhang: no translation entry
+    res = cpu_cli.run_store(src, tmp_path / "plain.zarr", ReconstructSettings(registration=RegisterSettings(affine_transform_zyx=m.tolist())),
+                            zarr_version="0.5")
+    meta = json.loads((tmp_path / "plain.zarr" / "0" / "0" / "000" / "zarr.json").read_text())
+    assert [t["type"] for t in meta["attributes"]["ome"]["multiscales"][0]["datasets"][0]["coordinateTransformations"]] == ["scale"]
+    partial = RegisterSettings(affine_transform_zyx=m.tolist(), keep_overhang=True, source_channel_names=[CHANNELS[0]])
+    with pytest.raises(click.ClickException, match="keep_overhang"):
+        cpu_cli.run_store(src, tmp_path / "no.zarr", ReconstructSettings(registration=partial), zarr_version="0.5")
+
+
 def test_heterogeneous_plates_are_refused_before_anything_is_written(tmp_path, cpu_cli):
     import click
 
@@ -969,3 +1000,34 @@ def test_staged_run_over_a_store_in_the_acquisition_format_on_gpu(tmp_path):
             ref = o.richardson_lucy(o.deskew(vols[key].astype(np.float32), 30.0, 0.755, True, 3), psf, 3).astype(np.float64)
             assert got.shape == ref.shape
             assert np.all(np.abs(got - ref) <= 5e-5 * np.abs(ref) + 2e-5 * np.abs(ref).max())
+
+
+def test_dash_i_takes_several_position_directories_through_clicks_public_parser(tmp_path, cpu_cli, monkeypatch):
+    """``-i a b c`` was parsed by patching click's private parser tables.  It is now a rewrite of the argument
+    list in ``Command.parse_args`` (public): several directories after one ``-i``, ``-i`` given twice, the list ended by
+    the next option, ``-s`` / ``-t`` of ``register`` alike."""
+    from click.testing import CliRunner
+
+    src = _make_plate(tmp_path / "raw.zarr", "0.4")
+    seen = {}
+
+    def fake_run_store(input_path, output_path, settings, positions, zarr_version, **kw):
+        seen.update(input=input_path, positions=tuple(positions))
+        return {"ok": True}
+
+    monkeypatch.setattr(cpu_cli, "run_store", fake_run_store)
+    cfg = tmp_path / "dec.yml"
+    cfg.write_text(yaml.safe_dump(dict(iterations=2)))
+    dirs = [str(src / k) for k in KEYS]
+    r = CliRunner().invoke(cpu_cli.cli, ["deconvolve", "-i", *dirs, "-c", str(cfg), "-o", str(tmp_path / "o")])
+    assert r.exit_code == 0, r.output
+    assert seen["input"] == src and seen["positions"] == tuple(KEYS)
+    r = CliRunner().invoke(cpu_cli.cli, ["deconvolve", "-c", str(cfg), "-i", dirs[1], "-i", dirs[0], "-o", str(tmp_path / "o")])
+    assert r.exit_code == 0 and set(seen["positions"]) == set(KEYS)
+    r = CliRunner().invoke(cpu_cli.cli, ["deconvolve", "-i", str(src), "-c", str(cfg), "-o", str(tmp_path / "o")])
+    assert r.exit_code == 0 and seen["input"] == src and seen["positions"] == ()
+    reg = tmp_path / "reg.yml"
+    reg.write_text(yaml.safe_dump(dict(affine_transform_zyx=np.eye(4).tolist())))
+    r = CliRunner().invoke(cpu_cli.cli, ["register", "-s", *dirs, "-t", dirs[0], "-c", str(reg), "-o", str(tmp_path / "o")])
+    assert r.exit_code == 0, r.output
+    assert seen["input"] == src and seen["positions"] == tuple(KEYS)

@@ -173,3 +173,26 @@ def test_iterate_padded_hands_the_scalars_to_the_slab_split(device):
     with pytest.raises(ValueError):
         plan.iterate_padded(ypad, a, b, stats=torch.zeros(3, device=device))   # float32: refused
     assert isinstance(ypad, PaddedVolume)
+
+
+def test_tol_means_the_same_on_cpu_and_gpu_tensors(device):
+    """``richardson_lucy(y, tol=...)`` stopped one iteration earlier on a CPU tensor than on a GPU tensor.  Both now
+    return the estimate one iteration past the first that met ``tol`` (the device reads iteration i's scalars while i + 1
+    runs): the same iteration count and, within the RL bar, the same estimate, for the separable and the dense route."""
+    import torch
+
+    from shrimpy_amd.deconvolve import richardson_lucy
+
+    psf, _ = o.gaussian_psf((5, 5, 7), (1.1, 0.9, 1.4))
+    rot = o.rotated_psf((5, 5, 7), (1.1, 0.9, 1.4), 30.0)
+    y = o.bead_scene((12, 20, 26), seed=2, psf=psf, density=2e-3)
+    for kernel in (psf, rot):
+        want = o.rl_iteration_scalars(y, kernel, 8)
+        rel = want["change"] / want["total"]
+        for first in (2, 4):
+            tol = float(0.5 * (rel[first - 1] + rel[first]))
+            xc, sc = richardson_lucy(torch.as_tensor(y), kernel, iterations=8, tol=tol, return_stats=True)
+            xg, sg = richardson_lucy(_t(y, device), kernel, iterations=8, tol=tol, return_stats=True)
+            assert sc.iterations == sg.iterations == first + 2 and sc.stopped_by_tol and sg.stopped_by_tol
+            a, b = xc.numpy().astype(np.float64), xg.cpu().numpy().astype(np.float64)
+            assert np.all(np.abs(a - b) <= 2e-4 * np.abs(a) + 1e-4 * np.abs(a).max())

@@ -541,3 +541,41 @@ def test_native_frame_encoder_writes_the_python_encoders_frames(dtype, n):
             np.testing.assert_array_equal(codecs.blosc_decode(f, backend="lsrecon"), p.view(np.uint8))
     with pytest.raises(codecs.CodecUnavailable):
         codecs.blosc_encode(a, a.itemsize, shuffle=codecs.SHUFFLE_BIT, backend="lsrecon")
+
+
+def test_shard_lock_table_never_hands_two_locks_to_one_directory(tmp_path):
+    """the table of per-directory locks was purged of unlocked entries past 4096 -- between a thread fetching
+    its Lock and acquiring it, which let a second Lock for the same directory in.  Entries are now counted while held or
+    waited for and dropped by the last thread out: many threads, many directories, never two in one critical section,
+    and nothing left in the table afterwards."""
+    import threading
+    import time
+
+    from shrimpy_amd.io import omezarr
+
+    dirs = [tmp_path / f"d{i}" for i in range(40)]
+    for d in dirs:
+        d.mkdir()
+    inside = {str(d): 0 for d in dirs}
+    worst = [0]
+    guard = threading.Lock()
+
+    def work(seed):
+        rng = np.random.default_rng(seed)
+        for _ in range(200):
+            d = dirs[int(rng.integers(0, len(dirs)))]
+            with omezarr._shard_lock(d / "c0"):
+                with guard:
+                    inside[str(d)] += 1
+                    worst[0] = max(worst[0], inside[str(d)])
+                time.sleep(0)
+                with guard:
+                    inside[str(d)] -= 1
+
+    threads = [threading.Thread(target=work, args=(s,)) for s in range(12)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert worst[0] == 1
+    assert omezarr._shard_locks == {}
