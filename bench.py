@@ -701,6 +701,11 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
                        + (f"OUTPUT chunks {args.output_compression}, " if args.output_compression != "none" else "")
                        + f"scratch {root.parent}, input from the page cache; pinned staging slots + copy streams (cli.run_store)"),
             }
+            if world > 1:       # every rank's own stage clocks (a rehearsal on one card, or the node-wide run)
+                clocks = [None] * world
+                dist.all_gather_object(clocks, {"rank": rank, "units": res["units"], "seconds": round(res["seconds"], 4),
+                                                **{k: round(v / max(res["units"], 1), 4) for k, v in res.get("stage_seconds", {}).items()}})
+                store["stage_s_per_unit_by_rank"] = clocks
             if rank == 0:
                 store["host_floor"] = host_floor(root, keys[0], out_shape)
             if world > 1:
