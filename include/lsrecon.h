@@ -579,13 +579,6 @@ int lsr_mask_centroid_f32(const float* in, int64_t Z, int64_t Y, int64_t X, floa
                           double* out4, void* scratch, lsr_stream_t stream);
 int lsr_blur_reflect_f32(const float* in, float* out, int64_t Z, int64_t Y, int64_t X, int axis,
                          const float* taps, int radius, float sub, float div, lsr_stream_t stream);
-/* The y and the x pass of the same blur in ONE launch (radii up to 16; lsr_blur_reflect_yx_supported says): a tile with
- * both halos is staged once, the y-filtered rows stay in LDS, the x pass writes the result -- the intermediate volume of
- * two lsr_blur_reflect_f32 calls (axis 1, then axis 2: 2 of the blur's 6 volume traversals) never exists.  The same FMA
- * chains in the same order: bit-identical to the two calls (tracking.py:386-422 runs the three axes in z, y, x order). */
-int lsr_blur_reflect_yx_supported(int ry, int rx);
-int lsr_blur_reflect_yx_f32(const float* in, float* out, int64_t Z, int64_t Y, int64_t X, const float* taps_y, int ry,
-                            const float* taps_x, int rx, lsr_stream_t stream);
 /*
  * Element-wise steps of _phase_cross_corr (:266-378); the FFTs between them are library calls.
  *   lsr_match_shape_f32       _match_shape: per axis reflect-pad (left = d / 2) or centre-crop to the FFT shape
@@ -738,8 +731,6 @@ int lsr_mask_centroid_f32_cpu(const float* in, int64_t Z, int64_t Y, int64_t X, 
                               double* out4, void* scratch, lsr_stream_t stream);
 int lsr_blur_reflect_f32_cpu(const float* in, float* out, int64_t Z, int64_t Y, int64_t X, int axis,
                              const float* taps, int radius, float sub, float div, lsr_stream_t stream);
-int lsr_blur_reflect_yx_f32_cpu(const float* in, float* out, int64_t Z, int64_t Y, int64_t X, const float* taps_y, int ry,
-                                const float* taps_x, int rx, lsr_stream_t stream);
 int lsr_match_shape_f32_cpu(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
                             int64_t Yo, int64_t Xo, lsr_stream_t stream);
 int lsr_cross_power_c64_cpu(float* a, const float* b, int64_t n, lsr_stream_t stream);

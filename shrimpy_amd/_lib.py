@@ -70,8 +70,6 @@ SIGNATURES: dict[str, list] = {
     "lsr_weighted_centroid_f32": [_c_f32p, _i64, _i64, _i64, _f32, ctypes.c_void_p, ctypes.c_void_p, _stream],
     "lsr_mask_centroid_f32": [_c_f32p, _i64, _i64, _i64, _f32, ctypes.c_void_p, ctypes.c_void_p, _stream],
     "lsr_blur_reflect_f32": [_c_f32p, _c_f32p, _i64, _i64, _i64, _int, _c_f32p, _int, _f32, _f32, _stream],
-    "lsr_blur_reflect_yx_supported": [_int, _int],
-    "lsr_blur_reflect_yx_f32": [_c_f32p, _c_f32p, _i64, _i64, _i64, _c_f32p, _int, _c_f32p, _int, _stream],
     "lsr_match_shape_f32": [_c_f32p, _i64, _i64, _i64, _c_f32p, _i64, _i64, _i64, _stream],
     "lsr_cross_power_c64": [_c_f32p, _c_f32p, _i64, _stream],
     "lsr_rfft_rows_supported": [_i64],
@@ -187,7 +185,7 @@ for _name in ("lsr_deskew_f32", "lsr_deskew_u16", "lsr_deskew_cval", "lsr_affine
               "lsr_flatfield_apply_f32", "lsr_flatfield_apply_u16",
               # ... and of the DynaTrack estimators (csrc/estimators_host.hip)
               "lsr_minmax_f32", "lsr_histogram_f32", "lsr_weighted_centroid_f32", "lsr_mask_centroid_f32",
-              "lsr_blur_reflect_f32", "lsr_blur_reflect_yx_f32", "lsr_match_shape_f32", "lsr_cross_power_c64", "lsr_cross_power_into_c64",
+              "lsr_blur_reflect_f32", "lsr_match_shape_f32", "lsr_cross_power_c64", "lsr_cross_power_into_c64",
               "lsr_peak_abs_shifted_f32",
               # ... and of the device-side chunk codecs (csrc/blosc_encode.hip)
               "lsr_blosc_encode_device", "lsr_blosc_decode_device"):

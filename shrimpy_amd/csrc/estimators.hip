@@ -551,118 +551,6 @@ __global__ __launch_bounds__(kThreads) void blur_contiguous_kernel(BlurArgs p) {
   }
 }
 
-// ---------------------------------------------------------------------------------- y and x passes in one launch
-// The two in-plane passes of the separable blur on one staged tile: (TY + 2 ry) x (TX + 2 rx) inputs (reflect indices)
-// -> LDS, the y pass on every staged column -> a second LDS buffer of TY x (TX + 2 rx), the x pass from it -> HBM.  The
-// intermediate volume of the two-launch form (one write + one read of the whole volume: 2 of the blur's 6 traversals)
-// never exists.  Every output is the same FMA chain in ascending tap order as in the one-axis kernels, y first, then x:
-// bit-identical results.  Radii up to kYxMaxR (sigma <= 4); larger ones keep the separate passes.
-constexpr int kYxTY = 32, kYxTX = 128, kYxMaxR = 16;
-struct BlurYxArgs {
-  const float* in;
-  float* out;
-  const float* taps_y;
-  const float* taps_x;
-  int64_t Z, Y, X;
-  int ry, rx;
-  int64_t tiles_x, tiles_y;
-};
-
-__global__ __launch_bounds__(kThreads) void blur_yx_kernel(BlurYxArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float yx_lds[];
-  __shared__ float s_ty[2 * kYxMaxR + 1], s_tx[2 * kYxMaxR + 1];
-  const int ry = p.ry, rx = p.rx, ny = 2 * ry + 1, nx = 2 * rx + 1;
-  const int SX = kYxTX + 2 * rx, SY = kYxTY + 2 * ry;
-  const int PS = SX + 1;                    // pitch of the staged tile (columns are walked down: odd pitch)
-  const int PT = (SX + 3) / 4 * 4 + 4;      // pitch of the y-filtered rows (16-byte reads along x)
-  float* const S = yx_lds;                  // [SY][PS]
-  float* const T = yx_lds + ((SY * PS + 3) / 4 * 4);   // [kYxTY][PT]
-  const int tid = threadIdx.x;
-  for (int t = tid; t < ny; t += kThreads) s_ty[t] = p.taps_y[t];
-  for (int t = tid; t < nx; t += kThreads) s_tx[t] = p.taps_x[t];
-  int64_t b = blockIdx.x;
-  const int64_t tx = b % p.tiles_x;
-  b /= p.tiles_x;
-  const int64_t ty = b % p.tiles_y, z = b / p.tiles_y;
-  const int64_t x0 = tx * kYxTX, y0 = ty * kYxTY;
-  const float* const plane = p.in + z * p.Y * p.X;
-  // stage: rows along y, lanes along x (coalesced), five loads in flight per thread
-  const int n_stage = SY * SX;
-  for (int t0 = tid; t0 < n_stage; t0 += kThreads * 5) {
-    float v[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int t = min(t0 + i * kThreads, n_stage - 1);
-      const int j = t / SX, c = t - j * SX;
-      v[i] = plane[static_cast<int64_t>(reflect(static_cast<int>(y0) + j - ry, static_cast<int>(p.Y))) * p.X +
-                   reflect(static_cast<int>(x0) + c - rx, static_cast<int>(p.X))];
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int t = t0 + i * kThreads;
-      if (t < n_stage) { const int j = t / SX, c = t - j * SX; S[j * PS + c] = v[i]; }
-    }
-  }
-  __syncthreads();
-  // y pass: an item = one staged column and eight consecutive rows; a register window of 8 + tap block values
-  constexpr int RG = 8;
-  const int n_items = SX * (kYxTY / RG);
-  for (int it = tid; it < n_items; it += kThreads) {
-    const int c = it % SX, g = it / SX;
-    float acc[RG];
-#pragma unroll
-    for (int k = 0; k < RG; ++k) acc[k] = 0.0f;
-    for (int t0 = 0; t0 < ny; t0 += kTapBlock) {
-      float win[RG + kTapBlock - 1];
-#pragma unroll
-      for (int q = 0; q < RG + kTapBlock - 1; ++q) {
-        const int row = g * RG + t0 + q;
-        win[q] = row < SY ? S[row * PS + c] : 0.0f;
-      }
-#pragma unroll
-      for (int tt = 0; tt < kTapBlock; ++tt) {
-        if (t0 + tt < ny) {
-          const float w = s_ty[t0 + tt];
-#pragma unroll
-          for (int k = 0; k < RG; ++k) acc[k] = fmaf(w, win[k + tt], acc[k]);
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < RG; ++k) T[(g * RG + k) * PT + c] = acc[k];
-  }
-  __syncthreads();
-  // x pass: an item = one row and four consecutive outputs (16-byte LDS reads, 16-byte stores where the row allows)
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const int n_out_x = static_cast<int>(min(static_cast<int64_t>(kYxTX), p.X - x0));
-  const int n_out_y = static_cast<int>(min(static_cast<int64_t>(kYxTY), p.Y - y0));
-  for (int it = tid; it < kYxTY * (kYxTX / 4); it += kThreads) {
-    const int row = it / (kYxTX / 4), k0 = 4 * (it % (kYxTX / 4));
-    if (row >= n_out_y || k0 >= n_out_x) continue;
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int t0 = 0; t0 < nx; t0 += kTapBlock) {
-      float win[12];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(T + row * PT + k0 + t0 + 4 * q);
-        win[4 * q] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
-      }
-#pragma unroll
-      for (int tt = 0; tt < kTapBlock; ++tt) {
-        if (t0 + tt < nx) {
-          const float w = s_tx[t0 + tt];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) acc[k] = fmaf(w, win[k + tt], acc[k]);
-        }
-      }
-    }
-    float* dst = p.out + (z * p.Y + y0 + row) * p.X + x0 + k0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (k0 + k < n_out_x) dst[k] = acc[k];
-  }
-}
-
 // ---------------------------------------------------------------------------------- phase cross-correlation
 // The element-wise steps around the two FFTs of _phase_cross_corr (tracking.py:309-378); the FFTs
 // themselves are library calls (rocFFT through torch.fft, like a plain library GEMM).
@@ -969,31 +857,6 @@ extern "C" int lsr_blur_reflect_f32(const float* in, float* out, int64_t Z, int6
       hipLaunchKernelGGL(blur_strided_kernel<16>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), lds, s, p);
   }
   return lsr::launch_status("lsr_blur_reflect_f32");
-}
-
-extern "C" int lsr_blur_reflect_yx_supported(int ry, int rx) { return ry >= 0 && rx >= 0 && ry <= kYxMaxR && rx <= kYxMaxR; }
-
-extern "C" int lsr_blur_reflect_yx_f32(const float* in, float* out, int64_t Z, int64_t Y, int64_t X, const float* taps_y,
-                                       int ry, const float* taps_x, int rx, lsr_stream_t stream) {
-  if (int rc = check_volume(in, Z, Y, X)) return rc;
-  LSR_REQUIRE_PTR(out);
-  LSR_REQUIRE_PTR(taps_y);
-  LSR_REQUIRE_PTR(taps_x);
-  LSR_REQUIRE(in != out, LSR_E_ARG, "out must not alias in");
-  LSR_REQUIRE(lsr_blur_reflect_yx_supported(ry, rx), LSR_E_UNSUPPORTED, "radii (%d, %d): the fused y-x pass takes up to %d", ry, rx,
-              kYxMaxR);
-  LSR_REQUIRE(ry < Y && rx < X, LSR_E_ARG, "reflect padding needs radii (%d, %d) < (%lld, %lld)", ry, rx, (long long)Y, (long long)X);
-  BlurYxArgs p;
-  p.in = in; p.out = out; p.taps_y = taps_y; p.taps_x = taps_x; p.Z = Z; p.Y = Y; p.X = X; p.ry = ry; p.rx = rx;
-  p.tiles_x = lsr::ceil_div(X, int64_t(kYxTX));
-  p.tiles_y = lsr::ceil_div(Y, int64_t(kYxTY));
-  const int64_t blocks = p.tiles_x * p.tiles_y * Z;
-  LSR_REQUIRE(blocks < (int64_t(1) << 31), LSR_E_SHAPE, "grid of %lld workgroups is too large", (long long)blocks);
-  const int SX = kYxTX + 2 * rx, SY = kYxTY + 2 * ry;
-  // (the x pass reads a window of 12 floats from k0 + t0: the last one ends at column kYxTX - 4 + 16 + 11 of a row)
-  const size_t lds = sizeof(float) * ((SY * (SX + 1) + 3) / 4 * 4 + kYxTY * ((SX + 3) / 4 * 4 + 4) + 32);
-  hipLaunchKernelGGL(blur_yx_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), lds, lsr::as_stream(stream), p);
-  return lsr::launch_status("lsr_blur_reflect_yx_f32");
 }
 
 extern "C" int lsr_match_shape_f32(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,

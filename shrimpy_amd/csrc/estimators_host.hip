@@ -207,46 +207,6 @@ extern "C" int lsr_blur_reflect_f32_cpu(const float* in, float* out, int64_t Z, 
   return LSR_OK;
 }
 
-// the two in-plane passes in one call: the y pass into a plane buffer, the x pass from it (the kernels' chain, bit-equal)
-extern "C" int lsr_blur_reflect_yx_f32_cpu(const float* in, float* out, int64_t Z, int64_t Y, int64_t X, const float* taps_y,
-                                           int ry, const float* taps_x, int rx, lsr_stream_t) {
-  LSR_REQUIRE_HOST_FMA();
-  if (int rc = check_volume(in, Z, Y, X)) return rc;
-  LSR_REQUIRE_PTR(out);
-  LSR_REQUIRE_PTR(taps_y);
-  LSR_REQUIRE_PTR(taps_x);
-  LSR_REQUIRE(in != out, LSR_E_ARG, "out must not alias in");
-  LSR_REQUIRE(ry >= 0 && rx >= 0 && ry <= kBlurMaxR && rx <= kBlurMaxR, LSR_E_UNSUPPORTED, "radii (%d, %d) outside [0, %d]", ry, rx, kBlurMaxR);
-  LSR_REQUIRE(ry < Y && rx < X, LSR_E_ARG, "reflect padding needs radii (%d, %d) < (%lld, %lld)", ry, rx, (long long)Y, (long long)X);
-  std::atomic<bool> failed{false};
-  parallel_ranges(Z, [&](int64_t z0, int64_t z1) {
-    std::vector<float> mid(static_cast<size_t>(Y * X));
-    for (int64_t z = z0; z < z1; ++z) {
-      const float* src = in + z * Y * X;
-      for (int64_t y = 0; y < Y; ++y) {
-        float* row = mid.data() + y * X;
-        for (int64_t x = 0; x < X; ++x) row[x] = 0.0f;
-        for (int t = 0; t <= 2 * ry; ++t) {
-          const float w = taps_y[t];
-          const float* s = src + reflect(y + t - ry, Y) * X;
-          for (int64_t x = 0; x < X; ++x) row[x] = std::fmaf(w, s[x], row[x]);
-        }
-      }
-      for (int64_t y = 0; y < Y; ++y) {
-        const float* row = mid.data() + y * X;
-        float* dst = out + (z * Y + y) * X;
-        for (int64_t x = 0; x < X; ++x) {
-          float c = 0.0f;
-          for (int t = 0; t <= 2 * rx; ++t) c = std::fmaf(taps_x[t], row[reflect(x + t - rx, X)], c);
-          dst[x] = c;
-        }
-      }
-    }
-  }, failed);
-  LSR_REQUIRE(!failed.load(), LSR_E_ARG, "lsr_blur_reflect_yx_f32_cpu: out of memory for a worker's plane buffer");
-  return LSR_OK;
-}
-
 extern "C" int lsr_match_shape_f32_cpu(const float* in, int64_t Zi, int64_t Yi, int64_t Xi, float* out, int64_t Zo,
                                        int64_t Yo, int64_t Xo, lsr_stream_t) {
   LSR_REQUIRE_HOST_FMA();

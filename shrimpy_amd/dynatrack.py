@@ -134,28 +134,15 @@ def _gaussian_blur_3d(img, sigma: float, _rescale: tuple[float, float] | None = 
     z, y, x = (int(v) for v in vol.shape)
     src = vol
     sub, div = (0.0, 0.0) if _rescale is None else (float(_rescale[0]), float(np.float32(_rescale[1]) - np.float32(_rescale[0])))
-
-    def taps(n):
+    for axis, n in enumerate((z, y, x)):
         r = min(max_radius, n - 1)   # reflect padding requires pad < dim (reference :403-404)
         xs = torch.arange(-r, r + 1, device=vol.device, dtype=torch.float32)
         k1d = torch.exp(-0.5 * (xs / sigma) ** 2)
-        return r, (k1d / k1d.sum()).contiguous()
-
-    (rz, kz), (ry, ky), (rx, kx) = taps(z), taps(y), taps(x)
-    dst = torch.empty_like(vol)
-    _run(vol.device, "lsr_blur_reflect_f32", src.data_ptr(), dst.data_ptr(), z, y, x, 0, kz.data_ptr(), rz,
-         ctypes.c_float(sub), ctypes.c_float(div))
-    src = dst
-    if _lib.call_value("lsr_blur_reflect_yx_supported", ry, rx) or vol.device.type == "cpu":
-        # the two in-plane passes in one launch: the y-filtered tile never leaves LDS (4 volume traversals instead of 6)
-        dst = torch.empty_like(vol)
-        _run(vol.device, "lsr_blur_reflect_yx_f32", src.data_ptr(), dst.data_ptr(), z, y, x, ky.data_ptr(), ry, kx.data_ptr(), rx)
-        return dst
-    for axis, (r, k1d) in ((1, (ry, ky)), (2, (rx, kx))):
+        k1d = (k1d / k1d.sum()).contiguous()
         dst = torch.empty_like(vol)
         _run(vol.device, "lsr_blur_reflect_f32", src.data_ptr(), dst.data_ptr(), z, y, x, axis, k1d.data_ptr(), r,
-             ctypes.c_float(0.0), ctypes.c_float(0.0))
-        src = dst
+             ctypes.c_float(sub), ctypes.c_float(div))
+        src, sub, div = dst, 0.0, 0.0
     return src
 
 
