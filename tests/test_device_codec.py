@@ -406,3 +406,54 @@ def test_store_to_store_with_device_codecs_equals_the_host_codec_run(tmp_path, d
     out = np.empty(codecs.blosc_header(raw)["nbytes"], np.uint8)
     codecs._py_blosc_decode(raw, out)
     assert np.array_equal(out, codecs.blosc_decode(raw, backend="lsrecon"))
+
+
+@pytest.mark.gpu
+def test_a_damaged_chunk_is_reported_by_the_device_decoder_and_skipped_on_request(tmp_path, device):
+    """A chunk whose bytes are damaged after it was written (the shard index still points at it): the device decoder's
+    status word names the unit at ``acquire``; the default run stops there, ``on_error="skip"`` leaves that unit out,
+    lists it with stage "load", and writes every other unit -- bit for bit what the undamaged plate gives."""
+    import torch
+
+    import bench
+    from shrimpy_amd import cli
+    from shrimpy_amd.io.device_codec import DecodeError
+    from shrimpy_amd.io.omezarr import as_volume_array, open_ome_zarr
+    from shrimpy_amd.settings import DeconvolveSettings, DeskewSettings, ReconstructSettings
+
+    raw_shape = (320, 48, 192)
+    keys = ["A/1/0", "A/2/0", "A/3/0", "A/4/0"]
+
+    def write(path):
+        with open_ome_zarr(path, layout="hcs", mode="w", channel_names=["LS"], prefer_iohub=False, version="0.5") as plate:
+            for p, key in enumerate(keys):
+                arr = plate.create_position(*key.split("/")).create_zeros(
+                    "0", shape=(1, 1) + raw_shape, dtype="uint16", scale=(1, 1, 0.15, 0.1133, 0.1133), compress="blosc-zstd",
+                    shards="volume", blocksize=32768)
+                arr.write_volume(0, 0, bench.synthetic_raw(raw_shape, seed=91 + p, device=device).to(torch.uint16).cpu().numpy())
+
+    write(tmp_path / "good.zarr")
+    write(tmp_path / "bad.zarr")
+    shard = next(f for f in sorted((tmp_path / "bad.zarr" / "A" / "3" / "0" / "0").rglob("*")) if f.is_file() and f.name != "zarr.json")
+    blob = bytearray(shard.read_bytes())
+    for k in range(4000, 4400):
+        blob[k] ^= 0xA5                                  # inside the first chunk's streams; index and checksum untouched
+    shard.write_bytes(bytes(blob))
+    settings = ReconstructSettings(
+        deskew=DeskewSettings(pixel_size_um=0.1133, scan_step_um=0.15, ls_angle_deg=30.0, keep_overhang=False, average_n_slices=3),
+        deconvolution=DeconvolveSettings(iterations=3))
+    with pytest.raises(DecodeError):
+        cli.run_store(tmp_path / "bad.zarr", tmp_path / "stops.zarr", settings, compression="blosc-zstd", zarr_version="0.5")
+    res = cli.run_store(tmp_path / "bad.zarr", tmp_path / "skipped.zarr", settings, compression="blosc-zstd", zarr_version="0.5",
+                        on_error="skip")
+    assert res["device_codec"]["decode"] and [(f["position"], f["stage"]) for f in res["failed"]] == [("A/3/0", "load")]
+    ref = cli.run_store(tmp_path / "good.zarr", tmp_path / "whole.zarr", settings, compression="blosc-zstd", zarr_version="0.5")
+    assert ref["failed"] == []
+    with open_ome_zarr(tmp_path / "skipped.zarr", prefer_iohub=False) as a, open_ome_zarr(tmp_path / "whole.zarr", prefer_iohub=False) as b:
+        pa, pb = dict(a.positions()), dict(b.positions())
+        for key in keys:
+            x, y = as_volume_array(pa[key]["0"]).read_volume(0, 0), as_volume_array(pb[key]["0"]).read_volume(0, 0)
+            if key == "A/3/0":
+                assert not x.any()
+            else:
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), key
