@@ -34,7 +34,8 @@ namespace {
 using namespace lsr::zd;
 
 constexpr int kThreads = 256;
-constexpr int kSymStride = 260;   // LDS bytes per lane: 256 symbols, an odd number of dwords between lanes
+constexpr int kSymStride = 304 + 4 * kFastRuns + 4;   // LDS bytes per lane: 256 symbols, 12 class entries, the run list; an odd number of dwords between lanes
+static_assert((kSymStride / 4) % 2 == 1 && kSymStride % 4 == 0, "lanes must sit an odd number of dwords apart");
 
 struct Frames {
   int64_t n_frames, frame_nbytes, blocksize, blocks_per_frame, n_blocks;
@@ -137,6 +138,12 @@ LSR_HD int decode_block(Lane<Store>& L, const BlockJob& job, int64_t frame_nbyte
 struct HostStore {
   uint32_t ws[kWorkEntries];
   uint8_t sym[256];
+  uint32_t cls[12];
+  uint32_t runs[kFastRuns];
+  uint32_t run_get(int i) const { return runs[i]; }
+  void run_set(int i, uint32_t v) { runs[i] = v; }
+  uint32_t cls_get(int i) const { return cls[i]; }
+  void cls_set(int i, uint32_t v) { cls[i] = v; }
   uint32_t ws_get(int i) const { return ws[i]; }
   void ws_set(int i, uint32_t v) { ws[i] = v; }
   uint8_t sym_get(int i) const { return sym[i & 255]; }
@@ -156,9 +163,17 @@ void unshuffle_host(const uint8_t* src, uint8_t* dst, int64_t nbytes, int T) {
 }
 
 // ---- device ---------------------------------------------------------------------------------------------------------------------------
+// The symbol table is LDS, and the pointer says so: through a generic pointer every lookup is a FLAT load, which counts
+// on the vector-memory counter as well -- each literal then waits for the wave's outstanding global loads and stores.
+using lds_u8 = __attribute__((address_space(3))) uint8_t;
+using lds_u32 = __attribute__((address_space(3))) uint32_t;
 struct DevStore {
   uint32_t* ws;     // this lane's entry 0; entries are 64 dwords apart (interleaved by lane)
-  uint8_t* sym;     // LDS
+  lds_u8* sym;      // LDS: 256 symbols in rank order, the 11 class entries of the Huffman code (at 256), the run list (at 304)
+  __device__ uint32_t cls_get(int i) const { return reinterpret_cast<const lds_u32*>(sym + 256)[i]; }
+  __device__ void cls_set(int i, uint32_t v) { reinterpret_cast<lds_u32*>(sym + 256)[i] = v; }
+  __device__ uint32_t run_get(int i) const { return reinterpret_cast<const lds_u32*>(sym + 304)[i]; }
+  __device__ void run_set(int i, uint32_t v) { reinterpret_cast<lds_u32*>(sym + 304)[i] = v; }
   __device__ uint32_t ws_get(int i) const { return ws[static_cast<int64_t>(i) * 64]; }
   __device__ void ws_set(int i, uint32_t v) { ws[static_cast<int64_t>(i) * 64] = v; }
   __device__ uint8_t sym_get(int i) const { return sym[i & 255]; }
@@ -179,14 +194,14 @@ struct DecArgs {
 };
 
 __global__ __launch_bounds__(kThreads) void decode_blocks_kernel(DecArgs a) {
-  __shared__ uint8_t sym_lds[kThreads * kSymStride];
+  __shared__ __attribute__((aligned(16))) uint8_t sym_lds[kThreads * kSymStride];
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t b = int64_t(blockIdx.x) * kThreads + tid;
   if (b >= a.n_blocks) return;
   const int64_t wave = b >> 6;
   Lane<DevStore> L;
   L.store.ws = a.work + wave * (int64_t(kWorkEntries) * 64) + lane;
-  L.store.sym = sym_lds + tid * kSymStride;
+  L.store.sym = (lds_u8*)(sym_lds) + tid * kSymStride;
   L.pre = a.pre;
   const int64_t f = b / a.blocks_per_frame;
   const int64_t at = a.frames[2 * f], size = a.frames[2 * f + 1];

@@ -21,6 +21,15 @@
 
 #include "zstd_huf.hpp"   // LSR_HD, highbit
 
+// Functions the kernel must see inlined: only then does the compiler know that the stream and workspace pointers come
+// from kernel arguments (global memory) and emit global_load / global_store for them.  Out of line they are generic
+// pointers, every access is a FLAT one, and a flat access counts on the LDS counter and the vector-memory counter both.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LSR_HD_INL LSR_HD __attribute__((always_inline))
+#else
+#define LSR_HD_INL LSR_HD
+#endif
+
 // Measurement build (-DLSR_DEC_PROBE, device code only): cycle stamps of the phases of a block, taken by lane 0 of the
 // first waves (csrc/blosc_decode.hip defines the buffer)
 #if defined(LSR_DEC_PROBE) && defined(__HIP_DEVICE_COMPILE__)
@@ -49,9 +58,11 @@ constexpr int kLLLogMax = 9, kOFLogMax = 8, kMLLogMax = 9;
 // 32-bit entries of the lane workspace: the three sequence tables (they persist from block to block: Repeat_Mode), the
 // Huffman weights while a tree description is read (eight 4-bit weights per entry) and their FSE table
 constexpr int kLLBase = 0, kOFBase = 512, kMLBase = 768, kWeightBase = 1280, kWeightTabBase = 1312, kSeqBase = 1376;
-// ... and the decoded sequences of a block (literal length, match length, offset: three entries each) when there are
-// few enough of them to place the literals directly (see decode_block_direct)
-constexpr int kMaxDirectSeq = 192, kWorkEntries = kSeqBase + 3 * kMaxDirectSeq;
+// ... and the match offsets of a block's sequences when there are few enough of them to place the literals directly
+// (decode_block_body); their literal and match lengths sit in the store's run list (run_get / run_set: LDS on the
+// device), 16 bits each, which is why the direct path takes blocks of at most 64 KB
+// (the first kFastRuns of them; later ones in the workspace behind the offsets)
+constexpr int kMaxDirectSeq = 192, kFastRuns = 72, kMaxDirectRoom = 65536, kWorkEntries = kSeqBase + 2 * kMaxDirectSeq;
 constexpr int kBlockMax = 128 * 1024;
 
 LSR_HD uint64_t load_le(const uint8_t* p, int n) {   // n <= 8 bytes, little endian
@@ -260,6 +271,8 @@ inline void build_predefined(Predefined& p) {
 //   ws_get(i) / ws_set(i, v)    32-bit entries, i < kWorkEntries (LL | OF | ML sequence tables; scratch while the Huffman
 //                               weights are decoded)
 //   sym_get(i) / sym_set(i, v)  the 256 Huffman symbols in rank order
+//   cls_get(j) / cls_set(j, v)  the 11 weight classes of the Huffman code: first code position (15-bit aligned) | first rank << 16
+//   run_get(k) / run_set(k, v)  the block's sequences, k < kFastRuns: literal length | (match length - 3) << 16
 template <class Store>
 struct WsTab {
   Store* s;
@@ -271,6 +284,7 @@ struct WsTab {
 struct HufCode {         // canonical code of the literals: classes by weight 1 .. 11 (weight w <-> length max_bits + 1 - w)
   uint16_t end[12];      // end[w]: first code-space position (max_bits wide) past the symbols of weight <= w
   uint16_t rank_end[12]; // symbols of weight <= w
+  uint32_t pair[5];      // end[1 .. 10] aligned to 15 bits, two per dword: what the fast path compares against (huf_class)
   int max_bits;          // 0 = no table yet
 };
 
@@ -311,7 +325,7 @@ LSR_HD void weight_set(Store& st, int i, uint32_t w) {
 }
 
 template <class Store>
-LSR_HD int read_huf_description(Lane<Store>& L, const uint8_t* p, int len) {
+LSR_HD_INL int read_huf_description(Lane<Store>& L, const uint8_t* p, int len) {
   if (len < 1) return kErrCorrupt;
   const int hb = p[0];
   int used, nw;
@@ -399,6 +413,13 @@ LSR_HD int read_huf_description(Lane<Store>& L, const uint8_t* p, int len) {
     if (w) L.store.sym_set(rank_start[w]++, static_cast<uint8_t>(i));
   }
   L.huf.max_bits = max_bits;
+  // the fast path's view of the same code: class bounds aligned to 15 bits (end[w] <= 2^max_bits becomes <= 0x8000), and
+  // per class the pair (first code position, first rank) where the store keeps it for an indexed read
+  const int up = 15 - max_bits;
+  for (int q = 0; q < 5; ++q)
+    L.huf.pair[q] = (static_cast<uint32_t>(L.huf.end[2 * q + 1]) << up) | ((static_cast<uint32_t>(L.huf.end[2 * q + 2]) << up) << 16);
+  for (int j = 0; j <= 10; ++j)
+    L.store.cls_set(j, (static_cast<uint32_t>(L.huf.end[j]) << up) | (static_cast<uint32_t>(L.huf.rank_end[j]) << 16));
   return used;
 }
 
@@ -481,21 +502,56 @@ LSR_HD void huf_rank(const HufCode& h, uint32_t v, uint32_t& rank, int& length) 
   length = h.max_bits + 1 - w;
 }
 
+// The same search for the fast path, on the top 15 bits of the stream.  The ten comparisons `v >= end[k]` run two to a
+// dword: with bit 15 of each half set in the minuend, the halves of `v2 - pair` cannot borrow from each other and keep
+// that bit exactly where v >= end (both operands are at most 0x8000); the flags are collected in one word and counted.
+// 16 instructions instead of 40, and the literal's LENGTH -- the only thing the next literal of the stream waits for --
+// is known before any table is read: class bounds and symbol come from the store behind it.
+LSR_HD int huf_class(const HufCode& h, uint32_t v15) {       // symbols' weight class - 1 = number of bounds at or below v
+  const uint32_t v2 = v15 * 0x10001u + 0x80008000u;
+  uint32_t m = 0;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) m = (m >> 1) | ((v2 - h.pair[q]) & 0x80008000u);
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __popc(m);
+#else
+  return __builtin_popcount(m);
+#endif
+}
+
+// Four literals of one stream in three steps, so that the caller can run each step for all four streams before the
+// next: (a) classes and lengths -- pure arithmetic on the window, the only serial chain -- with the four class entries
+// requested from the store; (b) ranks, with the four symbols requested; (c) the symbols packed, first in the low byte.
+// Written as one function the compiler waited for every table read right behind its request (one exposed LDS round trip
+// per literal); in steps, sixteen reads are in flight per wait.
+struct FourLits {
+  uint32_t v15[4], c[4];
+  int shift[4];          // 15 - length
+  uint8_t sym[4];
+};
 template <class Store>
-LSR_HD uint32_t fast_four(Lane<Store>& L, FastStream& f) {   // four literals of one stream, first in the low byte
+LSR_HD void four_classes(Lane<Store>& L, FastStream& f, FourLits& q) {
   uint64_t cur = fast_extract(f);
-  uint32_t out = 0;
   const int mb = L.huf.max_bits;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    uint32_t rank;
-    int length;
-    huf_rank(L.huf, static_cast<uint32_t>(cur >> (64 - mb)), rank, length);
-    out |= static_cast<uint32_t>(L.store.sym_get(static_cast<int>(rank))) << (8 * k);
+    q.v15[k] = static_cast<uint32_t>(cur >> 49);
+    const int j = huf_class(L.huf, q.v15[k]);
+    const int length = mb - j;
+    q.c[k] = L.store.cls_get(j);
+    q.shift[k] = 15 - length;
     cur <<= length;
     f.pos -= length;
   }
-  return out;
+}
+template <class Store>
+LSR_HD void four_symbols(Lane<Store>& L, FourLits& q) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    q.sym[k] = L.store.sym_get(static_cast<int>((q.c[k] >> 16) + ((q.v15[k] - (q.c[k] & 0xFFFFu)) >> q.shift[k])));
+}
+LSR_HD uint32_t four_packed(const FourLits& q) {
+  return q.sym[0] | (static_cast<uint32_t>(q.sym[1]) << 8) | (static_cast<uint32_t>(q.sym[2]) << 16) | (static_cast<uint32_t>(q.sym[3]) << 24);
 }
 
 LSR_HD void store32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
@@ -544,10 +600,20 @@ LSR_HD int huf_decode_4(Lane<Store>& L, const uint8_t* p, int len, int n, Sink& 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           fast_step(f0); fast_step(f1); fast_step(f2); fast_step(f3);
-          g0[k] = fast_four(L, f0);
-          g1[k] = fast_four(L, f1);
-          g2[k] = fast_four(L, f2);
-          g3[k] = fast_four(L, f3);
+          FourLits q0, q1, q2, q3;
+#if defined(LSR_DEC_FUSED_LOOKUP)
+          four_classes(L, f0, q0); four_symbols(L, q0); g0[k] = four_packed(q0);
+          four_classes(L, f1, q1); four_symbols(L, q1); g1[k] = four_packed(q1);
+          four_classes(L, f2, q2); four_symbols(L, q2); g2[k] = four_packed(q2);
+          four_classes(L, f3, q3); four_symbols(L, q3); g3[k] = four_packed(q3);
+#else
+          four_classes(L, f0, q0); four_classes(L, f1, q1); four_classes(L, f2, q2); four_classes(L, f3, q3);
+          four_symbols(L, q0); four_symbols(L, q1); four_symbols(L, q2); four_symbols(L, q3);
+          g0[k] = four_packed(q0);
+          g1[k] = four_packed(q1);
+          g2[k] = four_packed(q2);
+          g3[k] = four_packed(q3);
+#endif
         }
         sink.put16(0, i, Bytes16{g0[0] | static_cast<uint64_t>(g0[1]) << 32, g0[2] | static_cast<uint64_t>(g0[3]) << 32});
         sink.put16(1, q + i, Bytes16{g1[0] | static_cast<uint64_t>(g1[1]) << 32, g1[2] | static_cast<uint64_t>(g1[3]) << 32});
@@ -871,13 +937,22 @@ LSR_HD int run_sequences(Lane<Store>& L, SeqReader& r, const Literals& lit, uint
 // is the lane's own total -- lanes of a wave whose long matches sit at different sequence numbers do not wait for each
 // other sequence by sequence.
 template <class Store>
+LSR_HD uint32_t run_of(const Store& st, int k) {
+  return k < kFastRuns ? st.run_get(k) : st.ws_get(kSeqBase + kMaxDirectSeq + k);
+}
+template <class Store>
+LSR_HD void run_put(Store& st, int k, uint32_t v) {
+  if (k < kFastRuns) st.run_set(k, v);
+  else st.ws_set(kSeqBase + kMaxDirectSeq + k, v);
+}
+template <class Store>
 struct DirectSink {
   Store* st;
   uint8_t* op;
   int nseq;
   int k[4], run_end[4], shift[4];    // per stream: literals below run_end[s] belong to run k[s] and go to op[i + shift[s]]
-  LSR_HD int lit_of(int i) const { return static_cast<int>(st->ws_get(kSeqBase + 3 * i)); }
-  LSR_HD int match_of(int i) const { return static_cast<int>(st->ws_get(kSeqBase + 3 * i + 1)); }
+  LSR_HD int lit_of(int i) const { return static_cast<int>(run_of(*st, i) & 0xFFFFu); }
+  LSR_HD int match_of(int i) const { return static_cast<int>(run_of(*st, i) >> 16) + 3; }
   LSR_HD void seek(int s, int li) {               // the run literal li belongs to
     int kk = 0, sh = 0, end = nseq > 0 ? lit_of(0) : 0x7FFFFFFF;
     while (kk < nseq && li >= end) {
@@ -896,12 +971,41 @@ struct DirectSink {
     while (i >= run_end[s]) advance(s);
     op[i + shift[s]] = v;
   }
+  // Sixteen literals.  Inside a run they are one store.  Across a run's end (one lane in eighty, hence every other
+  // group of a wave) they leave piece by piece, a piece = the literals up to the next end, as at most four stores of
+  // 8 / 4 / 2 / 1 bytes: no loop over bytes, and nothing is read from memory on the way (the run list is in LDS) --
+  // a global load here would wait for every store the wave has in flight.
   LSR_HD void put16(int s, int i, const Bytes16& v) {
     if (i + 16 <= run_end[s]) {
       store16(op + i + shift[s], v);
-    } else {
-      for (int b = 0; b < 8; ++b) put1(s, i + b, static_cast<uint8_t>(v.a >> (8 * b)));
-      for (int b = 0; b < 8; ++b) put1(s, i + 8 + b, static_cast<uint8_t>(v.b >> (8 * b)));
+      return;
+    }
+#if defined(LSR_DEC_BYTE_BOUNDARY)
+    for (int q = 0; q < 8; ++q) put1(s, i + q, static_cast<uint8_t>(v.a >> (8 * q)));
+    for (int q = 0; q < 8; ++q) put1(s, i + 8 + q, static_cast<uint8_t>(v.b >> (8 * q)));
+    return;
+#endif
+    uint64_t a = v.a, b = v.b;
+    int pos = 0;
+    while (pos < 16) {
+      while (i + pos >= run_end[s]) advance(s);
+      const int left = run_end[s] - (i + pos);
+      const int n = left < 16 - pos ? left : 16 - pos;
+      uint8_t* d = op + i + pos + shift[s];
+      if (n == 16) {                       // (the previous run ended exactly at i)
+        store16(d, Bytes16{a, b});
+        return;
+      }
+      uint64_t x = a;
+      if (n & 8) { __builtin_memcpy(d, &x, 8); d += 8; x = b; }
+      if (n & 4) { const uint32_t w = static_cast<uint32_t>(x); __builtin_memcpy(d, &w, 4); d += 4; x >>= 32; }
+      if (n & 2) { const uint16_t w = static_cast<uint16_t>(x); __builtin_memcpy(d, &w, 2); d += 2; x >>= 16; }
+      if (n & 1) *d = static_cast<uint8_t>(x);
+      // drop the n bytes from the 128-bit value
+      if (n >= 8) { a = b; b = 0; }
+      const int sh = 8 * (n & 7);
+      if (sh) { a = (a >> sh) | (b << (64 - sh)); b >>= sh; }
+      pos += n;
     }
   }
 };
@@ -911,9 +1015,10 @@ template <class Store>
 LSR_HD int execute_matches(Lane<Store>& L, int nseq, uint8_t* dst0, uint8_t* op) {
   uint8_t* o = op;
   for (int k = 0; k < nseq; ++k) {
-    o += static_cast<int>(L.store.ws_get(kSeqBase + 3 * k));
-    const int n = static_cast<int>(L.store.ws_get(kSeqBase + 3 * k + 1));
-    const uint32_t off = L.store.ws_get(kSeqBase + 3 * k + 2);
+    const uint32_t run = run_of(L.store, k);
+    o += static_cast<int>(run & 0xFFFFu);
+    const int n = static_cast<int>(run >> 16) + 3;
+    const uint32_t off = L.store.ws_get(kSeqBase + k);
     if (off == 0 || off > static_cast<uint32_t>(o - dst0)) return kErrCorrupt;
     copy_match(o, off, n);
     o += n;
@@ -923,7 +1028,7 @@ LSR_HD int execute_matches(Lane<Store>& L, int nseq, uint8_t* dst0, uint8_t* op)
 
 // One compressed block.  Returns the bytes produced.
 template <class Store>
-LSR_HD int decode_block_body(Lane<Store>& L, const uint8_t* p, int size, uint8_t* dst0, uint8_t* op, int room) {
+LSR_HD_INL int decode_block_body(Lane<Store>& L, const uint8_t* p, int size, uint8_t* dst0, uint8_t* op, int room) {
   LSR_DEC_STAMP(0);
   LitHeader h;
   const int lu = parse_literals(L, p, size, h);
@@ -933,7 +1038,7 @@ LSR_HD int decode_block_body(Lane<Store>& L, const uint8_t* p, int size, uint8_t
   const int so = seq_open(L, p + lu, size - lu, r);
   if (so < 0) return so;
   LSR_DEC_STAMP(2);
-  if (h.type >= 2 && h.four && r.nseq >= 1 && r.nseq <= kMaxDirectSeq) {
+  if (h.type >= 2 && h.four && r.nseq >= 1 && r.nseq <= kMaxDirectSeq && room <= kMaxDirectRoom) {
     // sequences first: lengths and offsets into the workspace, with the totals checked before anything is written
     int lits = 0, total = 0;
     for (int i = 0; i < r.nseq; ++i) {
@@ -941,12 +1046,13 @@ LSR_HD int decode_block_body(Lane<Store>& L, const uint8_t* p, int size, uint8_t
       uint32_t offset;
       const int rc = seq_next(L, r, lit_len, match_len, offset);
       if (rc < 0) return rc;
-      L.store.ws_set(kSeqBase + 3 * i, static_cast<uint32_t>(lit_len));
-      L.store.ws_set(kSeqBase + 3 * i + 1, static_cast<uint32_t>(match_len));
-      L.store.ws_set(kSeqBase + 3 * i + 2, offset);
       lits += lit_len;
       total += lit_len + match_len;
       if (lits > h.size || total > room) return lits > h.size ? kErrCorrupt : kErrDstSmall;
+      // (both lengths are below 65536 now: a match is at least three bytes and the block at most kMaxDirectRoom)
+      if (match_len < 3) return kErrCorrupt;
+      run_put(L.store, i, static_cast<uint32_t>(lit_len) | (static_cast<uint32_t>(match_len - 3) << 16));
+      L.store.ws_set(kSeqBase + i, offset);
     }
     total += h.size - lits;
     if (total > room) return kErrDstSmall;
@@ -974,7 +1080,7 @@ LSR_HD int decode_block_body(Lane<Store>& L, const uint8_t* p, int size, uint8_t
 // ---- frame ------------------------------------------------------------------------------------------------------------------------
 // One zstd frame src[0, len) -> dst[0, cap).  Returns the decoded size or an error code.
 template <class Store>
-LSR_HD int decode_frame(Lane<Store>& L, const uint8_t* src, int len, uint8_t* dst, int cap) {
+LSR_HD_INL int decode_frame(Lane<Store>& L, const uint8_t* src, int len, uint8_t* dst, int cap) {
   if (len < 6) return kErrCorrupt;
   if (src[0] != 0x28 || src[1] != 0xB5 || src[2] != 0x2F || src[3] != 0xFD) return kErrUnsupported;
   const int fhd = src[4];

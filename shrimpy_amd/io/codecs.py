@@ -510,6 +510,7 @@ def _py_blosc_decode(frame, out: np.ndarray) -> None:
         return
     if nbytes == 0:
         return
+    typesize = typesize or 1            # (a zero in the header: one-byte elements, as the native walker reads it)
     byte_shuffled = bool(flags & _F_SHUFFLE) and typesize > 1
     bit_shuffled = not byte_shuffled and bool(flags & _F_BITSHUFFLE)
     if not 0 < blocksize <= nbytes:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # AddressSanitizer + UndefinedBehaviorSanitizer over the HOST side of liblsrecon -- the host twins, the estimator twins,
-# the blosc frame walker, and the argument checks / launch planning in front of every kernel -- on the CPU, where
+# the blosc frame walker, the device codecs' twins (the kernels' own zstd source compiled for the host), and the argument checks / launch planning in front of every kernel -- on the CPU, where
 # sanitizers run (GPU ASan is not available on the pool):
 #   bash tools/host_sanitize.sh [scratch-dir] [fuzz-seconds]        # from the repo root; no GPU needed (or wanted)
 # The sources are copied to a scratch directory and every translation unit's host side is built there with
@@ -25,7 +25,8 @@ cd "$R"
 export LSR_LIBRARY="$OUT/shrimpy_amd/csrc/liblsrecon.so" LD_PRELOAD="$RT"
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:detect_odr_violation=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 python -m pytest tests/test_host_twins.py tests/test_dynatrack_host.py tests/test_zarr_codecs.py tests/test_host.py \
-       tests/test_preprocessing_mirror.py tests/test_io_cli.py -q -m "not gpu" -p no:cacheprovider | tail -2
+       tests/test_preprocessing_mirror.py tests/test_io_cli.py tests/test_device_codec.py -q -m "not gpu" -p no:cacheprovider | tail -2
 python tools/fuzz_blosc.py --seconds "$SECS"
+python tools/fuzz_device_codec.py --seconds "$SECS"
 python tools/fuzz_host_args.py --seconds "$SECS"
 python tools/fuzz_device_args.py --seconds "$SECS"

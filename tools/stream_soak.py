@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--dir", default=None)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--engine-format", action="store_true",
+                    help="input stores in the acquisition's format (Zarr v3, one blosc-zstd shard per volume, 32 KB blocks): "
+                         "with the CLI's default blosc-zstd output both device codecs are in the loop")
     args = ap.parse_args()
 
     import torch
@@ -58,10 +61,12 @@ def main():
         root = Path(tempfile.mkdtemp(prefix="lsr_soak_", dir=args.dir))
         try:
             keys = [f"A/{p + 1}/0" for p in range(n_p)]
-            with open_ome_zarr(root / "in.zarr", layout="hcs", mode="w", channel_names=["LS"], prefer_iohub=False) as plate:
+            fmt = dict(compress="blosc-zstd", shards="volume", blocksize=32768) if args.engine_format else {}
+            with open_ome_zarr(root / "in.zarr", layout="hcs", mode="w", channel_names=["LS"], prefer_iohub=False,
+                               version="0.5" if args.engine_format else "0.4") as plate:
                 for p, key in enumerate(keys):
                     arr = plate.create_position(*key.split("/")).create_zeros(
-                        "0", shape=(n_t, 1) + raw_shape, dtype=dtype, scale=(1, 1, 0.15, 0.1133, 0.1133))
+                        "0", shape=(n_t, 1) + raw_shape, dtype=dtype, scale=(1, 1, 0.15, 0.1133, 0.1133), **fmt)
                     for t in range(n_t):
                         vol = np.random.default_rng(1000 * rnd + 50 * p + t).integers(90, 900, raw_shape)
                         arr.write_volume(t, 0, vol.astype(dtype))
@@ -81,7 +86,8 @@ def main():
                             bad.append((key, t))
             print(json.dumps({"round": rnd, "raw_shape": raw_shape, "dtype": dtype, "units": n_p * n_t, "rl_iterations": iters,
                               "seconds": round(dt, 3), "units_per_s": round(n_p * n_t / dt, 1), "mismatches": bad[:5],
-                              "n_mismatches": len(bad), "stage_seconds": res.get("stage_seconds")}), flush=True)
+                              "n_mismatches": len(bad), "device_codec": res.get("device_codec"),
+                              "stage_seconds": res.get("stage_seconds")}), flush=True)
             if bad:
                 raise SystemExit(1)
         finally:
