@@ -376,7 +376,11 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
     """Apply ``settings`` to every (position, t, c) volume of ``input_path`` -> ``output_path``.
 
     ``device_codec`` (default: on, ``LSR_DEVICE_CODEC=0`` turns it off): with a blosc-zstd output on a GPU the chunk
-    frames are written by the device (``io/device_codec.py``) and the host stores them as they are.
+    frames are written by the device (``io/device_codec.py``) and the host stores them as they are; an input stored as
+    blosc-zstd frames crosses PCIe compressed and is decoded by the device.  The decoder gives every blosc block to one
+    lane, so a volume takes ~6 ms whatever its size: left to itself (``None``) the run decodes on the device only volumes of
+    at least ``LSR_DEVICE_DECODE_MIN_BLOCKS`` blocks (default 8192 = 256 MB of the acquisition's 32 KB blocks; below that
+    sixteen host threads are faster); ``True`` decodes on the device whatever the size.
     ``on_error="skip"``: see ``pipeline.run_sharded``; skipped units are listed in the result's ``failed`` (all ranks')
     and recorded under ``<output>/.lsr_failed/``.
 
@@ -389,11 +393,13 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
     """
     rank, world, device, created = _distributed()
     try:
+        min_blocks = 0
         if device_codec is None:
             device_codec = os.environ.get("LSR_DEVICE_CODEC", "1") != "0"
+            min_blocks = int(os.environ.get("LSR_DEVICE_DECODE_MIN_BLOCKS", "8192") or 0)
         return _run_store(input_path, output_path, settings, positions, zarr_version, reconstructor_factory,
                           stage_through_pinned, resume, io_backend, compression, rank, world, device, device_codec,
-                          on_error)
+                          on_error, min_blocks)
     finally:
         if created:
             import torch.distributed as dist
@@ -403,7 +409,7 @@ def run_store(input_path: Path, output_path: Path, settings: ReconstructSettings
 
 def _run_store(input_path, output_path, settings, positions, zarr_version, reconstructor_factory,
                stage_through_pinned, resume, io_backend, compression, rank, world, device, device_codec=True,
-               on_error="raise") -> dict:
+               on_error="raise", min_decode_blocks=0) -> dict:
     import torch
 
     from .io.omezarr import as_volume_array, create_level, open_ome_zarr, position_scale
@@ -546,6 +552,12 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
         layout = None
         if device_codec and todo:
             layout = getattr(arrays[todo[0].position], "compressed_layout", lambda *a: None)(todo[0].t, todo[0].c)
+            if layout is not None:
+                blocks = layout["n_frames"] * -(-layout["nbytes"] // layout["blocksize"])
+                if blocks < min_decode_blocks:
+                    logger.info("input chunks decoded on the host: %d blosc blocks per volume, the device decoder pays from %d",
+                                blocks, min_decode_blocks)
+                    layout = None
         from ._lib import LsrUnsupported
 
         attempts = [(frame_bytes, layout)] + ([(None, layout)] if frame_bytes and layout else []) \

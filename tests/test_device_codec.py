@@ -385,8 +385,12 @@ def test_store_to_store_with_device_codecs_equals_the_host_codec_run(tmp_path, d
     settings = ReconstructSettings(
         deskew=DeskewSettings(pixel_size_um=0.1133, scan_step_um=0.15, ls_angle_deg=30.0, keep_overhang=False, average_n_slices=3),
         deconvolution=DeconvolveSettings(iterations=5))
-    res = cli.run_store(tmp_path / "in.zarr", tmp_path / "dev.zarr", settings, compression="blosc-zstd", zarr_version="0.5")
+    res = cli.run_store(tmp_path / "in.zarr", tmp_path / "dev.zarr", settings, compression="blosc-zstd", zarr_version="0.5",
+                        device_codec=True)
     assert res["device_codec"] == {"encode": True, "decode": True} and res["units"] == 6
+    # left to itself the run keeps volumes this small (180 blocks) on the host decoder and still encodes on the device
+    auto = cli.run_store(tmp_path / "in.zarr", tmp_path / "auto.zarr", settings, compression="blosc-zstd", zarr_version="0.5")
+    assert auto["device_codec"] == {"encode": True, "decode": False}
     ref = cli.run_store(tmp_path / "in.zarr", tmp_path / "host.zarr", settings, compression="blosc-zstd", zarr_version="0.5",
                         device_codec=False)
     assert ref["device_codec"] == {"encode": False, "decode": False}
@@ -443,9 +447,10 @@ def test_a_damaged_chunk_is_reported_by_the_device_decoder_and_skipped_on_reques
         deskew=DeskewSettings(pixel_size_um=0.1133, scan_step_um=0.15, ls_angle_deg=30.0, keep_overhang=False, average_n_slices=3),
         deconvolution=DeconvolveSettings(iterations=3))
     with pytest.raises(DecodeError):
-        cli.run_store(tmp_path / "bad.zarr", tmp_path / "stops.zarr", settings, compression="blosc-zstd", zarr_version="0.5")
+        cli.run_store(tmp_path / "bad.zarr", tmp_path / "stops.zarr", settings, compression="blosc-zstd", zarr_version="0.5",
+                      device_codec=True)
     res = cli.run_store(tmp_path / "bad.zarr", tmp_path / "skipped.zarr", settings, compression="blosc-zstd", zarr_version="0.5",
-                        on_error="skip")
+                        on_error="skip", device_codec=True)
     assert res["device_codec"]["decode"] and [(f["position"], f["stage"]) for f in res["failed"]] == [("A/3/0", "load")]
     ref = cli.run_store(tmp_path / "good.zarr", tmp_path / "whole.zarr", settings, compression="blosc-zstd", zarr_version="0.5")
     assert ref["failed"] == []

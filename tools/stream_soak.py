@@ -71,7 +71,9 @@ def main():
                         vol = np.random.default_rng(1000 * rnd + 50 * p + t).integers(90, 900, raw_shape)
                         arr.write_volume(t, 0, vol.astype(dtype))
             t0 = time.perf_counter()
-            res = cli.run_store(root / "in.zarr", root / "out.zarr", settings)
+            # (engine format: both device codecs forced -- left to itself the run would decode volumes this small on the host)
+            res = cli.run_store(root / "in.zarr", root / "out.zarr", settings,
+                                **(dict(compression="blosc-zstd", zarr_version="0.5", device_codec=True) if args.engine_format else {}))
             dt = time.perf_counter() - t0
             rec = VolumeReconstructor(raw_shape, settings, dev)
             bad = []
