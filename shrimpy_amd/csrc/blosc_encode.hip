@@ -336,11 +336,12 @@ struct __attribute__((aligned(16))) TreeScratch {
   HufScratch desc;
 };
 
+constexpr int kHistCopies = 8, kHistCopy = kMaxType * 256 + 4;    // (words)
 inline size_t encode_lds_bytes(int64_t blocksize, int T) {
   const int plane_len = static_cast<int>(blocksize / T);
   const Runs r = stream_runs(huf_stream_len(plane_len, 0));
   const size_t symbuf = size_t(4) * 64 * (r.c + kLanePad);
-  return sizeof(EncShared) + std::max(symbuf, size_t(kWaves) * sizeof(TreeScratch));
+  return sizeof(EncShared) + std::max(std::max(symbuf, size_t(kWaves) * sizeof(TreeScratch)), size_t(kHistCopies) * kHistCopy * 4);
 }
 
 extern __shared__ __attribute__((aligned(16))) uint8_t enc_dyn_lds[];
@@ -372,7 +373,12 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
 
   LSR_ENC_STAMP(0);
   // ---- histograms of all planes: one coalesced pass --------------------------------------------------------------
+  // Eight copies of the counters, a lane adds to copy (lane & 7): in the high planes of float32 data a third of a wave's
+  // symbols are one value, and atomics of one wave on one address run one after another.  The copies lie in the symbol
+  // buffer (not in use yet), kHistCopy words apart so that one symbol's eight counters sit in eight different banks.
+  uint32_t* const hcopy = reinterpret_cast<uint32_t*>(symbuf) + (lane & (kHistCopies - 1)) * kHistCopy;
   for (int i = tid; i < kMaxType * 256; i += kThreads) (&S.hist[0][0])[i] = 0;
+  for (int i = tid; i < kHistCopies * kHistCopy; i += kThreads) reinterpret_cast<uint32_t*>(symbuf)[i] = 0;
   __syncthreads();
   for (int64_t off0 = 0; off0 < bsize; off0 += int64_t(kAhead) * kThreads * 16) {
     uint32_t wa[kAhead][4];
@@ -394,10 +400,16 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
         if (__all(same && s0 == lead)) {
           if (lane == 0) atomicAdd(&S.hist[p][lead], 64u * kPer);
         } else {
-          for (int k = 0; k < nsym; ++k) atomicAdd(&S.hist[p][(s[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
+          for (int k = 0; k < nsym; ++k) atomicAdd(&hcopy[p * 256 + ((s[k >> 2] >> (8 * (k & 3))) & 0xFF)], 1u);
         }
       }
     }
+  }
+  __syncthreads();
+  for (int i = tid; i < T * 256; i += kThreads) {
+    uint32_t c = 0;
+    for (int r = 0; r < kHistCopies; ++r) c += reinterpret_cast<const uint32_t*>(symbuf)[r * kHistCopy + i];
+    (&S.hist[0][0])[i] += c;
   }
   __syncthreads();
 
