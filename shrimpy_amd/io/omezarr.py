@@ -93,6 +93,44 @@ def io_thread_budget(read: int | None = None, write: int | None = None) -> dict:
     return prev
 
 
+_TMPFS_MOUNTS: list[str] | None = None
+
+
+def _on_tmpfs(path) -> bool:
+    """Is ``path`` on a tmpfs mount (``/dev/shm``, a RAM-backed scratch)?  From /proc/mounts, longest prefix."""
+    global _TMPFS_MOUNTS
+    if _TMPFS_MOUNTS is None:
+        mounts = []
+        try:
+            with open("/proc/mounts") as f:
+                for line in f:
+                    parts = line.split()
+                    if len(parts) >= 3:
+                        mounts.append((parts[1].replace("\\040", " "), parts[2] in ("tmpfs", "ramfs")))
+        except OSError:
+            pass
+        _TMPFS_MOUNTS = sorted(mounts, key=lambda m: -len(m[0]))
+    real = os.path.realpath(str(path))
+    for mount, ram in _TMPFS_MOUNTS:
+        if real == mount or real.startswith(mount.rstrip("/") + "/"):
+            return ram
+    return False
+
+
+def _read_through_mapping(path) -> bool:
+    """Copy chunk bytes out of a private read-only mapping instead of ``preadv``?  On tmpfs the FIRST read of a freshly
+    written file through ``read`` runs at 11-15 GB/s however many threads share it (every page is moved to the active
+    LRU list under one lock; a second read: 69 GB/s), through a mapping at 20 GB/s (``tools/probes/shard_read.py``,
+    ``profiles/r05_shard_read.jsonl``; the streamed config-4 run: 0.064 -> 0.059 s per unit).  Used for the compressed
+    chunks of ``read_volume_frames`` only: the 64 uncompressed chunk files of a volume, one reader thread each, are
+    SLOWER through mappings (0.117 against 0.093 s per 2.15 GB volume).  On a real file system ``preadv`` stays: a
+    mapping there turns an I/O error into SIGBUS.  ``LSR_READ_MMAP=0|1`` overrides."""
+    env = os.environ.get("LSR_READ_MMAP")
+    if env in ("0", "1"):
+        return env == "1"
+    return _on_tmpfs(path)
+
+
 def _io_threads(role: str) -> int:
     env = os.environ.get("LSR_IO_THREADS")          # "r,w": measurement override
     if env:
@@ -843,16 +881,37 @@ class ZarrArray:
         if at > buf.size:
             raise ValueError(f"the compressed chunks take {at} bytes, the buffer holds {buf.size}")
 
+        import mmap
+
+        maps: dict = {}
+        maps_lock = threading.Lock()
+
+        def mapping(path):
+            with maps_lock:
+                m = maps.get(path)
+                if m is None:
+                    with open(path, "rb") as f:
+                        m = maps[path] = np.frombuffer(mmap.mmap(f.fileno(), 0, prot=mmap.PROT_READ), dtype=np.uint8)
+                return m
+
+        mapped = bool(sources) and _read_through_mapping(sources[0][1])
+
         def read_one(item):
             i, path, off, nb = item
             dest = memoryview(buf[int(table[i, 0]):int(table[i, 0]) + nb])
-            with open(path, "rb", buffering=0) as f:
-                got = 0
-                while got < nb:
-                    n = os.preadv(f.fileno(), [dest[got:]], off + got)
-                    if n <= 0:
-                        raise OSError(f"{path}: short read of chunk {i}")
-                    got += n
+            if mapped:
+                src = mapping(path)
+                if off + nb > src.size:
+                    raise OSError(f"{path}: chunk {i} runs past the end of the file")
+                np.copyto(buf[int(table[i, 0]):int(table[i, 0]) + nb], src[off:off + nb])     # (GIL released)
+            else:
+                with open(path, "rb", buffering=0) as f:
+                    got = 0
+                    while got < nb:
+                        n = os.preadv(f.fileno(), [dest[got:]], off + got)
+                        if n <= 0:
+                            raise OSError(f"{path}: short read of chunk {i}")
+                        got += n
             if crc:
                 if nb < 4 or int(crc32c(dest[:nb - 4])) != int.from_bytes(dest[nb - 4:nb], "little"):
                     raise ValueError(f"{path}: chunk {i}: CRC-32C mismatch")

@@ -246,6 +246,41 @@ def test_decoder_twin_reads_c_blosc_golden_frames(golden_dir):
     assert taken >= 4
 
 
+@pytest.mark.parametrize("shards", ["volume", None])
+@pytest.mark.parametrize("through_mapping", ["0", "1"])
+def test_a_stored_volume_read_as_frames_decodes_to_the_volume(tmp_path, monkeypatch, shards, through_mapping):
+    """``ZarrArray.read_volume_frames``: the compressed chunks of a volume in the acquisition's format, as they lie in the
+    shard (or in their chunk files), gathered into one buffer with an offset table -- by ``preadv`` and through a mapping
+    (what the reader does on tmpfs) -- decode, through the decoder twin, to the volume that was written; a volume that was
+    never written gives absent chunks; a buffer that is too small is refused."""
+    from shrimpy_amd.io.device_codec import decode_frames_host
+    from shrimpy_amd.io.omezarr import as_volume_array, open_ome_zarr
+
+    monkeypatch.setenv("LSR_READ_MMAP", through_mapping)
+    shape = (70, 24, 96)                                   # three z-chunks of 32 planes, the last one ragged
+    rng = np.random.default_rng(11)
+    vol = (100 + rng.poisson(40, shape)).astype(np.uint16)
+    with open_ome_zarr(tmp_path / "in.zarr", layout="hcs", mode="w", channel_names=["LS"], prefer_iohub=False, version="0.5") as plate:
+        arr = plate.create_position("A", "1", "0").create_zeros("0", shape=(2, 1) + shape, dtype="uint16", compress="blosc-zstd",
+                                                                shards=shards, blocksize=32768)
+        arr.write_volume(0, 0, vol)
+    with open_ome_zarr(tmp_path / "in.zarr", prefer_iohub=False) as plate:
+        a = as_volume_array(dict(plate.positions())["A/1/0"]["0"])
+        lay = a.compressed_layout(0, 0)
+        assert lay is not None and lay["n_frames"] == 3 and lay["typesize"] == 2
+        buf = np.zeros(3 * (lay["nbytes"] + 4096), np.uint8)
+        cv = a.read_volume_frames(0, 0, out=buf)
+        frames = [buf[o:o + n].tobytes() for o, n in cv.table]
+        assert all(frames) and cv.used <= buf.size
+        got = decode_frames_host(frames, lay["nbytes"], lay["blocksize"], 2, 3 * lay["nbytes"])
+        assert np.array_equal(got[:vol.nbytes].view(np.uint16).reshape(shape), vol)
+        assert np.array_equal(a.read_volume(0, 0), vol)
+        empty = a.read_volume_frames(1, 0, out=buf)        # (t = 1 was never written)
+        assert [int(n) for _, n in empty.table] == [0, 0, 0]
+        with pytest.raises(ValueError):
+            a.read_volume_frames(0, 0, out=np.zeros(1000, np.uint8))
+
+
 @pytest.mark.parametrize("dtype,blocksize", [("uint16", 32768), ("uint16", 0), ("float32", 0), ("float32", 65536), ("uint8", 4096)])
 def test_decoder_twin_on_volumes_of_frames(dtype, blocksize):
     """A volume as consecutive chunk frames -- written by the host zstd encoder (what a real store holds) and by this
