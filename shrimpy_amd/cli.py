@@ -583,6 +583,9 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
                              stager=stager, process_takes_unit=True, on_error=on_error)
     finally:
         if stager is not None:
+            times = stager.gpu_times() if hasattr(stager, "gpu_times") else None
+            if times:
+                logger.warning("GPU time per unit by HIP events: %s", times)
             stager.close()
         for s in (src, dst):
             close = getattr(s, "close", None)

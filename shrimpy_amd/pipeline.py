@@ -12,6 +12,7 @@ CPU tests) carries only the timing barrier and the optional final gather of resu
 from __future__ import annotations
 
 import logging
+import os
 import time
 
 from dataclasses import dataclass, field
@@ -367,9 +368,13 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None, f
     times = {} if times is None else times
     clock = time.perf_counter
 
+    per_unit = [] if os.environ.get("LSR_STAGE_EVENTS") == "1" else None     # [(key, ms), ...] of the caller's clocks
+
     def spent(key, since):
         now = clock()
         times[key] = times.get(key, 0.0) + (now - since)
+        if per_unit is not None and key in ("wait_load", "process", "wait_store", "stage_out"):
+            per_unit.append((key, round((now - since) * 1e3, 1)))
         return now
 
     def stage(i):
@@ -427,6 +432,14 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None, f
         while submitted < min(depth - 1, len(mine)):
             ahead.append(loader.submit(stage, submitted))
             submitted += 1
+        # while the first unit is being read: whatever the card does once per run (code objects of the codec kernels,
+        # their LDS limits) -- on a 12-unit run that is a tenth of the wall time when the first unit has to pay it
+        warm = getattr(stager, "warm_up", None)
+        if warm is not None and mine:
+            try:
+                warm()
+            except Exception as exc:  # noqa: BLE001 -- a warm-up is never worth a failed run
+                logger.debug("stager warm-up skipped: %s", exc)
         for i in range(len(mine)):
             t = clock()
             slot = None
@@ -495,6 +508,8 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None, f
         collector.shutdown(wait=True)
         storer.shutdown(wait=True)
         stager.drain()
+        if per_unit:
+            logger.warning("caller's clocks in order, ms: %s", per_unit)
 
 
 def gather_to_rank0(local: Iterable, n_total: int, keep_on_host: bool = False):

@@ -18,6 +18,8 @@ PyTorch is the plumbing here (pinned allocations, streams, events); there is no 
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -67,19 +69,23 @@ class VolumeStager:
     """
 
     def __init__(self, raw_shape, raw_dtype, out_shape, device, depth: int = 2, pin: str = "exact",
-                 encode_frame_bytes: int | None = None, encode_blocksize: int = 0, decode_layout: dict | None = None):
+                 encode_frame_bytes: int | None = None, encode_blocksize: int = 0, decode_layout: dict | None = None,
+                 codec_streams: str | None = None):
         """``depth`` slots each way (default 2; more only helps when load times vary a lot).
 
         ``encode_frame_bytes``: the result leaves the device as blosc-zstd chunk frames of that many decoded bytes
-        each (``csrc/blosc_encode.hip``): ``stage_out`` runs the encoder on the download stream, ``collect`` returns
+        each (``csrc/blosc_encode.hip``): ``stage_out`` runs the encoder behind the unit's kernels, ``collect`` returns
         an :class:`EncodedVolume` whose frames the writer stores as they are -- the host never sees the float32
         volume and never runs zstd.
 
         ``decode_layout`` (``dict(nbytes, blocksize, typesize)``, from ``ZarrArray.compressed_layout``): the raw stack
         arrives as the blosc-zstd chunk frames of the store.  ``host_in`` is then a pinned BYTE buffer the loader fills
         with ``ZarrArray.read_volume_frames`` (file reads only), ``stage_in`` takes the resulting ``CompressedVolume``,
-        uploads the compressed bytes and runs the decoder (``csrc/blosc_decode.hip``) on the upload stream, and
+        uploads the compressed bytes, the decoder (``csrc/blosc_decode.hip``) runs in front of the unit's kernels, and
         ``acquire`` checks the decoder's status word before the kernels use the stack.
+
+        ``codec_streams`` (``LSR_CODEC_STREAMS``): ``"serial"`` (default) launches decoder and encoder on the compute
+        stream, in line with the unit's kernels; ``"overlap"`` on streams of their own (see the comment at ``_serial``).
 
         ``pin``: ``"exact"`` takes page-locked allocations of exactly the slot size from the HIP runtime
         (``lsr_pinned_alloc`` = ``hipHostMalloc``) -- torch's caching host allocator rounds every pinned
@@ -134,8 +140,8 @@ class VolumeStager:
                                                decode_layout["typesize"], self.device)
             cap = self._decoder.comp_capacity + 16 * self._decoder.n_frames
             in_slot_shape, in_slot_dtype = (cap,), torch.uint8
-            self._comp_dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
-            self._table_in_dev = torch.empty((self._decoder.n_frames, 2), dtype=torch.int64, device=self.device)
+            self._comp_dev = [torch.empty(cap, dtype=torch.uint8, device=self.device) for _ in range(depth)]
+            self._table_in_dev = [torch.empty((self._decoder.n_frames, 2), dtype=torch.int64, device=self.device) for _ in range(depth)]
             self._table_in_host = [torch.empty((self._decoder.n_frames, 2), dtype=torch.int64).pin_memory() for _ in range(depth)]
             self._status_host = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(depth)]
         with torch.cuda.device(self.device):
@@ -147,7 +153,24 @@ class VolumeStager:
         # the encoder's launches get a stream of their own: on the download stream the frames of unit i + 1 (queued as soon
         # as its kernels are launched) would sit in front of the download of unit i (queued only once its frame table is
         # on the host) and hold it back by a whole unit of kernels
-        self._enc = torch.cuda.Stream(self.device) if self._encoders is not None else None
+        # codec_streams: "serial" (default) runs the decoder and the encoder on the COMPUTE stream, in line with the unit's
+        # kernels; "overlap" gives them streams of their own beside the kernels.  Neither codec kernel can share a CU
+        # with the fused RL kernel (143 KB of LDS and 247 of 256 VGPRs per lane are taken), so "beside" means that
+        # decode / encode workgroups and RL workgroups take CUs away from each other: traced (tools/probes/gpu_timeline.py,
+        # profiles/r05_gpu_timeline.txt) an RL launch then takes 3.2 ms instead of 1.43, a decode 21 ms instead of 6.9, and
+        # the GPU is busy 66 ms per config-4 unit for 45 ms of work.  The copies stay on their own streams either way.
+        if codec_streams is None:
+            codec_streams = os.environ.get("LSR_CODEC_STREAMS", "serial")
+        if codec_streams not in ("serial", "overlap"):
+            raise ValueError("codec_streams must be 'serial' or 'overlap'")
+        self._serial = codec_streams == "serial"
+        self._enc = torch.cuda.Stream(self.device) if self._encoders is not None and not self._serial else None
+        self._pending_decode = [None] * depth
+        # LSR_STAGE_EVENTS=1: HIP events around the decoder, the unit's kernels and the encoder (serial mode), reported by
+        # gpu_times() -- what the card spends on a unit without a profiler attached (rocprofv3 turns the device -> host
+        # copies into shader kernels that starve the decoder: a decode then reads 28 ms instead of 7)
+        self._ev = [] if os.environ.get("LSR_STAGE_EVENTS") == "1" else None
+        self._ev_open = {}
         self._uploaded = [None] * depth      # recorded on `up` after the H2D copy of the slot
         self._consumed = [None] * depth      # recorded on the compute stream when the raw slot is dead
         self._downloaded = [None] * depth    # recorded on `down` after the D2H copy of the slot
@@ -205,12 +228,14 @@ class VolumeStager:
                 if self._consumed[slot] is not None:
                     self._up.wait_event(self._consumed[slot])
                 used = max(int(data.used), 1)
-                self._comp_dev[:used].copy_(self._host_in[slot][:used], non_blocking=True)
-                self._table_in_dev.copy_(self._table_in_host[slot], non_blocking=True)
-                self._decoder.decode(self._comp_dev, int(data.used), self._table_in_dev, self._dev_in[slot])
-                self._status_host[slot].copy_(self._decoder.status, non_blocking=True)
+                self._comp_dev[slot][:used].copy_(self._host_in[slot][:used], non_blocking=True)
+                self._table_in_dev[slot].copy_(self._table_in_host[slot], non_blocking=True)
+                if not self._serial:
+                    self._decoder.decode(self._comp_dev[slot], int(data.used), self._table_in_dev[slot], self._dev_in[slot])
+                    self._status_host[slot].copy_(self._decoder.status, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self._up)
+            self._pending_decode[slot] = int(data.used) if self._serial else None
             self._uploaded[slot] = ev
             return slot
         if data is not None and not (isinstance(data, np.ndarray) and np.shares_memory(data, view)):
@@ -231,11 +256,24 @@ class VolumeStager:
         """Device tensor of the slot; the current stream waits (on the GPU) for its upload."""
         import torch
 
-        torch.cuda.current_stream(self.device).wait_event(self._uploaded[slot])
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self._uploaded[slot])
         if self._decoder is not None:
+            done = self._uploaded[slot]
+            if self._pending_decode[slot] is not None:
+                # serial mode: the decoder runs HERE, on the compute stream, between the previous unit's kernels and this
+                # unit's -- see __init__ (codec_streams)
+                e0 = self._mark(cur)
+                self._decoder.decode(self._comp_dev[slot], self._pending_decode[slot], self._table_in_dev[slot], self._dev_in[slot])
+                self._status_host[slot].copy_(self._decoder.status, non_blocking=True)
+                self._pending_decode[slot] = None
+                done = torch.cuda.Event(enable_timing=self._ev is not None)
+                done.record(cur)
+                if self._ev is not None:
+                    self._ev_open[slot] = (e0, done)
             # the decoder's verdict on this unit's chunks: known once its launches have run (the kernels of this unit
             # could not start before that anyway)
-            self._uploaded[slot].synchronize()
+            done.synchronize()
             self._decoder.check(int(self._status_host[slot].item()))
         return self._dev_in[slot]
 
@@ -264,18 +302,22 @@ class VolumeStager:
             if result.untyped_storage().data_ptr() == dev_slot.untyped_storage().data_ptr():
                 result = result.clone()
                 break
-        done = torch.cuda.Event()
+        done = torch.cuda.Event(enable_timing=self._ev is not None)
         done.record(torch.cuda.current_stream(self.device))
         if self._encoders is not None:
             # frames are written on the download stream (beside the next unit's kernels); only the (offset, size)
             # table comes down now -- collect() then copies exactly the compressed bytes
-            with torch.cuda.stream(self._enc):
-                self._enc.wait_event(done)
+            enc = self._enc if self._enc is not None else torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(enc):
+                if self._enc is not None:
+                    enc.wait_event(done)
+                    result.record_stream(enc)
                 _, table = self._encoders[slot].encode(result.contiguous())
-                result.record_stream(self._enc)
                 self._table_host[slot].copy_(table, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self._enc)
+                ev = torch.cuda.Event(enable_timing=self._ev is not None)
+                ev.record(enc)
+                if self._ev is not None and slot in self._ev_open:
+                    self._ev.append(self._ev_open.pop(slot) + (done, ev))
             self._table_ready[slot] = ev
             self._downloaded[slot] = None
             return
@@ -308,6 +350,48 @@ class VolumeStager:
             return EncodedVolume([host[int(o):int(o) + int(n)] for o, n in table], self.encode_frame_bytes, self.out_shape)
         self._downloaded[slot].synchronize()
         return self._host_out[slot].numpy()
+
+    def warm_up(self) -> None:
+        """One launch of the decoder (on a volume of absent chunks) and of the encoder (on zeros) before the first unit
+        arrives, on the streams the real launches will use (which therefore follow them in stream order): the kernels'
+        code objects are loaded and their LDS limits set while the loader reads -- the first unit of a config-4 run took
+        144 ms on the caller's clock without this, 45 ms with it."""
+        import torch
+
+        cur = torch.cuda.current_stream(self.device)
+        if self._decoder is not None:
+            with torch.cuda.stream(cur if self._serial else self._up):
+                self._table_in_dev[0].zero_()
+                self._decoder.decode(self._comp_dev[0], 0, self._table_in_dev[0], self._dev_in[0])
+        if self._encoders is not None:
+            zeros = torch.zeros(self.out_shape, dtype=torch.float32, device=self.device)
+            enc = cur if self._enc is None else self._enc
+            with torch.cuda.stream(enc):
+                if enc is not cur:
+                    enc.wait_stream(cur)
+                    zeros.record_stream(enc)
+                self._encoders[0].encode(zeros)
+
+    def _mark(self, stream):
+        if self._ev is None:
+            return None
+        import torch
+
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        return e
+
+    def gpu_times(self) -> dict | None:
+        """With ``LSR_STAGE_EVENTS=1`` (serial codec streams, decoder and encoder in use): median milliseconds the card
+        spent per unit in the decoder, in the unit's kernels and in the encoder, by HIP events on the compute stream."""
+        if not self._ev:
+            return None
+        self.drain()
+        rows = np.array([[a.elapsed_time(b), b.elapsed_time(c), c.elapsed_time(d)] for a, b, c, d in self._ev])
+        med = np.median(rows, axis=0)
+        return {"per_unit_gpu_ms [decode, kernels, encode]": [[round(float(v), 1) for v in r] for r in rows],
+                "units": len(rows), "decode_ms": round(float(med[0]), 2), "kernels_ms": round(float(med[1]), 2),
+                "encode_ms": round(float(med[2]), 2), "sum_ms": round(float(med.sum()), 2)}
 
     def drain(self) -> None:
         self._up.synchronize()
