@@ -178,7 +178,16 @@ int64_t encode_block_host(const uint8_t* src, int64_t valid, int64_t bsize, int 
   for (int64_t i = 0; i < bsize; ++i) planes[(i % T) * plane_len + i / T] = i < valid ? src[i] : 0;
   std::vector<PlaneCode> pcs(static_cast<size_t>(T));
   bool any = false;
+  const int per = 16 / T;                       // elements of one 16-byte vector of the block
   for (int p = 0; p < T; ++p) {
+    if (plane_len >= kSampleMinPlane) {         // hopeless on the sample: raw, and never counted (huf_hopeless_sample)
+      uint32_t sc[256] = {0};
+      uint64_t n = 0, coll = 0;
+      for (int i = 0; i < plane_len; ++i)
+        if ((i / per) % kSampleEvery == 0) { ++sc[planes[size_t(p) * plane_len + i]]; ++n; }
+      for (int v = 0; v < 256; ++v) coll += uint64_t(sc[v]) * (sc[v] ? sc[v] - 1 : 0);
+      if (huf_hopeless_sample(coll, n)) { pcs[p].mode = kPlaneRaw; pcs[p].desc_size = 0; continue; }
+    }
     uint32_t count[256] = {0};
     for (int i = 0; i < plane_len; ++i) ++count[planes[size_t(p) * plane_len + i]];
     build_plane_code_host(count, plane_len, pcs[p]);
@@ -326,6 +335,7 @@ struct __attribute__((aligned(16))) EncShared {
   unsigned long long sum_sq[kMaxType];
   int mode[kMaxType], desc_size[kMaxType], ns[kMaxType], max_bits[kMaxType], rle[kMaxType];
   int stream_bytes[4];
+  int skip[kMaxType];      // the plane is hopeless on the sample: raw, not counted
   int pos;
 };
 // the tree scratch of the waves overlays the symbol buffer (the code tables are finished before a plane is staged)
@@ -354,6 +364,10 @@ __device__ long long lsr_enc_probe_cycles[1024 * 16];
 #define LSR_ENC_STAMP(k) do { } while (0)
 #endif
 
+// (Step 2, the two-queue merge, stays zstd_huf.hpp's: one lane, queue heads in registers, ~620 cycles per merge against
+// LDS.  Two wave-uniform versions with the queues spread over the lanes of registers were measured and lost: with scalar
+// branches 920 cycles per merge -- 24 taken branches --, branch-free with eight readlanes and scalar selects 760: a chain of
+// ~100 dependent scalar instructions is no faster than five dependent LDS round trips.  profiles/r05_encode_phases.txt)
 template <int T>
 __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
   static_assert(T <= kMaxType && kMaxType <= kWaves, "one wave per plane");
@@ -380,6 +394,35 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
   for (int i = tid; i < kMaxType * 256; i += kThreads) (&S.hist[0][0])[i] = 0;
   for (int i = tid; i < kHistCopies * kHistCopy; i += kThreads) reinterpret_cast<uint32_t*>(symbuf)[i] = 0;
   __syncthreads();
+  // the sample first (huf_hopeless_sample): a plane that is noise on one vector in sixteen is stored raw and not counted
+  // -- for a float32 result that is the two low mantissa planes, i.e. half of the pass's LDS atomics
+  if (tid < kMaxType) S.skip[tid] = 0;
+  if (plane_len >= kSampleMinPlane) {
+    for (int64_t off = int64_t(tid) * 16 * kSampleEvery; off < bsize; off += int64_t(kThreads) * 16 * kSampleEvery) {
+      uint32_t w[4] = {0, 0, 0, 0};
+      load_block16(blk, off, valid, w);
+      const int nsym = static_cast<int>(imin64(16, bsize - off)) / T;
+      for (int p = 0; p < T; ++p) {
+        uint32_t s[4];
+        plane_symbols<T>(w, p, s);
+        for (int k = 0; k < nsym; ++k) atomicAdd(&S.hist[p][(s[k >> 2] >> (8 * (k & 3))) & 0xFF], 1u);
+      }
+    }
+    __syncthreads();
+    if (wave < T) {
+      unsigned long long n = 0, coll = 0;
+      for (int q = 0; q < 4; ++q) {
+        const unsigned long long c = S.hist[wave][lane + 64 * q];
+        n += c;
+        coll += c * (c ? c - 1 : 0);
+      }
+      for (int d = 32; d > 0; d >>= 1) { n += __shfl_xor(n, d); coll += __shfl_xor(coll, d); }
+      if (lane == 0) S.skip[wave] = huf_hopeless_sample(coll, n) ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < kMaxType * 256; i += kThreads) (&S.hist[0][0])[i] = 0;
+    __syncthreads();
+  }
   for (int64_t off0 = 0; off0 < bsize; off0 += int64_t(kAhead) * kThreads * 16) {
     uint32_t wa[kAhead][4];
     load_ahead(blk, off0, bsize, valid, tid, wa);
@@ -390,6 +433,7 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
       const uint32_t* w = wa[u];
       const int nsym = in ? static_cast<int>(imin64(16, bsize - off)) / T : 0;
       for (int p = 0; p < T; ++p) {
+        if (S.skip[p]) continue;
         uint32_t s[4];
         plane_symbols<T>(w, p, s);
         // one atomic for the whole wave when all its symbols of this plane agree (the exponent plane of float32 data)
@@ -417,42 +461,88 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
   // ---- code tables: wave w builds plane w (steps 1-8 of zstd_huf.hpp; the per-element steps on the 64 lanes) ------
   TreeScratch& W = *reinterpret_cast<TreeScratch*>(symbuf + size_t(wave) * sizeof(TreeScratch));
   const int pw = wave;
-  const bool own = pw < T;
+  const bool own = pw < T && !S.skip[pw < T ? pw : 0];
+  if (pw < T && !own && lane == 0) {             // hopeless on the sample: raw
+    S.mode[pw] = kPlaneRaw;
+    S.desc_size[pw] = 0;
+    S.ns[pw] = 0;
+    S.payload_bits[pw] = 0;
+    S.max_bits[pw] = 0;
+  }
   const uint32_t* const count = S.hist[own ? pw : 0];
+  // Steps 1 and 7 of zstd_huf.hpp are O(256) loops per symbol there (the host twin, and what defines the result); here
+  // the wave does them with 64 lanes at once -- a bitonic sort of the 256 (count, symbol) keys for the rank order, ballots
+  // for "symbols below me with my length" -- and only for planes that will be coded: the loops were two thirds of the
+  // kernel's VALU instructions.
+  uint32_t cnt4[4];
+  int ns;
+  bool coded;
   {
-    int present = 0;
+    int present = 0, only = 0;
+    unsigned long long sq = 0;
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = lane + 64 * q;
-      const int r = own ? huf_rank_of(count, i) : -1;
-      if (r >= 0) W.order[r] = static_cast<uint16_t>(i);
-      present += __popcll(__ballot(r >= 0));
+      cnt4[q] = own ? count[i] : 0;
+      const unsigned long long m = __ballot(cnt4[q] != 0);
+      if (m) only = q * 64 + __builtin_ctzll(m);
+      present += __popcll(m);
+      sq += static_cast<unsigned long long>(cnt4[q]) * cnt4[q];
       if (own) { S.nbits[pw][i] = 0; S.ct[pw][i] = 0; }
     }
-    unsigned long long sq = 0;
-    for (int q = 0; q < 4; ++q) {
-      const unsigned long long c = own ? count[lane + 64 * q] : 0;
-      sq += c * c;
-    }
-    for (int d = 32; d > 0; d >>= 1) sq += __shfl_down(sq, d);
+    for (int d = 32; d > 0; d >>= 1) sq += __shfl_xor(sq, d);
+    ns = present;
+    coded = own && ns >= 2 && plane_len >= kMinHufPlane && !huf_hopeless(sq, static_cast<uint64_t>(plane_len));
     if (own && lane == 0) {
       S.ns[pw] = present;
-      S.mode[pw] = kPlaneRaw;
+      S.mode[pw] = ns == 1 ? kPlaneRle : kPlaneRaw;
+      S.rle[pw] = only;
       S.desc_size[pw] = 0;
       S.payload_bits[pw] = 0;
       S.max_bits[pw] = 0;
       S.sum_sq[pw] = sq;
     }
     if (own && lane < kDepthSlots) S.per_depth[pw][lane] = 0;
-  }
-  __syncthreads();
-  const int ns = own ? S.ns[pw] : 0;
-  const bool coded = own && ns >= 2 && plane_len >= kMinHufPlane &&
-                     !huf_hopeless(S.sum_sq[own ? pw : 0], static_cast<uint64_t>(plane_len));
-  if (coded)
-    for (int k = lane; k < ns; k += 64) W.node_cnt[k] = count[W.order[k]];
-  if (own && ns == 1 && lane == 0) {
-    S.mode[pw] = kPlaneRle;
-    S.rle[pw] = W.order[0];
+    if (coded) {
+      // ascending (count, symbol); absent symbols sort last.  Element e = q * 64 + lane.
+      uint32_t key[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) key[q] = cnt4[q] ? (cnt4[q] << 8 | static_cast<uint32_t>(lane + 64 * q)) : 0xFFFFFFFFu;
+#pragma unroll
+      for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          if (j >= 64) {
+            const int jq = j >> 6;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (q & jq) continue;
+              const bool up = ((q * 64) & k) == 0;              // (k >= 128 here: the direction does not depend on the lane)
+              const uint32_t a = key[q], b = key[q | jq];
+              const bool swap = (a > b) == up;
+              key[q] = swap ? b : a;
+              key[q | jq] = swap ? a : b;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t other = static_cast<uint32_t>(__shfl_xor(static_cast<int>(key[q]), j));
+              const bool up = ((q * 64 + lane) & k) == 0, lower = (lane & j) == 0;
+              const uint32_t lo = key[q] < other ? key[q] : other, hi = key[q] < other ? other : key[q];
+              key[q] = lower == up ? lo : hi;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = q * 64 + lane;
+        if (e < ns) {
+          W.order[e] = static_cast<uint16_t>(key[q] & 0xFF);
+          W.node_cnt[e] = key[q] >> 8;
+        }
+      }
+    }
   }
   __syncthreads();
   LSR_ENC_STAMP(2);
@@ -471,21 +561,73 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
     for (int k = lane; k < ns; k += 64) S.nbits[pw][W.order[k]] = static_cast<uint8_t>(huf_length_of_rank(S.per_depth[pw], k));
   __syncthreads();
   if (coded) {
+    int len4[4], below[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) len4[q] = S.nbits[pw][lane + 64 * q];
+    const int top = S.max_bits[pw];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int l = 1; l <= top; ++l) {
+      int base = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned long long m = __ballot(len4[q] == l);
+        if (len4[q] == l) below[q] = base + __popcll(m & lt);
+        base += __popcll(m);
+      }
+    }
     uint32_t bits = 0;
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = lane + 64 * q;
-      const uint32_t e = huf_code_of(S.nbits[pw], S.first[pw], i);
+      const uint32_t e = len4[q] ? static_cast<uint32_t>(S.first[pw][len4[q]] + below[q]) | static_cast<uint32_t>(len4[q]) << 16 : 0u;
       S.ct[pw][i] = e;
-      bits += count[i] * (e >> 16);
+      bits += cnt4[q] * (e >> 16);
     }
     atomicAdd(&S.payload_bits[pw], bits);
   }
   __syncthreads();
   LSR_ENC_STAMP(4);
-  if (coded && lane == 0) {
-    const int ds = huf_write_description(S.nbits[pw], S.max_bits[pw], S.desc[pw], W.desc);
-    S.desc_size[pw] = ds;
-    if (ds > 0 && huf_pays(plane_len, S.payload_bits[pw], ds)) S.mode[pw] = kPlaneHuf;
+  // step 8: the weights and their histogram with all lanes, the FSE stream (more than 128 weights) by one lane, the
+  // chosen form's bytes with all lanes again
+  int nw = 0;
+  if (coded) {
+    int w4[4];
+    unsigned long long present[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int l = S.nbits[pw][lane + 64 * q];
+      present[q] = __ballot(l != 0);
+      w4[q] = l ? S.max_bits[pw] + 1 - l : 0;
+    }
+    const int last = present[3] ? 255 - __builtin_clzll(present[3]) : present[2] ? 191 - __builtin_clzll(present[2])
+                   : present[1] ? 127 - __builtin_clzll(present[1]) : present[0] ? 63 - __builtin_clzll(present[0]) : 0;
+    nw = last;                                        // (the last present symbol's weight is implied)
+    int hist_mine = 0;                                // lane s < 13 ends up with the count of weight s
+    for (int v = 0; v < 13; ++v) {
+      int n = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
+        n += __popcll(__ballot(i < nw && w4[q] == v));
+      }
+      if (lane == v) hist_mine = n;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (lane + 64 * q < nw) W.desc.w[lane + 64 * q] = static_cast<uint8_t>(w4[q]);
+    if (lane < 13) W.desc.hist[lane] = hist_mine;
+  }
+  __syncthreads();
+  if (coded && lane == 0) S.stream_bytes[pw] = nw >= 1 ? huf_description_body(nw, W.desc) : -1;   // (a slot free until the plane loop)
+  __syncthreads();
+  if (coded) {
+    const int fse_size = S.stream_bytes[pw];
+    const int ds = nw >= 1 ? huf_description_size(nw, fse_size) : -1;
+    for (int i = lane; i < ds; i += 64) S.desc[pw][i] = huf_description_byte(i, nw, fse_size, W.desc);
+    if (lane == 0) {
+      S.desc_size[pw] = ds;
+      if (ds > 0 && huf_pays(plane_len, S.payload_bits[pw], ds)) S.mode[pw] = kPlaneHuf;
+    }
   }
   __syncthreads();
 

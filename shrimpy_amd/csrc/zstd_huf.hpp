@@ -308,53 +308,62 @@ LSR_HD int fse_encode_weights(const FseEnc& t, const uint8_t* w, int n, int log,
   return bit_close(out, true);
 }
 
-// ---- step 8 (serial): the Huffman tree description ----------------------------------------------------------------------
-// nbits[256] / max_bits as built above.  Writes the description into hdr (kHufHeaderMax bytes) and returns its size, or
-// -1 when the weights can be written neither as nibbles (more than 128 of them) nor as an FSE stream below 128 bytes.
-LSR_HD int huf_write_description(const uint8_t* nbits, int max_bits, uint8_t* hdr, HufScratch& scratch) {
+// ---- step 8: the Huffman tree description ---------------------------------------------------------------------------------
+// nbits[256] / max_bits as built above.  Three parts, so that the device can run the first and the last with all lanes:
+//   (a) huf_weights: weights of symbols 0 .. last - 1 (the last present symbol's is implied) and their histogram;
+//   (b) huf_description_body (serial): more than 128 weights -> the FSE form into scratch.tmp, its size (or -1);
+//   (c) huf_description_size / huf_description_byte: which form is written, and byte i of it.
+// huf_write_description = the three in a row: the description in hdr (kHufHeaderMax bytes), its size, or -1 when the
+// weights can be written neither as nibbles (more than 128 of them) nor as an FSE stream below 128 bytes.
+LSR_HD int huf_weight_count(const uint8_t* nbits) {
   int last = 255;
   while (last > 0 && nbits[last] == 0) --last;
-  const int nw = last;                       // weights of symbols 0 .. last - 1; the last one is implied
-  if (nw < 1) return -1;
-  uint8_t* const w = scratch.w;
-  uint8_t* const tmp = scratch.tmp;
-  int* const hist = scratch.hist;
-  int* const norm = scratch.norm;
-  for (int s = 0; s < 13; ++s) hist[s] = 0;
+  return last;
+}
+LSR_HD void huf_weights(const uint8_t* nbits, int max_bits, int nw, HufScratch& scratch) {
+  for (int s = 0; s < 13; ++s) scratch.hist[s] = 0;
   for (int s = 0; s < nw; ++s) {
-    w[s] = nbits[s] ? static_cast<uint8_t>(max_bits + 1 - nbits[s]) : 0;
-    ++hist[w[s]];
+    scratch.w[s] = nbits[s] ? static_cast<uint8_t>(max_bits + 1 - nbits[s]) : 0;
+    ++scratch.hist[scratch.w[s]];
   }
-  int fse_size = -1;
+}
+LSR_HD int huf_description_body(int nw, HufScratch& scratch) {
   // up to 128 weights fit the nibble form (at most 64 bytes; an FSE stream would save a few dozen of them per plane of
   // tens of kilobytes -- not worth ~250 dependent steps of one lane); more than 128 need the FSE form
-  if (nw > 128) {
-    int top = 0;
-    if (fse_normalise_weights(hist, nw, norm, &top)) {
-      BitOut head;
-      bit_init(head, tmp, 127);
-      fse_write_ncount(head, norm, top, kWeightLog);
-      const int hb = bit_close(head, false);
-      if (hb > 0) {
-        fse_build_enc(scratch.enc, norm, top, kWeightLog);
-        const int body = fse_encode_weights(scratch.enc, w, nw, kWeightLog, tmp + hb, 127 - hb);
-        if (body > 0) fse_size = hb + body;
-      }
-    }
-  }
+  if (nw <= 128) return -1;
+  int top = 0;
+  if (!fse_normalise_weights(scratch.hist, nw, scratch.norm, &top)) return -1;
+  BitOut head;
+  bit_init(head, scratch.tmp, 127);
+  fse_write_ncount(head, scratch.norm, top, kWeightLog);
+  const int hb = bit_close(head, false);
+  if (hb <= 0) return -1;
+  fse_build_enc(scratch.enc, scratch.norm, top, kWeightLog);
+  const int body = fse_encode_weights(scratch.enc, scratch.w, nw, kWeightLog, scratch.tmp + hb, 127 - hb);
+  return body > 0 ? hb + body : -1;
+}
+LSR_HD int huf_description_size(int nw, int fse_size) {      // -1: neither form
   const int direct_size = nw <= 128 ? (nw + 1) / 2 : -1;
-  if (fse_size > 0 && fse_size < 128 && (direct_size < 0 || fse_size < direct_size)) {
-    hdr[0] = static_cast<uint8_t>(fse_size);
-    for (int i = 0; i < fse_size; ++i) hdr[1 + i] = tmp[i];
-    return 1 + fse_size;
-  }
-  if (direct_size < 0) return -1;
-  hdr[0] = static_cast<uint8_t>(127 + nw);
-  for (int i = 0; i < direct_size; ++i) {
-    const int hi = w[2 * i], lo = 2 * i + 1 < nw ? w[2 * i + 1] : 0;
-    hdr[1 + i] = static_cast<uint8_t>(hi << 4 | lo);
-  }
-  return 1 + direct_size;
+  if (fse_size > 0 && fse_size < 128 && (direct_size < 0 || fse_size < direct_size)) return 1 + fse_size;
+  return direct_size < 0 ? -1 : 1 + direct_size;
+}
+LSR_HD uint8_t huf_description_byte(int i, int nw, int fse_size, const HufScratch& scratch) {
+  const int direct_size = nw <= 128 ? (nw + 1) / 2 : -1;
+  const bool fse = fse_size > 0 && fse_size < 128 && (direct_size < 0 || fse_size < direct_size);
+  if (i == 0) return static_cast<uint8_t>(fse ? fse_size : 127 + nw);
+  if (fse) return scratch.tmp[i - 1];
+  const int k = i - 1;
+  const int hi = scratch.w[2 * k], lo = 2 * k + 1 < nw ? scratch.w[2 * k + 1] : 0;
+  return static_cast<uint8_t>(hi << 4 | lo);
+}
+LSR_HD int huf_write_description(const uint8_t* nbits, int max_bits, uint8_t* hdr, HufScratch& scratch) {
+  const int nw = huf_weight_count(nbits);
+  if (nw < 1) return -1;
+  huf_weights(nbits, max_bits, nw, scratch);
+  const int fse_size = huf_description_body(nw, scratch);
+  const int size = huf_description_size(nw, fse_size);
+  for (int i = 0; i < size; ++i) hdr[i] = huf_description_byte(i, nw, fse_size, scratch);
+  return size;
 }
 
 // ---- layout of one plane's zstd block ------------------------------------------------------------------------------------
@@ -411,6 +420,11 @@ LSR_HD bool huf_pays(int plane_len, int64_t payload_bits, int desc_size) {
 // save 1/64 with any prefix code: no tree is built for it (the noise planes of float32 / uint16 data).
 // sum_sq = sum of count^2 over the 256 symbols, n = their sum:  sum p^2 <= 2^-7.875  <=>  235 * sum_sq <= n^2 (rounded safe).
 LSR_HD bool huf_hopeless(uint64_t sum_sq, uint64_t n) { return 235ull * sum_sq <= n * n; }
+// The same test on a SAMPLE of the plane, before the plane is counted at all: one 16-byte vector of the block in every
+// kSampleEvery (an unbiased collision count: sum c (c - 1) against n (n - 1)).  Planes of at least kSampleMinPlane symbols
+// only: 4096 sampled symbols put a uniform plane's estimate within 1 % of 1 / 256, nine per cent below the threshold.
+constexpr int kSampleEvery = 16, kSampleMinPlane = 32768;
+LSR_HD bool huf_hopeless_sample(uint64_t sum_c_cm1, uint64_t n) { return n >= 1024 && 235ull * sum_c_cm1 <= n * (n - 1); }
 
 constexpr int kMinHufPlane = 2048;  // shorter planes (the tail block of a chunk) are written Raw / RLE: every lane of
                                     // the encode kernel then owns a run of at least 8 symbols of its stream
