@@ -393,8 +393,8 @@ def test_device_decoder_reads_libzstd_frames_of_every_kind(device):
 # ---------------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shards", ["volume", None])
-def test_store_to_store_with_device_codecs_equals_the_host_codec_run(tmp_path, device, shards):
+@pytest.mark.parametrize("shards,streams", [("volume", "serial"), (None, "serial"), ("volume", "overlap")])
+def test_store_to_store_with_device_codecs_equals_the_host_codec_run(tmp_path, device, shards, streams, monkeypatch):
     """An input plate in the acquisition's format (Zarr v3, blosc-zstd chunks of 32 planes with 32 KB blocks, one shard per
     volume) -> deskew + RL -> blosc-zstd output.  With the device codecs the host neither decodes nor encodes a byte; the
     output store must hold the same volumes, bit for bit, as the run with the host codecs, and every chunk file of it must
@@ -406,6 +406,9 @@ def test_store_to_store_with_device_codecs_equals_the_host_codec_run(tmp_path, d
     from shrimpy_amd.io.omezarr import as_volume_array, open_ome_zarr
     from shrimpy_amd.settings import DeconvolveSettings, DeskewSettings, ReconstructSettings
 
+    # decoder and encoder in line with the unit's kernels (the default) or on streams of their own; with the HIP-event clocks on
+    monkeypatch.setenv("LSR_CODEC_STREAMS", streams)
+    monkeypatch.setenv("LSR_STAGE_EVENTS", "1")
     raw_shape = (320, 48, 192)
     keys = ["A/1/0", "A/2/0", "B/1/0"]
     with open_ome_zarr(tmp_path / "in.zarr", layout="hcs", mode="w", channel_names=["LS"], prefer_iohub=False, version="0.5") as plate:
