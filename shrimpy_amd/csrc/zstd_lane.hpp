@@ -766,19 +766,41 @@ LSR_HD int read_seq_table(Lane<Store>& L, int which, int mode, const uint8_t* p,
   return used;
 }
 
-// copy n bytes within the destination from `offset` back (may overlap: the pattern repeats)
+// the first n < 16 bytes of the 128-bit value (a, b), low byte first: at most four stores of 8 / 4 / 2 / 1 bytes
+LSR_HD void store_head(uint8_t* d, uint64_t a, uint64_t b, int n) {
+  if (n & 8) { __builtin_memcpy(d, &a, 8); d += 8; a = b; }
+  if (n & 4) { const uint32_t w = static_cast<uint32_t>(a); __builtin_memcpy(d, &w, 4); d += 4; a >>= 32; }
+  if (n & 2) { const uint16_t w = static_cast<uint16_t>(a); __builtin_memcpy(d, &w, 2); d += 2; a >>= 16; }
+  if (n & 1) *d = static_cast<uint8_t>(a);
+}
+
+// copy n bytes within the destination from `offset` back (may overlap: the pattern repeats).  Nothing past o + n is
+// written (the literals behind a match are already in place) and nothing past o - 1 is read unless this copy wrote it.
+// No byte loops and no local arrays: the lanes of a wave run this side by side, every load -> store pair is a memory
+// round trip for all of them, and a local array is scratch memory on the device.  A rest shorter than a chunk is the
+// LAST chunk of the match once more (overlapping what was just written, with the same values) or, for a match shorter
+// than one chunk, the head of a chunk-sized load (which ends before o).
 LSR_HD void copy_match(uint8_t* o, uint32_t offset, int n) {
   const uint8_t* m = o - offset;
   int i = 0;
-  if (offset >= 32) {          // two independent 16-byte loads in flight
-    for (; i + 32 <= n; i += 32) {
-      const Bytes16 x = load16(m + i), y = load16(m + i + 16);
-      store16(o + i, x);
-      store16(o + i + 16, y);
-    }
-  }
   if (offset >= 16) {
+    if (offset >= 32) {          // two independent 16-byte loads in flight
+      for (; i + 32 <= n; i += 32) {
+        const Bytes16 x = load16(m + i), y = load16(m + i + 16);
+        store16(o + i, x);
+        store16(o + i + 16, y);
+      }
+    }
     for (; i + 16 <= n; i += 16) store16(o + i, load16(m + i));
+    if (i < n) {
+      if (n >= 16) {
+        store16(o + n - 16, load16(m + n - 16));
+      } else {
+        const Bytes16 x = load16(m);
+        store_head(o, x.a, x.b, n);
+      }
+    }
+    return;
   }
   if (offset >= 8) {
     for (; i + 8 <= n; i += 8) {
@@ -786,21 +808,33 @@ LSR_HD void copy_match(uint8_t* o, uint32_t offset, int n) {
       __builtin_memcpy(&v, m + i, 8);
       __builtin_memcpy(o + i, &v, 8);
     }
-    for (; i < n; ++i) o[i] = m[i];
+    if (i < n) {
+      uint64_t v;
+      if (n >= 8) {
+        __builtin_memcpy(&v, m + n - 8, 8);
+        __builtin_memcpy(o + n - 8, &v, 8);
+      } else {
+        __builtin_memcpy(&v, m, 8);
+        store_head(o, v, 0, n);
+      }
+    }
     return;
   }
-  // period < 8: the pattern in registers, sixteen bytes per store, advancing by the largest multiple of the period
+  // period p < 8: sixteen bytes of the pattern in two registers, stored in strides of the largest multiple of p
   const int p = static_cast<int>(offset);
-  uint8_t hist[8];
-  for (int k = 0; k < p; ++k) hist[k] = m[k];
-  Bytes16 pat{0, 0};
-  for (int k = 0; k < 8; ++k) {
-    pat.a |= static_cast<uint64_t>(hist[k % p]) << (8 * k);
-    pat.b |= static_cast<uint64_t>(hist[(k + 8) % p]) << (8 * k);
+  uint64_t v = 0;
+  for (int k = 0; k < 7; ++k)
+    if (k < p) v |= static_cast<uint64_t>(m[k]) << (8 * k);          // (independent byte loads, none past o - 1)
+  const int r = p == 3 ? 2 : p == 5 ? 3 : p == 6 ? 2 : p == 7 ? 1 : 0;    // 8 mod p
+  uint64_t a = v, b = r ? (v >> (8 * r)) | ((v << (8 * (p - r))) & ((1ull << (8 * p)) - 1ull)) : v;   // b: the pattern from byte 8 on
+  for (int len = p; len < 8; len *= 2) {
+    a |= a << (8 * len);
+    b |= b << (8 * len);
   }
-  const int step = (16 / p) * p;
+  const int step = p == 3 || p == 5 ? 15 : p == 6 ? 12 : p == 7 ? 14 : 16;
+  const Bytes16 pat{a, b};
   for (; i + 16 <= n; i += step) store16(o + i, pat);
-  for (int k = 0; i < n; ++i, ++k) o[i] = hist[k % p];
+  if (i < n) store_head(o + i, a, b, n - i);
 }
 
 LSR_HD void copy_forward(uint8_t* o, const uint8_t* s, int n) {   // s >= o or disjoint: exact length, 16 bytes at a time
