@@ -283,8 +283,9 @@ __device__ __forceinline__ void load_block16(const uint8_t* blk, int64_t off, in
 
 // The streaming loops of the encode kernel walk the block in 16-byte vectors, kThreads of them side by side.  With one
 // vector in flight per thread a pass costs a memory round trip per step (the kernel runs two workgroups per CU: nothing
-// else hides it); kAhead vectors are loaded before the first is used.
-constexpr int kAhead = 4;
+// else hides it); kAhead vectors are loaded before the first is used (4 -> 8: 5.75 -> 5.63 ms per config-4 result; 16 needs
+// 320 VGPRs, one workgroup per CU: 9.9 ms).
+constexpr int kAhead = 8;
 __device__ __forceinline__ void load_ahead(const uint8_t* blk, int64_t off0, int64_t bsize, int64_t valid, int tid,
                                            uint32_t w[kAhead][4]) {
   if (off0 + int64_t(kAhead) * kThreads * 16 <= valid) {
