@@ -226,7 +226,9 @@ def _rl(args, torch, dev, g, bench, RichardsonLucyPlan, oshape):
     plans = [("separable 9x7x7, one launch per iteration", RichardsonLucyPlan(oshape, None, dev, psf_factors=bench.gaussian_factors()), 4),
              ("separable 9x7x7, ratio / update launches",
               RichardsonLucyPlan(oshape, None, dev, psf_factors=bench.gaussian_factors(), fused="never"), 4),
-             ("rotated 9x7x7 as ky (x) kzx, ratio / update launches", RichardsonLucyPlan(oshape, bench.rotated_psf(), dev), 4)]
+             ("rotated 9x7x7 as ky (x) kzx, one launch per iteration (the default)", RichardsonLucyPlan(oshape, bench.rotated_psf(), dev), 4),
+             ("rotated 9x7x7 as ky (x) kzx, ratio / update launches",
+              RichardsonLucyPlan(oshape, bench.rotated_psf(), dev, fused="never"), 4)]
     if not args.skip_dense:
         plans.append(("dense 9x7x7 (rotated)", RichardsonLucyPlan(oshape, bench.rotated_psf(), dev, separable="never"), 1))
     for name, plan, iters in plans:
