@@ -694,6 +694,9 @@ def run_plate(args, rank, world, device, shared, backend, cpu):
                 # process, wait_store, stage_out; writer thread: collect, write)
                 "stage_s_per_unit": {k: round(v / max(res["units"], 1), 4) for k, v in res.get("stage_seconds", {}).items()},
                 "device_codec": res.get("device_codec"),
+                # rank 0's pace once its pipeline is full (median interval between consecutive units); `s_per_unit` above is
+                # the whole job including the first read and the last write
+                "steady_s_per_unit_rank0": res.get("steady_s_per_unit"),
                 "io": ("native OME-Zarr reader/writer, "
                        + ("input in the acquisition's format (Zarr v3, one shard per volume, blosc-zstd chunks (1,1,32,ny,nx), "
                           f"frames decoded by {_blosc_backend()}), output uncompressed ~64 MB chunks, " if args.engine_format

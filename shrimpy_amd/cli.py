@@ -606,6 +606,9 @@ def _run_store(input_path, output_path, settings, positions, zarr_version, recon
     return {"rank": rank, "world_size": world, "units": len(report.units), "units_total": len(units),
             "units_skipped": skipped, "failed": failed, "seconds": report.seconds, "job_seconds": report.max_seconds,
             "stage_seconds": {k: round(v, 4) for k, v in report.stage_seconds.items()},
+            # median interval between consecutive units on this rank once the pipeline is full (None: fewer than 4 units)
+            "steady_s_per_unit": (round(float(np.median(report.unit_intervals[1:])), 4)
+                                  if len(report.unit_intervals) >= 3 else None),
             "device_codec": {"encode": bool(stager is not None and getattr(stager, "encode_frame_bytes", None)),
                              "decode": bool(frames_in[0])},
             "output_shape": (oz, oy, ox)}

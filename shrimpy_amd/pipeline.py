@@ -222,6 +222,9 @@ class ShardReport:
     # seconds each stage of the staged pipeline was busy, summed over this rank's units (``_run_staged``):
     # wait_slot / load / write / collect on the two host threads, wait_load / process / wait_store on the caller
     stage_seconds: dict = field(default_factory=dict)
+    # seconds between the hand-overs of consecutive units to the download / writer side (``_run_staged``): the run's pace
+    # once the pipeline is full -- a short run's ``seconds / units`` also carries the first read and the last write
+    unit_intervals: list = field(default_factory=list)
     # units this rank gave up on (``on_error="skip"``): (unit, stage, message), in unit order
     failures: list = field(default_factory=list)
 
@@ -304,8 +307,9 @@ def run_sharded(
     sync()
     t0 = time.perf_counter()
     stage_seconds: dict = {}
+    marks: list = []
     if stager is not None and mine:
-        _run_staged(mine, load, run, store, stager, stage_seconds, failures if skip else None)
+        _run_staged(mine, load, run, store, stager, stage_seconds, failures if skip else None, marks)
     elif skip:
         for unit in mine:
             ok, data = guarded("load", load, unit, unit)
@@ -347,10 +351,12 @@ def run_sharded(
     logger.info("rank %d/%d: %d of %d units in %.3fs (job %.3fs)", rank, world, len(mine), len(units),
                 seconds, max_seconds)
     failures.sort(key=lambda f: mine.index(f[0]) if f[0] in mine else len(mine))
-    return ShardReport(rank, world, mine, seconds, max_seconds, len(units), stage_seconds, failures)
+    return ShardReport(rank, world, mine, seconds, max_seconds, len(units), stage_seconds, failures=failures,
+                       unit_intervals=[b - a for a, b in zip(marks, marks[1:])])
 
 
-def _run_staged(mine, load, process, store, stager, times: dict | None = None, failures: list | None = None) -> None:
+def _run_staged(mine, load, process, store, stager, times: dict | None = None, failures: list | None = None,
+                marks: list | None = None) -> None:
     """The ``stager`` branch of ``run_sharded``: loader thread -> up stream -> kernels -> down
     stream -> writer thread, slot ``i % depth`` for the i-th unit.  ``process(data, unit)``.
     ``times`` collects how long each stage was busy (each key is touched by one thread only).
@@ -481,6 +487,8 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None, f
                 continue
             stager.stage_out(i % depth, result)
             spent("stage_out", t)
+            if marks is not None:
+                marks.append(clock())
             stores.append(storer.submit(write, i, collector.submit(collect, i)))
         t = clock()
         for fut in stores:
