@@ -148,6 +148,10 @@ def deskew(raw, ls_angle_deg, px_to_scan_ratio, keep_overhang, average_n_slices=
     ``"min"`` / ``None`` for the stack's minimum ([RECALLED] biahub ``deskew_data``'s rule when its cval is None)."""
     if cval is None or isinstance(cval, str):
         cval = float(np.asarray(raw).min())
+    # the fill value is a float32 value, like every sample of the stack it stands beside (the product hands the kernel a
+    # float32 scalar): under "grid-constant" scipy blends with it in double precision, and 132.8 and float32(132.8) then
+    # give results one ulp apart (found by tests/soak_parity.py, round 5)
+    cval = float(np.float32(cval))
     matrix, offset, pre_shape = deskew_geometry(
         raw.shape, ls_angle_deg, px_to_scan_ratio, keep_overhang
     )

@@ -120,7 +120,7 @@ def deskew_with_matrix(raw_data, matrix_3x4, pre_average_shape, average_n_slices
     write into a padded RL volume; matrices that are not a deskew shear fall back to the general
     trilinear kernel under either rule.
 
-    ``cval``: the value outside the stack -- a number (default 0) or ``"min"`` / ``None`` for the stack's minimum
+    ``cval``: the value outside the stack, as a float32 -- a number (default 0) or ``"min"`` / ``None`` for the stack's minimum
     (scipy's ``cval``; [RECALLED] biahub's ``deskew_data(cval=None)`` fills with the minimum: the third unpinned
     convention beside ``orientation`` and ``border``).  With flat-field fusion the minimum is
     that of the uncorrected stack.

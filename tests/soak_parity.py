@@ -57,11 +57,12 @@ def main():
             return None
         if min(want_shape) <= 0:
             return None
-        raw = r.integers(0, 60000, shape).astype(np.uint16) if u16 else (r.random(shape) * 4000 - 500).astype(np.float32)
-        want = o.deskew(raw.astype(np.float32), angle, ratio, keep, avg, border=border)
+        raw = r.integers(90, 60000, shape).astype(np.uint16) if u16 else (r.random(shape) * 4000 - 500).astype(np.float32)
+        cval = [0.0, "min", float(np.round(r.uniform(-50, 200), 1))][int(r.integers(0, 3))]     # (round 5: the fill value)
+        want = o.deskew(raw.astype(np.float32), angle, ratio, keep, avg, border=border, cval=cval)
         got = fast_deskew_zyx(raw_data=t(raw), ls_angle_deg=angle, px_to_scan_ratio=ratio, keep_overhang=keep,
-                              average_n_slices=avg, border=border).cpu().numpy()
-        return got.shape == want.shape and np.array_equal(got, want), (shape, angle, ratio, keep, avg, u16, border)
+                              average_n_slices=avg, border=border, cval=cval).cpu().numpy()
+        return got.shape == want.shape and np.array_equal(got, want), (shape, angle, ratio, keep, avg, u16, border, cval)
 
     def affine_case(r):
         shape = (int(r.integers(1, 40)), int(r.integers(2, 90)), int(r.integers(2, 140)))
@@ -303,7 +304,41 @@ def main():
         ok = ok and np.array_equal(a[:, shape[2] - x0 - 2:shape[2] - x0, :].cpu().numpy(), want)
         return ok, (shape, angle, ratio, keep, avg, x0)
 
-    families = {"deskew": deskew_case, "affine": affine_case, "rl": rl_case, "flatfield": flat_case,
+    def codec_case(r):
+        """Device encoder == its host twin byte for byte and readable by libzstd; device decoder on those frames and on
+        libzstd's own (round 5, io/device_codec.py)."""
+        from shrimpy_amd.io import codecs
+        from shrimpy_amd.io.device_codec import DeviceBloscDecoder, DeviceBloscEncoder, encode_frames_host, frame_layout
+
+        dtype = [np.uint8, np.uint16, np.float32][int(r.integers(0, 3))]
+        item = np.dtype(dtype).itemsize
+        n = int(r.choice([1, 300, 70000, 400000, int(r.integers(1, 900000))]))
+        kind = int(r.integers(0, 4))
+        v = (100 + r.poisson(r.choice([2.0, 40.0, 900.0]), n) if kind == 0 else r.integers(0, 256, n) if kind == 1
+             else np.repeat(r.integers(0, 3, n // 50 + 1) * 700, 50)[:n] if kind == 2 else (1 + np.sin(np.linspace(0, 40, n))) * 3000)
+        vol = v.astype(dtype) if np.dtype(dtype).kind == "f" else np.clip(v, 0, np.iinfo(dtype).max).astype(dtype)
+        raw = vol.view(np.uint8).reshape(-1)
+        fb = int(r.choice([4096, 65536, 1 << 20, vol.nbytes])) // item * item or item
+        bs = int(r.choice([0, 4096, 32768, 65536 * item]))
+        frames = DeviceBloscEncoder(vol.nbytes, item, fb, dev, bs).encode_to_host(t(vol))
+        ok = frames == encode_frames_host(vol, fb, bs)
+        back = np.concatenate([codecs.blosc_decode(f, backend="python") for f in frames[:3]])
+        m = min(back.size, raw.size)
+        ok = ok and np.array_equal(back[:m], raw[:m])
+        lay = frame_layout(frames[0])
+        out = torch.empty(len(frames) * fb, dtype=torch.uint8, device=dev)
+        DeviceBloscDecoder(len(frames) * fb, fb, lay["blocksize"], item, dev).decode_from_host(frames, out)
+        ok = ok and np.array_equal(out.cpu().numpy()[:raw.size], raw)
+        own = codecs.blosc_encode(raw[:min(raw.size, 300000 * item)], item, cname="zstd", clevel=int(r.integers(1, 10)),
+                                  shuffle=1 if item > 1 else 0, blocksize=int(r.choice([0, 4096, 32768])))
+        lay = frame_layout(own)
+        if lay is not None:
+            out = torch.empty(lay["nbytes"], dtype=torch.uint8, device=dev)
+            DeviceBloscDecoder(lay["nbytes"], lay["nbytes"], lay["blocksize"], lay["typesize"], dev).decode_from_host([own], out)
+            ok = ok and np.array_equal(out.cpu().numpy(), raw[:lay["nbytes"]])
+        return ok, (np.dtype(dtype).name, n, kind, fb, bs)
+
+    families = {"deskew": deskew_case, "affine": affine_case, "rl": rl_case, "flatfield": flat_case, "codec": codec_case,
                 "blur": blur_case, "estimators": estimator_case, "rl_ysep": rl_ysep_case, "host_twins": host_twin_case,
                 "rl_stats": rl_stats_case, "rl_long_z": rl_long_z_case, "rl_fft": rl_fft_case}
     if args.only:
