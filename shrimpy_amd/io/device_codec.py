@@ -31,6 +31,8 @@ __all__ = ["DeviceBloscEncoder", "DeviceBloscDecoder", "CompressedVolume", "enco
 class DecodeError(ValueError):
     """A chunk did not decode (damaged bytes, or a frame that differs from the layout the decoder was planned for)."""
 
+    stage = "load"      # what a pipeline reports for the unit, wherever in it the decoder's status word is read
+
     _CODES = {1: "corrupt stream", 2: "decodes to more than the chunk holds", 3: "not a zstd stream / unsupported feature",
               4: "size differs from the chunk layout"}
 

@@ -417,7 +417,8 @@ def _run_staged(mine, load, process, store, stager, times: dict | None = None, f
             spent("write", t)
         except Exception as exc:  # noqa: BLE001
             if skip:
-                note(i, "store", exc)
+                # (a device decoder's verdict on the unit's input arrives with its result: that is a "load" failure)
+                note(i, getattr(exc, "stage", "store"), exc)
                 return
             failed.append(i)
             raise

@@ -166,6 +166,7 @@ class VolumeStager:
         self._serial = codec_streams == "serial"
         self._enc = torch.cuda.Stream(self.device) if self._encoders is not None and not self._serial else None
         self._pending_decode = [None] * depth
+        self._decode_done = [None] * depth
         # LSR_STAGE_EVENTS=1: HIP events around the decoder, the unit's kernels and the encoder (serial mode), reported by
         # gpu_times() -- what the card spends on a unit without a profiler attached (rocprofv3 turns the device -> host
         # copies into shader kernels that starve the decoder: a decode then reads 28 ms instead of 7)
@@ -259,23 +260,35 @@ class VolumeStager:
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(self._uploaded[slot])
         if self._decoder is not None:
-            done = self._uploaded[slot]
             if self._pending_decode[slot] is not None:
                 # serial mode: the decoder runs HERE, on the compute stream, between the previous unit's kernels and this
-                # unit's -- see __init__ (codec_streams)
+                # unit's -- see __init__ (codec_streams).  Nothing waits for it on the host: the unit's kernels are queued
+                # right behind it (waiting here for its verdict left the card idle for 2-4 ms per unit while the host
+                # caught up), and the verdict is read when the unit's result is collected -- a stack that did not decode
+                # has been processed for nothing, never stored.
                 e0 = self._mark(cur)
                 self._decoder.decode(self._comp_dev[slot], self._pending_decode[slot], self._table_in_dev[slot], self._dev_in[slot])
                 self._status_host[slot].copy_(self._decoder.status, non_blocking=True)
                 self._pending_decode[slot] = None
                 done = torch.cuda.Event(enable_timing=self._ev is not None)
                 done.record(cur)
+                self._decode_done[slot] = done
                 if self._ev is not None:
                     self._ev_open[slot] = (e0, done)
-            # the decoder's verdict on this unit's chunks: known once its launches have run (the kernels of this unit
-            # could not start before that anyway)
-            done.synchronize()
-            self._decoder.check(int(self._status_host[slot].item()))
+            else:
+                # streams of their own: the decoder ran ahead on the upload stream; its verdict is known by now
+                self._uploaded[slot].synchronize()
+                self._decoder.check(int(self._status_host[slot].item()))
         return self._dev_in[slot]
+
+    def _check_decoded(self, slot: int) -> None:
+        """Serial codec streams: the decoder's status word of the unit in ``slot`` (its launches are long over when the
+        unit's result is collected)."""
+        done = self._decode_done[slot] if self._decoder is not None else None
+        if done is not None:
+            done.synchronize()
+            self._decode_done[slot] = None
+            self._decoder.check(int(self._status_host[slot].item()))
 
     def release(self, slot: int) -> None:
         """The kernels enqueued so far on the current stream are the last readers of the slot."""
@@ -336,6 +349,7 @@ class VolumeStager:
             import torch
 
             self._table_ready[slot].synchronize()
+            self._check_decoded(slot)
             table = self._table_host[slot].numpy()
             end = int(table[-1, 0] + table[-1, 1])
             if end > self._host_out[slot].numel():
@@ -349,6 +363,7 @@ class VolumeStager:
             host = self._host_out[slot].numpy()
             return EncodedVolume([host[int(o):int(o) + int(n)] for o, n in table], self.encode_frame_bytes, self.out_shape)
         self._downloaded[slot].synchronize()
+        self._check_decoded(slot)
         return self._host_out[slot].numpy()
 
     def warm_up(self) -> None:
