@@ -394,10 +394,10 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
   uint32_t* const hcopy = reinterpret_cast<uint32_t*>(symbuf) + (lane & (kHistCopies - 1)) * kHistCopy;
   for (int i = tid; i < kMaxType * 256; i += kThreads) (&S.hist[0][0])[i] = 0;
   for (int i = tid; i < kHistCopies * kHistCopy; i += kThreads) reinterpret_cast<uint32_t*>(symbuf)[i] = 0;
+  if (tid < kMaxType) S.skip[tid] = 0;             // (read by every thread below: set in front of the barrier)
   __syncthreads();
   // the sample first (huf_hopeless_sample): a plane that is noise on one vector in sixteen is stored raw and not counted
   // -- for a float32 result that is the two low mantissa planes, i.e. half of the pass's LDS atomics
-  if (tid < kMaxType) S.skip[tid] = 0;
   if (plane_len >= kSampleMinPlane) {
     for (int64_t off = int64_t(tid) * 16 * kSampleEvery; off < bsize; off += int64_t(kThreads) * 16 * kSampleEvery) {
       uint32_t w[4] = {0, 0, 0, 0};
@@ -424,6 +424,9 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
     for (int i = tid; i < kMaxType * 256; i += kThreads) (&S.hist[0][0])[i] = 0;
     __syncthreads();
   }
+  int early = 0;                                   // leading planes that are hopeless on the sample
+  while (early < T && S.skip[early]) ++early;
+  if (early == T) early = 0;                       // (no plane left that could compress: the block is stored verbatim)
   for (int64_t off0 = 0; off0 < bsize; off0 += int64_t(kAhead) * kThreads * 16) {
     uint32_t wa[kAhead][4];
     load_ahead(blk, off0, bsize, valid, tid, wa);
@@ -434,7 +437,23 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
       const uint32_t* w = wa[u];
       const int nsym = in ? static_cast<int>(imin64(16, bsize - off)) / T : 0;
       for (int p = 0; p < T; ++p) {
-        if (S.skip[p]) continue;
+        if (S.skip[p]) {
+          // a leading plane that is stored raw leaves in THIS sweep (its place is known: nothing but raw planes of fixed
+          // size lies in front of it), on the assumption that some other plane of the block compresses -- the plane
+          // loop below repeats it in the other layout if none does
+          if (p < early && in) {
+            uint32_t s[4];
+            plane_symbols<T>(w, p, s);
+            uint8_t* const dst = out + 4 + kFrameHeader + p * (3 + plane_len) + 3;
+            const int64_t s_at = off / T;
+            if (nsym == kPer) {
+              for (int k = 0; k < (kPer + 3) / 4; ++k) store_u32_any(dst + s_at + 4 * k, s[k]);
+            } else {
+              for (int k = 0; k < nsym; ++k) dst[s_at + k] = static_cast<uint8_t>(s[k >> 2] >> (8 * (k & 3)));
+            }
+          }
+          continue;
+        }
         uint32_t s[4];
         plane_symbols<T>(w, p, s);
         // one atomic for the whole wave when all its symbols of this plane agree (the exponent plane of float32 data)
@@ -653,7 +672,8 @@ __global__ __launch_bounds__(kThreads) void encode_blocks_kernel(EncArgs a) {
       const int hdr = any ? 3 : 0;
       if (any && tid == 0) block_header(out + pos, 0, plane_len, last);
       uint8_t* const dst = out + pos + hdr;
-      for (int64_t off0 = 0; off0 < bsize; off0 += int64_t(kAhead) * kThreads * 16) {
+      const bool written = any && p < early;       // (the histogram sweep has put it where `pos` now points)
+      for (int64_t off0 = 0; off0 < bsize && !written; off0 += int64_t(kAhead) * kThreads * 16) {
         uint32_t wa[kAhead][4];
         load_ahead(blk, off0, bsize, valid, tid, wa);
 #pragma unroll
