@@ -409,6 +409,8 @@ def test_store_to_store_with_device_codecs_equals_the_host_codec_run(tmp_path, d
     # decoder and encoder in line with the unit's kernels (the default) or on streams of their own; with the HIP-event clocks on
     monkeypatch.setenv("LSR_CODEC_STREAMS", streams)
     monkeypatch.setenv("LSR_STAGE_EVENTS", "1")
+    monkeypatch.delenv("LSR_DEVICE_DECODE_MIN_BLOCKS", raising=False)      # (the default threshold is part of what is asserted)
+    monkeypatch.delenv("LSR_DEVICE_CODEC", raising=False)
     raw_shape = (320, 48, 192)
     keys = ["A/1/0", "A/2/0", "B/1/0"]
     with open_ome_zarr(tmp_path / "in.zarr", layout="hcs", mode="w", channel_names=["LS"], prefer_iohub=False, version="0.5") as plate:
