@@ -386,6 +386,13 @@ class VolumeStager:
                     enc.wait_stream(cur)
                     zeros.record_stream(enc)
                 self._encoders[0].encode(zeros)
+        # slot 0's buffers were touched on the compute stream: its first real upload (upload stream, loader thread) and the
+        # first real encode come behind this
+        done = torch.cuda.Event()
+        done.record(cur)
+        self._up.wait_event(done)
+        if self._enc is not None:
+            self._enc.wait_event(done)
 
     def _mark(self, stream):
         if self._ev is None:
