@@ -143,7 +143,9 @@ class VolumeStager:
             self._comp_dev = [torch.empty(cap, dtype=torch.uint8, device=self.device) for _ in range(depth)]
             self._table_in_dev = [torch.empty((self._decoder.n_frames, 2), dtype=torch.int64, device=self.device) for _ in range(depth)]
             self._table_in_host = [torch.empty((self._decoder.n_frames, 2), dtype=torch.int64).pin_memory() for _ in range(depth)]
-            self._status_host = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(depth)]
+            # (two status words per slot, used in turn: in serial mode a unit's word is read when its RESULT is collected,
+            # and by then the host may have queued the decode of the unit that takes the slot next)
+            self._status_host = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(2 * depth)]
         with torch.cuda.device(self.device):
             self._host_in = [self._host_slot(in_slot_shape, in_slot_dtype, pin) for _ in range(depth)]
             self._host_out = [self._host_slot(out_slot_shape, out_slot_dtype, pin) for _ in range(depth)]
@@ -166,7 +168,9 @@ class VolumeStager:
         self._serial = codec_streams == "serial"
         self._enc = torch.cuda.Stream(self.device) if self._encoders is not None and not self._serial else None
         self._pending_decode = [None] * depth
-        self._decode_done = [None] * depth
+        self._decode_done = [None] * depth      # input side: (event, status word) of the unit acquired in the slot
+        self._verdict = [None] * depth          # result side: the same pair, handed over at stage_out, read at collect
+        self._status_turn = [0] * depth
         # LSR_STAGE_EVENTS=1: HIP events around the decoder, the unit's kernels and the encoder (serial mode), reported by
         # gpu_times() -- what the card spends on a unit without a profiler attached (rocprofv3 turns the device -> host
         # copies into shader kernels that starve the decoder: a decode then reads 28 ms instead of 7)
@@ -268,14 +272,17 @@ class VolumeStager:
                 # has been processed for nothing, never stored.
                 e0 = self._mark(cur)
                 self._decoder.decode(self._comp_dev[slot], self._pending_decode[slot], self._table_in_dev[slot], self._dev_in[slot])
-                self._status_host[slot].copy_(self._decoder.status, non_blocking=True)
+                self._status_turn[slot] ^= 1
+                word = self._status_host[slot + self.depth * self._status_turn[slot]]
+                word.copy_(self._decoder.status, non_blocking=True)
                 self._pending_decode[slot] = None
                 done = torch.cuda.Event(enable_timing=self._ev is not None)
                 done.record(cur)
-                self._decode_done[slot] = done
+                self._decode_done[slot] = (done, word)
                 if self._ev is not None:
                     self._ev_open[slot] = (e0, done)
             else:
+                self._decode_done[slot] = None
                 # streams of their own: the decoder ran ahead on the upload stream; its verdict is known by now
                 self._uploaded[slot].synchronize()
                 self._decoder.check(int(self._status_host[slot].item()))
@@ -284,11 +291,12 @@ class VolumeStager:
     def _check_decoded(self, slot: int) -> None:
         """Serial codec streams: the decoder's status word of the unit in ``slot`` (its launches are long over when the
         unit's result is collected)."""
-        done = self._decode_done[slot] if self._decoder is not None else None
-        if done is not None:
+        verdict = self._verdict[slot] if self._decoder is not None else None
+        if verdict is not None:
+            done, word = verdict
+            self._verdict[slot] = None
             done.synchronize()
-            self._decode_done[slot] = None
-            self._decoder.check(int(self._status_host[slot].item()))
+            self._decoder.check(int(word.item()))
 
     def release(self, slot: int) -> None:
         """The kernels enqueued so far on the current stream are the last readers of the slot."""
@@ -308,6 +316,12 @@ class VolumeStager:
         prev = self._downloaded[slot]
         if prev is not None:
             prev.synchronize()                  # the writer may still be reading the host slot
+        # the decoder's verdict on this unit's input travels with its result: (the input slot of the unit has the result
+        # slot's index -- both are the unit's number modulo depth -- and the next unit to ACQUIRE that slot may do so before
+        # this result is collected; the next one to stage a result OUT of it cannot)
+        if self._decoder is not None:
+            self._verdict[slot] = self._decode_done[slot]
+            self._decode_done[slot] = None
         for dev_slot in self._dev_in:
             # a pipeline that hands its input back (e.g. zero RL iterations on a float32 stack):
             # the raw slot was released before this download was queued, so the upload two units on
