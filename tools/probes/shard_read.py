@@ -117,6 +117,24 @@ def main():
         timed("mmap + 16 threads copying -> pinned", mapped, len(paths))
         for p in paths:
             p.unlink()
+        for each in (8, 16):
+            paths = fresh("f", args.files // 2 * 2)
+
+            def mapped_one(path, dest, threads):
+                with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, prot=mmap.PROT_READ) as m:
+                    src = np.frombuffer(m, dtype=np.uint8)
+                    step = n // threads
+                    with ThreadPoolExecutor(threads) as pool:
+                        list(pool.map(lambda o: np.copyto(dest[o:o + step], src[o:o + step]), range(0, step * threads, step)))
+                    del src
+
+            def two_mapped():
+                with ThreadPoolExecutor(2) as outer:
+                    for i in range(0, len(paths), 2):
+                        list(outer.map(lambda a: mapped_one(paths[a[0]], pinned[a[1]], each), [(i, 0), (i + 1, 1)]))
+            timed(f"two files side by side through mappings, {each} threads each -> pinned", two_mapped, len(paths))
+            for p in paths:
+                p.unlink()
         # the write itself, for scale
         t0 = time.perf_counter()
         paths = fresh("e", args.files)
